@@ -1,0 +1,201 @@
+// K1 (fast path) — CSR SpMM on the back-end's internal "pad-8" matrix format.
+//
+// Same contract as spmm.hip (Y[:, y0:y0+m) = A X[:, x0:x0+m), reference
+// app/app_ccs.c:50-139), but tuned to what the counters showed on MI355X
+// (profiles/spmm_r01_notes.md): the texture-address path charges an 8-byte/lane
+// load like a 16-byte one, and every L2 miss — Infinity-Cache hit or HBM —
+// crosses the same ~6.2 TB/s fabric.  Therefore:
+//   * every lane moves 16 B (two adjacent columns): LPR = m/2 lanes serve one
+//     non-zero, so one wave instruction fetches G = 64/LPR X-row segments;
+//   * the matrix is held with every row padded to a multiple of 8 non-zeros
+//     (pad entries: the row's own column with value 0, so every load is
+//     unconditional — a branch around a load makes hipcc drain vmcnt(0) after
+//     each one), so a step of G <= 8 non-zeros never straddles a row and
+//     64-entry index/value chunks stay aligned;
+//   * BATCH steps are in flight per wave regardless of row boundaries;
+//   * Y is written once with a cache policy chosen by the caller
+//     (plain / nt / sc1 = write-through without keeping the line in L2).
+//
+// Row-major multivector layout: element (r,c) at data[r*ld + c]; requires m, ldx,
+// ldy even and 16-byte aligned x/y column origins (callers fall back to spmm.hip
+// otherwise).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gcge_hip_internal.h"
+
+namespace gcge {
+
+template <int ST>
+__device__ __forceinline__ void store_row16(double* q, double a, double b) {
+  if (ST == 2) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d t = {a, b};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(t) : "memory");
+  } else if (ST == 1) {
+    __builtin_nontemporal_store(a, q);
+    __builtin_nontemporal_store(b, q + 1);
+  } else {
+    *reinterpret_cast<double2*>(q) = make_double2(a, b);
+  }
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+  int lo = __shfl(__double2loint(v), src, 64);
+  int hi = __shfl(__double2hiint(v), src, 64);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  int lo = __shfl_xor(__double2loint(v), mask, 64);
+  int hi = __shfl_xor(__double2hiint(v), mask, 64);
+  return __hiloint2double(hi, lo);
+}
+
+// orp[r] = first OCTET (group of 8 padded non-zeros) of row r; orp[nrows] = total octets.
+template <int LPR, int BATCH, int ST>
+__global__ __launch_bounds__(256) void spmm_pad8_kernel(
+    int nrows, const int* __restrict__ orp, const int* __restrict__ pcol,
+    const double* __restrict__ pval, const double* __restrict__ x, size_t ldx,
+    double* __restrict__ y, size_t ldy, int m, int rpw) {
+  constexpr int G = 64 / LPR;  // non-zeros per wave instruction
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long row0 = ((long)blockIdx.x * 4 + wave) * (long)rpw;
+  if (row0 >= nrows) return;
+  const int nr = min(rpw, (int)(nrows - row0));
+  const int g = lane / LPR;
+  const int c0 = 2 * (lane % LPR);
+  const bool act = c0 < m;
+  const double* __restrict__ xl = x + (act ? c0 : 0);  // inactive lanes re-read column 0 (never stored)
+  double* __restrict__ yl = y + (size_t)row0 * ldy + c0;
+
+  const long myend = 8L * orp[row0 + 1 + min(lane, nr - 1)];
+  // positions are counted relative to the wave's first padded non-zero
+  const long s = 8L * orp[row0];
+  const int rel_end_mine = (int)(myend - s);
+  const int e = __builtin_amdgcn_readlane(rel_end_mine, nr - 1);
+  int r = 0;
+  int pos = 0;
+  int next_end = __builtin_amdgcn_readfirstlane(rel_end_mine);
+  double acc0 = 0.0, acc1 = 0.0;
+  const int* __restrict__ pc = pcol + s;
+  const double* __restrict__ pv = pval + s;
+
+#define GCGE_FLUSH_ROWS()                                                              \
+  while (r < nr && pos == next_end) {                                                  \
+    if (G >= 2) { acc0 += shfl_xor_f64(acc0, 32); acc1 += shfl_xor_f64(acc1, 32); }    \
+    if (G >= 4) { acc0 += shfl_xor_f64(acc0, 16); acc1 += shfl_xor_f64(acc1, 16); }    \
+    if (G >= 8) { acc0 += shfl_xor_f64(acc0, 8); acc1 += shfl_xor_f64(acc1, 8); }      \
+    if (act && g == 0) store_row16<ST>(yl + (size_t)r * ldy, acc0, acc1);              \
+    acc0 = 0.0; acc1 = 0.0;                                                            \
+    ++r;                                                                               \
+    next_end = __builtin_amdgcn_readlane(rel_end_mine, min(r, nr - 1));                \
+  }
+
+  GCGE_FLUSH_ROWS();  // leading empty rows
+  int ncol = 0;
+  double nval = 0.0;
+  if (lane < e) {
+    ncol = __builtin_nontemporal_load(pc + lane);
+    nval = __builtin_nontemporal_load(pv + lane);
+  }
+  for (int base = 0; base < e; base += 64) {
+    const int mycol = ncol;
+    const double myval = nval;
+    const int cnt = min(64, e - base);  // multiple of 8
+    ncol = 0; nval = 0.0;
+    if (base + 64 + lane < e) {
+      ncol = __builtin_nontemporal_load(pc + base + 64 + lane);
+      nval = __builtin_nontemporal_load(pv + base + 64 + lane);
+    }
+    const int nsteps = cnt / G;
+    for (int t0 = 0; t0 < nsteps; t0 += BATCH) {
+      double xv0[BATCH], xv1[BATCH], av[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        // branch-free: steps past the end of the chunk re-read its last step with weight 0
+        const int t = min(t0 + u, nsteps - 1);
+        const int idx = t * G + g;
+        const int c = __shfl(mycol, idx, 64);
+        const double a = shfl_f64(myval, idx);
+        av[u] = (t0 + u < nsteps) ? a : 0.0;
+        const double2 v = *reinterpret_cast<const double2*>(xl + (size_t)c * ldx);
+        xv0[u] = v.x; xv1[u] = v.y;
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int t = t0 + u;
+        if (t < nsteps) {
+          acc0 = fma(av[u], xv0[u], acc0);
+          acc1 = fma(av[u], xv1[u], acc1);
+          pos += G;
+          GCGE_FLUSH_ROWS();
+        }
+      }
+    }
+  }
+#undef GCGE_FLUSH_ROWS
+}
+
+}  // namespace gcge
+
+using namespace gcge;
+
+static int g_p8_rpw = 8, g_p8_batch = 8, g_p8_store = 1, g_p8_pass = 0;
+extern "C" void gcge_hip_spmm_pad8_tune(int rows_per_wave, int batch, int store_policy, int col_pass) {
+  if (rows_per_wave >= 1 && rows_per_wave <= 64) g_p8_rpw = rows_per_wave;
+  if (batch == 4 || batch == 8 || batch == 16) g_p8_batch = batch;
+  if (store_policy >= 0 && store_policy <= 2) g_p8_store = store_policy;
+  if (col_pass >= 0) g_p8_pass = col_pass;  // 0: widest pass that fits (<=128 columns)
+}
+
+template <int LPR, int BATCH, int ST>
+static void p8_launch(int nrows, const int* orp, const int* pcol, const double* pval,
+                      const double* x, size_t ldx, double* y, size_t ldy, int m, hipStream_t st) {
+  const unsigned rows_per_block = 4u * (unsigned)g_p8_rpw;
+  const unsigned grid = (unsigned)(((size_t)nrows + rows_per_block - 1) / rows_per_block);
+  hipLaunchKernelGGL((spmm_pad8_kernel<LPR, BATCH, ST>), dim3(grid), dim3(256), 0, st, nrows, orp,
+                     pcol, pval, x, ldx, y, ldy, m, g_p8_rpw);
+}
+template <int LPR, int BATCH>
+static void p8_store(int nrows, const int* orp, const int* pcol, const double* pval,
+                     const double* x, size_t ldx, double* y, size_t ldy, int m, hipStream_t st) {
+  switch (g_p8_store) {
+    case 0: p8_launch<LPR, BATCH, 0>(nrows, orp, pcol, pval, x, ldx, y, ldy, m, st); break;
+    case 2: p8_launch<LPR, BATCH, 2>(nrows, orp, pcol, pval, x, ldx, y, ldy, m, st); break;
+    default: p8_launch<LPR, BATCH, 1>(nrows, orp, pcol, pval, x, ldx, y, ldy, m, st); break;
+  }
+}
+template <int LPR>
+static void p8_batch(int nrows, const int* orp, const int* pcol, const double* pval,
+                     const double* x, size_t ldx, double* y, size_t ldy, int m, hipStream_t st) {
+  switch (g_p8_batch) {
+    case 4: p8_store<LPR, 4>(nrows, orp, pcol, pval, x, ldx, y, ldy, m, st); break;
+    case 16: p8_store<LPR, 16>(nrows, orp, pcol, pval, x, ldx, y, ldy, m, st); break;
+    default: p8_store<LPR, 8>(nrows, orp, pcol, pval, x, ldx, y, ldy, m, st); break;
+  }
+}
+
+// C-ABI (include/gcge_hip.h).  Returns 0 on success, -1 if the operands do not meet the
+// alignment contract (caller then uses gcge_hip_csr_spmm), else a hipError_t.
+extern "C" int gcge_hip_pad8_spmm(int nrows, const int* d_orp, const int* d_pcol,
+                                  const double* d_pval, const double* d_x, long ldx, double* d_y,
+                                  long ldy, int ncols, void* stream) {
+  if (nrows <= 0 || ncols <= 0) return 0;
+  if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15))
+    return -1;
+  hipStream_t st = (hipStream_t)stream;
+  int done = 0;
+  while (done < ncols) {
+    int m = ncols - done;
+    int cap = g_p8_pass > 0 ? g_p8_pass : 128;
+    if (m > cap) m = cap;
+    const double* x = d_x + done;
+    double* y = d_y + done;
+    if (m > 64) p8_batch<64>(nrows, d_orp, d_pcol, d_pval, x, ldx, y, ldy, m, st);
+    else if (m > 32) p8_batch<32>(nrows, d_orp, d_pcol, d_pval, x, ldx, y, ldy, m, st);
+    else if (m > 16) p8_batch<16>(nrows, d_orp, d_pcol, d_pval, x, ldx, y, ldy, m, st);
+    else p8_batch<8>(nrows, d_orp, d_pcol, d_pval, x, ldx, y, ldy, m, st);
+    done += m;
+  }
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,245 @@
+/* Deterministic symmetric model matrices (host CSR) — see include/gcge_problems.h.
+ *
+ * Reference counterparts: the 1-D pair restates test/test_app_ccs.c:142-184
+ * (CreateMatrixCCS); the 3-D generators are the synthetic inputs SURVEY.md §8(d)
+ * defines for BASELINE.json's configs (the reference's own 3-D matrices come
+ * from PHG / PETSc binary files that are not available here).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gcge_problems.h"
+
+void gcge_csr_free(GCGE_CSR *A)
+{
+	if (A == NULL) return;
+	free(A->rowptr); free(A->colidx); free(A->val);
+	memset(A, 0, sizeof(*A));
+}
+
+static int csr_alloc(GCGE_CSR *A, int64_t nrows, int64_t ncols, int64_t row_begin, int64_t cap)
+{
+	memset(A, 0, sizeof(*A));
+	A->nrows = (int)nrows; A->ncols = (int)ncols; A->row_begin = (int)row_begin;
+	A->rowptr = (int*)malloc((size_t)(nrows + 1) * sizeof(int));
+	A->colidx = (int*)malloc((size_t)(cap > 0 ? cap : 1) * sizeof(int));
+	A->val    = (double*)malloc((size_t)(cap > 0 ? cap : 1) * sizeof(double));
+	if (!A->rowptr || !A->colidx || !A->val) { gcge_csr_free(A); return -1; }
+	A->rowptr[0] = 0;
+	return 0;
+}
+
+double gcge_uniform(uint64_t seed, uint64_t index)
+{
+	uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ULL;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	z =  z ^ (z >> 31);
+	return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* ---- generic constant-coefficient stencil on an N^3 grid, Dirichlet truncation ---- */
+typedef struct { int di, dj, dk; double w; } StencilPt;
+
+static int cmp_stencil(const void *a, const void *b)
+{
+	const StencilPt *p = (const StencilPt*)a, *q = (const StencilPt*)b;
+	if (p->dk != q->dk) return p->dk < q->dk ? -1 : 1;
+	if (p->dj != q->dj) return p->dj < q->dj ? -1 : 1;
+	if (p->di != q->di) return p->di < q->di ? -1 : 1;
+	return 0;
+}
+
+/* st must be sorted by (dk,dj,di) so that column indices ascend inside a row */
+static int stencil_rows(int N, const StencilPt *st, int npt, double scale,
+		int64_t row_begin, int64_t row_end, GCGE_CSR *A)
+{
+	int64_t n = (int64_t)N * N * N, r; int s;
+	if (row_begin < 0) row_begin = 0;
+	if (row_end > n || row_end < 0) row_end = n;
+	if (n > 2147483647LL) return -2;
+	if (csr_alloc(A, row_end - row_begin, n, row_begin, (row_end - row_begin) * npt)) return -1;
+	int64_t p = 0;
+	for (r = row_begin; r < row_end; ++r) {
+		int i = (int)(r % N), j = (int)((r / N) % N), k = (int)(r / ((int64_t)N * N));
+		for (s = 0; s < npt; ++s) {
+			int ii = i + st[s].di, jj = j + st[s].dj, kk = k + st[s].dk;
+			if (ii < 0 || ii >= N || jj < 0 || jj >= N || kk < 0 || kk >= N) continue;
+			A->colidx[p] = (int)(ii + (int64_t)N * (jj + (int64_t)N * kk));
+			A->val[p]    = scale * st[s].w;
+			++p;
+		}
+		if (p > 2147483647LL) { gcge_csr_free(A); return -2; }
+		A->rowptr[r - row_begin + 1] = (int)p;
+	}
+	A->nnz = p;
+	return 0;
+}
+
+int gcge_problem_lap3d(int N, int64_t row_begin, int64_t row_end, GCGE_CSR *A)
+{
+	StencilPt st[7] = {
+		{0,0,-1,-1.0},{0,-1,0,-1.0},{-1,0,0,-1.0},{0,0,0,6.0},
+		{1,0,0,-1.0},{0,1,0,-1.0},{0,0,1,-1.0}};
+	qsort(st, 7, sizeof(StencilPt), cmp_stencil);
+	return stencil_rows(N, st, 7, 1.0, row_begin, row_end, A);
+}
+
+int gcge_problem_fe1d(int n, GCGE_CSR *A, GCGE_CSR *B)
+{
+	double h = 1.0 / (n + 1); int r; int64_t p = 0;
+	if (csr_alloc(A, n, n, 0, 3 * (int64_t)n)) return -1;
+	for (r = 0; r < n; ++r) {
+		if (r > 0)     { A->colidx[p] = r - 1; A->val[p] = -1.0 / h; ++p; }
+		                 A->colidx[p] = r;     A->val[p] = +2.0 / h; ++p;
+		if (r < n - 1) { A->colidx[p] = r + 1; A->val[p] = -1.0 / h; ++p; }
+		A->rowptr[r + 1] = (int)p;
+	}
+	A->nnz = p;
+	if (B != NULL) {
+		if (csr_alloc(B, n, n, 0, n)) { gcge_csr_free(A); return -1; }
+		for (r = 0; r < n; ++r) {
+			B->colidx[r] = r; B->val[r] = 1.0 * h; B->rowptr[r + 1] = r + 1;
+		}
+		B->nnz = n;
+	}
+	return 0;
+}
+
+int gcge_problem_fe3d(int M, int64_t row_begin, int64_t row_end, GCGE_CSR *A, GCGE_CSR *B)
+{
+	double h = 1.0 / (M + 1); int rc;
+	StencilPt sa[7] = {
+		{0,0,-1,-1.0},{0,-1,0,-1.0},{-1,0,0,-1.0},{0,0,0,6.0},
+		{1,0,0,-1.0},{0,1,0,-1.0},{0,0,1,-1.0}};
+	StencilPt sb[15] = {
+		{0,0,0,0.4},
+		{1,0,0,1.0/20},{-1,0,0,1.0/20},{0,1,0,1.0/20},{0,-1,0,1.0/20},
+		{0,0,1,1.0/20},{0,0,-1,1.0/20},{1,1,1,1.0/20},{-1,-1,-1,1.0/20},
+		{1,1,0,1.0/30},{-1,-1,0,1.0/30},{1,0,1,1.0/30},{-1,0,-1,1.0/30},
+		{0,1,1,1.0/30},{0,-1,-1,1.0/30}};
+	qsort(sa, 7, sizeof(StencilPt), cmp_stencil);
+	qsort(sb, 15, sizeof(StencilPt), cmp_stencil);
+	rc = stencil_rows(M, sa, 7, h, row_begin, row_end, A);
+	if (rc) return rc;
+	if (B != NULL) {
+		rc = stencil_rows(M, sb, 15, h * h * h, row_begin, row_end, B);
+		if (rc) { gcge_csr_free(A); return rc; }
+	}
+	return 0;
+}
+
+/* ---- SiO2-like: 37-point 12th-order -Laplacian + Gaussian rank-one "atoms" ---- */
+typedef struct { int col; double v; } Entry;
+static int cmp_entry(const void *a, const void *b)
+{
+	int x = ((const Entry*)a)->col, y = ((const Entry*)b)->col;
+	return x < y ? -1 : (x > y);
+}
+
+int gcge_problem_sio2_like(int G, int K, double R0, double R1, uint64_t seed,
+		int64_t row_begin, int64_t row_end, GCGE_CSR *A)
+{
+	static const double c12[7] = { 5369.0/1800, -12.0/7, 15.0/56, -10.0/189,
+		1.0/112, -2.0/1925, 1.0/16632 };
+	int64_t n = (int64_t)G * G * G, r, p, cap;
+	int a, d, axis;
+	if (n > 2147483647LL) return -2;
+	if (row_begin < 0) row_begin = 0;
+	if (row_end > n || row_end < 0) row_end = n;
+
+	/* atom supports: the FULL atom list is generated on every slab so that slabs agree */
+	int     *sup_ptr = (int*)malloc((size_t)(K + 1) * sizeof(int));
+	int     *sup_col = NULL; double *sup_u = NULL; int sup_cap = 0;
+	sup_ptr[0] = 0;
+	for (a = 0; a < K; ++a) {
+		double u0 = gcge_uniform(seed, 6ULL * a + 0), u1 = gcge_uniform(seed, 6ULL * a + 1);
+		double u2 = gcge_uniform(seed, 6ULL * a + 2), u3 = gcge_uniform(seed, 6ULL * a + 3);
+		double u4 = gcge_uniform(seed, 6ULL * a + 4), u5 = gcge_uniform(seed, 6ULL * a + 5);
+		int cx = (int)(u0 * G), cy = (int)(u1 * G), cz = (int)(u2 * G);
+		double R = R0 + R1 * u3 * u4, w = 0.5 + u5;
+		int ir = (int)floor(R), dx, dy, dz, cnt = sup_ptr[a];
+		for (dz = -ir; dz <= ir; ++dz) for (dy = -ir; dy <= ir; ++dy) for (dx = -ir; dx <= ir; ++dx) {
+			double r2 = (double)(dx * dx + dy * dy + dz * dz);
+			int x = cx + dx, y = cy + dy, z = cz + dz;
+			if (r2 > R * R) continue;
+			if (x < 0 || x >= G || y < 0 || y >= G || z < 0 || z >= G) continue;
+			if (cnt >= sup_cap) {
+				sup_cap = sup_cap ? 2 * sup_cap : 4096;
+				sup_col = (int*)realloc(sup_col, (size_t)sup_cap * sizeof(int));
+				sup_u   = (double*)realloc(sup_u, (size_t)sup_cap * sizeof(double));
+			}
+			sup_col[cnt] = (int)(x + (int64_t)G * (y + (int64_t)G * z));
+			sup_u[cnt]   = w * exp(-r2 / (R * R));
+			++cnt;
+		}
+		sup_ptr[a + 1] = cnt;
+	}
+	/* per-row list of (atom, position inside its support) for rows of this slab */
+	int64_t nloc = row_end - row_begin;
+	int *cov_ptr = (int*)calloc((size_t)(nloc + 1), sizeof(int));
+	for (a = 0; a < K; ++a) for (d = sup_ptr[a]; d < sup_ptr[a + 1]; ++d) {
+		int64_t q = sup_col[d];
+		if (q >= row_begin && q < row_end) ++cov_ptr[q - row_begin + 1];
+	}
+	for (r = 0; r < nloc; ++r) cov_ptr[r + 1] += cov_ptr[r];
+	int *cov_atom = (int*)malloc((size_t)(cov_ptr[nloc] > 0 ? cov_ptr[nloc] : 1) * sizeof(int));
+	int *cov_pos  = (int*)malloc((size_t)(cov_ptr[nloc] > 0 ? cov_ptr[nloc] : 1) * sizeof(int));
+	int *fill     = (int*)calloc((size_t)(nloc > 0 ? nloc : 1), sizeof(int));
+	for (a = 0; a < K; ++a) for (d = sup_ptr[a]; d < sup_ptr[a + 1]; ++d) {
+		int64_t q = sup_col[d];
+		if (q >= row_begin && q < row_end) {
+			int at = cov_ptr[q - row_begin] + fill[q - row_begin]++;
+			cov_atom[at] = a; cov_pos[at] = d;
+		}
+	}
+	free(fill);
+
+	cap = nloc * 64 + 1024;
+	if (csr_alloc(A, nloc, n, row_begin, cap)) return -1;
+	Entry *tmp = NULL; int tmp_cap = 0;
+	p = 0;
+	for (r = row_begin; r < row_end; ++r) {
+		int i = (int)(r % G), j = (int)((r / G) % G), k = (int)(r / ((int64_t)G * G));
+		int cnt = 0, need = 37, t, m;
+		for (t = cov_ptr[r - row_begin]; t < cov_ptr[r - row_begin + 1]; ++t)
+			need += sup_ptr[cov_atom[t] + 1] - sup_ptr[cov_atom[t]];
+		if (need > tmp_cap) { tmp_cap = 2 * need; tmp = (Entry*)realloc(tmp, (size_t)tmp_cap * sizeof(Entry)); }
+		tmp[cnt].col = (int)r; tmp[cnt].v = 3.0 * c12[0]; ++cnt;
+		for (axis = 0; axis < 3; ++axis) for (d = 1; d <= 6; ++d) {
+			int s;
+			for (s = -1; s <= 1; s += 2) {
+				int ii = i + (axis == 0 ? s * d : 0), jj = j + (axis == 1 ? s * d : 0);
+				int kk = k + (axis == 2 ? s * d : 0);
+				if (ii < 0 || ii >= G || jj < 0 || jj >= G || kk < 0 || kk >= G) continue;
+				tmp[cnt].col = (int)(ii + (int64_t)G * (jj + (int64_t)G * kk));
+				tmp[cnt].v = c12[d]; ++cnt;
+			}
+		}
+		for (t = cov_ptr[r - row_begin]; t < cov_ptr[r - row_begin + 1]; ++t) {
+			int at = cov_atom[t]; double up = sup_u[cov_pos[t]];
+			for (d = sup_ptr[at]; d < sup_ptr[at + 1]; ++d) {
+				tmp[cnt].col = sup_col[d]; tmp[cnt].v = up * sup_u[d]; ++cnt;
+			}
+		}
+		qsort(tmp, (size_t)cnt, sizeof(Entry), cmp_entry);
+		for (t = 0, m = 0; t < cnt; ++t) {  /* merge duplicates */
+			if (m > 0 && tmp[m - 1].col == tmp[t].col) tmp[m - 1].v += tmp[t].v;
+			else tmp[m++] = tmp[t];
+		}
+		if (p + m > cap) {
+			cap = (p + m) * 2;
+			A->colidx = (int*)realloc(A->colidx, (size_t)cap * sizeof(int));
+			A->val    = (double*)realloc(A->val, (size_t)cap * sizeof(double));
+		}
+		for (t = 0; t < m; ++t) { A->colidx[p] = tmp[t].col; A->val[p] = tmp[t].v; ++p; }
+		if (p > 2147483647LL) { gcge_csr_free(A); p = -1; break; }
+		A->rowptr[r - row_begin + 1] = (int)p;
+	}
+	free(tmp); free(cov_ptr); free(cov_atom); free(cov_pos);
+	free(sup_ptr); free(sup_col); free(sup_u);
+	if (p < 0) return -2;
+	A->nnz = p;
+	return 0;
+}

@@ -1,0 +1,147 @@
+/* gcge_ops.h — the operator table ("plugin ABI") of the GCG hot path.
+ *
+ * This is OUR declaration of the function-pointer table that GCGE's solver
+ * layers are written against.  It must stay bit-identical in layout (member
+ * order, types, the five opaque workspace pointers and the two nested table
+ * pointers) to the reference's `struct OPS_`  (/root/reference/src/ops.h:43-152)
+ * so that
+ *   - a back-end written against this header (OPS_HIP_Set) can be handed to the
+ *     reference's unmodified solver code (GCG, ModifiedGramSchmidt, BlockPCG), and
+ *   - our solver stack can be driven by a back-end compiled against the
+ *     reference header (e.g. app_ccs in oracle/_ref).
+ * tests/test_abi.py checks sizeof/offsetof of every member against the reference
+ * header when /root/reference is present.
+ *
+ * Argument conventions (reference: src/ops.h:78-103):
+ *   - a "multivector" is an opaque handle `void **`; only the back-end that
+ *     created it may look inside;
+ *   - column ranges are half open: start[0]:end[0] selects columns of the FIRST
+ *     multivector argument, start[1]:end[1] of the SECOND;
+ *   - small dense results (inner products, Q^T A P, coefficients) live in HOST
+ *     memory, column-major, and are complete when the call returns.
+ */
+#ifndef GCGE_OPS_H
+#define GCGE_OPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OPS_ {
+	/* ---- services -------------------------------------------------------- */
+	void   (*Printf) (const char *fmt, ...);
+	double (*GetWtime) (void);
+	int    (*GetOptionFromCommandLine) (const char *name, char type, void *data,
+			int argc, char *argv[], struct OPS_ *ops);
+	/* ---- sparse matrix --------------------------------------------------- */
+	void (*MatView)  (void *mat, struct OPS_ *ops);
+	void (*MatAxpby) (double alpha, void *matX, double beta, void *matY, struct OPS_ *ops);
+	/* ---- single vector (unused when the multivector slots are set) -------- */
+	void (*VecCreateByMat)    (void **des_vec, void *src_mat, struct OPS_ *ops);
+	void (*VecCreateByVec)    (void **des_vec, void *src_vec, struct OPS_ *ops);
+	void (*VecDestroy)        (void **des_vec, struct OPS_ *ops);
+	void (*VecView)           (void *x, struct OPS_ *ops);
+	void (*VecInnerProd)      (void *x, void *y, double *inner_prod, struct OPS_ *ops);
+	void (*VecLocalInnerProd) (void *x, void *y, double *inner_prod, struct OPS_ *ops);
+	void (*VecSetRandomValue) (void *x, struct OPS_ *ops);
+	void (*VecAxpby)          (double alpha, void *x, double beta, void *y, struct OPS_ *ops);
+	void (*MatDotVec)         (void *mat, void *x, void *y, struct OPS_ *ops);
+	void (*MatTransDotVec)    (void *mat, void *x, void *y, struct OPS_ *ops);
+	/* ---- block of vectors ------------------------------------------------- */
+	void (*MultiVecCreateByMat)      (void ***multi_vec, int num_vec, void *src_mat, struct OPS_ *ops);
+	void (*MultiVecCreateByVec)      (void ***multi_vec, int num_vec, void *src_vec, struct OPS_ *ops);
+	void (*MultiVecCreateByMultiVec) (void ***multi_vec, int num_vec, void **src_mv, struct OPS_ *ops);
+	void (*MultiVecDestroy)          (void ***multi_vec, int num_vec, struct OPS_ *ops);
+	void (*GetVecFromMultiVec)       (void **multi_vec, int col, void **vec, struct OPS_ *ops);
+	void (*RestoreVecForMultiVec)    (void **multi_vec, int col, void **vec, struct OPS_ *ops);
+	void (*MultiVecView)             (void **x, int start, int end, struct OPS_ *ops);
+	/* inner_prod(k x m) = x[:,s0:e0)^T y[:,s1:e1); nsdIP: 'N' full, 'S' symmetric, 'D' diagonal */
+	void (*MultiVecLocalInnerProd)   (char nsdIP, void **x, void **y, int is_vec,
+			int *start, int *end, double *inner_prod, int ldIP, struct OPS_ *ops);
+	void (*MultiVecInnerProd)        (char nsdIP, void **x, void **y, int is_vec,
+			int *start, int *end, double *inner_prod, int ldIP, struct OPS_ *ops);
+	void (*MultiVecSetRandomValue)   (void **multi_vec, int start, int end, struct OPS_ *ops);
+	/* y = alpha x + beta y on column ranges (x == NULL: scale only) */
+	void (*MultiVecAxpby)            (double alpha, void **x, double beta, void **y,
+			int *start, int *end, struct OPS_ *ops);
+	/* y = x coef + y diag(beta) */
+	void (*MultiVecLinearComb)       (void **x, void **y, int is_vec, int *start, int *end,
+			double *coef, int ldc, double *beta, int incb, struct OPS_ *ops);
+	void (*MatDotMultiVec)           (void *mat, void **x, void **y, int *start, int *end, struct OPS_ *ops);
+	void (*MatTransDotMultiVec)      (void *mat, void **x, void **y, int *start, int *end, struct OPS_ *ops);
+	/* qAp = Q^T A P ; ntsdQAP: 'N','S','D' or 'T' (store the transpose) */
+	void (*MultiVecQtAP)             (char ntsA, char ntsdQAP, void **mvQ, void *matA, void **mvP,
+			int is_vec, int *start, int *end, double *qAp, int ldQAP, void **mv_ws, struct OPS_ *ops);
+	/* ---- small dense (host) ----------------------------------------------- */
+	struct OPS_ *lapack_ops;
+	void (*DenseMatQtAP) (char ntluA, char nsdC, int nrowsA, int ncolsA, int nrowsC, int ncolsC,
+			double alpha, double *matQ, int ldQ, double *matA, int ldA, double *matP, int ldP,
+			double beta, double *matC, int ldC, double *dbl_ws);
+	void (*DenseMatOrth) (double *mat, int nrows, int ldm, int start, int *end,
+			double orth_zero_tol, double *dbl_ws, int length, int *int_ws);
+	/* ---- linear solvers ---------------------------------------------------- */
+	void (*LinearSolver)      (void *mat, void *b, void *x, struct OPS_ *ops);
+	void *linear_solver_workspace;
+	void (*MultiLinearSolver) (void *mat, void **b, void **x, int *start, int *end, struct OPS_ *ops);
+	void *multi_linear_solver_workspace;
+	/* ---- block orthonormalisation ------------------------------------------ */
+	void (*MultiVecOrth) (void **x, int start_x, int *end_x, void *B, struct OPS_ *ops);
+	void *orth_workspace;
+	/* ---- multigrid transfer (not on the GCG hot path; kept for layout) ------ */
+	void (*MultiGridCreate)  (void ***A_array, void ***B_array, void ***P_array,
+			int *num_levels, void *A, void *B, struct OPS_ *ops);
+	void (*MultiGridDestroy) (void ***A_array, void ***B_array, void ***P_array,
+			int *num_levels, struct OPS_ *ops);
+	void (*VecFromItoJ)      (void **P_array, int level_i, int level_j,
+			void *vec_i, void *vec_j, void **vec_ws, struct OPS_ *ops);
+	void (*MultiVecFromItoJ) (void **P_array, int level_i, int level_j,
+			void **multi_vec_i, void **multi_vec_j, int *startIJ, int *endIJ,
+			void ***multi_vec_ws, struct OPS_ *ops);
+	/* ---- eigensolver ------------------------------------------------------- */
+	void (*EigenSolver) (void *A, void *B, double *eval, void **evec,
+			int nevGiven, int *nevConv, struct OPS_ *ops);
+	void *eigen_solver_workspace;
+	/* ---- composite back-ends (PAS) ----------------------------------------- */
+	struct OPS_ *app_ops;
+} OPS;
+
+/* life cycle (reference: src/ops.c:26-149) */
+void OPS_Create  (OPS **ops);   /* all slots NULL                               */
+void OPS_Setup   (OPS  *ops);   /* back-fill NULL slots with the defaults below */
+void OPS_Destroy (OPS **ops);
+
+/* defaults installed by OPS_Setup (reference: src/ops_multi_vec.c) */
+void   DefaultPrintf (const char *fmt, ...);
+double DefaultGetWtime (void);
+int    DefaultGetOptionFromCommandLine (const char *name, char type, void *value,
+		int argc, char *argv[], struct OPS_ *ops);
+void   DefaultMultiVecInnerProd (char nsdIP, void **x, void **y, int is_vec,
+		int *start, int *end, double *inner_prod, int ldIP, struct OPS_ *ops);
+void   DefaultMultiVecQtAP (char ntsA, char ntsdQAP, void **mvQ, void *matA, void **mvP,
+		int is_vec, int *startQP, int *endQP, double *qAp, int ldQAP,
+		void **mv_ws, struct OPS_ *ops);
+
+/* Host dense back-end: column-major blocks in host memory.  Layout-compatible
+ * with the reference's LAPACKVEC/LAPACKMAT (app/app_lapack.h:17-20).          */
+typedef struct GCGE_DENSE_ {
+	double *data; int nrows; int ncols; int ldd;
+} GCGE_DENSE;
+void OPS_DENSE_Set (struct OPS_ *ops);   /* counterpart of OPS_LAPACK_Set (app_lapack.c) */
+
+/* Communicator hook for row-partitioned back-ends (one process per GPU).
+ * The reference reduces partial Gram matrices with MPI_Allreduce
+ * (src/ops_multi_vec.c:206-228, src/ops_lin_sol.c:317,365); here the reduction
+ * is a callback so the same host code runs over RCCL, gloo or nothing.       */
+typedef struct GCGE_COMM_ {
+	int rank, size;
+	/* in-place sum over ranks of n contiguous doubles in HOST memory */
+	void (*allreduce_sum) (double *buf, int n, void *ctx);
+	void *ctx;
+} GCGE_COMM;
+void       GCGE_SetComm (const GCGE_COMM *comm);   /* NULL: single rank */
+GCGE_COMM *GCGE_GetComm (void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCGE_OPS_H */

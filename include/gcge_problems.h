@@ -1,0 +1,61 @@
+/* Synthetic symmetric test matrices for the GCG hot path (host CSR arrays).
+ *
+ * These are the deterministic generators SURVEY.md §8(d) names; for a symmetric
+ * matrix the three arrays are at the same time the reference's CCS triple
+ * (app/app_ccs.h:20-24: data / i_row / j_col), so one generator feeds the
+ * reference build under oracle/_ref, the CPU oracle and the HIP back-end.
+ *
+ * Every generator can emit a contiguous slab of rows [row_begin,row_end) with
+ * GLOBAL column indices — the row partition used by the multi-GPU path.
+ */
+#ifndef GCGE_PROBLEMS_H
+#define GCGE_PROBLEMS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct GCGE_CSR_ {
+	int     nrows;      /* rows held (= row_end-row_begin)            */
+	int     ncols;      /* global dimension                           */
+	int     row_begin;  /* first global row of this slab              */
+	int64_t nnz;
+	int    *rowptr;     /* nrows+1, 0-based, local to this slab       */
+	int    *colidx;     /* nnz, global, ascending inside a row        */
+	double *val;        /* nnz                                        */
+} GCGE_CSR;
+
+void gcge_csr_free(GCGE_CSR *A);
+
+/* 3-D 7-point Laplacian on an N^3 grid, index c = i + N (j + N k):
+ * diagonal 6, six -1 neighbours, Dirichlet truncation.  B = NULL problem.
+ * eigenvalues 6 - 2cos(i pi/(N+1)) - 2cos(j pi/(N+1)) - 2cos(k pi/(N+1)).   */
+int gcge_problem_lap3d(int N, int64_t row_begin, int64_t row_end, GCGE_CSR *A);
+
+/* The reference's stock pair (test/test_app_ccs.c:142-184): 1-D linear FE,
+ * A = tridiag(-1,2,-1)/h, B = h I, h = 1/(n+1).                             */
+int gcge_problem_fe1d(int n, GCGE_CSR *A, GCGE_CSR *B);
+
+/* P1 stiffness/mass pair on the Kuhn (6-tet) triangulation of a uniform cube,
+ * M^3 interior nodes, all-Dirichlet, h = 1/(M+1)  (SURVEY.md §8d):
+ *   A = h   [6; -1 at +-e_x,+-e_y,+-e_z]
+ *   B = h^3 [0.4; 1/20 at +-e_x,+-e_y,+-e_z,+-(1,1,1); 1/30 at +-(1,1,0),+-(1,0,1),+-(0,1,1)] */
+int gcge_problem_fe3d(int M, int64_t row_begin, int64_t row_end, GCGE_CSR *A, GCGE_CSR *B);
+
+/* SiO2-like irregular SPD matrix on a G^3 grid: 12th-order central-difference
+ * -Laplacian (37-point) plus K Gaussian "atoms" u u^T with heavy-tailed radius
+ * R = R0 + R1 u1 u2 (grid cells) and weight in [0.5,1.5]; rows differ in
+ * length by more than an order of magnitude (load-imbalance stress).        */
+int gcge_problem_sio2_like(int G, int K, double R0, double R1, uint64_t seed,
+		int64_t row_begin, int64_t row_end, GCGE_CSR *A);
+
+/* Reproducible U[0,1) stream shared by C and the python tests:
+ * splitmix64(seed + index) >> 11 scaled by 2^-53.                           */
+double gcge_uniform(uint64_t seed, uint64_t index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,244 @@
+/* TEST INFRASTRUCTURE — never linked into the product.
+ *
+ * Thin ctypes-friendly entry points over the REAL reference (compiled in place
+ * from /root/reference by oracle/Makefile into oracle/_ref/libgcge_ref.so).
+ * This file contains no reference code: it only calls the reference's public
+ * API (src/ops.h, src/ops_orth.h, src/ops_lin_sol.h, src/ops_eig_sol_gcg.h,
+ * app/app_ccs.h) on plain arrays, so that tests/golden/make_golden.py can
+ * produce golden vectors and tests can pin oracle/cpu_backend.c against it.
+ *
+ * Conventions: dense blocks are column-major (the reference's LAPACKVEC,
+ * app/app_lapack.h:17-20) with ld == nrows; sparse matrices are the CCS triple
+ * of a symmetric matrix (== CSR arrays).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#include <time.h>
+
+#include "ops.h"
+#include "ops_orth.h"
+#include "ops_lin_sol.h"
+#include "ops_eig_sol_gcg.h"
+#include "app_ccs.h"
+#include "app_lapack.h"
+
+static int g_verbose = 0;
+static void quiet_printf(const char *fmt, ...) { (void)fmt; }
+static double wall_now(void)
+{
+	struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+void ref_set_verbose(int v) { g_verbose = v; }
+
+static OPS *make_ops(void)
+{
+	OPS *ops = NULL;
+	OPS_Create(&ops);
+	OPS_CCS_Set(ops);
+	OPS_Setup(ops);
+	if (!g_verbose) { ops->Printf = quiet_printf; ops->lapack_ops->Printf = quiet_printf; }
+	ops->GetWtime = wall_now;
+	return ops;
+}
+static void set_ccs(CCSMAT *m, int n, int *rowptr, int *colidx, double *val)
+{
+	m->nrows = n; m->ncols = n; m->j_col = rowptr; m->i_row = colidx; m->data = val;
+}
+static void set_vec(LAPACKVEC *v, double *data, int nrows, int ncols)
+{
+	v->data = data; v->nrows = nrows; v->ncols = ncols; v->ldd = nrows;
+}
+
+/* ---- eigensolver: same parameter flow as test/test_eig_sol_gcg.c:28-169 ---- */
+int ref_gcg_solve(int n, int *a_rowptr, int *a_colidx, double *a_val,
+		int *b_rowptr, int *b_colidx, double *b_val,
+		int nevConv, int nevMax, int block_size, int nevInit,
+		double abs_tol, double rel_tol, int max_iter, int flag,
+		int argc, char **argv,
+		double *eval_out, double *evec_out, int *nevConv_out, int *numIter_out,
+		double *seconds_out)
+{
+	OPS *ops = make_ops();
+	CCSMAT A, B; void *matA, *matB = NULL;
+	set_ccs(&A, n, a_rowptr, a_colidx, a_val); matA = &A;
+	if (b_rowptr != NULL) { set_ccs(&B, n, b_rowptr, b_colidx, b_val); matB = &B; }
+
+	int multiMax = 1; double gapMin = 1e-5; int nevGiven = 0;
+	if (nevMax <= 0) nevMax = 2 * nevConv;
+	if (block_size <= 0) block_size = nevConv < 30 ? (nevMax - nevConv) : nevConv / 5;
+	if (nevInit <= 0 || nevInit > nevMax) nevInit = nevMax;
+	double tol_gcg[2] = {abs_tol, rel_tol};
+	double *eval = calloc(nevMax, sizeof(double)); void **evec;
+	ops->MultiVecCreateByMat(&evec, nevMax, matA, ops);
+	ops->MultiVecSetRandomValue(evec, 0, nevMax, ops);
+	void **ws[4]; double *dbl_ws; int *int_ws;
+	ops->MultiVecCreateByMat(&ws[0], nevMax + 2 * block_size, matA, ops);
+	ops->MultiVecSetRandomValue(ws[0], 0, nevMax + 2 * block_size, ops);
+	int i;
+	for (i = 1; i < 4; ++i) {
+		ops->MultiVecCreateByMat(&ws[i], block_size, matA, ops);
+		ops->MultiVecSetRandomValue(ws[i], 0, block_size, ops);
+	}
+	int sizeV = nevInit + 2 * block_size;
+	int length_dbl_ws = 2 * sizeV * sizeV + 10 * sizeV + (nevMax + 2 * block_size) + nevMax * block_size;
+	int length_int_ws = 6 * sizeV + 2 * (block_size + 3);
+	dbl_ws = calloc(length_dbl_ws, sizeof(double));
+	int_ws = calloc(length_int_ws, sizeof(int));
+
+	srand(0);
+	double t0 = wall_now();
+	EigenSolverSetup_GCG(multiMax, gapMin, nevInit, nevMax, block_size,
+			tol_gcg, max_iter, flag, ws, dbl_ws, int_ws, ops);
+	EigenSolverSetParameters_GCG(50,
+			"mgs", 80, 2, 2 * DBL_EPSILON,
+			"mgs", -1, 2, 2 * DBL_EPSILON,
+			"mgs", 80, 2, 2 * DBL_EPSILON,
+			30, 1e-2, 1e-14, "abs", 0,
+			-1, gapMin, 2 * DBL_EPSILON, ops);
+	if (argc > 0) {
+		int quiet_usage = 0, k, has = 0;
+		for (k = 0; k < argc; ++k) if (0 == strcmp(argv[k], "-gcge_print_usage")) has = 1;
+		(void)quiet_usage;
+		if (has) EigenSolverSetParametersFromCommandLine_GCG(argc, argv, ops);
+		else {
+			char **av = malloc((argc + 2) * sizeof(char*));
+			memcpy(av, argv, argc * sizeof(char*));
+			av[argc] = "-gcge_print_usage"; av[argc + 1] = "0";
+			EigenSolverSetParametersFromCommandLine_GCG(argc + 2, av, ops);
+			free(av);
+		}
+	}
+	int conv = nevConv;
+	ops->EigenSolver(matA, matB, eval, evec, nevGiven, &conv, ops);
+	double t1 = wall_now();
+	if (seconds_out) *seconds_out = t1 - t0;
+	if (numIter_out) *numIter_out = ((GCGSolver*)ops->eigen_solver_workspace)->numIter;
+	if (nevConv_out) *nevConv_out = conv;
+	memcpy(eval_out, eval, nevMax * sizeof(double));
+	if (evec_out) memcpy(evec_out, ((LAPACKVEC*)evec)->data, (size_t)n * nevMax * sizeof(double));
+
+	ops->MultiVecDestroy(&ws[0], nevMax + 2 * block_size, ops);
+	for (i = 1; i < 4; ++i) ops->MultiVecDestroy(&ws[i], block_size, ops);
+	ops->MultiVecDestroy(&evec, nevMax, ops);
+	free(dbl_ws); free(int_ws); free(eval);
+	OPS_Destroy(&ops);
+	return 0;
+}
+
+/* ---- slot-level calls on plain column-major arrays ---- */
+void ref_spmm(int n, int *rowptr, int *colidx, double *val,
+		double *x, int ncx, double *y, int ncy, int *start, int *end)
+{
+	OPS *ops = make_ops(); CCSMAT A; LAPACKVEC vx, vy;
+	set_vec(&vx, x, n, ncx); set_vec(&vy, y, n, ncy);
+	if (rowptr) { set_ccs(&A, n, rowptr, colidx, val); ops->MatDotMultiVec(&A, (void**)&vx, (void**)&vy, start, end, ops); }
+	else ops->MatDotMultiVec(NULL, (void**)&vx, (void**)&vy, start, end, ops);
+	OPS_Destroy(&ops);
+}
+void ref_inner_prod(char nsd, int n, double *x, int ncx, double *y, int ncy,
+		int *start, int *end, double *ip, int ldip)
+{
+	OPS *ops = make_ops(); LAPACKVEC vx, vy;
+	set_vec(&vx, x, n, ncx); set_vec(&vy, y, n, ncy);
+	ops->MultiVecInnerProd(nsd, (void**)&vx, (void**)&vy, 0, start, end, ip, ldip, ops);
+	OPS_Destroy(&ops);
+}
+void ref_qtap(char ntsA, char ntsd, int n, double *q, int ncq,
+		int *rowptr, int *colidx, double *val, double *p, int ncp,
+		int *start, int *end, double *qap, int ldqap, double *ws, int ncws)
+{
+	OPS *ops = make_ops(); CCSMAT A; LAPACKVEC vq, vp, vw; void *mat = NULL;
+	set_vec(&vq, q, n, ncq); set_vec(&vp, p, n, ncp); set_vec(&vw, ws, n, ncws);
+	if (rowptr) { set_ccs(&A, n, rowptr, colidx, val); mat = &A; }
+	ops->MultiVecQtAP(ntsA, ntsd, (void**)&vq, mat, (void**)&vp, 0, start, end, qap, ldqap, (void**)&vw, ops);
+	OPS_Destroy(&ops);
+}
+void ref_axpby(double alpha, int n, double *x, int ncx, double beta, double *y, int ncy,
+		int *start, int *end)
+{
+	OPS *ops = make_ops(); LAPACKVEC vx, vy;
+	if (x) set_vec(&vx, x, n, ncx);
+	set_vec(&vy, y, n, ncy);
+	ops->MultiVecAxpby(alpha, x ? (void**)&vx : NULL, beta, (void**)&vy, start, end, ops);
+	OPS_Destroy(&ops);
+}
+void ref_lincomb(int n, double *x, int ncx, double *y, int ncy, int *start, int *end,
+		double *coef, int ldc, double *beta, int incb)
+{
+	OPS *ops = make_ops(); LAPACKVEC vx, vy;
+	if (x) set_vec(&vx, x, n, ncx);
+	set_vec(&vy, y, n, ncy);
+	ops->MultiVecLinearComb(x ? (void**)&vx : NULL, (void**)&vy, 0, start, end, coef, ldc, beta, incb, ops);
+	OPS_Destroy(&ops);
+}
+void ref_set_random(unsigned seed, int n, double *x, int ncx, int start, int end)
+{
+	OPS *ops = make_ops(); LAPACKVEC vx;
+	set_vec(&vx, x, n, ncx);
+	srand(seed);
+	ops->MultiVecSetRandomValue((void**)&vx, start, end, ops);
+	OPS_Destroy(&ops);
+}
+/* method: 0 = ModifiedGramSchmidt (ops_orth.c:203), 1 = BinaryGramSchmidt (ops_orth.c:517) */
+int ref_orth(int method, int n, double *x, int ncx, int start, int end,
+		int *rowptr, int *colidx, double *val,
+		int block_size, int max_reorth, double zero_tol)
+{
+	OPS *ops = make_ops(); CCSMAT B; LAPACKVEC vx, vw; void *mat = NULL;
+	int ncws = end - start > 0 ? end : 1;
+	double *ws = calloc((size_t)n * ncws, sizeof(double));
+	double *dbl = calloc((size_t)ncx * ncx * 4 + 64, sizeof(double));
+	set_vec(&vx, x, n, ncx); set_vec(&vw, ws, n, ncws);
+	if (rowptr) { set_ccs(&B, n, rowptr, colidx, val); mat = &B; }
+	if (method == 0) MultiVecOrthSetup_ModifiedGramSchmidt(block_size, max_reorth, zero_tol, (void**)&vw, dbl, ops);
+	else MultiVecOrthSetup_BinaryGramSchmidt(block_size, max_reorth, zero_tol, (void**)&vw, dbl, ops);
+	ops->MultiVecOrth((void**)&vx, start, &end, mat, ops);
+	free(ws); free(dbl);
+	OPS_Destroy(&ops);
+	return end;
+}
+/* BlockPCG (ops_lin_sol.c:140): b columns [start[0],end[0]) , x columns [start[1],end[1]) */
+void ref_block_pcg(int n, int *rowptr, int *colidx, double *val,
+		double *b, int ncb, double *x, int ncx, int *start, int *end,
+		int max_iter, double rate, double tol, const char *tol_type,
+		int *niter_out, double *residual_out)
+{
+	OPS *ops = make_ops(); CCSMAT A; LAPACKVEC vb, vx, w0, w1, w2; void **mv_ws[3];
+	int nc = end[0] - start[0];
+	double *r = calloc((size_t)n * nc, sizeof(double)), *p = calloc((size_t)n * nc, sizeof(double));
+	double *w = calloc((size_t)n * nc, sizeof(double));
+	double *dbl = calloc(6 * nc + 8, sizeof(double)); int *iw = calloc(2 * nc + 8, sizeof(int));
+	set_ccs(&A, n, rowptr, colidx, val);
+	set_vec(&vb, b, n, ncb); set_vec(&vx, x, n, ncx);
+	set_vec(&w0, r, n, nc); set_vec(&w1, p, n, nc); set_vec(&w2, w, n, nc);
+	mv_ws[0] = (void**)&w0; mv_ws[1] = (void**)&w1; mv_ws[2] = (void**)&w2;
+	MultiLinearSolverSetup_BlockPCG(max_iter, rate, tol, tol_type, mv_ws, dbl, iw, NULL, NULL, ops);
+	ops->MultiLinearSolver(&A, (void**)&vb, (void**)&vx, start, end, ops);
+	BlockPCGSolver *s = (BlockPCGSolver*)ops->multi_linear_solver_workspace;
+	if (niter_out) *niter_out = s->niter;
+	if (residual_out) *residual_out = s->residual;
+	free(r); free(p); free(w); free(dbl); free(iw);
+	OPS_Destroy(&ops);
+}
+/* host dense helpers (app_lapack.c:24-227, :653-699) */
+void ref_dense_qtap(char ntluA, char nsdC, int nrowsA, int ncolsA, int nrowsC, int ncolsC,
+		double alpha, double *Q, int ldQ, double *A, int ldA, double *P, int ldP,
+		double beta, double *C, int ldC, double *ws)
+{
+	OPS *ops = make_ops();
+	ops->DenseMatQtAP(ntluA, nsdC, nrowsA, ncolsA, nrowsC, ncolsC, alpha, Q, ldQ, A, ldA, P, ldP, beta, C, ldC, ws);
+	OPS_Destroy(&ops);
+}
+int ref_dense_orth(double *mat, int nrows, int ldm, int start, int end, double zero_tol)
+{
+	OPS *ops = make_ops();
+	int n = end - start, length = 2 * n + (n + 1) * 64 + nrows + nrows * n + 64;
+	double *dbl = calloc(length, sizeof(double)); int *iw = calloc(n + 8, sizeof(int));
+	ops->DenseMatOrth(mat, nrows, ldm, start, &end, zero_tol, dbl, length, iw);
+	free(dbl); free(iw);
+	OPS_Destroy(&ops);
+	return end;
+}

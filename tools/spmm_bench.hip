@@ -1,0 +1,180 @@
+// Stand-alone micro-benchmark for K1 fast path (pad-8 format) on the 3-D 7-point Laplacian.
+// Build:  hipcc -O3 --offload-arch=gfx950 -I gcge_amd/csrc/hip tools/spmm_bench.hip gcge_amd/csrc/hip/spmm.hip -o tools/spmm_bench
+// Run  :  tools/spmm_bench N m ldx [reps]
+// Prints one line per tuning variant: ms per launch, algorithmic GB/s (SURVEY.md §8d formula).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "gcge_hip_internal.h"
+
+extern "C" int gcge_hip_csr_spmm(int nrows, const int*, const int*, const double*, const double*,
+                                 long, double*, long, int, void*);
+extern "C" void gcge_hip_spmm_tune(int rows_per_wave, int xcd_group, int nt_store);
+extern "C" void gcge_hip_spmm_variant(int variant, int batch);
+extern "C" int gcge_hip_pad8_spmm(int nrows, const int*, const int*, const double*, const double*,
+                                  long, double*, long, int, void*);
+extern "C" void gcge_hip_spmm_pad8_tune(int rows_per_wave, int batch, int store_policy, int col_pass);
+
+__global__ void fill_kernel(double* x, size_t n, unsigned seed) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+    z ^= z >> 31;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 29;
+    x[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+  }
+}
+
+__global__ void copy_kernel(const double2* __restrict__ a, double2* __restrict__ b, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) b[i] = a[i];
+}
+
+static void build_lap3d(int N, std::vector<int>& rp, std::vector<int>& ci, std::vector<double>& va) {
+  const int npt = getenv("NPT") ? atoi(getenv("NPT")) : 7;
+  size_t n = (size_t)N * N * N;
+  rp.resize(n + 1);
+  ci.reserve(7 * n);
+  va.reserve(7 * n);
+  size_t p = 0;
+  for (int k = 0; k < N; ++k)
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < N; ++i) {
+        size_t r = i + (size_t)N * (j + (size_t)N * k);
+        rp[r] = (int)p;
+        if (npt >= 7 && k > 0) ci.push_back((int)(r - (size_t)N * N)), va.push_back(-1.0), ++p;
+        if (npt >= 5 && j > 0) ci.push_back((int)(r - N)), va.push_back(-1.0), ++p;
+        if (npt >= 3 && i > 0) ci.push_back((int)(r - 1)), va.push_back(-1.0), ++p;
+        ci.push_back((int)r), va.push_back(6.0), ++p;
+        if (npt >= 3 && i < N - 1) ci.push_back((int)(r + 1)), va.push_back(-1.0), ++p;
+        if (npt >= 5 && j < N - 1) ci.push_back((int)(r + N)), va.push_back(-1.0), ++p;
+        if (npt >= 7 && k < N - 1) ci.push_back((int)(r + (size_t)N * N)), va.push_back(-1.0), ++p;
+      }
+  rp[n] = (int)p;
+}
+
+int main(int argc, char** argv) {
+  int N = argc > 1 ? atoi(argv[1]) : 128;
+  int m = argc > 2 ? atoi(argv[2]) : 64;
+  long ldx = argc > 3 ? atol(argv[3]) : m;
+  int reps = argc > 4 ? atoi(argv[4]) : 10;
+  size_t n = (size_t)N * N * N;
+  std::vector<int> rp, ci;
+  std::vector<double> va;
+  build_lap3d(N, rp, ci, va);
+  size_t nnz = ci.size();
+  printf("Lap3D N=%d n=%zu nnz=%zu m=%d ldx=%ld\n", N, n, nnz, m, ldx);
+  int *d_rp, *d_ci;
+  double *d_va, *d_x, *d_y;
+  GCGE_HIP_CHECK(hipMalloc(&d_rp, (n + 1) * sizeof(int)));
+  GCGE_HIP_CHECK(hipMalloc(&d_ci, nnz * sizeof(int)));
+  GCGE_HIP_CHECK(hipMalloc(&d_va, nnz * sizeof(double)));
+  GCGE_HIP_CHECK(hipMalloc(&d_x, n * ldx * sizeof(double)));
+  GCGE_HIP_CHECK(hipMalloc(&d_y, n * (size_t)m * sizeof(double)));
+  GCGE_HIP_CHECK(hipMemcpy(d_rp, rp.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice));
+  GCGE_HIP_CHECK(hipMemcpy(d_ci, ci.data(), nnz * sizeof(int), hipMemcpyHostToDevice));
+  GCGE_HIP_CHECK(hipMemcpy(d_va, va.data(), nnz * sizeof(double), hipMemcpyHostToDevice));
+  fill_kernel<<<4096, 256>>>(d_x, n * ldx, 1234u);
+  GCGE_HIP_CHECK(hipDeviceSynchronize());
+  const int x0 = (ldx >= 2 * m) ? (int)(ldx - m) : 0;  // use the LAST m columns of a wide block
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const double alg_bytes = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * (double)n * m;
+
+  // calibration: float4-style copy of the same volume as X+Y
+  {
+    size_t cnt = n * (size_t)m / 2;
+    copy_kernel<<<2048, 256>>>((const double2*)d_x, (double2*)d_y, cnt);
+    hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r) copy_kernel<<<2048, 256>>>((const double2*)d_x, (double2*)d_y, cnt);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("copy   %8.3f ms  %8.1f GB/s (read+write %0.2f GB)\n", ms, 16.0 * cnt * 1e-6 / ms * 1e-3 * 1e3,
+           16.0 * cnt * 1e-9);
+  }
+
+  // build the pad-8 format on the host
+  std::vector<int> orp(n + 1);
+  std::vector<int> pc;
+  std::vector<double> pv;
+  pc.reserve(8 * n);
+  pv.reserve(8 * n);
+  for (size_t r = 0; r < n; ++r) {
+    orp[r] = (int)(pc.size() / 8);
+    for (int k = rp[r]; k < rp[r + 1]; ++k) pc.push_back(ci[k]), pv.push_back(va[k]);
+    while (pc.size() % 8) pc.push_back((int)r), pv.push_back(0.0);
+  }
+  orp[n] = (int)(pc.size() / 8);
+  int *d_orp, *d_pc;
+  double* d_pv;
+  GCGE_HIP_CHECK(hipMalloc(&d_orp, (n + 1) * sizeof(int)));
+  GCGE_HIP_CHECK(hipMalloc(&d_pc, pc.size() * sizeof(int)));
+  GCGE_HIP_CHECK(hipMalloc(&d_pv, pv.size() * sizeof(double)));
+  GCGE_HIP_CHECK(hipMemcpy(d_orp, orp.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice));
+  GCGE_HIP_CHECK(hipMemcpy(d_pc, pc.data(), pc.size() * sizeof(int), hipMemcpyHostToDevice));
+  GCGE_HIP_CHECK(hipMemcpy(d_pv, pv.data(), pv.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (argc > 8) {
+    int rpw = atoi(argv[5]), batch = atoi(argv[6]), store = atoi(argv[7]), pass = atoi(argv[8]);
+    gcge_hip_spmm_pad8_tune(rpw, batch, store, pass);
+    for (int r = 0; r < reps; ++r)
+      gcge_hip_pad8_spmm((int)n, d_orp, d_pc, d_pv, d_x + x0, ldx, d_y, m, m, 0);
+    GCGE_HIP_CHECK(hipDeviceSynchronize());
+    printf("single config done\n");
+    return 0;
+  }
+  double best = 1e30;
+  int rpw_list[] = {2, 4, 8};
+  int batch_list[] = {4, 8, 16};
+  int pass_list[] = {0, 32, 16};
+  const bool quick = getenv("QUICK") != nullptr;
+  for (int pi = 0; pi < 3; ++pi)
+    for (int store = 0; store < 3; ++store)
+      for (int ri = 0; ri < 3; ++ri)
+        for (int bi = 0; bi < 3; ++bi) {
+          if (pass_list[pi] >= m) continue;
+          if (quick && (pi > 0 || store != 1 || batch_list[bi] == 16)) continue;
+          gcge_hip_spmm_pad8_tune(rpw_list[ri], batch_list[bi], store, pass_list[pi]);
+          int rc = gcge_hip_pad8_spmm((int)n, d_orp, d_pc, d_pv, d_x + x0, ldx, d_y, m, m, 0);
+          if (rc) { printf("pad8 rc=%d\n", rc); return 2; }
+          GCGE_HIP_CHECK(hipDeviceSynchronize());
+          hipEventRecord(e0);
+          for (int r = 0; r < reps; ++r)
+            gcge_hip_pad8_spmm((int)n, d_orp, d_pc, d_pv, d_x + x0, ldx, d_y, m, m, 0);
+          hipEventRecord(e1);
+          hipEventSynchronize(e1);
+          float ms;
+          hipEventElapsedTime(&ms, e0, e1);
+          ms /= reps;
+          if (ms < best) best = ms;
+          printf("pad8 pass=%3d store=%d rpw=%2d batch=%2d  %8.3f ms  %8.1f GB/s alg  (%.1f%% of 8 TB/s)\n",
+                 pass_list[pi], store, rpw_list[ri], batch_list[bi], ms, alg_bytes * 1e-6 / ms,
+                 alg_bytes * 1e-6 / ms / 80.0);
+        }
+  printf("best %.3f ms  alg bytes %.3f GB\n", best, alg_bytes * 1e-9);
+
+  // verification on sampled rows against a host recomputation
+  std::vector<double> hy(64 * (size_t)m), hx;
+  double maxerr = 0.0;
+  size_t sample_rows[] = {0, 1, (size_t)N, n / 2 + 17, n - 1, n / 3, (size_t)N * N + 5};
+  for (size_t r : sample_rows) {
+    std::vector<double> yr(m), acc(m, 0.0), xr(m);
+    GCGE_HIP_CHECK(hipMemcpy(yr.data(), d_y + r * (size_t)m, m * sizeof(double), hipMemcpyDeviceToHost));
+    for (int k = rp[r]; k < rp[r + 1]; ++k) {
+      GCGE_HIP_CHECK(hipMemcpy(xr.data(), d_x + (size_t)ci[k] * ldx + x0, m * sizeof(double),
+                               hipMemcpyDeviceToHost));
+      for (int j = 0; j < m; ++j) acc[j] = fma(va[k], xr[j], acc[j]);
+    }
+    for (int j = 0; j < m; ++j) maxerr = fmax(maxerr, fabs(acc[j] - yr[j]));
+  }
+  printf("verify: max abs err on sampled rows = %.3e\n", maxerr);
+  return maxerr < 1e-12 ? 0 : 1;
+}
