@@ -1,0 +1,161 @@
+/* Operator-table life cycle and the solver-side default slots.
+ *
+ * Restates the behaviour of the reference's src/ops.c:26-149 (OPS_Create,
+ * OPS_Setup, OPS_Destroy) and of the defaults in src/ops_multi_vec.c
+ * (DefaultPrintf :26-44, DefaultGetWtime :45-56, DefaultGetOptionFromCommandLine
+ * :58-95, DefaultMultiVecInnerProd :202-230, DefaultMultiVecQtAP :351-411).
+ *
+ * Differences by design:
+ *  - GetWtime is a monotonic WALL clock (the reference falls back to clock(),
+ *    i.e. CPU time, in serial builds — SURVEY.md §5.1);
+ *  - the cross-rank reduction of Gram results goes through GCGE_COMM (one
+ *    process per GPU, RCCL/gloo behind a callback) instead of MPI_Allreduce; a
+ *    strided result (ldIP > rows) is packed contiguously before the reduction,
+ *    which replaces the reference's MPI_Type_vector + user MPI_Op (src/ops.c:259-318).
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <assert.h>
+
+#include "gcge_ops.h"
+
+/* ---------------------------------------------------------------- comm hook */
+static GCGE_COMM  g_comm_storage;
+static GCGE_COMM *g_comm = NULL;
+
+void GCGE_SetComm(const GCGE_COMM *comm)
+{
+	if (comm == NULL || comm->size <= 1) { g_comm = NULL; return; }
+	g_comm_storage = *comm; g_comm = &g_comm_storage;
+}
+GCGE_COMM *GCGE_GetComm(void) { return g_comm; }
+
+/* ---------------------------------------------------------------- services */
+void DefaultPrintf(const char *fmt, ...)
+{
+	va_list ap;
+	if (g_comm != NULL && g_comm->rank != 0) return;   /* rank 0 prints */
+	va_start(ap, fmt);
+	vprintf(fmt, ap);
+	va_end(ap);
+}
+
+double DefaultGetWtime(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* scan argv for `name`; the token after it is parsed as int ('i'), double ('f')
+ * or copied as a string ('s').  Returns 1 when a value was read. */
+int DefaultGetOptionFromCommandLine(const char *name, char type, void *value,
+		int argc, char *argv[], struct OPS_ *ops)
+{
+	int k;
+	for (k = 0; k < argc; ++k) {
+		if (argv[k] == NULL || strcmp(argv[k], name) != 0) continue;
+		if (ops != NULL && ops->Printf != NULL)
+			ops->Printf("argv[%d] = \"%s\", name = \"%s\"\n", k, argv[k], name);
+		if (k + 1 >= argc) return 0;
+		switch (type) {
+			case 'i': *(int*)value    = atoi(argv[k + 1]); break;
+			case 'f': *(double*)value = atof(argv[k + 1]); break;
+			case 's': strcpy((char*)value, argv[k + 1]);   break;
+			default : break;
+		}
+		return 1;
+	}
+	return 0;
+}
+
+/* ---------------------------------------------------------------- defaults */
+void DefaultMultiVecInnerProd(char nsdIP, void **x, void **y, int is_vec,
+		int *start, int *end, double *inner_prod, int ldIP, struct OPS_ *ops)
+{
+	int nrows = end[0] - start[0], ncols = end[1] - start[1];
+	ops->MultiVecLocalInnerProd(nsdIP, x, y, is_vec, start, end, inner_prod, ldIP, ops);
+	if (g_comm == NULL || nrows <= 0 || ncols <= 0) return;
+	if (nsdIP == 'D') nrows = 1;          /* one value per column, stride ldIP */
+	if (nrows == ldIP) {
+		g_comm->allreduce_sum(inner_prod, nrows * ncols, g_comm->ctx);
+	} else {
+		double *pack = (double*)malloc((size_t)nrows * ncols * sizeof(double));
+		int c;
+		for (c = 0; c < ncols; ++c)
+			memcpy(pack + (size_t)c * nrows, inner_prod + (size_t)c * ldIP, nrows * sizeof(double));
+		g_comm->allreduce_sum(pack, nrows * ncols, g_comm->ctx);
+		for (c = 0; c < ncols; ++c)
+			memcpy(inner_prod + (size_t)c * ldIP, pack + (size_t)c * nrows, nrows * sizeof(double));
+		free(pack);
+	}
+}
+
+/* qAp = Q[:,s0:e0)^T A P[:,s1:e1).  A != NULL: mv_ws[:,0:m) = A P is a visible side
+ * effect the orthogonalisation re-uses; 'T' stores the transpose (m x k). */
+void DefaultMultiVecQtAP(char ntsA, char ntsdQAP, void **mvQ, void *matA, void **mvP,
+		int is_vec, int *startQP, int *endQP, double *qAp, int ldQAP,
+		void **mv_ws, struct OPS_ *ops)
+{
+	int s[2], e[2];
+	int k = endQP[0] - startQP[0], m = endQP[1] - startQP[1];
+	if (k <= 0 || m <= 0) return;
+	if (matA == NULL) {
+		if (ntsdQAP == 'T') {
+			s[0] = startQP[1]; e[0] = endQP[1]; s[1] = startQP[0]; e[1] = endQP[0];
+			ops->MultiVecInnerProd('N', mvP, mvQ, is_vec, s, e, qAp, ldQAP, ops);
+		} else {
+			ops->MultiVecInnerProd(ntsdQAP, mvQ, mvP, is_vec, startQP, endQP, qAp, ldQAP, ops);
+		}
+		return;
+	}
+	s[0] = startQP[1]; e[0] = endQP[1]; s[1] = 0; e[1] = m;
+	if (ntsA == 'T') ops->MatTransDotMultiVec(matA, mvP, mv_ws, s, e, ops);
+	else             ops->MatDotMultiVec     (matA, mvP, mv_ws, s, e, ops);
+	if (ntsdQAP == 'T') {
+		s[0] = 0; e[0] = m; s[1] = startQP[0]; e[1] = endQP[0];
+		ops->MultiVecInnerProd('N', mv_ws, mvQ, is_vec, s, e, qAp, ldQAP, ops);
+	} else {
+		s[0] = startQP[0]; e[0] = endQP[0]; s[1] = 0; e[1] = m;
+		ops->MultiVecInnerProd(ntsdQAP, mvQ, mv_ws, is_vec, s, e, qAp, ldQAP, ops);
+	}
+}
+
+/* ---------------------------------------------------------------- life cycle */
+void OPS_Create(OPS **ops)
+{
+	*ops = (OPS*)calloc(1, sizeof(OPS));   /* every slot and workspace NULL */
+}
+
+void OPS_Setup(OPS *ops)
+{
+	if (ops->Printf == NULL)                   ops->Printf = DefaultPrintf;
+	if (ops->GetWtime == NULL)                 ops->GetWtime = DefaultGetWtime;
+	if (ops->GetOptionFromCommandLine == NULL) ops->GetOptionFromCommandLine = DefaultGetOptionFromCommandLine;
+	if (ops->lapack_ops == NULL) {
+		OPS_Create(&ops->lapack_ops);
+		OPS_DENSE_Set(ops->lapack_ops);
+	}
+	if (ops->DenseMatQtAP == NULL)      ops->DenseMatQtAP = ops->lapack_ops->DenseMatQtAP;
+	if (ops->DenseMatOrth == NULL)      ops->DenseMatOrth = ops->lapack_ops->DenseMatOrth;
+	if (ops->MultiVecInnerProd == NULL) ops->MultiVecInnerProd = DefaultMultiVecInnerProd;
+	if (ops->MultiVecQtAP == NULL)      ops->MultiVecQtAP = DefaultMultiVecQtAP;
+}
+
+void OPS_Destroy(OPS **ops)
+{
+	if (ops == NULL || *ops == NULL) return;
+	if ((*ops)->lapack_ops != NULL) OPS_Destroy(&(*ops)->lapack_ops);
+	free(*ops); *ops = NULL;
+}
+
+/* convenience for drivers that want the numbers, not the log */
+static void QuietPrintf(const char *fmt, ...) { (void)fmt; }
+void GCGE_SetQuiet(OPS *ops, int quiet)
+{
+	ops->Printf = quiet ? QuietPrintf : DefaultPrintf;
+	if (ops->lapack_ops != NULL) ops->lapack_ops->Printf = ops->Printf;
+}

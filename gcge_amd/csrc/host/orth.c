@@ -1,0 +1,247 @@
+/* Block B-orthonormalisation against the operator table.
+ *
+ *   MultiVecOrth(x, start, &end, B):  columns [0,start) of x are B-orthonormal;
+ *   make [start,end) B-orthonormal and B-orthogonal to them, drop numerically
+ *   dependent columns, compact the survivors to the front and return the new end.
+ *
+ * Two schemes, selected by the Setup call (semantics of the reference's
+ * src/ops_orth.c; restated, not copied):
+ *   - block modified Gram–Schmidt   (ModifiedGramSchmidt :203-393, OrthSelf :45-118)
+ *   - recursive-halving Gram–Schmidt (BinaryGramSchmidt :517-617, OrthBinary :415-515,
+ *     leaf = Gram matrix + symmetric eigensolve, OrthSelfEVP :122-201)
+ * Only ops->MultiVecQtAP / MultiVecLinearComb / MultiVecAxpby touch O(n) data, so
+ * the same code drives the HIP back-end, the CPU oracle and the host dense table.
+ */
+#include <assert.h>
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gcge_solver.h"
+
+static double max_abs(const double *v, int n)
+{
+	double m = 0.0; int i;
+	for (i = 0; i < n; ++i) if (fabs(v[i]) > m) m = fabs(v[i]);
+	return m;
+}
+static void negate(double *v, int n) { int i; for (i = 0; i < n; ++i) v[i] = -v[i]; }
+
+/* x[:, s1:e1) -= x[:, s0:e0) * (x[:, s0:e0)^T B x[:, s1:e1)), repeated up to 1+max_reorth
+ * times.  Returns nothing; coef scratch needs (e0-s0)*(e1-s1) doubles. */
+static void project_out(void **x, int s0, int e0, int s1, int e1, void *B,
+		int max_reorth, double reorth_tol, void **mv_ws, double *coef, struct OPS_ *ops)
+{
+	int pass, start[2], end[2], k = e0 - s0, m = e1 - s1; double one = 1.0;
+	if (k <= 0 || m <= 0) return;
+	for (pass = 0; pass < 1 + max_reorth; ++pass) {
+		start[0] = s0; end[0] = e0; start[1] = s1; end[1] = e1;
+		ops->MultiVecQtAP('S', 'N', x, B, x, 0, start, end, coef, k, mv_ws, ops);
+		negate(coef, k * m);
+		ops->MultiVecLinearComb(x, x, 0, start, end, coef, k, &one, 0, ops);
+		if (max_abs(coef, k * m) < reorth_tol) break;
+	}
+}
+
+/* Column-by-column modified Gram–Schmidt inside x[:, start:*end) in the B inner product. */
+static void orth_self(void **x, int start_x, int *end_x, void *B, int max_reorth,
+		double zero_tol, double reorth_tol, void **mv_ws, double *ws, struct OPS_ *ops)
+{
+	int k, start[2], end[2], pass; double one = 1.0;
+	for (k = start_x; k < *end_x; ++k) {
+		int tail = *end_x - (k + 1);
+		double *g = ws;                    /* g[0] = x_k^T B x_k, g[1..] = x_j^T B x_k, j > k */
+		double nrm, inv;
+		start[0] = k; end[0] = *end_x; start[1] = k; end[1] = k + 1;
+		ops->MultiVecQtAP('S', 'N', x, B, x, 0, start, end, g, *end_x - k, mv_ws, ops);
+		nrm = sqrt(g[0]);
+		if (!(nrm >= zero_tol)) {          /* dependent (or NaN): drop, pull the last column in */
+			ops->Printf("r_[%d] = %6.4e\n", k, nrm);
+			if (k < *end_x - 1) {
+				start[0] = *end_x - 1; end[0] = *end_x; start[1] = k; end[1] = k + 1;
+				ops->MultiVecAxpby(1.0, x, 0.0, x, start, end, ops);
+			}
+			--(*end_x); --k;
+			continue;
+		}
+		inv = 1.0 / nrm;
+		start[0] = k; end[0] = k + 1; start[1] = k; end[1] = k + 1;
+		ops->MultiVecAxpby(0.0, NULL, inv, x, start, end, ops);          /* x_k /= ||x_k||_B */
+		if (tail <= 0) continue;
+		{
+			int i; double *c = g + 1;
+			for (i = 0; i < tail; ++i) c[i] *= -inv;                     /* -(q_k^T B x_j) */
+			start[0] = k; end[0] = k + 1; start[1] = k + 1; end[1] = *end_x;
+			ops->MultiVecLinearComb(x, x, 0, start, end, c, 1, &one, 0, ops);
+			for (pass = 1; pass < max_reorth - 1; ++pass) {
+				start[0] = k + 1; end[0] = *end_x; start[1] = k; end[1] = k + 1;
+				ops->MultiVecQtAP('S', 'N', x, B, x, 0, start, end, c, tail, mv_ws, ops);
+				negate(c, tail);
+				start[0] = k; end[0] = k + 1; start[1] = k + 1; end[1] = *end_x;
+				ops->MultiVecLinearComb(x, x, 0, start, end, c, 1, &one, 0, ops);
+				if (max_abs(c, tail) < reorth_tol) break;
+			}
+		}
+	}
+}
+
+/* Project the freshly orthonormalised block [b0,b1) out of the columns [b1,e) that follow
+ * it.  On the first pass B*block is formed in mv_ws (side effect of QtAP); later passes
+ * re-use it ('T' output keeps the coefficient matrix in the layout LinearComb wants). */
+static void project_block_from_rest(void **x, int b0, int b1, int e, void *B,
+		int max_reorth, double reorth_tol, void **mv_ws, double *coef, struct OPS_ *ops)
+{
+	int pass, start[2], end[2], nb = b1 - b0, rem = e - b1; double one = 1.0;
+	if (nb <= 0 || rem <= 0) return;
+	for (pass = 0; pass < 1 + max_reorth; ++pass) {
+		if (B != NULL && pass > 0) {
+			start[0] = b1; end[0] = e; start[1] = 0; end[1] = nb;
+			ops->MultiVecQtAP('S', 'T', x, NULL, mv_ws, 0, start, end, coef, nb, mv_ws, ops);
+		} else {
+			start[0] = b1; end[0] = e; start[1] = b0; end[1] = b1;
+			ops->MultiVecQtAP('S', 'T', x, B, x, 0, start, end, coef, nb, mv_ws, ops);
+		}
+		negate(coef, nb * rem);
+		start[0] = b0; end[0] = b1; start[1] = b1; end[1] = e;
+		ops->MultiVecLinearComb(x, x, 0, start, end, coef, nb, &one, 0, ops);
+		if (max_abs(coef, nb * rem) < reorth_tol) break;
+	}
+}
+
+static void ModifiedGramSchmidt(void **x, int start_x, int *end_x, void *B, struct OPS_ *ops)
+{
+	ModifiedGramSchmidtOrth *p = (ModifiedGramSchmidtOrth*)ops->orth_workspace;
+	double *coef = p->dbl_ws;
+	int block, b0, b1, start[2], end[2];
+	if (*end_x <= start_x) return;
+	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, p->mv_ws, coef, ops);
+
+	b0 = start_x;
+	block = p->block_size;
+	if (block <= 0) block = ((*end_x - b0) / 2 > 2) ? (*end_x - b0) / 2 : 2;
+	if (block > *end_x - b0) block = *end_x - b0;
+	while (block > 0) {
+		int dropped, refill;
+		b1 = b0 + block;
+		orth_self(x, b0, &b1, B, p->max_reorth, p->orth_zero_tol, p->reorth_tol, p->mv_ws, coef, ops);
+		dropped = block - (b1 - b0);
+		refill  = *end_x - (b0 + block);            /* columns not yet visited */
+		if (refill > dropped) refill = dropped;
+		if (refill > 0) {                          /* move tail columns into the holes */
+			start[0] = *end_x - refill; end[0] = *end_x; start[1] = b1; end[1] = b1 + refill;
+			ops->MultiVecAxpby(1.0, x, 0.0, x, start, end, ops);
+		}
+		*end_x -= dropped;
+		if (b1 < *end_x && b0 < b1)
+			project_block_from_rest(x, b0, b1, *end_x, B, p->max_reorth, p->reorth_tol, p->mv_ws, coef, ops);
+		b0 = b1;
+		if (block > *end_x - b0) block = *end_x - b0;
+	}
+}
+
+void MultiVecOrthSetup_ModifiedGramSchmidt(int block_size, int max_reorth, double orth_zero_tol,
+		void **mv_ws, double *dbl_ws, struct OPS_ *ops)
+{
+	static ModifiedGramSchmidtOrth mgs;
+	mgs.block_size = block_size; mgs.max_reorth = max_reorth;
+	mgs.orth_zero_tol = orth_zero_tol; mgs.reorth_tol = 50 * DBL_EPSILON;
+	mgs.mv_ws = mv_ws; mgs.dbl_ws = dbl_ws;
+	ops->orth_workspace = (void*)&mgs;
+	ops->MultiVecOrth   = ModifiedGramSchmidt;
+}
+
+/* ---------------------------------------------------------------- binary scheme */
+/* Leaf: G = X^T B X, G = U diag(w) U^T, X <- X U diag(w^-1/2) for w above the threshold
+ * (a threshold on the SQUARED norm, unlike orth_self).  ws: N*N + 3N doubles. */
+static void orth_self_evp(void **x, int start_x, int *end_x, void *B, int max_reorth,
+		double zero_tol, double reorth_tol, void **mv_ws, double *ws, struct OPS_ *ops)
+{
+	int pass, start[2], end[2];
+	for (pass = 0; pass < 1 + max_reorth; ++pass) {
+		int N = *end_x - start_x, k, dep = 0, info; double sum = 0.0;
+		double *G, *U, *w, *work;
+		if (N <= 0) return;
+		G = ws; U = G + (size_t)N * N; w = U + (size_t)N * N; work = w + N;
+		start[0] = start_x; end[0] = *end_x; start[1] = start_x; end[1] = *end_x;
+		ops->MultiVecQtAP('S', 'S', x, B, x, 0, start, end, G, N, mv_ws, ops);
+		info = GCGE_SymEig('L', N, G, N, w, U, N, work);
+		assert(info == 0); (void)info;
+		for (k = 0; k < N; ++k) {
+			assert(w[k] > -zero_tol);
+			if (fabs(w[k]) > zero_tol) w[k] = 1.0 / sqrt(w[k]);
+			else ++dep;
+		}
+		if (dep > 0) ops->Printf("There has %d linear dependent vec\n", dep);
+		start[0] = start_x; end[0] = *end_x; start[1] = 0; end[1] = N - dep;
+		ops->MultiVecLinearComb(x, mv_ws, 0, start, end, U + (size_t)N * dep, N, NULL, 0, ops);
+		ops->MultiVecLinearComb(NULL, mv_ws, 0, start, end, NULL, 0, w + dep, 1, ops);
+		*end_x -= dep;
+		start[0] = 0; end[0] = N - dep; start[1] = start_x; end[1] = *end_x;
+		ops->MultiVecAxpby(1.0, mv_ws, 0.0, x, start, end, ops);
+		for (k = 0; k < N; ++k) sum += fabs(w[k]);
+		if (dep == 0 && fabs(sum - N) < reorth_tol) break;
+	}
+}
+
+static void orth_binary(void **x, int start_x, int *end_x, void *B, char leaf, int block_size,
+		int max_reorth, double zero_tol, double reorth_tol, void **mv_ws, double *ws, struct OPS_ *ops)
+{
+	int ncols = *end_x - start_x, s0, e0, s1, e1, dropped, move, start[2], end[2];
+	if (ncols <= 0) return;
+	if (ncols <= block_size) {
+		if (leaf == 'E') orth_self_evp(x, start_x, end_x, B, max_reorth, zero_tol, reorth_tol, mv_ws, ws, ops);
+		else orth_self(x, start_x, end_x, B, max_reorth, zero_tol, reorth_tol, mv_ws, ws, ops);
+		return;
+	}
+	s0 = start_x; e0 = start_x + ncols / 2; s1 = e0; e1 = *end_x;
+	orth_binary(x, s0, &e0, B, leaf, block_size, max_reorth, zero_tol, reorth_tol, mv_ws, ws, ops);
+	{   /* second half minus the span of the first; 'T' layout + B*X0 cached in mv_ws */
+		int pass, nb = e0 - s0, rem = e1 - s1; double one = 1.0;
+		for (pass = 0; pass < 1 + max_reorth && nb > 0 && rem > 0; ++pass) {
+			if (B != NULL && pass > 0) {
+				start[0] = s1; end[0] = e1; start[1] = 0; end[1] = nb;
+				ops->MultiVecQtAP('S', 'T', x, NULL, mv_ws, 0, start, end, ws, nb, mv_ws, ops);
+			} else {
+				start[0] = s1; end[0] = e1; start[1] = s0; end[1] = e0;
+				ops->MultiVecQtAP('S', 'T', x, B, x, 0, start, end, ws, nb, mv_ws, ops);
+			}
+			negate(ws, nb * rem);
+			start[0] = s0; end[0] = e0; start[1] = s1; end[1] = e1;
+			ops->MultiVecLinearComb(x, x, 0, start, end, ws, nb, &one, 0, ops);
+			if (max_abs(ws, nb * rem) < reorth_tol) break;
+		}
+	}
+	orth_binary(x, s1, &e1, B, leaf, block_size, max_reorth, zero_tol, reorth_tol, mv_ws, ws, ops);
+	dropped = s1 - e0;                     /* holes left by the first half */
+	*end_x  = e1 - dropped;
+	move    = dropped < e1 - s1 ? dropped : e1 - s1;
+	if (move > 0) {
+		start[0] = e1 - move; end[0] = e1; start[1] = e0; end[1] = e0 + move;
+		ops->MultiVecAxpby(1.0, x, 0.0, x, start, end, ops);
+	}
+}
+
+static void BinaryGramSchmidt(void **x, int start_x, int *end_x, void *B, struct OPS_ *ops)
+{
+	BinaryGramSchmidtOrth *p = (BinaryGramSchmidtOrth*)ops->orth_workspace;
+	int n, block = p->block_size; char leaf;
+	if (*end_x <= start_x) return;
+	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, p->mv_ws, p->dbl_ws, ops);
+	n = *end_x - start_x;
+	if (n < 16) { if (block <= 0) block = 4; leaf = 'M'; }
+	else { if (block <= 0 || block > n / 4) block = n / 4; leaf = 'E'; }
+	orth_binary(x, start_x, end_x, B, leaf, block, p->max_reorth, p->orth_zero_tol, p->reorth_tol,
+			p->mv_ws, p->dbl_ws, ops);
+}
+
+void MultiVecOrthSetup_BinaryGramSchmidt(int block_size, int max_reorth, double orth_zero_tol,
+		void **mv_ws, double *dbl_ws, struct OPS_ *ops)
+{
+	static BinaryGramSchmidtOrth bgs;
+	bgs.block_size = block_size; bgs.max_reorth = max_reorth;
+	bgs.orth_zero_tol = orth_zero_tol; bgs.reorth_tol = 50 * DBL_EPSILON;
+	bgs.mv_ws = mv_ws; bgs.dbl_ws = dbl_ws;
+	ops->orth_workspace = (void*)&bgs;
+	ops->MultiVecOrth   = BinaryGramSchmidt;
+}

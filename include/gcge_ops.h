@@ -140,6 +140,7 @@ typedef struct GCGE_COMM_ {
 } GCGE_COMM;
 void       GCGE_SetComm (const GCGE_COMM *comm);   /* NULL: single rank */
 GCGE_COMM *GCGE_GetComm (void);
+void       GCGE_SetQuiet (OPS *ops, int quiet);   /* silence ops->Printf (and the dense table's) */
 
 #ifdef __cplusplus
 }

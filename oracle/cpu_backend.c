@@ -1,0 +1,206 @@
+/* TEST INFRASTRUCTURE — the CPU oracle.  Never linked into, imported by or called
+ * from the product path (gcge_amd/); only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it.
+ *
+ * Plain-C restatement of the reference's built-in CPU back-end for the GCG hot
+ * path: the CCS sparse matrix with column-major dense blocks of vectors
+ *   app/app_ccs.c     MultiVecCreateByMat :40-49, MatDotMultiVec :50-139 (scatter
+ *                     form, OpenMP over the block columns :117-131), OPS_CCS_Set :213-249
+ *   app/app_lapack.c  DenseMatQtAP (matA == NULL branch) :64-183, MultiVecLocalInnerProd
+ *                     :299-313, MultiVecSetRandomValue :322-333, MultiVecAxpby :334-395,
+ *                     MultiVecLinearComb :463-534
+ *   src/ops_multi_vec.c  DefaultMultiVecQtAP :351-411 (A P staged in mv_ws)
+ * BLAS calls are written out as loops (deliberately naive: this is the checker).
+ *
+ * Parity pin: tests/test_oracle_vs_ref.py compares every slot and whole GCG runs
+ * with the real reference compiled under oracle/_ref (here, where /root/reference
+ * exists) and tests/golden/ holds the vectors produced by it for the GPU box.
+ *
+ * Struct layouts equal the reference's LAPACKVEC (app_lapack.h:17-20) and CCSMAT
+ * (app_ccs.h:20-24) on purpose: either solver stack can drive either back-end.
+ */
+#include <assert.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "gcge_ops.h"
+#include "oracle.h"
+
+typedef ORACLE_VEC VEC;
+typedef ORACLE_CCS CCS;
+
+static int g_threads = 1;
+void oracle_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+int  oracle_get_threads(void) { return g_threads; }
+
+/* app_ccs.c:40-49 — zero-filled n x num_vec block, ldd = nrows = mat->ncols */
+static void O_MultiVecCreateByMat(void ***mv, int num_vec, void *mat, struct OPS_ *ops)
+{
+	VEC *v = (VEC*)malloc(sizeof(VEC)); CCS *m = (CCS*)mat;
+	v->nrows = m->ncols; v->ncols = num_vec; v->ldd = v->nrows;
+	v->data = (double*)calloc((size_t)v->ldd * (num_vec > 0 ? num_vec : 1), sizeof(double));
+	*mv = (void**)v;
+}
+static void O_MultiVecCreateByMultiVec(void ***mv, int num_vec, void **src, struct OPS_ *ops)
+{
+	VEC *v = (VEC*)malloc(sizeof(VEC)), *s = (VEC*)src;
+	v->nrows = s->nrows; v->ncols = num_vec; v->ldd = s->ldd;
+	v->data = (double*)calloc((size_t)v->ldd * (num_vec > 0 ? num_vec : 1), sizeof(double));
+	*mv = (void**)v;
+}
+/* app_lapack.c:260-268 */
+static void O_MultiVecDestroy(void ***mv, int num_vec, struct OPS_ *ops)
+{
+	VEC *v = *(VEC**)mv;
+	if (v != NULL) { free(v->data); free(v); }
+	*mv = NULL;
+}
+static void O_MultiVecView(void **x, int start, int end, struct OPS_ *ops)
+{
+	VEC *v = (VEC*)x; int r, c;
+	for (r = 0; r < v->nrows; ++r) {
+		for (c = start; c < end; ++c) ops->Printf("%6.4e\t", v->data[(size_t)v->ldd * c + r]);
+		ops->Printf("\n");
+	}
+}
+/* app_lapack.c:322-333 — glibc rand(), columns outer, rows inner */
+static void O_MultiVecSetRandomValue(void **x, int start, int end, struct OPS_ *ops)
+{
+	VEC *v = (VEC*)x; int r, c;
+	for (c = start; c < end; ++c)
+		for (r = 0; r < v->nrows; ++r)
+			v->data[(size_t)v->ldd * c + r] = ((double)rand()) / ((double)RAND_MAX + 1);
+}
+/* app_lapack.c:334-395 — beta == 0 zeroes y (never multiplies), x == NULL scales only */
+static void O_MultiVecAxpby(double alpha, void **x, double beta, void **y,
+		int *start, int *end, struct OPS_ *ops)
+{
+	VEC *vx = (VEC*)x, *vy = (VEC*)y; int c, m = end[1] - start[1];
+	assert(end[0] - start[0] == m);
+	if (m <= 0 || vy->nrows == 0) return;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+	for (c = 0; c < m; ++c) {
+		double *d = vy->data + (size_t)vy->ldd * (start[1] + c); int r;
+		if (beta == 0.0) for (r = 0; r < vy->nrows; ++r) d[r] = 0.0;
+		else if (beta != 1.0) for (r = 0; r < vy->nrows; ++r) d[r] *= beta;
+		if (vx != NULL) {
+			const double *s = vx->data + (size_t)vx->ldd * (start[0] + c);
+			for (r = 0; r < vy->nrows; ++r) d[r] += alpha * s[r];
+		}
+	}
+}
+/* app_lapack.c:463-534 — y_j = sum_i x_i coef(i,j) + beta_j y_j */
+static void O_MultiVecLinearComb(void **x, void **y, int is_vec, int *start, int *end,
+		double *coef, int ldc, double *beta, int incb, struct OPS_ *ops)
+{
+	VEC *vx = (VEC*)x, *vy = (VEC*)y; int k = end[0] - start[0], m = end[1] - start[1], j;
+	if (k == 0 || m == 0 || vy->nrows == 0) return;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+	for (j = 0; j < m; ++j) {
+		double *d = vy->data + (size_t)vy->ldd * (start[1] + j); int r, i;
+		double g = (beta == NULL) ? 0.0 : (incb == 0 ? *beta : beta[(size_t)incb * j]);
+		if (beta != NULL && g != 1.0) for (r = 0; r < vy->nrows; ++r) d[r] *= g;
+		if (vx != NULL && coef != NULL) {
+			if (beta == NULL) for (r = 0; r < vy->nrows; ++r) d[r] = 0.0;   /* dgemm with beta = 0 */
+			for (i = 0; i < k; ++i) {
+				const double *s = vx->data + (size_t)vx->ldd * (start[0] + i);
+				double cij = coef[(size_t)ldc * j + i];
+				for (r = 0; r < vy->nrows; ++r) d[r] += cij * s[r];
+			}
+		}
+	}
+}
+/* app_lapack.c:299-313 -> DenseMatQtAP :64-183 with matA == NULL */
+static void O_MultiVecLocalInnerProd(char nsd, void **x, void **y, int is_vec,
+		int *start, int *end, double *ip, int ldIP, struct OPS_ *ops)
+{
+	VEC *vx = (VEC*)x, *vy = (VEC*)y; int k = end[0] - start[0], m = end[1] - start[1], j;
+	if (k <= 0 || m <= 0) return;
+	assert(vx->nrows == vy->nrows);
+	if (nsd == 'D' || nsd == 'S') assert(k == m);
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+	for (j = 0; j < m; ++j) {
+		const double *pj = vy->data + (size_t)vy->ldd * (start[1] + j); int i, r;
+		int i0 = (nsd == 'D') ? j : (nsd == 'S' ? j : 0), i1 = (nsd == 'D') ? j + 1 : k;
+		for (i = i0; i < i1; ++i) {
+			const double *qi = vx->data + (size_t)vx->ldd * (start[0] + i); double s = 0.0;
+			for (r = 0; r < vx->nrows; ++r) s += qi[r] * pj[r];
+			if (nsd == 'D') ip[(size_t)ldIP * j] = s;
+			else ip[(size_t)ldIP * j + i] = s;
+		}
+	}
+	if (nsd == 'S')   /* lower triangle computed, mirrored (dcopy at :127-129) */
+		for (j = 0; j < m; ++j) { int i; for (i = j + 1; i < k; ++i) ip[(size_t)ldIP * i + j] = ip[(size_t)ldIP * j + i]; }
+}
+/* app_ccs.c:50-139 — y = 0, then for each column j of A: y[i_row] += a * x[j]
+ * (CCS scatter; equals A x for the symmetric matrices GCGE handles); mat == NULL copies */
+static void O_MatDotMultiVec(void *mat, void **x, void **y, int *start, int *end, struct OPS_ *ops)
+{
+	CCS *A = (CCS*)mat; VEC *vx = (VEC*)x, *vy = (VEC*)y; int c, m = end[0] - start[0];
+	assert(m == end[1] - start[1]);
+	assert(vx->nrows == vx->ldd && vy->nrows == vy->ldd);
+	if (m <= 0) return;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+	for (c = 0; c < m; ++c) {
+		const double *xs = vx->data + (size_t)vx->ldd * (start[0] + c);
+		double *yd = vy->data + (size_t)vy->ldd * (start[1] + c); int j, i;
+		if (A == NULL) { memcpy(yd, xs, (size_t)vy->nrows * sizeof(double)); continue; }
+		memset(yd, 0, (size_t)vy->nrows * sizeof(double));
+		for (j = 0; j < A->ncols; ++j)
+			for (i = A->j_col[j]; i < A->j_col[j + 1]; ++i) yd[A->i_row[i]] += A->data[i] * xs[j];
+	}
+}
+/* app_ccs.c:140-150 — symmetric only */
+static void O_MatTransDotMultiVec(void *mat, void **x, void **y, int *start, int *end, struct OPS_ *ops)
+{
+	if (mat != NULL) assert(((CCS*)mat)->nrows == ((CCS*)mat)->ncols);
+	O_MatDotMultiVec(mat, x, y, start, end, ops);
+}
+/* ops_multi_vec.c:351-411 */
+static void O_MultiVecQtAP(char ntsA, char ntsd, void **mvQ, void *matA, void **mvP, int is_vec,
+		int *startQP, int *endQP, double *qAp, int ldQAP, void **mv_ws, struct OPS_ *ops)
+{
+	int s[2], e[2], k = endQP[0] - startQP[0], m = endQP[1] - startQP[1];
+	if (k <= 0 || m <= 0) return;
+	if (matA == NULL) {
+		if (ntsd == 'T') {
+			s[0] = startQP[1]; e[0] = endQP[1]; s[1] = startQP[0]; e[1] = endQP[0];
+			O_MultiVecLocalInnerProd('N', mvP, mvQ, is_vec, s, e, qAp, ldQAP, ops);
+		} else O_MultiVecLocalInnerProd(ntsd, mvQ, mvP, is_vec, startQP, endQP, qAp, ldQAP, ops);
+		return;
+	}
+	s[0] = startQP[1]; e[0] = endQP[1]; s[1] = 0; e[1] = m;
+	O_MatDotMultiVec(matA, mvP, mv_ws, s, e, ops);
+	if (ntsd == 'T') {
+		s[0] = 0; e[0] = m; s[1] = startQP[0]; e[1] = endQP[0];
+		O_MultiVecLocalInnerProd('N', mv_ws, mvQ, is_vec, s, e, qAp, ldQAP, ops);
+	} else {
+		s[0] = startQP[0]; e[0] = endQP[0]; s[1] = 0; e[1] = m;
+		O_MultiVecLocalInnerProd(ntsd, mvQ, mv_ws, is_vec, s, e, qAp, ldQAP, ops);
+	}
+}
+
+/* app_ccs.c:213-249 */
+void OPS_ORACLE_Set(struct OPS_ *ops)
+{
+	ops->Printf                   = DefaultPrintf;
+	ops->GetWtime                 = DefaultGetWtime;
+	ops->GetOptionFromCommandLine = DefaultGetOptionFromCommandLine;
+	ops->MultiVecCreateByMat      = O_MultiVecCreateByMat;
+	ops->MultiVecCreateByMultiVec = O_MultiVecCreateByMultiVec;
+	ops->MultiVecDestroy          = O_MultiVecDestroy;
+	ops->MultiVecView             = O_MultiVecView;
+	ops->MultiVecLocalInnerProd   = O_MultiVecLocalInnerProd;
+	ops->MultiVecInnerProd        = O_MultiVecLocalInnerProd;
+	ops->MultiVecSetRandomValue   = O_MultiVecSetRandomValue;
+	ops->MultiVecAxpby            = O_MultiVecAxpby;
+	ops->MultiVecLinearComb       = O_MultiVecLinearComb;
+	ops->MatDotMultiVec           = O_MatDotMultiVec;
+	ops->MatTransDotMultiVec      = O_MatTransDotMultiVec;
+	ops->MultiVecQtAP             = O_MultiVecQtAP;
+}
