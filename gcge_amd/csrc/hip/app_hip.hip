@@ -1,0 +1,357 @@
+// app_hip — the MI355X back-end behind GCGE's operator table.
+//
+// Counterpart of the reference's app/app_ccs.c (sparse matrix + block of vectors)
+// with every O(n) operand resident in HBM: OPS_HIP_Set fills the same slots
+// OPS_CCS_Set does (app_ccs.c:213-249), each slot keeps the contract of SURVEY.md
+// Appendix A, and small dense results are returned to HOST pointers, complete on
+// return (the solver layers are synchronous).  Handles are opaque:
+//   matrix       GCGE_HIP_MAT  (CSR + pad-8 copy on the device)      <- CCSMAT   (app_ccs.h:20-24)
+//   multivector  GcgeHipMV     (row-major n x ld block on the device) <- LAPACKVEC (app_lapack.h:17-20)
+#include <hip/hip_runtime.h>
+#include <assert.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "gcge_hip.h"
+#include "gcge_hip_internal.h"
+
+extern "C" {
+int gcge_hip_colscale(int nrows, double* d_y, long ldy, int m, const double* d_s, void* stream);
+int gcge_hip_fill_uniform(int nrows, long row_begin, long nglobal, double* d_y, long ldy, int c0, int m,
+                          unsigned long long seed, void* stream);
+int gcge_hip_colmajor_to_rowmajor(int nrows, int m, const double* d_src, long lds, double* d_dst, long ldd, void* stream);
+int gcge_hip_rowmajor_to_colmajor(int nrows, int m, const double* d_src, long lds, double* d_dst, long ldd, void* stream);
+}
+
+struct GCGE_HIP_MAT_ {
+  int nrows;      // local rows
+  int nglobal;    // global dimension
+  int row_begin;  // first global row
+  int nghost;     // halo rows appended to every block of vectors
+  long nnz;
+  int *d_rowptr, *d_colidx; double* d_val;    // CSR, LOCAL column indices (ghosts >= nrows)
+  int *d_orp, *d_pcol; double* d_pval;        // pad-8 copy for the 16-byte-lane kernel
+  long noct;
+};
+
+struct GcgeHipMV {
+  double* d;
+  long ld;
+  int nrows, nrows_alloc, ncols;
+  const GCGE_HIP_MAT_* mat;   // shape donor (row partition)
+};
+
+static hipStream_t g_stream = nullptr;
+static int g_inited = 0;
+static double* g_stage_d = nullptr; static size_t g_stage_d_len = 0;   // device staging (doubles)
+static double* g_stage_h = nullptr; static size_t g_stage_h_len = 0;   // pinned host staging
+static int g_rand_mode = 0; static unsigned long long g_rand_seed = 0x5DEECE66Dull;
+
+static double* stage_d(size_t len) {
+  if (len > g_stage_d_len) {
+    if (g_stage_d) GCGE_HIP_CHECK(hipFree(g_stage_d));
+    g_stage_d_len = len + len / 4 + 4096;
+    GCGE_HIP_CHECK(hipMalloc(&g_stage_d, g_stage_d_len * sizeof(double)));
+  }
+  return g_stage_d;
+}
+static double* stage_h(size_t len) {
+  if (len > g_stage_h_len) {
+    if (g_stage_h) GCGE_HIP_CHECK(hipHostFree(g_stage_h));
+    g_stage_h_len = len + len / 4 + 4096;
+    GCGE_HIP_CHECK(hipHostMalloc(&g_stage_h, g_stage_h_len * sizeof(double)));
+  }
+  return g_stage_h;
+}
+
+extern "C" int gcge_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" int gcge_hip_init(int device) {
+  if (g_inited) return 0;
+  if (gcge_hip_device_count() <= 0) {
+    fprintf(stderr, "gcge_hip_init: no HIP device visible — the HIP back-end has no CPU fallback\n");
+    return -1;
+  }
+  GCGE_HIP_CHECK(hipSetDevice(device));
+  g_stream = nullptr;   // the legacy default stream: ordered with torch's current stream and hipMemcpy
+  g_inited = 1;
+  return 0;
+}
+extern "C" void gcge_hip_finalize(void) {
+  if (g_stage_d) hipFree(g_stage_d);
+  if (g_stage_h) hipHostFree(g_stage_h);
+  g_stage_d = nullptr; g_stage_h = nullptr; g_stage_d_len = g_stage_h_len = 0; g_inited = 0;
+}
+extern "C" void gcge_hip_sync(void) { GCGE_HIP_CHECK(hipStreamSynchronize(g_stream)); }
+extern "C" void* gcge_hip_stream(void) { return (void*)g_stream; }
+extern "C" void gcge_hip_set_random_mode(int mode, unsigned long long seed) { g_rand_mode = mode; g_rand_seed = seed; }
+
+// ------------------------------------------------------------------ matrix
+extern "C" GCGE_HIP_MAT* gcge_hip_mat_create(int nrows, int nglobal, int row_begin, const int* rowptr,
+                                             const int* colidx, const double* val) {
+  if (gcge_hip_init(0) != 0) return nullptr;
+  GCGE_HIP_MAT* A = (GCGE_HIP_MAT*)calloc(1, sizeof(GCGE_HIP_MAT));
+  A->nrows = nrows; A->nglobal = nglobal; A->row_begin = row_begin; A->nnz = rowptr[nrows];
+  if (row_begin != 0 || nrows != nglobal) {
+    fprintf(stderr, "gcge_hip_mat_create: row-partitioned matrices need gcge_hip_mat_create_dist\n");
+    free(A); return nullptr;
+  }
+  const size_t nnz = (size_t)A->nnz;
+  GCGE_HIP_CHECK(hipMalloc(&A->d_rowptr, ((size_t)nrows + 1) * sizeof(int)));
+  GCGE_HIP_CHECK(hipMalloc(&A->d_colidx, (nnz ? nnz : 1) * sizeof(int)));
+  GCGE_HIP_CHECK(hipMalloc(&A->d_val, (nnz ? nnz : 1) * sizeof(double)));
+  GCGE_HIP_CHECK(hipMemcpy(A->d_rowptr, rowptr, ((size_t)nrows + 1) * sizeof(int), hipMemcpyHostToDevice));
+  GCGE_HIP_CHECK(hipMemcpy(A->d_colidx, colidx, nnz * sizeof(int), hipMemcpyHostToDevice));
+  GCGE_HIP_CHECK(hipMemcpy(A->d_val, val, nnz * sizeof(double), hipMemcpyHostToDevice));
+  // pad-8 copy: every row padded to a multiple of 8 entries with (own column, 0.0)
+  std::vector<int> orp((size_t)nrows + 1);
+  size_t noct = 0;
+  for (int r = 0; r < nrows; ++r) { orp[r] = (int)noct; noct += ((size_t)(rowptr[r + 1] - rowptr[r]) + 7) / 8; }
+  orp[nrows] = (int)noct;
+  std::vector<int> pc(noct * 8);
+  std::vector<double> pv(noct * 8);
+  for (int r = 0; r < nrows; ++r) {
+    size_t o = (size_t)orp[r] * 8; int k;
+    for (k = rowptr[r]; k < rowptr[r + 1]; ++k, ++o) { pc[o] = colidx[k]; pv[o] = val[k]; }
+    for (; o < (size_t)orp[r + 1] * 8; ++o) { pc[o] = r; pv[o] = 0.0; }
+  }
+  A->noct = (long)noct;
+  GCGE_HIP_CHECK(hipMalloc(&A->d_orp, ((size_t)nrows + 1) * sizeof(int)));
+  GCGE_HIP_CHECK(hipMalloc(&A->d_pcol, (noct ? noct * 8 : 1) * sizeof(int)));
+  GCGE_HIP_CHECK(hipMalloc(&A->d_pval, (noct ? noct * 8 : 1) * sizeof(double)));
+  GCGE_HIP_CHECK(hipMemcpy(A->d_orp, orp.data(), ((size_t)nrows + 1) * sizeof(int), hipMemcpyHostToDevice));
+  GCGE_HIP_CHECK(hipMemcpy(A->d_pcol, pc.data(), noct * 8 * sizeof(int), hipMemcpyHostToDevice));
+  GCGE_HIP_CHECK(hipMemcpy(A->d_pval, pv.data(), noct * 8 * sizeof(double), hipMemcpyHostToDevice));
+  return A;
+}
+extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_csr(const GCGE_CSR* A) {
+  return gcge_hip_mat_create(A->nrows, A->ncols, A->row_begin, A->rowptr, A->colidx, A->val);
+}
+extern "C" void gcge_hip_mat_destroy(GCGE_HIP_MAT* A) {
+  if (!A) return;
+  hipFree(A->d_rowptr); hipFree(A->d_colidx); hipFree(A->d_val);
+  hipFree(A->d_orp); hipFree(A->d_pcol); hipFree(A->d_pval);
+  free(A);
+}
+extern "C" int gcge_hip_mat_nrows(const GCGE_HIP_MAT* A) { return A->nrows; }
+extern "C" long gcge_hip_mat_nnz(const GCGE_HIP_MAT* A) { return A->nnz; }
+
+// ------------------------------------------------------------------ multivector
+static GcgeHipMV* mv_new(int nrows, int nghost, int ncols, const GCGE_HIP_MAT_* mat) {
+  GcgeHipMV* v = (GcgeHipMV*)calloc(1, sizeof(GcgeHipMV));
+  v->nrows = nrows; v->nrows_alloc = nrows + nghost; v->ncols = ncols; v->mat = mat;
+  v->ld = ((long)(ncols > 0 ? ncols : 1) + 7) / 8 * 8;
+  const size_t bytes = (size_t)v->nrows_alloc * v->ld * sizeof(double);
+  GCGE_HIP_CHECK(hipMalloc(&v->d, bytes ? bytes : 8));
+  GCGE_HIP_CHECK(hipMemsetAsync(v->d, 0, bytes, g_stream));   // zero-filled like app_ccs.c:47
+  return v;
+}
+static void HIP_MultiVecCreateByMat(void*** mv, int num_vec, void* mat, struct OPS_* ops) {
+  const GCGE_HIP_MAT_* A = (const GCGE_HIP_MAT_*)mat;
+  *mv = (void**)mv_new(A->nrows, A->nghost, num_vec, A);
+}
+static void HIP_MultiVecCreateByMultiVec(void*** mv, int num_vec, void** src, struct OPS_* ops) {
+  const GcgeHipMV* s = (const GcgeHipMV*)src;
+  *mv = (void**)mv_new(s->nrows, s->nrows_alloc - s->nrows, num_vec, s->mat);
+}
+static void HIP_MultiVecDestroy(void*** mv, int num_vec, struct OPS_* ops) {
+  GcgeHipMV* v = *(GcgeHipMV**)mv;
+  if (v) { GCGE_HIP_CHECK(hipStreamSynchronize(g_stream)); hipFree(v->d); free(v); }
+  *mv = nullptr;
+}
+extern "C" int gcge_hip_mv_nrows(void** mv) { return ((GcgeHipMV*)mv)->nrows; }
+extern "C" int gcge_hip_mv_ncols(void** mv) { return ((GcgeHipMV*)mv)->ncols; }
+extern "C" double* gcge_hip_mv_device_ptr(void** mv, long* ld) {
+  GcgeHipMV* v = (GcgeHipMV*)mv; if (ld) *ld = v->ld; return v->d;
+}
+
+// host column-major  <->  device row-major, in panels so the staging stays bounded
+extern "C" void gcge_hip_mv_from_host(void** mv, int c0, int c1, const double* host, long ldh) {
+  GcgeHipMV* v = (GcgeHipMV*)mv;
+  const int n = v->nrows;
+  const int panel = 32;
+  for (int c = c0; c < c1; c += panel) {
+    const int m = (c1 - c < panel) ? c1 - c : panel;
+    double* st = stage_d((size_t)n * m);
+    GCGE_HIP_CHECK(hipMemcpy2DAsync(st, (size_t)n * sizeof(double), host + (size_t)(c - c0) * ldh,
+                                    (size_t)ldh * sizeof(double), (size_t)n * sizeof(double), m,
+                                    hipMemcpyHostToDevice, g_stream));
+    gcge_hip_colmajor_to_rowmajor(n, m, st, n, v->d + c, v->ld, g_stream);
+    GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+  }
+}
+extern "C" void gcge_hip_mv_to_host(void** mv, int c0, int c1, double* host, long ldh) {
+  GcgeHipMV* v = (GcgeHipMV*)mv;
+  const int n = v->nrows;
+  const int panel = 32;
+  for (int c = c0; c < c1; c += panel) {
+    const int m = (c1 - c < panel) ? c1 - c : panel;
+    double* st = stage_d((size_t)n * m);
+    gcge_hip_rowmajor_to_colmajor(n, m, v->d + c, v->ld, st, n, g_stream);
+    GCGE_HIP_CHECK(hipMemcpy2DAsync(host + (size_t)(c - c0) * ldh, (size_t)ldh * sizeof(double), st,
+                                    (size_t)n * sizeof(double), (size_t)n * sizeof(double), m,
+                                    hipMemcpyDeviceToHost, g_stream));
+    GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+  }
+}
+
+static void HIP_MultiVecView(void** x, int start, int end, struct OPS_* ops) {
+  GcgeHipMV* v = (GcgeHipMV*)x;
+  const int m = end - start;
+  if (m <= 0) return;
+  std::vector<double> h((size_t)v->nrows * m);
+  gcge_hip_mv_to_host(x, start, end, h.data(), v->nrows);
+  for (int r = 0; r < v->nrows; ++r) {
+    for (int c = 0; c < m; ++c) ops->Printf("%6.4e\t", h[(size_t)c * v->nrows + r]);
+    ops->Printf("\n");
+  }
+}
+
+// app_lapack.c:322-333 — mode 0: the reference's rand() stream, column by column
+static void HIP_MultiVecSetRandomValue(void** x, int start, int end, struct OPS_* ops) {
+  GcgeHipMV* v = (GcgeHipMV*)x;
+  const int m = end - start;
+  if (m <= 0) return;
+  if (g_rand_mode == 1) {
+    const long rb = v->mat ? v->mat->row_begin : 0, ng = v->mat ? v->mat->nglobal : v->nrows;
+    gcge_hip_fill_uniform(v->nrows, rb, ng, v->d, v->ld, start, m, g_rand_seed, g_stream);
+    g_rand_seed += 0x9E3779B97F4A7C15ull;   // a later fill of the same columns differs
+    return;
+  }
+  const int panel = 16;
+  std::vector<double> h((size_t)v->nrows * panel);
+  for (int c = start; c < end; c += panel) {
+    const int mm = (end - c < panel) ? end - c : panel;
+    for (int j = 0; j < mm; ++j)
+      for (int r = 0; r < v->nrows; ++r) h[(size_t)j * v->nrows + r] = ((double)rand()) / ((double)RAND_MAX + 1);
+    gcge_hip_mv_from_host(x, c, c + mm, h.data(), v->nrows);
+  }
+}
+
+// app_lapack.c:334-395
+static void HIP_MultiVecAxpby(double alpha, void** x, double beta, void** y, int* start, int* end, struct OPS_* ops) {
+  GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
+  const int m = end[1] - start[1];
+  assert(end[0] - start[0] == m);
+  if (m <= 0 || vy->nrows == 0) return;
+  gcge_hip_axpby(vy->nrows, alpha, vx ? vx->d + start[0] : nullptr, vx ? vx->ld : 0, beta, vy->d + start[1],
+                 vy->ld, m, g_stream);
+}
+
+// app_lapack.c:463-534
+static void HIP_MultiVecLinearComb(void** x, void** y, int is_vec, int* start, int* end, double* coef, int ldc,
+                                   double* beta, int incb, struct OPS_* ops) {
+  GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
+  const int k = end[0] - start[0], m = end[1] - start[1];
+  if (k == 0 || m == 0 || vy->nrows == 0) return;
+  if (vx == nullptr || coef == nullptr) {       // scaling only: y_j *= beta_j
+    if (beta == nullptr) return;
+    if (incb == 0) { gcge_hip_axpby(vy->nrows, 0.0, nullptr, 0, *beta, vy->d + start[1], vy->ld, m, g_stream); return; }
+    double* hb = stage_h(m);
+    GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+    for (int j = 0; j < m; ++j) hb[j] = beta[(size_t)j * incb];
+    double* db = stage_d(m);
+    GCGE_HIP_CHECK(hipMemcpyAsync(db, hb, m * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    gcge_hip_colscale(vy->nrows, vy->d + start[1], vy->ld, m, db, g_stream);
+    return;
+  }
+  // panels of <= 128 output columns; coefficient panel uploaded row-major (k x mp) [+ beta]
+  for (int j0 = 0; j0 < m; j0 += 128) {
+    const int mp = (m - j0 < 128) ? m - j0 : 128;
+    const size_t len = (size_t)k * mp + mp;
+    GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));   // staging buffers are reused
+    double* hc = stage_h(len);
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < mp; ++j) hc[(size_t)i * mp + j] = coef[(size_t)(j0 + j) * ldc + i];
+    if (beta != nullptr) for (int j = 0; j < mp; ++j) hc[(size_t)k * mp + j] = (incb == 0) ? *beta : beta[(size_t)(j0 + j) * incb];
+    double* dc = stage_d(len);
+    GCGE_HIP_CHECK(hipMemcpyAsync(dc, hc, len * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    int rc = gcge_hip_lincomb(vy->nrows, vx->d + start[0], vx->ld, k, dc, mp, beta ? dc + (size_t)k * mp : nullptr,
+                              vy->d + start[1] + j0, vy->ld, g_stream);
+    assert(rc == 0); (void)rc;
+  }
+}
+
+// app_lapack.c:299-313 -> DenseMatQtAP(matA == NULL) :64-183.  Result to HOST, column-major ldIP.
+static void HIP_MultiVecLocalInnerProd(char nsd, void** x, void** y, int is_vec, int* start, int* end,
+                                       double* ip, int ldIP, struct OPS_* ops) {
+  GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
+  const int k = end[0] - start[0], m = end[1] - start[1];
+  if (k <= 0 || m <= 0) return;
+  assert(vx->nrows == vy->nrows);
+  if (nsd == 'D') {
+    assert(k == m);
+    double* dd = stage_d(m);
+    gcge_hip_coldots(vx->nrows, vx->d + start[0], vx->ld, vy->d + start[1], vy->ld, m, dd, g_stream);
+    double* hd = stage_h(m);
+    GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+    for (int j = 0; j < m; ++j) ip[(size_t)ldIP * j] = hd[j];
+    return;
+  }
+  double* dg = stage_d((size_t)k * m);
+  gcge_hip_gram(vx->nrows, vx->d + start[0], vx->ld, k, vy->d + start[1], vy->ld, m, dg, g_stream);
+  double* hg = stage_h((size_t)k * m);
+  GCGE_HIP_CHECK(hipMemcpyAsync(hg, dg, (size_t)k * m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+  if (nsd == 'S') {   // lower triangle is authoritative, mirrored (app_lapack.c:119-130)
+    assert(k == m);
+    for (int j = 0; j < m; ++j)
+      for (int i = j; i < k; ++i) { const double v = hg[(size_t)i * m + j]; ip[(size_t)ldIP * j + i] = v; ip[(size_t)ldIP * i + j] = v; }
+  } else {
+    for (int j = 0; j < m; ++j)
+      for (int i = 0; i < k; ++i) ip[(size_t)ldIP * j + i] = hg[(size_t)i * m + j];
+  }
+}
+
+// app_ccs.c:50-139;  mat == NULL copies (identity B)
+static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* end, struct OPS_* ops) {
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
+  GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
+  const int m = end[0] - start[0];
+  assert(m == end[1] - start[1]);
+  if (m <= 0) return;
+  if (A == nullptr) {
+    gcge_hip_axpby(vy->nrows, 1.0, vx->d + start[0], vx->ld, 0.0, vy->d + start[1], vy->ld, m, g_stream);
+    return;
+  }
+  const double* dx = vx->d + start[0];
+  double* dy = vy->d + start[1];
+  int rc = -1;
+  if (m >= 16) rc = gcge_hip_pad8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
+  if (rc == -1) rc = gcge_hip_csr_spmm(A->nrows, A->d_rowptr, A->d_colidx, A->d_val, dx, vx->ld, dy, vy->ld, m, g_stream);
+  assert(rc == 0); (void)rc;
+}
+// app_ccs.c:140-150 — symmetric matrices only
+static void HIP_MatTransDotMultiVec(void* mat, void** x, void** y, int* start, int* end, struct OPS_* ops) {
+  HIP_MatDotMultiVec(mat, x, y, start, end, ops);
+}
+
+extern "C" void OPS_HIP_Set(struct OPS_* ops) {
+  if (gcge_hip_init(0) != 0) {
+    fprintf(stderr, "OPS_HIP_Set: HIP back-end unavailable (no GPU): aborting — there is no CPU fallback\n");
+    abort();
+  }
+  ops->Printf                   = DefaultPrintf;
+  ops->GetWtime                 = DefaultGetWtime;
+  ops->GetOptionFromCommandLine = DefaultGetOptionFromCommandLine;
+  ops->MultiVecCreateByMat      = HIP_MultiVecCreateByMat;
+  ops->MultiVecCreateByMultiVec = HIP_MultiVecCreateByMultiVec;
+  ops->MultiVecDestroy          = HIP_MultiVecDestroy;
+  ops->MultiVecView             = HIP_MultiVecView;
+  ops->MultiVecLocalInnerProd   = HIP_MultiVecLocalInnerProd;
+  ops->MultiVecInnerProd        = nullptr;   // OPS_Setup installs Local + all-reduce
+  ops->MultiVecSetRandomValue   = HIP_MultiVecSetRandomValue;
+  ops->MultiVecAxpby            = HIP_MultiVecAxpby;
+  ops->MultiVecLinearComb       = HIP_MultiVecLinearComb;
+  ops->MatDotMultiVec           = HIP_MatDotMultiVec;
+  ops->MatTransDotMultiVec      = HIP_MatTransDotMultiVec;
+  ops->MultiVecQtAP             = nullptr;   // OPS_Setup installs SpMM-into-mv_ws + Gram
+}

@@ -1,0 +1,246 @@
+// K4 / K6 and helpers — streaming kernels on row-major blocks of vectors.
+//
+//   gcge_hip_axpby        Y[:,0:m) = alpha X[:,0:m) + beta Y      reference: app/app_lapack.c:334-395
+//   gcge_hip_colscale     Y[:,j)  *= s[j]                          (x == NULL branch of :463-534)
+//   gcge_hip_coldots      d[j] = sum_r X[r,j] Y[r,j]               ('D' branch of DenseMatQtAP :70-118)
+//   gcge_hip_fill_uniform counter-based U[0,1) fill (mode 1 of MultiVecSetRandomValue)
+//   transposing copies    row-major device block <-> column-major staging
+//
+// Roofline: HBM.  Bytes per element: axpby 8*(2 or 3), dots 16, scale 16.
+// One lane per COLUMN of a row segment, rows looped: a wave touches contiguous
+// 8*m-byte row segments; 16-byte lanes are used when the column origin and the
+// leading dimensions are even.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gcge_hip_internal.h"
+
+namespace gcge {
+
+// generic: thread = (row, column) with the column index fastest
+__global__ __launch_bounds__(256) void axpby_kernel(long nrows, double alpha,
+    const double* __restrict__ x, long ldx, double beta, double* y, long ldy, int m, int mode) {
+  // mode: 0 y = a x + b y ; 1 y = a x (no read of y) ; 2 y = b y ; 3 y = 0
+  const long total = nrows * (long)m;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; idx < total; idx += stride) {
+    const long r = idx / m;
+    const int j = (int)(idx - r * m);
+    double* py = y + r * ldy + j;
+    if (mode == 0) *py = alpha * x[r * ldx + j] + beta * (*py);
+    else if (mode == 1) *py = alpha * x[r * ldx + j];
+    else if (mode == 2) *py = beta * (*py);
+    else *py = 0.0;
+  }
+}
+
+// 16-byte lanes: m even, x/y origins 16-byte aligned, ldx/ldy even
+__global__ __launch_bounds__(256) void axpby2_kernel(long nrows, double alpha,
+    const double* __restrict__ x, long ldx, double beta, double* y, long ldy, int m2, int mode) {
+  const long total = nrows * (long)m2;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; idx < total; idx += stride) {
+    const long r = idx / m2;
+    const int j = 2 * (int)(idx - r * m2);
+    double2* py = reinterpret_cast<double2*>(y + r * ldy + j);
+    double2 v;
+    if (mode == 0) {
+      const double2 a = *reinterpret_cast<const double2*>(x + r * ldx + j);
+      const double2 b = *py;
+      v.x = alpha * a.x + beta * b.x; v.y = alpha * a.y + beta * b.y;
+    } else if (mode == 1) {
+      const double2 a = *reinterpret_cast<const double2*>(x + r * ldx + j);
+      v.x = alpha * a.x; v.y = alpha * a.y;
+    } else if (mode == 2) {
+      const double2 b = *py;
+      v.x = beta * b.x; v.y = beta * b.y;
+    } else { v.x = 0.0; v.y = 0.0; }
+    *py = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void colscale_kernel(long nrows, double* y, long ldy, int m,
+    const double* __restrict__ s) {
+  const long total = nrows * (long)m;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; idx < total; idx += stride) {
+    const long r = idx / m;
+    const int j = (int)(idx - r * m);
+    y[r * ldy + j] *= s[j];
+  }
+}
+
+// partial[b*m + j] = sum over the block's rows of x[r,j]*y[r,j];  256 threads = 4 row lanes x 64 cols
+__global__ __launch_bounds__(256) void coldots_partial(long nrows, const double* __restrict__ x, long ldx,
+    const double* __restrict__ y, long ldy, int m, double* __restrict__ partial, long rows_per_block) {
+  __shared__ double red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(nrows, r0 + rows_per_block);
+  for (int c0 = 0; c0 < m; c0 += 64) {
+    const int j = c0 + tx;
+    double s0 = 0.0, s1 = 0.0;
+    if (j < m) {
+      long r = r0 + ty;
+      for (; r + 4 < r1; r += 8) {
+        s0 = fma(x[r * ldx + j], y[r * ldy + j], s0);
+        s1 = fma(x[(r + 4) * ldx + j], y[(r + 4) * ldy + j], s1);
+      }
+      for (; r < r1; r += 4) s0 = fma(x[r * ldx + j], y[r * ldy + j], s0);
+    }
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && j < m)
+      partial[(long)blockIdx.x * m + j] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    __syncthreads();
+  }
+}
+// out[j] = sum_b partial[b*m + j], fixed order (bitwise reproducible)
+__global__ void reduce_partials(const double* __restrict__ partial, int nblocks, int len, double* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= len) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * len + j];
+  out[j] = s;
+}
+
+__device__ __forceinline__ double u01(unsigned long long seed, unsigned long long index) {
+  unsigned long long z = seed + (index + 1ull) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+// element (global row g, column c) <- u01(seed, c*nglobal + g): independent of the row partition
+__global__ __launch_bounds__(256) void fill_uniform_kernel(long nrows, long row_begin, long nglobal,
+    double* y, long ldy, int c0, int m, unsigned long long seed) {
+  const long total = nrows * (long)m;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; idx < total; idx += stride) {
+    const long r = idx / m;
+    const int j = (int)(idx - r * m);
+    y[r * ldy + c0 + j] = u01(seed, (unsigned long long)(c0 + j) * (unsigned long long)nglobal +
+                                        (unsigned long long)(row_begin + r));
+  }
+}
+
+// dst (row-major, ld ldd) [r, j] = src (column-major, ld lds) [r + lds*j], tile-transposed through LDS
+__global__ __launch_bounds__(256) void colmajor_to_rowmajor(long nrows, int m, const double* __restrict__ src,
+    long lds, double* __restrict__ dst, long ldd) {
+  __shared__ double tile[32][33];
+  const long r0 = (long)blockIdx.x * 32;
+  const int j0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int jj = ty; jj < 32; jj += 8)
+    if (r0 + tx < nrows && j0 + jj < m) tile[jj][tx] = src[(long)(j0 + jj) * lds + r0 + tx];
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8)
+    if (r0 + rr < nrows && j0 + tx < m) dst[(r0 + rr) * ldd + j0 + tx] = tile[tx][rr];
+}
+__global__ __launch_bounds__(256) void rowmajor_to_colmajor(long nrows, int m, const double* __restrict__ src,
+    long lds, double* __restrict__ dst, long ldd) {
+  __shared__ double tile[32][33];
+  const long r0 = (long)blockIdx.x * 32;
+  const int j0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int rr = ty; rr < 32; rr += 8)
+    if (r0 + rr < nrows && j0 + tx < m) tile[rr][tx] = src[(r0 + rr) * lds + j0 + tx];
+  __syncthreads();
+  for (int jj = ty; jj < 32; jj += 8)
+    if (r0 + tx < nrows && j0 + jj < m) dst[(long)(j0 + jj) * ldd + r0 + tx] = tile[tx][jj];
+}
+
+}  // namespace gcge
+
+using namespace gcge;
+
+static inline unsigned grid_for(long total) {
+  long g = (total + 255) / 256;
+  const long cap = 256L * 32;  // 32 blocks per CU, grid-stride the rest
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+extern "C" int gcge_hip_axpby(int nrows, double alpha, const double* d_x, long ldx, double beta,
+                              double* d_y, long ldy, int m, void* stream) {
+  if (nrows <= 0 || m <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int mode;
+  if (d_x == nullptr || alpha == 0.0) mode = (beta == 0.0) ? 3 : 2;
+  else mode = (beta == 0.0) ? 1 : 0;
+  if (mode == 2 && beta == 1.0) return 0;
+  if (mode == 3 && ldy == m) {  // contiguous block: plain memset
+    return (int)hipMemsetAsync(d_y, 0, (size_t)nrows * m * sizeof(double), st);
+  }
+  const bool vec2 = (m % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)d_y & 15) == 0) &&
+                    (mode >= 2 || ((ldx % 2 == 0) && (((uintptr_t)d_x & 15) == 0)));
+  if (vec2)
+    hipLaunchKernelGGL(axpby2_kernel, dim3(grid_for((long)nrows * (m / 2))), dim3(256), 0, st, (long)nrows,
+                       alpha, d_x, ldx, beta, d_y, ldy, m / 2, mode);
+  else
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for((long)nrows * m)), dim3(256), 0, st, (long)nrows, alpha,
+                       d_x, ldx, beta, d_y, ldy, m, mode);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gcge_hip_colscale(int nrows, double* d_y, long ldy, int m, const double* d_s, void* stream) {
+  if (nrows <= 0 || m <= 0) return 0;
+  hipLaunchKernelGGL(colscale_kernel, dim3(grid_for((long)nrows * m)), dim3(256), 0, (hipStream_t)stream,
+                     (long)nrows, d_y, ldy, m, d_s);
+  return (int)hipGetLastError();
+}
+
+// workspace for partial sums, grown on demand (owned by this translation unit)
+static double* g_partial = nullptr;
+static size_t g_partial_len = 0;
+extern "C" double* gcge_hip_partial_ws(size_t len) {
+  if (len > g_partial_len) {
+    if (g_partial) GCGE_HIP_CHECK(hipFree(g_partial));
+    g_partial_len = len + len / 4 + 4096;
+    GCGE_HIP_CHECK(hipMalloc(&g_partial, g_partial_len * sizeof(double)));
+  }
+  return g_partial;
+}
+
+extern "C" int gcge_hip_coldots(int nrows, const double* d_x, long ldx, const double* d_y, long ldy, int m,
+                                double* d_out, void* stream) {
+  if (m <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (nrows <= 0) return (int)hipMemsetAsync(d_out, 0, m * sizeof(double), st);
+  long nb = ((long)nrows + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  const long rpb = (((long)nrows + nb - 1) / nb + 3) / 4 * 4;
+  nb = ((long)nrows + rpb - 1) / rpb;
+  double* part = gcge_hip_partial_ws((size_t)nb * m);
+  hipLaunchKernelGGL(coldots_partial, dim3((unsigned)nb), dim3(256), 0, st, (long)nrows, d_x, ldx, d_y, ldy, m,
+                     part, rpb);
+  hipLaunchKernelGGL(reduce_partials, dim3((m + 127) / 128), dim3(128), 0, st, part, (int)nb, m, d_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gcge_hip_fill_uniform(int nrows, long row_begin, long nglobal, double* d_y, long ldy, int c0,
+                                     int m, unsigned long long seed, void* stream) {
+  if (nrows <= 0 || m <= 0) return 0;
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for((long)nrows * m)), dim3(256), 0, (hipStream_t)stream,
+                     (long)nrows, row_begin, nglobal, d_y, ldy, c0, m, seed);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gcge_hip_colmajor_to_rowmajor(int nrows, int m, const double* d_src, long lds, double* d_dst,
+                                             long ldd, void* stream) {
+  if (nrows <= 0 || m <= 0) return 0;
+  dim3 grid((unsigned)((nrows + 31) / 32), (unsigned)((m + 31) / 32));
+  hipLaunchKernelGGL(colmajor_to_rowmajor, grid, dim3(256), 0, (hipStream_t)stream, (long)nrows, m, d_src, lds,
+                     d_dst, ldd);
+  return (int)hipGetLastError();
+}
+extern "C" int gcge_hip_rowmajor_to_colmajor(int nrows, int m, const double* d_src, long lds, double* d_dst,
+                                             long ldd, void* stream) {
+  if (nrows <= 0 || m <= 0) return 0;
+  dim3 grid((unsigned)((nrows + 31) / 32), (unsigned)((m + 31) / 32));
+  hipLaunchKernelGGL(rowmajor_to_colmajor, grid, dim3(256), 0, (hipStream_t)stream, (long)nrows, m, d_src, lds,
+                     d_dst, ldd);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,81 @@
+/* gcge_hip.h — C ABI of the MI355X (gfx950) back-end, libgcge_hip.so.
+ *
+ * Drop-in boundary: `OPS_HIP_Set` fills the operator table of gcge_ops.h exactly as
+ * the reference's built-in back-ends do (pattern: app/app_ccs.c:213-249 OPS_CCS_Set,
+ * app/app_slepc.c:610-634 OPS_SLEPC_Set), so GCGE's solver layers — the
+ * reference's or ours — run with every O(n) operand resident in HBM.
+ * Everything below is plain C: pointers and sizes only, no C++/torch types.
+ *
+ * Device layout of a block of vectors: ROW-major, element (r,c) at d[r*ld + c],
+ * ld a multiple of 8 doubles; rows [nrows, nrows+nghost) are halo rows used only
+ * while a row-partitioned SpMM runs.  Handles are opaque to the solver
+ * (the reference never dereferences them: SURVEY.md §8b "Layout opacity").
+ */
+#ifndef GCGE_HIP_H
+#define GCGE_HIP_H
+
+#include "gcge_ops.h"
+#include "gcge_problems.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime ---------------------------------------------------------------- */
+int  gcge_hip_init (int device);              /* hipSetDevice + workspace; 0 on success   */
+void gcge_hip_finalize (void);
+int  gcge_hip_device_count (void);
+void gcge_hip_sync (void);
+void *gcge_hip_stream (void);                 /* hipStream_t all kernels are launched on  */
+
+/* ---- back-end registration (replaces OPS_CCS_Set, app/app_ccs.c:213-249) ------ */
+void OPS_HIP_Set (struct OPS_ *ops);
+
+/* ---- sparse matrix handle (replaces CCSMAT, app/app_ccs.h:20-24) -------------- */
+typedef struct GCGE_HIP_MAT_ GCGE_HIP_MAT;
+/* rows [row_begin,row_begin+nrows) of a symmetric matrix, GLOBAL column indices, host CSR
+ * (== the CCS triple j_col/i_row/data).  Single rank: row_begin = 0, nrows = nglobal. */
+GCGE_HIP_MAT *gcge_hip_mat_create (int nrows, int nglobal, int row_begin,
+		const int *rowptr, const int *colidx, const double *val);
+GCGE_HIP_MAT *gcge_hip_mat_create_csr (const GCGE_CSR *A);
+void gcge_hip_mat_destroy (GCGE_HIP_MAT *A);
+int  gcge_hip_mat_nrows (const GCGE_HIP_MAT *A);
+long gcge_hip_mat_nnz (const GCGE_HIP_MAT *A);
+
+/* ---- block-of-vectors transfers (tests, final eigenvectors) ------------------- */
+/* columns [c0,c1) <-> host column-major array with leading dimension ldh (>= nrows) */
+void gcge_hip_mv_to_host   (void **mv, int c0, int c1, double *host, long ldh);
+void gcge_hip_mv_from_host (void **mv, int c0, int c1, const double *host, long ldh);
+int  gcge_hip_mv_nrows (void **mv);
+int  gcge_hip_mv_ncols (void **mv);
+double *gcge_hip_mv_device_ptr (void **mv, long *ld);
+
+/* 0: MultiVecSetRandomValue draws glibc rand() on the host in the reference's order
+ *    (app/app_lapack.c:322-333) and uploads — bit-identical start vectors;
+ * 1: counter-based generator on the device (for n ~ 1e7, where 2e9 rand() calls
+ *    would dominate the run).                                                      */
+void gcge_hip_set_random_mode (int mode, unsigned long long seed);
+
+/* ---- raw kernels (what the slots launch; exposed for micro-benchmarks) --------- */
+/* K1  Y[:,0:m) = A X[:,0:m);  x/y point at (row 0, first column); see csrc/hip/spmm*.hip */
+int gcge_hip_csr_spmm  (int nrows, const int *d_rowptr, const int *d_colidx, const double *d_val,
+		const double *d_x, long ldx, double *d_y, long ldy, int ncols, void *stream);
+int gcge_hip_pad8_spmm (int nrows, const int *d_orp, const int *d_pcol, const double *d_pval,
+		const double *d_x, long ldx, double *d_y, long ldy, int ncols, void *stream);
+/* K2  G(k x m, row-major on device, ld m) = Q[:,0:k)^T P[:,0:m)  over nrows rows (MFMA f64) */
+int gcge_hip_gram (int nrows, const double *d_q, long ldq, int k, const double *d_p, long ldp, int m,
+		double *d_g, void *stream);
+/*     d_out[j] = sum_r x[r,j] y[r,j] */
+int gcge_hip_coldots (int nrows, const double *d_x, long ldx, const double *d_y, long ldy, int m,
+		double *d_out, void *stream);
+/* K3  Y[:,0:m) = X[:,0:k) C + Y diag(beta);  d_c row-major k x m; d_beta NULL => overwrite */
+int gcge_hip_lincomb (int nrows, const double *d_x, long ldx, int k, const double *d_c, int m,
+		const double *d_beta, double *d_y, long ldy, void *stream);
+/* K4  Y[:,0:m) = alpha X[:,0:m) + beta Y   (d_x NULL: scale only; beta == 0: no read of Y) */
+int gcge_hip_axpby (int nrows, double alpha, const double *d_x, long ldx, double beta,
+		double *d_y, long ldy, int m, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,99 @@
+"""Shared test helpers: the CPU oracle behind the same Python face as gcge_amd.HipBackend,
+seeded inputs (gcge_uniform stream) and the problems used by both GPU and CPU tests."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+import pyoracle as po
+from gcge_amd.lib import host_lib, make_problem, run_gcg
+from gcge_amd.ops_struct import OpsTable
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def uniform(seed, shape):
+    """The gcge_uniform(seed, index) stream, vectorised (splitmix64)."""
+    n = int(np.prod(shape))
+    idx = np.arange(1, n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)).reshape(shape, order="F")
+
+
+def test_matrix(kind, size, **kw):
+    return make_problem(kind, size, **kw)
+
+
+def csr_to_scipy(A):
+    import scipy.sparse as sp
+    n = A.nrows
+    rp = np.ctypeslib.as_array(A.rowptr, shape=(n + 1,)).copy()
+    ci = np.ctypeslib.as_array(A.colidx, shape=(int(A.nnz),)).copy()
+    va = np.ctypeslib.as_array(A.val, shape=(int(A.nnz),)).copy()
+    return sp.csr_matrix((va, ci, rp), shape=(n, A.ncols))
+
+
+class OracleBackend:
+    """CPU oracle with the interface of gcge_amd.hip_backend.HipBackendImpl."""
+
+    def __init__(self, quiet=True):
+        self.h = host_lib()
+        self.o = po.oracle_lib()
+        self.ops_handle = po.make_ops(quiet)
+        self.ops = OpsTable(self.ops_handle)
+        self._keep = []
+
+    def matrix(self, csr):
+        m = po.ccs_from_csr(csr)
+        self._keep.append((m, csr))
+        return C.cast(C.pointer(m), C.c_void_p)
+
+    def free_matrix(self, m):
+        pass
+
+    def mv_from_numpy(self, mat, arr):
+        a = np.asfortranarray(arr, dtype=np.float64)
+        mv = self.ops.mv_create(a.shape[1], mat)
+        v = C.cast(mv, C.POINTER(po.OVec)).contents
+        dst = np.ctypeslib.as_array(v.data, shape=(v.ncols, v.ldd))
+        dst[:, :a.shape[0]] = a.T
+        return mv
+
+    def mv_to_numpy(self, mv, n, c0, c1):
+        v = C.cast(mv, C.POINTER(po.OVec)).contents
+        src = np.ctypeslib.as_array(v.data, shape=(v.ncols, v.ldd))
+        return np.asfortranarray(src[c0:c1, :n].T.copy())
+
+    def set_random_mode(self, mode, seed=0):
+        pass
+
+    def sync(self):
+        pass
+
+
+def gcg_on(backend, kind, size, args, flag=0, **kw):
+    """Run the GCG harness through `backend` on a generated problem."""
+    A, B = make_problem(kind, size, **kw)
+    mA = backend.matrix(A)
+    mB = backend.matrix(B) if B is not None else None
+    ev, res = run_gcg(backend.ops_handle, mA, mB, args, flag=flag)
+    backend.free_matrix(mA)
+    if mB is not None:
+        backend.free_matrix(mB)
+    return ev, res
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN_DIR, name)) as f:
+        return json.load(f)
+
+
+def lap3d_exact(N, count):
+    c = 2.0 * np.cos(np.arange(1, N + 1) * np.pi / (N + 1))
+    lam = (6.0 - c[:, None, None] - c[None, :, None] - c[None, None, :]).ravel()
+    return np.sort(lam)[:count]

@@ -1,0 +1,181 @@
+"""GPU parity tests (MI355X): every call goes through the C ABI of libgcge_hip.so; the checker
+is the CPU oracle (oracle/) and the golden vectors produced by the real reference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import OracleBackend, csr_to_scipy, gcg_on, lap3d_exact, load_golden, uniform
+from slot_cases import run_bpcg_case, run_orth_cases, run_slot_cases, _close
+from solver_setup import bpcg_setup, orth_setup
+from gcge_amd.lib import make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_library_is_loaded(hip):
+    maps = open("/proc/self/maps").read()
+    assert "libgcge_hip.so" in maps and "libgcge_host.so" in maps
+
+
+def test_slots_match_reference_vectors(hip):
+    P = run_slot_cases(hip)
+    run_orth_cases(hip, P, orth_setup(hip.ops_handle))
+    run_bpcg_case(hip, P, bpcg_setup(hip.ops_handle))
+
+
+@pytest.fixture(scope="module")
+def both(hip):
+    return hip, OracleBackend()
+
+
+def _pair_mats(both, kind, size, **kw):
+    hip, ora = both
+    A, B = make_problem(kind, size, **kw)
+    return A, hip.matrix(A), ora.matrix(A)
+
+
+@pytest.mark.parametrize("kind,size,kw", [("lap3d", 13, {}), ("fe3d", 11, {}), ("sio2", 10, {"K": 8, "R0": 2.0, "R1": 3.0})])
+def test_spmm_vs_oracle(both, kind, size, kw):
+    hip, ora = both
+    A, mh, mo = _pair_mats(both, kind, size, **kw)
+    n = A.nrows
+    X = uniform(7, (n, 140)) - 0.5
+    xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
+    for m, s0, s1 in [(1, 0, 0), (1, 3, 5), (2, 0, 2), (3, 1, 0), (5, 2, 3), (8, 0, 0), (16, 0, 0), (17, 1, 2), (31, 0, 1),
+                      (32, 0, 0), (33, 2, 0), (48, 8, 16), (64, 0, 0), (64, 1, 3), (65, 0, 0), (100, 0, 2), (128, 0, 0),
+                      (128, 2, 4), (130, 1, 1)]:
+        Y0 = uniform(8, (n, 140))
+        yh, yo = hip.mv_from_numpy(mh, Y0), ora.mv_from_numpy(mo, Y0)
+        hip.ops.spmm(mh, xh, yh, (s0, s1), (s0 + m, s1 + m))
+        ora.ops.spmm(mo, xo, yo, (s0, s1), (s0 + m, s1 + m))
+        _close(hip.mv_to_numpy(yh, n, 0, 140), ora.mv_to_numpy(yo, n, 0, 140), tol=1e-13, what="spmm m=%d" % m)
+        hip.ops.mv_destroy(yh); ora.ops.mv_destroy(yo)
+    # independent check against scipy on one shape
+    S = csr_to_scipy(A)
+    yh = hip.mv_from_numpy(mh, np.zeros((n, 64)))
+    hip.ops.spmm(mh, xh, yh, (4, 0), (68, 64))
+    _close(hip.mv_to_numpy(yh, n, 0, 64), S @ X[:, 4:68], tol=1e-13, what="spmm vs scipy")
+
+
+def test_gram_and_dots_vs_oracle(both):
+    hip, ora = both
+    A, mh, mo = _pair_mats(both, "lap3d", 13)
+    n = A.nrows
+    X = uniform(17, (n, 210)) - 0.5; Y = uniform(18, (n, 210)) - 0.5
+    xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
+    yh, yo = hip.mv_from_numpy(mh, Y), ora.mv_from_numpy(mo, Y)
+    for k, m, s0, s1 in [(1, 1, 0, 0), (3, 5, 1, 2), (16, 16, 0, 0), (64, 64, 0, 0), (65, 33, 3, 1), (130, 70, 0, 5),
+                         (200, 128, 2, 7), (7, 200, 0, 0)]:
+        got = hip.ops.inner_prod("N", xh, yh, (s0, s1), (s0 + k, s1 + m), ld=k + 3)
+        ref = ora.ops.inner_prod("N", xo, yo, (s0, s1), (s0 + k, s1 + m), ld=k + 3)
+        _close(got, ref, tol=1e-12, what="gram N %dx%d" % (k, m))
+        _close(got, X[:, s0:s0 + k].T @ Y[:, s1:s1 + m], tol=1e-12, what="gram N vs numpy")
+    for k, s in [(1, 0), (5, 2), (64, 0), (77, 3)]:
+        got = hip.ops.inner_prod("S", xh, xh, (s, s), (s + k, s + k))
+        _close(got, ora.ops.inner_prod("S", xo, xo, (s, s), (s + k, s + k)), tol=1e-12, what="gram S")
+        assert np.array_equal(got, got.T)
+        got = hip.ops.inner_prod("D", xh, yh, (s, s + 1), (s + k, s + 1 + k), ld=2)
+        _close(got, ora.ops.inner_prod("D", xo, yo, (s, s + 1), (s + k, s + 1 + k), ld=2), tol=1e-12, what="dots D")
+
+
+def test_lincomb_axpby_vs_oracle(both):
+    hip, ora = both
+    A, mh, mo = _pair_mats(both, "lap3d", 13)
+    n = A.nrows
+    X = uniform(27, (n, 270)) - 0.5
+    for k, m, s0, s1 in [(1, 1, 0, 0), (5, 7, 1, 2), (32, 16, 0, 0), (33, 64, 3, 1), (100, 65, 0, 5), (260, 128, 2, 3),
+                         (64, 140, 0, 1), (3, 1, 4, 9)]:
+        Y0 = uniform(28, (n, 150))
+        xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
+        coef = np.asfortranarray(uniform(29, (k + 2, m)) - 0.5)
+        beta = uniform(30, (2 * m,)) * 2 - 1
+        for bmode in ("none", "scalar", "vec"):
+            yh, yo = hip.mv_from_numpy(mh, Y0), ora.mv_from_numpy(mo, Y0)
+            b, incb = (None, 0) if bmode == "none" else ((beta, 0) if bmode == "scalar" else (beta, 2))
+            hip.ops.lincomb(xh, yh, (s0, s1), (s0 + k, s1 + m), coef, k + 2, b, incb)
+            ora.ops.lincomb(xo, yo, (s0, s1), (s0 + k, s1 + m), coef, k + 2, b, incb)
+            _close(hip.mv_to_numpy(yh, n, 0, 150), ora.mv_to_numpy(yo, n, 0, 150), tol=1e-12, what="lincomb %d %d %s" % (k, m, bmode))
+            hip.ops.mv_destroy(yh); ora.ops.mv_destroy(yo)
+        hip.ops.mv_destroy(xh); ora.ops.mv_destroy(xo)
+    # axpby incl. NaN-safety of beta == 0 (y is zeroed, never multiplied: app_lapack.c:349-351)
+    Y0 = uniform(31, (n, 20)); Y0[5, 3] = np.nan
+    xh, yh = hip.mv_from_numpy(mh, X[:, :20]), hip.mv_from_numpy(mh, Y0)
+    hip.ops.axpby(2.0, xh, 0.0, yh, (1, 2), (9, 10))
+    got = hip.mv_to_numpy(yh, n, 0, 20)
+    assert np.all(np.isfinite(got[:, 2:10])) and np.allclose(got[:, 2:10], 2.0 * X[:, 1:9])
+    for m, s0, s1, a, b in [(1, 0, 0, 1.0, 1.0), (1, 3, 7, -2.0, 0.5), (7, 1, 2, 0.3, -1.0), (16, 0, 4, 1.0, 0.0), (19, 1, 0, 0.0, 2.0)]:
+        Y0 = uniform(32, (n, 20))
+        xh, xo = hip.mv_from_numpy(mh, X[:, :20]), ora.mv_from_numpy(mo, X[:, :20])
+        yh, yo = hip.mv_from_numpy(mh, Y0), ora.mv_from_numpy(mo, Y0)
+        hip.ops.axpby(a, xh, b, yh, (s0, s1), (s0 + m, s1 + m)); ora.ops.axpby(a, xo, b, yo, (s0, s1), (s0 + m, s1 + m))
+        _close(hip.mv_to_numpy(yh, n, 0, 20), ora.mv_to_numpy(yo, n, 0, 20), tol=1e-15, what="axpby")
+
+
+GCG = load_golden("gcg.json")
+
+
+@pytest.mark.parametrize("key", ["lap3d_12_nev10", "lap3d_20_nev20", "lap3d_16_nev12_b8", "fe3d_12_nev10",
+                                 "fe3d_20_nev20", "fe1d_807_nev30", "sio2_12_nev10"])
+def test_gcg_on_hip_matches_reference_run(hip, key):
+    c = GCG[key]
+    args = ["-nevConv", c["nev"]]
+    if c["nev_max"]:
+        args += ["-nevMax", c["nev_max"]]
+    if c["block"]:
+        args += ["-blockSize", c["block"]]
+    hip.set_random_mode(0)     # the reference's rand() stream after srand(0)
+    ev, res = gcg_on(hip, c["kind"], c["size"], args, K=6, R0=1.5, R1=2.0, seed=12345)
+    assert res.nevConv == c["nevConv"]
+    assert abs(res.numIter - c["numIter"]) <= 2
+    ref = np.array(c["eval"])
+    rel = np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref))
+    assert rel < 1e-10, "Ritz values differ from the reference CPU path: %.3e" % rel
+
+
+def test_gcg_device_rng_closed_form(hip):
+    """Start vectors from the device generator (what the n ~ 1e7 runs use): converged Ritz values do
+    not depend on the start block — compare with the closed-form spectrum."""
+    hip.set_random_mode(1, 2024)
+    ev, res = gcg_on(hip, "lap3d", 32, ["-nevConv", 20, "-nevMax", 48, "-blockSize", 16])
+    hip.set_random_mode(0)
+    assert res.nevConv >= 20
+    exact = lap3d_exact(32, res.nevConv)
+    assert np.max(np.abs(ev[:res.nevConv] - exact) / exact) < 1e-10
+
+
+def test_full_size_spmm_properties(hip):
+    """BASELINE config 2 shape (Lap3D 256^3, 64 columns): size-independent properties instead of a
+    CPU recomputation — symmetry x^T (A y) = (A x)^T y column-wise, and A applied to the constant
+    vector gives the boundary-degree pattern with known sum 6 N^2."""
+    N = 256
+    A, _ = make_problem("lap3d", N)
+    mh = hip.matrix(A)
+    n = A.nrows
+    ops = hip.ops
+    x = ops.mv_create(64, mh); y = ops.mv_create(64, mh); ax = ops.mv_create(64, mh); ay = ops.mv_create(64, mh)
+    hip.set_random_mode(1, 99)
+    ops.set_random(x, 0, 64); ops.set_random(y, 0, 64)
+    hip.set_random_mode(0)
+    ops.spmm(mh, x, ax, (0, 0), (64, 64)); ops.spmm(mh, y, ay, (0, 0), (64, 64))
+    d1 = ops.inner_prod("D", x, ay, (0, 0), (64, 64)); d2 = ops.inner_prod("D", ax, y, (0, 0), (64, 64))
+    assert np.max(np.abs(d1 - d2) / np.abs(d1)) < 1e-12
+    # A * ones: row sums; total = 6 N^2 (each of the 6 faces loses one neighbour per boundary node)
+    ops.axpby(0.0, None, 0.0, x, (0, 0), (2, 2))
+    one = np.ones((1, 1))
+    ops.lincomb(None, x, (0, 0), (0, 0), None, 0)  # no-op with empty ranges (must not crash)
+    hip.g.gcge_hip_sync()
+    ones = ops.mv_create(2, mh)
+    import ctypes
+    ld = ctypes.c_long()
+    hip.g.gcge_hip_mv_device_ptr.restype = ctypes.c_void_p
+    # fill with ones through axpby on a zero block: y = 0*y then y += 1 via lincomb of a one-column block is awkward;
+    # use set_random + scale trick instead: (u - u) + 1 is not available -> use from_host for 2 columns (268 MB)
+    hones = np.ones((n, 2), order="F")
+    hip.g.gcge_hip_mv_from_host(ones, 0, 2, hones.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n)
+    ops.spmm(mh, ones, x, (0, 0), (2, 2))
+    s = ops.inner_prod("D", ones, x, (0, 0), (2, 2))
+    assert abs(s[0] - 6.0 * N * N) < 1e-6 * 6.0 * N * N
+    for hnd in (x, y, ax, ay, ones):
+        ops.mv_destroy(hnd)
+    hip.free_matrix(mh)

@@ -1,0 +1,41 @@
+"""CPU (no GPU): the oracle back-end and the host solver stack against the golden vectors made
+by the REAL reference (tests/golden/make_golden.py, oracle/_ref)."""
+import numpy as np
+import pytest
+
+from helpers import gcg_on, lap3d_exact, load_golden
+from slot_cases import run_bpcg_case, run_orth_cases, run_slot_cases
+from solver_setup import bpcg_setup, orth_setup
+
+
+def test_oracle_slots_match_reference_vectors(oracle):
+    P = run_slot_cases(oracle)
+    run_orth_cases(oracle, P, orth_setup(oracle.ops_handle))
+    run_bpcg_case(oracle, P, bpcg_setup(oracle.ops_handle))
+
+
+GCG = load_golden("gcg.json")
+
+
+@pytest.mark.parametrize("key", sorted(GCG.keys()))
+def test_gcg_driver_on_oracle_matches_reference_run(oracle, key):
+    c = GCG[key]
+    args = ["-nevConv", c["nev"]]
+    if c["nev_max"]:
+        args += ["-nevMax", c["nev_max"]]
+    if c["block"]:
+        args += ["-blockSize", c["block"]]
+    args += c["extra"]
+    ev, res = gcg_on(oracle, c["kind"], c["size"], args, K=6, R0=1.5, R1=2.0, seed=12345)
+    assert res.nevConv == c["nevConv"]
+    assert abs(res.numIter - c["numIter"]) <= 1, (res.numIter, c["numIter"])
+    ref = np.array(c["eval"])
+    rel = np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref))
+    assert rel < 1e-10, "Ritz values differ from the reference: %.3e" % rel
+
+
+def test_lap3d_closed_form(oracle):
+    ev, res = gcg_on(oracle, "lap3d", 14, ["-nevConv", 12])
+    exact = lap3d_exact(14, res.nevConv)
+    assert res.nevConv >= 12
+    assert np.max(np.abs(ev[:res.nevConv] - exact) / exact) < 1e-10
