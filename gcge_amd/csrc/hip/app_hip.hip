@@ -45,6 +45,16 @@ struct GcgeHipMV {
   const GCGE_HIP_MAT_* mat;   // shape donor (row partition)
 };
 
+// Shape contract of every slot is checked on the HOST before a kernel is launched: a
+// mismatch must abort here, never turn into an out-of-bounds access on the device.
+#define GCGE_REQUIRE(cond, what)                                                        \
+  do {                                                                                  \
+    if (!(cond)) {                                                                      \
+      fprintf(stderr, "gcge_hip: %s violated (%s) at %s:%d\n", what, #cond, __FILE__, __LINE__); \
+      abort();                                                                          \
+    }                                                                                   \
+  } while (0)
+
 static hipStream_t g_stream = nullptr;
 static int g_inited = 0;
 static double* g_stage_d = nullptr; static size_t g_stage_d_len = 0;   // device staging (doubles)
@@ -176,6 +186,7 @@ extern "C" double* gcge_hip_mv_device_ptr(void** mv, long* ld) {
 extern "C" void gcge_hip_mv_from_host(void** mv, int c0, int c1, const double* host, long ldh) {
   GcgeHipMV* v = (GcgeHipMV*)mv;
   const int n = v->nrows;
+  GCGE_REQUIRE(c0 >= 0 && c1 <= v->ncols && ldh >= n, "gcge_hip_mv_from_host: ranges");
   const int panel = 32;
   for (int c = c0; c < c1; c += panel) {
     const int m = (c1 - c < panel) ? c1 - c : panel;
@@ -190,6 +201,7 @@ extern "C" void gcge_hip_mv_from_host(void** mv, int c0, int c1, const double* h
 extern "C" void gcge_hip_mv_to_host(void** mv, int c0, int c1, double* host, long ldh) {
   GcgeHipMV* v = (GcgeHipMV*)mv;
   const int n = v->nrows;
+  GCGE_REQUIRE(c0 >= 0 && c1 <= v->ncols && ldh >= n, "gcge_hip_mv_to_host: ranges");
   const int panel = 32;
   for (int c = c0; c < c1; c += panel) {
     const int m = (c1 - c < panel) ? c1 - c : panel;
@@ -219,6 +231,7 @@ static void HIP_MultiVecSetRandomValue(void** x, int start, int end, struct OPS_
   GcgeHipMV* v = (GcgeHipMV*)x;
   const int m = end - start;
   if (m <= 0) return;
+  GCGE_REQUIRE(start >= 0 && end <= v->ncols, "MultiVecSetRandomValue: column range");
   if (g_rand_mode == 1) {
     const long rb = v->mat ? v->mat->row_begin : 0, ng = v->mat ? v->mat->nglobal : v->nrows;
     gcge_hip_fill_uniform(v->nrows, rb, ng, v->d, v->ld, start, m, g_rand_seed, g_stream);
@@ -239,8 +252,13 @@ static void HIP_MultiVecSetRandomValue(void** x, int start, int end, struct OPS_
 static void HIP_MultiVecAxpby(double alpha, void** x, double beta, void** y, int* start, int* end, struct OPS_* ops) {
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int m = end[1] - start[1];
-  assert(end[0] - start[0] == m);
+  GCGE_REQUIRE(end[0] - start[0] == m, "MultiVecAxpby: equal column counts");
   if (m <= 0 || vy->nrows == 0) return;
+  GCGE_REQUIRE(start[1] >= 0 && end[1] <= vy->ncols, "MultiVecAxpby: y column range");
+  if (vx) {
+    GCGE_REQUIRE(vx->nrows == vy->nrows, "MultiVecAxpby: equal row counts");
+    GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols, "MultiVecAxpby: x column range");
+  }
   gcge_hip_axpby(vy->nrows, alpha, vx ? vx->d + start[0] : nullptr, vx ? vx->ld : 0, beta, vy->d + start[1],
                  vy->ld, m, g_stream);
 }
@@ -251,6 +269,11 @@ static void HIP_MultiVecLinearComb(void** x, void** y, int is_vec, int* start, i
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int k = end[0] - start[0], m = end[1] - start[1];
   if (k == 0 || m == 0 || vy->nrows == 0) return;
+  GCGE_REQUIRE(start[1] >= 0 && end[1] <= vy->ncols && m > 0, "MultiVecLinearComb: y column range");
+  if (vx != nullptr && coef != nullptr) {
+    GCGE_REQUIRE(vx->nrows == vy->nrows, "MultiVecLinearComb: equal row counts");
+    GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols && k > 0 && ldc >= k, "MultiVecLinearComb: x column range / ldc");
+  }
   if (vx == nullptr || coef == nullptr) {       // scaling only: y_j *= beta_j
     if (beta == nullptr) return;
     if (incb == 0) { gcge_hip_axpby(vy->nrows, 0.0, nullptr, 0, *beta, vy->d + start[1], vy->ld, m, g_stream); return; }
@@ -275,7 +298,7 @@ static void HIP_MultiVecLinearComb(void** x, void** y, int is_vec, int* start, i
     GCGE_HIP_CHECK(hipMemcpyAsync(dc, hc, len * sizeof(double), hipMemcpyHostToDevice, g_stream));
     int rc = gcge_hip_lincomb(vy->nrows, vx->d + start[0], vx->ld, k, dc, mp, beta ? dc + (size_t)k * mp : nullptr,
                               vy->d + start[1] + j0, vy->ld, g_stream);
-    assert(rc == 0); (void)rc;
+    GCGE_REQUIRE(rc == 0, "MultiVecLinearComb: kernel launch");
   }
 }
 
@@ -285,9 +308,11 @@ static void HIP_MultiVecLocalInnerProd(char nsd, void** x, void** y, int is_vec,
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int k = end[0] - start[0], m = end[1] - start[1];
   if (k <= 0 || m <= 0) return;
-  assert(vx->nrows == vy->nrows);
+  GCGE_REQUIRE(vx->nrows == vy->nrows, "MultiVecInnerProd: equal row counts");
+  GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols && start[1] >= 0 && end[1] <= vy->ncols, "MultiVecInnerProd: column ranges");
+  GCGE_REQUIRE(nsd == 'D' ? ldIP >= 1 : ldIP >= k, "MultiVecInnerProd: ldIP");
   if (nsd == 'D') {
-    assert(k == m);
+    GCGE_REQUIRE(k == m, "MultiVecInnerProd 'D': square");
     double* dd = stage_d(m);
     gcge_hip_coldots(vx->nrows, vx->d + start[0], vx->ld, vy->d + start[1], vy->ld, m, dd, g_stream);
     double* hd = stage_h(m);
@@ -302,7 +327,7 @@ static void HIP_MultiVecLocalInnerProd(char nsd, void** x, void** y, int is_vec,
   GCGE_HIP_CHECK(hipMemcpyAsync(hg, dg, (size_t)k * m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
   if (nsd == 'S') {   // lower triangle is authoritative, mirrored (app_lapack.c:119-130)
-    assert(k == m);
+    GCGE_REQUIRE(k == m, "MultiVecInnerProd 'S': square");
     for (int j = 0; j < m; ++j)
       for (int i = j; i < k; ++i) { const double v = hg[(size_t)i * m + j]; ip[(size_t)ldIP * j + i] = v; ip[(size_t)ldIP * i + j] = v; }
   } else {
@@ -316,8 +341,12 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int m = end[0] - start[0];
-  assert(m == end[1] - start[1]);
+  GCGE_REQUIRE(m == end[1] - start[1], "MatDotMultiVec: equal column counts");
   if (m <= 0) return;
+  GCGE_REQUIRE(vx != vy || end[0] <= start[1] || end[1] <= start[0], "MatDotMultiVec: x and y ranges must not overlap");
+  GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols && start[1] >= 0 && end[1] <= vy->ncols, "MatDotMultiVec: column ranges");
+  GCGE_REQUIRE(vx->nrows == vy->nrows, "MatDotMultiVec: equal row counts");
+  if (A != nullptr) GCGE_REQUIRE(A->nrows == vy->nrows && A->nrows + A->nghost <= vx->nrows_alloc, "MatDotMultiVec: matrix/vector shapes");
   if (A == nullptr) {
     gcge_hip_axpby(vy->nrows, 1.0, vx->d + start[0], vx->ld, 0.0, vy->d + start[1], vy->ld, m, g_stream);
     return;
@@ -327,7 +356,7 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
   int rc = -1;
   if (m >= 16) rc = gcge_hip_pad8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
   if (rc == -1) rc = gcge_hip_csr_spmm(A->nrows, A->d_rowptr, A->d_colidx, A->d_val, dx, vx->ld, dy, vy->ld, m, g_stream);
-  assert(rc == 0); (void)rc;
+  GCGE_REQUIRE(rc == 0, "MatDotMultiVec: kernel launch");
 }
 // app_ccs.c:140-150 — symmetric matrices only
 static void HIP_MatTransDotMultiVec(void* mat, void** x, void** y, int* start, int* end, struct OPS_* ops) {

@@ -1,0 +1,242 @@
+// K5 — block conjugate gradients with the vector work fused on the device.
+//
+// Same recurrence, stopping rules and per-column retirement as the reference's
+// BlockPCG (src/ops_lin_sol.c:140-437) — every right-hand side has its own alpha,
+// beta, rho and leaves the iteration on its own — but instead of ~3 b single-column
+// MultiVecAxpby calls + 2 inner products per iteration an iteration
+// is four launches on whole blocks:
+//     p = r + beta_j p                 (cg_update_p,   3 block streams)
+//     w = A p                          (K1 SpMM)
+//     pTw_j = p_j . w_j                (column dots,   2 streams)
+//     x += alpha_j p ; r -= alpha_j w ; rho_j = r_j . r_j   (cg_update_xr, 6 streams)
+// The b scalars per iteration stay on the host exactly as in the reference (two tiny
+// device->host reads per iteration, which is also where the cross-rank all-reduce of
+// ops_lin_sol.c:317,365 happens); retired columns get alpha = 0 / keep-flag so their
+// x, r, p are bit-for-bit untouched, as if they had been skipped.
+//
+// Installed as ops->MultiLinearSolver by gcge_hip_bpcg_setup(); GCG calls it through
+// the reference's user_defined_multi_linear_solver = 1 hook (ops_eig_sol_gcg.c:584-618).
+#include <hip/hip_runtime.h>
+#include <assert.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "gcge_hip.h"
+#include "gcge_hip_internal.h"
+
+extern "C" double* gcge_hip_partial_ws(size_t len);
+
+namespace gcge {
+
+// p_j = r_j + beta_j p_j for flagged columns (flag 2: p_j = r_j, first iteration; flag 0: keep)
+__global__ __launch_bounds__(256) void cg_update_p(long nrows, const double* __restrict__ r, long ldr,
+    double* __restrict__ p, long ldp, int m, const double* __restrict__ beta, const int* __restrict__ flag) {
+  const long total = nrows * (long)m;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; idx < total; idx += stride) {
+    const long row = idx / m;
+    const int j = (int)(idx - row * m);
+    const int f = flag[j];
+    if (f == 0) continue;
+    const double rv = r[row * ldr + j];
+    double* pp = p + row * ldp + j;
+    *pp = (f == 2) ? rv : fma(beta[j], *pp, rv);
+  }
+}
+
+// x_j += alpha_j p_j ; r_j -= alpha_j w_j ; partial[b*m + j] = sum_rows r_j^2   (flag 0: untouched)
+__global__ __launch_bounds__(256) void cg_update_xr(long nrows, const double* __restrict__ p, long ldp,
+    const double* __restrict__ w, long ldw, double* __restrict__ x, long ldx, double* __restrict__ r, long ldr,
+    int m, const double* __restrict__ alpha, const int* __restrict__ flag, double* __restrict__ partial,
+    long rows_per_block) {
+  __shared__ double red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(nrows, r0 + rows_per_block);
+  for (int c0 = 0; c0 < m; c0 += 64) {
+    const int j = c0 + tx;
+    double s = 0.0;
+    if (j < m) {
+      const int f = flag[j];
+      const double a = alpha[j];
+      for (long row = r0 + ty; row < r1; row += 4) {
+        double rv = r[row * ldr + j];
+        if (f) {
+          const double pv = p[row * ldp + j], wv = w[row * ldw + j];
+          x[row * ldx + j] = fma(a, pv, x[row * ldx + j]);
+          rv = fma(-a, wv, rv);
+          r[row * ldr + j] = rv;
+        }
+        s = fma(rv, rv, s);
+      }
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && j < m)
+      partial[(long)blockIdx.x * m + j] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    __syncthreads();
+  }
+}
+__global__ void cg_reduce(const double* __restrict__ partial, int nblocks, int len, double* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= len) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * len + j];
+  out[j] = s;
+}
+
+}  // namespace gcge
+
+using namespace gcge;
+
+struct HipBpcg {
+  int max_iter; double rate, tol; char tol_type[8];
+  void** mv_ws[3];       // r, p, w (created lazily with the right width)
+  int ws_cols, ws_rows;
+  int niter; double residual;
+  long spmm_calls, spmm_cols;   // statistics for bench.py
+  double* d_coef; int* d_flag; double* h_pin; int cap;
+};
+static HipBpcg g_bpcg = {30, 1e-2, 1e-14, "abs", {nullptr, nullptr, nullptr}, 0, 0, 0, -1.0, 0, 0, nullptr, nullptr, nullptr, 0};
+
+static void reduce_over_ranks(double* v, int n) {
+  GCGE_COMM* c = GCGE_GetComm();
+  if (c != nullptr && n > 0) c->allreduce_sum(v, n, c->ctx);
+}
+
+static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int* end_bx, struct OPS_* ops) {
+  HipBpcg* s = (HipBpcg*)ops->multi_linear_solver_workspace;
+  hipStream_t st = (hipStream_t)gcge_hip_stream();
+  const int nrhs = end_bx[0] - start_bx[0];
+  assert(nrhs == end_bx[1] - start_bx[1]);
+  if (nrhs <= 0) { s->niter = 0; return; }
+  const int n = gcge_hip_mv_nrows(mv_x);
+  if (gcge_hip_mv_nrows(mv_b) != n) { fprintf(stderr, "HIP_BlockPCG: b and x have different row counts\n"); abort(); }
+  if (s->ws_cols < nrhs || s->ws_rows != n) {   // (re)create r, p, w for this problem shape
+    for (int i = 0; i < 3; ++i) {
+      if (s->mv_ws[i]) ops->MultiVecDestroy(&s->mv_ws[i], s->ws_cols, ops);
+      ops->MultiVecCreateByMultiVec(&s->mv_ws[i], nrhs, mv_x, ops);
+    }
+    s->ws_cols = nrhs; s->ws_rows = n;
+  }
+  if (s->cap < nrhs) {
+    if (s->d_coef) { hipFree(s->d_coef); hipFree(s->d_flag); hipHostFree(s->h_pin); }
+    s->cap = nrhs + 64;
+    GCGE_HIP_CHECK(hipMalloc(&s->d_coef, s->cap * sizeof(double)));
+    GCGE_HIP_CHECK(hipMalloc(&s->d_flag, s->cap * sizeof(int)));
+    GCGE_HIP_CHECK(hipHostMalloc(&s->h_pin, 2 * s->cap * sizeof(double)));
+  }
+  long ldb, ldx, ldr, ldp, ldw;
+  double* db = gcge_hip_mv_device_ptr(mv_b, &ldb) + start_bx[0];
+  double* dx = gcge_hip_mv_device_ptr(mv_x, &ldx) + start_bx[1];
+  double* dr = gcge_hip_mv_device_ptr(s->mv_ws[0], &ldr);
+  double* dp = gcge_hip_mv_device_ptr(s->mv_ws[1], &ldp);
+  double* dw = gcge_hip_mv_device_ptr(s->mv_ws[2], &ldw);
+  (void)db; (void)dw;
+
+  std::vector<double> norm_b(nrhs), rho1(nrhs), rho2(nrhs), pTw(nrhs), init_res(nrhs), last_res(nrhs), coef(nrhs);
+  std::vector<int> active(nrhs), flag(nrhs);
+  int st2[2], en2[2];
+  if (0 == strcmp(s->tol_type, "rel")) {
+    st2[0] = start_bx[0]; en2[0] = end_bx[0]; st2[1] = start_bx[0]; en2[1] = end_bx[0];
+    ops->MultiVecInnerProd('D', mv_b, mv_b, 0, st2, en2, norm_b.data(), 1, ops);
+    for (int i = 0; i < nrhs; ++i) norm_b[i] = sqrt(norm_b[i]);
+  } else {
+    for (int i = 0; i < nrhs; ++i) norm_b[i] = 1.0;   // "abs" ("user" scales are a BlockPCG-internal feature)
+  }
+  // r = b - A x ; rho2 = diag(r^T r)
+  st2[0] = start_bx[1]; en2[0] = end_bx[1]; st2[1] = 0; en2[1] = nrhs;
+  ops->MatDotMultiVec(mat, mv_x, s->mv_ws[0], st2, en2, ops);
+  s->spmm_calls++; s->spmm_cols += nrhs;
+  st2[0] = start_bx[0]; en2[0] = end_bx[0]; st2[1] = 0; en2[1] = nrhs;
+  ops->MultiVecAxpby(1.0, mv_b, -1.0, s->mv_ws[0], st2, en2, ops);
+  st2[0] = 0; en2[0] = nrhs; st2[1] = 0; en2[1] = nrhs;
+  ops->MultiVecInnerProd('D', s->mv_ws[0], s->mv_ws[0], 0, st2, en2, rho2.data(), 1, ops);
+  int nact = 0;
+  for (int i = 0; i < nrhs; ++i) {
+    init_res[i] = sqrt(rho2[i]); last_res[i] = init_res[i];
+    active[i] = init_res[i] > s->tol * norm_b[i];
+    nact += active[i];
+  }
+  long nb = ((long)n + 255) / 256; if (nb > 2048) nb = 2048;
+  const long rpb = (((long)n + nb - 1) / nb + 3) / 4 * 4;
+  nb = ((long)n + rpb - 1) / rpb;
+
+  int niter = 0;
+  while (niter < s->max_iter && nact > 0) {
+    // contiguous column window covering every active column
+    int lo = 0, hi = nrhs;
+    while (lo < nrhs && !active[lo]) ++lo;
+    while (hi > lo && !active[hi - 1]) --hi;
+    const int mw = hi - lo;
+    // p = r + beta p
+    for (int j = lo; j < hi; ++j) {
+      flag[j] = active[j] ? (niter == 0 ? 2 : 1) : 0;
+      coef[j] = (active[j] && niter > 0) ? rho2[j] / rho1[j] : 0.0;
+    }
+    GCGE_HIP_CHECK(hipStreamSynchronize(st));
+    memcpy(s->h_pin, coef.data() + lo, mw * sizeof(double));
+    memcpy(s->h_pin + s->cap, flag.data() + lo, mw * sizeof(int));
+    GCGE_HIP_CHECK(hipMemcpyAsync(s->d_coef, s->h_pin, mw * sizeof(double), hipMemcpyHostToDevice, st));
+    GCGE_HIP_CHECK(hipMemcpyAsync(s->d_flag, s->h_pin + s->cap, mw * sizeof(int), hipMemcpyHostToDevice, st));
+    {
+      long total = (long)n * mw, g = (total + 255) / 256; if (g > 8192) g = 8192;
+      hipLaunchKernelGGL(cg_update_p, dim3((unsigned)g), dim3(256), 0, st, (long)n, dr + lo, ldr, dp + lo, ldp, mw,
+                         s->d_coef, s->d_flag);
+    }
+    // w = A p on the window ; pTw
+    st2[0] = lo; en2[0] = hi; st2[1] = lo; en2[1] = hi;
+    ops->MatDotMultiVec(mat, s->mv_ws[1], s->mv_ws[2], st2, en2, ops);
+    s->spmm_calls++; s->spmm_cols += mw;
+    ops->MultiVecLocalInnerProd('D', s->mv_ws[1], s->mv_ws[2], 0, st2, en2, pTw.data() + lo, 1, ops);
+    reduce_over_ranks(pTw.data() + lo, mw);
+    // x += alpha p ; r -= alpha w ; rho2 = diag(r^T r)
+    for (int j = lo; j < hi; ++j) { rho1[j] = rho2[j]; coef[j] = active[j] ? rho2[j] / pTw[j] : 0.0; flag[j] = active[j]; }
+    memcpy(s->h_pin, coef.data() + lo, mw * sizeof(double));
+    memcpy(s->h_pin + s->cap, flag.data() + lo, mw * sizeof(int));
+    GCGE_HIP_CHECK(hipMemcpyAsync(s->d_coef, s->h_pin, mw * sizeof(double), hipMemcpyHostToDevice, st));
+    GCGE_HIP_CHECK(hipMemcpyAsync(s->d_flag, s->h_pin + s->cap, mw * sizeof(int), hipMemcpyHostToDevice, st));
+    double* part = gcge_hip_partial_ws((size_t)nb * mw + mw);
+    hipLaunchKernelGGL(cg_update_xr, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dp + lo, ldp, dw + lo, ldw,
+                       dx + lo, ldx, dr + lo, ldr, mw, s->d_coef, s->d_flag, part, rpb);
+    hipLaunchKernelGGL(cg_reduce, dim3((mw + 127) / 128), dim3(128), 0, st, part, (int)nb, mw, part + (size_t)nb * mw);
+    GCGE_HIP_CHECK(hipMemcpyAsync(s->h_pin, part + (size_t)nb * mw, mw * sizeof(double), hipMemcpyDeviceToHost, st));
+    GCGE_HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<double> newrho(s->h_pin, s->h_pin + mw);
+    reduce_over_ranks(newrho.data(), mw);
+    nact = 0;
+    for (int j = lo; j < hi; ++j) {
+      if (!active[j]) continue;
+      rho2[j] = newrho[j - lo];
+      last_res[j] = sqrt(rho2[j]);
+      active[j] = (last_res[j] > s->rate * init_res[j]) && (last_res[j] > s->tol * norm_b[j]);
+      nact += active[j];
+    }
+    ++niter;
+  }
+  s->niter = niter;
+  s->residual = last_res[0];
+}
+
+// C-ABI: install the fused solver (GCG: pass flag = 1 to the harness / -gcge_user_defined_multi_lin_sol 1)
+extern "C" void gcge_hip_bpcg_setup(struct OPS_* ops, int max_iter, double rate, double tol, const char* tol_type) {
+  g_bpcg.max_iter = max_iter; g_bpcg.rate = rate; g_bpcg.tol = tol;
+  strncpy(g_bpcg.tol_type, tol_type ? tol_type : "abs", 7); g_bpcg.tol_type[7] = 0;
+  ops->multi_linear_solver_workspace = (void*)&g_bpcg;
+  ops->MultiLinearSolver = HIP_BlockPCG;
+}
+extern "C" void gcge_hip_bpcg_stats(long* spmm_calls, long* spmm_cols, int* last_niter) {
+  if (spmm_calls) *spmm_calls = g_bpcg.spmm_calls;
+  if (spmm_cols) *spmm_cols = g_bpcg.spmm_cols;
+  if (last_niter) *last_niter = g_bpcg.niter;
+}
+extern "C" void gcge_hip_bpcg_release(struct OPS_* ops) {
+  for (int i = 0; i < 3; ++i)
+    if (g_bpcg.mv_ws[i]) ops->MultiVecDestroy(&g_bpcg.mv_ws[i], g_bpcg.ws_cols, ops);
+  g_bpcg.ws_cols = 0; g_bpcg.ws_rows = 0;
+}

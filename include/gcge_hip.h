@@ -56,6 +56,15 @@ double *gcge_hip_mv_device_ptr (void **mv, long *ld);
  *    would dominate the run).                                                      */
 void gcge_hip_set_random_mode (int mode, unsigned long long seed);
 
+/* ---- fused block CG behind ops->MultiLinearSolver ------------------------------
+ * Same recurrence/stopping rules as BlockPCG (src/ops_lin_sol.c:140-437) with the vector
+ * work of an iteration fused into four launches.  GCG uses it through the reference's
+ * user_defined_multi_linear_solver = 1 hook (ops_eig_sol_gcg.c:584-618, test_app_ccs.c:109-120):
+ * call this once, then run the harness with flag = 1.                                  */
+void gcge_hip_bpcg_setup (struct OPS_ *ops, int max_iter, double rate, double tol, const char *tol_type);
+void gcge_hip_bpcg_stats (long *spmm_calls, long *spmm_cols, int *last_niter);
+void gcge_hip_bpcg_release (struct OPS_ *ops);
+
 /* ---- raw kernels (what the slots launch; exposed for micro-benchmarks) --------- */
 /* K1  Y[:,0:m) = A X[:,0:m);  x/y point at (row 0, first column); see csrc/hip/spmm*.hip */
 int gcge_hip_csr_spmm  (int nrows, const int *d_rowptr, const int *d_colidx, const double *d_val,

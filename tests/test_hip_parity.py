@@ -133,6 +133,34 @@ def test_gcg_on_hip_matches_reference_run(hip, key):
     assert rel < 1e-10, "Ritz values differ from the reference CPU path: %.3e" % rel
 
 
+def test_fused_block_pcg_matches_reference(hip):
+    """ops->MultiLinearSolver = fused device CG: same iteration count and solution as the reference's BlockPCG."""
+    from slot_cases import Problems
+    P = Problems(hip)
+
+    def setup(max_iter, rate, tol, ws, solve):
+        hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+        hip.g.gcge_hip_bpcg_setup(hip.ops_handle, max_iter, rate, tol, b"abs")
+        solve()
+        it = C.c_int()
+        hip.g.gcge_hip_bpcg_stats(None, None, C.byref(it))
+        return it.value
+    run_bpcg_case(hip, P, setup)
+
+
+@pytest.mark.parametrize("key", ["lap3d_20_nev20", "fe3d_12_nev10", "sio2_12_nev10"])
+def test_gcg_with_fused_cg_matches_reference_run(hip, key):
+    c = GCG[key]
+    hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    hip.g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")     # harness CG parameters
+    hip.set_random_mode(0)
+    ev, res = gcg_on(hip, c["kind"], c["size"], ["-nevConv", c["nev"]], flag=1, K=6, R0=1.5, R1=2.0, seed=12345)
+    assert res.nevConv == c["nevConv"]
+    assert abs(res.numIter - c["numIter"]) <= 2
+    ref = np.array(c["eval"])
+    assert np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref)) < 1e-10
+
+
 def test_gcg_device_rng_closed_form(hip):
     """Start vectors from the device generator (what the n ~ 1e7 runs use): converged Ritz values do
     not depend on the start block — compare with the closed-form spectrum."""
