@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the GCG hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE full eigensolve (GCG to convergence) of BASELINE.json config 2:
+3-D 7-point Laplacian 256^3 (n = 16 777 216, CSR), nev = 50, block = 64, nevMax = 128,
+standard problem, harness-default parameters (test/test_eig_sol_gcg.c:33-49,98-115 of
+the reference), fused device block-CG behind ops->MultiLinearSolver, matrix and all
+blocks of vectors resident in HBM before the timed region starts.
+  value    = converged eigenpairs per second over the K timed solves (whole job)
+  roofline = K1 CSR SpMM: algorithmic bytes (12 nnz + 4(n+1) + 16 n m) of the m = block
+             launches / their average duration from HIP events inside the timed region
+  cpu_baseline = the reference's own CPU path (oracle/_ref, kind "reference") or our C
+             restatement (kind "port") on a bounded sample of the same workload.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--size", type=int, default=256, help="grid points per direction (n = size^3)")
+    ap.add_argument("--nev", type=int, default=50)
+    ap.add_argument("--block", type=int, default=64)
+    ap.add_argument("--nevmax", type=int, default=128)
+    ap.add_argument("--cpu-size", type=int, default=40, help="grid size of the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--orth", default="chol", help="block orthonormalisation scheme for X and W: chol | mgs | bgs")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Reference CPU path on a bounded sample: same solver configuration, smaller grid."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pyoracle as po
+    from gcge_amd.lib import make_problem, run_gcg
+    N = args.cpu_size
+    A, _ = make_problem("lap3d", N)
+    sample = "Lap3D %d^3 (n=%d), nev=%d, block=%d, nevMax=%d, same parameters" % (N, A.nrows, args.nev, args.block, args.nevmax)
+    ref = po.ref_lib()
+    if ref is not None:
+        ev, conv, it, sec = po.ref_gcg(A, None, args.nev, nev_max=args.nevmax, block=args.block)
+        cores = int(os.environ.get("MKL_NUM_THREADS", os.cpu_count() or 1))
+        return {"value": conv / sec, "unit": "eigenpairs/s", "cores": cores, "kind": "reference",
+                "sample": sample + "; stock serial app_ccs build, threaded MKL BLAS/LAPACK; %d GCG its, %.1f s" % (it, sec)}
+    ops = po.make_ops()
+    po.oracle_lib().oracle_set_threads(os.cpu_count() or 1)
+    m = po.ccs_from_csr(A)
+    ev, res = run_gcg(ops, C.byref(m), None, ["-nevConv", args.nev, "-nevMax", args.nevmax, "-blockSize", args.block])
+    return {"value": res.nevConv / res.seconds, "unit": "eigenpairs/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": sample + "; oracle/cpu_backend.c, OpenMP over block columns; %d GCG its, %.1f s" % (res.numIter, res.seconds)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from gcge_amd import HipBackend, make_problem, run_gcg
+    from gcge_amd import dist as gdist
+    hip = HipBackend(device=local_rank)
+    g = hip.g
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    g.gcge_hip_profile_enable.argtypes = [C.c_int]
+    g.gcge_hip_profile_spmm.restype = C.c_long
+    g.gcge_hip_profile_spmm.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+
+    N = args.size
+    n_global = N ** 3
+    # weak scaling: every rank owns a slab of `size^3` rows (planes along k), so n_global grows with the rank count
+    planes = N * world
+    if world > 1:
+        comm = gdist.install(hip, dist, rank, world)
+        A, mat = gdist.lap3d_slab(hip, N, planes, rank, world)
+        n_global = N * N * planes
+    else:
+        A, _ = make_problem("lap3d", N)
+        mat = hip.matrix(A)
+    hip.set_random_mode(1, 20240601)          # device generator: 2e9 rand() calls would dominate at this n
+    g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    solver_args = ["-nevConv", args.nev, "-nevMax", args.nevmax, "-blockSize", args.block,
+                   "-gcge_initX_orth_method", args.orth, "-gcge_compW_orth_method", args.orth]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_gcg(hip.ops_handle, mat, None, solver_args, flag=1)
+    g.gcge_hip_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    conv_total, iters, last = 0, 0, None
+    for _ in range(args.steps):
+        ev, res = run_gcg(hip.ops_handle, mat, None, solver_args, flag=1)
+        conv_total += res.nevConv
+        iters += res.numIter
+        last = (ev, res)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms, by = C.c_double(), C.c_double()
+    cnt = g.gcge_hip_profile_spmm(args.block, C.byref(ms), C.byref(by))
+    ms_all, by_all = C.c_double(), C.c_double()
+    cnt_all = g.gcge_hip_profile_spmm(0, C.byref(ms_all), C.byref(by_all))
+    g.gcge_hip_profile_enable(0)
+
+    if rank == 0:
+        ev, res = last
+        import numpy as np
+        # parity guard inside the bench: converged Ritz values vs the closed-form spectrum
+        c = 2.0 * np.cos(np.arange(1, N + 1) * np.pi / (N + 1))
+        ck = 2.0 * np.cos(np.arange(1, planes + 1) * np.pi / (planes + 1))
+        small = np.sort((6.0 - np.sort(c)[::-1][:24, None, None] - np.sort(c)[::-1][None, :24, None] - np.sort(ck)[::-1][None, None, :48]).ravel())
+        rel = float(np.max(np.abs(ev[:res.nevConv] - small[:res.nevConv]) / small[:res.nevConv]))
+        achieved = (by.value / cnt) / (ms.value / cnt * 1e-3) / 1e9 if cnt else 0.0
+        out = {
+            "metric": "converged eigenpairs/sec (GCG, 3D Laplacian n=%d, block=%d)" % (n_global, args.block),
+            "value": conv_total / elapsed, "unit": "eigenpairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Lap3D %d^3 per GPU (7-pt, CSR, n=%d global), nev=%d, block=%d, nevMax=%d, B=NULL, "
+                                   "tol abs 1e-1 rel 1e-8, fused device block-CG (30 its, rate 1e-2), X/W orthonormalisation '%s', device RNG start block"
+                                   % (N, n_global, args.nev, args.block, args.nevmax, args.orth),
+                       "gcg_iterations": iters, "nev_converged": conv_total,
+                       "max_rel_err_vs_closed_form": rel,
+                       "phase_seconds": {k: getattr(res.timing, k) for k in ("initX", "checkconv", "compP", "compRR", "compRV", "compW", "linsol", "total")}},
+            "roofline": {"bound": "hbm", "kernel": "spmm_pad8 (K1 CSR SpMM, m=%d)" % args.block, "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "launches": int(cnt),
+                         "avg_launch_ms": (ms.value / cnt) if cnt else None,
+                         "alg_bytes_per_launch": (by.value / cnt) if cnt else None,
+                         "spmm_share_of_step": (ms_all.value * 1e-3) / elapsed if elapsed > 0 else None},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,7 +36,28 @@ struct GCGE_HIP_MAT_ {
   int *d_rowptr, *d_colidx; double* d_val;    // CSR, LOCAL column indices (ghosts >= nrows)
   int *d_orp, *d_pcol; double* d_pval;        // pad-8 copy for the 16-byte-lane kernel
   long noct;
+  // halo plan of a row-partitioned matrix (one process per GPU); nghost == 0 on a single rank
+  int nsend; int* d_send_rows;                 // local rows other ranks need, grouped by destination rank
+  double *sendbuf, *recvbuf; int buf_cols;     // exchange buffers (owned by the caller: torch tensors)
+  gcge_halo_exchange_fn exchange; void* exchange_ctx;
 };
+
+__global__ __launch_bounds__(256) void halo_pack(int nsend, const int* __restrict__ rows, const double* __restrict__ x,
+    long ldx, int m, double* __restrict__ buf) {
+  const long total = (long)nsend * m;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long i = idx / m; const int j = (int)(idx - i * m);
+    buf[idx] = x[(long)rows[i] * ldx + j];
+  }
+}
+__global__ __launch_bounds__(256) void halo_unpack(int nghost, const double* __restrict__ buf, int m, double* __restrict__ xg,
+    long ldx) {
+  const long total = (long)nghost * m;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long g = idx / m; const int j = (int)(idx - g * m);
+    xg[g * ldx + j] = buf[idx];
+  }
+}
 
 struct GcgeHipMV {
   double* d;
@@ -89,7 +110,7 @@ extern "C" int gcge_hip_init(int device) {
     fprintf(stderr, "gcge_hip_init: no HIP device visible — the HIP back-end has no CPU fallback\n");
     return -1;
   }
-  GCGE_HIP_CHECK(hipSetDevice(device));
+  if (device >= 0) GCGE_HIP_CHECK(hipSetDevice(device));
   g_stream = nullptr;   // the legacy default stream: ordered with torch's current stream and hipMemcpy
   g_inited = 1;
   return 0;
@@ -103,16 +124,43 @@ extern "C" void gcge_hip_sync(void) { GCGE_HIP_CHECK(hipStreamSynchronize(g_stre
 extern "C" void* gcge_hip_stream(void) { return (void*)g_stream; }
 extern "C" void gcge_hip_set_random_mode(int mode, unsigned long long seed) { g_rand_mode = mode; g_rand_seed = seed; }
 
+// ------------------------------------------------------------------ SpMM launch profiling
+// HIP events around every K1 launch on the launch stream (bench.py: roofline.achieved =
+// algorithmic bytes / average launch duration, measured live inside the timed region).
+struct SpmmEvent { hipEvent_t e0, e1; int m; double bytes; };
+static std::vector<SpmmEvent> g_prof;
+static int g_prof_on = 0;
+extern "C" void gcge_hip_profile_enable(int on) {
+  for (auto& e : g_prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
+  g_prof.clear();
+  g_prof_on = on;
+}
+// sums over the recorded launches with exactly `ncols` columns (0: all); returns the count
+extern "C" long gcge_hip_profile_spmm(int ncols, double* total_ms, double* total_alg_bytes) {
+  long cnt = 0; double ms = 0.0, by = 0.0;
+  GCGE_HIP_CHECK(hipDeviceSynchronize());
+  for (auto& e : g_prof) {
+    if (ncols > 0 && e.m != ncols) continue;
+    float t = 0.f;
+    GCGE_HIP_CHECK(hipEventElapsedTime(&t, e.e0, e.e1));
+    ms += t; by += e.bytes; ++cnt;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_alg_bytes) *total_alg_bytes = by;
+  return cnt;
+}
+
 // ------------------------------------------------------------------ matrix
-extern "C" GCGE_HIP_MAT* gcge_hip_mat_create(int nrows, int nglobal, int row_begin, const int* rowptr,
-                                             const int* colidx, const double* val) {
-  if (gcge_hip_init(0) != 0) return nullptr;
+// rows of one slab with LOCAL column indices in [0, ncols_local); columns >= nrows are halo rows
+extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, int nglobal, int row_begin,
+                                                   const int* rowptr, const int* colidx, const double* val) {
+  if (gcge_hip_init(-1) != 0) return nullptr;
   GCGE_HIP_MAT* A = (GCGE_HIP_MAT*)calloc(1, sizeof(GCGE_HIP_MAT));
   A->nrows = nrows; A->nglobal = nglobal; A->row_begin = row_begin; A->nnz = rowptr[nrows];
-  if (row_begin != 0 || nrows != nglobal) {
-    fprintf(stderr, "gcge_hip_mat_create: row-partitioned matrices need gcge_hip_mat_create_dist\n");
-    free(A); return nullptr;
-  }
+  A->nghost = ncols_local - nrows;
+  GCGE_REQUIRE(A->nghost >= 0, "gcge_hip_mat_create_local: ncols_local >= nrows");
+  for (long k = 0; k < A->nnz; ++k)
+    GCGE_REQUIRE(colidx[k] >= 0 && colidx[k] < ncols_local, "gcge_hip_mat_create_local: column index in range");
   const size_t nnz = (size_t)A->nnz;
   GCGE_HIP_CHECK(hipMalloc(&A->d_rowptr, ((size_t)nrows + 1) * sizeof(int)));
   GCGE_HIP_CHECK(hipMalloc(&A->d_colidx, (nnz ? nnz : 1) * sizeof(int)));
@@ -141,13 +189,35 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create(int nrows, int nglobal, int row_beg
   GCGE_HIP_CHECK(hipMemcpy(A->d_pval, pv.data(), noct * 8 * sizeof(double), hipMemcpyHostToDevice));
   return A;
 }
+extern "C" GCGE_HIP_MAT* gcge_hip_mat_create(int nrows, int nglobal, int row_begin, const int* rowptr,
+                                             const int* colidx, const double* val) {
+  if (row_begin != 0 || nrows != nglobal) {
+    fprintf(stderr, "gcge_hip_mat_create: a row slab needs gcge_dist_localize + gcge_hip_mat_create_local\n");
+    return nullptr;
+  }
+  return gcge_hip_mat_create_local(nrows, nrows, nglobal, 0, rowptr, colidx, val);
+}
 extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_csr(const GCGE_CSR* A) {
-  return gcge_hip_mat_create(A->nrows, A->ncols, A->row_begin, A->rowptr, A->colidx, A->val);
+  if (A->row_begin == 0 && A->nrows == A->ncols) return gcge_hip_mat_create(A->nrows, A->ncols, 0, A->rowptr, A->colidx, A->val);
+  // a localized slab: ncols = nrows + nghost (gcge_dist_localize)
+  return gcge_hip_mat_create_local(A->nrows, A->ncols, -1, A->row_begin, A->rowptr, A->colidx, A->val);
+}
+// halo plan: send_rows = local rows to ship (grouped by destination rank, ascending), buffers hold
+// buf_cols columns of nsend / nghost rows; exchange() moves sendbuf -> the peers' recvbuf.
+extern "C" void gcge_hip_mat_set_halo(GCGE_HIP_MAT* A, int nglobal, int nsend, const int* send_rows, double* sendbuf,
+                                      double* recvbuf, int buf_cols, gcge_halo_exchange_fn fn, void* ctx) {
+  A->nglobal = nglobal; A->nsend = nsend; A->sendbuf = sendbuf; A->recvbuf = recvbuf; A->buf_cols = buf_cols;
+  A->exchange = fn; A->exchange_ctx = ctx;
+  for (int i = 0; i < nsend; ++i) GCGE_REQUIRE(send_rows[i] >= 0 && send_rows[i] < A->nrows, "halo send row in range");
+  if (A->d_send_rows) hipFree(A->d_send_rows);
+  GCGE_HIP_CHECK(hipMalloc(&A->d_send_rows, (nsend ? nsend : 1) * sizeof(int)));
+  GCGE_HIP_CHECK(hipMemcpy(A->d_send_rows, send_rows, nsend * sizeof(int), hipMemcpyHostToDevice));
 }
 extern "C" void gcge_hip_mat_destroy(GCGE_HIP_MAT* A) {
   if (!A) return;
   hipFree(A->d_rowptr); hipFree(A->d_colidx); hipFree(A->d_val);
   hipFree(A->d_orp); hipFree(A->d_pcol); hipFree(A->d_pval);
+  if (A->d_send_rows) hipFree(A->d_send_rows);
   free(A);
 }
 extern "C" int gcge_hip_mat_nrows(const GCGE_HIP_MAT* A) { return A->nrows; }
@@ -354,8 +424,30 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
   const double* dx = vx->d + start[0];
   double* dy = vy->d + start[1];
   int rc = -1;
+  if (A->nghost > 0) {   // row-partitioned: fetch the halo rows of X[:, start[0]:end[0]) from their owners
+    GCGE_REQUIRE(A->exchange != nullptr && A->buf_cols > 0, "MatDotMultiVec: halo plan installed (gcge_hip_mat_set_halo)");
+    for (int c0 = 0; c0 < m; c0 += A->buf_cols) {
+      const int mc = (m - c0 < A->buf_cols) ? m - c0 : A->buf_cols;
+      if (A->nsend > 0) {
+        long tot = (long)A->nsend * mc, g = (tot + 255) / 256; if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(halo_pack, dim3((unsigned)g), dim3(256), 0, g_stream, A->nsend, A->d_send_rows, dx + c0, vx->ld, mc, A->sendbuf);
+      }
+      A->exchange(A->sendbuf, A->recvbuf, mc, A->exchange_ctx);
+      long tot = (long)A->nghost * mc, g = (tot + 255) / 256; if (g > 4096) g = 4096;
+      hipLaunchKernelGGL(halo_unpack, dim3((unsigned)g), dim3(256), 0, g_stream, A->nghost, A->recvbuf, mc,
+                         vx->d + (long)A->nrows * vx->ld + start[0] + c0, vx->ld);
+    }
+  }
+  SpmmEvent ev;
+  if (g_prof_on) {
+    GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
+    ev.m = m;   // algorithmic bytes: values+indices once, row pointers once, X once, Y once
+    ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
+    GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
+  }
   if (m >= 16) rc = gcge_hip_pad8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
   if (rc == -1) rc = gcge_hip_csr_spmm(A->nrows, A->d_rowptr, A->d_colidx, A->d_val, dx, vx->ld, dy, vy->ld, m, g_stream);
+  if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "MatDotMultiVec: kernel launch");
 }
 // app_ccs.c:140-150 — symmetric matrices only
@@ -364,7 +456,7 @@ static void HIP_MatTransDotMultiVec(void* mat, void** x, void** y, int* start, i
 }
 
 extern "C" void OPS_HIP_Set(struct OPS_* ops) {
-  if (gcge_hip_init(0) != 0) {
+  if (gcge_hip_init(-1) != 0) {
     fprintf(stderr, "OPS_HIP_Set: HIP back-end unavailable (no GPU): aborting — there is no CPU fallback\n");
     abort();
   }

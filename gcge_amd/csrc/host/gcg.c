@@ -53,6 +53,8 @@ static void setup_orth(Ctx *c, const char *method, int block, int reorth, double
 {
 	if (0 == strcmp(method, "bgs"))
 		MultiVecOrthSetup_BinaryGramSchmidt(block, reorth, zero_tol, mv_ws, c->scratch, target);
+	else if (0 == strcmp(method, "chol"))
+		MultiVecOrthSetup_CholeskyQR(block, reorth, zero_tol, mv_ws, c->scratch, target);
 	else
 		MultiVecOrthSetup_ModifiedGramSchmidt(block, reorth, zero_tol, mv_ws, c->scratch, target);
 }

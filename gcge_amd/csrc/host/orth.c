@@ -151,6 +151,132 @@ void MultiVecOrthSetup_ModifiedGramSchmidt(int block_size, int max_reorth, doubl
 	ops->MultiVecOrth   = ModifiedGramSchmidt;
 }
 
+/* ---------------------------------------------------------------- Cholesky-QR scheme
+ * Same contract and the same outer structure as the block MGS above (project out the
+ * leading columns, then sweep the new columns block by block, dropping dependent ones and
+ * projecting every finished block out of the rest), but a block is orthonormalised among
+ * itself with BLOCK operations only:  G = X^T B X  ->  G = R^T R  ->  X <- X R^-1, repeated
+ * until G = I to rounding (Cholesky-QR2/3).  In exact arithmetic the result equals the
+ * Gram-Schmidt columns (QR is unique); on a GPU it replaces ~4 single-column passes per
+ * column (orth_self) by 2-3 Gram + panel-update passes per block.
+ * Rank decision: a column whose Cholesky pivot falls below chol_drop^2 of its squared norm
+ * in the first pass is dependent (relative 1e-7, the resolution of a Gram matrix in FP64;
+ * orth_self decides at orth_zero_tol on the absolute norm).  If a factorisation breaks down
+ * later the block falls back to orth_self. */
+static int chol_upper(int m, const double *G, int ldg, double *R, double drop2, int first_pass, int *bad)
+{
+	/* R upper triangular (column-major, ld m) with G = R^T R; returns 0, or 1 with *bad = column */
+	int i, j, k;
+	for (j = 0; j < m; ++j) {
+		double piv = G[(size_t)ldg * j + j];
+		for (i = 0; i < j; ++i) {
+			double v = G[(size_t)ldg * j + i];
+			for (k = 0; k < i; ++k) v -= R[(size_t)m * i + k] * R[(size_t)m * j + k];
+			v /= R[(size_t)m * i + i];
+			R[(size_t)m * j + i] = v;
+			piv -= v * v;
+		}
+		if (!(piv > (first_pass ? drop2 * G[(size_t)ldg * j + j] : 0.0)) || !(G[(size_t)ldg * j + j] > 0.0)) { *bad = j; return 1; }
+		R[(size_t)m * j + j] = sqrt(piv);
+		for (i = j + 1; i < m; ++i) R[(size_t)m * j + i] = 0.0;
+	}
+	return 0;
+}
+static void invert_upper(int m, const double *R, double *Ri)
+{
+	int i, j, k;
+	for (j = 0; j < m; ++j) {
+		for (i = 0; i < m; ++i) Ri[(size_t)m * j + i] = 0.0;
+		Ri[(size_t)m * j + j] = 1.0 / R[(size_t)m * j + j];
+		for (i = j - 1; i >= 0; --i) {
+			double v = 0.0;
+			for (k = i + 1; k <= j; ++k) v += R[(size_t)m * k + i] * Ri[(size_t)m * j + k];
+			Ri[(size_t)m * j + i] = -v / R[(size_t)m * i + i];
+		}
+	}
+}
+/* orthonormalise x[:, b0:*b1) among themselves; dependent columns are replaced by the block's
+ * last column and *b1 shrinks.  ws: 3 m^2 doubles. */
+static void orth_self_chol(void **x, int b0, int *b1, void *B, int max_reorth, double zero_tol,
+		double reorth_tol, void **mv_ws, double *ws, struct OPS_ *ops)
+{
+	const double drop = 1e-7;
+	int pass = 0, start[2], end[2];
+	while (*b1 > b0 && pass < 4) {
+		int m = *b1 - b0, bad = -1, i, j; double dev = 0.0;
+		double *G = ws, *R = G + (size_t)m * m, *Ri = R + (size_t)m * m;
+		start[0] = b0; end[0] = *b1; start[1] = b0; end[1] = *b1;
+		ops->MultiVecQtAP('S', 'S', x, B, x, 0, start, end, G, m, mv_ws, ops);
+		for (j = 0; j < m; ++j) for (i = 0; i < m; ++i) {
+			double d = fabs(G[(size_t)m * j + i] - (i == j ? 1.0 : 0.0));
+			if (d > dev) dev = d;
+		}
+		if (dev < reorth_tol) return;                       /* already B-orthonormal */
+		if (chol_upper(m, G, m, R, drop * drop, pass == 0, &bad)) {
+			if (pass == 0) {                                 /* dependent column: pull the last one in, retry */
+				ops->Printf("chol: column %d dependent (pivot/norm^2 below %.1e)\n", b0 + bad, drop * drop);
+				if (b0 + bad < *b1 - 1) {
+					start[0] = *b1 - 1; end[0] = *b1; start[1] = b0 + bad; end[1] = b0 + bad + 1;
+					ops->MultiVecAxpby(1.0, x, 0.0, x, start, end, ops);
+				}
+				--(*b1);
+				continue;
+			}
+			/* breakdown after a successful pass: finish with the column-wise scheme */
+			orth_self(x, b0, b1, B, max_reorth, zero_tol, reorth_tol, mv_ws, ws, ops);
+			return;
+		}
+		invert_upper(m, R, Ri);
+		start[0] = b0; end[0] = *b1; start[1] = 0; end[1] = m;
+		ops->MultiVecLinearComb(x, mv_ws, 0, start, end, Ri, m, NULL, 0, ops);      /* ws = X R^-1 */
+		start[0] = 0; end[0] = m; start[1] = b0; end[1] = *b1;
+		ops->MultiVecAxpby(1.0, mv_ws, 0.0, x, start, end, ops);
+		++pass;
+		if (dev < 1e-8) return;   /* deviation after this pass is O(dev^2 + eps) */
+	}
+}
+
+static void CholeskyQR(void **x, int start_x, int *end_x, void *B, struct OPS_ *ops)
+{
+	ModifiedGramSchmidtOrth *p = (ModifiedGramSchmidtOrth*)ops->orth_workspace;
+	double *coef = p->dbl_ws;
+	int block, b0, b1, start[2], end[2];
+	if (*end_x <= start_x) return;
+	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, p->mv_ws, coef, ops);
+	b0 = start_x;
+	block = p->block_size;
+	if (block <= 0) block = *end_x - b0;
+	if (block > *end_x - b0) block = *end_x - b0;
+	while (block > 0) {
+		int dropped, refill;
+		b1 = b0 + block;
+		orth_self_chol(x, b0, &b1, B, p->max_reorth, p->orth_zero_tol, p->reorth_tol, p->mv_ws, coef, ops);
+		dropped = block - (b1 - b0);
+		refill  = *end_x - (b0 + block);
+		if (refill > dropped) refill = dropped;
+		if (refill > 0) {
+			start[0] = *end_x - refill; end[0] = *end_x; start[1] = b1; end[1] = b1 + refill;
+			ops->MultiVecAxpby(1.0, x, 0.0, x, start, end, ops);
+		}
+		*end_x -= dropped;
+		if (b1 < *end_x && b0 < b1)
+			project_block_from_rest(x, b0, b1, *end_x, B, p->max_reorth, p->reorth_tol, p->mv_ws, coef, ops);
+		b0 = b1;
+		if (block > *end_x - b0) block = *end_x - b0;
+	}
+}
+
+void MultiVecOrthSetup_CholeskyQR(int block_size, int max_reorth, double orth_zero_tol,
+		void **mv_ws, double *dbl_ws, struct OPS_ *ops)
+{
+	static ModifiedGramSchmidtOrth cqr;
+	cqr.block_size = block_size; cqr.max_reorth = max_reorth;
+	cqr.orth_zero_tol = orth_zero_tol; cqr.reorth_tol = 50 * DBL_EPSILON;
+	cqr.mv_ws = mv_ws; cqr.dbl_ws = dbl_ws;
+	ops->orth_workspace = (void*)&cqr;
+	ops->MultiVecOrth   = CholeskyQR;
+}
+
 /* ---------------------------------------------------------------- binary scheme */
 /* Leaf: G = X^T B X, G = U diag(w) U^T, X <- X U diag(w^-1/2) for w above the threshold
  * (a threshold on the SQUARED norm, unlike orth_self).  ws: N*N + 3N doubles. */

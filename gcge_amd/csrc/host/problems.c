@@ -52,21 +52,21 @@ static int cmp_stencil(const void *a, const void *b)
 }
 
 /* st must be sorted by (dk,dj,di) so that column indices ascend inside a row */
-static int stencil_rows(int N, const StencilPt *st, int npt, double scale,
+static int stencil_box(int Nx, int Ny, int Nz, const StencilPt *st, int npt, double scale,
 		int64_t row_begin, int64_t row_end, GCGE_CSR *A)
 {
-	int64_t n = (int64_t)N * N * N, r; int s;
+	int64_t n = (int64_t)Nx * Ny * Nz, r; int s;
 	if (row_begin < 0) row_begin = 0;
 	if (row_end > n || row_end < 0) row_end = n;
 	if (n > 2147483647LL) return -2;
 	if (csr_alloc(A, row_end - row_begin, n, row_begin, (row_end - row_begin) * npt)) return -1;
 	int64_t p = 0;
 	for (r = row_begin; r < row_end; ++r) {
-		int i = (int)(r % N), j = (int)((r / N) % N), k = (int)(r / ((int64_t)N * N));
+		int i = (int)(r % Nx), j = (int)((r / Nx) % Ny), k = (int)(r / ((int64_t)Nx * Ny));
 		for (s = 0; s < npt; ++s) {
 			int ii = i + st[s].di, jj = j + st[s].dj, kk = k + st[s].dk;
-			if (ii < 0 || ii >= N || jj < 0 || jj >= N || kk < 0 || kk >= N) continue;
-			A->colidx[p] = (int)(ii + (int64_t)N * (jj + (int64_t)N * kk));
+			if (ii < 0 || ii >= Nx || jj < 0 || jj >= Ny || kk < 0 || kk >= Nz) continue;
+			A->colidx[p] = (int)(ii + (int64_t)Nx * (jj + (int64_t)Ny * kk));
 			A->val[p]    = scale * st[s].w;
 			++p;
 		}
@@ -77,13 +77,24 @@ static int stencil_rows(int N, const StencilPt *st, int npt, double scale,
 	return 0;
 }
 
-int gcge_problem_lap3d(int N, int64_t row_begin, int64_t row_end, GCGE_CSR *A)
+static int stencil_rows(int N, const StencilPt *st, int npt, double scale,
+		int64_t row_begin, int64_t row_end, GCGE_CSR *A)
+{
+	return stencil_box(N, N, N, st, npt, scale, row_begin, row_end, A);
+}
+
+int gcge_problem_lap3d_box(int Nx, int Ny, int Nz, int64_t row_begin, int64_t row_end, GCGE_CSR *A)
 {
 	StencilPt st[7] = {
 		{0,0,-1,-1.0},{0,-1,0,-1.0},{-1,0,0,-1.0},{0,0,0,6.0},
 		{1,0,0,-1.0},{0,1,0,-1.0},{0,0,1,-1.0}};
 	qsort(st, 7, sizeof(StencilPt), cmp_stencil);
-	return stencil_rows(N, st, 7, 1.0, row_begin, row_end, A);
+	return stencil_box(Nx, Ny, Nz, st, 7, 1.0, row_begin, row_end, A);
+}
+
+int gcge_problem_lap3d(int N, int64_t row_begin, int64_t row_end, GCGE_CSR *A)
+{
+	return gcge_problem_lap3d_box(N, N, N, row_begin, row_end, A);
 }
 
 int gcge_problem_fe1d(int n, GCGE_CSR *A, GCGE_CSR *B)
@@ -241,5 +252,48 @@ int gcge_problem_sio2_like(int G, int K, double R0, double R1, uint64_t seed,
 	free(sup_ptr); free(sup_col); free(sup_u);
 	if (p < 0) return -2;
 	A->nnz = p;
+	return 0;
+}
+
+/* ---- row-partition helpers ---------------------------------------------------------- */
+static int cmp_int(const void *a, const void *b)
+{
+	int x = *(const int*)a, y = *(const int*)b;
+	return x < y ? -1 : (x > y);
+}
+void gcge_free_ints(int *p) { free(p); }
+
+int gcge_dist_ghosts(const GCGE_CSR *A, int **ghosts_out, int *nghost_out)
+{
+	int64_t k, cnt = 0, cap = 1024, lo = A->row_begin, hi = (int64_t)A->row_begin + A->nrows;
+	int *g = (int*)malloc((size_t)cap * sizeof(int)), last = -1, m = 0, i;
+	if (g == NULL) return -1;
+	for (k = 0; k < A->nnz; ++k) {
+		int c = A->colidx[k];
+		if (c >= lo && c < hi) continue;
+		if (c == last) continue;               /* cheap filter for runs of equal columns */
+		if (cnt == cap) { cap *= 2; g = (int*)realloc(g, (size_t)cap * sizeof(int)); if (!g) return -1; }
+		g[cnt++] = c; last = c;
+	}
+	qsort(g, (size_t)cnt, sizeof(int), cmp_int);
+	for (i = 0; i < cnt; ++i) if (m == 0 || g[m - 1] != g[i]) g[m++] = g[i];
+	*ghosts_out = g; *nghost_out = m;
+	return 0;
+}
+
+int gcge_dist_localize(GCGE_CSR *A, const int *ghosts, int nghost)
+{
+	int64_t k, lo = A->row_begin, hi = (int64_t)A->row_begin + A->nrows;
+	for (k = 0; k < A->nnz; ++k) {
+		int c = A->colidx[k];
+		if (c >= lo && c < hi) { A->colidx[k] = (int)(c - lo); continue; }
+		{   /* binary search in the ghost list */
+			int a = 0, b = nghost - 1, pos = -1;
+			while (a <= b) { int mid = (a + b) / 2; if (ghosts[mid] == c) { pos = mid; break; } if (ghosts[mid] < c) a = mid + 1; else b = mid - 1; }
+			if (pos < 0) return -1;
+			A->colidx[k] = A->nrows + pos;
+		}
+	}
+	A->ncols = A->nrows + nghost;
 	return 0;
 }

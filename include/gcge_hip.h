@@ -38,6 +38,16 @@ typedef struct GCGE_HIP_MAT_ GCGE_HIP_MAT;
 GCGE_HIP_MAT *gcge_hip_mat_create (int nrows, int nglobal, int row_begin,
 		const int *rowptr, const int *colidx, const double *val);
 GCGE_HIP_MAT *gcge_hip_mat_create_csr (const GCGE_CSR *A);
+/* Row-partitioned use (one process per GPU): localize the slab with gcge_dist_localize
+ * (include/gcge_problems.h), create it with ncols_local = nrows + nghost, then install the halo
+ * plan.  exchange(sendbuf, recvbuf, ncols, ctx) must deliver, for every peer, rows
+ * [send_off[p], +send_cnt[p]) x ncols of sendbuf into the peer's recvbuf at its ghost offset for
+ * this rank (both buffers row-major with ncols columns; device memory for this back-end).    */
+typedef void (*gcge_halo_exchange_fn) (double *sendbuf, double *recvbuf, int ncols, void *ctx);
+GCGE_HIP_MAT *gcge_hip_mat_create_local (int nrows, int ncols_local, int nglobal, int row_begin,
+		const int *rowptr, const int *colidx, const double *val);
+void gcge_hip_mat_set_halo (GCGE_HIP_MAT *A, int nglobal, int nsend, const int *send_rows,
+		double *sendbuf, double *recvbuf, int buf_cols, gcge_halo_exchange_fn fn, void *ctx);
 void gcge_hip_mat_destroy (GCGE_HIP_MAT *A);
 int  gcge_hip_mat_nrows (const GCGE_HIP_MAT *A);
 long gcge_hip_mat_nnz (const GCGE_HIP_MAT *A);
@@ -64,6 +74,10 @@ void gcge_hip_set_random_mode (int mode, unsigned long long seed);
 void gcge_hip_bpcg_setup (struct OPS_ *ops, int max_iter, double rate, double tol, const char *tol_type);
 void gcge_hip_bpcg_stats (long *spmm_calls, long *spmm_cols, int *last_niter);
 void gcge_hip_bpcg_release (struct OPS_ *ops);
+
+/* ---- live measurement of the K1 launches (HIP events on the launch stream) ---------- */
+void gcge_hip_profile_enable (int on);        /* also clears what was recorded            */
+long gcge_hip_profile_spmm (int ncols, double *total_ms, double *total_alg_bytes);
 
 /* ---- raw kernels (what the slots launch; exposed for micro-benchmarks) --------- */
 /* K1  Y[:,0:m) = A X[:,0:m);  x/y point at (row 0, first column); see csrc/hip/spmm*.hip */

@@ -33,6 +33,8 @@ void gcge_csr_free(GCGE_CSR *A);
  * diagonal 6, six -1 neighbours, Dirichlet truncation.  B = NULL problem.
  * eigenvalues 6 - 2cos(i pi/(N+1)) - 2cos(j pi/(N+1)) - 2cos(k pi/(N+1)).   */
 int gcge_problem_lap3d(int N, int64_t row_begin, int64_t row_end, GCGE_CSR *A);
+/* same stencil on an Nx x Ny x Nz box (weak scaling: Nz grows with the number of slabs) */
+int gcge_problem_lap3d_box(int Nx, int Ny, int Nz, int64_t row_begin, int64_t row_end, GCGE_CSR *A);
 
 /* The reference's stock pair (test/test_app_ccs.c:142-184): 1-D linear FE,
  * A = tridiag(-1,2,-1)/h, B = h I, h = 1/(n+1).                             */
@@ -50,6 +52,16 @@ int gcge_problem_fe3d(int M, int64_t row_begin, int64_t row_end, GCGE_CSR *A, GC
  * length by more than an order of magnitude (load-imbalance stress).        */
 int gcge_problem_sio2_like(int G, int K, double R0, double R1, uint64_t seed,
 		int64_t row_begin, int64_t row_end, GCGE_CSR *A);
+
+/* ---- row partition helpers (one process per GPU) ---------------------
+ * A slab holds rows [row_begin,row_begin+nrows) with GLOBAL column indices.
+ * gcge_dist_ghosts   lists (ascending, unique) the global columns the slab references outside
+ *                    its own row range — the halo rows of X an SpMM needs from other ranks;
+ * gcge_dist_localize rewrites colidx in place to slab-local numbering: owned column g ->
+ *                    g-row_begin, ghost ghosts[i] -> nrows+i (ncols becomes nrows+nghost).  */
+int gcge_dist_ghosts (const GCGE_CSR *A, int **ghosts_out, int *nghost_out);
+int gcge_dist_localize (GCGE_CSR *A, const int *ghosts, int nghost);
+void gcge_free_ints (int *p);
 
 /* Reproducible U[0,1) stream shared by C and the python tests:
  * splitmix64(seed + index) >> 11 scaled by 2^-53.                           */

@@ -36,6 +36,10 @@ void MultiVecOrthSetup_ModifiedGramSchmidt (int block_size, int max_reorth,
 		double orth_zero_tol, void **mv_ws, double *dbl_ws, struct OPS_ *ops);
 void MultiVecOrthSetup_BinaryGramSchmidt (int block_size, int max_reorth,
 		double orth_zero_tol, void **mv_ws, double *dbl_ws, struct OPS_ *ops);
+/* block Cholesky-QR variant of the MGS scheme (method name "chol"): the same contract with
+ * BLOCK operations only — what a GPU back-end wants (block_size <= columns of mv_ws).      */
+void MultiVecOrthSetup_CholeskyQR (int block_size, int max_reorth,
+		double orth_zero_tol, void **mv_ws, double *dbl_ws, struct OPS_ *ops);
 
 /* ---- block conjugate gradients (sets ops->MultiLinearSolver) --------------- */
 typedef struct BlockPCGSolver_ {

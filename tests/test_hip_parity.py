@@ -161,6 +161,19 @@ def test_gcg_with_fused_cg_matches_reference_run(hip, key):
     assert np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref)) < 1e-10
 
 
+def test_gcg_cholesky_qr_orth_matches_reference_run(hip):
+    """Block Cholesky-QR orthonormalisation (what bench.py uses) + fused CG: same Ritz values."""
+    c = GCG["fe3d_20_nev20"]
+    hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    hip.g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    hip.set_random_mode(0)
+    ev, res = gcg_on(hip, c["kind"], c["size"], ["-nevConv", c["nev"], "-gcge_initX_orth_method", "chol",
+                                                 "-gcge_compW_orth_method", "chol"], flag=1)
+    assert res.nevConv == c["nevConv"] and abs(res.numIter - c["numIter"]) <= 2
+    ref = np.array(c["eval"])
+    assert np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref)) < 1e-10
+
+
 def test_gcg_device_rng_closed_form(hip):
     """Start vectors from the device generator (what the n ~ 1e7 runs use): converged Ritz values do
     not depend on the start block — compare with the closed-form spectrum."""

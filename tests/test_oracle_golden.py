@@ -39,3 +39,15 @@ def test_lap3d_closed_form(oracle):
     exact = lap3d_exact(14, res.nevConv)
     assert res.nevConv >= 12
     assert np.max(np.abs(ev[:res.nevConv] - exact) / exact) < 1e-10
+
+
+@pytest.mark.parametrize("key", ["lap3d_20_nev20", "fe3d_20_nev20", "sio2_12_nev10"])
+def test_cholesky_qr_orth_scheme(oracle, key):
+    """Block Cholesky-QR orthonormalisation (method 'chol', the GPU-friendly variant of the MGS scheme)
+    reaches the reference's Ritz values with the same number of locked pairs."""
+    c = GCG[key]
+    ev, res = gcg_on(oracle, c["kind"], c["size"], ["-nevConv", c["nev"], "-gcge_initX_orth_method", "chol",
+                                                    "-gcge_compW_orth_method", "chol"], K=6, R0=1.5, R1=2.0, seed=12345)
+    assert res.nevConv == c["nevConv"] and abs(res.numIter - c["numIter"]) <= 2
+    ref = np.array(c["eval"])
+    assert np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref)) < 1e-10
