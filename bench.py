@@ -92,7 +92,7 @@ def main():
     planes = N * world
     if world > 1:
         comm = gdist.install(hip, dist, rank, world)
-        A, mat = gdist.lap3d_slab(hip, N, planes, rank, world)
+        A, mat = gdist.lap3d_slab(hip, N, planes, rank, world, comm)
         n_global = N * N * planes
     else:
         A, _ = make_problem("lap3d", N)

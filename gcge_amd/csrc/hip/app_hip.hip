@@ -20,6 +20,8 @@
 #include "gcge_hip_internal.h"
 
 extern "C" {
+int gcge_hip_pad8_spmm_dot(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval, const double* d_x,
+                           long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream);
 int gcge_hip_colscale(int nrows, double* d_y, long ldy, int m, const double* d_s, void* stream);
 int gcge_hip_fill_uniform(int nrows, long row_begin, long nglobal, double* d_y, long ldy, int c0, int m,
                           unsigned long long seed, void* stream);
@@ -450,6 +452,43 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "MatDotMultiVec: kernel launch");
 }
+// Fused  y = A x  and  dots[j] = sum_r x[r,j] y[r,j]  (the p.w of a CG step) — LOCAL part only; the
+// caller reduces over ranks.  Falls back to SpMM + column dots when the fast kernel's alignment
+// contract is not met.  Internal entry point of the fused block CG (block_pcg.hip).
+extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots,
+                                     struct OPS_* ops) {
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
+  GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
+  const int m = end[0] - start[0];
+  if (m <= 0) return;
+  const bool fast = A != nullptr && m >= 16 && m <= 128 && (m % 2 == 0) && (vx->ld % 2 == 0) && (vy->ld % 2 == 0) &&
+                    (((uintptr_t)(vx->d + start[0]) & 15) == 0) && (((uintptr_t)(vy->d + start[1]) & 15) == 0) &&
+                    A->nghost == 0;
+  if (!fast) {
+    HIP_MatDotMultiVec(mat, x, y, start, end, ops);
+    ops->MultiVecLocalInnerProd('D', x, y, 0, start, end, host_dots, 1, ops);
+    return;
+  }
+  GCGE_REQUIRE(vx != vy && vx->nrows == vy->nrows && A->nrows == vy->nrows, "spmm_dot: shapes");
+  GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols && start[1] >= 0 && end[1] <= vy->ncols, "spmm_dot: column ranges");
+  double* dd = stage_d(m);
+  SpmmEvent ev;
+  if (g_prof_on) {   // the fused kernel IS the K1 launch of a CG step (same algorithmic bytes: the dots add no HBM traffic)
+    GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
+    ev.m = m;
+    ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
+    GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
+  }
+  int rc = gcge_hip_pad8_spmm_dot(A->nrows, A->d_orp, A->d_pcol, A->d_pval, vx->d + start[0], vx->ld,
+                                  vy->d + start[1], vy->ld, m, dd, g_stream);
+  if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
+  GCGE_REQUIRE(rc == 0, "spmm_dot: kernel launch");
+  double* hd = stage_h(m);
+  GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+  memcpy(host_dots, hd, m * sizeof(double));
+}
+
 // app_ccs.c:140-150 — symmetric matrices only
 static void HIP_MatTransDotMultiVec(void* mat, void** x, void** y, int* start, int* end, struct OPS_* ops) {
   HIP_MatDotMultiVec(mat, x, y, start, end, ops);

@@ -5,10 +5,11 @@
 // beta, rho and leaves the iteration on its own — but instead of ~3 b single-column
 // MultiVecAxpby calls + 2 inner products per iteration an iteration
 // is four launches on whole blocks:
-//     p = r + beta_j p                 (cg_update_p,   3 block streams)
-//     w = A p                          (K1 SpMM)
-//     pTw_j = p_j . w_j                (column dots,   2 streams)
-//     x += alpha_j p ; r -= alpha_j w ; rho_j = r_j . r_j   (cg_update_xr, 6 streams)
+//     x += alpha'_j p ; p = r + beta_j p       (cg_update_xp: the x update of the PREVIOUS step is
+//                                               deferred into this pass: 3 reads + 2 writes)
+//     w = A p ; pTw_j = p_j . w_j              (K1 SpMM with the column dots fused in its epilogue)
+//     r -= alpha_j w ; rho_j = r_j . r_j       (cg_update_r: 2 reads + 1 write)
+// i.e. 8 block streams + the SpMM instead of the 13 + SpMM of the unfused recurrence.
 // The b scalars per iteration stay on the host exactly as in the reference (two tiny
 // device->host reads per iteration, which is also where the cross-rank all-reduce of
 // ops_lin_sol.c:317,365 happens); retired columns get alpha = 0 / keep-flag so their
@@ -29,12 +30,16 @@
 #include "gcge_hip_internal.h"
 
 extern "C" double* gcge_hip_partial_ws(size_t len);
+extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, int len, double* d_out, void* stream);
+extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots, struct OPS_* ops);
 
 namespace gcge {
 
-// p_j = r_j + beta_j p_j for flagged columns (flag 2: p_j = r_j, first iteration; flag 0: keep)
-__global__ __launch_bounds__(256) void cg_update_p(long nrows, const double* __restrict__ r, long ldr,
-    double* __restrict__ p, long ldp, int m, const double* __restrict__ beta, const int* __restrict__ flag) {
+// x_j += aprev_j p_j (flag bit 2: deferred x update of the previous step), then
+// p_j = r_j (flag bits 0-1 == 2, first step) or p_j = r_j + beta_j p_j (== 1); 0: p untouched
+__global__ __launch_bounds__(256) void cg_update_xp(long nrows, const double* __restrict__ r, long ldr,
+    double* __restrict__ p, long ldp, double* __restrict__ x, long ldx, int m, const double* __restrict__ beta,
+    const double* __restrict__ aprev, const int* __restrict__ flag) {
   const long total = nrows * (long)m;
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -43,17 +48,19 @@ __global__ __launch_bounds__(256) void cg_update_p(long nrows, const double* __r
     const int j = (int)(idx - row * m);
     const int f = flag[j];
     if (f == 0) continue;
-    const double rv = r[row * ldr + j];
     double* pp = p + row * ldp + j;
-    *pp = (f == 2) ? rv : fma(beta[j], *pp, rv);
+    double pv = 0.0;
+    if ((f & 4) || (f & 3) == 1) pv = *pp;
+    if (f & 4) { double* px = x + row * ldx + j; *px = fma(aprev[j], pv, *px); }
+    if ((f & 3) == 2) *pp = r[row * ldr + j];
+    else if ((f & 3) == 1) *pp = fma(beta[j], pv, r[row * ldr + j]);
   }
 }
 
-// x_j += alpha_j p_j ; r_j -= alpha_j w_j ; partial[b*m + j] = sum_rows r_j^2   (flag 0: untouched)
-__global__ __launch_bounds__(256) void cg_update_xr(long nrows, const double* __restrict__ p, long ldp,
-    const double* __restrict__ w, long ldw, double* __restrict__ x, long ldx, double* __restrict__ r, long ldr,
-    int m, const double* __restrict__ alpha, const int* __restrict__ flag, double* __restrict__ partial,
-    long rows_per_block) {
+// r_j -= alpha_j w_j (flagged columns) ; partial[b*m + j] = sum_rows r_j^2
+__global__ __launch_bounds__(256) void cg_update_r(long nrows, const double* __restrict__ w, long ldw,
+    double* __restrict__ r, long ldr, int m, const double* __restrict__ alpha, const int* __restrict__ flag,
+    double* __restrict__ partial, long rows_per_block) {
   __shared__ double red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const long r0 = (long)blockIdx.x * rows_per_block;
@@ -61,17 +68,11 @@ __global__ __launch_bounds__(256) void cg_update_xr(long nrows, const double* __
   for (int c0 = 0; c0 < m; c0 += 64) {
     const int j = c0 + tx;
     double s = 0.0;
-    if (j < m) {
-      const int f = flag[j];
+    if (j < m && flag[j]) {
       const double a = alpha[j];
       for (long row = r0 + ty; row < r1; row += 4) {
-        double rv = r[row * ldr + j];
-        if (f) {
-          const double pv = p[row * ldp + j], wv = w[row * ldw + j];
-          x[row * ldx + j] = fma(a, pv, x[row * ldx + j]);
-          rv = fma(-a, wv, rv);
-          r[row * ldr + j] = rv;
-        }
+        const double rv = fma(-a, w[row * ldw + j], r[row * ldr + j]);
+        r[row * ldr + j] = rv;
         s = fma(rv, rv, s);
       }
     }
@@ -82,14 +83,6 @@ __global__ __launch_bounds__(256) void cg_update_xr(long nrows, const double* __
     __syncthreads();
   }
 }
-__global__ void cg_reduce(const double* __restrict__ partial, int nblocks, int len, double* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= len) return;
-  double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * len + j];
-  out[j] = s;
-}
-
 }  // namespace gcge
 
 using namespace gcge;
@@ -127,9 +120,9 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
   if (s->cap < nrhs) {
     if (s->d_coef) { hipFree(s->d_coef); hipFree(s->d_flag); hipHostFree(s->h_pin); }
     s->cap = nrhs + 64;
-    GCGE_HIP_CHECK(hipMalloc(&s->d_coef, s->cap * sizeof(double)));
+    GCGE_HIP_CHECK(hipMalloc(&s->d_coef, 2 * s->cap * sizeof(double)));
     GCGE_HIP_CHECK(hipMalloc(&s->d_flag, s->cap * sizeof(int)));
-    GCGE_HIP_CHECK(hipHostMalloc(&s->h_pin, 2 * s->cap * sizeof(double)));
+    GCGE_HIP_CHECK(hipHostMalloc(&s->h_pin, 3 * s->cap * sizeof(double)));
   }
   long ldb, ldx, ldr, ldp, ldw;
   double* db = gcge_hip_mv_device_ptr(mv_b, &ldb) + start_bx[0];
@@ -167,57 +160,82 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
   const long rpb = (((long)n + nb - 1) / nb + 3) / 4 * 4;
   nb = ((long)n + rpb - 1) / rpb;
 
+  // d_coef holds [beta | aprev/alpha] (2*cap doubles), d_flag the per-column flags
+  std::vector<double> aprev(nrhs, 0.0);
+  std::vector<int> pend(nrhs, 0);           // x update of the last step still to be applied
+  auto upload = [&](int lo, int mw, const double* c0v, const double* c1v, const int* fl) {
+    GCGE_HIP_CHECK(hipStreamSynchronize(st));
+    memcpy(s->h_pin, c0v + lo, mw * sizeof(double));
+    memcpy(s->h_pin + s->cap, c1v + lo, mw * sizeof(double));
+    memcpy(s->h_pin + 2 * s->cap, fl + lo, mw * sizeof(int));
+    GCGE_HIP_CHECK(hipMemcpyAsync(s->d_coef, s->h_pin, mw * sizeof(double), hipMemcpyHostToDevice, st));
+    GCGE_HIP_CHECK(hipMemcpyAsync(s->d_coef + s->cap, s->h_pin + s->cap, mw * sizeof(double), hipMemcpyHostToDevice, st));
+    GCGE_HIP_CHECK(hipMemcpyAsync(s->d_flag, s->h_pin + 2 * s->cap, mw * sizeof(int), hipMemcpyHostToDevice, st));
+  };
   int niter = 0;
   while (niter < s->max_iter && nact > 0) {
-    // contiguous column window covering every active column
+    // contiguous column window covering every active column and every pending x update
     int lo = 0, hi = nrhs;
-    while (lo < nrhs && !active[lo]) ++lo;
-    while (hi > lo && !active[hi - 1]) --hi;
-    const int mw = hi - lo;
-    // p = r + beta p
+    while (lo < nrhs && !active[lo] && !pend[lo]) ++lo;
+    while (hi > lo && !active[hi - 1] && !pend[hi - 1]) --hi;
+    int mw = hi - lo;
+    // x += alpha' p (deferred) ; p = r + beta p
     for (int j = lo; j < hi; ++j) {
-      flag[j] = active[j] ? (niter == 0 ? 2 : 1) : 0;
+      flag[j] = (active[j] ? (niter == 0 ? 2 : 1) : 0) | (pend[j] ? 4 : 0);
       coef[j] = (active[j] && niter > 0) ? rho2[j] / rho1[j] : 0.0;
     }
-    GCGE_HIP_CHECK(hipStreamSynchronize(st));
-    memcpy(s->h_pin, coef.data() + lo, mw * sizeof(double));
-    memcpy(s->h_pin + s->cap, flag.data() + lo, mw * sizeof(int));
-    GCGE_HIP_CHECK(hipMemcpyAsync(s->d_coef, s->h_pin, mw * sizeof(double), hipMemcpyHostToDevice, st));
-    GCGE_HIP_CHECK(hipMemcpyAsync(s->d_flag, s->h_pin + s->cap, mw * sizeof(int), hipMemcpyHostToDevice, st));
+    upload(lo, mw, coef.data(), aprev.data(), flag.data());
     {
       long total = (long)n * mw, g = (total + 255) / 256; if (g > 8192) g = 8192;
-      hipLaunchKernelGGL(cg_update_p, dim3((unsigned)g), dim3(256), 0, st, (long)n, dr + lo, ldr, dp + lo, ldp, mw,
-                         s->d_coef, s->d_flag);
+      hipLaunchKernelGGL(cg_update_xp, dim3((unsigned)g), dim3(256), 0, st, (long)n, dr + lo, ldr, dp + lo, ldp,
+                         dx + lo, ldx, mw, s->d_coef, s->d_coef + s->cap, s->d_flag);
     }
-    // w = A p on the window ; pTw
-    st2[0] = lo; en2[0] = hi; st2[1] = lo; en2[1] = hi;
-    ops->MatDotMultiVec(mat, s->mv_ws[1], s->mv_ws[2], st2, en2, ops);
-    s->spmm_calls++; s->spmm_cols += mw;
-    ops->MultiVecLocalInnerProd('D', s->mv_ws[1], s->mv_ws[2], 0, st2, en2, pTw.data() + lo, 1, ops);
-    reduce_over_ranks(pTw.data() + lo, mw);
-    // x += alpha p ; r -= alpha w ; rho2 = diag(r^T r)
-    for (int j = lo; j < hi; ++j) { rho1[j] = rho2[j]; coef[j] = active[j] ? rho2[j] / pTw[j] : 0.0; flag[j] = active[j]; }
-    memcpy(s->h_pin, coef.data() + lo, mw * sizeof(double));
-    memcpy(s->h_pin + s->cap, flag.data() + lo, mw * sizeof(int));
-    GCGE_HIP_CHECK(hipMemcpyAsync(s->d_coef, s->h_pin, mw * sizeof(double), hipMemcpyHostToDevice, st));
-    GCGE_HIP_CHECK(hipMemcpyAsync(s->d_flag, s->h_pin + s->cap, mw * sizeof(int), hipMemcpyHostToDevice, st));
-    double* part = gcge_hip_partial_ws((size_t)nb * mw + mw);
-    hipLaunchKernelGGL(cg_update_xr, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dp + lo, ldp, dw + lo, ldw,
-                       dx + lo, ldx, dr + lo, ldr, mw, s->d_coef, s->d_flag, part, rpb);
-    hipLaunchKernelGGL(cg_reduce, dim3((mw + 127) / 128), dim3(128), 0, st, part, (int)nb, mw, part + (size_t)nb * mw);
-    GCGE_HIP_CHECK(hipMemcpyAsync(s->h_pin, part + (size_t)nb * mw, mw * sizeof(double), hipMemcpyDeviceToHost, st));
+    for (int j = lo; j < hi; ++j) pend[j] = 0;
+    // w = A p and pTw on the window of ACTIVE columns
+    int alo = lo, ahi = hi;
+    while (alo < hi && !active[alo]) ++alo;
+    while (ahi > alo && !active[ahi - 1]) --ahi;
+    const int aw = ahi - alo;
+    st2[0] = alo; en2[0] = ahi; st2[1] = alo; en2[1] = ahi;
+    gcge_hip_spmm_dot_mv(mat, s->mv_ws[1], s->mv_ws[2], st2, en2, pTw.data() + alo, ops);
+    s->spmm_calls++; s->spmm_cols += aw;
+    reduce_over_ranks(pTw.data() + alo, aw);
+    // r -= alpha w ; rho2 = diag(r^T r)
+    for (int j = alo; j < ahi; ++j) {
+      rho1[j] = rho2[j]; coef[j] = active[j] ? rho2[j] / pTw[j] : 0.0; flag[j] = active[j];
+      if (active[j]) { aprev[j] = coef[j]; pend[j] = 1; }
+    }
+    upload(alo, aw, coef.data(), coef.data(), flag.data());
+    double* part = gcge_hip_partial_ws((size_t)nb * aw + aw);
+    hipLaunchKernelGGL(cg_update_r, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr, aw,
+                       s->d_coef, s->d_flag, part, rpb);
+    gcge_hip_reduce_partials(part, (int)nb, aw, part + (size_t)nb * aw, st);
+    GCGE_HIP_CHECK(hipMemcpyAsync(s->h_pin, part + (size_t)nb * aw, aw * sizeof(double), hipMemcpyDeviceToHost, st));
     GCGE_HIP_CHECK(hipStreamSynchronize(st));
-    std::vector<double> newrho(s->h_pin, s->h_pin + mw);
-    reduce_over_ranks(newrho.data(), mw);
+    std::vector<double> newrho(s->h_pin, s->h_pin + aw);
+    reduce_over_ranks(newrho.data(), aw);
     nact = 0;
-    for (int j = lo; j < hi; ++j) {
+    for (int j = alo; j < ahi; ++j) {
       if (!active[j]) continue;
-      rho2[j] = newrho[j - lo];
+      rho2[j] = newrho[j - alo];
       last_res[j] = sqrt(rho2[j]);
       active[j] = (last_res[j] > s->rate * init_res[j]) && (last_res[j] > s->tol * norm_b[j]);
       nact += active[j];
     }
     ++niter;
+  }
+  {   // flush the x updates still pending
+    int lo = 0, hi = nrhs;
+    while (lo < nrhs && !pend[lo]) ++lo;
+    while (hi > lo && !pend[hi - 1]) --hi;
+    if (hi > lo) {
+      const int mw = hi - lo;
+      for (int j = lo; j < hi; ++j) { flag[j] = pend[j] ? 4 : 0; coef[j] = 0.0; }
+      upload(lo, mw, coef.data(), aprev.data(), flag.data());
+      long total = (long)n * mw, g = (total + 255) / 256; if (g > 8192) g = 8192;
+      hipLaunchKernelGGL(cg_update_xp, dim3((unsigned)g), dim3(256), 0, st, (long)n, dr + lo, ldr, dp + lo, ldp,
+                         dx + lo, ldx, mw, s->d_coef, s->d_coef + s->cap, s->d_flag);
+    }
   }
   s->niter = niter;
   s->residual = last_res[0];

@@ -61,23 +61,34 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(long nrows, const double
     pcol[a] = pb[a] ? (p + j0 + 16 * a + li) : p;
   }
 
-  for (long r = r0 + 4 * wave; r < r1; r += 16) {
-    const long rr = r + kk;
-    const bool rv = rr < r1;
-    const long rc = min(rr, nrows - 1);
-    double af[4], bf[4];
+  // fragments of step s+1 are requested before the 16 MFMAs of step s are issued (the loop is
+  // otherwise latency-bound: one 4-row step in flight per wave at 2 waves/SIMD)
+  double af[4], bf[4], an[4], bn[4];
+  long r = r0 + 4 * wave;
+  {
+    const long rr = r + kk; const bool rv = rr < r1; const long rc = min(rr, nrows - 1);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      const double qv = qcol[a][rc * ldq];
-      const double pv = pcol[a][rc * ldp];
-      af[a] = (rv && qa[a]) ? qv : 0.0;
-      bf[a] = (rv && pb[a]) ? pv : 0.0;
+      const double qv = qcol[a][rc * ldq], pv = pcol[a][rc * ldp];
+      af[a] = (rv && qa[a]) ? qv : 0.0; bf[a] = (rv && pb[a]) ? pv : 0.0;
+    }
+  }
+  for (; r < r1; r += 16) {
+    {
+      const long rr = r + 16 + kk; const bool rv = rr < r1; const long rc = min(rr, nrows - 1);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const double qv = qcol[a][rc * ldq], pv = pcol[a][rc * ldp];
+        an[a] = (rv && qa[a]) ? qv : 0.0; bn[a] = (rv && pb[a]) ? pv : 0.0;
+      }
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b)
         acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { af[a] = an[a]; bf[a] = bn[a]; }
   }
 
   // combine the four waves: wave 0 stores, the others add (LDS f64 atomics avoided: sequenced)

@@ -51,22 +51,37 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 }
 
 // orp[r] = first OCTET (group of 8 padded non-zeros) of row r; orp[nrows] = total octets.
-template <int LPR, int BATCH, int ST>
+// DOT = 1 additionally accumulates dot_j = sum_r X[r,j] * Y[r,j] (the p.w of a CG step, with X = p
+// the SpMM input): per-block partials go to dot_partial[blockIdx.x * m + j].  Blocks walk the row
+// chunks grid-stride (chunk = blockIdx.x, += gridDim.x): consecutive blocks still work on
+// consecutive chunks at the same time, and the number of partials stays small.
+template <int LPR, int BATCH, int ST, int DOT>
 __global__ __launch_bounds__(256) void spmm_pad8_kernel(
     int nrows, const int* __restrict__ orp, const int* __restrict__ pcol,
     const double* __restrict__ pval, const double* __restrict__ x, size_t ldx,
-    double* __restrict__ y, size_t ldy, int m, int rpw) {
+    double* __restrict__ y, size_t ldy, int m, int rpw, long nchunks, double* __restrict__ dot_partial) {
   constexpr int G = 64 / LPR;  // non-zeros per wave instruction
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long row0 = ((long)blockIdx.x * 4 + wave) * (long)rpw;
-  if (row0 >= nrows) return;
-  const int nr = min(rpw, (int)(nrows - row0));
   const int g = lane / LPR;
   const int c0 = 2 * (lane % LPR);
   const bool act = c0 < m;
   const double* __restrict__ xl = x + (act ? c0 : 0);  // inactive lanes re-read column 0 (never stored)
+  double d0 = 0.0, d1 = 0.0;
+ for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+  const long row0 = (chunk * 4 + wave) * (long)rpw;
+  if (row0 >= nrows) continue;
+  const int nr = min(rpw, (int)(nrows - row0));
   double* __restrict__ yl = y + (size_t)row0 * ldy + c0;
+  // DOT: the wave's own rows of X (rpw <= 4), loaded up front
+  double xo0[4] = {0.0, 0.0, 0.0, 0.0}, xo1[4] = {0.0, 0.0, 0.0, 0.0};
+  if (DOT) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double2 v = *reinterpret_cast<const double2*>(xl + (size_t)min(row0 + q, (long)nrows - 1) * ldx);
+      xo0[q] = v.x; xo1[q] = v.y;
+    }
+  }
 
   const long myend = 8L * orp[row0 + 1 + min(lane, nr - 1)];
   // positions are counted relative to the wave's first padded non-zero
@@ -86,6 +101,11 @@ __global__ __launch_bounds__(256) void spmm_pad8_kernel(
     if (G >= 4) { acc0 += shfl_xor_f64(acc0, 16); acc1 += shfl_xor_f64(acc1, 16); }    \
     if (G >= 8) { acc0 += shfl_xor_f64(acc0, 8); acc1 += shfl_xor_f64(acc1, 8); }      \
     if (act && g == 0) store_row16<ST>(yl + (size_t)r * ldy, acc0, acc1);              \
+    if (DOT) {                                                                         \
+      const double o0 = r == 0 ? xo0[0] : (r == 1 ? xo0[1] : (r == 2 ? xo0[2] : xo0[3])); \
+      const double o1 = r == 0 ? xo1[0] : (r == 1 ? xo1[1] : (r == 2 ? xo1[2] : xo1[3])); \
+      d0 = fma(acc0, o0, d0); d1 = fma(acc1, o1, d1);                                  \
+    }                                                                                  \
     acc0 = 0.0; acc1 = 0.0;                                                            \
     ++r;                                                                               \
     next_end = __builtin_amdgcn_readlane(rel_end_mine, min(r, nr - 1));                \
@@ -134,6 +154,16 @@ __global__ __launch_bounds__(256) void spmm_pad8_kernel(
     }
   }
 #undef GCGE_FLUSH_ROWS
+ }  // chunk loop
+  if (DOT) {   // block partial: every group holds the row totals, group 0 of each wave contributes
+    __shared__ double sred[4][128];
+    for (int e = threadIdx.x; e < 512; e += 256) (&sred[0][0])[e] = 0.0;
+    __syncthreads();
+    if (g == 0) { sred[wave][2 * lane] = act ? d0 : 0.0; sred[wave][2 * lane + 1] = act ? d1 : 0.0; }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < m && t < 2 * LPR) dot_partial[(long)blockIdx.x * m + t] = (sred[0][t] + sred[1][t]) + (sred[2][t] + sred[3][t]);
+  }
 }
 
 }  // namespace gcge
@@ -148,13 +178,26 @@ extern "C" void gcge_hip_spmm_pad8_tune(int rows_per_wave, int batch, int store_
   if (col_pass >= 0) g_p8_pass = col_pass;  // 0: widest pass that fits (<=128 columns)
 }
 
+static int g_p8_gridcap = 0;   // 0: one chunk per block
+extern "C" void gcge_hip_spmm_pad8_gridcap(int cap) { g_p8_gridcap = cap; }
+
 template <int LPR, int BATCH, int ST>
 static void p8_launch(int nrows, const int* orp, const int* pcol, const double* pval,
                       const double* x, size_t ldx, double* y, size_t ldy, int m, hipStream_t st) {
   const unsigned rows_per_block = 4u * (unsigned)g_p8_rpw;
-  const unsigned grid = (unsigned)(((size_t)nrows + rows_per_block - 1) / rows_per_block);
-  hipLaunchKernelGGL((spmm_pad8_kernel<LPR, BATCH, ST>), dim3(grid), dim3(256), 0, st, nrows, orp,
-                     pcol, pval, x, ldx, y, ldy, m, g_p8_rpw);
+  const long nchunks = ((long)nrows + rows_per_block - 1) / rows_per_block;
+  long grid = nchunks;
+  if (g_p8_gridcap > 0 && grid > g_p8_gridcap) grid = g_p8_gridcap;
+  hipLaunchKernelGGL((spmm_pad8_kernel<LPR, BATCH, ST, 0>), dim3((unsigned)grid), dim3(256), 0, st, nrows, orp,
+                     pcol, pval, x, ldx, y, ldy, m, g_p8_rpw, nchunks, (double*)nullptr);
+}
+// fused SpMM + column dots: rows_per_wave fixed at 4, at most `grid` partial rows
+template <int LPR>
+static void p8_launch_dot(int nrows, const int* orp, const int* pcol, const double* pval, const double* x,
+                          size_t ldx, double* y, size_t ldy, int m, double* partial, long grid, hipStream_t st) {
+  const long nchunks = ((long)nrows + 15) / 16;
+  hipLaunchKernelGGL((spmm_pad8_kernel<LPR, 4, 1, 1>), dim3((unsigned)grid), dim3(256), 0, st, nrows, orp, pcol,
+                     pval, x, ldx, y, ldy, m, 4, nchunks, partial);
 }
 template <int LPR, int BATCH>
 static void p8_store(int nrows, const int* orp, const int* pcol, const double* pval,
@@ -173,6 +216,27 @@ static void p8_batch(int nrows, const int* orp, const int* pcol, const double* p
     case 16: p8_store<LPR, 16>(nrows, orp, pcol, pval, x, ldx, y, ldy, m, st); break;
     default: p8_store<LPR, 8>(nrows, orp, pcol, pval, x, ldx, y, ldy, m, st); break;
   }
+}
+
+extern "C" double* gcge_hip_partial_ws(size_t len);
+extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, int len, double* d_out, void* stream);
+
+// Y = A X and d_dots[j] = sum_r X[r,j] Y[r,j] in one pass (ncols <= 128).  -1: alignment contract not met.
+extern "C" int gcge_hip_pad8_spmm_dot(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval,
+                                      const double* d_x, long ldx, double* d_y, long ldy, int ncols,
+                                      double* d_dots, void* stream) {
+  if (nrows <= 0 || ncols <= 0) return 0;
+  if (ncols > 128 || (ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const long nchunks = ((long)nrows + 15) / 16;
+  const long grid = nchunks < 8192 ? nchunks : 8192;
+  double* part = gcge_hip_partial_ws((size_t)grid * ncols);
+  if (ncols > 64) p8_launch_dot<64>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st);
+  else if (ncols > 32) p8_launch_dot<32>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st);
+  else if (ncols > 16) p8_launch_dot<16>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st);
+  else p8_launch_dot<8>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st);
+  gcge_hip_reduce_partials(part, (int)grid, ncols, d_dots, st);
+  return (int)hipGetLastError();
 }
 
 // C-ABI (include/gcge_hip.h).  Returns 0 on success, -1 if the operands do not meet the

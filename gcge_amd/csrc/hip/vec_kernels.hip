@@ -97,13 +97,26 @@ __global__ __launch_bounds__(256) void coldots_partial(long nrows, const double*
     __syncthreads();
   }
 }
-// out[j] = sum_b partial[b*m + j], fixed order (bitwise reproducible)
-__global__ void reduce_partials(const double* __restrict__ partial, int nblocks, int len, double* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= len) return;
-  double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * len + j];
-  out[j] = s;
+// out[j] = sum_b partial[b*len + j]; 16 row groups x 64 columns per block, fixed summation
+// tree => bitwise reproducible, and no thread walks more than nblocks/16 entries
+__global__ __launch_bounds__(1024) void reduce_partials(const double* __restrict__ partial, int nblocks, int len,
+    double* __restrict__ out) {
+  __shared__ double red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx;
+  double s0 = 0.0, s1 = 0.0;
+  if (j < len) {
+    int b = ty;
+    for (; b + 16 < nblocks; b += 32) { s0 += partial[(long)b * len + j]; s1 += partial[(long)(b + 16) * len + j]; }
+    for (; b < nblocks; b += 16) s0 += partial[(long)b * len + j];
+  }
+  red[ty][tx] = s0 + s1;
+  __syncthreads();
+  for (int h = 8; h > 0; h >>= 1) {
+    if (ty < h) red[ty][tx] += red[ty + h][tx];
+    __syncthreads();
+  }
+  if (ty == 0 && j < len) out[j] = red[0][tx];
 }
 
 __device__ __forceinline__ double u01(unsigned long long seed, unsigned long long index) {
@@ -216,8 +229,14 @@ extern "C" int gcge_hip_coldots(int nrows, const double* d_x, long ldx, const do
   double* part = gcge_hip_partial_ws((size_t)nb * m);
   hipLaunchKernelGGL(coldots_partial, dim3((unsigned)nb), dim3(256), 0, st, (long)nrows, d_x, ldx, d_y, ldy, m,
                      part, rpb);
-  hipLaunchKernelGGL(reduce_partials, dim3((m + 127) / 128), dim3(128), 0, st, part, (int)nb, m, d_out);
+  hipLaunchKernelGGL(reduce_partials, dim3((m + 63) / 64), dim3(1024), 0, st, part, (int)nb, m, d_out);
   return (int)hipGetLastError();
+}
+
+// exported so other translation units reuse the same fixed-order reduction
+extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, int len, double* d_out, void* stream) {
+  hipLaunchKernelGGL(reduce_partials, dim3((len + 63) / 64), dim3(1024), 0, (hipStream_t)stream, d_partial, nblocks,
+                     len, d_out);
 }
 
 extern "C" int gcge_hip_fill_uniform(int nrows, long row_begin, long nglobal, double* d_y, long ldy, int c0,

@@ -1,9 +1,186 @@
-"""Row-partitioned (one process per GPU) execution of the GCG hot path — see DESIGN.md §multi-GPU."""
+"""Row-partitioned execution: one process per GPU, every block of vectors and the matrix split by
+contiguous row slabs (the reference's MPI back-ends do the same: app/app_slepc.c:49-60,
+src/ops_multi_vec.c:206-228).  Two exchanges exist on the hot path:
+
+  * all-reduce (sum, f64) of every small Gram / dot result — GCGE_COMM.allreduce_sum, installed
+    here over torch.distributed (backend "nccl" == RCCL over xGMI on the GPUs, "gloo" on CPU);
+  * the SpMM halo: rows of X owned by other ranks — point-to-point batch_isend_irecv of packed
+    row blocks (RCCL send/recv), planned once per matrix by plan_halo().
+
+Python is plumbing: planning happens once, the callbacks only move buffers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .lib import CSR, host_lib
 
 
-def install(hip, dist, rank, world):
-    raise NotImplementedError("multi-GPU path: see gcge_amd/csrc/hip/dist.hip (in progress)")
+class GcgeComm(C.Structure):
+    """GCGE_COMM (include/gcge_ops.h)."""
+    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("allreduce_sum", C.c_void_p), ("ctx", C.c_void_p)]
 
 
-def lap3d_slab(hip, N, planes, rank, world):
-    raise NotImplementedError
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_void_p)
+
+
+def row_partition(n_global, world):
+    """Contiguous, as even as possible: part[r] .. part[r+1] are rank r's rows."""
+    base, rem = divmod(n_global, world)
+    part = [0]
+    for r in range(world):
+        part.append(part[-1] + base + (1 if r < rem else 0))
+    return part
+
+
+class Comm:
+    """Owns the torch.distributed plumbing of one rank and the ctypes callbacks built on it."""
+
+    def __init__(self, dist, rank, world, device=None, stage_through_host=False):
+        import torch
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.device = device                  # torch.device for device-resident exchange buffers, None = host
+        self.stage = stage_through_host       # device buffers but a host-only transport (gloo): copy through host
+        self._allreduce_cb = ALLREDUCE_FN(self._allreduce)
+        self._keep = []
+        self.n_allreduce = 0
+
+    # ---- small-result all-reduce (host buffer in, host buffer out) -------------------------------
+    def _allreduce(self, buf, n, ctx):
+        torch = self.torch
+        arr = np.ctypeslib.as_array(buf, shape=(n,))
+        t = torch.from_numpy(arr)
+        if self.device is not None and not self.stage:
+            td = t.to(self.device)
+            self.dist.all_reduce(td)
+            t.copy_(td.cpu())
+        else:
+            self.dist.all_reduce(t)
+        self.n_allreduce += 1
+
+    def install(self):
+        """GCGE_SetComm: from now on inner products / CG scalars are summed over the ranks."""
+        h = host_lib()
+        c = GcgeComm(self.rank, self.world, C.cast(self._allreduce_cb, C.c_void_p), None)
+        self._keep.append(c)
+        h.GCGE_SetComm(C.byref(c))
+
+    def uninstall(self):
+        host_lib().GCGE_SetComm(None)
+
+    # ---- halo planning ------------------------------------------------------------------------
+    def plan_halo(self, ghosts, part):
+        """ghosts: ascending global row ids this rank needs.  Returns (send_rows, send_cnt, recv_cnt):
+        local rows to ship grouped by destination rank, and per-peer counts."""
+        mine = (part[self.rank], part[self.rank + 1])
+        all_ghosts = [None] * self.world
+        self.dist.all_gather_object(all_ghosts, np.asarray(ghosts, dtype=np.int64))
+        send_rows, send_cnt = [], [0] * self.world
+        for q in range(self.world):
+            if q == self.rank:
+                continue
+            g = all_ghosts[q]
+            sel = g[(g >= mine[0]) & (g < mine[1])] - mine[0]
+            send_cnt[q] = int(sel.size)
+            send_rows.append(sel.astype(np.int32))
+        gh = np.asarray(ghosts, dtype=np.int64)
+        recv_cnt = [int(((gh >= part[q]) & (gh < part[q + 1])).sum()) if q != self.rank else 0 for q in range(self.world)]
+        send_rows = np.concatenate(send_rows) if send_rows else np.zeros(0, dtype=np.int32)
+        return np.ascontiguousarray(send_rows, dtype=np.int32), send_cnt, recv_cnt
+
+    def make_exchange(self, send_cnt, recv_cnt, cap_cols):
+        """Allocates the exchange buffers and returns (callback, send_ptr, recv_ptr, keepalive)."""
+        torch = self.torch
+        nsend, nrecv = sum(send_cnt), sum(recv_cnt)
+        dev = self.device if self.device is not None else torch.device("cpu")
+        send_t = torch.zeros(max(1, nsend * cap_cols), dtype=torch.float64, device=dev)
+        recv_t = torch.zeros(max(1, nrecv * cap_cols), dtype=torch.float64, device=dev)
+        soff = np.concatenate([[0], np.cumsum(send_cnt)]).astype(int)
+        roff = np.concatenate([[0], np.cumsum(recv_cnt)]).astype(int)
+        host_buffers = self.device is None
+
+        def exchange(sendbuf, recvbuf, ncols, ctx):
+            dist = self.dist
+            if host_buffers:     # the caller owns plain host arrays of exactly nsend/nrecv x ncols
+                s_all = torch.from_numpy(np.ctypeslib.as_array(sendbuf, shape=(max(1, nsend * ncols),)))
+                r_all = torch.from_numpy(np.ctypeslib.as_array(recvbuf, shape=(max(1, nrecv * ncols),)))
+            elif self.stage:
+                torch.cuda.synchronize()
+                s_all = send_t[:max(1, nsend * ncols)].cpu()
+                r_all = torch.zeros(max(1, nrecv * ncols), dtype=torch.float64)
+            else:
+                s_all, r_all = send_t, recv_t
+            ops = []
+            for q in range(self.world):
+                if q == self.rank:
+                    continue
+                if send_cnt[q]:
+                    ops.append(dist.P2POp(dist.isend, s_all[soff[q] * ncols:soff[q + 1] * ncols], q))
+                if recv_cnt[q]:
+                    ops.append(dist.P2POp(dist.irecv, r_all[roff[q] * ncols:roff[q + 1] * ncols], q))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            if self.stage and not host_buffers:
+                recv_t[:max(1, nrecv * ncols)].copy_(r_all)
+                torch.cuda.synchronize()
+
+        cb = EXCHANGE_FN(exchange)
+        self._keep += [cb, send_t, recv_t]
+        sp = C.cast(send_t.data_ptr(), C.POINTER(C.c_double))
+        rp = C.cast(recv_t.data_ptr(), C.POINTER(C.c_double))
+        return cb, sp, rp
+
+
+def localize_slab(A):
+    """A: CSR slab with GLOBAL columns.  Returns the ascending ghost list; A is rewritten to local numbering."""
+    h = host_lib()
+    gp = C.POINTER(C.c_int)()
+    ng = C.c_int()
+    rc = h.gcge_dist_ghosts(C.byref(A), C.byref(gp), C.byref(ng))
+    if rc != 0:
+        raise RuntimeError("gcge_dist_ghosts failed")
+    ghosts = np.ctypeslib.as_array(gp, shape=(ng.value,)).copy() if ng.value else np.zeros(0, dtype=np.int32)
+    rc = h.gcge_dist_localize(C.byref(A), gp, ng)
+    h.gcge_free_ints(gp)
+    if rc != 0:
+        raise RuntimeError("gcge_dist_localize failed")
+    return ghosts
+
+
+def install(hip, dist, rank, world, stage_through_host=False):
+    """Comm for the HIP back-end of this rank (device-resident exchange buffers)."""
+    import torch
+    comm = Comm(dist, rank, world, device=torch.device("cuda", torch.cuda.current_device()),
+                stage_through_host=stage_through_host)
+    comm.install()
+    return comm
+
+
+def hip_slab_matrix(hip, comm, A, n_global, part, cap_cols=128):
+    """Upload a CSR slab (GLOBAL columns on entry) and install its halo plan."""
+    g = hip.g
+    ghosts = localize_slab(A)
+    send_rows, send_cnt, recv_cnt = comm.plan_halo(ghosts, part)
+    mat = hip.matrix(A)
+    cb, sp, rp = comm.make_exchange(send_cnt, recv_cnt, cap_cols)
+    g.gcge_hip_mat_set_halo.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), C.c_int, C.c_void_p, C.c_void_p]
+    g.gcge_hip_mat_set_halo(mat, n_global, int(send_rows.size), send_rows.ctypes.data_as(C.POINTER(C.c_int)), sp, rp,
+                            cap_cols, C.cast(cb, C.c_void_p), None)
+    return mat
+
+
+def lap3d_slab(hip, N, planes, rank, world, comm=None):
+    """Weak-scaling workload of bench.py: an N x N x planes box, rank r owns planes*N*N/world rows."""
+    h = host_lib()
+    n_global = N * N * planes
+    part = row_partition(n_global, world)
+    A = CSR()
+    rc = h.gcge_problem_lap3d_box(C.c_int(N), C.c_int(N), C.c_int(planes), C.c_int64(part[rank]),
+                                  C.c_int64(part[rank + 1]), C.byref(A))
+    if rc != 0:
+        raise RuntimeError("gcge_problem_lap3d_box failed")
+    mat = hip_slab_matrix(hip, comm, A, n_global, part)
+    return A, mat

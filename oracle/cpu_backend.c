@@ -38,11 +38,19 @@ static int g_threads = 1;
 void oracle_set_threads(int n) { g_threads = n > 0 ? n : 1; }
 int  oracle_get_threads(void) { return g_threads; }
 
+/* Row-partitioned variant (one rank per slab; the counterpart of the reference's MPI back-ends,
+ * app/app_slepc.c:49-60, app/app_phg.c:292-359): a slab is stored as CSR with LOCAL column indices,
+ * nrows owned rows and ncols = nrows + nghost; blocks of vectors carry nghost extra rows (ldd) that
+ * are filled by the halo exchange callback right before a product. */
+static int is_dist(const CCS *m) { return m != NULL && m->ncols > m->nrows; }
+static ORACLE_HALO g_halo;    /* one partition per process */
+void oracle_set_halo(const ORACLE_HALO *h) { g_halo = *h; }
+
 /* app_ccs.c:40-49 — zero-filled n x num_vec block, ldd = nrows = mat->ncols */
 static void O_MultiVecCreateByMat(void ***mv, int num_vec, void *mat, struct OPS_ *ops)
 {
 	VEC *v = (VEC*)malloc(sizeof(VEC)); CCS *m = (CCS*)mat;
-	v->nrows = m->ncols; v->ncols = num_vec; v->ldd = v->nrows;
+	v->nrows = is_dist(m) ? m->nrows : m->ncols; v->ncols = num_vec; v->ldd = m->ncols;
 	v->data = (double*)calloc((size_t)v->ldd * (num_vec > 0 ? num_vec : 1), sizeof(double));
 	*mv = (void**)v;
 }
@@ -143,8 +151,30 @@ static void O_MatDotMultiVec(void *mat, void **x, void **y, int *start, int *end
 {
 	CCS *A = (CCS*)mat; VEC *vx = (VEC*)x, *vy = (VEC*)y; int c, m = end[0] - start[0];
 	assert(m == end[1] - start[1]);
-	assert(vx->nrows == vx->ldd && vy->nrows == vy->ldd);
 	if (m <= 0) return;
+	if (is_dist(A)) {   /* slab: fetch halo rows, then row-wise (gather) product with local indices */
+		int nloc = A->nrows, ng = A->ncols - A->nrows, i, j, k;
+		double *sb = (double*)malloc((size_t)(g_halo.nsend > 0 ? g_halo.nsend : 1) * m * sizeof(double));
+		double *rb = (double*)malloc((size_t)(ng > 0 ? ng : 1) * m * sizeof(double));
+		assert(vx->ldd >= A->ncols);
+		for (i = 0; i < g_halo.nsend; ++i) for (j = 0; j < m; ++j)
+			sb[(size_t)i * m + j] = vx->data[(size_t)vx->ldd * (start[0] + j) + g_halo.send_rows[i]];
+		g_halo.exchange(sb, rb, m, g_halo.ctx);
+		for (i = 0; i < ng; ++i) for (j = 0; j < m; ++j)
+			vx->data[(size_t)vx->ldd * (start[0] + j) + nloc + i] = rb[(size_t)i * m + j];
+		free(sb); free(rb);
+		for (c = 0; c < m; ++c) {
+			const double *xs = vx->data + (size_t)vx->ldd * (start[0] + c);
+			double *yd = vy->data + (size_t)vy->ldd * (start[1] + c);
+			for (i = 0; i < nloc; ++i) {   /* j_col doubles as the CSR row pointer of the slab */
+				double acc = 0.0;
+				for (k = A->j_col[i]; k < A->j_col[i + 1]; ++k) acc += A->data[k] * xs[A->i_row[k]];
+				yd[i] = acc;
+			}
+		}
+		return;
+	}
+	if (A != NULL) assert(vx->nrows == vx->ldd && vy->nrows == vy->ldd);   /* app_ccs.c:54-55 */
 #pragma omp parallel for schedule(static) num_threads(g_threads)
 	for (c = 0; c < m; ++c) {
 		const double *xs = vx->data + (size_t)vx->ldd * (start[0] + c);
@@ -170,18 +200,18 @@ static void O_MultiVecQtAP(char ntsA, char ntsd, void **mvQ, void *matA, void **
 	if (matA == NULL) {
 		if (ntsd == 'T') {
 			s[0] = startQP[1]; e[0] = endQP[1]; s[1] = startQP[0]; e[1] = endQP[0];
-			O_MultiVecLocalInnerProd('N', mvP, mvQ, is_vec, s, e, qAp, ldQAP, ops);
-		} else O_MultiVecLocalInnerProd(ntsd, mvQ, mvP, is_vec, startQP, endQP, qAp, ldQAP, ops);
+			ops->MultiVecInnerProd('N', mvP, mvQ, is_vec, s, e, qAp, ldQAP, ops);
+		} else ops->MultiVecInnerProd(ntsd, mvQ, mvP, is_vec, startQP, endQP, qAp, ldQAP, ops);
 		return;
 	}
 	s[0] = startQP[1]; e[0] = endQP[1]; s[1] = 0; e[1] = m;
 	O_MatDotMultiVec(matA, mvP, mv_ws, s, e, ops);
 	if (ntsd == 'T') {
 		s[0] = 0; e[0] = m; s[1] = startQP[0]; e[1] = endQP[0];
-		O_MultiVecLocalInnerProd('N', mv_ws, mvQ, is_vec, s, e, qAp, ldQAP, ops);
+		ops->MultiVecInnerProd('N', mv_ws, mvQ, is_vec, s, e, qAp, ldQAP, ops);
 	} else {
 		s[0] = startQP[0]; e[0] = endQP[0]; s[1] = 0; e[1] = m;
-		O_MultiVecLocalInnerProd(ntsd, mvQ, mv_ws, is_vec, s, e, qAp, ldQAP, ops);
+		ops->MultiVecInnerProd(ntsd, mvQ, mv_ws, is_vec, s, e, qAp, ldQAP, ops);
 	}
 }
 
@@ -196,7 +226,7 @@ void OPS_ORACLE_Set(struct OPS_ *ops)
 	ops->MultiVecDestroy          = O_MultiVecDestroy;
 	ops->MultiVecView             = O_MultiVecView;
 	ops->MultiVecLocalInnerProd   = O_MultiVecLocalInnerProd;
-	ops->MultiVecInnerProd        = O_MultiVecLocalInnerProd;
+	ops->MultiVecInnerProd        = NULL;   /* OPS_Setup: local part + sum over ranks (src/ops_multi_vec.c:202-230) */
 	ops->MultiVecSetRandomValue   = O_MultiVecSetRandomValue;
 	ops->MultiVecAxpby            = O_MultiVecAxpby;
 	ops->MultiVecLinearComb       = O_MultiVecLinearComb;

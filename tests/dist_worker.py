@@ -1,0 +1,91 @@
+"""Worker of the 2-rank tests (launched by tests/test_dist.py with RANK/WORLD_SIZE/MASTER_* set).
+mode 'oracle': CPU oracle back-end, gloo.   mode 'hip': HIP back-end on cuda:0 for every rank, gloo
+transport staged through the host (what differs from production is only the torch.distributed backend)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+
+def box_exact(dims, count):
+    cs = [2.0 * np.cos(np.arange(1, d + 1) * np.pi / (d + 1)) for d in dims]
+    lam = (6.0 - cs[0][:, None, None] - cs[1][None, :, None] - cs[2][None, None, :]).ravel()
+    return np.sort(lam)[:count]
+
+
+def main():
+    mode = sys.argv[1]
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gcge_amd import dist as gdist
+    from gcge_amd.lib import CSR, host_lib, run_gcg
+    from helpers import uniform, csr_to_scipy
+    h = host_lib()
+    dims = (8, 6, 10)
+    n_global = dims[0] * dims[1] * dims[2]
+    part = gdist.row_partition(n_global, world)
+    n_loc = part[rank + 1] - part[rank]
+    # the global matrix (for checking) and this rank's slab
+    Ag = CSR(); h.gcge_problem_lap3d_box(dims[0], dims[1], dims[2], C.c_int64(0), C.c_int64(-1), C.byref(Ag))
+    S = csr_to_scipy(Ag)
+    A = CSR(); h.gcge_problem_lap3d_box(dims[0], dims[1], dims[2], C.c_int64(part[rank]), C.c_int64(part[rank + 1]), C.byref(A))
+    X = uniform(5, (n_global, 6)) - 0.5
+    Yref = S @ X
+
+    if mode == "oracle":
+        import pyoracle as po
+        from helpers import OracleBackend
+        be = OracleBackend()
+        comm = gdist.Comm(dist, rank, world, device=None)
+        comm.install()
+        ghosts = gdist.localize_slab(A)
+        send_rows, send_cnt, recv_cnt = comm.plan_halo(ghosts, part)
+        cb, sp, rp = comm.make_exchange(send_cnt, recv_cnt, 1)
+
+        class Halo(C.Structure):
+            _fields_ = [("nsend", C.c_int), ("send_rows", C.POINTER(C.c_int)), ("exchange", C.c_void_p), ("ctx", C.c_void_p)]
+        halo = Halo(int(send_rows.size), send_rows.ctypes.data_as(C.POINTER(C.c_int)), C.cast(cb, C.c_void_p), None)
+        po.oracle_lib().oracle_set_halo(C.byref(halo))
+        mat = be.matrix(A)             # ORACLE_CCS view: nrows = n_loc, ncols = n_loc + nghost
+    else:
+        from gcge_amd import HipBackend
+        be = HipBackend(device=0)
+        comm = gdist.install(be, dist, rank, world, stage_through_host=True)
+        mat = gdist.hip_slab_matrix(be, comm, A, n_global, part, cap_cols=4)   # small cap: exercises the column chunking
+        be.set_random_mode(1, 777)
+
+    # 1. distributed SpMM == rows of the global product
+    x = be.mv_from_numpy(mat, X[part[rank]:part[rank + 1], :])
+    y = be.ops.mv_create(6, mat)
+    be.ops.spmm(mat, x, y, (1, 0), (6, 5))
+    got = be.mv_to_numpy(y, n_loc, 0, 5)
+    err = np.max(np.abs(got - Yref[part[rank]:part[rank + 1], 1:6]))
+    assert err < 1e-13, "distributed SpMM differs: %g" % err
+    # 2. global inner product == numpy on the full vectors
+    ip = be.ops.inner_prod("N", x, x, (0, 1), (3, 5))
+    assert np.max(np.abs(ip - X[:, 0:3].T @ X[:, 1:5])) < 1e-12
+    # 3. whole eigensolve, SPMD
+    if mode == "hip":
+        be.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+        be.g.gcge_hip_bpcg_setup(be.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    ev, res = run_gcg(be.ops_handle, mat, None, ["-nevConv", 8, "-gcge_compW_orth_method", "chol"], flag=1 if mode == "hip" else 0)
+    exact = box_exact(dims, res.nevConv)
+    rel = np.max(np.abs(ev[:res.nevConv] - exact) / exact)
+    assert res.nevConv >= 8 and rel < 1e-10, (res.nevConv, rel)
+    allc = [None] * world
+    dist.all_gather_object(allc, (res.nevConv, res.numIter, float(ev[0])))
+    assert all(a[:2] == allc[0][:2] for a in allc), "ranks disagree: %r" % (allc,)
+    print("rank %d ok: nevConv=%d numIter=%d rel=%.2e allreduces=%d" % (rank, res.nevConv, res.numIter, rel, comm.n_allreduce))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
