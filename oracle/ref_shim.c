@@ -52,6 +52,13 @@ static void set_vec(LAPACKVEC *v, double *data, int nrows, int ncols)
 	v->data = data; v->nrows = nrows; v->ncols = ncols; v->ldd = nrows;
 }
 
+/* Drop-in check: the REFERENCE solver stack (GCG, ModifiedGramSchmidt, BlockPCG, OPS_Setup defaults)
+ * driving a back-end that was written against OUR gcge_ops.h.  `foreign_ops` is a table created and
+ * filled by that back-end (its MultiVec and MatDotMultiVec slots); everything else is the reference one. */
+static OPS *g_foreign_ops = NULL;
+void ref_use_foreign_backend(void *foreign_ops) { g_foreign_ops = (OPS*)foreign_ops; }
+void *ref_make_ccs_ops(void) { return (void*)make_ops(); }   /* reference app_ccs table, for OUR solver to drive */
+
 /* ---- eigensolver: same parameter flow as test/test_eig_sol_gcg.c:28-169 ---- */
 int ref_gcg_solve(int n, int *a_rowptr, int *a_colidx, double *a_val,
 		int *b_rowptr, int *b_colidx, double *b_val,
@@ -61,8 +68,13 @@ int ref_gcg_solve(int n, int *a_rowptr, int *a_colidx, double *a_val,
 		double *eval_out, double *evec_out, int *nevConv_out, int *numIter_out,
 		double *seconds_out)
 {
-	OPS *ops = make_ops();
+	OPS *ops;
 	CCSMAT A, B; void *matA, *matB = NULL;
+	if (g_foreign_ops != NULL) {
+		ops = g_foreign_ops;
+		OPS_Setup(ops);                       /* the reference back-fills lapack_ops, QtAP, InnerProd */
+		if (!g_verbose) { ops->Printf = quiet_printf; ops->lapack_ops->Printf = quiet_printf; }
+	} else ops = make_ops();
 	set_ccs(&A, n, a_rowptr, a_colidx, a_val); matA = &A;
 	if (b_rowptr != NULL) { set_ccs(&B, n, b_rowptr, b_colidx, b_val); matB = &B; }
 
@@ -118,13 +130,13 @@ int ref_gcg_solve(int n, int *a_rowptr, int *a_colidx, double *a_val,
 	if (numIter_out) *numIter_out = ((GCGSolver*)ops->eigen_solver_workspace)->numIter;
 	if (nevConv_out) *nevConv_out = conv;
 	memcpy(eval_out, eval, nevMax * sizeof(double));
-	if (evec_out) memcpy(evec_out, ((LAPACKVEC*)evec)->data, (size_t)n * nevMax * sizeof(double));
+	if (evec_out && g_foreign_ops == NULL) memcpy(evec_out, ((LAPACKVEC*)evec)->data, (size_t)n * nevMax * sizeof(double));
 
 	ops->MultiVecDestroy(&ws[0], nevMax + 2 * block_size, ops);
 	for (i = 1; i < 4; ++i) ops->MultiVecDestroy(&ws[i], block_size, ops);
 	ops->MultiVecDestroy(&evec, nevMax, ops);
 	free(dbl_ws); free(int_ws); free(eval);
-	OPS_Destroy(&ops);
+	if (g_foreign_ops == NULL) OPS_Destroy(&ops);
 	return 0;
 }
 
