@@ -22,6 +22,8 @@
 extern "C" {
 int gcge_hip_pad8_spmm_dot(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval, const double* d_x,
                            long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream);
+int gcge_hip_sell8_spmm(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval, const double* d_x, long ldx,
+                        double* d_y, long ldy, int ncols, void* stream);
 int gcge_hip_colscale(int nrows, double* d_y, long ldy, int m, const double* d_s, void* stream);
 int gcge_hip_fill_uniform(int nrows, long row_begin, long nglobal, double* d_y, long ldy, int c0, int m,
                           unsigned long long seed, void* stream);
@@ -82,6 +84,8 @@ static hipStream_t g_stream = nullptr;
 static int g_inited = 0;
 static double* g_stage_d = nullptr; static size_t g_stage_d_len = 0;   // device staging (doubles)
 static double* g_stage_h = nullptr; static size_t g_stage_h_len = 0;   // pinned host staging
+static int g_spmm_path = 0;   // 0: pad-8 wide kernel, 1: SELL-8 passes of 16 columns
+extern "C" void gcge_hip_set_spmm_path(int path) { g_spmm_path = path; }
 static int g_rand_mode = 0; static unsigned long long g_rand_seed = 0x5DEECE66Dull;
 
 static double* stage_d(size_t len) {
@@ -447,7 +451,8 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
-  if (m >= 16) rc = gcge_hip_pad8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
+  if (m >= 16 && g_spmm_path == 1) rc = gcge_hip_sell8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
+  else if (m >= 16) rc = gcge_hip_pad8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
   if (rc == -1) rc = gcge_hip_csr_spmm(A->nrows, A->d_rowptr, A->d_colidx, A->d_val, dx, vx->ld, dy, vy->ld, m, g_stream);
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "MatDotMultiVec: kernel launch");

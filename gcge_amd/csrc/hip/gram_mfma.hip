@@ -61,34 +61,34 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(long nrows, const double
     pcol[a] = pb[a] ? (p + j0 + 16 * a + li) : p;
   }
 
-  // fragments of step s+1 are requested before the 16 MFMAs of step s are issued (the loop is
-  // otherwise latency-bound: one 4-row step in flight per wave at 2 waves/SIMD)
-  double af[4], bf[4], an[4], bn[4];
-  long r = r0 + 4 * wave;
-  {
-    const long rr = r + kk; const bool rv = rr < r1; const long rc = min(rr, nrows - 1);
+  // A wave owns 4*MS consecutive rows per macro-step: all fragment loads of the macro-step are issued
+  // before its MFMAs, so several KB per wave are in flight while the previous results are consumed
+  // (a 4-row step at a time leaves the loop latency-bound: measured 8 TF).
+  constexpr int MS = 2;   // 4-row steps per macro-step (MS = 4 needs 288 registers: 1 wave/SIMD)
+  for (long base = r0 + 4 * MS * wave; base < r1; base += 16 * MS) {
+    double af[MS][4], bf[MS][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const double qv = qcol[a][rc * ldq], pv = pcol[a][rc * ldp];
-      af[a] = (rv && qa[a]) ? qv : 0.0; bf[a] = (rv && pb[a]) ? pv : 0.0;
-    }
-  }
-  for (; r < r1; r += 16) {
-    {
-      const long rr = r + 16 + kk; const bool rv = rr < r1; const long rc = min(rr, nrows - 1);
+    for (int u = 0; u < MS; ++u) {
+      const long rr = base + 4 * u + kk;
+      const bool rv = rr < r1;
+      const long rc = min(rr, nrows - 1);
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const double qv = qcol[a][rc * ldq], pv = pcol[a][rc * ldp];
-        an[a] = (rv && qa[a]) ? qv : 0.0; bn[a] = (rv && pb[a]) ? pv : 0.0;
+        double qv = qcol[a][rc * ldq], pv = pcol[a][rc * ldp];
+        // keep the loads unconditional: without this hipcc sinks each load into its select and puts a
+        // branch + s_waitcnt vmcnt(0) around every one of them (seen in the ISA; 10 TF instead of 30+)
+        asm volatile("" : "+v"(qv), "+v"(pv));
+        af[u][a] = (rv && qa[a]) ? qv : 0.0;
+        bf[u][a] = (rv && pb[a]) ? pv : 0.0;
       }
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int u = 0; u < MS; ++u)
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { af[a] = an[a]; bf[a] = bn[a]; }
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u][a], bf[u][b], acc[a][b], 0, 0, 0);
   }
 
   // combine the four waves: wave 0 stores, the others add (LDS f64 atomics avoided: sequenced)
@@ -140,7 +140,7 @@ extern "C" int gcge_hip_gram(int nrows, const double* d_q, long ldq, int k, cons
   // enough blocks to fill 256 CUs a few times over, chunks a multiple of 16 rows
   long nchunks = 2048 / ((long)ti * tj);
   if (nchunks < 64) nchunks = 64;
-  long rpc = (((long)nrows + nchunks - 1) / nchunks + 15) / 16 * 16;
+  long rpc = (((long)nrows + nchunks - 1) / nchunks + 63) / 64 * 64;
   if (rpc < 64) rpc = 64;
   nchunks = ((long)nrows + rpc - 1) / rpc;
   double* slab = gcge_hip_partial_ws((size_t)nchunks * ti * tj * 4096);

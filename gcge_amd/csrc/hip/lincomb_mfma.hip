@@ -44,22 +44,40 @@ __global__ __launch_bounds__(256) void lincomb_kernel(long nrows, const double* 
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  for (int k0 = 0; k0 < k; k0 += LC_KT) {
-    // stage X[r0:r0+64, k0:k0+KT) and C[k0:k0+KT, 0:m); zero-fill outside
-    for (int e = threadIdx.x; e < 64 * LC_KT; e += 256) {
-      const int row = e / LC_KT, col = e % LC_KT;
+  // register double-buffering: the next k-tile is fetched from global memory while the MFMAs of the
+  // current one run; it is written to LDS after the barrier that ends the current tile
+  constexpr int XE = 64 * LC_KT / 256;            // X elements per thread and tile (8)
+  constexpr int CE = LC_KT * 16 * NT / 256;       // C elements per thread and tile (2 NT)
+  double xr[XE];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < XE; ++q) {
+      const int e = threadIdx.x + 256 * q, row = e / LC_KT, col = e % LC_KT;
       const long gr = min(r0 + row, nrows - 1);
       const int gc = min(k0 + col, k - 1);
-      const double v = x[gr * ldx + gc];
-      xs[row * LC_XS + col] = (r0 + row < nrows && k0 + col < k) ? v : 0.0;
+      double v = x[gr * ldx + gc];
+      asm volatile("" : "+v"(v));   // unconditional load (see gram_mfma.hip)
+      xr[q] = (r0 + row < nrows && k0 + col < k) ? v : 0.0;
     }
-    for (int e = threadIdx.x; e < LC_KT * 16 * NT; e += 256) {
-      const int row = e / (16 * NT), col = e % (16 * NT);
+  };
+  // the coefficient tile is small and L2-resident: it goes straight to LDS (no register stage)
+  auto stash = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < XE; ++q) { const int e = threadIdx.x + 256 * q; xs[(e / LC_KT) * LC_XS + e % LC_KT] = xr[q]; }
+#pragma unroll
+    for (int q = 0; q < CE; ++q) {
+      const int e = threadIdx.x + 256 * q, row = e / (16 * NT), col = e % (16 * NT);
       const int gr = min(k0 + row, k - 1), gc = min(col, m - 1);
-      const double v = c[(long)gr * m + gc];
+      double v = c[(long)gr * m + gc];
+      asm volatile("" : "+v"(v));
       cst[row * cs + col] = (k0 + row < k && col < m) ? v : 0.0;
     }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < k; k0 += LC_KT) {
+    stash(k0);
     __syncthreads();
+    if (k0 + LC_KT < k) fetch(k0 + LC_KT);
 #pragma unroll
     for (int s = 0; s < LC_KT; s += 4) {
       const double a = xs[(16 * wave + li) * LC_XS + s + kk];

@@ -59,7 +59,8 @@ template <int LPR, int BATCH, int ST, int DOT>
 __global__ __launch_bounds__(256) void spmm_pad8_kernel(
     int nrows, const int* __restrict__ orp, const int* __restrict__ pcol,
     const double* __restrict__ pval, const double* __restrict__ x, size_t ldx,
-    double* __restrict__ y, size_t ldy, int m, int rpw, long nchunks, double* __restrict__ dot_partial) {
+    double* __restrict__ y, size_t ldy, int m, int rpw, long nchunks, double* __restrict__ dot_partial,
+    const int* __restrict__ sched, int sched_len) {
   constexpr int G = 64 / LPR;  // non-zeros per wave instruction
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -68,7 +69,22 @@ __global__ __launch_bounds__(256) void spmm_pad8_kernel(
   const bool act = c0 < m;
   const double* __restrict__ xl = x + (act ? c0 : 0);  // inactive lanes re-read column 0 (never stored)
   double d0 = 0.0, d1 = 0.0;
- for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+  // Chunk order.  Default: chunk = blockIdx.x, += gridDim.x (the chip sweeps the matrix front to back).
+  // With a schedule (8 lists of sched_len chunk ids, one per XCD; -1 = empty slot) the blocks that share
+  // an XCD (blockIdx.x % 8, observed round-robin placement: speed only, never correctness) walk THEIR list
+  // together, so a list that enumerates the matrix brick by brick keeps a brick's X rows in that XCD's L2.
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, Jx = gridDim.x >> 3;
+ for (long it = 0;; ++it) {
+  long chunk;
+  if (sched != nullptr) {
+    const long pos = it * Jx + jx;
+    if (pos >= sched_len) break;
+    chunk = sched[(long)xcd * sched_len + pos];
+    if (chunk < 0) continue;
+  } else {
+    chunk = blockIdx.x + it * (long)gridDim.x;
+    if (chunk >= nchunks) break;
+  }
   const long row0 = (chunk * 4 + wave) * (long)rpw;
   if (row0 >= nrows) continue;
   const int nr = min(rpw, (int)(nrows - row0));
@@ -180,6 +196,11 @@ extern "C" void gcge_hip_spmm_pad8_tune(int rows_per_wave, int batch, int store_
 
 static int g_p8_gridcap = 0;   // 0: one chunk per block
 extern "C" void gcge_hip_spmm_pad8_gridcap(int cap) { g_p8_gridcap = cap; }
+// optional per-XCD chunk schedule (device array of 8*len ints) valid for ONE rows-per-wave value
+static const int* g_p8_sched = nullptr; static int g_p8_sched_len = 0, g_p8_sched_rpw = 0, g_p8_sched_grid = 0;
+extern "C" void gcge_hip_spmm_pad8_schedule(const int* d_sched, int len, int rows_per_wave, int grid) {
+  g_p8_sched = d_sched; g_p8_sched_len = len; g_p8_sched_rpw = rows_per_wave; g_p8_sched_grid = grid;
+}
 
 template <int LPR, int BATCH, int ST>
 static void p8_launch(int nrows, const int* orp, const int* pcol, const double* pval,
@@ -188,8 +209,10 @@ static void p8_launch(int nrows, const int* orp, const int* pcol, const double* 
   const long nchunks = ((long)nrows + rows_per_block - 1) / rows_per_block;
   long grid = nchunks;
   if (g_p8_gridcap > 0 && grid > g_p8_gridcap) grid = g_p8_gridcap;
+  const int* sched = nullptr; int slen = 0;
+  if (g_p8_sched != nullptr && g_p8_sched_rpw == g_p8_rpw) { sched = g_p8_sched; slen = g_p8_sched_len; grid = g_p8_sched_grid; }
   hipLaunchKernelGGL((spmm_pad8_kernel<LPR, BATCH, ST, 0>), dim3((unsigned)grid), dim3(256), 0, st, nrows, orp,
-                     pcol, pval, x, ldx, y, ldy, m, g_p8_rpw, nchunks, (double*)nullptr);
+                     pcol, pval, x, ldx, y, ldy, m, g_p8_rpw, nchunks, (double*)nullptr, sched, slen);
 }
 // fused SpMM + column dots: rows_per_wave fixed at 4, at most `grid` partial rows
 template <int LPR>
@@ -197,7 +220,7 @@ static void p8_launch_dot(int nrows, const int* orp, const int* pcol, const doub
                           size_t ldx, double* y, size_t ldy, int m, double* partial, long grid, hipStream_t st) {
   const long nchunks = ((long)nrows + 15) / 16;
   hipLaunchKernelGGL((spmm_pad8_kernel<LPR, 4, 1, 1>), dim3((unsigned)grid), dim3(256), 0, st, nrows, orp, pcol,
-                     pval, x, ldx, y, ldy, m, 4, nchunks, partial);
+                     pval, x, ldx, y, ldy, m, 4, nchunks, partial, (const int*)nullptr, 0);
 }
 template <int LPR, int BATCH>
 static void p8_store(int nrows, const int* orp, const int* pcol, const double* pval,

@@ -88,6 +88,11 @@ int gcge_hip_pad8_spmm (int nrows, const int *d_orp, const int *d_pcol, const do
 /* K2  G(k x m, row-major on device, ld m) = Q[:,0:k)^T P[:,0:m)  over nrows rows (MFMA f64) */
 int gcge_hip_gram (int nrows, const double *d_q, long ldq, int k, const double *d_p, long ldp, int m,
 		double *d_g, void *stream);
+/*     experimental narrow-pass variant (16 columns per pass, 8 rows per wave instruction: keeps a grid plane of X
+ *     in L2; csrc/hip/spmm_sell8.hip); gcge_hip_set_spmm_path(1) routes MatDotMultiVec through it              */
+int gcge_hip_sell8_spmm (int nrows, const int *d_orp, const int *d_pcol, const double *d_pval,
+		const double *d_x, long ldx, double *d_y, long ldy, int ncols, void *stream);
+void gcge_hip_set_spmm_path (int path);
 /*     d_out[j] = sum_r x[r,j] y[r,j] */
 int gcge_hip_coldots (int nrows, const double *d_x, long ldx, const double *d_y, long ldy, int m,
 		double *d_out, void *stream);

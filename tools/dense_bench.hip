@@ -1,0 +1,41 @@
+// Micro-benchmark of K2 (Gram) and K3 (panel update) at the C2 shapes.  Not part of the product.
+// hipcc -O3 --offload-arch=gfx950 -I gcge_amd/csrc/hip -I include tools/dense_bench.hip gcge_amd/csrc/hip/gram_mfma.hip gcge_amd/csrc/hip/lincomb_mfma.hip gcge_amd/csrc/hip/vec_kernels.hip -o /tmp/dense_bench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "gcge_hip_internal.h"
+extern "C" int gcge_hip_gram(int, const double*, long, int, const double*, long, int, double*, void*);
+extern "C" int gcge_hip_lincomb(int, const double*, long, int, const double*, int, const double*, double*, long, void*);
+__global__ void fillk(double* x, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += st) { unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull; z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
+    x[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+}
+int main(int argc, char** argv) {
+  long n = argc > 1 ? atol(argv[1]) : 16777216; int reps = 3;
+  const long ldv = 256, ldw = 128;
+  double *V, *W, *G, *C;
+  GCGE_HIP_CHECK(hipMalloc(&V, n * ldv * 8)); GCGE_HIP_CHECK(hipMalloc(&W, n * ldw * 8));
+  GCGE_HIP_CHECK(hipMalloc(&G, 656 * 656 * 8)); GCGE_HIP_CHECK(hipMalloc(&C, 656 * 128 * 8));
+  fillk<<<4096, 256>>>(V, n * ldv); fillk<<<4096, 256>>>(W, n * ldw); fillk<<<64, 256>>>(C, 656 * 128);
+  GCGE_HIP_CHECK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  int gk[] = {256, 192, 128, 64, 64}, gm[] = {64, 64, 64, 64, 1};
+  for (int i = 0; i < 5; ++i) {
+    int k = gk[i], m = gm[i];
+    gcge_hip_gram((int)n, V, ldv, k, W, ldw, m, G, 0); hipDeviceSynchronize();
+    hipEventRecord(e0); for (int r = 0; r < reps; ++r) gcge_hip_gram((int)n, V, ldv, k, W, ldw, m, G, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("gram    k=%3d m=%3d  %8.3f ms  %6.1f TF  %7.1f GB/s (min traffic)\n", k, m, ms, 2.0 * n * k * m / ms * 1e-9, 8.0 * n * (k + m) / ms * 1e-6);
+  }
+  int lk[] = {256, 256, 192, 64, 1}, lm[] = {128, 64, 64, 64, 63};
+  for (int i = 0; i < 5; ++i) {
+    int k = lk[i], m = lm[i];
+    gcge_hip_lincomb((int)n, V, ldv, k, C, m, nullptr, W, ldw, 0); hipDeviceSynchronize();
+    hipEventRecord(e0); for (int r = 0; r < reps; ++r) gcge_hip_lincomb((int)n, V, ldv, k, C, m, nullptr, W, ldw, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("lincomb k=%3d m=%3d  %8.3f ms  %6.1f TF  %7.1f GB/s (min traffic)\n", k, m, ms, 2.0 * n * k * m / ms * 1e-9, 8.0 * n * (k + m) / ms * 1e-6);
+  }
+  return 0;
+}

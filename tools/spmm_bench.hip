@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <array>
+#include <algorithm>
 #include "gcge_hip_internal.h"
 
 extern "C" int gcge_hip_csr_spmm(int nrows, const int*, const int*, const double*, const double*,
@@ -16,6 +18,10 @@ extern "C" void gcge_hip_spmm_variant(int variant, int batch);
 extern "C" int gcge_hip_pad8_spmm(int nrows, const int*, const int*, const double*, const double*,
                                   long, double*, long, int, void*);
 extern "C" void gcge_hip_spmm_pad8_tune(int rows_per_wave, int batch, int store_policy, int col_pass);
+extern "C" void gcge_hip_spmm_pad8_gridcap(int cap);
+extern "C" int gcge_hip_sell8_spmm(int, const int*, const int*, const double*, const double*, long, double*, long, int, void*);
+extern "C" void gcge_hip_spmm_sell8_tune(int);
+extern "C" void gcge_hip_spmm_pad8_schedule(const int* d_sched, int len, int rows_per_wave, int grid);
 
 __global__ void fill_kernel(double* x, size_t n, unsigned seed) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,6 +137,61 @@ int main(int argc, char** argv) {
     printf("single config done\n");
     return 0;
   }
+  if (getenv("BRICKS")) {
+    // per-XCD brick schedules: brick = bx x by x bz grid points, chunk = 4*rpw consecutive rows along i
+    struct Cfg { int bx, by, bz, rpw, grid, store; };
+    std::vector<Cfg> cfgs;
+    for (int store : {1, 2})
+      for (int rpw : {4, 8})
+        for (int grid : {1024, 2048, 4096})
+          for (auto b : {std::array<int,3>{16,16,16}, {32,16,8}, {32,8,8}, {16,16,8}, {64,8,8}, {32,16,16}, {256,4,4}, {256,8,2}, {256,2,8}})
+            cfgs.push_back({b[0], b[1], b[2], rpw, grid, store});
+    int one[6] = {0,0,0,0,0,0}; bool only = false;
+    if (getenv("BRICK_ONE")) { only = sscanf(getenv("BRICK_ONE"), "%d,%d,%d,%d,%d,%d", &one[0], &one[1], &one[2], &one[3], &one[4], &one[5]) == 6; }
+    for (auto& c : cfgs) {
+      if (only && !(c.bx == one[0] && c.by == one[1] && c.bz == one[2] && c.rpw == one[3] && c.grid == one[4] && c.store == one[5])) continue;
+      const int rpb = 4 * c.rpw;
+      if (c.bx % rpb || N % c.bx || N % c.by || N % c.bz) continue;
+      std::vector<std::vector<int>> lists(8);
+      int t = 0;
+      for (int k0 = 0; k0 < N; k0 += c.bz) for (int j0 = 0; j0 < N; j0 += c.by) for (int i0 = 0; i0 < N; i0 += c.bx, ++t) {
+        auto& L = lists[t % 8];
+        for (int k = k0; k < k0 + c.bz; ++k) for (int j = j0; j < j0 + c.by; ++j) for (int ic = i0 / rpb; ic < (i0 + c.bx) / rpb; ++ic)
+          L.push_back(ic + (N / rpb) * (j + N * k));
+      }
+      size_t len = 0; for (auto& L : lists) len = std::max(len, L.size());
+      std::vector<int> sched(8 * len, -1);
+      for (int x = 0; x < 8; ++x) for (size_t q = 0; q < lists[x].size(); ++q) sched[x * len + q] = lists[x][q];
+      int* d_s; GCGE_HIP_CHECK(hipMalloc(&d_s, sched.size() * sizeof(int)));
+      GCGE_HIP_CHECK(hipMemcpy(d_s, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice));
+      gcge_hip_spmm_pad8_tune(c.rpw, 4, c.store, 0);
+      gcge_hip_spmm_pad8_schedule(d_s, (int)len, c.rpw, c.grid);
+      gcge_hip_pad8_spmm((int)n, d_orp, d_pc, d_pv, d_x + x0, ldx, d_y, m, m, 0);
+      GCGE_HIP_CHECK(hipDeviceSynchronize());
+      hipEventRecord(e0);
+      for (int r = 0; r < reps; ++r) gcge_hip_pad8_spmm((int)n, d_orp, d_pc, d_pv, d_x + x0, ldx, d_y, m, m, 0);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      printf("brick %3dx%2dx%2d rpw=%d grid=%4d store=%d  %8.3f ms  %8.1f GB/s alg (%.1f%%)\n", c.bx, c.by, c.bz, c.rpw, c.grid,
+             c.store, ms, alg_bytes * 1e-6 / ms, alg_bytes * 1e-6 / ms / 80.0);
+      gcge_hip_spmm_pad8_schedule(nullptr, 0, 0, 0);
+      hipFree(d_s);
+    }
+    // grid-stride without schedule for comparison
+    for (int cap : {0, 2048, 4096, 8192, 16384}) {
+      if (only && cap != 0) continue;
+      gcge_hip_spmm_pad8_tune(4, 4, 1, 0); gcge_hip_spmm_pad8_gridcap(cap);
+      gcge_hip_pad8_spmm((int)n, d_orp, d_pc, d_pv, d_x + x0, ldx, d_y, m, m, 0);
+      GCGE_HIP_CHECK(hipDeviceSynchronize());
+      hipEventRecord(e0);
+      for (int r = 0; r < reps; ++r) gcge_hip_pad8_spmm((int)n, d_orp, d_pc, d_pv, d_x + x0, ldx, d_y, m, m, 0);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      printf("gridcap %5d  %8.3f ms (%.1f%%)\n", cap, ms, alg_bytes * 1e-6 / ms / 80.0);
+    }
+    gcge_hip_spmm_pad8_gridcap(0);
+    if (only) return 0;
+  }
   double best = 1e30;
   int rpw_list[] = {2, 4, 8};
   int batch_list[] = {4, 8, 16};
@@ -161,6 +222,20 @@ int main(int argc, char** argv) {
         }
   printf("best %.3f ms  alg bytes %.3f GB\n", best, alg_bytes * 1e-9);
 
+  if (getenv("SELL8")) {
+    for (int spw : {1, 2, 4, 8}) {
+      gcge_hip_spmm_sell8_tune(spw);
+      GCGE_HIP_CHECK(hipMemset(d_y, 0xff, n * (size_t)m * sizeof(double)));
+      int rc = gcge_hip_sell8_spmm((int)n, d_orp, d_pc, d_pv, d_x + x0, ldx, d_y, m, m, 0);
+      if (rc) { printf("sell8 rc=%d\n", rc); return 2; }
+      GCGE_HIP_CHECK(hipDeviceSynchronize());
+      hipEventRecord(e0);
+      for (int r = 0; r < reps; ++r) gcge_hip_sell8_spmm((int)n, d_orp, d_pc, d_pv, d_x + x0, ldx, d_y, m, m, 0);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      printf("sell8 spw=%d  %8.3f ms  %8.1f GB/s alg  (%.1f%% of 8 TB/s)\n", spw, ms, alg_bytes * 1e-6 / ms, alg_bytes * 1e-6 / ms / 80.0);
+    }
+  }
   // verification on sampled rows against a host recomputation
   std::vector<double> hy(64 * (size_t)m), hx;
   double maxerr = 0.0;
