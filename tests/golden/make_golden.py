@@ -168,11 +168,19 @@ for key, kind, size, nev, extra, kw in (
         ("sio2_12_nev10", "sio2", 12, 10, (), {}),
         ("lap3d_12_nev10_bgsX", "lap3d", 12, 10, ("-gcge_initX_orth_method", "bgs"), {}),
         ("lap3d_12_nev10_bqrP", "lap3d", 12, 10, ("-gcge_compP_orth_method", "bqr"), {}),
+        # X grows from nevInit to nevMax as pairs lock (ops_eig_sol_gcg.c:1281,1395-1412)
+        ("fe3d_14_nev20_init30", "fe3d", 14, 20, (), {"nev_max": 40, "block": 10, "nev_init": 30}),
+        ("lap3d_16_nev20_init24", "lap3d", 16, 20, (), {"nev_max": 40, "block": 8, "nev_init": 24}),
+        # shifted W solves (A + sigma B) W = ..., fixed and automatic sigma (ops_eig_sol_gcg.c:483-497,709)
+        ("lap3d_12_nev10_shift1", "lap3d", 12, 10, ("-gcge_compW_cg_shift", "1.0"), {}),
+        ("lap3d_12_nev10_autoshift", "lap3d", 12, 10, ("-gcge_compW_cg_auto_shift", "1"), {}),
+        ("fe3d_12_nev10_autoshift", "fe3d", 12, 10, ("-gcge_compW_cg_auto_shift", "1"), {}),
 ):
     A, B = make_problem(kind, size, K=6, R0=1.5, R1=2.0, seed=12345)
-    ev, conv, it, sec = po.ref_gcg(A, B, nev, nev_max=kw.get("nev_max", 0), block=kw.get("block", 0), extra=extra)
+    ev, conv, it, sec = po.ref_gcg(A, B, nev, nev_max=kw.get("nev_max", 0), block=kw.get("block", 0),
+                                  nev_init=kw.get("nev_init", 0), extra=extra)
     runs[key] = {"kind": kind, "size": size, "nev": nev, "nev_max": kw.get("nev_max", 0), "block": kw.get("block", 0),
-                 "extra": list(extra), "n": A.nrows, "nnz": int(A.nnz), "nevConv": conv, "numIter": it,
+                 "nev_init": kw.get("nev_init", 0), "extra": list(extra), "n": A.nrows, "nnz": int(A.nnz), "nevConv": conv, "numIter": it,
                  "eval": ev[:conv].tolist()}
     print(key, "conv", conv, "it", it, "%.3fs" % sec, "lambda1 %.14e" % ev[0])
 with open(os.path.join(HERE, "gcg.json"), "w") as f:
