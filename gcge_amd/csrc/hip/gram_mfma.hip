@@ -29,7 +29,36 @@ namespace gcge {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// Fragment loads of one macro-step (4*MS rows): no predication at all, so the compiler is free to keep
+// all 8*MS loads of a wave in flight (any select/branch next to a load makes hipcc wait with vmcnt(0)
+// after every pair of loads: measured 15 TF).  `row` is wave-uniform.
+template <int MS>
+__device__ __forceinline__ void gram_load(double (&af)[MS][4], double (&bf)[MS][4], const double* const (&qp)[4],
+                                          const double* const (&pp)[4], long row, long ldq, long ldp) {
+#pragma unroll
+  for (int u = 0; u < MS; ++u)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      af[u][a] = qp[a][(row + 4 * u) * ldq];
+      bf[u][a] = pp[a][(row + 4 * u) * ldp];
+    }
+}
+
+template <int MS>
+__device__ __forceinline__ void gram_mfma(v4d (&acc)[4][4], const double (&af)[MS][4], const double (&bf)[MS][4]) {
+#pragma unroll
+  for (int u = 0; u < MS; ++u)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u][a], bf[u][b], acc[a][b], 0, 0, 0);
+}
+
 // One block: output tile rows [i0,i0+64) x cols [j0,j0+64), matrix rows [r0,r1).
+// Columns beyond k (or m) are not masked: those lanes read column 0 of the block instead, which only
+// pollutes output entries (i >= k or j >= m) that the reduction kernel never reads.
+template <int MS>
 __global__ __launch_bounds__(256) void gram_tile_kernel(long nrows, const double* __restrict__ q, long ldq,
     int k, const double* __restrict__ p, long ldp, int m, double* __restrict__ slab, long rows_per_chunk,
     int ntile_i, int ntile_j) {
@@ -47,48 +76,54 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(long nrows, const double
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  // column validity of my fragment lanes (partial tiles are zero-padded)
-  bool qa[4], pb[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) { qa[a] = (i0 + 16 * a + li) < k; pb[a] = (j0 + 16 * a + li) < m; }
-  // unconditional loads (a branch around a load serialises the wave on vmcnt(0)):
-  // out-of-range columns read column 0, out-of-range rows read the last row, then a select zeroes them
-  const double* qcol[4];
-  const double* pcol[4];
+  // per-lane fragment origins: row kk of a 4-row step, my column of each 16-column fragment
+  const double* qp[4];
+  const double* pp[4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    qcol[a] = qa[a] ? (q + i0 + 16 * a + li) : q;
-    pcol[a] = pb[a] ? (p + j0 + 16 * a + li) : p;
+    const int qc = i0 + 16 * a + li, pc = j0 + 16 * a + li;
+    qp[a] = q + (long)kk * ldq + (qc < k ? qc : 0);
+    pp[a] = p + (long)kk * ldp + (pc < m ? pc : 0);
   }
 
-  // A wave owns 4*MS consecutive rows per macro-step: all fragment loads of the macro-step are issued
-  // before its MFMAs, so several KB per wave are in flight while the previous results are consumed
-  // (a 4-row step at a time leaves the loop latency-bound: measured 8 TF).
-  constexpr int MS = 2;   // 4-row steps per macro-step (MS = 4 needs 288 registers: 1 wave/SIMD)
-  for (long base = r0 + 4 * MS * wave; base < r1; base += 16 * MS) {
-    double af[MS][4], bf[MS][4];
-#pragma unroll
-    for (int u = 0; u < MS; ++u) {
-      const long rr = base + 4 * u + kk;
-      const bool rv = rr < r1;
-      const long rc = min(rr, nrows - 1);
+  // macro-steps of 4*MS rows are dealt round-robin to the four waves; two register sets so the
+  // loads of the next macro-step are in flight while the MFMAs of the current one issue
+  const long full = (r1 - r0) / (4 * MS);
+  long s = wave;
+  if (s < full) {
+    // my macro-steps: s, s+4, ...; processed in pairs with two register sets.  No branch and no copy inside the
+    // loop (hipcc sinks loads into a conditional consumer, and a register copy waits for the prefetch); the
+    // scheduling barriers keep the machine scheduler from moving the prefetch below the MFMAs it overlaps.
+    const long cnt = (full - s + 3) / 4, last = s + 4 * (cnt - 1);
+    double a0[MS][4], b0[MS][4], a1[MS][4], b1[MS][4];
+    gram_load<MS>(a0, b0, qp, pp, r0 + s * (4 * MS), ldq, ldp);
+    for (long i = 0; i < cnt / 2; ++i, s += 8) {
+      gram_load<MS>(a1, b1, qp, pp, r0 + (s + 4) * (4 * MS), ldq, ldp);
+      __builtin_amdgcn_sched_barrier(0);
+      gram_mfma<MS>(acc, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      gram_load<MS>(a0, b0, qp, pp, r0 + (s + 8 < last ? s + 8 : last) * (4 * MS), ldq, ldp);   // clamped
+      __builtin_amdgcn_sched_barrier(0);
+      gram_mfma<MS>(acc, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (cnt & 1) gram_mfma<MS>(acc, a0, b0);   // a0/b0 hold macro-step `last`
+  }
+  // the last (r1 - r0) mod 4*MS rows: predicated 4-row steps on wave 0 (at most MS of them per block)
+  if (wave == 0) {
+    for (long base = r0 + full * (4 * MS); base < r1; base += 4) {
+      const bool rv = base + kk < r1;
+      const long off = rv ? base : (r1 - 1 - kk);   // any valid row; the select below zeroes it
+      double af[1][4], bf[1][4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        double qv = qcol[a][rc * ldq], pv = pcol[a][rc * ldp];
-        // keep the loads unconditional: without this hipcc sinks each load into its select and puts a
-        // branch + s_waitcnt vmcnt(0) around every one of them (seen in the ISA; 10 TF instead of 30+)
+        double qv = qp[a][off * ldq], pv = pp[a][off * ldp];
         asm volatile("" : "+v"(qv), "+v"(pv));
-        af[u][a] = (rv && qa[a]) ? qv : 0.0;
-        bf[u][a] = (rv && pb[a]) ? pv : 0.0;
+        af[0][a] = rv ? qv : 0.0;
+        bf[0][a] = rv ? pv : 0.0;
       }
+      gram_mfma<1>(acc, af, bf);
     }
-#pragma unroll
-    for (int u = 0; u < MS; ++u)
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u][a], bf[u][b], acc[a][b], 0, 0, 0);
   }
 
   // combine the four waves: wave 0 stores, the others add (LDS f64 atomics avoided: sequenced)
@@ -131,6 +166,9 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
 
 using namespace gcge;
 
+static int g_gram_ms = 4;   // measured: MS 1/2/4 = 36.8 / 42.3 / 45.2 TF at k=256, m=64, n=2^24 (profiles/r01_dense)
+extern "C" void gcge_hip_gram_tune(int ms) { if (ms == 1 || ms == 2 || ms == 4) g_gram_ms = ms; }
+
 extern "C" int gcge_hip_gram(int nrows, const double* d_q, long ldq, int k, const double* d_p, long ldp,
                              int m, double* d_g, void* stream) {
   if (k <= 0 || m <= 0) return 0;
@@ -144,8 +182,10 @@ extern "C" int gcge_hip_gram(int nrows, const double* d_q, long ldq, int k, cons
   if (rpc < 64) rpc = 64;
   nchunks = ((long)nrows + rpc - 1) / rpc;
   double* slab = gcge_hip_partial_ws((size_t)nchunks * ti * tj * 4096);
-  hipLaunchKernelGGL(gram_tile_kernel, dim3((unsigned)nchunks, ti, tj), dim3(256), 0, st, (long)nrows, d_q,
-                     ldq, k, d_p, ldp, m, slab, rpc, ti, tj);
+#define GCGE_GRAM(MS) hipLaunchKernelGGL(gram_tile_kernel<MS>, dim3((unsigned)nchunks, ti, tj), dim3(256), 0, st, \
+                                         (long)nrows, d_q, ldq, k, d_p, ldp, m, slab, rpc, ti, tj)
+  if (g_gram_ms == 1) GCGE_GRAM(1); else if (g_gram_ms == 4) GCGE_GRAM(4); else GCGE_GRAM(2);
+#undef GCGE_GRAM
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(16, ti, tj), dim3(256), 0, st, slab, (int)nchunks, ti, tj, k, m,
                      d_g);
   return (int)hipGetLastError();

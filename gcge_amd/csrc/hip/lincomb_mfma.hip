@@ -16,6 +16,12 @@
 //     B: lane l holds C[k0 + (l >> 4)][16 t + (l & 15)]        (LDS, row stride = 16 mod 32)
 //     D: lane l, reg u holds Y[r0 + 16 w + 4 u + (l >> 4)][16 t + (l & 15)]
 //
+// No load in the main loop is predicated (a select or branch next to a load makes hipcc wait with
+// vmcnt(0) after every single load: measured 23 TF): rows beyond nrows and columns beyond k are
+// CLAMPED to the last valid one, and the coefficient block is first copied into a zero-padded
+// (k rounded to 32) x (16 NT) workspace, so a clamped X column meets a zero coefficient row and a
+// clamped X row only feeds output rows that are never stored.
+//
 // In-place use (x == y with disjoint column ranges, ops_orth.c:70,90,253) is safe:
 // a block reads and writes only its own 64 rows and never the same columns.
 // Roofline: 2 n k m flops (FP64 MFMA) vs 8 n (k + m [+ m]) bytes.
@@ -32,7 +38,7 @@ constexpr int LC_XS = LC_KT + 2;   // LDS row stride of the X tile (doubles)
 
 template <int NT>  // NT 16-column output fragments per wave: m <= 16 NT
 __global__ __launch_bounds__(256) void lincomb_kernel(long nrows, const double* x, long ldx, int k,
-    const double* __restrict__ c, int m, const double* __restrict__ beta, double* y, long ldy, int cs) {
+    const double* __restrict__ cpad, int m, const double* __restrict__ beta, double* y, long ldy, int cs) {
   extern __shared__ __align__(16) double lds[];
   double* xs = lds;                 // [64][LC_XS]
   double* cst = lds + 64 * LC_XS;   // [LC_KT][cs]
@@ -48,34 +54,33 @@ __global__ __launch_bounds__(256) void lincomb_kernel(long nrows, const double* 
   // current one run; it is written to LDS after the barrier that ends the current tile
   constexpr int XE = 64 * LC_KT / 256;            // X elements per thread and tile (8)
   constexpr int CE = LC_KT * 16 * NT / 256;       // C elements per thread and tile (2 NT)
-  double xr[XE];
+  double xr[XE], cr[CE];
   auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < CE; ++q) {
+      const int e = threadIdx.x + 256 * q, row = e / (16 * NT), col = e % (16 * NT);
+      cr[q] = cpad[(long)(k0 + row) * (16 * NT) + col];
+    }
 #pragma unroll
     for (int q = 0; q < XE; ++q) {
       const int e = threadIdx.x + 256 * q, row = e / LC_KT, col = e % LC_KT;
       const long gr = min(r0 + row, nrows - 1);
       const int gc = min(k0 + col, k - 1);
-      double v = x[gr * ldx + gc];
-      asm volatile("" : "+v"(v));   // unconditional load (see gram_mfma.hip)
-      xr[q] = (r0 + row < nrows && k0 + col < k) ? v : 0.0;
+      xr[q] = x[gr * ldx + gc];
     }
   };
-  // the coefficient tile is small and L2-resident: it goes straight to LDS (no register stage)
-  auto stash = [&](int k0) {
+  auto stash = [&]() {
 #pragma unroll
     for (int q = 0; q < XE; ++q) { const int e = threadIdx.x + 256 * q; xs[(e / LC_KT) * LC_XS + e % LC_KT] = xr[q]; }
 #pragma unroll
     for (int q = 0; q < CE; ++q) {
       const int e = threadIdx.x + 256 * q, row = e / (16 * NT), col = e % (16 * NT);
-      const int gr = min(k0 + row, k - 1), gc = min(col, m - 1);
-      double v = c[(long)gr * m + gc];
-      asm volatile("" : "+v"(v));
-      cst[row * cs + col] = (k0 + row < k && col < m) ? v : 0.0;
+      cst[row * cs + col] = cr[q];
     }
   };
   fetch(0);
   for (int k0 = 0; k0 < k; k0 += LC_KT) {
-    stash(k0);
+    stash();
     __syncthreads();
     if (k0 + LC_KT < k) fetch(k0 + LC_KT);
 #pragma unroll
@@ -89,35 +94,65 @@ __global__ __launch_bounds__(256) void lincomb_kernel(long nrows, const double* 
     }
     __syncthreads();
   }
-  // epilogue: Y = acc + beta_j * Y
+  // epilogue: Y = acc + beta_j * Y.  The old Y values are fetched with clamped (row, column) and no
+  // predicate so that all 4 NT loads of a lane are in flight together; only the stores are guarded.
+  if (beta != nullptr) {
+    double yv[NT][4], bj[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int colc = min(16 * t + li, m - 1);
+      bj[t] = beta[colc];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) yv[t][u] = y[min(r0 + 16 * wave + 4 * u + kk, nrows - 1) * ldy + colc];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[t][u] = fma(bj[t], yv[t][u], acc[t][u]);
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = 16 * t + li;
-    if (col >= m) continue;
-    const double bj = (beta != nullptr) ? beta[col] : 0.0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long row = r0 + 16 * wave + 4 * u + kk;
-      if (row < nrows) {
-        double* py = y + row * ldy + col;
-        *py = (beta != nullptr) ? fma(bj, *py, acc[t][u]) : acc[t][u];
-      }
+      if (col < m && row < nrows) y[row * ldy + col] = acc[t][u];
     }
   }
 }
 
 }  // namespace gcge
 
+// cpad (kp x mp, row-major, zero outside k x m) <- c (k x m, row-major)
+__global__ __launch_bounds__(256) void lincomb_pad_c(const double* __restrict__ c, int k, int m, double* __restrict__ cpad,
+                                                     int kp, int mp) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= kp * mp) return;
+  const int row = e / mp, col = e % mp;
+  cpad[e] = (row < k && col < m) ? c[(long)row * m + col] : 0.0;
+}
+
 using namespace gcge;
 
+static double* g_cpad = nullptr;
+static size_t g_cpad_len = 0;
+
 template <int NT>
-static void lc_launch(int nrows, const double* x, long ldx, int k, const double* c, int m,
-                      const double* beta, double* y, long ldy, hipStream_t st) {
+static int lc_launch(int nrows, const double* x, long ldx, int k, const double* c, int m,
+                     const double* beta, double* y, long ldy, hipStream_t st) {
+  const int kp = (k + LC_KT - 1) / LC_KT * LC_KT, mp = 16 * NT;
+  if ((size_t)kp * mp > g_cpad_len) {   // grows rarely; freeing synchronises with kernels still reading the old one
+    if (g_cpad) GCGE_HIP_CHECK(hipFree(g_cpad));
+    g_cpad_len = (size_t)kp * mp * 2;
+    GCGE_HIP_CHECK(hipMalloc(&g_cpad, g_cpad_len * sizeof(double)));
+  }
+  hipLaunchKernelGGL(lincomb_pad_c, dim3((kp * mp + 255) / 256), dim3(256), 0, st, c, k, m, g_cpad, kp, mp);
   const int cs = (16 * NT + 31) / 32 * 32 + 16;  // row stride of the C tile: 16 mod 32 doubles
   const size_t shmem = (size_t)(64 * LC_XS + LC_KT * cs) * sizeof(double);
   const unsigned grid = (unsigned)(((long)nrows + 63) / 64);
-  hipLaunchKernelGGL((lincomb_kernel<NT>), dim3(grid), dim3(256), shmem, st, (long)nrows, x, ldx, k, c, m, beta,
+  hipLaunchKernelGGL((lincomb_kernel<NT>), dim3(grid), dim3(256), shmem, st, (long)nrows, x, ldx, k, g_cpad, m, beta,
                      y, ldy, cs);
+  return 0;
 }
 
 // d_c: row-major k x m coefficient block on the device; d_beta: m scale factors or NULL

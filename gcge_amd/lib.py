@@ -98,8 +98,9 @@ def make_argv(args):
     return len(args), arr
 
 
-def run_gcg(ops, matA, matB, args, flag=0, quiet=True):
-    """GCGE_RunGCG through the operator table `ops` (a void* OPS handle)."""
+def run_gcg(ops, matA, matB, args, flag=0, quiet=True, keep_evec=False):
+    """GCGE_RunGCG through the operator table `ops` (a void* OPS handle).
+    keep_evec: also return the eigenvector multivector handle (nevMax columns; the caller destroys it)."""
     import numpy as np
     h = host_lib()
     args = ["gcge"] + [str(a) for a in args]
@@ -116,10 +117,13 @@ def run_gcg(ops, matA, matB, args, flag=0, quiet=True):
     nev_max = nev_max or 2 * nev
     ev = np.zeros(nev_max)
     res = RunResult()
+    evec = C.c_void_p()
     rc = h.GCGE_RunGCG(matA, matB, flag, argc, argv, ops,
-                       ev.ctypes.data_as(C.POINTER(C.c_double)), None, C.byref(res))
+                       ev.ctypes.data_as(C.POINTER(C.c_double)), C.byref(evec) if keep_evec else None, C.byref(res))
     if rc != 0:
         raise RuntimeError("GCGE_RunGCG rc=%d" % rc)
+    if keep_evec:
+        return ev, res, evec
     return ev, res
 
 

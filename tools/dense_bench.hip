@@ -6,6 +6,7 @@
 #include <vector>
 #include "gcge_hip_internal.h"
 extern "C" int gcge_hip_gram(int, const double*, long, int, const double*, long, int, double*, void*);
+extern "C" void gcge_hip_gram_tune(int);
 extern "C" int gcge_hip_lincomb(int, const double*, long, int, const double*, int, const double*, double*, long, void*);
 __global__ void fillk(double* x, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
@@ -22,8 +23,10 @@ int main(int argc, char** argv) {
   GCGE_HIP_CHECK(hipDeviceSynchronize());
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   int gk[] = {256, 192, 128, 64, 64}, gm[] = {64, 64, 64, 64, 1};
+  for (int ms = 1; ms <= 4; ms *= 2)
   for (int i = 0; i < 5; ++i) {
     int k = gk[i], m = gm[i];
+    gcge_hip_gram_tune(ms); if (i == 0) printf("gram MS=%d\n", ms);
     gcge_hip_gram((int)n, V, ldv, k, W, ldw, m, G, 0); hipDeviceSynchronize();
     hipEventRecord(e0); for (int r = 0; r < reps; ++r) gcge_hip_gram((int)n, V, ldv, k, W, ldw, m, G, 0);
     hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;

@@ -1,0 +1,96 @@
+"""Run one eigenproblem through the HIP operator table and check it independently.
+
+    python tools/run_case.py --kind fe3d --size 100 --nev 100 --block 128 --nevmax 256      # BASELINE config 3
+    python tools/run_case.py --kind lap3d --size 50 --nev 20 --block 20 --ref                # config 1, vs the CPU reference
+    python tools/run_case.py --kind sio2 --size 86 --nev 100 --block 64 --K 60              # config 5 shape on one GPU
+
+Prints one JSON line: timing by phase, converged count, the relative residuals
+||A x - lambda B x|| / (lambda ||B x||) recomputed through the slots (not taken from the solver), and with
+--ref the relative difference of the Ritz values to the reference CPU path (oracle/_ref, same input).
+This is a measurement/parity tool, not part of the product path."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kind", default="fe3d")
+    ap.add_argument("--size", type=int, default=100)
+    ap.add_argument("--nev", type=int, default=100)
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--nevmax", type=int, default=0)
+    ap.add_argument("--orth", default="chol")
+    ap.add_argument("--flag", type=int, default=1, help="1: fused device block CG, 0: BlockPCG over the slots")
+    ap.add_argument("--rng", type=int, default=1, help="0: reference rand() stream, 1: device generator")
+    ap.add_argument("--K", type=int, default=6)
+    ap.add_argument("--R0", type=float, default=1.5)
+    ap.add_argument("--R1", type=float, default=2.0)
+    ap.add_argument("--ref", action="store_true", help="also run the CPU reference (oracle/_ref) on the same input")
+    ap.add_argument("--extra", nargs="*", default=[])
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch  # noqa: F401  (one libamdhip64 for torch and the extension)
+    from gcge_amd import HipBackend, make_problem, run_gcg
+    t0 = time.perf_counter()
+    A, B = make_problem(a.kind, a.size, K=a.K, R0=a.R0, R1=a.R1, seed=12345)
+    t_gen = time.perf_counter() - t0
+    hip = HipBackend()
+    hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    mA = hip.matrix(A)
+    mB = hip.matrix(B) if B is not None else None
+    hip.set_random_mode(a.rng, 20240601)
+    if a.flag:
+        hip.g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    args = ["-nevConv", a.nev]
+    if a.nevmax:
+        args += ["-nevMax", a.nevmax]
+    if a.block:
+        args += ["-blockSize", a.block]
+    args += ["-gcge_initX_orth_method", a.orth, "-gcge_compW_orth_method", a.orth] + list(a.extra)
+    ev, res, evec = run_gcg(hip.ops_handle, mA, mB, args, flag=a.flag, keep_evec=True)
+
+    # independent check: R = A X - B X diag(lambda) through the slots
+    ops, n, k = hip.ops, A.nrows, res.nevConv
+    ax = ops.mv_create(k, mA)
+    bx = ops.mv_create(k, mA)
+    ops.spmm(mA, evec, ax, (0, 0), (k, k))
+    ops.spmm(mB, evec, bx, (0, 0), (k, k))          # mat == NULL copies
+    nb = np.sqrt(ops.inner_prod("D", bx, bx, (0, 0), (k, k)))
+    coef = np.zeros((k, k))
+    coef[np.arange(k), np.arange(k)] = -ev[:k]
+    ops.lincomb(bx, ax, (0, 0), (k, k), np.asfortranarray(coef).ravel(order="F"), k, beta=np.ones(1), incb=0)
+    nr = np.sqrt(ops.inner_prod("D", ax, ax, (0, 0), (k, k)))
+    relres = nr / (np.abs(ev[:k]) * nb)
+    ops.mv_destroy(ax, k)
+    ops.mv_destroy(bx, k)
+
+    out = {"kind": a.kind, "size": a.size, "n": int(n), "nnz": int(A.nnz), "generalized": B is not None, "nev": a.nev,
+           "block": res.block_size, "nevMax": res.nevMax, "orth": a.orth, "fused_cg": bool(a.flag),
+           "nev_converged": int(res.nevConv), "gcg_iterations": int(res.numIter), "seconds": res.seconds,
+           "eigenpairs_per_s": res.nevConv / res.seconds, "matrix_build_seconds": t_gen,
+           "phase_seconds": {q: getattr(res.timing, q) for q in ("initX", "checkconv", "compP", "compRR", "compRV", "compW", "linsol", "total")},
+           "lambda_first": ev[:3].tolist(), "lambda_last": float(ev[k - 1]),
+           "max_rel_residual_recomputed": float(relres.max())}
+    if a.ref:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as po
+        if po.ref_lib() is None:
+            out["ref"] = "oracle/_ref not built"
+        else:
+            rv, conv, it, sec = po.ref_gcg(A, B, a.nev, nev_max=a.nevmax, block=a.block)
+            kk = min(conv, k)
+            out["ref"] = {"nev_converged": conv, "gcg_iterations": it, "seconds": sec,
+                          "max_rel_diff_ritz_values": float(np.max(np.abs(ev[:kk] - rv[:kk]) / np.abs(rv[:kk])))}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -223,7 +223,7 @@ int main(int argc, char** argv) {
   printf("best %.3f ms  alg bytes %.3f GB\n", best, alg_bytes * 1e-9);
 
   if (getenv("SELL8")) {
-    for (int spw : {1, 2, 4, 8}) {
+    for (int spw : {1, 2, 4, 7}) {
       gcge_hip_spmm_sell8_tune(spw);
       GCGE_HIP_CHECK(hipMemset(d_y, 0xff, n * (size_t)m * sizeof(double)));
       int rc = gcge_hip_sell8_spmm((int)n, d_orp, d_pc, d_pv, d_x + x0, ldx, d_y, m, m, 0);
