@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <unordered_map>
+#include <algorithm>
 
 #include "gcge_hip.h"
 #include "gcge_hip_internal.h"
@@ -24,6 +26,9 @@ int gcge_hip_pad8_spmm_dot(int nrows, const int* d_orp, const int* d_pcol, const
                            long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream);
 int gcge_hip_sell8_spmm(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval, const double* d_x, long ldx,
                         double* d_y, long ldy, int ncols, void* stream);
+int gcge_hip_pattern_width(int max_row_len);
+int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, const double* d_x, long ldx,
+                          double* d_y, long ldy, int ncols, double* d_dots, void* stream);
 int gcge_hip_colscale(int nrows, double* d_y, long ldy, int m, const double* d_s, void* stream);
 int gcge_hip_fill_uniform(int nrows, long row_begin, long nglobal, double* d_y, long ldy, int c0, int m,
                           unsigned long long seed, void* stream);
@@ -40,6 +45,7 @@ struct GCGE_HIP_MAT_ {
   int *d_rowptr, *d_colidx; double* d_val;    // CSR, LOCAL column indices (ghosts >= nrows)
   int *d_orp, *d_pcol; double* d_pval;        // pad-8 copy for the 16-byte-lane kernel
   long noct;
+  unsigned short* d_pid; void* d_tab; int npat, pat_lt; long pat_span;   // pattern format (spmm_pattern.hip); d_pid == NULL: not applicable
   // halo plan of a row-partitioned matrix (one process per GPU); nghost == 0 on a single rank
   int nsend; int* d_send_rows;                 // local rows other ranks need, grouped by destination rank
   double *sendbuf, *recvbuf; int buf_cols;     // exchange buffers (owned by the caller: torch tensors)
@@ -84,7 +90,7 @@ static hipStream_t g_stream = nullptr;
 static int g_inited = 0;
 static double* g_stage_d = nullptr; static size_t g_stage_d_len = 0;   // device staging (doubles)
 static double* g_stage_h = nullptr; static size_t g_stage_h_len = 0;   // pinned host staging
-static int g_spmm_path = 0;   // 0: pad-8 wide kernel, 1: SELL-8 passes of 16 columns
+static int g_spmm_path = 0;   // 0: automatic (pattern > pad-8 > CSR), 1: SELL-8 passes, 2: generic only (no pattern path)
 extern "C" void gcge_hip_set_spmm_path(int path) { g_spmm_path = path; }
 static int g_rand_mode = 0; static unsigned long long g_rand_seed = 0x5DEECE66Dull;
 
@@ -157,6 +163,71 @@ extern "C" long gcge_hip_profile_spmm(int ncols, double* total_ms, double* total
 }
 
 // ------------------------------------------------------------------ matrix
+// Pattern format: rows written as {(column - row, value)} in CSR order; at most 64 KB of table.  Leaves
+// A->d_pid == NULL when the matrix has too many distinct rows (irregular matrices give up after a few
+// hundred rows, so the scan costs nothing there).
+struct PatEntryH { double val; long off; };
+static void build_patterns(GCGE_HIP_MAT* A, int nrows, const int* rowptr, const int* colidx, const double* val) {
+  A->d_pid = nullptr; A->d_tab = nullptr; A->npat = 0; A->pat_lt = 0;
+  int maxlen = 0;
+  for (int r = 0; r < nrows; ++r) maxlen = std::max(maxlen, rowptr[r + 1] - rowptr[r]);
+  const int lt = gcge_hip_pattern_width(maxlen);
+  if (lt == 0 || nrows == 0) return;
+  const int maxpat = std::min(65535, (int)(64 * 1024 / (lt * sizeof(PatEntryH))));
+  std::vector<PatEntryH> tab;
+  std::unordered_map<uint64_t, std::vector<int>> byhash;
+  std::vector<unsigned short> pid((size_t)nrows);
+  auto same = [&](int p, int r) {
+    const PatEntryH* e = &tab[(size_t)p * lt];
+    const int len = rowptr[r + 1] - rowptr[r];
+    for (int k = 0; k < len; ++k) {
+      const int q = rowptr[r] + k;
+      if (e[k].off != (long)colidx[q] - r || memcmp(&e[k].val, &val[q], sizeof(double)) != 0) return false;
+    }
+    for (int k = len; k < lt; ++k) if (e[k].off != 0 || e[k].val != 0.0) return false;
+    return true;
+  };
+  int prev = -1;
+  for (int r = 0; r < nrows; ++r) {
+    if (prev >= 0 && same(prev, r)) { pid[r] = (unsigned short)prev; continue; }
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)(rowptr[r + 1] - rowptr[r]);
+    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
+      uint64_t vb; memcpy(&vb, &val[q], 8);
+      h = (h ^ (uint64_t)((long)colidx[q] - r)) * 0xBF58476D1CE4E5B9ull; h ^= h >> 29;
+      h = (h ^ vb) * 0x94D049BB133111EBull; h ^= h >> 32;
+    }
+    int found = -1;
+    std::vector<int>& cand = byhash[h];
+    for (int p : cand) if (same(p, r)) { found = p; break; }
+    if (found < 0) {
+      if ((int)(tab.size() / lt) >= maxpat) return;   // not a pattern matrix
+      found = (int)(tab.size() / lt);
+      for (int k = 0; k < lt; ++k) {
+        const int q = rowptr[r] + k;
+        PatEntryH e = {0.0, 0};
+        if (q < rowptr[r + 1]) { e.val = val[q]; e.off = (long)colidx[q] - r; }
+        tab.push_back(e);
+      }
+      cand.push_back(found);
+    }
+    pid[r] = (unsigned short)found; prev = found;
+  }
+  A->npat = (int)(tab.size() / lt); A->pat_lt = lt; A->pat_span = 0;
+  // reuse distance that matters for the launch geometry: the longest offset of the MOST FREQUENT pattern
+  // (interior rows); boundary and halo patterns may reach much further
+  std::vector<long> freq((size_t)A->npat, 0);
+  for (int r = 0; r < nrows; ++r) ++freq[pid[r]];
+  const int common = (int)(std::max_element(freq.begin(), freq.end()) - freq.begin());
+  for (int k = 0; k < lt; ++k) {
+    const long o = tab[(size_t)common * lt + k].off;
+    A->pat_span = std::max(A->pat_span, o < 0 ? -o : o);
+  }
+  GCGE_HIP_CHECK(hipMalloc(&A->d_pid, (size_t)nrows * sizeof(unsigned short)));
+  GCGE_HIP_CHECK(hipMalloc(&A->d_tab, tab.size() * sizeof(PatEntryH)));
+  GCGE_HIP_CHECK(hipMemcpy(A->d_pid, pid.data(), (size_t)nrows * sizeof(unsigned short), hipMemcpyHostToDevice));
+  GCGE_HIP_CHECK(hipMemcpy(A->d_tab, tab.data(), tab.size() * sizeof(PatEntryH), hipMemcpyHostToDevice));
+}
+
 // rows of one slab with LOCAL column indices in [0, ncols_local); columns >= nrows are halo rows
 extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, int nglobal, int row_begin,
                                                    const int* rowptr, const int* colidx, const double* val) {
@@ -193,6 +264,7 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, i
   GCGE_HIP_CHECK(hipMemcpy(A->d_orp, orp.data(), ((size_t)nrows + 1) * sizeof(int), hipMemcpyHostToDevice));
   GCGE_HIP_CHECK(hipMemcpy(A->d_pcol, pc.data(), noct * 8 * sizeof(int), hipMemcpyHostToDevice));
   GCGE_HIP_CHECK(hipMemcpy(A->d_pval, pv.data(), noct * 8 * sizeof(double), hipMemcpyHostToDevice));
+  build_patterns(A, nrows, rowptr, colidx, val);
   return A;
 }
 extern "C" GCGE_HIP_MAT* gcge_hip_mat_create(int nrows, int nglobal, int row_begin, const int* rowptr,
@@ -223,11 +295,14 @@ extern "C" void gcge_hip_mat_destroy(GCGE_HIP_MAT* A) {
   if (!A) return;
   hipFree(A->d_rowptr); hipFree(A->d_colidx); hipFree(A->d_val);
   hipFree(A->d_orp); hipFree(A->d_pcol); hipFree(A->d_pval);
+  if (A->d_pid) { hipFree(A->d_pid); hipFree(A->d_tab); }
   if (A->d_send_rows) hipFree(A->d_send_rows);
   free(A);
 }
 extern "C" int gcge_hip_mat_nrows(const GCGE_HIP_MAT* A) { return A->nrows; }
 extern "C" long gcge_hip_mat_nnz(const GCGE_HIP_MAT* A) { return A->nnz; }
+// number of row patterns the SpMM pattern path works with (0: the matrix is served by the generic pad-8 kernels)
+extern "C" int gcge_hip_mat_patterns(const GCGE_HIP_MAT* A) { return A->d_pid ? A->npat : 0; }
 
 // ------------------------------------------------------------------ multivector
 static GcgeHipMV* mv_new(int nrows, int nghost, int ncols, const GCGE_HIP_MAT_* mat) {
@@ -412,6 +487,24 @@ static void HIP_MultiVecLocalInnerProd(char nsd, void** x, void** y, int is_vec,
   }
 }
 
+// row-partitioned matrices: fetch the halo rows of X[:, c_begin : c_begin + m) from their owners
+static void halo_fetch(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, int m) {
+  if (A->nghost <= 0) return;
+  const double* dx = vx->d + c_begin;
+  GCGE_REQUIRE(A->exchange != nullptr && A->buf_cols > 0, "MatDotMultiVec: halo plan installed (gcge_hip_mat_set_halo)");
+  for (int c0 = 0; c0 < m; c0 += A->buf_cols) {
+    const int mc = (m - c0 < A->buf_cols) ? m - c0 : A->buf_cols;
+    if (A->nsend > 0) {
+      long tot = (long)A->nsend * mc, g = (tot + 255) / 256; if (g > 4096) g = 4096;
+      hipLaunchKernelGGL(halo_pack, dim3((unsigned)g), dim3(256), 0, g_stream, A->nsend, A->d_send_rows, dx + c0, vx->ld, mc, A->sendbuf);
+    }
+    A->exchange(A->sendbuf, A->recvbuf, mc, A->exchange_ctx);
+    long tot = (long)A->nghost * mc, g = (tot + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(halo_unpack, dim3((unsigned)g), dim3(256), 0, g_stream, A->nghost, A->recvbuf, mc,
+                       vx->d + (long)A->nrows * vx->ld + c_begin + c0, vx->ld);
+  }
+}
+
 // app_ccs.c:50-139;  mat == NULL copies (identity B)
 static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* end, struct OPS_* ops) {
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
@@ -430,20 +523,7 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
   const double* dx = vx->d + start[0];
   double* dy = vy->d + start[1];
   int rc = -1;
-  if (A->nghost > 0) {   // row-partitioned: fetch the halo rows of X[:, start[0]:end[0]) from their owners
-    GCGE_REQUIRE(A->exchange != nullptr && A->buf_cols > 0, "MatDotMultiVec: halo plan installed (gcge_hip_mat_set_halo)");
-    for (int c0 = 0; c0 < m; c0 += A->buf_cols) {
-      const int mc = (m - c0 < A->buf_cols) ? m - c0 : A->buf_cols;
-      if (A->nsend > 0) {
-        long tot = (long)A->nsend * mc, g = (tot + 255) / 256; if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(halo_pack, dim3((unsigned)g), dim3(256), 0, g_stream, A->nsend, A->d_send_rows, dx + c0, vx->ld, mc, A->sendbuf);
-      }
-      A->exchange(A->sendbuf, A->recvbuf, mc, A->exchange_ctx);
-      long tot = (long)A->nghost * mc, g = (tot + 255) / 256; if (g > 4096) g = 4096;
-      hipLaunchKernelGGL(halo_unpack, dim3((unsigned)g), dim3(256), 0, g_stream, A->nghost, A->recvbuf, mc,
-                         vx->d + (long)A->nrows * vx->ld + start[0] + c0, vx->ld);
-    }
-  }
+  halo_fetch(A, vx, start[0], m);
   SpmmEvent ev;
   if (g_prof_on) {
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
@@ -451,7 +531,10 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
-  if (m >= 16 && g_spmm_path == 1) rc = gcge_hip_sell8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
+  if (A->d_pid != nullptr && g_spmm_path == 0)
+    rc = gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, dx, vx->ld, dy, vy->ld, m, nullptr, g_stream);
+  if (rc != -1) {}
+  else if (m >= 16 && g_spmm_path == 1) rc = gcge_hip_sell8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
   else if (m >= 16) rc = gcge_hip_pad8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
   if (rc == -1) rc = gcge_hip_csr_spmm(A->nrows, A->d_rowptr, A->d_colidx, A->d_val, dx, vx->ld, dy, vy->ld, m, g_stream);
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
@@ -466,9 +549,10 @@ extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, 
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int m = end[0] - start[0];
   if (m <= 0) return;
-  const bool fast = A != nullptr && m >= 16 && m <= 128 && (m % 2 == 0) && (vx->ld % 2 == 0) && (vy->ld % 2 == 0) &&
-                    (((uintptr_t)(vx->d + start[0]) & 15) == 0) && (((uintptr_t)(vy->d + start[1]) & 15) == 0) &&
-                    A->nghost == 0;
+  const bool aligned = A != nullptr && (m % 2 == 0) && (vx->ld % 2 == 0) && (vy->ld % 2 == 0) &&
+                       (((uintptr_t)(vx->d + start[0]) & 15) == 0) && (((uintptr_t)(vy->d + start[1]) & 15) == 0);
+  const bool use_pat = aligned && A->d_pid != nullptr && g_spmm_path == 0;
+  const bool fast = aligned && (use_pat || (m >= 16 && m <= 128));
   if (!fast) {
     HIP_MatDotMultiVec(mat, x, y, start, end, ops);
     ops->MultiVecLocalInnerProd('D', x, y, 0, start, end, host_dots, 1, ops);
@@ -476,6 +560,8 @@ extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, 
   }
   GCGE_REQUIRE(vx != vy && vx->nrows == vy->nrows && A->nrows == vy->nrows, "spmm_dot: shapes");
   GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols && start[1] >= 0 && end[1] <= vy->ncols, "spmm_dot: column ranges");
+  GCGE_REQUIRE(A->nrows + A->nghost <= vx->nrows_alloc, "spmm_dot: halo rows allocated");
+  halo_fetch(A, vx, start[0], m);
   double* dd = stage_d(m);
   SpmmEvent ev;
   if (g_prof_on) {   // the fused kernel IS the K1 launch of a CG step (same algorithmic bytes: the dots add no HBM traffic)
@@ -484,8 +570,11 @@ extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, 
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
-  int rc = gcge_hip_pad8_spmm_dot(A->nrows, A->d_orp, A->d_pcol, A->d_pval, vx->d + start[0], vx->ld,
-                                  vy->d + start[1], vy->ld, m, dd, g_stream);
+  int rc = use_pat
+      ? gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, vx->d + start[0], vx->ld, vy->d + start[1],
+                              vy->ld, m, dd, g_stream)
+      : gcge_hip_pad8_spmm_dot(A->nrows, A->d_orp, A->d_pcol, A->d_pval, vx->d + start[0], vx->ld,
+                               vy->d + start[1], vy->ld, m, dd, g_stream);
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "spmm_dot: kernel launch");
   double* hd = stage_h(m);

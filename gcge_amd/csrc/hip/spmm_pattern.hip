@@ -1,0 +1,198 @@
+// K1 (pattern path) — SpMM for matrices whose rows repeat a small set of stencils.
+//
+// Same contract as spmm.hip / spmm_pad8.hip (Y[:, y0:y0+m) = A X[:, x0:x0+m), reference
+// app/app_ccs.c:50-139).  The finite-difference and finite-element matrices the reference is
+// exercised with (test_app_ccs.c:33-83 3-D Laplacian, the cube4 P1 pair) have only a few dozen
+// distinct rows when a row is written as {(column - row, value)}.  The back-end detects that
+// at matrix creation (app_hip.hip: build_patterns) and keeps
+//     pid[r]            (16 bit)      which pattern row r follows
+//     tab[p][0..LT)     (16 bytes)    (value, column offset), padded with (0.0, 0)
+// so the matrix stream shrinks from 12 B per non-zero to 2 B per ROW and the (col,val)
+// loads and their cross-lane broadcasts disappear (measured upper bound of this format in
+// profiles/r01_spmm_explore: 4.0-4.2 ms against 5.4-5.9 ms for the generic kernels at 256^3 x 64).
+// Matrices without such structure keep the pad-8 path.
+//
+// Kernel shape (what the counters asked for, profiles/r01_spmm_explore/README.md):
+//   * passes of 16 columns: a grid plane of X (N^2 rows x 128 B) then fits the L2s, so the +-N^2
+//     neighbours are L2 hits instead of second and third trips over the fabric;
+//   * lane l -> row slot g = l >> 3 of an 8-row slice, column pair i = l & 7: one 16-byte load
+//     per lane fetches the 128-byte X segments of 8 rows; no cross-lane reduction at all;
+//   * a wave walks its slices (slice w, w + W, ...: 32-row chunks stay interleaved over the XCDs
+//     exactly like a one-chunk-per-block launch) with two register sets: the X rows of the NEXT
+//     slice are requested before the current one is reduced, pattern ids two slices ahead;
+//   * no load sits next to a branch or select (hipcc would wait with vmcnt(0) after each);
+//     surplus iterations re-do the wave's last slice and only their stores are predicated.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gcge_hip_internal.h"
+
+extern "C" double* gcge_hip_partial_ws(size_t len);
+extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, int len, double* d_out, void* stream);
+
+namespace gcge {
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+struct PatEntry { double val; long off; };   // 16 bytes: one ds_read_b128
+
+// DOT: also dot_partial[block][j] = sum over the block's rows of X[r,j] * Y[r,j]
+template <int LT, int DOT>
+__global__ __launch_bounds__(256) void spmm_pattern_kernel(
+    long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
+    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long nslices,
+    double* __restrict__ dot_partial) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
+  for (int e = threadIdx.x; e < ntab; e += 256) s_tab[e] = tab[e];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 3, i = lane & 7;
+  const bool act = 2 * i < m;
+  const double* __restrict__ xl = x + (act ? 2 * i : 0);   // idle lanes of a narrow last pass re-read column 0
+  double d0 = 0.0, d1 = 0.0;
+
+  const long W = (long)gridDim.x * 4, w0 = (long)blockIdx.x * 4 + wave;
+  if (w0 < nslices) {   // wave-uniform
+    const long cnt = (nslices - w0 + W - 1) / W;
+    auto row_of = [&](long it) { return min((w0 + min(it, cnt - 1) * W) * 8 + g, nrows - 1); };   // clamped
+    auto issue = [&](v2d (&buf)[LT + DOT], double (&val)[LT], long row, int p) {
+#pragma unroll
+      for (int t = 0; t < LT; ++t) {
+        const PatEntry e = s_tab[p * LT + t];
+        val[t] = e.val;
+        buf[t] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e.off) * ldx);
+      }
+      if (DOT) buf[LT] = *reinterpret_cast<const v2d*>(xl + (size_t)row * ldx);
+    };
+    auto finish = [&](const v2d (&buf)[LT + DOT], const double (&val)[LT], long it) {
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int t = 0; t < LT; ++t) { a0 = fma(val[t], buf[t].x, a0); a1 = fma(val[t], buf[t].y, a1); }
+      const long row = (w0 + it * W) * 8 + g;   // unclamped: surplus iterations and tail rows store nothing
+      const bool ok = it < cnt && row < nrows && act;
+      if (ok) {
+        v2d o = {a0, a1};
+        __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(y + (size_t)row * ldy + 2 * i));
+      }
+      if (DOT) {
+        const double wgt = ok ? 1.0 : 0.0;
+        d0 = fma(a0 * wgt, buf[LT].x, d0); d1 = fma(a1 * wgt, buf[LT].y, d1);
+      }
+    };
+    v2d b0[LT + DOT], b1[LT + DOT];
+    double v0[LT], v1[LT];
+    int p0 = pid[row_of(0)], p1 = pid[row_of(1)];
+    issue(b0, v0, row_of(0), p0);
+    for (long it = 0; it < cnt; it += 2) {
+      const int p2 = pid[row_of(it + 2)];
+      issue(b1, v1, row_of(it + 1), p1);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(b0, v0, it);
+      __builtin_amdgcn_sched_barrier(0);
+      const int p3 = pid[row_of(it + 3)];
+      issue(b0, v0, row_of(it + 2), p2);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(b1, v1, it + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      p1 = p3;
+    }
+  }
+  if (DOT) {
+    // sum the 8 row slots of the wave (lanes l, l^8, l^16, l^32 share a column pair), then the 4 waves
+    auto sx = [](double v, int mask) {
+      int lo = __shfl_xor(__double2loint(v), mask, 64), hi = __shfl_xor(__double2hiint(v), mask, 64);
+      return __hiloint2double(hi, lo);
+    };
+    d0 += sx(d0, 8);  d1 += sx(d1, 8);
+    d0 += sx(d0, 16); d1 += sx(d1, 16);
+    d0 += sx(d0, 32); d1 += sx(d1, 32);
+    __shared__ double sred[4][16];
+    if (lane < 8) { sred[wave][2 * lane] = d0; sred[wave][2 * lane + 1] = d1; }
+    __syncthreads();
+    if (threadIdx.x < 16 && (int)threadIdx.x < m)
+      dot_partial[(long)blockIdx.x * m + threadIdx.x] =
+          (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+  }
+}
+
+}  // namespace gcge
+
+using namespace gcge;
+
+// Blocks per pass.  A wave handles slices w, w + W, w + 2W, ... (W = 4 * blocks), i.e. rows 32 * blocks apart.
+// Measured on the 256^3 Laplacian (64 columns, profiles/r01_spmm_explore/13_pattern_grid.log):
+//     blocks  512    768    1024   1536   2048   4096   8192
+//     ms      4.78   6.18   5.02   6.29   4.55   5.23   6.28
+// Fast whenever the row stride divides the matrix's longest column offset (here N^2 = 65536 rows = 2048
+// blocks): then the X rows a wave fetched as "+N^2" neighbours are the rows it needs itself one (or a few)
+// iterations later, so the reuse is private to the wave / CU and does not depend on blocks advancing in
+// lock-step.  Otherwise fast blocks drift planes ahead of slow ones and the reuse is lost from L2.
+// Hence: blocks = span / 32 / j with the smallest j that keeps the grid below ~3072 blocks.
+static int g_pat_grid = 0;   // > 0: forced (tuning)
+extern "C" void gcge_hip_spmm_pattern_tune(int grid) { g_pat_grid = grid > 0 ? (grid + 7) / 8 * 8 : 0; }
+static long pat_grid(long span, long nslices) {
+  long g;
+  if (g_pat_grid > 0) g = g_pat_grid;
+  else {
+    const long target = span / 32;
+    if (target < 256) g = 1024;                          // short reuse distances live in L2 anyway
+    else { const long j = (target + 3071) / 3072; g = (target / j + 7) / 8 * 8; }
+  }
+  const long need = (nslices + 3) / 4;
+  return g < need ? g : need;
+}
+
+template <int LT, int DOT>
+static long pat_launch(long nrows, const unsigned short* pid, const void* tab, int npat, const double* x, size_t ldx,
+                       double* y, size_t ldy, int m, double* partial, long nb, hipStream_t st) {
+  const long nslices = (nrows + 7) / 8;
+  const int ntab = npat * LT;
+  hipLaunchKernelGGL((spmm_pattern_kernel<LT, DOT>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
+                     nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, nslices, partial);
+  return nb;
+}
+
+template <int DOT>
+static long pat_dispatch(int lt, long nrows, const unsigned short* pid, const void* tab, int npat, const double* x,
+                         size_t ldx, double* y, size_t ldy, int m, double* partial, long nb, hipStream_t st) {
+  switch (lt) {
+    case 7: return pat_launch<7, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, nb, st);
+    case 8: return pat_launch<8, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, nb, st);
+    case 16: return pat_launch<16, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, nb, st);
+    default: return -1;
+  }
+}
+
+// table entries per pattern the kernels are built for (rows are padded up to one of these), 0: too long
+extern "C" int gcge_hip_pattern_width(int max_row_len) {
+  if (max_row_len <= 7) return 7;
+  if (max_row_len <= 8) return 8;
+  if (max_row_len <= 16) return 16;
+  return 0;
+}
+
+// Y[:,0:ncols) = A X[:,0:ncols); d_dots != NULL: also d_dots[j] = sum_r X[r,j] Y[r,j].
+// d_tab: npat * lt entries of {double value; long column_offset}; span: largest |column_offset|.
+// -1: alignment contract not met.
+extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+                                     long span, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
+                                     double* d_dots, void* stream) {
+  if (nrows <= 0 || ncols <= 0) return 0;
+  if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15)) return -1;
+  if ((size_t)npat * lt * sizeof(PatEntry) > 64 * 1024) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const int npass = (ncols + 15) / 16;
+  const long nb = pat_grid(span, ((long)nrows + 7) / 8);
+  double* part = d_dots ? gcge_hip_partial_ws((size_t)nb * 16 * npass) : nullptr;
+  for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
+    const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
+    if (d_dots) {
+      double* pp = part + (size_t)ps * nb * 16;
+      if (pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, nb, st) < 0) return -1;
+      gcge_hip_reduce_partials(pp, (int)nb, m, d_dots + c0, st);
+    } else if (pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, nb, st) < 0) {
+      return -1;
+    }
+  }
+  return (int)hipGetLastError();
+}

@@ -78,6 +78,35 @@ def test_spmm_sell8_path_vs_oracle(both, kind, size, kw):
         hip.g.gcge_hip_set_spmm_path(0)
 
 
+@pytest.mark.parametrize("kind,size,expect", [("lap3d", 13, True), ("fe3d", 11, True), ("fe1d", 500, True),
+                                              ("sio2", 10, False)])
+def test_spmm_pattern_path_vs_generic_and_oracle(both, kind, size, expect):
+    """Stencil matrices take the pattern path (16-bit pattern ids + table); it must agree with the generic
+    pad-8/CSR kernels and the oracle for wide, narrow and offset column ranges; irregular matrices must not qualify."""
+    hip, ora = both
+    A, mh, mo = _pair_mats(both, kind, size, K=8, R0=2.0, R1=3.0)
+    hip.g.gcge_hip_mat_patterns.argtypes = [C.c_void_p]
+    npat = hip.g.gcge_hip_mat_patterns(mh)
+    assert (npat > 0) == expect, npat
+    n = A.nrows
+    X = uniform(19, (n, 80)) - 0.5
+    xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
+    for m, s0, s1 in [(64, 0, 0), (16, 2, 4), (18, 8, 6), (2, 0, 0), (70, 8, 2), (6, 3, 1)]:
+        outs = []
+        for path in (0, 2):
+            hip.g.gcge_hip_set_spmm_path(path)
+            Y0 = uniform(20, (n, 80))
+            yh = hip.mv_from_numpy(mh, Y0)
+            hip.ops.spmm(mh, xh, yh, (s0, s1), (s0 + m, s1 + m))
+            outs.append(hip.mv_to_numpy(yh, n, 0, 80))
+        hip.g.gcge_hip_set_spmm_path(0)
+        yo = ora.mv_from_numpy(mo, uniform(20, (n, 80)))
+        ora.ops.spmm(mo, xo, yo, (s0, s1), (s0 + m, s1 + m))
+        ref = ora.mv_to_numpy(yo, n, 0, 80)
+        _close(outs[0], ref, tol=1e-13, what="pattern spmm %s m=%d" % (kind, m))
+        _close(outs[1], ref, tol=1e-13, what="generic spmm %s m=%d" % (kind, m))
+
+
 def test_gram_and_dots_vs_oracle(both):
     hip, ora = both
     A, mh, mo = _pair_mats(both, "lap3d", 13)
