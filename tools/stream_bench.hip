@@ -67,6 +67,37 @@ __global__ __launch_bounds__(256) void xp_slab(long nrows, const double* __restr
     }
   }
 }
+template <int UNR>
+__global__ __launch_bounds__(256) void r_rows(long nrows, const double* __restrict__ w, long ldw, double* __restrict__ r, long ldr,
+                                              double a, double* __restrict__ partial) {
+  __shared__ double red[256][2];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j = 2 * tx;
+  const long step = (long)gridDim.x * 8;
+  double s0 = 0, s1 = 0;
+  long row = (long)blockIdx.x * 8 + ty;
+  for (; row + (UNR - 1) * step < nrows; row += step * UNR) {
+    v2d wv[UNR], rv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const long rr = row + u * step;
+      wv[u] = __builtin_nontemporal_load((const v2d*)(w + rr * ldw + j));
+      rv[u] = __builtin_nontemporal_load((const v2d*)(r + rr * ldr + j));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const long rr = row + u * step;
+      v2d ro = {fma(-a, wv[u].x, rv[u].x), fma(-a, wv[u].y, rv[u].y)};
+      __builtin_nontemporal_store(ro, (v2d*)(r + rr * ldr + j));
+      s0 = fma(ro.x, ro.x, s0); s1 = fma(ro.y, ro.y, s1);
+    }
+  }
+  red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1;
+  __syncthreads();
+  if (ty == 0) { for (int q = 1; q < 8; ++q) { s0 += red[q * 32 + tx][0]; s1 += red[q * 32 + tx][1]; }
+    partial[(long)blockIdx.x * 64 + j] = s0; partial[(long)blockIdx.x * 64 + j + 1] = s1; }
+}
 __global__ void copyk(const v2d* __restrict__ a, v2d* __restrict__ b, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x, st = (long)gridDim.x * blockDim.x;
   for (; i < n; i += st) b[i] = a[i];
@@ -99,7 +130,19 @@ int main(int argc, char** argv) {
     snprintf(nm, 96, "write 1 stream grid %d", g); timeit(nm, gb1, [&] { writek<<<g, 256>>>((v2d*)p, n * m / 2); });
     snprintf(nm, 96, "copy 1R+1W grid %d", g); timeit(nm, 2 * gb1, [&] { copyk<<<g, 256>>>((const v2d*)r, (v2d*)p, n * m / 2); });
   }
-  for (long ld : {64L, ldx}) for (int g : {2048, 4096, 16384, 65536}) {
+  { double* part; CK(hipMalloc(&part, 65536 * 64 * 8));
+    for (long sh : {0L, 512L, 2048L, 8192L + 512, 65536L + 4096 + 256, 1048576L + 65536 + 4096}) {   // w shifted by sh doubles against r
+      char nm[96]; double* w2; CK(hipMalloc(&w2, (n * m + sh) * 8)); CK(hipMemset(w2, 0, (n * m + sh) * 8));
+      snprintf(nm, 96, "r-update unr4 grid 2048, w shifted %ld B", sh * 8); timeit(nm, 3 * gb1, [&] { r_rows<4><<<2048, 256>>>(n, w2 + sh, m, r, m, 0.5, part); });
+      CK(hipFree(w2));
+    }
+    for (int g : {2048}) {
+      char nm[96];
+      snprintf(nm, 96, "r-update 2R+1W unr4 grid %d", g); timeit(nm, 3 * gb1, [&] { r_rows<4><<<g, 256>>>(n, p, m, r, m, 0.5, part); });
+      snprintf(nm, 96, "r-update 2R+1W unr8 grid %d", g); timeit(nm, 3 * gb1, [&] { r_rows<8><<<g, 256>>>(n, p, m, r, m, 0.5, part); });
+    }
+  }
+  if (getenv("XP")) for (long ld : {64L, ldx}) for (int g : {2048, 4096, 16384, 65536}) {
     char nm[96];
     snprintf(nm, 96, "xp rows unr4 nt  ldx %ld grid %d", ld, g); timeit(nm, gb5, [&] { xp_rows<4, 1><<<g, 256>>>(n, r, m, p, m, x, ld, 0.5, 0.25); });
     snprintf(nm, 96, "xp rows unr4 pl  ldx %ld grid %d", ld, g); timeit(nm, gb5, [&] { xp_rows<4, 0><<<g, 256>>>(n, r, m, p, m, x, ld, 0.5, 0.25); });
