@@ -79,10 +79,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # GCGE_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo transport staged through the host — a way to run
+    # the multi-rank code path on a one-GPU box (numbers from it mean nothing)
+    rehearse = world > 1 and os.environ.get("GCGE_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from gcge_amd import HipBackend, make_problem, run_gcg
@@ -100,12 +108,21 @@ def main():
     # weak scaling: every rank owns a slab of `size^3` rows (planes along k), so n_global grows with the rank count
     planes = N * world
     if world > 1:
-        comm = gdist.install(hip, dist, rank, world)
+        comm = gdist.install(hip, dist, rank, world, stage_through_host=rehearse)
         A, mat = gdist.lap3d_slab(hip, N, planes, rank, world, comm)
         n_global = N * N * planes
     else:
         A, _ = make_problem("lap3d", N)
         mat = hip.matrix(A)
+    if world > 1:
+        # communicator set-up (RCCL creates its point-to-point channels lazily on first use): one 2-column halo
+        # exchange and one tiny all-reduce before anything is timed
+        wv, wy = hip.ops.mv_create(2, mat), hip.ops.mv_create(2, mat)
+        hip.ops.set_random(wv, 0, 2)
+        hip.ops.spmm(mat, wv, wy, (0, 0), (2, 2))
+        hip.ops.inner_prod("D", wv, wy, (0, 0), (2, 2))
+        hip.ops.mv_destroy(wv, 2)
+        hip.ops.mv_destroy(wy, 2)
     hip.set_random_mode(1, 20240601)          # device generator: 2e9 rand() calls would dominate at this n
     g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
     solver_args = ["-nevConv", args.nev, "-nevMax", args.nevmax, "-blockSize", args.block,

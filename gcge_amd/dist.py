@@ -110,6 +110,9 @@ class Comm:
                 s_all = send_t[:max(1, nsend * ncols)].cpu()
                 r_all = torch.zeros(max(1, nrecv * ncols), dtype=torch.float64)
             else:
+                # The pack/unpack kernels run on the back-end's own HIP stream, RCCL on torch's: order them through
+                # the host (device-wide sync before the sends are posted and after the receives have completed).
+                torch.cuda.synchronize()
                 s_all, r_all = send_t, recv_t
             ops = []
             for q in range(self.world):
@@ -124,6 +127,8 @@ class Comm:
                     w.wait()
             if self.stage and not host_buffers:
                 recv_t[:max(1, nrecv * ncols)].copy_(r_all)
+                torch.cuda.synchronize()
+            elif not host_buffers:
                 torch.cuda.synchronize()
 
         cb = EXCHANGE_FN(exchange)
