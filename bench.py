@@ -171,6 +171,13 @@ def main():
         # `achieved` prices every launch at the CSR algorithmic bytes of SURVEY.md 8(d) (12 B per non-zero + X + Y).
         # On the pattern path the matrix is streamed as 2 B per row instead, so the bytes actually
         # moved are lower than the algorithmic ones: X and Y (16 n m) dominate either way.
+        # HBM/fabric bytes per launch from separate rocprofv3 --pmc passes of this kernel at this shape (not collected
+        # live: counters need their own runs): TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B, gfx950 correction of
+        # MI355X_MICROARCH.md applied; profiles/r01_spmm_explore/15_pattern_pmc.log
+        traffic, traffic_note = None, "no PMC profile for this shape"
+        if npat > 0 and N == 256 and args.block == 64:
+            traffic = 4 * (2.69835e7 * 128 + 3.35544e7 * 64)
+            traffic_note = "4 passes x (2.698e7 x 128 B reads + 3.355e7 x 64 B writes), profiles/r01_spmm_explore/15_pattern_pmc.log"
         kname = ("spmm_pattern<7> x %d passes of 16 columns + column dots (K1, %d row patterns, m=%d)" % ((args.block + 15) // 16, npat, args.block)
                  if npat > 0 else "spmm_pad8 (K1 CSR SpMM, m=%d)" % args.block)
         out = {
@@ -185,7 +192,8 @@ def main():
                        "max_rel_err_vs_closed_form": rel,
                        "phase_seconds": {k: getattr(res.timing, k) for k in ("initX", "checkconv", "compP", "compRR", "compRV", "compW", "linsol", "total")}},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "launches": int(cnt),
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note,
+                         "launches": int(cnt),
                          "avg_launch_ms": (ms.value / cnt) if cnt else None,
                          "alg_bytes_per_launch": (by.value / cnt) if cnt else None,
                          "spmm_share_of_step": (ms_all.value * 1e-3) / elapsed if elapsed > 0 else None},

@@ -27,7 +27,7 @@ int gcge_hip_pad8_spmm_dot(int nrows, const int* d_orp, const int* d_pcol, const
 int gcge_hip_sell8_spmm(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval, const double* d_x, long ldx,
                         double* d_y, long ldy, int ncols, void* stream);
 int gcge_hip_pattern_width(int max_row_len);
-int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, const double* d_x, long ldx,
+int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2, const double* d_x, long ldx,
                           double* d_y, long ldy, int ncols, double* d_dots, void* stream);
 int gcge_hip_colscale(int nrows, double* d_y, long ldy, int m, const double* d_s, void* stream);
 int gcge_hip_fill_uniform(int nrows, long row_begin, long nglobal, double* d_y, long ldy, int c0, int m,
@@ -45,7 +45,7 @@ struct GCGE_HIP_MAT_ {
   int *d_rowptr, *d_colidx; double* d_val;    // CSR, LOCAL column indices (ghosts >= nrows)
   int *d_orp, *d_pcol; double* d_pval;        // pad-8 copy for the 16-byte-lane kernel
   long noct;
-  unsigned short* d_pid; void* d_tab; int npat, pat_lt; long pat_span;   // pattern format (spmm_pattern.hip); d_pid == NULL: not applicable
+  unsigned short* d_pid; void* d_tab; int npat, pat_lt; long pat_span, pat_span2;   // pattern format (spmm_pattern.hip); d_pid == NULL: not applicable
   // halo plan of a row-partitioned matrix (one process per GPU); nghost == 0 on a single rank
   int nsend; int* d_send_rows;                 // local rows other ranks need, grouped by destination rank
   double *sendbuf, *recvbuf; int buf_cols;     // exchange buffers (owned by the caller: torch tensors)
@@ -218,9 +218,14 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, const int* rowptr, const 
   std::vector<long> freq((size_t)A->npat, 0);
   for (int r = 0; r < nrows; ++r) ++freq[pid[r]];
   const int common = (int)(std::max_element(freq.begin(), freq.end()) - freq.begin());
+  A->pat_span2 = 0;
   for (int k = 0; k < lt; ++k) {
     const long o = tab[(size_t)common * lt + k].off;
     A->pat_span = std::max(A->pat_span, o < 0 ? -o : o);
+  }
+  for (int k = 0; k < lt; ++k) {
+    const long o = tab[(size_t)common * lt + k].off, ao = o < 0 ? -o : o;
+    if (ao < A->pat_span) A->pat_span2 = std::max(A->pat_span2, ao);
   }
   GCGE_HIP_CHECK(hipMalloc(&A->d_pid, (size_t)nrows * sizeof(unsigned short)));
   GCGE_HIP_CHECK(hipMalloc(&A->d_tab, tab.size() * sizeof(PatEntryH)));
@@ -532,7 +537,7 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
   if (A->d_pid != nullptr && g_spmm_path == 0)
-    rc = gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, dx, vx->ld, dy, vy->ld, m, nullptr, g_stream);
+    rc = gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, dx, vx->ld, dy, vy->ld, m, nullptr, g_stream);
   if (rc != -1) {}
   else if (m >= 16 && g_spmm_path == 1) rc = gcge_hip_sell8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
   else if (m >= 16) rc = gcge_hip_pad8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
@@ -571,7 +576,7 @@ extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, 
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
   int rc = use_pat
-      ? gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, vx->d + start[0], vx->ld, vy->d + start[1],
+      ? gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, vx->d + start[0], vx->ld, vy->d + start[1],
                               vy->ld, m, dd, g_stream)
       : gcge_hip_pad8_spmm_dot(A->nrows, A->d_orp, A->d_pcol, A->d_pval, vx->d + start[0], vx->ld,
                                vy->d + start[1], vy->ld, m, dd, g_stream);

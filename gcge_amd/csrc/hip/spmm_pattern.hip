@@ -17,9 +17,12 @@
 //     neighbours are L2 hits instead of second and third trips over the fabric;
 //   * lane l -> row slot g = l >> 3 of an 8-row slice, column pair i = l & 7: one 16-byte load
 //     per lane fetches the 128-byte X segments of 8 rows; no cross-lane reduction at all;
-//   * a wave walks its slices (slice w, w + W, ...: 32-row chunks stay interleaved over the XCDs
-//     exactly like a one-chunk-per-block launch) with two register sets: the X rows of the NEXT
-//     slice are requested before the current one is reduced, pattern ids two slices ahead;
+//   * a block works on TILES of 4 slices, one per wave: 4 consecutive slices by default (32-row
+//     chunks stay interleaved over the XCDs like a one-chunk-per-block launch); optionally `line`
+//     rows apart (the second longest stencil offset) so that the +-N neighbours of one wave are
+//     the centre rows of the next — measured, no gain, kept as a tuning hook;
+//   * a block walks its tiles (tile b, b + G, ...) with two register sets: the X rows of the NEXT
+//     tile are requested before the current one is reduced, pattern ids two tiles ahead;
 //   * no load sits next to a branch or select (hipcc would wait with vmcnt(0) after each);
 //     surplus iterations re-do the wave's last slice and only their stores are predicated.
 #include <hip/hip_runtime.h>
@@ -38,7 +41,7 @@ struct PatEntry { double val; long off; };   // 16 bytes: one ds_read_b128
 template <int LT, int DOT>
 __global__ __launch_bounds__(256) void spmm_pattern_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
-    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long nslices,
+    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
     double* __restrict__ dot_partial) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
@@ -51,10 +54,12 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
   const double* __restrict__ xl = x + (act ? 2 * i : 0);   // idle lanes of a narrow last pass re-read column 0
   double d0 = 0.0, d1 = 0.0;
 
-  const long W = (long)gridDim.x * 4, w0 = (long)blockIdx.x * 4 + wave;
-  if (w0 < nslices) {   // wave-uniform
-    const long cnt = (nslices - w0 + W - 1) / W;
-    auto row_of = [&](long it) { return min((w0 + min(it, cnt - 1) * W) * 8 + g, nrows - 1); };   // clamped
+  // tile t = (group of 4 lines q, slice a inside the line); wave w takes line 4q + w
+  const long G = gridDim.x, aslices = line / 8;
+  auto first_row = [&](long t) { const long q = t / aslices, a = t - q * aslices; return ((4 * q + wave) * line) + 8 * a; };
+  if ((long)blockIdx.x < ntiles) {   // block-uniform
+    const long cnt = (ntiles - blockIdx.x + G - 1) / G;
+    auto row_of = [&](long it) { return min(first_row(blockIdx.x + min(it, cnt - 1) * G) + g, nrows - 1); };   // clamped
     auto issue = [&](v2d (&buf)[LT + DOT], double (&val)[LT], long row, int p) {
 #pragma unroll
       for (int t = 0; t < LT; ++t) {
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
       double a0 = 0.0, a1 = 0.0;
 #pragma unroll
       for (int t = 0; t < LT; ++t) { a0 = fma(val[t], buf[t].x, a0); a1 = fma(val[t], buf[t].y, a1); }
-      const long row = (w0 + it * W) * 8 + g;   // unclamped: surplus iterations and tail rows store nothing
+      const long row = first_row(blockIdx.x + it * G) + g;   // unclamped: surplus iterations and tail rows store nothing
       const bool ok = it < cnt && row < nrows && act;
       if (ok) {
         v2d o = {a0, a1};
@@ -130,7 +135,17 @@ using namespace gcge;
 // Hence: blocks = span / 32 / j with the smallest j that keeps the grid below ~3072 blocks.
 static int g_pat_grid = 0;   // > 0: forced (tuning)
 extern "C" void gcge_hip_spmm_pattern_tune(int grid) { g_pat_grid = grid > 0 ? (grid + 7) / 8 * 8 : 0; }
-static long pat_grid(long span, long nslices) {
+// tiles of 4 slices `line` rows apart: groups of 4 lines x (line / 8) slices per line
+static long pat_ntiles(long nrows, long line) {
+  const long nlines = (nrows + line - 1) / line;
+  return (nlines + 3) / 4 * (line / 8);
+}
+// Measured (profiles/r01_spmm_explore/16_pattern_line_tiles.log): tiles one grid line apart do NOT pay — 4.98 vs
+// 5.02 ms at 256^3, 3.05 vs 2.84 ms on the 200^3 FE matrix — the four waves of a block are not in step closely
+// enough for the +-N rows to still be in the 32 KB L1.  Default: 4 consecutive slices (line = 8).
+static int g_pat_line = 8;    // tuning: -1 = from the stencil's second longest offset, 8 = consecutive slices
+extern "C" void gcge_hip_spmm_pattern_tune_line(int line) { g_pat_line = line; }
+static long pat_grid(long span, long ntiles) {
   long g;
   if (g_pat_grid > 0) g = g_pat_grid;
   else {
@@ -138,27 +153,25 @@ static long pat_grid(long span, long nslices) {
     if (target < 256) g = 1024;                          // short reuse distances live in L2 anyway
     else { const long j = (target + 3071) / 3072; g = (target / j + 7) / 8 * 8; }
   }
-  const long need = (nslices + 3) / 4;
-  return g < need ? g : need;
+  return g < ntiles ? g : ntiles;
 }
 
 template <int LT, int DOT>
 static long pat_launch(long nrows, const unsigned short* pid, const void* tab, int npat, const double* x, size_t ldx,
-                       double* y, size_t ldy, int m, double* partial, long nb, hipStream_t st) {
-  const long nslices = (nrows + 7) / 8;
+                       double* y, size_t ldy, int m, double* partial, long nb, long line, hipStream_t st) {
   const int ntab = npat * LT;
   hipLaunchKernelGGL((spmm_pattern_kernel<LT, DOT>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
-                     nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, nslices, partial);
+                     nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, pat_ntiles(nrows, line), line, partial);
   return nb;
 }
 
 template <int DOT>
 static long pat_dispatch(int lt, long nrows, const unsigned short* pid, const void* tab, int npat, const double* x,
-                         size_t ldx, double* y, size_t ldy, int m, double* partial, long nb, hipStream_t st) {
+                         size_t ldx, double* y, size_t ldy, int m, double* partial, long nb, long line, hipStream_t st) {
   switch (lt) {
-    case 7: return pat_launch<7, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, nb, st);
-    case 8: return pat_launch<8, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, nb, st);
-    case 16: return pat_launch<16, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, nb, st);
+    case 7: return pat_launch<7, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, nb, line, st);
+    case 8: return pat_launch<8, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, nb, line, st);
+    case 16: return pat_launch<16, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, nb, line, st);
     default: return -1;
   }
 }
@@ -172,25 +185,29 @@ extern "C" int gcge_hip_pattern_width(int max_row_len) {
 }
 
 // Y[:,0:ncols) = A X[:,0:ncols); d_dots != NULL: also d_dots[j] = sum_r X[r,j] Y[r,j].
-// d_tab: npat * lt entries of {double value; long column_offset}; span: largest |column_offset|.
-// -1: alignment contract not met.
+// d_tab: npat * lt entries of {double value; long column_offset}; span / span2: the longest and second longest
+// |column_offset| of the interior stencil (launch geometry only; 0 if unknown).  -1: alignment contract not met.
 extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
-                                     long span, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
+                                     long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
                                      double* d_dots, void* stream) {
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15)) return -1;
   if ((size_t)npat * lt * sizeof(PatEntry) > 64 * 1024) return -1;
   hipStream_t st = (hipStream_t)stream;
   const int npass = (ncols + 15) / 16;
-  const long nb = pat_grid(span, ((long)nrows + 7) / 8);
+  // lines of `span2` rows when they tile the matrix exactly (a plane = a whole number of 4-line groups)
+  long line = 8;
+  if (g_pat_line < 0 && span2 >= 8 && span2 % 8 == 0 && span > span2 && span % (4 * span2) == 0) line = span2;
+  if (g_pat_line >= 8 && g_pat_line % 8 == 0) line = g_pat_line;
+  const long nb = pat_grid(span, pat_ntiles(nrows, line));
   double* part = d_dots ? gcge_hip_partial_ws((size_t)nb * 16 * npass) : nullptr;
   for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
     const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
     if (d_dots) {
       double* pp = part + (size_t)ps * nb * 16;
-      if (pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, nb, st) < 0) return -1;
+      if (pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, nb, line, st) < 0) return -1;
       gcge_hip_reduce_partials(pp, (int)nb, m, d_dots + c0, st);
-    } else if (pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, nb, st) < 0) {
+    } else if (pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, nb, line, st) < 0) {
       return -1;
     }
   }

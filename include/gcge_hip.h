@@ -94,9 +94,9 @@ int gcge_hip_sell8_spmm (int nrows, const int *d_orp, const int *d_pcol, const d
 		const double *d_x, long ldx, double *d_y, long ldy, int ncols, void *stream);
 void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > pad-8 > CSR), 1 SELL-8 passes, 2 generic kernels only */
 /*     pattern path (csrc/hip/spmm_pattern.hip): matrices whose rows repeat a few stencils {(col - row, value)} are
- *     additionally kept as 16-bit pattern ids + a table of npat * lt {double value; long offset} entries (span =
- *     largest |offset|); d_dots may be NULL.  gcge_hip_mat_patterns() tells whether a matrix qualified (0: served by the generic kernels).       */
-int gcge_hip_pattern_spmm (int nrows, const unsigned short *d_pid, const void *d_tab, int npat, int lt, long span,
+ *     additionally kept as 16-bit pattern ids + a table of npat * lt {double value; long offset} entries (span, span2 =
+ *     longest and second longest |offset| of the interior stencil: launch geometry only); d_dots may be NULL.  gcge_hip_mat_patterns() tells whether a matrix qualified (0: served by the generic kernels).       */
+int gcge_hip_pattern_spmm (int nrows, const unsigned short *d_pid, const void *d_tab, int npat, int lt, long span, long span2,
 		const double *d_x, long ldx, double *d_y, long ldy, int ncols, double *d_dots, void *stream);
 int gcge_hip_pattern_width (int max_row_len);
 int gcge_hip_mat_patterns (const GCGE_HIP_MAT *A);

@@ -22,6 +22,8 @@ ops = hip.ops
 V = ops.mv_create(256, mA); ops.set_random(V, 0, 256)
 Wv = ops.mv_create(m, mA)
 g.gcge_hip_set_spmm_path(path)
+if os.environ.get('PAT_LINE'):
+    g.gcge_hip_spmm_pattern_tune_line(int(os.environ['PAT_LINE']))
 if os.environ.get('PAT_GRID'):
     g.gcge_hip_spmm_pattern_tune(int(os.environ['PAT_GRID']))
 for x0 in (192, 128):

@@ -142,6 +142,15 @@ int main(int argc, char** argv) {
       snprintf(nm, 96, "r-update 2R+1W unr8 grid %d", g); timeit(nm, 3 * gb1, [&] { r_rows<8><<<g, 256>>>(n, p, m, r, m, 0.5, part); });
     }
   }
+  if (getenv("SKEW")) {   // xp update with r placed at different offsets behind p inside ONE allocation, x as in the solver (ld 256)
+    double* big; const long nb = n * m;
+    CK(hipMalloc(&big, (2 * nb + (1L << 24)) * 8)); CK(hipMemset(big, 0, (2 * nb + (1L << 24)) * 8));
+    for (long sk : {0L, 32L, 512L, 4096L + 32, 65536L, 65536L + 512, 1L << 20, (1L << 20) + 4096 + 64, (1L << 23) + 8192}) {
+      char nm[96]; snprintf(nm, 96, "xp unr4 nt grid 4096 ldx 256, r = p + n*m + %ld doubles", sk);
+      timeit(nm, gb5, [&] { xp_rows<4, 1><<<4096, 256>>>(n, big + nb + sk, m, big, m, x, 256, 0.5, 0.25); });
+    }
+    CK(hipFree(big));
+  }
   if (getenv("XP")) for (long ld : {64L, ldx}) for (int g : {2048, 4096, 16384, 65536}) {
     char nm[96];
     snprintf(nm, 96, "xp rows unr4 nt  ldx %ld grid %d", ld, g); timeit(nm, gb5, [&] { xp_rows<4, 1><<<g, 256>>>(n, r, m, p, m, x, ld, 0.5, 0.25); });
