@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void halo_unpack(int nghost, const double* __r
 
 struct GcgeHipMV {
   double* d;
+  size_t bytes;   // size of the allocation behind d
   long ld;
   int nrows, nrows_alloc, ncols;
   const GCGE_HIP_MAT_* mat;   // shape donor (row partition)
@@ -127,7 +128,9 @@ extern "C" int gcge_hip_init(int device) {
   g_inited = 1;
   return 0;
 }
+extern "C" void gcge_hip_pool_release(void);
 extern "C" void gcge_hip_finalize(void) {
+  gcge_hip_pool_release();
   if (g_stage_d) hipFree(g_stage_d);
   if (g_stage_h) hipHostFree(g_stage_h);
   g_stage_d = nullptr; g_stage_h = nullptr; g_stage_d_len = g_stage_h_len = 0; g_inited = 0;
@@ -309,13 +312,49 @@ extern "C" long gcge_hip_mat_nnz(const GCGE_HIP_MAT* A) { return A->nnz; }
 // number of row patterns the SpMM pattern path works with (0: the matrix is served by the generic pad-8 kernels)
 extern "C" int gcge_hip_mat_patterns(const GCGE_HIP_MAT* A) { return A->d_pid ? A->npat : 0; }
 
+// ------------------------------------------------------------------ device buffer pool
+// hipMalloc / hipFree of the multi-GB blocks cost 0.25-0.3 s each on this stack (page-table set-up; hipFree also
+// synchronises the device): ~1.9 s of a 21 s solve.  Freed blocks are kept by exact size and handed out again —
+// every use of the back-end happens on one stream, so a recycled block is ordered behind the kernels that last
+// touched it.  The reference allocates its work blocks per solve as well (test_eig_sol_gcg.c:66-92); a second
+// solve of the same shape then allocates nothing.  gcge_hip_pool_release() returns everything to the driver.
+static std::unordered_map<size_t, std::vector<void*>> g_pool;
+static size_t g_pool_bytes = 0;
+static int g_pool_on = 1;
+extern "C" void gcge_hip_pool_release(void) {
+  for (auto& kv : g_pool) for (void* q : kv.second) hipFree(q);
+  g_pool.clear(); g_pool_bytes = 0;
+}
+extern "C" void gcge_hip_pool_enable(int on) { g_pool_on = on; if (!on) gcge_hip_pool_release(); }
+static void* pool_alloc(size_t bytes) {
+  auto it = g_pool.find(bytes);
+  if (it != g_pool.end() && !it->second.empty()) {
+    void* q = it->second.back(); it->second.pop_back(); g_pool_bytes -= bytes;
+    return q;
+  }
+  void* q = nullptr;
+  if (hipMalloc(&q, bytes) != hipSuccess) {   // out of memory: give the cached blocks back and try once more
+    (void)hipGetLastError();
+    gcge_hip_pool_release();
+    GCGE_HIP_CHECK(hipMalloc(&q, bytes));
+  }
+  return q;
+}
+static void pool_free(void* q, size_t bytes) {
+  if (!g_pool_on || bytes < ((size_t)1 << 20)) {   // small blocks are not worth tracking
+    GCGE_HIP_CHECK(hipStreamSynchronize(g_stream)); hipFree(q); return;
+  }
+  g_pool[bytes].push_back(q); g_pool_bytes += bytes;
+}
+
 // ------------------------------------------------------------------ multivector
 static GcgeHipMV* mv_new(int nrows, int nghost, int ncols, const GCGE_HIP_MAT_* mat) {
   GcgeHipMV* v = (GcgeHipMV*)calloc(1, sizeof(GcgeHipMV));
   v->nrows = nrows; v->nrows_alloc = nrows + nghost; v->ncols = ncols; v->mat = mat;
   v->ld = ((long)(ncols > 0 ? ncols : 1) + 7) / 8 * 8;
   const size_t bytes = (size_t)v->nrows_alloc * v->ld * sizeof(double);
-  GCGE_HIP_CHECK(hipMalloc(&v->d, bytes ? bytes : 8));
+  v->bytes = bytes ? bytes : 8;
+  v->d = (double*)pool_alloc(v->bytes);
   GCGE_HIP_CHECK(hipMemsetAsync(v->d, 0, bytes, g_stream));   // zero-filled like app_ccs.c:47
   return v;
 }
@@ -329,7 +368,7 @@ static void HIP_MultiVecCreateByMultiVec(void*** mv, int num_vec, void** src, st
 }
 static void HIP_MultiVecDestroy(void*** mv, int num_vec, struct OPS_* ops) {
   GcgeHipMV* v = *(GcgeHipMV**)mv;
-  if (v) { GCGE_HIP_CHECK(hipStreamSynchronize(g_stream)); hipFree(v->d); free(v); }
+  if (v) { pool_free(v->d, v->bytes); free(v); }
   *mv = nullptr;
 }
 extern "C" int gcge_hip_mv_nrows(void** mv) { return ((GcgeHipMV*)mv)->nrows; }

@@ -92,6 +92,10 @@ int gcge_hip_gram (int nrows, const double *d_q, long ldq, int k, const double *
  *     in L2; csrc/hip/spmm_sell8.hip); gcge_hip_set_spmm_path(1) routes MatDotMultiVec through it              */
 int gcge_hip_sell8_spmm (int nrows, const int *d_orp, const int *d_pcol, const double *d_pval,
 		const double *d_x, long ldx, double *d_y, long ldy, int ncols, void *stream);
+/*     blocks of vectors freed through MultiVecDestroy are kept by size and reused (hipMalloc/hipFree of multi-GB
+ *     blocks cost ~0.3 s each); release returns them to the driver, enable(0) switches the cache off            */
+void gcge_hip_pool_release (void);
+void gcge_hip_pool_enable (int on);
 void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > pad-8 > CSR), 1 SELL-8 passes, 2 generic kernels only */
 /*     pattern path (csrc/hip/spmm_pattern.hip): matrices whose rows repeat a few stencils {(col - row, value)} are
  *     additionally kept as 16-bit pattern ids + a table of npat * lt {double value; long offset} entries (span, span2 =
