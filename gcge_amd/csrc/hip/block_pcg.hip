@@ -15,6 +15,10 @@
 // ops_lin_sol.c:317,365 happens); retired columns get alpha = 0 / keep-flag so their
 // x, r, p are bit-for-bit untouched, as if they had been skipped.
 //
+// A shift published by the caller (GCGE_SetLinearSolverShift: our GCG does it for -gcge_compW_cg_shift, the
+// reference leaves sigma to a user-defined solver, ops_eig_sol_gcg.c:584-618) turns the operator into
+// A + sigma B (second SpMM + axpy per application; B == NULL: + sigma I).
+//
 // Installed as ops->MultiLinearSolver by gcge_hip_bpcg_setup(); GCG calls it through
 // the reference's user_defined_multi_linear_solver = 1 hook (ops_eig_sol_gcg.c:584-618).
 #include <hip/hip_runtime.h>
@@ -227,13 +231,13 @@ static void launch_update_xp(long n, const double* r, long ldr, double* p, long 
 
 struct HipBpcg {
   int max_iter; double rate, tol; char tol_type[8];
-  void** mv_ws[3];       // r, p, w (created lazily with the right width)
+  void** mv_ws[4];       // r, p, w (+ B p scratch when a shift with B != NULL is active), created lazily
   int ws_cols, ws_rows;
   int niter; double residual;
   long spmm_calls, spmm_cols;   // statistics for bench.py
   double* d_coef; int* d_flag; double* h_pin; int cap;
 };
-static HipBpcg g_bpcg = {30, 1e-2, 1e-14, "abs", {nullptr, nullptr, nullptr}, 0, 0, 0, -1.0, 0, 0, nullptr, nullptr, nullptr, 0};
+static HipBpcg g_bpcg = {30, 1e-2, 1e-14, "abs", {nullptr, nullptr, nullptr, nullptr}, 0, 0, 0, -1.0, 0, 0, nullptr, nullptr, nullptr, 0};
 
 static void reduce_over_ranks(double* v, int n) {
   GCGE_COMM* c = GCGE_GetComm();
@@ -249,12 +253,35 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
   const int n = gcge_hip_mv_nrows(mv_x);
   if (gcge_hip_mv_nrows(mv_b) != n) { fprintf(stderr, "HIP_BlockPCG: b and x have different row counts\n"); abort(); }
   if (s->ws_cols < nrhs || s->ws_rows != n) {   // (re)create r, p, w for this problem shape
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
       if (s->mv_ws[i]) ops->MultiVecDestroy(&s->mv_ws[i], s->ws_cols, ops);
-      ops->MultiVecCreateByMultiVec(&s->mv_ws[i], nrhs, mv_x, ops);
+      if (i < 3) ops->MultiVecCreateByMultiVec(&s->mv_ws[i], nrhs, mv_x, ops);
     }
     s->ws_cols = nrhs; s->ws_rows = n;
   }
+  // operator: A, or A + sigma B when the caller published a shift (GCGE_SetLinearSolverShift)
+  double sigma = 0.0; void* matB = nullptr;
+  GCGE_GetLinearSolverShift(&sigma, &matB);
+  if (sigma != 0.0 && matB != nullptr && s->mv_ws[3] == nullptr) ops->MultiVecCreateByMultiVec(&s->mv_ws[3], s->ws_cols, mv_x, ops);
+  // y[:, ys:ys+k) = (A + sigma B) x[:, xs:xs+k); dots != NULL: dots[j] = x_j . y_j (local part)
+  auto apply = [&](void** xin, int xs, void** yout, int ys, int k, double* dots) {
+    int a2[2] = {xs, ys}, b2[2] = {xs + k, ys + k};
+    if (sigma == 0.0) {
+      if (dots) gcge_hip_spmm_dot_mv(mat, xin, yout, a2, b2, dots, ops);
+      else ops->MatDotMultiVec(mat, xin, yout, a2, b2, ops);
+      return;
+    }
+    ops->MatDotMultiVec(mat, xin, yout, a2, b2, ops);
+    if (matB != nullptr) {
+      int a3[2] = {xs, 0}, b3[2] = {xs + k, k};
+      ops->MatDotMultiVec(matB, xin, s->mv_ws[3], a3, b3, ops);
+      int a4[2] = {0, ys}, b4[2] = {k, ys + k};
+      ops->MultiVecAxpby(sigma, s->mv_ws[3], 1.0, yout, a4, b4, ops);
+    } else {
+      ops->MultiVecAxpby(sigma, xin, 1.0, yout, a2, b2, ops);
+    }
+    if (dots) ops->MultiVecLocalInnerProd('D', xin, yout, 0, a2, b2, dots, 1, ops);
+  };
   if (s->cap < nrhs) {
     if (s->d_coef) { hipFree(s->d_coef); hipFree(s->d_flag); hipHostFree(s->h_pin); }
     s->cap = nrhs + 64;
@@ -281,8 +308,7 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
     for (int i = 0; i < nrhs; ++i) norm_b[i] = 1.0;   // "abs" ("user" scales are a BlockPCG-internal feature)
   }
   // r = b - A x ; rho2 = diag(r^T r)
-  st2[0] = start_bx[1]; en2[0] = end_bx[1]; st2[1] = 0; en2[1] = nrhs;
-  ops->MatDotMultiVec(mat, mv_x, s->mv_ws[0], st2, en2, ops);
+  apply(mv_x, start_bx[1], s->mv_ws[0], 0, nrhs, nullptr);
   s->spmm_calls++; s->spmm_cols += nrhs;
   st2[0] = start_bx[0]; en2[0] = end_bx[0]; st2[1] = 0; en2[1] = nrhs;
   ops->MultiVecAxpby(1.0, mv_b, -1.0, s->mv_ws[0], st2, en2, ops);
@@ -337,8 +363,7 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
     while (alo < hi && !active[alo]) ++alo;
     while (ahi > alo && !active[ahi - 1]) --ahi;
     const int aw = ahi - alo;
-    st2[0] = alo; en2[0] = ahi; st2[1] = alo; en2[1] = ahi;
-    gcge_hip_spmm_dot_mv(mat, s->mv_ws[1], s->mv_ws[2], st2, en2, pTw.data() + alo, ops);
+    apply(s->mv_ws[1], alo, s->mv_ws[2], alo, aw, pTw.data() + alo);
     s->spmm_calls++; s->spmm_cols += aw;
     reduce_over_ranks(pTw.data() + alo, aw);
     // r -= alpha w ; rho2 = diag(r^T r)
@@ -407,7 +432,7 @@ extern "C" void gcge_hip_bpcg_stats(long* spmm_calls, long* spmm_cols, int* last
   if (last_niter) *last_niter = g_bpcg.niter;
 }
 extern "C" void gcge_hip_bpcg_release(struct OPS_* ops) {
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 4; ++i)
     if (g_bpcg.mv_ws[i]) ops->MultiVecDestroy(&g_bpcg.mv_ws[i], g_bpcg.ws_cols, ops);
   g_bpcg.ws_cols = 0; g_bpcg.ws_rows = 0;
 }

@@ -252,7 +252,9 @@ static void ComputeW(Ctx *c, int *offset)
 					sigma != 0.0 ? MatDotMultiVecShift : NULL, ops);
 		}
 	}
+	if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverShift(sigma, c->B);
 	ops->MultiLinearSolver(c->A, b, c->V, s, e, ops);
+	if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverShift(0.0, NULL);
 	if (sigma != 0.0 && c->B != NULL && ops->MatAxpby != NULL
 			&& p->user_defined_multi_linear_solver != 1)
 		ops->MatAxpby(-sigma, c->B, 1.0, c->A, ops);

@@ -33,6 +33,14 @@ void GCGE_SetComm(const GCGE_COMM *comm)
 }
 GCGE_COMM *GCGE_GetComm(void) { return g_comm; }
 
+static double g_ls_sigma = 0.0; static void *g_ls_matB = NULL;
+void GCGE_SetLinearSolverShift(double sigma, void *matB) { g_ls_sigma = sigma; g_ls_matB = matB; }
+void GCGE_GetLinearSolverShift(double *sigma, void **matB)
+{
+	if (sigma) *sigma = g_ls_sigma;
+	if (matB) *matB = g_ls_matB;
+}
+
 /* ---------------------------------------------------------------- services */
 void DefaultPrintf(const char *fmt, ...)
 {

