@@ -105,12 +105,13 @@ def main():
 
     N = args.size
     n_global = N ** 3
-    # weak scaling: every rank owns a slab of `size^3` rows (planes along k), so n_global grows with the rank count
-    planes = N * world
+    # weak scaling: every rank owns size^3 rows of a grid that stays as cube-like as the rank count allows
+    # (1: N^3, 2: 2N x N x N, 4: 2N x 2N x N, 8: (2N)^3 = BASELINE config 4), cut into slabs along the last index
+    dims = gdist.weak_scaling_box(N, world)
     if world > 1:
         comm = gdist.install(hip, dist, rank, world, stage_through_host=rehearse)
-        A, mat = gdist.lap3d_slab(hip, N, planes, rank, world, comm)
-        n_global = N * N * planes
+        A, mat = gdist.lap3d_slab(hip, dims, rank, world, comm)
+        n_global = dims[0] * dims[1] * dims[2]
     else:
         A, _ = make_problem("lap3d", N)
         mat = hip.matrix(A)
@@ -162,9 +163,8 @@ def main():
         ev, res = last
         import numpy as np
         # parity guard inside the bench: converged Ritz values vs the closed-form spectrum
-        c = 2.0 * np.cos(np.arange(1, N + 1) * np.pi / (N + 1))
-        ck = 2.0 * np.cos(np.arange(1, planes + 1) * np.pi / (planes + 1))
-        small = np.sort((6.0 - np.sort(c)[::-1][:24, None, None] - np.sort(c)[::-1][None, :24, None] - np.sort(ck)[::-1][None, None, :48]).ravel())
+        cs = [np.sort(2.0 * np.cos(np.arange(1, d + 1) * np.pi / (d + 1)))[::-1][:48] for d in dims]
+        small = np.sort((6.0 - cs[0][:, None, None] - cs[1][None, :, None] - cs[2][None, None, :]).ravel())
         rel = float(np.max(np.abs(ev[:res.nevConv] - small[:res.nevConv]) / small[:res.nevConv]))
         achieved = (by.value / cnt) / (ms.value / cnt * 1e-3) / 1e9 if cnt else 0.0
         npat = g.gcge_hip_mat_patterns(mat)
@@ -175,7 +175,7 @@ def main():
         # live: counters need their own runs): TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B, gfx950 correction of
         # MI355X_MICROARCH.md applied; profiles/r01_spmm_explore/15_pattern_pmc.log
         traffic, traffic_note = None, "no PMC profile for this shape"
-        if npat > 0 and N == 256 and args.block == 64:
+        if npat > 0 and N == 256 and args.block == 64 and world == 1:
             traffic = 4 * (2.69835e7 * 128 + 3.35544e7 * 64)
             traffic_note = "4 passes x (2.698e7 x 128 B reads + 3.355e7 x 64 B writes), profiles/r01_spmm_explore/15_pattern_pmc.log"
         kname = ("spmm_pattern<7> x %d passes of 16 columns + column dots (K1, %d row patterns, m=%d)" % ((args.block + 15) // 16, npat, args.block)
@@ -185,9 +185,9 @@ def main():
             "value": conv_total / elapsed, "unit": "eigenpairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Lap3D %d^3 per GPU (7-pt, CSR, n=%d global), nev=%d, block=%d, nevMax=%d, B=NULL, "
+            "config": {"workload": "Lap3D %d^3 rows per GPU, grid %dx%dx%d (7-pt, CSR, n=%d global), nev=%d, block=%d, nevMax=%d, B=NULL, "
                                    "tol abs 1e-1 rel 1e-8, fused device block-CG (30 its, rate 1e-2), X/W orthonormalisation '%s', device RNG start block"
-                                   % (N, n_global, args.nev, args.block, args.nevmax, args.orth),
+                                   % (N, dims[0], dims[1], dims[2], n_global, args.nev, args.block, args.nevmax, args.orth),
                        "gcg_iterations": iters, "nev_converged": conv_total,
                        "max_rel_err_vs_closed_form": rel,
                        "phase_seconds": {k: getattr(res.timing, k) for k in ("initX", "checkconv", "compP", "compRR", "compRV", "compW", "linsol", "total")}},

@@ -132,7 +132,7 @@ using namespace gcge;
 // blocks): then the X rows a wave fetched as "+N^2" neighbours are the rows it needs itself one (or a few)
 // iterations later, so the reuse is private to the wave / CU and does not depend on blocks advancing in
 // lock-step.  Otherwise fast blocks drift planes ahead of slow ones and the reuse is lost from L2.
-// Hence: blocks = span / 32 / j with the smallest j that keeps the grid below ~3072 blocks.
+// Hence: blocks = span / 32 / j with the smallest j that divides span / 32 and keeps the grid below ~3072 blocks.
 static int g_pat_grid = 0;   // > 0: forced (tuning)
 extern "C" void gcge_hip_spmm_pattern_tune(int grid) { g_pat_grid = grid > 0 ? (grid + 7) / 8 * 8 : 0; }
 // tiles of 4 slices `line` rows apart: groups of 4 lines x (line / 8) slices per line
@@ -151,7 +151,11 @@ static long pat_grid(long span, long ntiles) {
   else {
     const long target = span / 32;
     if (target < 256) g = 1024;                          // short reuse distances live in L2 anyway
-    else { const long j = (target + 3071) / 3072; g = (target / j + 7) / 8 * 8; }
+    else {   // smallest j that divides the plane into an integral number of strides of at most ~3072 blocks
+      long j = (target + 3071) / 3072;
+      while (j < 64 && target % j != 0) ++j;
+      g = (target % j == 0) ? target / j : (target / j + 7) / 8 * 8;
+    }
   }
   return g < ntiles ? g : ntiles;
 }

@@ -177,13 +177,23 @@ def hip_slab_matrix(hip, comm, A, n_global, part, cap_cols=128):
     return mat
 
 
-def lap3d_slab(hip, N, planes, rank, world, comm=None):
-    """Weak-scaling workload of bench.py: an N x N x planes box, rank r owns planes*N*N/world rows."""
+def weak_scaling_box(N, world):
+    """Grid of bench.py's weak-scaling workload: N^3 rows per rank, as cube-like as possible so that the spectrum
+    (and with it the GCG iteration count) stays comparable across rank counts: 1: N^3, 2: 2N x N x N,
+    4: 2N x 2N x N, 8: (2N)^3 (= BASELINE config 4 at N = 256); other counts: N x N x (N world).
+    Slabs are cut along the last (slowest) index."""
+    dims = {1: (N, N, N), 2: (2 * N, N, N), 4: (2 * N, 2 * N, N), 8: (2 * N, 2 * N, 2 * N)}
+    return dims.get(world, (N, N, N * world))
+
+
+def lap3d_slab(hip, dims, rank, world, comm=None):
+    """Slab of the 7-point Laplacian on an Nx x Ny x Nz grid: rank r owns Nz/world planes (rows in natural order)."""
     h = host_lib()
-    n_global = N * N * planes
+    nx, ny, nz = dims
+    n_global = nx * ny * nz
     part = row_partition(n_global, world)
     A = CSR()
-    rc = h.gcge_problem_lap3d_box(C.c_int(N), C.c_int(N), C.c_int(planes), C.c_int64(part[rank]),
+    rc = h.gcge_problem_lap3d_box(C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int64(part[rank]),
                                   C.c_int64(part[rank + 1]), C.byref(A))
     if rc != 0:
         raise RuntimeError("gcge_problem_lap3d_box failed")
