@@ -29,15 +29,19 @@ static double max_abs(const double *v, int n)
 static void negate(double *v, int n) { int i; for (i = 0; i < n; ++i) v[i] = -v[i]; }
 
 /* x[:, s1:e1) -= x[:, s0:e0) * (x[:, s0:e0)^T B x[:, s1:e1)), repeated up to 1+max_reorth
- * times.  Returns nothing; coef scratch needs (e0-s0)*(e1-s1) doubles. */
+ * times.  Returns nothing; coef scratch needs (e0-s0)*(e1-s1) doubles.
+ * lazy = 0: the reference's order (ops_orth.c:235-265: apply the update, then test its size);
+ * lazy = 1: a re-orthogonalisation pass whose coefficients are already below reorth_tol is not
+ * applied at all (it would change x by < 50 eps; saves one n x k x m panel update per call). */
 static void project_out(void **x, int s0, int e0, int s1, int e1, void *B,
-		int max_reorth, double reorth_tol, void **mv_ws, double *coef, struct OPS_ *ops)
+		int max_reorth, double reorth_tol, int lazy, void **mv_ws, double *coef, struct OPS_ *ops)
 {
 	int pass, start[2], end[2], k = e0 - s0, m = e1 - s1; double one = 1.0;
 	if (k <= 0 || m <= 0) return;
 	for (pass = 0; pass < 1 + max_reorth; ++pass) {
 		start[0] = s0; end[0] = e0; start[1] = s1; end[1] = e1;
 		ops->MultiVecQtAP('S', 'N', x, B, x, 0, start, end, coef, k, mv_ws, ops);
+		if (lazy && pass > 0 && max_abs(coef, k * m) < reorth_tol) break;
 		negate(coef, k * m);
 		ops->MultiVecLinearComb(x, x, 0, start, end, coef, k, &one, 0, ops);
 		if (max_abs(coef, k * m) < reorth_tol) break;
@@ -90,7 +94,7 @@ static void orth_self(void **x, int start_x, int *end_x, void *B, int max_reorth
  * it.  On the first pass B*block is formed in mv_ws (side effect of QtAP); later passes
  * re-use it ('T' output keeps the coefficient matrix in the layout LinearComb wants). */
 static void project_block_from_rest(void **x, int b0, int b1, int e, void *B,
-		int max_reorth, double reorth_tol, void **mv_ws, double *coef, struct OPS_ *ops)
+		int max_reorth, double reorth_tol, int lazy, void **mv_ws, double *coef, struct OPS_ *ops)
 {
 	int pass, start[2], end[2], nb = b1 - b0, rem = e - b1; double one = 1.0;
 	if (nb <= 0 || rem <= 0) return;
@@ -102,6 +106,7 @@ static void project_block_from_rest(void **x, int b0, int b1, int e, void *B,
 			start[0] = b1; end[0] = e; start[1] = b0; end[1] = b1;
 			ops->MultiVecQtAP('S', 'T', x, B, x, 0, start, end, coef, nb, mv_ws, ops);
 		}
+		if (lazy && pass > 0 && max_abs(coef, nb * rem) < reorth_tol) break;
 		negate(coef, nb * rem);
 		start[0] = b0; end[0] = b1; start[1] = b1; end[1] = e;
 		ops->MultiVecLinearComb(x, x, 0, start, end, coef, nb, &one, 0, ops);
@@ -115,7 +120,7 @@ static void ModifiedGramSchmidt(void **x, int start_x, int *end_x, void *B, stru
 	double *coef = p->dbl_ws;
 	int block, b0, b1, start[2], end[2];
 	if (*end_x <= start_x) return;
-	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, p->mv_ws, coef, ops);
+	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, 0, p->mv_ws, coef, ops);
 
 	b0 = start_x;
 	block = p->block_size;
@@ -134,7 +139,7 @@ static void ModifiedGramSchmidt(void **x, int start_x, int *end_x, void *B, stru
 		}
 		*end_x -= dropped;
 		if (b1 < *end_x && b0 < b1)
-			project_block_from_rest(x, b0, b1, *end_x, B, p->max_reorth, p->reorth_tol, p->mv_ws, coef, ops);
+			project_block_from_rest(x, b0, b1, *end_x, B, p->max_reorth, p->reorth_tol, 0, p->mv_ws, coef, ops);
 		b0 = b1;
 		if (block > *end_x - b0) block = *end_x - b0;
 	}
@@ -242,7 +247,7 @@ static void CholeskyQR(void **x, int start_x, int *end_x, void *B, struct OPS_ *
 	double *coef = p->dbl_ws;
 	int block, b0, b1, start[2], end[2];
 	if (*end_x <= start_x) return;
-	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, p->mv_ws, coef, ops);
+	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, 1, p->mv_ws, coef, ops);
 	b0 = start_x;
 	block = p->block_size;
 	if (block <= 0) block = *end_x - b0;
@@ -260,7 +265,7 @@ static void CholeskyQR(void **x, int start_x, int *end_x, void *B, struct OPS_ *
 		}
 		*end_x -= dropped;
 		if (b1 < *end_x && b0 < b1)
-			project_block_from_rest(x, b0, b1, *end_x, B, p->max_reorth, p->reorth_tol, p->mv_ws, coef, ops);
+			project_block_from_rest(x, b0, b1, *end_x, B, p->max_reorth, p->reorth_tol, 1, p->mv_ws, coef, ops);
 		b0 = b1;
 		if (block > *end_x - b0) block = *end_x - b0;
 	}
@@ -353,7 +358,7 @@ static void BinaryGramSchmidt(void **x, int start_x, int *end_x, void *B, struct
 	BinaryGramSchmidtOrth *p = (BinaryGramSchmidtOrth*)ops->orth_workspace;
 	int n, block = p->block_size; char leaf;
 	if (*end_x <= start_x) return;
-	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, p->mv_ws, p->dbl_ws, ops);
+	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, 0, p->mv_ws, p->dbl_ws, ops);
 	n = *end_x - start_x;
 	if (n < 16) { if (block <= 0) block = 4; leaf = 'M'; }
 	else { if (block <= 0 || block > n / 4) block = n / 4; leaf = 'E'; }
