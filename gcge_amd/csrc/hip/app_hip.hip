@@ -170,7 +170,7 @@ extern "C" long gcge_hip_profile_spmm(int ncols, double* total_ms, double* total
 // A->d_pid == NULL when the matrix has too many distinct rows (irregular matrices give up after a few
 // hundred rows, so the scan costs nothing there).
 struct PatEntryH { double val; long off; };
-static void build_patterns(GCGE_HIP_MAT* A, int nrows, const int* rowptr, const int* colidx, const double* val) {
+static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val) {
   A->d_pid = nullptr; A->d_tab = nullptr; A->npat = 0; A->pat_lt = 0;
   int maxlen = 0;
   for (int r = 0; r < nrows; ++r) maxlen = std::max(maxlen, rowptr[r + 1] - rowptr[r]);
@@ -230,6 +230,64 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, const int* rowptr, const 
     const long o = tab[(size_t)common * lt + k].off, ao = o < 0 ? -o : o;
     if (ao < A->pat_span) A->pat_span2 = std::max(A->pat_span2, ao);
   }
+  // Chain layout (spmm_pattern_chain_kernel): possible when the interior stencil reaches -S, 0 and +S with S a
+  // multiple of 32 rows and all patterns together use at most lt distinct offsets.  Every pattern is then rewritten
+  // on the same slots [-S, 0, +S, the other offsets ascending]: entries a row does not have get value 0 but keep
+  // their offset as long as the address stays inside the block of vectors (patterns are split by that validity),
+  // so what a lane loads through a slot depends on its position only, never on its pattern.
+  do {
+    const long S = A->pat_span;
+    if (getenv("GCGE_NO_CHAIN") != nullptr || lt < 4 || S <= 0 || S % 32 != 0) break;
+    std::vector<long> offs;
+    for (const PatEntryH& e : tab) if (e.val != 0.0 || e.off != 0) offs.push_back(e.off);
+    offs.push_back(0);
+    std::sort(offs.begin(), offs.end()); offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+    if ((int)offs.size() > lt) break;
+    auto has = [&](long o) { return std::binary_search(offs.begin(), offs.end(), o); };
+    bool common_ok = has(-S) && has(S);
+    { bool m = false, c = false, q = false;
+      for (int k = 0; k < lt; ++k) { const PatEntryH& e = tab[(size_t)common * lt + k]; if (e.val != 0.0) { m |= e.off == -S; c |= e.off == 0; q |= e.off == S; } }
+      common_ok = common_ok && m && c && q; }
+    if (!common_ok) break;
+    std::vector<long> slot = {-S, 0, S};
+    for (long o : offs) if (o != -S && o != 0 && o != S) slot.push_back(o);
+    while ((int)slot.size() < lt) slot.push_back(0);            // unused slots: own row, value 0
+    const int nslot_used = (int)offs.size();
+    // per generic pattern: value on every slot
+    const int np = A->npat;
+    std::vector<double> pval((size_t)np * lt, 0.0);
+    for (int p = 0; p < np; ++p)
+      for (int k = 0; k < lt; ++k) {
+        const PatEntryH& e = tab[(size_t)p * lt + k];
+        if (e.val == 0.0 && e.off == 0) continue;
+        for (int sidx = 0; sidx < nslot_used; ++sidx) if (slot[sidx] == e.off) { pval[(size_t)p * lt + sidx] += e.val; break; }
+      }
+    // split by address validity of the slots
+    std::unordered_map<uint64_t, int> id_of;
+    std::vector<PatEntryH> ctab;
+    std::vector<unsigned short> cpid((size_t)nrows);
+    bool ok = true;
+    for (int r = 0; r < nrows && ok; ++r) {
+      unsigned mask = 0;
+      for (int sidx = 0; sidx < nslot_used; ++sidx) { const long c = (long)r + slot[sidx]; if (c < 0 || c >= ncols_local) mask |= 1u << sidx; }
+      const uint64_t key = ((uint64_t)pid[r] << 32) | mask;
+      auto it = id_of.find(key);
+      if (it == id_of.end()) {
+        const int id = (int)(ctab.size() / lt);
+        if (id >= maxpat) { ok = false; break; }
+        for (int sidx = 0; sidx < lt; ++sidx) {
+          PatEntryH e = {pval[(size_t)pid[r] * lt + sidx], (sidx < nslot_used && !(mask >> sidx & 1)) ? slot[sidx] : 0};
+          if (mask >> sidx & 1) { if (e.val != 0.0) ok = false; e.val = 0.0; }   // an entry cannot point outside the matrix
+          ctab.push_back(e);
+        }
+        it = id_of.emplace(key, id).first;
+      }
+      cpid[r] = (unsigned short)it->second;
+    }
+    if (!ok) break;
+    tab.swap(ctab); pid.swap(cpid);
+    A->npat = (int)(tab.size() / lt); A->pat_span2 = -1;
+  } while (0);
   GCGE_HIP_CHECK(hipMalloc(&A->d_pid, (size_t)nrows * sizeof(unsigned short)));
   GCGE_HIP_CHECK(hipMalloc(&A->d_tab, tab.size() * sizeof(PatEntryH)));
   GCGE_HIP_CHECK(hipMemcpy(A->d_pid, pid.data(), (size_t)nrows * sizeof(unsigned short), hipMemcpyHostToDevice));
@@ -272,7 +330,7 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, i
   GCGE_HIP_CHECK(hipMemcpy(A->d_orp, orp.data(), ((size_t)nrows + 1) * sizeof(int), hipMemcpyHostToDevice));
   GCGE_HIP_CHECK(hipMemcpy(A->d_pcol, pc.data(), noct * 8 * sizeof(int), hipMemcpyHostToDevice));
   GCGE_HIP_CHECK(hipMemcpy(A->d_pval, pv.data(), noct * 8 * sizeof(double), hipMemcpyHostToDevice));
-  build_patterns(A, nrows, rowptr, colidx, val);
+  build_patterns(A, nrows, ncols_local, rowptr, colidx, val);
   return A;
 }
 extern "C" GCGE_HIP_MAT* gcge_hip_mat_create(int nrows, int nglobal, int row_begin, const int* rowptr,
@@ -311,6 +369,8 @@ extern "C" int gcge_hip_mat_nrows(const GCGE_HIP_MAT* A) { return A->nrows; }
 extern "C" long gcge_hip_mat_nnz(const GCGE_HIP_MAT* A) { return A->nnz; }
 // number of row patterns the SpMM pattern path works with (0: the matrix is served by the generic pad-8 kernels)
 extern "C" int gcge_hip_mat_patterns(const GCGE_HIP_MAT* A) { return A->d_pid ? A->npat : 0; }
+// 1: the pattern table is in chain layout (the +-S rows of the stencil stay in registers between iterations)
+extern "C" int gcge_hip_mat_pattern_chain(const GCGE_HIP_MAT* A) { return A->d_pid && A->pat_span2 == -1; }
 
 // ------------------------------------------------------------------ device buffer pool
 // hipMalloc / hipFree of the multi-GB blocks cost 0.25-0.3 s each on this stack (page-table set-up; hipFree also

@@ -27,10 +27,13 @@
 //     surplus iterations re-do the wave's last slice and only their stores are predicated.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "gcge_hip_internal.h"
 
 extern "C" double* gcge_hip_partial_ws(size_t len);
 extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, int len, double* d_out, void* stream);
+extern "C" void gcge_hip_reduce_partials16(const double* d_partial, int nblocks, long slab_stride, int ncols, double* d_out,
+                                           void* stream);
 
 namespace gcge {
 
@@ -120,6 +123,123 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
   }
 }
 
+
+// ---- chain variant: the +-S rows stay in registers ------------------------------------------------------------
+// Table layout per pattern (built by app_hip.hip when the matrix qualifies): slot 0: offset -S, slot 1: offset 0,
+// slot 2: offset +S, slots 3..LT-1: the remaining offsets, where S = the row stride of a wave between two of its
+// iterations (blocks = S / 32).  Then the row fetched through slot 2 at iteration it, L(it) = X[row + S], IS the
+// centre row of iteration it+1 and the "-S" row of iteration it+2: one new load per iteration replaces three
+// (7 -> 5 loads per row on the 7-point stencil; the column dot gets its own-row value for free).  Four rotating
+// registers hold L(it-2) .. L(it+1) (the loop is unrolled four times so the rotation is pure renaming), the other
+// slots keep their two alternating register sets.  Offsets of slots 0 and 2 that would leave the matrix are stored
+// as 0 with value 0 (patterns are split by that validity), so every lane whose NEXT row exists has loaded exactly
+// that row through slot 2.
+template <int LT, int DOT>
+__global__ __launch_bounds__(256) void spmm_pattern_chain_kernel(
+    long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
+    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
+    double* __restrict__ dot_partial) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
+  for (int e = threadIdx.x; e < ntab; e += 256) s_tab[e] = tab[e];
+  __syncthreads();
+  constexpr int NO = LT - 3;   // slots outside the chain
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 3, i = lane & 7;
+  const bool act = 2 * i < m;
+  const double* __restrict__ xl = x + (act ? 2 * i : 0);
+  double d0 = 0.0, d1 = 0.0;
+  const long G = gridDim.x;
+  if ((long)blockIdx.x < ntiles) {
+    const long cnt = (ntiles - blockIdx.x + G - 1) / G;
+    // tile t -> (group of 4 lines q, slice a): wave w works on line 4q + w (line = 8: four consecutive slices);
+    // the launch guarantees that G tiles are exactly S rows, so the chain holds for either geometry
+    const long aslices = line / 8;
+    auto row_at = [&](long it) {                                                                   // unclamped
+      const long t = blockIdx.x + it * G, q = t / aslices, a = t - q * aslices;
+      return (4 * q + wave) * line + 8 * a + g;
+    };
+    auto row_of = [&](long it) { return min(row_at(min(it, cnt - 1)), nrows - 1); };               // clamped
+    auto issue = [&](v2d& lnew, v2d (&oth)[NO], double (&val)[LT], long row, int p) {
+      const PatEntry* e = s_tab + p * LT;
+      val[0] = e[0].val; val[1] = e[1].val;
+      { const PatEntry c = e[2]; val[2] = c.val; lnew = *reinterpret_cast<const v2d*>(xl + (size_t)(row + c.off) * ldx); }
+#pragma unroll
+      for (int t = 0; t < NO; ++t) {
+        const PatEntry c = e[3 + t];
+        val[3 + t] = c.val;
+        oth[t] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + c.off) * ldx);
+      }
+    };
+    auto finish = [&](const v2d& a, const v2d& b, const v2d& c, const v2d (&oth)[NO], const double (&val)[LT], long it) {
+      double a0 = val[0] * a.x, a1 = val[0] * a.y;
+      a0 = fma(val[1], b.x, a0); a1 = fma(val[1], b.y, a1);
+      a0 = fma(val[2], c.x, a0); a1 = fma(val[2], c.y, a1);
+#pragma unroll
+      for (int t = 0; t < NO; ++t) { a0 = fma(val[3 + t], oth[t].x, a0); a1 = fma(val[3 + t], oth[t].y, a1); }
+      const long row = row_at(it);
+      const bool ok = it < cnt && row < nrows && act;
+      if (ok) {
+        v2d o = {a0, a1};
+        __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(y + (size_t)row * ldy + 2 * i));
+      }
+      if (DOT) {
+        const double wgt = ok ? 1.0 : 0.0;
+        d0 = fma(a0 * wgt, b.x, d0); d1 = fma(a1 * wgt, b.y, d1);
+      }
+    };
+    v2d r0, r1, r2, r3, o0[NO], o1[NO];
+    double v0[LT], v1[LT];
+    int p0 = pid[row_of(0)], p1 = pid[row_of(1)];
+    {   // start of the chain: L(-2) = X[row0 - S] and L(-1) = X[row0] through slots 0 and 1 of the first row's pattern
+      const long row = row_of(0);
+      const PatEntry* e = s_tab + p0 * LT;
+      r2 = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[0].off) * ldx);
+      r3 = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[1].off) * ldx);
+    }
+    issue(r0, o0, v0, row_of(0), p0);
+    for (long it = 0; it < cnt; it += 4) {
+      const int p2 = pid[row_of(it + 2)];
+      issue(r1, o1, v1, row_of(it + 1), p1);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(r2, r3, r0, o0, v0, it);
+      __builtin_amdgcn_sched_barrier(0);
+      const int p3 = pid[row_of(it + 3)];
+      issue(r2, o0, v0, row_of(it + 2), p2);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(r3, r0, r1, o1, v1, it + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int p4 = pid[row_of(it + 4)];
+      issue(r3, o1, v1, row_of(it + 3), p3);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(r0, r1, r2, o0, v0, it + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      const int p5 = pid[row_of(it + 5)];
+      issue(r0, o0, v0, row_of(it + 4), p4);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(r1, r2, r3, o1, v1, it + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      p1 = p5;
+    }
+  }
+  if (DOT) {
+    auto sx = [](double v, int mask) {
+      int lo = __shfl_xor(__double2loint(v), mask, 64), hi = __shfl_xor(__double2hiint(v), mask, 64);
+      return __hiloint2double(hi, lo);
+    };
+    d0 += sx(d0, 8);  d1 += sx(d1, 8);
+    d0 += sx(d0, 16); d1 += sx(d1, 16);
+    d0 += sx(d0, 32); d1 += sx(d1, 32);
+    __shared__ double sred[4][16];
+    if (lane < 8) { sred[wave][2 * lane] = d0; sred[wave][2 * lane + 1] = d1; }
+    __syncthreads();
+    if (threadIdx.x < 16 && (int)threadIdx.x < m)
+      dot_partial[(long)blockIdx.x * m + threadIdx.x] =
+          (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+  }
+}
+
 }  // namespace gcge
 
 using namespace gcge;
@@ -164,6 +284,12 @@ template <int LT, int DOT>
 static long pat_launch(long nrows, const unsigned short* pid, const void* tab, int npat, const double* x, size_t ldx,
                        double* y, size_t ldy, int m, double* partial, long nb, long line, hipStream_t st) {
   const int ntab = npat * LT;
+  if (line < 0) {   // chain variant: consecutive slices, the caller fixed nb = S / 32
+    const long cl = -line;   // geometry of the chain variant is passed as -line
+    hipLaunchKernelGGL((spmm_pattern_chain_kernel<LT, DOT>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
+                       nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, pat_ntiles(nrows, cl), cl, partial);
+    return nb;
+  }
   hipLaunchKernelGGL((spmm_pattern_kernel<LT, DOT>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
                      nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, pat_ntiles(nrows, line), line, partial);
   return nb;
@@ -190,7 +316,9 @@ extern "C" int gcge_hip_pattern_width(int max_row_len) {
 
 // Y[:,0:ncols) = A X[:,0:ncols); d_dots != NULL: also d_dots[j] = sum_r X[r,j] Y[r,j].
 // d_tab: npat * lt entries of {double value; long column_offset}; span / span2: the longest and second longest
-// |column_offset| of the interior stencil (launch geometry only; 0 if unknown).  -1: alignment contract not met.
+// |column_offset| of the interior stencil (launch geometry only; 0 if unknown).  span2 == -1: the table is in
+// CHAIN layout (slots 0,1,2 = offsets -span, 0, +span; see spmm_pattern_chain_kernel) and span is a multiple of 32.
+// -1: alignment contract not met.
 extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                      long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
                                      double* d_dots, void* stream) {
@@ -201,6 +329,24 @@ extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, con
   const int npass = (ncols + 15) / 16;
   // lines of `span2` rows when they tile the matrix exactly (a plane = a whole number of 4-line groups)
   long line = 8;
+  if (span2 == -1) {   // chain layout: the wave stride must be exactly `span` rows
+    if (span % 32 != 0 || lt < 4) return -1;
+    long cline = 8;   // tuning hook: waves of a block `cline` rows apart (must keep G tiles == span rows)
+    if (g_pat_line > 8 && g_pat_line % 8 == 0 && (span / 32) % (g_pat_line / 8) == 0) cline = g_pat_line;
+    const long nbc = std::min(span / 32, pat_ntiles(nrows, cline));
+    const int npassc = (ncols + 15) / 16;
+    hipStream_t stc = (hipStream_t)stream;
+    double* partc = d_dots ? gcge_hip_partial_ws((size_t)nbc * 16 * npassc) : nullptr;
+    for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
+      const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
+      double* pp = partc ? partc + (size_t)ps * nbc * 16 : nullptr;
+      long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, nbc, -cline, stc)
+                        : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, nbc, -cline, stc);
+      if (rcl < 0) return -1;
+    }
+    if (d_dots) gcge_hip_reduce_partials16(partc, (int)nbc, nbc * 16, ncols, d_dots, stc);   // all passes in one launch
+    return (int)hipGetLastError();
+  }
   if (g_pat_line < 0 && span2 >= 8 && span2 % 8 == 0 && span > span2 && span % (4 * span2) == 0) line = span2;
   if (g_pat_line >= 8 && g_pat_line % 8 == 0) line = g_pat_line;
   const long nb = pat_grid(span, pat_ntiles(nrows, line));
@@ -210,10 +356,10 @@ extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, con
     if (d_dots) {
       double* pp = part + (size_t)ps * nb * 16;
       if (pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, nb, line, st) < 0) return -1;
-      gcge_hip_reduce_partials(pp, (int)nb, m, d_dots + c0, st);
     } else if (pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, nb, line, st) < 0) {
       return -1;
     }
   }
+  if (d_dots) gcge_hip_reduce_partials16(part, (int)nb, nb * 16, ncols, d_dots, st);   // all passes in one launch
   return (int)hipGetLastError();
 }

@@ -233,6 +233,34 @@ extern "C" int gcge_hip_coldots(int nrows, const double* d_x, long ldx, const do
   return (int)hipGetLastError();
 }
 
+// npass slabs of [nblocks][m_ps] partials (m_ps <= 16 columns each; slab ps starts at partial + ps*slab_stride) ->
+// out[16*ps + j]: one block per slab, 64 row lanes x 16 columns, fixed order
+__global__ __launch_bounds__(1024) void reduce_partials16(const double* __restrict__ partial, int nblocks, long slab_stride,
+    int ncols, double* __restrict__ out) {
+  __shared__ double red[64][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c0 = 16 * blockIdx.x, m = min(16, ncols - c0);
+  const double* src = partial + (long)blockIdx.x * slab_stride;
+  double s0 = 0.0, s1 = 0.0;
+  if (tx < m) {
+    int b = ty;
+    for (; b + 64 < nblocks; b += 128) { s0 += src[(long)b * m + tx]; s1 += src[(long)(b + 64) * m + tx]; }
+    for (; b < nblocks; b += 64) s0 += src[(long)b * m + tx];
+  }
+  red[ty][tx] = s0 + s1;
+  __syncthreads();
+  for (int h = 32; h > 0; h >>= 1) {
+    if (ty < h) red[ty][tx] += red[ty + h][tx];
+    __syncthreads();
+  }
+  if (ty == 0 && tx < m) out[c0 + tx] = red[0][tx];
+}
+extern "C" void gcge_hip_reduce_partials16(const double* d_partial, int nblocks, long slab_stride, int ncols, double* d_out,
+                                           void* stream) {
+  hipLaunchKernelGGL(reduce_partials16, dim3((ncols + 15) / 16), dim3(1024), 0, (hipStream_t)stream, d_partial, nblocks,
+                     slab_stride, ncols, d_out);
+}
+
 // exported so other translation units reuse the same fixed-order reduction
 extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, int len, double* d_out, void* stream) {
   hipLaunchKernelGGL(reduce_partials, dim3((len + 63) / 64), dim3(1024), 0, (hipStream_t)stream, d_partial, nblocks,

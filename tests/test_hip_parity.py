@@ -78,9 +78,10 @@ def test_spmm_sell8_path_vs_oracle(both, kind, size, kw):
         hip.g.gcge_hip_set_spmm_path(0)
 
 
-@pytest.mark.parametrize("kind,size,expect", [("lap3d", 13, True), ("fe3d", 11, True), ("fe1d", 500, True),
-                                              ("sio2", 10, False)])
-def test_spmm_pattern_path_vs_generic_and_oracle(both, kind, size, expect):
+@pytest.mark.parametrize("kind,size,expect,chain", [("lap3d", 13, True, False), ("fe3d", 11, True, False),
+                                                    ("fe1d", 500, True, False), ("sio2", 10, False, False),
+                                                    ("lap3d", 16, True, True), ("fe3d", 24, True, True)])
+def test_spmm_pattern_path_vs_generic_and_oracle(both, kind, size, expect, chain):
     """Stencil matrices take the pattern path (16-bit pattern ids + table); it must agree with the generic
     pad-8/CSR kernels and the oracle for wide, narrow and offset column ranges; irregular matrices must not qualify."""
     hip, ora = both
@@ -88,6 +89,9 @@ def test_spmm_pattern_path_vs_generic_and_oracle(both, kind, size, expect):
     hip.g.gcge_hip_mat_patterns.argtypes = [C.c_void_p]
     npat = hip.g.gcge_hip_mat_patterns(mh)
     assert (npat > 0) == expect, npat
+    # grids whose plane is a multiple of 32 rows get the chain layout (the +-N^2 rows stay in registers)
+    hip.g.gcge_hip_mat_pattern_chain.argtypes = [C.c_void_p]
+    assert bool(hip.g.gcge_hip_mat_pattern_chain(mh)) == chain
     n = A.nrows
     X = uniform(19, (n, 80)) - 0.5
     xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)

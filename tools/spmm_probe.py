@@ -19,7 +19,8 @@ mA = hip.matrix(A)
 print("n", A.nrows, "nnz", A.nnz, "patterns", g.gcge_hip_mat_patterns(mA))
 hip.set_random_mode(1, 7)
 ops = hip.ops
-V = ops.mv_create(256, mA); ops.set_random(V, 0, 256)
+vc = int(os.environ.get('V_COLS', '256'))
+V = ops.mv_create(vc, mA); ops.set_random(V, 0, vc)
 Wv = ops.mv_create(m, mA)
 g.gcge_hip_set_spmm_path(path)
 if os.environ.get('PAT_LINE'):
@@ -36,4 +37,4 @@ for x0 in (192, 128):
     cnt = g.gcge_hip_profile_spmm(m, C.byref(ms), C.byref(by))
     g.gcge_hip_profile_enable(0)
     t = ms.value / cnt
-    print("path %d  m=%d x0=%d (ld 256 -> ld %d): %.3f ms  %.1f GB/s on CSR bytes (%.1f%% of 8 TB/s)" % (path, m, x0, m, t, by.value / cnt / t * 1e-6, by.value / cnt / t * 1e-6 / 80))
+    print("path %d  m=%d x0=%d (V cols %d -> ld %d): %.3f ms  %.1f GB/s on CSR bytes (%.1f%% of 8 TB/s)" % (path, m, x0, vc, m, t, by.value / cnt / t * 1e-6, by.value / cnt / t * 1e-6 / 80))
