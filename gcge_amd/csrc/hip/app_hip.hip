@@ -28,7 +28,7 @@ int gcge_hip_sell8_spmm(int nrows, const int* d_orp, const int* d_pcol, const do
                         double* d_y, long ldy, int ncols, void* stream);
 int gcge_hip_pattern_width(int max_row_len);
 int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2, const double* d_x, long ldx,
-                          double* d_y, long ldy, int ncols, double* d_dots, void* stream);
+                          double* d_y, long ldy, int ncols, double* d_dots, double* d_dots_yy, void* stream);
 int gcge_hip_colscale(int nrows, double* d_y, long ldy, int m, const double* d_s, void* stream);
 int gcge_hip_fill_uniform(int nrows, long row_begin, long nglobal, double* d_y, long ldy, int c0, int m,
                           unsigned long long seed, void* stream);
@@ -636,7 +636,7 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
   if (A->d_pid != nullptr && g_spmm_path == 0)
-    rc = gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, dx, vx->ld, dy, vy->ld, m, nullptr, g_stream);
+    rc = gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, dx, vx->ld, dy, vy->ld, m, nullptr, nullptr, g_stream);
   if (rc != -1) {}
   else if (m >= 16 && g_spmm_path == 1) rc = gcge_hip_sell8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
   else if (m >= 16) rc = gcge_hip_pad8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
@@ -647,8 +647,15 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
 // Fused  y = A x  and  dots[j] = sum_r x[r,j] y[r,j]  (the p.w of a CG step) — LOCAL part only; the
 // caller reduces over ranks.  Falls back to SpMM + column dots when the fast kernel's alignment
 // contract is not met.  Internal entry point of the fused block CG (block_pcg.hip).
+extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots,
+                                      double* host_yy, struct OPS_* ops);
 extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots,
                                      struct OPS_* ops) {
+  gcge_hip_spmm_dot2_mv(mat, x, y, start, end, host_dots, nullptr, ops);
+}
+// host_yy != NULL: additionally yy[j] = sum_r y[r,j]^2 (local part) — free on the pattern path
+extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots,
+                                      double* host_yy, struct OPS_* ops) {
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int m = end[0] - start[0];
@@ -660,13 +667,18 @@ extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, 
   if (!fast) {
     HIP_MatDotMultiVec(mat, x, y, start, end, ops);
     ops->MultiVecLocalInnerProd('D', x, y, 0, start, end, host_dots, 1, ops);
+    if (host_yy) {
+      int s2[2] = {start[1], start[1]}, e2[2] = {end[1], end[1]};
+      ops->MultiVecLocalInnerProd('D', y, y, 0, s2, e2, host_yy, 1, ops);
+    }
     return;
   }
   GCGE_REQUIRE(vx != vy && vx->nrows == vy->nrows && A->nrows == vy->nrows, "spmm_dot: shapes");
   GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols && start[1] >= 0 && end[1] <= vy->ncols, "spmm_dot: column ranges");
   GCGE_REQUIRE(A->nrows + A->nghost <= vx->nrows_alloc, "spmm_dot: halo rows allocated");
   halo_fetch(A, vx, start[0], m);
-  double* dd = stage_d(m);
+  double* dd = stage_d(2 * (size_t)m);
+  double* dyy = host_yy ? dd + m : nullptr;
   SpmmEvent ev;
   if (g_prof_on) {   // the fused kernel IS the K1 launch of a CG step (same algorithmic bytes: the dots add no HBM traffic)
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
@@ -676,15 +688,18 @@ extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, 
   }
   int rc = use_pat
       ? gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, vx->d + start[0], vx->ld, vy->d + start[1],
-                              vy->ld, m, dd, g_stream)
+                              vy->ld, m, dd, dyy, g_stream)
       : gcge_hip_pad8_spmm_dot(A->nrows, A->d_orp, A->d_pcol, A->d_pval, vx->d + start[0], vx->ld,
                                vy->d + start[1], vy->ld, m, dd, g_stream);
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "spmm_dot: kernel launch");
-  double* hd = stage_h(m);
-  GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  if (dyy && !use_pat)   // generic kernels: one more read of y
+    GCGE_REQUIRE(gcge_hip_coldots(A->nrows, vy->d + start[1], vy->ld, vy->d + start[1], vy->ld, m, dyy, g_stream) == 0, "spmm_dot: y.y");
+  double* hd = stage_h(2 * (size_t)m);
+  GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, (dyy ? 2 : 1) * m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
   memcpy(host_dots, hd, m * sizeof(double));
+  if (host_yy) memcpy(host_yy, hd + m, m * sizeof(double));
 }
 
 // app_ccs.c:140-150 — symmetric matrices only

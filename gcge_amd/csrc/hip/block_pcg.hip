@@ -4,12 +4,18 @@
 // BlockPCG (src/ops_lin_sol.c:140-437) — every right-hand side has its own alpha,
 // beta, rho and leaves the iteration on its own — but instead of ~3 b single-column
 // MultiVecAxpby calls + 2 inner products per iteration an iteration
-// is four launches on whole blocks:
+// is two launches on whole blocks (one-pass scheme, the default):
+//     w = A p ; pTw_j = p_j . w_j ; wTw_j = w_j . w_j     (K1 SpMM, both column sums fused in its epilogue)
+//     r -= alpha_j w ; x += alpha_j p ; p = r + beta_j p ; rho_j = r_j . r_j
+//                                                          (cg_update_all: 4 reads + 3 writes)
+// with beta_j = rho_pred_j / rho_j, rho_pred = alpha^2 wTw - rho (what r_new . r_new is in exact arithmetic for CG
+// directions); the measured rho_j of the sweep drives the next alpha and the stopping test.  7 block streams + the
+// SpMM instead of the 13 + SpMM of the unfused recurrence.  The older two-sweep form (GCGE_CG_TWO_PASS=1, also
+// the fallback when a block cannot be walked with 16-byte lanes) needs no prediction:
 //     x += alpha'_j p ; p = r + beta_j p       (cg_update_xp: the x update of the PREVIOUS step is
 //                                               deferred into this pass: 3 reads + 2 writes)
-//     w = A p ; pTw_j = p_j . w_j              (K1 SpMM with the column dots fused in its epilogue)
+//     w = A p ; pTw_j = p_j . w_j
 //     r -= alpha_j w ; rho_j = r_j . r_j       (cg_update_r: 2 reads + 1 write)
-// i.e. 8 block streams + the SpMM instead of the 13 + SpMM of the unfused recurrence.
 // The b scalars per iteration stay on the host exactly as in the reference (two tiny
 // device->host reads per iteration, which is also where the cross-rank all-reduce of
 // ops_lin_sol.c:317,365 happens); retired columns get alpha = 0 / keep-flag so their
@@ -24,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <assert.h>
 #include <math.h>
+#include <cmath>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,6 +43,8 @@
 extern "C" double* gcge_hip_partial_ws(size_t len);
 extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, int len, double* d_out, void* stream);
 extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots, struct OPS_* ops);
+extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots, double* host_yy,
+                                      struct OPS_* ops);
 
 namespace gcge {
 
@@ -200,6 +209,68 @@ __global__ __launch_bounds__(256) void cg_update_r_v2(long nrows, const double* 
     partial[(long)blockIdx.x * m + j + 1] = s1;
   }
 }
+
+// ---- one-pass step -------------------------------------------------------------------------------------------
+// r -= alpha w ; x += alpha p ; p = r_new + beta p ; partial[b*m + j] = sum over the block's rows of r_new^2
+// in ONE sweep (4 reads + 3 writes instead of the 5 + 3 streams of the two kernels above).  beta = rho_new / rho
+// is needed before r_new exists, so the caller predicts rho_new = alpha^2 (w.w) - rho from the column sums the
+// SpMM kernel delivers for free (exact in exact arithmetic: r_new.r_new = rho - 2 alpha r.w + alpha^2 w.w and
+// r.w = p.w = rho / alpha for CG directions); the TRUE rho_new comes back from this sweep and is what the next
+// alpha and the stopping test use.  Retired columns: alpha = 0, (cr, cb) = (0, 1): r, x, p stay bit-identical.
+template <int UNR>
+__global__ __launch_bounds__(256) void cg_update_all(long nrows, const double* __restrict__ w, long ldw,
+    double* __restrict__ r, long ldr, double* __restrict__ p, long ldp, double* __restrict__ x, long ldx, int m,
+    const double* __restrict__ alpha, const double* __restrict__ beta, const int* __restrict__ flag,
+    double* __restrict__ partial, int tpr) {
+  __shared__ double red[256][2];
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr, rpb = 256 / tpr;
+  const int j = 2 * tx;
+  double s0 = 0.0, s1 = 0.0;
+  const bool mine = j < m;
+  const int f0 = mine ? flag[j] : 0, f1 = mine ? flag[j + 1] : 0;
+  if (mine && (f0 | f1)) {
+    const double a0 = f0 ? alpha[j] : 0.0, a1 = f1 ? alpha[j + 1] : 0.0;
+    const double cr0 = f0 ? 1.0 : 0.0, cr1 = f1 ? 1.0 : 0.0;
+    const double cb0 = f0 ? beta[j] : 1.0, cb1 = f1 ? beta[j + 1] : 1.0;
+    const long step = rpb, group = (long)rpb * UNR;
+    const long slab = (((nrows + gridDim.x - 1) / gridDim.x) + group - 1) / group * group;
+    const long rend = min(nrows, ((long)blockIdx.x + 1) * slab);
+    auto one = [&](long rr, v2d wv, v2d rv, v2d pv, v2d xv) {
+      v2d rn = {fma(-a0, wv.x, rv.x), fma(-a1, wv.y, rv.y)};
+      v2d xn = {fma(a0, pv.x, xv.x), fma(a1, pv.y, xv.y)};
+      v2d pn = {fma(cb0, pv.x, cr0 * rn.x), fma(cb1, pv.y, cr1 * rn.y)};
+      __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(r + rr * ldr + j));
+      __builtin_nontemporal_store(xn, reinterpret_cast<v2d*>(x + rr * ldx + j));
+      __builtin_nontemporal_store(pn, reinterpret_cast<v2d*>(p + rr * ldp + j));
+      s0 = fma(cr0 * rn.x, rn.x, s0); s1 = fma(cr1 * rn.y, rn.y, s1);
+    };
+    long row = (long)blockIdx.x * slab + ty;
+    for (; row + (UNR - 1) * step < rend; row += step * UNR) {
+      v2d wv[UNR], rv[UNR], pv[UNR], xv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long rr = row + u * step;
+        wv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(w + rr * ldw + j));
+        rv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(r + rr * ldr + j));
+        pv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p + rr * ldp + j));
+        xv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(x + rr * ldx + j));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) one(row + u * step, wv[u], rv[u], pv[u], xv[u]);
+    }
+    for (; row < rend; row += step)
+      one(row, *reinterpret_cast<const v2d*>(w + row * ldw + j), *reinterpret_cast<const v2d*>(r + row * ldr + j),
+          *reinterpret_cast<const v2d*>(p + row * ldp + j), *reinterpret_cast<const v2d*>(x + row * ldx + j));
+  }
+  red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1;
+  __syncthreads();
+  if (ty == 0 && mine) {
+    for (int q = 1; q < rpb; ++q) { s0 += red[q * tpr + tx][0]; s1 += red[q * tpr + tx][1]; }
+    partial[(long)blockIdx.x * m + j] = s0;
+    partial[(long)blockIdx.x * m + j + 1] = s1;
+  }
+}
 }  // namespace gcge
 
 using namespace gcge;
@@ -264,10 +335,10 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
   GCGE_GetLinearSolverShift(&sigma, &matB);
   if (sigma != 0.0 && matB != nullptr && s->mv_ws[3] == nullptr) ops->MultiVecCreateByMultiVec(&s->mv_ws[3], s->ws_cols, mv_x, ops);
   // y[:, ys:ys+k) = (A + sigma B) x[:, xs:xs+k); dots != NULL: dots[j] = x_j . y_j (local part)
-  auto apply = [&](void** xin, int xs, void** yout, int ys, int k, double* dots) {
+  auto apply = [&](void** xin, int xs, void** yout, int ys, int k, double* dots, double* yy = nullptr) {
     int a2[2] = {xs, ys}, b2[2] = {xs + k, ys + k};
     if (sigma == 0.0) {
-      if (dots) gcge_hip_spmm_dot_mv(mat, xin, yout, a2, b2, dots, ops);
+      if (dots) gcge_hip_spmm_dot2_mv(mat, xin, yout, a2, b2, dots, yy, ops);
       else ops->MatDotMultiVec(mat, xin, yout, a2, b2, ops);
       return;
     }
@@ -281,6 +352,7 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
       ops->MultiVecAxpby(sigma, xin, 1.0, yout, a2, b2, ops);
     }
     if (dots) ops->MultiVecLocalInnerProd('D', xin, yout, 0, a2, b2, dots, 1, ops);
+    if (yy) { int a5[2] = {ys, ys}, b5[2] = {ys + k, ys + k}; ops->MultiVecLocalInnerProd('D', yout, yout, 0, a5, b5, yy, 1, ops); }
   };
   if (s->cap < nrhs) {
     if (s->d_coef) { hipFree(s->d_coef); hipFree(s->d_flag); hipHostFree(s->h_pin); }
@@ -339,6 +411,62 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
     GCGE_HIP_CHECK(hipMemcpyAsync(s->d_flag, s->h_pin + 2 * s->cap, mw * sizeof(int), hipMemcpyHostToDevice, st));
   };
   int niter = 0;
+  // ---- one-pass scheme (default whenever all four blocks can be walked with 16-byte lanes) ----
+  static const bool two_pass = getenv("GCGE_CG_TWO_PASS") != nullptr;
+  if (!two_pass && nrhs <= 512 && cg_vec_ok(nrhs, {dw, dr, dp, dx}, {ldw, ldr, ldp, ldx})) {
+    std::vector<double> wTw(nrhs), bet(nrhs);
+    if (nact > 0) {   // p0 = r0
+      st2[0] = 0; en2[0] = nrhs; st2[1] = 0; en2[1] = nrhs;
+      ops->MultiVecAxpby(1.0, s->mv_ws[0], 0.0, s->mv_ws[1], st2, en2, ops);
+    }
+    while (niter < s->max_iter && nact > 0) {
+      int alo = 0, ahi = nrhs;
+      while (alo < nrhs && !active[alo]) ++alo;
+      while (ahi > alo && !active[ahi - 1]) --ahi;
+      int aw = ahi - alo;
+      if (((alo & 1) || (aw & 1))) { alo &= ~1; ahi = (ahi + 1) & ~1; aw = ahi - alo; }   // keep 16-byte column pairs
+      apply(s->mv_ws[1], alo, s->mv_ws[2], alo, aw, pTw.data() + alo, wTw.data() + alo);
+      s->spmm_calls++; s->spmm_cols += aw;
+      {   // one all-reduce for both sums
+        std::vector<double> both(2 * (size_t)aw);
+        memcpy(both.data(), pTw.data() + alo, aw * sizeof(double)); memcpy(both.data() + aw, wTw.data() + alo, aw * sizeof(double));
+        reduce_over_ranks(both.data(), 2 * aw);
+        memcpy(pTw.data() + alo, both.data(), aw * sizeof(double)); memcpy(wTw.data() + alo, both.data() + aw, aw * sizeof(double));
+      }
+      for (int j = alo; j < ahi; ++j) {
+        flag[j] = active[j]; coef[j] = 0.0; bet[j] = 0.0;
+        if (!active[j]) continue;
+        const double al = rho2[j] / pTw[j];
+        double rho_pred = al * al * wTw[j] - rho2[j];
+        if (!(rho_pred > 0.0) || !std::isfinite(rho_pred)) rho_pred = 0.0;   // cancellation: restart this column from r
+        coef[j] = al; bet[j] = rho_pred / rho2[j];
+      }
+      upload(alo, aw, bet.data(), coef.data(), flag.data());   // d_coef = [beta | alpha]
+      double* part = gcge_hip_partial_ws((size_t)nb * aw + aw);
+      static const int a_unr = getenv("GCGE_CG_AUNR") ? atoi(getenv("GCGE_CG_AUNR")) : 4;   // tuning hook
+#define GCGE_UA(U) hipLaunchKernelGGL(cg_update_all<U>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr, \
+                                      dp + alo, ldp, dx + alo, ldx, aw, s->d_coef + s->cap, s->d_coef, s->d_flag, part, cg_tpr(aw))
+      if (a_unr == 2) GCGE_UA(2); else if (a_unr == 3) GCGE_UA(3); else if (a_unr == 6) GCGE_UA(6); else GCGE_UA(4);
+#undef GCGE_UA
+      gcge_hip_reduce_partials(part, (int)nb, aw, part + (size_t)nb * aw, st);
+      GCGE_HIP_CHECK(hipMemcpyAsync(s->h_pin, part + (size_t)nb * aw, aw * sizeof(double), hipMemcpyDeviceToHost, st));
+      GCGE_HIP_CHECK(hipStreamSynchronize(st));
+      std::vector<double> newrho(s->h_pin, s->h_pin + aw);
+      reduce_over_ranks(newrho.data(), aw);
+      nact = 0;
+      for (int j = alo; j < ahi; ++j) {
+        if (!active[j]) continue;
+        rho1[j] = rho2[j]; rho2[j] = newrho[j - alo];
+        last_res[j] = sqrt(rho2[j]);
+        active[j] = (last_res[j] > s->rate * init_res[j]) && (last_res[j] > s->tol * norm_b[j]);
+        nact += active[j];
+      }
+      ++niter;
+    }
+    s->niter = niter;
+    s->residual = last_res[0];
+    return;
+  }
   while (niter < s->max_iter && nact > 0) {
     // contiguous column window covering every active column and every pending x update
     int lo = 0, hi = nrhs;

@@ -45,7 +45,7 @@ template <int LT, int DOT>
 __global__ __launch_bounds__(256) void spmm_pattern_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
     const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
-    double* __restrict__ dot_partial) {
+    double* __restrict__ dot_partial, long yy_offset) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
   for (int e = threadIdx.x; e < ntab; e += 256) s_tab[e] = tab[e];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
   const int g = lane >> 3, i = lane & 7;
   const bool act = 2 * i < m;
   const double* __restrict__ xl = x + (act ? 2 * i : 0);   // idle lanes of a narrow last pass re-read column 0
-  double d0 = 0.0, d1 = 0.0;
+  double d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;   // x.y and y.y column sums (DOT)
 
   // tile t = (group of 4 lines q, slice a inside the line); wave w takes line 4q + w
   const long G = gridDim.x, aslices = line / 8;
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
       if (DOT) {
         const double wgt = ok ? 1.0 : 0.0;
         d0 = fma(a0 * wgt, buf[LT].x, d0); d1 = fma(a1 * wgt, buf[LT].y, d1);
+        e0 = fma(a0 * wgt, a0, e0); e1 = fma(a1 * wgt, a1, e1);
       }
     };
     v2d b0[LT + DOT], b1[LT + DOT];
@@ -111,15 +112,20 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
       int lo = __shfl_xor(__double2loint(v), mask, 64), hi = __shfl_xor(__double2hiint(v), mask, 64);
       return __hiloint2double(hi, lo);
     };
-    d0 += sx(d0, 8);  d1 += sx(d1, 8);
-    d0 += sx(d0, 16); d1 += sx(d1, 16);
-    d0 += sx(d0, 32); d1 += sx(d1, 32);
-    __shared__ double sred[4][16];
-    if (lane < 8) { sred[wave][2 * lane] = d0; sred[wave][2 * lane + 1] = d1; }
+    d0 += sx(d0, 8);  d1 += sx(d1, 8);  e0 += sx(e0, 8);  e1 += sx(e1, 8);
+    d0 += sx(d0, 16); d1 += sx(d1, 16); e0 += sx(e0, 16); e1 += sx(e1, 16);
+    d0 += sx(d0, 32); d1 += sx(d1, 32); e0 += sx(e0, 32); e1 += sx(e1, 32);
+    __shared__ double sred[4][32];
+    if (lane < 8) {
+      sred[wave][2 * lane] = d0; sred[wave][2 * lane + 1] = d1;
+      sred[wave][16 + 2 * lane] = e0; sred[wave][16 + 2 * lane + 1] = e1;
+    }
     __syncthreads();
-    if (threadIdx.x < 16 && (int)threadIdx.x < m)
-      dot_partial[(long)blockIdx.x * m + threadIdx.x] =
-          (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+    const int tq = threadIdx.x & 15;
+    if (threadIdx.x < 32 && tq < m) {   // threads 0-15: x.y partials, 16-31: y.y partials (second half of the workspace)
+      const double v = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+      dot_partial[(threadIdx.x < 16 ? 0 : yy_offset) + (long)blockIdx.x * m + tq] = v;
+    }
   }
 }
 
@@ -138,7 +144,7 @@ template <int LT, int DOT>
 __global__ __launch_bounds__(256) void spmm_pattern_chain_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
     const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
-    double* __restrict__ dot_partial) {
+    double* __restrict__ dot_partial, long yy_offset) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
   for (int e = threadIdx.x; e < ntab; e += 256) s_tab[e] = tab[e];
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_chain_kernel(
   const int g = lane >> 3, i = lane & 7;
   const bool act = 2 * i < m;
   const double* __restrict__ xl = x + (act ? 2 * i : 0);
-  double d0 = 0.0, d1 = 0.0;
+  double d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;   // x.y and y.y column sums (DOT)
   const long G = gridDim.x;
   if ((long)blockIdx.x < ntiles) {
     const long cnt = (ntiles - blockIdx.x + G - 1) / G;
@@ -187,6 +193,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_chain_kernel(
       if (DOT) {
         const double wgt = ok ? 1.0 : 0.0;
         d0 = fma(a0 * wgt, b.x, d0); d1 = fma(a1 * wgt, b.y, d1);
+        e0 = fma(a0 * wgt, a0, e0); e1 = fma(a1 * wgt, a1, e1);
       }
     };
     v2d r0, r1, r2, r3, o0[NO], o1[NO];
@@ -228,15 +235,20 @@ __global__ __launch_bounds__(256) void spmm_pattern_chain_kernel(
       int lo = __shfl_xor(__double2loint(v), mask, 64), hi = __shfl_xor(__double2hiint(v), mask, 64);
       return __hiloint2double(hi, lo);
     };
-    d0 += sx(d0, 8);  d1 += sx(d1, 8);
-    d0 += sx(d0, 16); d1 += sx(d1, 16);
-    d0 += sx(d0, 32); d1 += sx(d1, 32);
-    __shared__ double sred[4][16];
-    if (lane < 8) { sred[wave][2 * lane] = d0; sred[wave][2 * lane + 1] = d1; }
+    d0 += sx(d0, 8);  d1 += sx(d1, 8);  e0 += sx(e0, 8);  e1 += sx(e1, 8);
+    d0 += sx(d0, 16); d1 += sx(d1, 16); e0 += sx(e0, 16); e1 += sx(e1, 16);
+    d0 += sx(d0, 32); d1 += sx(d1, 32); e0 += sx(e0, 32); e1 += sx(e1, 32);
+    __shared__ double sred[4][32];
+    if (lane < 8) {
+      sred[wave][2 * lane] = d0; sred[wave][2 * lane + 1] = d1;
+      sred[wave][16 + 2 * lane] = e0; sred[wave][16 + 2 * lane + 1] = e1;
+    }
     __syncthreads();
-    if (threadIdx.x < 16 && (int)threadIdx.x < m)
-      dot_partial[(long)blockIdx.x * m + threadIdx.x] =
-          (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+    const int tq = threadIdx.x & 15;
+    if (threadIdx.x < 32 && tq < m) {   // threads 0-15: x.y partials, 16-31: y.y partials (second half of the workspace)
+      const double v = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+      dot_partial[(threadIdx.x < 16 ? 0 : yy_offset) + (long)blockIdx.x * m + tq] = v;
+    }
   }
 }
 
@@ -282,26 +294,26 @@ static long pat_grid(long span, long ntiles) {
 
 template <int LT, int DOT>
 static long pat_launch(long nrows, const unsigned short* pid, const void* tab, int npat, const double* x, size_t ldx,
-                       double* y, size_t ldy, int m, double* partial, long nb, long line, hipStream_t st) {
+                       double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st) {
   const int ntab = npat * LT;
   if (line < 0) {   // chain variant: consecutive slices, the caller fixed nb = S / 32
     const long cl = -line;   // geometry of the chain variant is passed as -line
     hipLaunchKernelGGL((spmm_pattern_chain_kernel<LT, DOT>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
-                       nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, pat_ntiles(nrows, cl), cl, partial);
+                       nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, pat_ntiles(nrows, cl), cl, partial, yy_off);
     return nb;
   }
   hipLaunchKernelGGL((spmm_pattern_kernel<LT, DOT>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
-                     nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, pat_ntiles(nrows, line), line, partial);
+                     nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, pat_ntiles(nrows, line), line, partial, yy_off);
   return nb;
 }
 
 template <int DOT>
 static long pat_dispatch(int lt, long nrows, const unsigned short* pid, const void* tab, int npat, const double* x,
-                         size_t ldx, double* y, size_t ldy, int m, double* partial, long nb, long line, hipStream_t st) {
+                         size_t ldx, double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st) {
   switch (lt) {
-    case 7: return pat_launch<7, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, nb, line, st);
-    case 8: return pat_launch<8, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, nb, line, st);
-    case 16: return pat_launch<16, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, nb, line, st);
+    case 7: return pat_launch<7, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st);
+    case 8: return pat_launch<8, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st);
+    case 16: return pat_launch<16, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st);
     default: return -1;
   }
 }
@@ -314,14 +326,15 @@ extern "C" int gcge_hip_pattern_width(int max_row_len) {
   return 0;
 }
 
-// Y[:,0:ncols) = A X[:,0:ncols); d_dots != NULL: also d_dots[j] = sum_r X[r,j] Y[r,j].
+// Y[:,0:ncols) = A X[:,0:ncols); d_dots != NULL: also d_dots[j] = sum_r X[r,j] Y[r,j] and, if d_dots_yy != NULL,
+// d_dots_yy[j] = sum_r Y[r,j]^2 (both free: the kernel has the rows in registers).
 // d_tab: npat * lt entries of {double value; long column_offset}; span / span2: the longest and second longest
 // |column_offset| of the interior stencil (launch geometry only; 0 if unknown).  span2 == -1: the table is in
 // CHAIN layout (slots 0,1,2 = offsets -span, 0, +span; see spmm_pattern_chain_kernel) and span is a multiple of 32.
 // -1: alignment contract not met.
 extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                      long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
-                                     double* d_dots, void* stream) {
+                                     double* d_dots, double* d_dots_yy, void* stream) {
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15)) return -1;
   if ((size_t)npat * lt * sizeof(PatEntry) > 64 * 1024) return -1;
@@ -336,30 +349,34 @@ extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, con
     const long nbc = std::min(span / 32, pat_ntiles(nrows, cline));
     const int npassc = (ncols + 15) / 16;
     hipStream_t stc = (hipStream_t)stream;
-    double* partc = d_dots ? gcge_hip_partial_ws((size_t)nbc * 16 * npassc) : nullptr;
+    double* partc = d_dots ? gcge_hip_partial_ws((size_t)nbc * 16 * npassc * 2) : nullptr;
+    const long yyc = (long)nbc * 16 * npassc;   // the y.y partials follow the x.y partials
     for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
       const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
       double* pp = partc ? partc + (size_t)ps * nbc * 16 : nullptr;
-      long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, nbc, -cline, stc)
-                        : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, nbc, -cline, stc);
+      long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyc, nbc, -cline, stc)
+                        : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nbc, -cline, stc);
       if (rcl < 0) return -1;
     }
     if (d_dots) gcge_hip_reduce_partials16(partc, (int)nbc, nbc * 16, ncols, d_dots, stc);   // all passes in one launch
+    if (d_dots && d_dots_yy) gcge_hip_reduce_partials16(partc + yyc, (int)nbc, nbc * 16, ncols, d_dots_yy, stc);
     return (int)hipGetLastError();
   }
   if (g_pat_line < 0 && span2 >= 8 && span2 % 8 == 0 && span > span2 && span % (4 * span2) == 0) line = span2;
   if (g_pat_line >= 8 && g_pat_line % 8 == 0) line = g_pat_line;
   const long nb = pat_grid(span, pat_ntiles(nrows, line));
-  double* part = d_dots ? gcge_hip_partial_ws((size_t)nb * 16 * npass) : nullptr;
+  double* part = d_dots ? gcge_hip_partial_ws((size_t)nb * 16 * npass * 2) : nullptr;
+  const long yyo = (long)nb * 16 * npass;
   for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
     const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
     if (d_dots) {
       double* pp = part + (size_t)ps * nb * 16;
-      if (pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, nb, line, st) < 0) return -1;
-    } else if (pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, nb, line, st) < 0) {
+      if (pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyo, nb, line, st) < 0) return -1;
+    } else if (pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nb, line, st) < 0) {
       return -1;
     }
   }
   if (d_dots) gcge_hip_reduce_partials16(part, (int)nb, nb * 16, ncols, d_dots, st);   // all passes in one launch
+  if (d_dots && d_dots_yy) gcge_hip_reduce_partials16(part + yyo, (int)nb, nb * 16, ncols, d_dots_yy, st);
   return (int)hipGetLastError();
 }

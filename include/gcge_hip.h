@@ -101,7 +101,7 @@ void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > pad-8 > CSR)
  *     additionally kept as 16-bit pattern ids + a table of npat * lt {double value; long offset} entries (span, span2 =
  *     longest and second longest |offset| of the interior stencil: launch geometry only); d_dots may be NULL.  gcge_hip_mat_patterns() tells whether a matrix qualified (0: served by the generic kernels).       */
 int gcge_hip_pattern_spmm (int nrows, const unsigned short *d_pid, const void *d_tab, int npat, int lt, long span, long span2,
-		const double *d_x, long ldx, double *d_y, long ldy, int ncols, double *d_dots, void *stream);
+		const double *d_x, long ldx, double *d_y, long ldy, int ncols, double *d_dots, double *d_dots_yy, void *stream);
 int gcge_hip_pattern_width (int max_row_len);
 int gcge_hip_mat_patterns (const GCGE_HIP_MAT *A);
 int gcge_hip_mat_pattern_chain (const GCGE_HIP_MAT *A);   /* 1: chain layout (span2 == -1 above) */
