@@ -238,48 +238,62 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const in
   do {
     const long S = A->pat_span;
     if (getenv("GCGE_NO_CHAIN") != nullptr || lt < 4 || S <= 0 || S % 32 != 0) break;
+    // canonical slots: the offsets of the interior stencil, chain first
     std::vector<long> offs;
-    for (const PatEntryH& e : tab) if (e.val != 0.0 || e.off != 0) offs.push_back(e.off);
-    offs.push_back(0);
-    std::sort(offs.begin(), offs.end()); offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
-    if ((int)offs.size() > lt) break;
-    auto has = [&](long o) { return std::binary_search(offs.begin(), offs.end(), o); };
-    bool common_ok = has(-S) && has(S);
     { bool m = false, c = false, q = false;
-      for (int k = 0; k < lt; ++k) { const PatEntryH& e = tab[(size_t)common * lt + k]; if (e.val != 0.0) { m |= e.off == -S; c |= e.off == 0; q |= e.off == S; } }
-      common_ok = common_ok && m && c && q; }
-    if (!common_ok) break;
+      for (int k = 0; k < lt; ++k) {
+        const PatEntryH& e = tab[(size_t)common * lt + k];
+        if (e.val == 0.0 && e.off == 0) continue;
+        offs.push_back(e.off); m |= e.off == -S; c |= e.off == 0; q |= e.off == S;
+      }
+      if (!(m && c && q)) break; }
     std::vector<long> slot = {-S, 0, S};
+    std::sort(offs.begin(), offs.end());
     for (long o : offs) if (o != -S && o != 0 && o != S) slot.push_back(o);
+    const int nslot_used = (int)slot.size();
+    if (nslot_used > lt) break;
     while ((int)slot.size() < lt) slot.push_back(0);            // unused slots: own row, value 0
-    const int nslot_used = (int)offs.size();
-    // per generic pattern: value on every slot
+    // per generic pattern: value on every canonical slot + the entries that fit no slot ("extras": halo columns of
+    // a row slab).  An extra may ride in slot 0 of a row of the first S rows (no predecessor in the chain: slot 0 is
+    // loaded explicitly when a wave starts) or in slot 2 of a row of the last S rows (no successor reads it).
     const int np = A->npat;
     std::vector<double> pval((size_t)np * lt, 0.0);
-    for (int p = 0; p < np; ++p)
+    std::vector<std::vector<PatEntryH>> extras((size_t)np);
+    bool ok = true;
+    for (int p = 0; p < np && ok; ++p)
       for (int k = 0; k < lt; ++k) {
         const PatEntryH& e = tab[(size_t)p * lt + k];
         if (e.val == 0.0 && e.off == 0) continue;
-        for (int sidx = 0; sidx < nslot_used; ++sidx) if (slot[sidx] == e.off) { pval[(size_t)p * lt + sidx] += e.val; break; }
+        int sidx = -1;
+        for (int q = 0; q < nslot_used; ++q) if (slot[q] == e.off) { sidx = q; break; }
+        if (sidx >= 0) pval[(size_t)p * lt + sidx] += e.val;
+        else { extras[p].push_back(e); if (extras[p].size() > 2) ok = false; }
       }
-    // split by address validity of the slots
+    if (!ok) break;
     std::unordered_map<uint64_t, int> id_of;
     std::vector<PatEntryH> ctab;
     std::vector<unsigned short> cpid((size_t)nrows);
-    bool ok = true;
     for (int r = 0; r < nrows && ok; ++r) {
-      unsigned mask = 0;
-      for (int sidx = 0; sidx < nslot_used; ++sidx) { const long c = (long)r + slot[sidx]; if (c < 0 || c >= ncols_local) mask |= 1u << sidx; }
-      const uint64_t key = ((uint64_t)pid[r] << 32) | mask;
+      unsigned mask = 0;   // slots whose canonical address leaves the block of vectors
+      for (int q = 0; q < nslot_used; ++q) { const long c = (long)r + slot[q]; if (c < 0 || c >= ncols_local) mask |= 1u << q; }
+      const unsigned head = r < S, tail = (long)r + S >= nrows;
+      const uint64_t key = ((uint64_t)pid[r] << 32) | ((uint64_t)head << 31) | ((uint64_t)tail << 30) | mask;
       auto it = id_of.find(key);
       if (it == id_of.end()) {
         const int id = (int)(ctab.size() / lt);
         if (id >= maxpat) { ok = false; break; }
-        for (int sidx = 0; sidx < lt; ++sidx) {
-          PatEntryH e = {pval[(size_t)pid[r] * lt + sidx], (sidx < nslot_used && !(mask >> sidx & 1)) ? slot[sidx] : 0};
-          if (mask >> sidx & 1) { if (e.val != 0.0) ok = false; e.val = 0.0; }   // an entry cannot point outside the matrix
-          ctab.push_back(e);
+        std::vector<PatEntryH> row((size_t)lt);
+        for (int q = 0; q < lt; ++q) {
+          row[q].val = pval[(size_t)pid[r] * lt + q];
+          row[q].off = (q < nslot_used && !(mask >> q & 1)) ? slot[q] : 0;
+          if (mask >> q & 1) { if (row[q].val != 0.0) ok = false; row[q].val = 0.0; }   // an entry cannot point outside
         }
+        for (const PatEntryH& e : extras[pid[r]]) {
+          if (head && row[0].val == 0.0) row[0] = e;
+          else if (tail && row[2].val == 0.0) row[2] = e;
+          else ok = false;
+        }
+        for (int q = 0; q < lt; ++q) ctab.push_back(row[q]);
         it = id_of.emplace(key, id).first;
       }
       cpid[r] = (unsigned short)it->second;
