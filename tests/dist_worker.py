@@ -28,7 +28,7 @@ def main():
     from gcge_amd.lib import CSR, host_lib, run_gcg
     from helpers import uniform, csr_to_scipy
     h = host_lib()
-    dims = (8, 6, 10)
+    dims = (8, 8, 10)      # planes of 64 rows: the slab matrices qualify for the chain layout of the pattern SpMM
     n_global = dims[0] * dims[1] * dims[2]
     part = gdist.row_partition(n_global, world)
     n_loc = part[rank + 1] - part[rank]
@@ -60,6 +60,8 @@ def main():
         comm = gdist.install(be, dist, rank, world, stage_through_host=True)
         mat = gdist.hip_slab_matrix(be, comm, A, n_global, part, cap_cols=4)   # small cap: exercises the column chunking
         be.set_random_mode(1, 777)
+        be.g.gcge_hip_mat_pattern_chain.argtypes = [C.c_void_p]
+        assert be.g.gcge_hip_mat_pattern_chain(mat) == 1, "slab matrix with halo columns should keep the chain layout"
 
     # 1. distributed SpMM == rows of the global product
     x = be.mv_from_numpy(mat, X[part[rank]:part[rank + 1], :])
