@@ -249,7 +249,11 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const in
       if (!(m && c && q)) break; }
     std::vector<long> slot = {-S, 0, S};
     std::sort(offs.begin(), offs.end());
-    for (long o : offs) if (o != -S && o != 0 && o != S) slot.push_back(o);
+    // second longest offset L with both signs present: slots 3,4 (line exchange of spmm_pattern_chain2_kernel)
+    long Lline = 0;
+    for (long o : offs) { const long ao = o < 0 ? -o : o; if (ao < S && ao > Lline && std::binary_search(offs.begin(), offs.end(), -o)) Lline = ao; }
+    if (Lline >= 8 && Lline % 8 == 0 && lt >= 5) { slot.push_back(-Lline); slot.push_back(Lline); } else Lline = 0;
+    for (long o : offs) if (o != -S && o != 0 && o != S && !(Lline && (o == -Lline || o == Lline))) slot.push_back(o);
     const int nslot_used = (int)slot.size();
     if (nslot_used > lt) break;
     while ((int)slot.size() < lt) slot.push_back(0);            // unused slots: own row, value 0
@@ -300,7 +304,7 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const in
     }
     if (!ok) break;
     tab.swap(ctab); pid.swap(cpid);
-    A->npat = (int)(tab.size() / lt); A->pat_span2 = -1;
+    A->npat = (int)(tab.size() / lt); A->pat_span2 = Lline ? -Lline : -1;
   } while (0);
   GCGE_HIP_CHECK(hipMalloc(&A->d_pid, (size_t)nrows * sizeof(unsigned short)));
   GCGE_HIP_CHECK(hipMalloc(&A->d_tab, tab.size() * sizeof(PatEntryH)));
@@ -384,7 +388,7 @@ extern "C" long gcge_hip_mat_nnz(const GCGE_HIP_MAT* A) { return A->nnz; }
 // number of row patterns the SpMM pattern path works with (0: the matrix is served by the generic pad-8 kernels)
 extern "C" int gcge_hip_mat_patterns(const GCGE_HIP_MAT* A) { return A->d_pid ? A->npat : 0; }
 // 1: the pattern table is in chain layout (the +-S rows of the stencil stay in registers between iterations)
-extern "C" int gcge_hip_mat_pattern_chain(const GCGE_HIP_MAT* A) { return A->d_pid && A->pat_span2 == -1; }
+extern "C" int gcge_hip_mat_pattern_chain(const GCGE_HIP_MAT* A) { return A->d_pid && A->pat_span2 <= -1; }
 
 // ------------------------------------------------------------------ device buffer pool
 // hipMalloc / hipFree of the multi-GB blocks cost 0.25-0.3 s each on this stack (page-table set-up; hipFree also

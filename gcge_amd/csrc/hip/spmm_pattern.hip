@@ -34,6 +34,8 @@ extern "C" double* gcge_hip_partial_ws(size_t len);
 extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, int len, double* d_out, void* stream);
 extern "C" void gcge_hip_reduce_partials16(const double* d_partial, int nblocks, long slab_stride, int ncols, double* d_out,
                                            void* stream);
+extern "C" void gcge_hip_reduce_partials_slabs(const double* d_partial, int nblocks, long slab_stride, int cpp, int ncols,
+                                               double* d_out, void* stream);
 
 namespace gcge {
 
@@ -140,10 +142,13 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
 // slots keep their two alternating register sets.  Offsets of slots 0 and 2 that would leave the matrix are stored
 // as 0 with value 0 (patterns are split by that validity), so every lane whose NEXT row exists has loaded exactly
 // that row through slot 2.
-template <int LT, int DOT>
+// LPR lanes serve one row (16 bytes each): a pass covers 2 LPR columns, a wave instruction 64 / LPR rows, a tile
+// (4 waves) 256 / LPR rows.  With the +-S rows in registers the L2 no longer has to hold a grid plane, so wide
+// passes are possible again (fewer table look-ups and launches per byte).
+template <int LT, int DOT, int LPR>
 __global__ __launch_bounds__(256) void spmm_pattern_chain_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
-    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
+    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles,
     double* __restrict__ dot_partial, long yy_offset) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
@@ -152,20 +157,15 @@ __global__ __launch_bounds__(256) void spmm_pattern_chain_kernel(
   constexpr int NO = LT - 3;   // slots outside the chain
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane >> 3, i = lane & 7;
+  constexpr int RPS = 64 / LPR, TR = 4 * RPS;   // rows per slice (wave instruction) and per tile (block iteration)
+  const int g = lane / LPR, i = lane % LPR;
   const bool act = 2 * i < m;
   const double* __restrict__ xl = x + (act ? 2 * i : 0);
   double d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;   // x.y and y.y column sums (DOT)
   const long G = gridDim.x;
   if ((long)blockIdx.x < ntiles) {
     const long cnt = (ntiles - blockIdx.x + G - 1) / G;
-    // tile t -> (group of 4 lines q, slice a): wave w works on line 4q + w (line = 8: four consecutive slices);
-    // the launch guarantees that G tiles are exactly S rows, so the chain holds for either geometry
-    const long aslices = line / 8;
-    auto row_at = [&](long it) {                                                                   // unclamped
-      const long t = blockIdx.x + it * G, q = t / aslices, a = t - q * aslices;
-      return (4 * q + wave) * line + 8 * a + g;
-    };
+    auto row_at = [&](long it) { return (blockIdx.x + it * G) * TR + RPS * wave + g; };              // unclamped
     auto row_of = [&](long it) { return min(row_at(min(it, cnt - 1)), nrows - 1); };               // clamped
     auto issue = [&](v2d& lnew, v2d (&oth)[NO], double (&val)[LT], long row, int p) {
       const PatEntry* e = s_tab + p * LT;
@@ -235,18 +235,162 @@ __global__ __launch_bounds__(256) void spmm_pattern_chain_kernel(
       int lo = __shfl_xor(__double2loint(v), mask, 64), hi = __shfl_xor(__double2hiint(v), mask, 64);
       return __hiloint2double(hi, lo);
     };
+#pragma unroll
+    for (int mk = LPR; mk < 64; mk <<= 1) { d0 += sx(d0, mk); d1 += sx(d1, mk); e0 += sx(e0, mk); e1 += sx(e1, mk); }
+    constexpr int CPP = 2 * LPR;   // columns per pass
+    __shared__ double sred[4][2 * CPP];
+    if (lane < LPR) {
+      sred[wave][2 * lane] = d0; sred[wave][2 * lane + 1] = d1;
+      sred[wave][CPP + 2 * lane] = e0; sred[wave][CPP + 2 * lane + 1] = e1;
+    }
+    __syncthreads();
+    const int tq = threadIdx.x % CPP;
+    if (threadIdx.x < 2 * CPP && tq < m) {   // first CPP threads: x.y partials, next CPP: y.y partials (second half of the workspace)
+      const double v = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+      dot_partial[(threadIdx.x < CPP ? 0 : yy_offset) + (long)blockIdx.x * m + tq] = v;
+    }
+  }
+}
+
+
+// ---- chain + line exchange: the +-S rows in registers, the +-L rows through LDS ------------------------------
+// Table layout: slots 0,1,2 = offsets -S, 0, +S as above, slots 3,4 = offsets -L, +L (L = the second longest
+// offset of the interior stencil: N on an N^3 grid), slots 5.. the rest.  A block of NW waves works on NW slices
+// that lie L rows apart (wave w on grid line NW q + w), so the "-L" row of wave w IS the centre row of wave w-1 of
+// the same block in the same iteration, lane for lane.  The centre row is known one iteration ahead (it arrived as
+// the "+S" row), so every wave posts it in LDS, one barrier later the neighbours read it: only the lowest wave
+// still loads its -L row and the highest its +L row from memory.  Loads per row on the 7-point stencil:
+// 1 (+S) + 2 (+-1) + 2/NW, against 5 for the chain alone and 7 without it.  The barrier carries no memory fence
+// (raw s_barrier after lgkmcnt(0)): the global loads of the NEXT iteration stay in flight across it.
+// ROLE: 0 lowest wave, 1 inner wave, 2 highest wave (three copies of the loop: no branch near a load).
+template <int LT, int DOT, int NW, int ROLE>
+__device__ __forceinline__ void chain2_body(
+    long nrows, const unsigned short* __restrict__ pid, const PatEntry* s_tab, v2d (*xch)[NW][64],
+    const double* __restrict__ xl, size_t ldx, double* __restrict__ y, size_t ldy, bool act, int i, int g, int wave, int lane,
+    long ntiles, long line, double& d0, double& d1, double& e0, double& e1) {
+  constexpr int NO = LT - 5;               // slots that are neither chain nor line
+  constexpr int NE = (ROLE == 1) ? 0 : 1;  // line row still loaded from memory
+  const long G = gridDim.x, asl = line / 8;
+  const long cnt = (ntiles - blockIdx.x + G - 1) / G;
+  auto row_at = [&](long it) {
+    const long t = blockIdx.x + it * G, q = t / asl, a = t - q * asl;
+    return ((long)NW * q + wave) * line + 8 * a + g;
+  };
+  auto row_of = [&](long it) { return min(row_at(min(it, cnt - 1)), nrows - 1); };
+  auto issue = [&](v2d& lnew, v2d (&edge)[NE + 1], v2d (&oth)[NO + 1], double (&val)[LT], long row, int p) {
+    const PatEntry* e = s_tab + p * LT;
+    val[0] = e[0].val; val[1] = e[1].val;
+    { const PatEntry c = e[2]; val[2] = c.val; lnew = *reinterpret_cast<const v2d*>(xl + (size_t)(row + c.off) * ldx); }
+    { const PatEntry c = e[3]; val[3] = c.val; if (ROLE == 0) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + c.off) * ldx); }
+    { const PatEntry c = e[4]; val[4] = c.val; if (ROLE == 2) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + c.off) * ldx); }
+#pragma unroll
+    for (int t = 0; t < NO; ++t) {
+      const PatEntry c = e[5 + t];
+      val[5 + t] = c.val;
+      oth[t] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + c.off) * ldx);
+    }
+  };
+  auto finish = [&](const v2d& a, const v2d& b, const v2d& c, const v2d (&edge)[NE + 1], const v2d (&oth)[NO + 1],
+                    const double (&val)[LT], long it, int buf) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const v2d vm = (ROLE == 0) ? edge[0] : xch[buf][wave - (ROLE == 0 ? 0 : 1)][lane];
+    const v2d vp = (ROLE == 2) ? edge[0] : xch[buf][wave + (ROLE == 2 ? 0 : 1)][lane];
+    double a0 = val[0] * a.x, a1 = val[0] * a.y;
+    a0 = fma(val[1], b.x, a0); a1 = fma(val[1], b.y, a1);
+    a0 = fma(val[2], c.x, a0); a1 = fma(val[2], c.y, a1);
+    a0 = fma(val[3], vm.x, a0); a1 = fma(val[3], vm.y, a1);
+    a0 = fma(val[4], vp.x, a0); a1 = fma(val[4], vp.y, a1);
+#pragma unroll
+    for (int t = 0; t < NO; ++t) { a0 = fma(val[5 + t], oth[t].x, a0); a1 = fma(val[5 + t], oth[t].y, a1); }
+    const long row = row_at(it);
+    const bool ok = it < cnt && row < nrows && act;
+    if (ok) {
+      v2d o = {a0, a1};
+      __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(y + (size_t)row * ldy + 2 * i));
+    }
+    if (DOT) {
+      const double wgt = ok ? 1.0 : 0.0;
+      d0 = fma(a0 * wgt, b.x, d0); d1 = fma(a1 * wgt, b.y, d1);
+      e0 = fma(a0 * wgt, a0, e0); e1 = fma(a1 * wgt, a1, e1);
+    }
+    xch[buf ^ 1][wave][lane] = c;   // the centre row of my next iteration
+  };
+  v2d r0, r1, r2, r3, ed0[NE + 1], ed1[NE + 1], o0[NO + 1], o1[NO + 1];
+  double v0[LT], v1[LT];
+  int p0 = pid[row_of(0)], p1 = pid[row_of(1)];
+  {
+    const long row = row_of(0);
+    const PatEntry* e = s_tab + p0 * LT;
+    r2 = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[0].off) * ldx);
+    r3 = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[1].off) * ldx);
+    xch[0][wave][lane] = r3;
+  }
+  issue(r0, ed0, o0, v0, row_of(0), p0);
+  for (long it = 0; it < cnt; it += 4) {
+    const int p2 = pid[row_of(it + 2)];
+    issue(r1, ed1, o1, v1, row_of(it + 1), p1);
+    __builtin_amdgcn_sched_barrier(0);
+    finish(r2, r3, r0, ed0, o0, v0, it, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int p3 = pid[row_of(it + 3)];
+    issue(r2, ed0, o0, v0, row_of(it + 2), p2);
+    __builtin_amdgcn_sched_barrier(0);
+    finish(r3, r0, r1, ed1, o1, v1, it + 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int p4 = pid[row_of(it + 4)];
+    issue(r3, ed1, o1, v1, row_of(it + 3), p3);
+    __builtin_amdgcn_sched_barrier(0);
+    finish(r0, r1, r2, ed0, o0, v0, it + 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int p5 = pid[row_of(it + 5)];
+    issue(r0, ed0, o0, v0, row_of(it + 4), p4);
+    __builtin_amdgcn_sched_barrier(0);
+    finish(r1, r2, r3, ed1, o1, v1, it + 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    p1 = p5;
+  }
+}
+
+template <int LT, int DOT, int NW>
+__global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
+    long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
+    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
+    double* __restrict__ dot_partial, long yy_offset) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
+  __shared__ v2d xch[2][NW][64];
+  for (int e = threadIdx.x; e < ntab; e += 64 * NW) s_tab[e] = tab[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 3, i = lane & 7;
+  const bool act = 2 * i < m;
+  const double* __restrict__ xl = x + (act ? 2 * i : 0);
+  double d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;
+  if ((long)blockIdx.x < ntiles) {   // block-uniform: every wave of the block runs the same number of barriers
+    if (wave == 0) chain2_body<LT, DOT, NW, 0>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, d0, d1, e0, e1);
+    else if (wave == NW - 1) chain2_body<LT, DOT, NW, 2>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, d0, d1, e0, e1);
+    else chain2_body<LT, DOT, NW, 1>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, d0, d1, e0, e1);
+  }
+  if (DOT) {
+    auto sx = [](double v, int mask) {
+      int lo = __shfl_xor(__double2loint(v), mask, 64), hi = __shfl_xor(__double2hiint(v), mask, 64);
+      return __hiloint2double(hi, lo);
+    };
     d0 += sx(d0, 8);  d1 += sx(d1, 8);  e0 += sx(e0, 8);  e1 += sx(e1, 8);
     d0 += sx(d0, 16); d1 += sx(d1, 16); e0 += sx(e0, 16); e1 += sx(e1, 16);
     d0 += sx(d0, 32); d1 += sx(d1, 32); e0 += sx(e0, 32); e1 += sx(e1, 32);
-    __shared__ double sred[4][32];
+    __shared__ double sred[NW][32];
     if (lane < 8) {
       sred[wave][2 * lane] = d0; sred[wave][2 * lane + 1] = d1;
       sred[wave][16 + 2 * lane] = e0; sred[wave][16 + 2 * lane + 1] = e1;
     }
     __syncthreads();
     const int tq = threadIdx.x & 15;
-    if (threadIdx.x < 32 && tq < m) {   // threads 0-15: x.y partials, 16-31: y.y partials (second half of the workspace)
-      const double v = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+    if (threadIdx.x < 32 && tq < m) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += sred[w][threadIdx.x];
       dot_partial[(threadIdx.x < 16 ? 0 : yy_offset) + (long)blockIdx.x * m + tq] = v;
     }
   }
@@ -275,6 +419,10 @@ static long pat_ntiles(long nrows, long line) {
 // Measured (profiles/r01_spmm_explore/16_pattern_line_tiles.log): tiles one grid line apart do NOT pay — 4.98 vs
 // 5.02 ms at 256^3, 3.05 vs 2.84 ms on the 200^3 FE matrix — the four waves of a block are not in step closely
 // enough for the +-N rows to still be in the 32 KB L1.  Default: 4 consecutive slices (line = 8).
+static int g_chain2_nw = 8;    // chain + line exchange: waves per block (4 or 8); 0: use the plain chain kernel
+extern "C" void gcge_hip_spmm_chain2_tune(int waves) { if (waves == 0 || waves == 4 || waves == 8) g_chain2_nw = waves; }
+static int g_chain_lpr = 8;    // chain variant: lanes per row = half the columns per pass (8, 16, 32)
+extern "C" void gcge_hip_spmm_chain_tune(int lanes_per_row) { if (lanes_per_row == 8 || lanes_per_row == 16 || lanes_per_row == 32) g_chain_lpr = lanes_per_row; }
 static int g_pat_line = 8;    // tuning: -1 = from the stencil's second longest offset, 8 = consecutive slices
 extern "C" void gcge_hip_spmm_pattern_tune_line(int line) { g_pat_line = line; }
 static long pat_grid(long span, long ntiles) {
@@ -294,12 +442,25 @@ static long pat_grid(long span, long ntiles) {
 
 template <int LT, int DOT>
 static long pat_launch(long nrows, const unsigned short* pid, const void* tab, int npat, const double* x, size_t ldx,
-                       double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st) {
+                       double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st,
+                       long cline = 0, int nw = 4) {
   const int ntab = npat * LT;
+  if (cline > 0) {   // chain + line exchange: nw waves per block, lines of `cline` rows
+    if (LT < 5) return -1;
+    const long nlines = (nrows + cline - 1) / cline, ntl = (nlines + nw - 1) / nw * (cline / 8);
+#define GCGE_C2(NWV) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), DOT, NWV>), dim3((unsigned)nb), dim3(64 * NWV), \
+                       (size_t)ntab * sizeof(PatEntry), st, nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, ntl, cline, partial, yy_off)
+    if (nw == 8) GCGE_C2(8); else GCGE_C2(4);
+#undef GCGE_C2
+    return nb;
+  }
   if (line < 0) {   // chain variant: consecutive slices, the caller fixed nb = S / 32
-    const long cl = -line;   // geometry of the chain variant is passed as -line
-    hipLaunchKernelGGL((spmm_pattern_chain_kernel<LT, DOT>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
-                       nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, pat_ntiles(nrows, cl), cl, partial, yy_off);
+    const long lpr = -line;   // chain variant: lanes per row is passed as -line (8, 16 or 32)
+    const long tr = 256 / lpr, ntl = (nrows + tr - 1) / tr;
+#define GCGE_CH(L) hipLaunchKernelGGL((spmm_pattern_chain_kernel<LT, DOT, L>), dim3((unsigned)nb), dim3(256), \
+                       (size_t)ntab * sizeof(PatEntry), st, nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, ntl, partial, yy_off)
+    if (lpr == 32) GCGE_CH(32); else if (lpr == 16) GCGE_CH(16); else GCGE_CH(8);
+#undef GCGE_CH
     return nb;
   }
   hipLaunchKernelGGL((spmm_pattern_kernel<LT, DOT>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
@@ -309,11 +470,12 @@ static long pat_launch(long nrows, const unsigned short* pid, const void* tab, i
 
 template <int DOT>
 static long pat_dispatch(int lt, long nrows, const unsigned short* pid, const void* tab, int npat, const double* x,
-                         size_t ldx, double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st) {
+                         size_t ldx, double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st,
+                         long cline = 0, int nw = 4) {
   switch (lt) {
-    case 7: return pat_launch<7, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st);
-    case 8: return pat_launch<8, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st);
-    case 16: return pat_launch<16, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st);
+    case 7: return pat_launch<7, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw);
+    case 8: return pat_launch<8, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw);
+    case 16: return pat_launch<16, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw);
     default: return -1;
   }
 }
@@ -330,7 +492,8 @@ extern "C" int gcge_hip_pattern_width(int max_row_len) {
 // d_dots_yy[j] = sum_r Y[r,j]^2 (both free: the kernel has the rows in registers).
 // d_tab: npat * lt entries of {double value; long column_offset}; span / span2: the longest and second longest
 // |column_offset| of the interior stencil (launch geometry only; 0 if unknown).  span2 == -1: the table is in
-// CHAIN layout (slots 0,1,2 = offsets -span, 0, +span; see spmm_pattern_chain_kernel) and span is a multiple of 32.
+// CHAIN layout (slots 0,1,2 = offsets -span, 0, +span; see spmm_pattern_chain_kernel) and span is a multiple of 32;
+// span2 == -L <= -8: additionally slots 3,4 = offsets -L, +L (spmm_pattern_chain2_kernel).
 // -1: alignment contract not met.
 extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                      long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
@@ -342,24 +505,46 @@ extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, con
   const int npass = (ncols + 15) / 16;
   // lines of `span2` rows when they tile the matrix exactly (a plane = a whole number of 4-line groups)
   long line = 8;
-  if (span2 == -1) {   // chain layout: the wave stride must be exactly `span` rows
-    if (span % 32 != 0 || lt < 4) return -1;
-    long cline = 8;   // tuning hook: waves of a block `cline` rows apart (must keep G tiles == span rows)
-    if (g_pat_line > 8 && g_pat_line % 8 == 0 && (span / 32) % (g_pat_line / 8) == 0) cline = g_pat_line;
-    const long nbc = std::min(span / 32, pat_ntiles(nrows, cline));
+  if (span2 <= -8 && g_chain2_nw > 0 && span % (g_chain2_nw * -span2) == 0 && (-span2) % 8 == 0 && lt >= 5 &&
+      (long)nrows >= g_chain2_nw * -span2) {   // chain layout with line exchange: L = -span2 rows per grid line
+    const long L = -span2; const int nw = g_chain2_nw;
+    const long nbc = std::min(span / (8L * nw), ((((long)nrows + L - 1) / L + nw - 1) / nw) * (L / 8));
     const int npassc = (ncols + 15) / 16;
     hipStream_t stc = (hipStream_t)stream;
     double* partc = d_dots ? gcge_hip_partial_ws((size_t)nbc * 16 * npassc * 2) : nullptr;
-    const long yyc = (long)nbc * 16 * npassc;   // the y.y partials follow the x.y partials
+    const long yyc = (long)nbc * 16 * npassc;
     for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
       const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
       double* pp = partc ? partc + (size_t)ps * nbc * 16 : nullptr;
-      long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyc, nbc, -cline, stc)
-                        : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nbc, -cline, stc);
+      long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyc, nbc, 8, stc, L, nw)
+                        : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nbc, 8, stc, L, nw);
       if (rcl < 0) return -1;
     }
-    if (d_dots) gcge_hip_reduce_partials16(partc, (int)nbc, nbc * 16, ncols, d_dots, stc);   // all passes in one launch
+    if (d_dots) gcge_hip_reduce_partials16(partc, (int)nbc, nbc * 16, ncols, d_dots, stc);
     if (d_dots && d_dots_yy) gcge_hip_reduce_partials16(partc + yyc, (int)nbc, nbc * 16, ncols, d_dots_yy, stc);
+    return (int)hipGetLastError();
+  }
+  if (span2 <= -1) {   // chain layout: the wave stride must be exactly `span` rows
+    if (span % 32 != 0 || lt < 4) return -1;
+    // pass width: 16, 32 or 64 columns (lanes per row 8 / 16 / 32); the wave stride must stay exactly `span` rows
+    int lpr = g_chain_lpr;
+    while (lpr > 8 && (2 * lpr > ((ncols + 15) / 16) * 16 || span % (256 / lpr) != 0)) lpr /= 2;
+    const int cpp = 2 * lpr;
+    const long tr = 256 / lpr;
+    const long nbc = std::min(span / tr, ((long)nrows + tr - 1) / tr);
+    const int npassc = (ncols + cpp - 1) / cpp;
+    hipStream_t stc = (hipStream_t)stream;
+    double* partc = d_dots ? gcge_hip_partial_ws((size_t)nbc * cpp * npassc * 2) : nullptr;
+    const long yyc = (long)nbc * cpp * npassc;   // the y.y partials follow the x.y partials
+    for (int c0 = 0, ps = 0; c0 < ncols; c0 += cpp, ++ps) {
+      const int m = (ncols - c0 < cpp) ? ncols - c0 : cpp;
+      double* pp = partc ? partc + (size_t)ps * nbc * cpp : nullptr;
+      long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyc, nbc, -lpr, stc)
+                        : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nbc, -lpr, stc);
+      if (rcl < 0) return -1;
+    }
+    if (d_dots) gcge_hip_reduce_partials_slabs(partc, (int)nbc, nbc * cpp, cpp, ncols, d_dots, stc);   // all passes in one launch
+    if (d_dots && d_dots_yy) gcge_hip_reduce_partials_slabs(partc + yyc, (int)nbc, nbc * cpp, cpp, ncols, d_dots_yy, stc);
     return (int)hipGetLastError();
   }
   if (g_pat_line < 0 && span2 >= 8 && span2 % 8 == 0 && span > span2 && span % (4 * span2) == 0) line = span2;

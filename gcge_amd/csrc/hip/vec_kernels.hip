@@ -255,6 +255,28 @@ __global__ __launch_bounds__(1024) void reduce_partials16(const double* __restri
   }
   if (ty == 0 && tx < m) out[c0 + tx] = red[0][tx];
 }
+// same with cpp (16, 32 or 64) columns per slab
+__global__ __launch_bounds__(1024) void reduce_partials_slabs(const double* __restrict__ partial, int nblocks, long slab_stride,
+    int cpp, int ncols, double* __restrict__ out) {
+  __shared__ double red[1024];
+  const int tx = threadIdx.x % cpp, ty = threadIdx.x / cpp, nl = 1024 / cpp;
+  const int c0 = cpp * blockIdx.x, m = min(cpp, ncols - c0);
+  const double* src = partial + (long)blockIdx.x * slab_stride;
+  double s0 = 0.0;
+  if (tx < m) for (int b = ty; b < nblocks; b += nl) s0 += src[(long)b * m + tx];
+  red[threadIdx.x] = s0;
+  __syncthreads();
+  for (int h = nl / 2; h > 0; h >>= 1) {
+    if (ty < h) red[threadIdx.x] += red[threadIdx.x + h * cpp];
+    __syncthreads();
+  }
+  if (ty == 0 && tx < m) out[c0 + tx] = red[tx];
+}
+extern "C" void gcge_hip_reduce_partials_slabs(const double* d_partial, int nblocks, long slab_stride, int cpp, int ncols,
+                                               double* d_out, void* stream) {
+  hipLaunchKernelGGL(reduce_partials_slabs, dim3((ncols + cpp - 1) / cpp), dim3(1024), 0, (hipStream_t)stream, d_partial,
+                     nblocks, slab_stride, cpp, ncols, d_out);
+}
 extern "C" void gcge_hip_reduce_partials16(const double* d_partial, int nblocks, long slab_stride, int ncols, double* d_out,
                                            void* stream) {
   hipLaunchKernelGGL(reduce_partials16, dim3((ncols + 15) / 16), dim3(1024), 0, (hipStream_t)stream, d_partial, nblocks,

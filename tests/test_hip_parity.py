@@ -109,6 +109,13 @@ def test_spmm_pattern_path_vs_generic_and_oracle(both, kind, size, expect, chain
         ref = ora.mv_to_numpy(yo, n, 0, 80)
         _close(outs[0], ref, tol=1e-13, what="pattern spmm %s m=%d" % (kind, m))
         _close(outs[1], ref, tol=1e-13, what="generic spmm %s m=%d" % (kind, m))
+        if chain:   # wider column passes of the chain kernel (32 and 64 columns per pass)
+            for lpr in (16, 32):
+                hip.g.gcge_hip_spmm_chain_tune(lpr)
+                yh = hip.mv_from_numpy(mh, uniform(20, (n, 80)))
+                hip.ops.spmm(mh, xh, yh, (s0, s1), (s0 + m, s1 + m))
+                _close(hip.mv_to_numpy(yh, n, 0, 80), ref, tol=1e-13, what="chain spmm lpr=%d %s m=%d" % (lpr, kind, m))
+            hip.g.gcge_hip_spmm_chain_tune(8)
 
 
 def test_gram_and_dots_vs_oracle(both):

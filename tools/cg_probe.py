@@ -13,6 +13,10 @@ hip.set_random_mode(1, 7)
 ops = hip.ops
 V = ops.mv_create(256, mA)
 ops.set_random(V, 0, 256)
+if os.environ.get('CHAIN2_NW') is not None:
+    hip.g.gcge_hip_spmm_chain2_tune(int(os.environ['CHAIN2_NW']))
+if os.environ.get('CHAIN_LPR'):
+    hip.g.gcge_hip_spmm_chain_tune(int(os.environ['CHAIN_LPR']))
 hip.g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
 for rep in range(2):
     hip.sync(); t = time.perf_counter()

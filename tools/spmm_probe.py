@@ -25,6 +25,10 @@ Wv = ops.mv_create(m, mA)
 g.gcge_hip_set_spmm_path(path)
 if os.environ.get('PAT_LINE'):
     g.gcge_hip_spmm_pattern_tune_line(int(os.environ['PAT_LINE']))
+if os.environ.get('CHAIN2_NW') is not None:
+    g.gcge_hip_spmm_chain2_tune(int(os.environ['CHAIN2_NW']))
+if os.environ.get('CHAIN_LPR'):
+    g.gcge_hip_spmm_chain_tune(int(os.environ['CHAIN_LPR']))
 if os.environ.get('PAT_GRID'):
     g.gcge_hip_spmm_pattern_tune(int(os.environ['PAT_GRID']))
 for x0 in (192, 128):
