@@ -277,23 +277,23 @@ __device__ __forceinline__ void chain2_body(
     return ((long)NW * q + wave) * line + 8 * a + g;
   };
   auto row_of = [&](long it) { return min(row_at(min(it, cnt - 1)), nrows - 1); };
-  auto issue = [&](v2d& lnew, v2d (&edge)[NE + 1], v2d (&oth)[NO + 1], double (&val)[LT], long row, int p) {
+  // the stencil values are looked up again when the rows are reduced (7 LDS reads) instead of being carried in
+  // 2 x LT registers from issue to finish: keeps the kernel at 4 waves per SIMD with the dot accumulators
+  auto issue = [&](v2d& lnew, v2d (&edge)[NE + 1], v2d (&oth)[NO + 1], long row, int p) {
     const PatEntry* e = s_tab + p * LT;
-    val[0] = e[0].val; val[1] = e[1].val;
-    { const PatEntry c = e[2]; val[2] = c.val; lnew = *reinterpret_cast<const v2d*>(xl + (size_t)(row + c.off) * ldx); }
-    { const PatEntry c = e[3]; val[3] = c.val; if (ROLE == 0) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + c.off) * ldx); }
-    { const PatEntry c = e[4]; val[4] = c.val; if (ROLE == 2) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + c.off) * ldx); }
+    lnew = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[2].off) * ldx);
+    if (ROLE == 0) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[3].off) * ldx);
+    if (ROLE == 2) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[4].off) * ldx);
 #pragma unroll
-    for (int t = 0; t < NO; ++t) {
-      const PatEntry c = e[5 + t];
-      val[5 + t] = c.val;
-      oth[t] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + c.off) * ldx);
-    }
+    for (int t = 0; t < NO; ++t) oth[t] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[5 + t].off) * ldx);
   };
   auto finish = [&](const v2d& a, const v2d& b, const v2d& c, const v2d (&edge)[NE + 1], const v2d (&oth)[NO + 1],
-                    const double (&val)[LT], long it, int buf) {
+                    int p, long it, int buf) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    double val[LT];
+#pragma unroll
+    for (int t = 0; t < LT; ++t) val[t] = s_tab[p * LT + t].val;
     const v2d vm = (ROLE == 0) ? edge[0] : xch[buf][wave - (ROLE == 0 ? 0 : 1)][lane];
     const v2d vp = (ROLE == 2) ? edge[0] : xch[buf][wave + (ROLE == 2 ? 0 : 1)][lane];
     double a0 = val[0] * a.x, a1 = val[0] * a.y;
@@ -317,7 +317,6 @@ __device__ __forceinline__ void chain2_body(
     xch[buf ^ 1][wave][lane] = c;   // the centre row of my next iteration
   };
   v2d r0, r1, r2, r3, ed0[NE + 1], ed1[NE + 1], o0[NO + 1], o1[NO + 1];
-  double v0[LT], v1[LT];
   int p0 = pid[row_of(0)], p1 = pid[row_of(1)];
   {
     const long row = row_of(0);
@@ -326,29 +325,29 @@ __device__ __forceinline__ void chain2_body(
     r3 = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[1].off) * ldx);
     xch[0][wave][lane] = r3;
   }
-  issue(r0, ed0, o0, v0, row_of(0), p0);
-  for (long it = 0; it < cnt; it += 4) {
+  issue(r0, ed0, o0, row_of(0), p0);
+  for (long it = 0; it < cnt; it += 4) {   // pattern ids: p0 = row(it), p1 = row(it+1)
     const int p2 = pid[row_of(it + 2)];
-    issue(r1, ed1, o1, v1, row_of(it + 1), p1);
+    issue(r1, ed1, o1, row_of(it + 1), p1);
     __builtin_amdgcn_sched_barrier(0);
-    finish(r2, r3, r0, ed0, o0, v0, it, 0);
+    finish(r2, r3, r0, ed0, o0, p0, it, 0);
     __builtin_amdgcn_sched_barrier(0);
     const int p3 = pid[row_of(it + 3)];
-    issue(r2, ed0, o0, v0, row_of(it + 2), p2);
+    issue(r2, ed0, o0, row_of(it + 2), p2);
     __builtin_amdgcn_sched_barrier(0);
-    finish(r3, r0, r1, ed1, o1, v1, it + 1, 1);
+    finish(r3, r0, r1, ed1, o1, p1, it + 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     const int p4 = pid[row_of(it + 4)];
-    issue(r3, ed1, o1, v1, row_of(it + 3), p3);
+    issue(r3, ed1, o1, row_of(it + 3), p3);
     __builtin_amdgcn_sched_barrier(0);
-    finish(r0, r1, r2, ed0, o0, v0, it + 2, 0);
+    finish(r0, r1, r2, ed0, o0, p2, it + 2, 0);
     __builtin_amdgcn_sched_barrier(0);
     const int p5 = pid[row_of(it + 5)];
-    issue(r0, ed0, o0, v0, row_of(it + 4), p4);
+    issue(r0, ed0, o0, row_of(it + 4), p4);
     __builtin_amdgcn_sched_barrier(0);
-    finish(r1, r2, r3, ed1, o1, v1, it + 3, 1);
+    finish(r1, r2, r3, ed1, o1, p3, it + 3, 1);
     __builtin_amdgcn_sched_barrier(0);
-    p1 = p5;
+    p0 = p4; p1 = p5;
   }
 }
 
@@ -419,8 +418,10 @@ static long pat_ntiles(long nrows, long line) {
 // Measured (profiles/r01_spmm_explore/16_pattern_line_tiles.log): tiles one grid line apart do NOT pay — 4.98 vs
 // 5.02 ms at 256^3, 3.05 vs 2.84 ms on the 200^3 FE matrix — the four waves of a block are not in step closely
 // enough for the +-N rows to still be in the 32 KB L1.  Default: 4 consecutive slices (line = 8).
-static int g_chain2_nw = 8;    // chain + line exchange: waves per block (4 or 8); 0: use the plain chain kernel
-extern "C" void gcge_hip_spmm_chain2_tune(int waves) { if (waves == 0 || waves == 4 || waves == 8) g_chain2_nw = waves; }
+// chain + line exchange: most waves per block to try (16, 8, 4; measured 3.20 / 3.37 / 3.67 ms at 256^3 x 64);
+// 0: use the plain chain kernel
+static int g_chain2_nw = 16;
+extern "C" void gcge_hip_spmm_chain2_tune(int waves) { if (waves == 0 || waves == 4 || waves == 8 || waves == 16) g_chain2_nw = waves; }
 static int g_chain_lpr = 8;    // chain variant: lanes per row = half the columns per pass (8, 16, 32)
 extern "C" void gcge_hip_spmm_chain_tune(int lanes_per_row) { if (lanes_per_row == 8 || lanes_per_row == 16 || lanes_per_row == 32) g_chain_lpr = lanes_per_row; }
 static int g_pat_line = 8;    // tuning: -1 = from the stencil's second longest offset, 8 = consecutive slices
@@ -450,7 +451,7 @@ static long pat_launch(long nrows, const unsigned short* pid, const void* tab, i
     const long nlines = (nrows + cline - 1) / cline, ntl = (nlines + nw - 1) / nw * (cline / 8);
 #define GCGE_C2(NWV) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), DOT, NWV>), dim3((unsigned)nb), dim3(64 * NWV), \
                        (size_t)ntab * sizeof(PatEntry), st, nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, ntl, cline, partial, yy_off)
-    if (nw == 8) GCGE_C2(8); else GCGE_C2(4);
+    if (nw == 16) GCGE_C2(16); else if (nw == 8) GCGE_C2(8); else GCGE_C2(4);
 #undef GCGE_C2
     return nb;
   }
@@ -505,9 +506,13 @@ extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, con
   const int npass = (ncols + 15) / 16;
   // lines of `span2` rows when they tile the matrix exactly (a plane = a whole number of 4-line groups)
   long line = 8;
-  if (span2 <= -8 && g_chain2_nw > 0 && span % (g_chain2_nw * -span2) == 0 && (-span2) % 8 == 0 && lt >= 5 &&
-      (long)nrows >= g_chain2_nw * -span2) {   // chain layout with line exchange: L = -span2 rows per grid line
-    const long L = -span2; const int nw = g_chain2_nw;
+  // chain layout with line exchange: L = -span2 rows per grid line, nw waves per block (the most that tile a plane)
+  int nw = 0;
+  if (span2 <= -8 && (-span2) % 8 == 0 && lt >= 5)
+    for (int cand = g_chain2_nw; cand >= 4; cand /= 2)
+      if (span % (cand * -span2) == 0 && (long)nrows >= cand * -span2) { nw = cand; break; }
+  if (nw > 0) {
+    const long L = -span2;
     const long nbc = std::min(span / (8L * nw), ((((long)nrows + L - 1) / L + nw - 1) / nw) * (L / 8));
     const int npassc = (ncols + 15) / 16;
     hipStream_t stc = (hipStream_t)stream;
