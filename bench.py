@@ -181,13 +181,14 @@ def main():
         # moved are lower than the algorithmic ones: X and Y (16 n m) dominate either way.
         # HBM/fabric bytes per launch from separate rocprofv3 --pmc passes of this kernel at this shape (not collected
         # live: counters need their own runs): TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B, gfx950 correction of
-        # MI355X_MICROARCH.md applied; profiles/r01_spmm_explore/17_chain_pmc.log
+        # MI355X_MICROARCH.md applied; profiles/r01_spmm_explore/23_chain2_pmc.log
         traffic, traffic_note = None, "no PMC profile for this shape"
-        if npat > 0 and N == 256 and args.block == 64 and world == 1 and g.gcge_hip_mat_pattern_chain(mat):
-            traffic = 4 * (2.55411e7 * 128 + 3.35544e7 * 64)
-            traffic_note = "4 passes x (2.554e7 x 128 B reads + 3.355e7 x 64 B writes), profiles/r01_spmm_explore/17_chain_pmc.log"
+        chain = g.gcge_hip_mat_pattern_chain(mat)
+        if npat > 0 and N == 256 and args.block == 64 and world == 1 and chain == 2:
+            traffic = 4 * (2.35094e7 * 128 + 3.35544e7 * 64)
+            traffic_note = "4 passes x (2.351e7 x 128 B reads + 3.355e7 x 64 B writes), profiles/r01_spmm_explore/23_chain2_pmc.log"
         kname = ("%s<7> x %d passes of 16 columns + column dots (K1, %d row patterns, m=%d)"
-                 % ("spmm_pattern_chain" if g.gcge_hip_mat_pattern_chain(mat) else "spmm_pattern", (args.block + 15) // 16, npat, args.block)
+                 % (("spmm_pattern", "spmm_pattern_chain", "spmm_pattern_chain2")[chain], (args.block + 15) // 16, npat, args.block)
                  if npat > 0 else "spmm_pad8 (K1 CSR SpMM, m=%d)" % args.block)
         out = {
             "metric": "converged eigenpairs/sec (GCG, 3D Laplacian n=%d, block=%d)" % (n_global, args.block),

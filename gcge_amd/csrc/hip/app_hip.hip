@@ -387,8 +387,12 @@ extern "C" int gcge_hip_mat_nrows(const GCGE_HIP_MAT* A) { return A->nrows; }
 extern "C" long gcge_hip_mat_nnz(const GCGE_HIP_MAT* A) { return A->nnz; }
 // number of row patterns the SpMM pattern path works with (0: the matrix is served by the generic pad-8 kernels)
 extern "C" int gcge_hip_mat_patterns(const GCGE_HIP_MAT* A) { return A->d_pid ? A->npat : 0; }
-// 1: the pattern table is in chain layout (the +-S rows of the stencil stay in registers between iterations)
-extern "C" int gcge_hip_mat_pattern_chain(const GCGE_HIP_MAT* A) { return A->d_pid && A->pat_span2 <= -1; }
+// 1: the pattern table is in chain layout (the +-S rows of the stencil stay in registers between iterations);
+// 2: additionally slots 3,4 hold the +-L rows that the waves of a block exchange through LDS
+extern "C" int gcge_hip_mat_pattern_chain(const GCGE_HIP_MAT* A) {
+  if (!A->d_pid || A->pat_span2 > -1) return 0;
+  return A->pat_span2 <= -8 ? 2 : 1;
+}
 
 // ------------------------------------------------------------------ device buffer pool
 // hipMalloc / hipFree of the multi-GB blocks cost 0.25-0.3 s each on this stack (page-table set-up; hipFree also

@@ -104,7 +104,7 @@ int gcge_hip_pattern_spmm (int nrows, const unsigned short *d_pid, const void *d
 		const double *d_x, long ldx, double *d_y, long ldy, int ncols, double *d_dots, double *d_dots_yy, void *stream);
 int gcge_hip_pattern_width (int max_row_len);
 int gcge_hip_mat_patterns (const GCGE_HIP_MAT *A);
-int gcge_hip_mat_pattern_chain (const GCGE_HIP_MAT *A);   /* 1: chain layout (span2 == -1 above) */
+int gcge_hip_mat_pattern_chain (const GCGE_HIP_MAT *A);   /* 0 none, 1 chain layout (span2 == -1), 2 chain + line exchange (span2 == -L) */
 /*     d_out[j] = sum_r x[r,j] y[r,j] */
 int gcge_hip_coldots (int nrows, const double *d_x, long ldx, const double *d_y, long ldy, int m,
 		double *d_out, void *stream);

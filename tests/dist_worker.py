@@ -61,7 +61,7 @@ def main():
         mat = gdist.hip_slab_matrix(be, comm, A, n_global, part, cap_cols=4)   # small cap: exercises the column chunking
         be.set_random_mode(1, 777)
         be.g.gcge_hip_mat_pattern_chain.argtypes = [C.c_void_p]
-        assert be.g.gcge_hip_mat_pattern_chain(mat) == 1, "slab matrix with halo columns should keep the chain layout"
+        assert be.g.gcge_hip_mat_pattern_chain(mat) >= 1, "slab matrix with halo columns should keep the chain layout"
 
     # 1. distributed SpMM == rows of the global product
     x = be.mv_from_numpy(mat, X[part[rank]:part[rank + 1], :])
