@@ -267,13 +267,17 @@ template <int LT, int DOT, int NW, int ROLE>
 __device__ __forceinline__ void chain2_body(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* s_tab, v2d (*xch)[NW][64],
     const double* __restrict__ xl, size_t ldx, double* __restrict__ y, size_t ldy, bool act, int i, int g, int wave, int lane,
-    long ntiles, long line, double& d0, double& d1, double& e0, double& e1) {
+    long ntiles, long line, int xcd_runs, double& d0, double& d1, double& e0, double& e1) {
   constexpr int NO = LT - 5;               // slots that are neither chain nor line
   constexpr int NE = (ROLE == 1) ? 0 : 1;  // line row still loaded from memory
+  // Tuning hook (off): blocks are dealt round-robin to the 8 XCDs; tiles that are neighbours along a grid line share
+  // the rows at their common edge, so one could give each XCD a CONTIGUOUS run of the G tiles of a sweep (block b
+  // takes tile (b % 8) * G/8 + b / 8).  Measured: slower (3.43 vs 3.19 ms at 256^3), same at 240^3.
   const long G = gridDim.x, asl = line / 8;
-  const long cnt = (ntiles - blockIdx.x + G - 1) / G;
+  const long b0 = (G % 8 == 0 && xcd_runs) ? ((long)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3)) : (long)blockIdx.x;
+  const long cnt = (ntiles - b0 + G - 1) / G;
   auto row_at = [&](long it) {
-    const long t = blockIdx.x + it * G, q = t / asl, a = t - q * asl;
+    const long t = b0 + it * G, q = t / asl, a = t - q * asl;
     return ((long)NW * q + wave) * line + 8 * a + g;
   };
   auto row_of = [&](long it) { return min(row_at(min(it, cnt - 1)), nrows - 1); };
@@ -355,7 +359,7 @@ template <int LT, int DOT, int NW>
 __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
     const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
-    double* __restrict__ dot_partial, long yy_offset) {
+    double* __restrict__ dot_partial, long yy_offset, int xcd_runs) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
   __shared__ v2d xch[2][NW][64];
@@ -366,10 +370,12 @@ __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
   const bool act = 2 * i < m;
   const double* __restrict__ xl = x + (act ? 2 * i : 0);
   double d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;
-  if ((long)blockIdx.x < ntiles) {   // block-uniform: every wave of the block runs the same number of barriers
-    if (wave == 0) chain2_body<LT, DOT, NW, 0>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, d0, d1, e0, e1);
-    else if (wave == NW - 1) chain2_body<LT, DOT, NW, 2>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, d0, d1, e0, e1);
-    else chain2_body<LT, DOT, NW, 1>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, d0, d1, e0, e1);
+  const long gq = gridDim.x;
+  const long bperm = (gq % 8 == 0 && xcd_runs) ? ((long)(blockIdx.x & 7) * (gq >> 3) + (blockIdx.x >> 3)) : (long)blockIdx.x;
+  if (bperm < ntiles) {   // block-uniform: every wave of the block runs the same number of barriers
+    if (wave == 0) chain2_body<LT, DOT, NW, 0>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1);
+    else if (wave == NW - 1) chain2_body<LT, DOT, NW, 2>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1);
+    else chain2_body<LT, DOT, NW, 1>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1);
   }
   if (DOT) {
     auto sx = [](double v, int mask) {
@@ -421,6 +427,8 @@ static long pat_ntiles(long nrows, long line) {
 // chain + line exchange: most waves per block to try (16, 8, 4; measured 3.20 / 3.37 / 3.67 ms at 256^3 x 64);
 // 0: use the plain chain kernel
 static int g_chain2_nw = 16;
+static int g_chain2_xcd = 0;   // 1: contiguous tile runs per XCD (see chain2_body); measured slower: 3.43 vs 3.19 ms at 256^3
+extern "C" void gcge_hip_spmm_chain2_xcd(int on) { g_chain2_xcd = on; }
 extern "C" void gcge_hip_spmm_chain2_tune(int waves) { if (waves == 0 || waves == 4 || waves == 8 || waves == 16) g_chain2_nw = waves; }
 static int g_chain_lpr = 8;    // chain variant: lanes per row = half the columns per pass (8, 16, 32)
 extern "C" void gcge_hip_spmm_chain_tune(int lanes_per_row) { if (lanes_per_row == 8 || lanes_per_row == 16 || lanes_per_row == 32) g_chain_lpr = lanes_per_row; }
@@ -450,7 +458,7 @@ static long pat_launch(long nrows, const unsigned short* pid, const void* tab, i
     if (LT < 5) return -1;
     const long nlines = (nrows + cline - 1) / cline, ntl = (nlines + nw - 1) / nw * (cline / 8);
 #define GCGE_C2(NWV) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), DOT, NWV>), dim3((unsigned)nb), dim3(64 * NWV), \
-                       (size_t)ntab * sizeof(PatEntry), st, nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, ntl, cline, partial, yy_off)
+                       (size_t)ntab * sizeof(PatEntry), st, nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, ntl, cline, partial, yy_off, g_chain2_xcd)
     if (nw == 16) GCGE_C2(16); else if (nw == 8) GCGE_C2(8); else GCGE_C2(4);
 #undef GCGE_C2
     return nb;
