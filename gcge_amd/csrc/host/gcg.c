@@ -270,6 +270,84 @@ static void ComputeW(Ctx *c, int *offset)
 	g_timing.compW += ops->GetWtime() - t0;
 }
 
+/* Second-order variant (-gcge_compW_cg_order 2; reference ComputeW12, ops_eig_sol_gcg.c:697-923): only the first
+ * half of the unconverged columns gets search directions, but two of them each: W1 ~ (A + sigma B)^-1 (lambda + sigma) B x
+ * started from x, and W2 = the same system solved again starting from W1 (a second leg of the Krylov iteration).
+ * The reference refuses a user-defined solver here (:703); ours may be used (it is called twice in the same way). */
+static void ComputeW12(Ctx *c, int *offset)
+{
+	struct OPS_ *ops = c->ops; GCGSolver *p = c->p; void **b = c->ritz;
+	int s[2], e[2], idx, blk = 0, i, total = 0, half, pass;
+	double sigma = 0.0, *scales = c->scratch, t0 = ops->GetWtime(), t1;
+	void (*saved_solver)(void*, void**, void**, int*, int*, struct OPS_*) = ops->MultiLinearSolver;
+	void *saved_ws = ops->multi_linear_solver_workspace;
+	void **cg_ws[3];
+	int use_axpby;
+	if (p->compW_cg_auto_shift == 1)
+		sigma = -c->ss_eval[c->sizeC] + (c->ss_eval[c->sizeC + 1] - c->ss_eval[c->sizeC]) * 0.01;
+	p->sigma = sigma = p->compW_cg_shift + sigma;
+	assert(p->compW_cg_auto_shift == 0 || p->user_defined_multi_linear_solver == 0);
+	use_axpby = sigma != 0.0 && c->B != NULL && ops->MatAxpby != NULL && p->user_defined_multi_linear_solver != 1;
+
+	for (idx = 0; idx < offset[0]; ++idx) total += offset[idx * 2 + 2] - offset[idx * 2 + 1];
+	half = total / 2;
+	c->startW = c->endP;
+	for (pass = 0; pass < 2; ++pass) {
+		/* x (first pass only) and the right-hand side (lambda + sigma) B x for the first `half` unconverged columns;
+		 * the shift wrapper of BlockPCG uses the rhs block as scratch, so it is rebuilt before the second solve */
+		if (pass == 1 && !(sigma != 0.0 && c->B != NULL && !use_axpby && p->user_defined_multi_linear_solver != 1)) break;
+		blk = 0;
+		for (idx = 0; idx < offset[0] && blk < half; ++idx) {
+			int lo = offset[idx * 2 + 1], len = offset[idx * 2 + 2] - lo;
+			if (blk + len > half) len = half - blk;
+			if (pass == 0) {
+				s[0] = lo; e[0] = lo + len; s[1] = c->startW + blk; e[1] = s[1] + len;
+				ops->MultiVecAxpby(1.0, c->ritz, 0.0, c->V, s, e, ops);
+			}
+			s[0] = lo; e[0] = lo + len; s[1] = offset[1] + blk; e[1] = s[1] + len;
+			ops->MatDotMultiVec(c->B, c->V, b, s, e, ops);
+			for (i = 0; i < len; ++i) scales[blk + i] = c->ss_eval[lo + i] + sigma;
+			ops->MultiVecLinearComb(NULL, b, 0, s, e, NULL, 0, scales + blk, 1, ops);
+			blk += len;
+		}
+		if (pass == 0) {
+			t1 = ops->GetWtime();
+			if (p->user_defined_multi_linear_solver == 0 || p->user_defined_multi_linear_solver == 2) {
+				cg_ws[0] = c->ws0; cg_ws[1] = c->ws1; cg_ws[2] = c->ws2;
+				g_shift_ctx = c;
+				if (use_axpby) ops->MatAxpby(sigma, c->B, 1.0, c->A, ops);
+				MultiLinearSolverSetup_BlockPCG(p->compW_cg_max_iter, p->compW_cg_rate, p->compW_cg_tol,
+						p->compW_cg_tol_type, cg_ws, c->scratch, c->iscratch, NULL,
+						(sigma != 0.0 && !use_axpby) ? MatDotMultiVecShift : NULL, ops);
+			}
+			if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverShift(sigma, c->B);
+			s[0] = offset[1]; e[0] = s[0] + half; s[1] = c->startW; e[1] = s[1] + half;
+			ops->MultiLinearSolver(c->A, b, c->V, s, e, ops);
+			g_timing.linsol += ops->GetWtime() - t1;
+			c->endW = c->startW + half;
+			/* second leg starts from W1 */
+			s[0] = c->startW; e[0] = c->endW; s[1] = c->endW; e[1] = c->endW + half;
+			ops->MultiVecAxpby(1.0, c->V, 0.0, c->V, s, e, ops);
+		}
+	}
+	t1 = ops->GetWtime();
+	s[0] = offset[1]; e[0] = s[0] + half; s[1] = c->endW; e[1] = s[1] + half;
+	ops->MultiLinearSolver(c->A, b, c->V, s, e, ops);
+	g_timing.linsol += ops->GetWtime() - t1;
+	if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverShift(0.0, NULL);
+	c->endW += half;
+	assert(c->endW - c->startW <= total);
+	if (use_axpby) ops->MatAxpby(-sigma, c->B, 1.0, c->A, ops);
+	ops->MultiLinearSolver = saved_solver;
+	ops->multi_linear_solver_workspace = saved_ws;
+
+	setup_orth(c, p->compW_orth_method, p->compW_orth_block_size, p->compW_orth_max_reorth,
+			p->compW_orth_zero_tol, c->ws0, ops);
+	ops->MultiVecOrth(c->V, c->startW, &c->endW, c->B, ops);
+	c->sizeW = c->endW - c->startW;
+	g_timing.compW += ops->GetWtime() - t0;
+}
+
 static void ComputeRayleighRitz(Ctx *c, int nevConv)
 {
 	struct OPS_ *ops = c->ops; GCGSolver *p = c->p;
@@ -347,7 +425,6 @@ static void GCG(void *A, void *B, double *eval, void **evec, int nevGiven, int *
 	assert(nevMax >= *nevConv + b);
 	assert(nevMax <= *nevConv + nevInit);
 	assert(p->multiMax <= b);
-	assert(p->compW_cg_order == 1);   /* 2nd-order Krylov W (ComputeW12) is not on this path */
 
 	c->sizeC = 0; c->sizeN = b; c->sizeX = nevInit; c->sizeP = 0; c->sizeW = 0;
 	c->sizeV = c->sizeX; c->startN = 0; c->endN = c->sizeN; c->endX = c->sizeX;
@@ -402,7 +479,8 @@ static void GCG(void *A, void *B, double *eval, void **evec, int nevGiven, int *
 		if (numIter == 0) { c->sizeP = 0; c->startP = c->endX; c->endP = c->startP; }
 		else ComputeP(c, c->offsetP);
 		ComputeX(c);
-		ComputeW(c, c->offsetW);
+		if (p->compW_cg_order != 1) ComputeW12(c, c->offsetW);
+		else ComputeW(c, c->offsetW);
 		tmp = c->offsetP; c->offsetP = c->offsetW; c->offsetW = tmp;
 		ComputeRayleighRitz(c, *nevConv);
 		for (idx = c->sizeV; idx < T; ++idx) c->ss_eval[idx] = c->ss_eval[c->sizeV - 1];

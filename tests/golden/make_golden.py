@@ -175,6 +175,11 @@ for key, kind, size, nev, extra, kw in (
         ("lap3d_12_nev10_shift1", "lap3d", 12, 10, ("-gcge_compW_cg_shift", "1.0"), {}),
         ("lap3d_12_nev10_autoshift", "lap3d", 12, 10, ("-gcge_compW_cg_auto_shift", "1"), {}),
         ("fe3d_12_nev10_autoshift", "fe3d", 12, 10, ("-gcge_compW_cg_auto_shift", "1"), {}),
+        # second-order W: two CG legs on half of the unconverged columns (ComputeW12, ops_eig_sol_gcg.c:697-923)
+        ("lap3d_12_nev10_order2", "lap3d", 12, 10, ("-gcge_compW_cg_order", "2"), {}),
+        ("fe3d_12_nev10_order2", "fe3d", 12, 10, ("-gcge_compW_cg_order", "2"), {}),
+        ("lap3d_16_nev12_b8_order2_shift", "lap3d", 16, 12, ("-gcge_compW_cg_order", "2", "-gcge_compW_cg_shift", "0.5"),
+         {"nev_max": 24, "block": 8}),
 ):
     A, B = make_problem(kind, size, K=6, R0=1.5, R1=2.0, seed=12345)
     ev, conv, it, sec = po.ref_gcg(A, B, nev, nev_max=kw.get("nev_max", 0), block=kw.get("block", 0),

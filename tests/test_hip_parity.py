@@ -177,7 +177,8 @@ GCG = load_golden("gcg.json")
 
 @pytest.mark.parametrize("key", ["lap3d_12_nev10", "lap3d_20_nev20", "lap3d_16_nev12_b8", "fe3d_12_nev10",
                                  "fe3d_20_nev20", "fe1d_807_nev30", "sio2_12_nev10", "fe3d_14_nev20_init30",
-                                 "lap3d_16_nev20_init24", "lap3d_12_nev10_shift1", "fe3d_12_nev10_autoshift"])
+                                 "lap3d_16_nev20_init24", "lap3d_12_nev10_shift1", "fe3d_12_nev10_autoshift",
+                                 "fe3d_12_nev10_order2", "lap3d_16_nev12_b8_order2_shift"])
 def test_gcg_on_hip_matches_reference_run(hip, key):
     c = GCG[key]
     args = ["-nevConv", c["nev"]]
@@ -191,7 +192,7 @@ def test_gcg_on_hip_matches_reference_run(hip, key):
     hip.set_random_mode(0)     # the reference's rand() stream after srand(0)
     ev, res = gcg_on(hip, c["kind"], c["size"], args, K=6, R0=1.5, R1=2.0, seed=12345)
     assert res.nevConv == c["nevConv"]
-    if "autoshift" not in key:   # see test_oracle_golden.py: the reference's own count is not reproducible there
+    if "autoshift" not in key and "order2" not in key:   # see test_oracle_golden.py: the reference's own count is not reproducible there
         assert abs(res.numIter - c["numIter"]) <= 2
     ref = np.array(c["eval"])
     rel = np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref))
