@@ -297,3 +297,101 @@ int gcge_dist_localize(GCGE_CSR *A, const int *ghosts, int nghost)
 	A->ncols = A->nrows + nghost;
 	return 0;
 }
+
+/* ---------------------------------------------------------------- ingestion */
+#include <stdio.h>
+
+static uint32_t be32(const unsigned char *q) { return ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3]; }
+static double be64f(const unsigned char *q)
+{
+	uint64_t u = 0; double d; int i;
+	for (i = 0; i < 8; ++i) u = (u << 8) | q[i];
+	memcpy(&d, &u, 8);
+	return d;
+}
+static int read_be32(FILE *f, int32_t *dst, int64_t count)
+{
+	unsigned char buf[4096]; int64_t done = 0;
+	while (done < count) {
+		int64_t chunk = count - done, i; if (chunk > 1024) chunk = 1024;
+		if (fread(buf, 4, (size_t)chunk, f) != (size_t)chunk) return -1;
+		if (dst) for (i = 0; i < chunk; ++i) dst[done + i] = (int32_t)be32(buf + 4 * i);
+		done += chunk;
+	}
+	return 0;
+}
+
+int gcge_load_petsc_binary(const char *path, int64_t row_begin, int64_t row_end, GCGE_CSR *A)
+{
+	FILE *f = fopen(path, "rb");
+	unsigned char hdr[16], buf[4096];
+	int32_t rows, cols, nnz, *len = NULL;
+	int64_t r, first = 0, mine = 0, skip_after, i;
+	if (f == NULL) return -1;
+	if (fread(hdr, 1, 16, f) != 16) { fclose(f); return -1; }
+	if (be32(hdr) != 1211216u) { fclose(f); return -2; }     /* MAT_FILE_CLASSID */
+	rows = (int32_t)be32(hdr + 4); cols = (int32_t)be32(hdr + 8); nnz = (int32_t)be32(hdr + 12);
+	if (rows < 0 || cols < 0 || nnz < 0) { fclose(f); return -2; }   /* nnz = -1 marks a dense file */
+	if (row_end < 0 || row_end > rows) row_end = rows;
+	if (row_begin < 0 || row_begin > row_end) { fclose(f); return -2; }
+	len = (int32_t*)malloc((size_t)(rows > 0 ? rows : 1) * sizeof(int32_t));
+	if (len == NULL) { fclose(f); return -3; }
+	if (read_be32(f, len, rows)) { free(len); fclose(f); return -1; }
+	for (r = 0; r < row_begin; ++r) first += len[r];
+	for (r = row_begin; r < row_end; ++r) mine += len[r];
+	skip_after = (int64_t)nnz - first - mine;
+	if (skip_after < 0 || csr_alloc(A, row_end - row_begin, cols, row_begin, mine)) { free(len); fclose(f); return skip_after < 0 ? -2 : -3; }
+	A->rowptr[0] = 0;
+	for (r = row_begin; r < row_end; ++r) A->rowptr[r - row_begin + 1] = A->rowptr[r - row_begin] + len[r];
+	A->nnz = mine;
+	free(len);
+	/* column indices: skip `first`, read `mine`, skip the rest; then the values likewise */
+	if (fseek(f, (long)(4 * first), SEEK_CUR) || read_be32(f, A->colidx, mine) || fseek(f, (long)(4 * skip_after), SEEK_CUR)
+			|| fseek(f, (long)(8 * first), SEEK_CUR)) { gcge_csr_free(A); fclose(f); return -1; }
+	for (i = 0; i < mine; ) {
+		int64_t chunk = mine - i, k; if (chunk > 512) chunk = 512;
+		if (fread(buf, 8, (size_t)chunk, f) != (size_t)chunk) { gcge_csr_free(A); fclose(f); return -1; }
+		for (k = 0; k < chunk; ++k) A->val[i + k] = be64f(buf + 8 * k);
+		i += chunk;
+	}
+	fclose(f);
+	for (i = 0; i < mine; ++i) if (A->colidx[i] < 0 || A->colidx[i] >= cols) { gcge_csr_free(A); return -2; }
+	return 0;
+}
+
+int gcge_save_petsc_binary(const char *path, const GCGE_CSR *A)
+{
+	FILE *f = fopen(path, "wb");
+	unsigned char q[8]; int64_t i; int r, k;
+	uint32_t hdr[4];
+	if (f == NULL) return -1;
+	hdr[0] = 1211216u; hdr[1] = (uint32_t)A->nrows; hdr[2] = (uint32_t)A->ncols; hdr[3] = (uint32_t)A->nnz;
+	for (k = 0; k < 4; ++k) { q[0] = hdr[k] >> 24; q[1] = hdr[k] >> 16; q[2] = hdr[k] >> 8; q[3] = hdr[k]; fwrite(q, 1, 4, f); }
+	for (r = 0; r < A->nrows; ++r) { uint32_t v = (uint32_t)(A->rowptr[r + 1] - A->rowptr[r]); q[0] = v >> 24; q[1] = v >> 16; q[2] = v >> 8; q[3] = v; fwrite(q, 1, 4, f); }
+	for (i = 0; i < A->nnz; ++i) { uint32_t v = (uint32_t)A->colidx[i]; q[0] = v >> 24; q[1] = v >> 16; q[2] = v >> 8; q[3] = v; fwrite(q, 1, 4, f); }
+	for (i = 0; i < A->nnz; ++i) { uint64_t u; memcpy(&u, &A->val[i], 8); for (k = 0; k < 8; ++k) q[k] = (unsigned char)(u >> (56 - 8 * k)); fwrite(q, 1, 8, f); }
+	return fclose(f) ? -1 : 0;
+}
+
+int gcge_csr_from_ccs(int nrows, int ncols, const int *j_col, const int *i_row, const double *data,
+		int one_based, GCGE_CSR *A)
+{
+	const int ob = one_based ? 1 : 0;
+	int64_t nnz = (int64_t)j_col[ncols] - ob, k; int c, r;
+	int *fill;
+	if (nnz < 0 || csr_alloc(A, nrows, ncols, 0, nnz)) return -3;
+	A->nnz = nnz;
+	memset(A->rowptr, 0, ((size_t)nrows + 1) * sizeof(int));
+	for (k = 0; k < nnz; ++k) { r = i_row[k] - ob; if (r < 0 || r >= nrows) { gcge_csr_free(A); return -2; } ++A->rowptr[r + 1]; }
+	for (r = 0; r < nrows; ++r) A->rowptr[r + 1] += A->rowptr[r];
+	fill = (int*)malloc((size_t)(nrows > 0 ? nrows : 1) * sizeof(int));
+	if (fill == NULL) { gcge_csr_free(A); return -3; }
+	memcpy(fill, A->rowptr, (size_t)nrows * sizeof(int));
+	for (c = 0; c < ncols; ++c)          /* columns ascending => column indices ascending inside every row */
+		for (k = j_col[c] - ob; k < j_col[c + 1] - ob; ++k) {
+			r = i_row[k] - ob;
+			A->colidx[fill[r]] = c; A->val[fill[r]] = data[k]; ++fill[r];
+		}
+	free(fill);
+	return 0;
+}

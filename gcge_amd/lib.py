@@ -70,6 +70,18 @@ def hip_lib():
     return _hip
 
 
+def load_petsc_binary(path, row_begin=0, row_end=-1):
+    """PETSc binary Mat file (what the reference's SLEPc driver reads: test/test_app_slepc.c:416-445) -> host CSR;
+    rows [row_begin, row_end) with global columns (row_end < 0: to the end)."""
+    h = host_lib()
+    h.gcge_load_petsc_binary.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.POINTER(CSR)]
+    A = CSR()
+    rc = h.gcge_load_petsc_binary(os.fsencode(path), row_begin, row_end, C.byref(A))
+    if rc != 0:
+        raise RuntimeError("gcge_load_petsc_binary(%r) failed: %d" % (path, rc))
+    return A
+
+
 def make_problem(kind, size, row_begin=0, row_end=-1, **kw):
     """Returns (A, B) CSR structs (B is None for standard problems)."""
     h = host_lib()

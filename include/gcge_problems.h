@@ -53,6 +53,20 @@ int gcge_problem_fe3d(int M, int64_t row_begin, int64_t row_end, GCGE_CSR *A, GC
 int gcge_problem_sio2_like(int G, int K, double R0, double R1, uint64_t seed,
 		int64_t row_begin, int64_t row_end, GCGE_CSR *A);
 
+/* ---- matrix ingestion (the formats the reference's users hold) --------------------------
+ * PETSc binary Mat file (what test/test_app_slepc.c:416-445 loads with MatLoad: SiO2, Ga41As41H72, ... of
+ * submit.sh:9-15): big-endian int32 header {1211216, rows, cols, nnz}, int32 row lengths, int32 column
+ * indices, float64 values (AIJ, 32-bit indices).  Rows [row_begin,row_end) only (row_end < 0: all), global
+ * columns.  Returns 0, -1 cannot open / short file, -2 not a (32-bit index, real) Mat file, -3 out of memory. */
+int gcge_load_petsc_binary(const char *path, int64_t row_begin, int64_t row_end, GCGE_CSR *A);
+/* writer of the same format (tests, data exchange with a PETSc build) */
+int gcge_save_petsc_binary(const char *path, const GCGE_CSR *A);
+/* Compressed-column triple (app/app_ccs.h:20-24 CCSMAT; MATLAB's jc/ir/pr of app/app_matlab.c:80-98) of a
+ * general square or rectangular matrix -> CSR (transposition by counting; a symmetric matrix comes out
+ * identical).  one_based != 0: MATLAB-style 1-based indices. */
+int gcge_csr_from_ccs(int nrows, int ncols, const int *j_col, const int *i_row, const double *data,
+		int one_based, GCGE_CSR *A);
+
 /* ---- row partition helpers (one process per GPU) ---------------------
  * A slab holds rows [row_begin,row_begin+nrows) with GLOBAL column indices.
  * gcge_dist_ghosts   lists (ascending, unique) the global columns the slab references outside

@@ -33,14 +33,21 @@ def main():
     ap.add_argument("--R0", type=float, default=1.5)
     ap.add_argument("--R1", type=float, default=2.0)
     ap.add_argument("--ref", action="store_true", help="also run the CPU reference (oracle/_ref) on the same input")
+    ap.add_argument("--petsc", nargs="+", default=None, metavar="FILE",
+                    help="PETSc binary Mat file(s): A [B] (the reference's -filename_matA / -filename_matB) instead of a generator")
     ap.add_argument("--extra", nargs="*", default=[])
     a = ap.parse_args()
 
     import numpy as np
     import torch  # noqa: F401  (one libamdhip64 for torch and the extension)
-    from gcge_amd import HipBackend, make_problem, run_gcg
+    from gcge_amd import HipBackend, load_petsc_binary, make_problem, run_gcg
     t0 = time.perf_counter()
-    A, B = make_problem(a.kind, a.size, K=a.K, R0=a.R0, R1=a.R1, seed=12345)
+    if a.petsc:
+        A = load_petsc_binary(a.petsc[0])
+        B = load_petsc_binary(a.petsc[1]) if len(a.petsc) > 1 else None
+        a.kind, a.size = "petsc:" + os.path.basename(a.petsc[0]), A.nrows
+    else:
+        A, B = make_problem(a.kind, a.size, K=a.K, R0=a.R0, R1=a.R1, seed=12345)
     t_gen = time.perf_counter() - t0
     hip = HipBackend()
     hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
