@@ -515,12 +515,20 @@ static void HIP_MultiVecSetRandomValue(void** x, int start, int end, struct OPS_
     g_rand_seed += 0x9E3779B97F4A7C15ull;   // a later fill of the same columns differs
     return;
   }
+  // Row slabs: every rank walks the GLOBAL rand() sequence (columns outer, global rows inner) and keeps its own
+  // rows, so the start block is the single-rank one whatever the number of ranks (identical local streams would
+  // make it periodic in the slab index).  O(n_global) draws per column: use mode 1 for large n.
+  const long before = (v->mat && v->mat->nglobal > v->nrows) ? v->mat->row_begin : 0;
+  const long after = (v->mat && v->mat->nglobal > v->nrows) ? (long)v->mat->nglobal - v->mat->row_begin - v->nrows : 0;
   const int panel = 16;
   std::vector<double> h((size_t)v->nrows * panel);
   for (int c = start; c < end; c += panel) {
     const int mm = (end - c < panel) ? end - c : panel;
-    for (int j = 0; j < mm; ++j)
+    for (int j = 0; j < mm; ++j) {
+      for (long k = 0; k < before; ++k) (void)rand();
       for (int r = 0; r < v->nrows; ++r) h[(size_t)j * v->nrows + r] = ((double)rand()) / ((double)RAND_MAX + 1);
+      for (long k = 0; k < after; ++k) (void)rand();
+    }
     gcge_hip_mv_from_host(x, c, c + mm, h.data(), v->nrows);
   }
 }

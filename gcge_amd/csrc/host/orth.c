@@ -30,9 +30,13 @@ static void negate(double *v, int n) { int i; for (i = 0; i < n; ++i) v[i] = -v[
 
 /* x[:, s1:e1) -= x[:, s0:e0) * (x[:, s0:e0)^T B x[:, s1:e1)), repeated up to 1+max_reorth
  * times.  Returns nothing; coef scratch needs (e0-s0)*(e1-s1) doubles.
- * lazy = 0: the reference's order (ops_orth.c:235-265: apply the update, then test its size);
- * lazy = 1: a re-orthogonalisation pass whose coefficients are already below reorth_tol is not
- * applied at all (it would change x by < 50 eps; saves one n x k x m panel update per call). */
+ * lazy = 0: the reference's order (ops_orth.c:235-265: apply the update, then test its size) — what every
+ * caller uses;
+ * lazy = 1: a re-orthogonalisation pass whose coefficients are already below reorth_tol is not applied
+ * (saves one n x k x m panel update per call).  NOT safe in general: the test is absolute, and when the
+ * columns being projected are tiny (W blocks close to convergence are ~1e-9 of the basis vectors) a
+ * coefficient of 1e-14 is a relative 1e-5 that the subsequent normalisation blows up — an 8-rank run on an
+ * 8^3 grid stagnated at 7 of 8 pairs with it (tests/test_dist.py). */
 static void project_out(void **x, int s0, int e0, int s1, int e1, void *B,
 		int max_reorth, double reorth_tol, int lazy, void **mv_ws, double *coef, struct OPS_ *ops)
 {
@@ -247,7 +251,7 @@ static void CholeskyQR(void **x, int start_x, int *end_x, void *B, struct OPS_ *
 	double *coef = p->dbl_ws;
 	int block, b0, b1, start[2], end[2];
 	if (*end_x <= start_x) return;
-	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, 1, p->mv_ws, coef, ops);
+	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, 0, p->mv_ws, coef, ops);
 	b0 = start_x;
 	block = p->block_size;
 	if (block <= 0) block = *end_x - b0;
@@ -265,7 +269,7 @@ static void CholeskyQR(void **x, int start_x, int *end_x, void *B, struct OPS_ *
 		}
 		*end_x -= dropped;
 		if (b1 < *end_x && b0 < b1)
-			project_block_from_rest(x, b0, b1, *end_x, B, p->max_reorth, p->reorth_tol, 1, p->mv_ws, coef, ops);
+			project_block_from_rest(x, b0, b1, *end_x, B, p->max_reorth, p->reorth_tol, 0, p->mv_ws, coef, ops);
 		b0 = b1;
 		if (block > *end_x - b0) block = *end_x - b0;
 	}

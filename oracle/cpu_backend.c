@@ -76,13 +76,23 @@ static void O_MultiVecView(void **x, int start, int end, struct OPS_ *ops)
 		ops->Printf("\n");
 	}
 }
+/* row partition of this rank (row-partitioned runs only): lets every rank draw the GLOBAL rand() sequence and
+ * keep its own rows, so the start block does not depend on the number of ranks (identical local streams would
+ * make the global block periodic in the slab index and starve the solver of whole families of modes) */
+static long g_part_begin = 0, g_part_nglobal = 0;
+void oracle_set_partition(long row_begin, long nglobal) { g_part_begin = row_begin; g_part_nglobal = nglobal; }
 /* app_lapack.c:322-333 — glibc rand(), columns outer, rows inner */
 static void O_MultiVecSetRandomValue(void **x, int start, int end, struct OPS_ *ops)
 {
-	VEC *v = (VEC*)x; int r, c;
-	for (c = start; c < end; ++c)
+	VEC *v = (VEC*)x; int r, c; long k;
+	const long before = g_part_nglobal > 0 ? g_part_begin : 0;
+	const long after = g_part_nglobal > 0 ? g_part_nglobal - g_part_begin - v->nrows : 0;
+	for (c = start; c < end; ++c) {
+		for (k = 0; k < before; ++k) (void)rand();
 		for (r = 0; r < v->nrows; ++r)
 			v->data[(size_t)v->ldd * c + r] = ((double)rand()) / ((double)RAND_MAX + 1);
+		for (k = 0; k < after; ++k) (void)rand();
+	}
 }
 /* app_lapack.c:334-395 — beta == 0 zeroes y (never multiplies), x == NULL scales only */
 static void O_MultiVecAxpby(double alpha, void **x, double beta, void **y,

@@ -15,6 +15,7 @@ typedef struct ORACLE_HALO_ {
 	void *ctx;
 } ORACLE_HALO;
 void oracle_set_halo (const ORACLE_HALO *h);
+void oracle_set_partition (long row_begin, long nglobal);   /* for the rank-count independent random start block */
 void OPS_ORACLE_Set (struct OPS_ *ops);     /* counterpart of OPS_CCS_Set (app/app_ccs.c:213-249) */
 void oracle_set_threads (int n);            /* OpenMP threads over block columns (app_ccs.c:117) */
 int  oracle_get_threads (void);

@@ -16,13 +16,14 @@ def _free_port():
     return p
 
 
-def _run(mode, world=2, timeout=600):
+def _run(mode, world=2, timeout=600, dims=None):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode]
+                                      + ([",".join(str(d) for d in dims)] if dims else []),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -40,6 +41,16 @@ def _run(mode, world=2, timeout=600):
 
 def test_two_ranks_gloo_cpu_oracle():
     _run("oracle")
+
+
+def test_eight_ranks_gloo_cpu_oracle():
+    """The 8-rank shape of bench.py's weak-scaling grid ((2N)^3 cut into 8 slabs, here N = 4: one plane per rank,
+    every inner rank exchanges with two neighbours)."""
+    sys.path.insert(0, ROOT)
+    from gcge_amd import dist as gdist
+    assert gdist.weak_scaling_box(4, 8) == (8, 8, 8) and gdist.weak_scaling_box(4, 2) == (8, 4, 4)
+    assert gdist.weak_scaling_box(4, 4) == (8, 8, 4) and gdist.weak_scaling_box(4, 3) == (4, 4, 12)
+    _run("oracle", world=8, dims=gdist.weak_scaling_box(4, 8))
 
 
 def test_row_partition_helpers():
