@@ -107,7 +107,7 @@ def main():
     N = args.size
     n_global = N ** 3
     # weak scaling: every rank owns size^3 rows of a grid that stays as cube-like as the rank count allows
-    # (1: N^3, 2: 2N x N x N, 4: 2N x 2N x N, 8: (2N)^3 = BASELINE config 4), cut into slabs along the last index
+    # (1: N^3, 2: N x N x 2N, 4: N x 2N x 2N, 8: (2N)^3 = BASELINE config 4), cut into slabs along the last index
     dims = gdist.weak_scaling_box(N, world)
     if world > 1:
         comm = gdist.install(hip, dist, rank, world, stage_through_host=rehearse)

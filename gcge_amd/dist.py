@@ -179,10 +179,11 @@ def hip_slab_matrix(hip, comm, A, n_global, part, cap_cols=128):
 
 def weak_scaling_box(N, world):
     """Grid of bench.py's weak-scaling workload: N^3 rows per rank, as cube-like as possible so that the spectrum
-    (and with it the GCG iteration count) stays comparable across rank counts: 1: N^3, 2: 2N x N x N,
-    4: 2N x 2N x N, 8: (2N)^3 (= BASELINE config 4 at N = 256); other counts: N x N x (N world).
-    Slabs are cut along the last (slowest) index."""
-    dims = {1: (N, N, N), 2: (2 * N, N, N), 4: (2 * N, 2 * N, N), 8: (2 * N, 2 * N, 2 * N)}
+    (and with it the GCG iteration count) stays comparable across rank counts: 1: N^3, 2: N x N x 2N,
+    4: N x 2N x 2N, 8: (2N)^3 (= BASELINE config 4 at N = 256); other counts: N x N x (N world).
+    Slabs are cut along the last (slowest) index, so the short edges come first: the halo plane (product of the
+    first two) is the smallest face of the box."""
+    dims = {1: (N, N, N), 2: (N, N, 2 * N), 4: (N, 2 * N, 2 * N), 8: (2 * N, 2 * N, 2 * N)}
     return dims.get(world, (N, N, N * world))
 
 

@@ -48,8 +48,8 @@ def test_eight_ranks_gloo_cpu_oracle():
     every inner rank exchanges with two neighbours)."""
     sys.path.insert(0, ROOT)
     from gcge_amd import dist as gdist
-    assert gdist.weak_scaling_box(4, 8) == (8, 8, 8) and gdist.weak_scaling_box(4, 2) == (8, 4, 4)
-    assert gdist.weak_scaling_box(4, 4) == (8, 8, 4) and gdist.weak_scaling_box(4, 3) == (4, 4, 12)
+    assert gdist.weak_scaling_box(4, 8) == (8, 8, 8) and gdist.weak_scaling_box(4, 2) == (4, 4, 8)
+    assert gdist.weak_scaling_box(4, 4) == (4, 8, 8) and gdist.weak_scaling_box(4, 3) == (4, 4, 12)
     _run("oracle", world=8, dims=gdist.weak_scaling_box(4, 8))
 
 
