@@ -17,15 +17,19 @@
 // block writes its partial tile to a slab that a second kernel sums in fixed order
 // (bitwise reproducible, no float atomics on global memory).
 //
-// Roofline: 2 n k m flops on the FP64 MFMA pipe (78.6 TF peak) vs 8 n (k + m) bytes
-// from HBM: k = m = 64 is 8 flop/B (HBM-bound at ~50 TF), k >= 256 is MFMA-bound.
+// Roofline: 2 n k m flops on the FP64 MFMA pipe (78.6 TF peak; a register-only loop of the same instruction
+// reaches 76.9 TF on this chip, tools/dense_bench.hip) vs 8 n (k + m) bytes from HBM: k = m = 64 is 8 flop/B
+// (HBM-bound at ~50 TF), k >= 256 is MFMA-bound.  Measured 48-50 TF for k >= 128 whatever the prefetch depth,
+// occupancy or tile-to-wave mapping.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "gcge_hip_internal.h"
 
 extern "C" double* gcge_hip_partial_ws(size_t len);
 
 namespace gcge {
+#include "agpr_tiles.inc"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -44,37 +48,43 @@ __device__ __forceinline__ void gram_load(double (&af)[MS][4], double (&bf)[MS][
     }
 }
 
+// the 64 x 64 accumulator tile of a wave lives in a[0:127] by name (agpr_tiles.inc): fragment (a, b) = tile 4a + b
 template <int MS>
-__device__ __forceinline__ void gram_mfma(v4d (&acc)[4][4], const double (&af)[MS][4], const double (&bf)[MS][4]) {
+__device__ __forceinline__ void gram_mfma(const double (&af)[MS][4], const double (&bf)[MS][4]) {
 #pragma unroll
   for (int u = 0; u < MS; ++u)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u][a], bf[u][b], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < 4; ++b) agpr_tile_mfma(4 * a + b, af[u][a], bf[u][b]);
 }
 
-// One block: output tile rows [i0,i0+64) x cols [j0,j0+64), matrix rows [r0,r1).
-// Columns beyond k (or m) are not masked: those lanes read column 0 of the block instead, which only
-// pollutes output entries (i >= k or j >= m) that the reduction kernel never reads.
-template <int MS>
+// One block: TIB output tiles rows [i0,i0+64) x cols [j0,j0+64) side by side in i, matrix rows [r0,r1).
+// The 4 waves are split TIB x RP (RP = 4 / TIB): wave w works on tile i = w % TIB and takes every RP-th macro-step
+// of the chunk.  With TIB = 4 (k a multiple of 256: the Rayleigh-Ritz and W-projection Grams) every wave owns a
+// whole 64 x 64 tile for the chunk, all four read the SAME P rows (L1 hits after the first) and nothing has to be
+// combined; launching the four Q tiles as separate blocks instead re-reads P four times and makes the kernel
+// bandwidth-bound (measured 48 TF whatever the prefetch depth).  Columns beyond k (or m) are not masked: those
+// lanes read column 0 of the block, which only pollutes output entries the reduction kernel never reads.
+template <int MS, int TIB>
 __global__ __launch_bounds__(256) void gram_tile_kernel(long nrows, const double* __restrict__ q, long ldq,
     int k, const double* __restrict__ p, long ldp, int m, double* __restrict__ slab, long rows_per_chunk,
     int ntile_i, int ntile_j) {
-  __shared__ double red[64 * 64];
+  constexpr int RP = 4 / TIB;
+  __shared__ double red[RP > 1 ? TIB * 64 * 64 : 1];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int i0 = blockIdx.y * 64, j0 = blockIdx.z * 64;
+  // readfirstlane: tells the compiler the wave index is uniform, so row bases live in scalar registers
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tsel = wave % TIB, rpart = wave / TIB;
+  const int ti = blockIdx.y * TIB + tsel;            // may be >= ntile_i for the last block in y: that wave idles
+  const int i0 = ti * 64, j0 = blockIdx.z * 64;
   const long r0 = (long)blockIdx.x * rows_per_chunk;
   const long r1 = min(nrows, r0 + rows_per_chunk);
   const int li = lane & 15, kk = lane >> 4;
+  const bool live = ti < ntile_i;
 
-  v4d acc[4][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int T = 0; T < 16; ++T) agpr_tile_zero(T);
 
   // per-lane fragment origins: row kk of a 4-row step, my column of each 16-column fragment
   const double* qp[4];
@@ -86,31 +96,31 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(long nrows, const double
     pp[a] = p + (long)kk * ldp + (pc < m ? pc : 0);
   }
 
-  // macro-steps of 4*MS rows are dealt round-robin to the four waves; two register sets so the
+  // macro-steps of 4*MS rows are dealt round-robin to the RP row parts; two register sets so the
   // loads of the next macro-step are in flight while the MFMAs of the current one issue
   const long full = (r1 - r0) / (4 * MS);
-  long s = wave;
-  if (s < full) {
-    // my macro-steps: s, s+4, ...; processed in pairs with two register sets.  No branch and no copy inside the
+  long s = rpart;
+  if (live && s < full) {
+    // my macro-steps: s, s+RP, ...; processed in pairs with two register sets.  No branch and no copy inside the
     // loop (hipcc sinks loads into a conditional consumer, and a register copy waits for the prefetch); the
     // scheduling barriers keep the machine scheduler from moving the prefetch below the MFMAs it overlaps.
-    const long cnt = (full - s + 3) / 4, last = s + 4 * (cnt - 1);
+    const long cnt = (full - s + RP - 1) / RP, last = s + RP * (cnt - 1);
     double a0[MS][4], b0[MS][4], a1[MS][4], b1[MS][4];
     gram_load<MS>(a0, b0, qp, pp, r0 + s * (4 * MS), ldq, ldp);
-    for (long i = 0; i < cnt / 2; ++i, s += 8) {
-      gram_load<MS>(a1, b1, qp, pp, r0 + (s + 4) * (4 * MS), ldq, ldp);
+    for (long i = 0; i < cnt / 2; ++i, s += 2 * RP) {
+      gram_load<MS>(a1, b1, qp, pp, r0 + (s + RP) * (4 * MS), ldq, ldp);
       __builtin_amdgcn_sched_barrier(0);
-      gram_mfma<MS>(acc, a0, b0);
+      gram_mfma<MS>(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-      gram_load<MS>(a0, b0, qp, pp, r0 + (s + 8 < last ? s + 8 : last) * (4 * MS), ldq, ldp);   // clamped
+      gram_load<MS>(a0, b0, qp, pp, r0 + (s + 2 * RP < last ? s + 2 * RP : last) * (4 * MS), ldq, ldp);   // clamped
       __builtin_amdgcn_sched_barrier(0);
-      gram_mfma<MS>(acc, a1, b1);
+      gram_mfma<MS>(a1, b1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (cnt & 1) gram_mfma<MS>(acc, a0, b0);   // a0/b0 hold macro-step `last`
+    if (cnt & 1) gram_mfma<MS>(a0, b0);   // a0/b0 hold macro-step `last`
   }
-  // the last (r1 - r0) mod 4*MS rows: predicated 4-row steps on wave 0 (at most MS of them per block)
-  if (wave == 0) {
+  // the last (r1 - r0) mod 4*MS rows: predicated 4-row steps on the first row part (at most MS of them per block)
+  if (live && rpart == 0) {
     for (long base = r0 + full * (4 * MS); base < r1; base += 4) {
       const bool rv = base + kk < r1;
       const long off = rv ? base : (r1 - 1 - kk);   // any valid row; the select below zeroes it
@@ -122,13 +132,30 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(long nrows, const double
         af[0][a] = rv ? qv : 0.0;
         bf[0][a] = rv ? pv : 0.0;
       }
-      gram_mfma<1>(acc, af, bf);
+      gram_mfma<1>(af, bf);
     }
   }
 
-  // combine the four waves: wave 0 stores, the others add (LDS f64 atomics avoided: sequenced)
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
+  // the MFMAs above are inline asm, invisible to the hazard recogniser: let the last ones retire before the
+  // accumulators are read (16 passes x 4 cycles)
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  // slab layout: [chunk][tile_i][tile_j][64*64]
+  if (RP == 1) {   // every wave owns its tile: straight to the slab
+    if (live) {
+      double* out = slab + (((long)blockIdx.x * ntile_i + ti) * ntile_j + blockIdx.z) * 4096;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) out[(16 * a + 4 * t + kk) * 64 + 16 * b + li] = agpr_tile_read(4 * a + b, t);
+    }
+    return;
+  }
+  // combine the RP row parts of a tile: part 0 stores, the others add (LDS f64 atomics avoided: sequenced)
+  double* mine = red + tsel * 4096;
+  for (int w = 0; w < RP; ++w) {
+    if (rpart == w) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -136,15 +163,19 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(long nrows, const double
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int row = 16 * a + 4 * t + kk, col = 16 * b + li;
-            if (w == 0) red[row * 64 + col] = acc[a][b][t];
-            else red[row * 64 + col] += acc[a][b][t];
+            const double v = agpr_tile_read(4 * a + b, t);
+            if (w == 0) mine[row * 64 + col] = v;
+            else mine[row * 64 + col] += v;
           }
     }
     __syncthreads();
   }
-  // slab layout: [chunk][tile_i][tile_j][64*64]
-  double* out = slab + (((long)blockIdx.x * ntile_i + blockIdx.y) * ntile_j + blockIdx.z) * 4096;
-  for (int e = threadIdx.x; e < 4096; e += 256) out[e] = red[e];
+  for (int tt = 0; tt < TIB; ++tt) {
+    const int tio = blockIdx.y * TIB + tt;
+    if (tio >= ntile_i) break;
+    double* out = slab + (((long)blockIdx.x * ntile_i + tio) * ntile_j + blockIdx.z) * 4096;
+    for (int e = threadIdx.x; e < 4096; e += 256) out[e] = red[tt * 4096 + e];
+  }
 }
 
 // g (row-major k x m) = sum over chunks of the slab tiles, fixed order
@@ -166,7 +197,8 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
 
 using namespace gcge;
 
-static int g_gram_ms = 4;   // measured: MS 1/2/4 = 36.8 / 42.3 / 45.2 TF at k=256, m=64, n=2^24 (profiles/r01_dense)
+static int g_gram_ms = 2;   // 4-row steps per macro-step; with the accumulators pinned to AGPRs MS = 1, 2, 4 all give 48-50 TF at
+                            // k=256, m=64, n=2^24 (profiles/r01_dense/07); MS = 2 keeps two waves per SIMD
 extern "C" void gcge_hip_gram_tune(int ms) { if (ms == 1 || ms == 2 || ms == 4) g_gram_ms = ms; }
 
 extern "C" int gcge_hip_gram(int nrows, const double* d_q, long ldq, int k, const double* d_p, long ldp,
@@ -175,16 +207,22 @@ extern "C" int gcge_hip_gram(int nrows, const double* d_q, long ldq, int k, cons
   hipStream_t st = (hipStream_t)stream;
   if (nrows <= 0) return (int)hipMemsetAsync(d_g, 0, (size_t)k * m * sizeof(double), st);
   const int ti = (k + 63) / 64, tj = (m + 63) / 64;
+  // waves of a block side by side on Q tiles when the tile count divides (P rows shared through L1); an idle wave
+  // (3 tiles on 4 waves) costs more than it saves: 10.6 vs 8.5 ms at k = 192
+  const int tib = ti % 4 == 0 ? 4 : (ti % 2 == 0 ? 2 : 1);
+  const int gy = (ti + tib - 1) / tib;
   // enough blocks to fill 256 CUs a few times over, chunks a multiple of 16 rows
-  long nchunks = 2048 / ((long)ti * tj);
+  long nchunks = 2048 / ((long)gy * tj);
   if (nchunks < 64) nchunks = 64;
   long rpc = (((long)nrows + nchunks - 1) / nchunks + 63) / 64 * 64;
   if (rpc < 64) rpc = 64;
   nchunks = ((long)nrows + rpc - 1) / rpc;
   double* slab = gcge_hip_partial_ws((size_t)nchunks * ti * tj * 4096);
-#define GCGE_GRAM(MS) hipLaunchKernelGGL(gram_tile_kernel<MS>, dim3((unsigned)nchunks, ti, tj), dim3(256), 0, st, \
-                                         (long)nrows, d_q, ldq, k, d_p, ldp, m, slab, rpc, ti, tj)
-  if (g_gram_ms == 1) GCGE_GRAM(1); else if (g_gram_ms == 4) GCGE_GRAM(4); else GCGE_GRAM(2);
+#define GCGE_GRAM(MS, TIBV) hipLaunchKernelGGL((gram_tile_kernel<MS, TIBV>), dim3((unsigned)nchunks, gy, tj), dim3(256), 0, st, \
+                                               (long)nrows, d_q, ldq, k, d_p, ldp, m, slab, rpc, ti, tj)
+#define GCGE_GRAM_MS(TIBV) do { if (g_gram_ms == 1) GCGE_GRAM(1, TIBV); else if (g_gram_ms == 4) GCGE_GRAM(4, TIBV); else GCGE_GRAM(2, TIBV); } while (0)
+  if (tib == 4) GCGE_GRAM_MS(4); else if (tib == 2) GCGE_GRAM_MS(2); else GCGE_GRAM_MS(1);
+#undef GCGE_GRAM_MS
 #undef GCGE_GRAM
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(16, ti, tj), dim3(256), 0, st, slab, (int)nchunks, ti, tj, k, m,
                      d_g);

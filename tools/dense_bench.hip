@@ -13,6 +13,22 @@ __global__ void fillk(double* x, size_t n) {
   for (; i < n; i += st) { unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull; z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
     x[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
 }
+// practical FP64 MFMA ceiling: 16 independent accumulator tiles per wave pinned to a[0:127], operands in registers
+#include "agpr_tiles.inc"
+__global__ __launch_bounds__(256) void mfma_peak(double* out, int iters, double seed) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) agpr_tile_zero(t);
+  double a = seed + threadIdx.x * 1e-3, b = seed * 0.5 + threadIdx.x * 2e-3;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) agpr_tile_mfma(t, a, b);
+  }
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  double s = 0;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) s += agpr_tile_read(t, 0);
+  if (s == 1.2345) out[0] = s;
+}
 int main(int argc, char** argv) {
   long n = argc > 1 ? atol(argv[1]) : 16777216; int reps = 3;
   const long ldv = 256, ldw = 128;
@@ -22,6 +38,13 @@ int main(int argc, char** argv) {
   fillk<<<4096, 256>>>(V, n * ldv); fillk<<<4096, 256>>>(W, n * ldw); fillk<<<64, 256>>>(C, 656 * 128);
   GCGE_HIP_CHECK(hipDeviceSynchronize());
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int wpc : {4, 8}) {   // waves per CU: 1 or 2 per SIMD
+    const int iters = 20000; const int blocks = 256 * wpc / 4 * 4;   // several blocks per CU
+    mfma_peak<<<blocks, 256>>>(G, 100, 0.37); hipDeviceSynchronize();
+    hipEventRecord(e0); mfma_peak<<<blocks, 256>>>(G, iters, 0.37); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("mfma f64 16x16x4 register-only: %d blocks x 4 waves, %.2f ms -> %.1f TF\n", blocks, ms, 2048.0 * 16 * iters * blocks * 4 / ms * 1e-9);
+  }
   int gk[] = {256, 192, 128, 64, 64}, gm[] = {64, 64, 64, 64, 1};
   for (int ms = 1; ms <= 4; ms *= 2)
   for (int i = 0; i < 5; ++i) {
