@@ -38,6 +38,20 @@ def csr_to_scipy(A):
     return sp.csr_matrix((va, ci, rp), shape=(n, A.ncols))
 
 
+def csr_from_scipy(S):
+    """scipy sparse matrix -> (CSR struct, keepalive arrays) with ascending column indices inside every row."""
+    import ctypes as C
+    from gcge_amd.lib import CSR
+    S = S.tocsr()
+    S.sort_indices()
+    rp = np.ascontiguousarray(S.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(S.indices, dtype=np.int32)
+    va = np.ascontiguousarray(S.data, dtype=np.float64)
+    A = CSR(S.shape[0], S.shape[1], 0, int(S.nnz), rp.ctypes.data_as(C.POINTER(C.c_int)),
+            ci.ctypes.data_as(C.POINTER(C.c_int)), va.ctypes.data_as(C.POINTER(C.c_double)))
+    return A, (rp, ci, va)
+
+
 class OracleBackend:
     """CPU oracle with the interface of gcge_amd.hip_backend.HipBackendImpl."""
 

@@ -118,6 +118,35 @@ def test_spmm_pattern_path_vs_generic_and_oracle(both, kind, size, expect, chain
             hip.g.gcge_hip_spmm_chain_tune(8)
 
 
+@pytest.mark.parametrize("n,offs", [(1000, (-64, -8, -1, 0, 1, 8, 64)),       # incomplete last "plane" and "line"
+                                    (4096 + 37, (-256, -16, -1, 0, 1, 16, 256)),
+                                    (777, (-96, -32, 0, 32, 96)),                 # no +-1 neighbours, 5 slots
+                                    (2048, (-128, -64, -8, 0, 8, 64, 128))])      # two long offsets
+def test_spmm_pattern_kernels_on_banded_toeplitz(hip, n, offs):
+    """Banded Toeplitz matrices of awkward sizes through the pattern kernels (chain / chain2 where the offsets
+    qualify): rows near both ends lose entries, the last tile is ragged.  Checker: scipy on the host."""
+    import scipy.sparse as sp
+    from helpers import csr_from_scipy
+    vals = [0.5 + 0.25 * abs(o) ** 0.5 * (1 if o >= 0 else -0.5) for o in offs]
+    S = sp.diags(vals, offs, shape=(n, n), format="csr")
+    S = (S + S.T) * 0.5 + sp.eye(n) * 3.0           # symmetric, as the back-end's contract wants
+    A, keep = csr_from_scipy(S)
+    mh = hip.matrix(A)
+    hip.g.gcge_hip_mat_patterns.argtypes = [C.c_void_p]
+    assert hip.g.gcge_hip_mat_patterns(mh) > 0
+    X = uniform(31, (n, 40)) - 0.5
+    xh = hip.mv_from_numpy(mh, X)
+    for m, s0, s1 in [(32, 0, 0), (16, 8, 2), (6, 2, 4), (40, 0, 0)]:
+        for path in (0, 2):
+            hip.g.gcge_hip_set_spmm_path(path)
+            yh = hip.mv_from_numpy(mh, uniform(32, (n, 48)))
+            hip.ops.spmm(mh, xh, yh, (s0, s1), (s0 + m, s1 + m))
+            got = hip.mv_to_numpy(yh, n, s1, s1 + m)
+            _close(got, S @ X[:, s0:s0 + m], tol=1e-13, what="toeplitz n=%d path %d m=%d" % (n, path, m))
+    hip.g.gcge_hip_set_spmm_path(0)
+    hip.free_matrix(mh)
+
+
 def test_gram_and_dots_vs_oracle(both):
     hip, ora = both
     A, mh, mo = _pair_mats(both, "lap3d", 13)
