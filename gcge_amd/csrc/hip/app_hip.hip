@@ -26,6 +26,7 @@ int gcge_hip_pad8_spmm_dot(int nrows, const int* d_orp, const int* d_pcol, const
                            long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream);
 int gcge_hip_sell8_spmm(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval, const double* d_x, long ldx,
                         double* d_y, long ldy, int ncols, void* stream);
+void gcge_hip_spmm_pad8_auto(double avg_octets_per_row);
 int gcge_hip_pattern_width(int max_row_len);
 int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2, const double* d_x, long ldx,
                           double* d_y, long ldy, int ncols, double* d_dots, double* d_dots_yy, void* stream);
@@ -669,7 +670,7 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
     rc = gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, dx, vx->ld, dy, vy->ld, m, nullptr, nullptr, g_stream);
   if (rc != -1) {}
   else if (m >= 16 && g_spmm_path == 1) rc = gcge_hip_sell8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
-  else if (m >= 16) rc = gcge_hip_pad8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
+  else if (m >= 16) { gcge_hip_spmm_pad8_auto(A->nrows > 0 ? (double)A->noct / A->nrows : 1.0); rc = gcge_hip_pad8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream); }
   if (rc == -1) rc = gcge_hip_csr_spmm(A->nrows, A->d_rowptr, A->d_colidx, A->d_val, dx, vx->ld, dy, vy->ld, m, g_stream);
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "MatDotMultiVec: kernel launch");
@@ -693,7 +694,10 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
   const bool aligned = A != nullptr && (m % 2 == 0) && (vx->ld % 2 == 0) && (vy->ld % 2 == 0) &&
                        (((uintptr_t)(vx->d + start[0]) & 15) == 0) && (((uintptr_t)(vy->d + start[1]) & 15) == 0);
   const bool use_pat = aligned && A->d_pid != nullptr && g_spmm_path == 0;
-  const bool fast = aligned && (use_pat || (m >= 16 && m <= 128));
+  // generic matrices with long rows (>= 2.5 octets on average): the plain pad-8 kernel with one or two rows per wave
+  // plus separate column dots beats the fused kernel (SiO2-like, 36 nnz/row: 6.8 + 1.5 ms against 11 ms)
+  const bool long_rows = A != nullptr && A->nrows > 0 && (double)A->noct / A->nrows >= 2.5;
+  const bool fast = aligned && (use_pat || (m >= 16 && m <= 128 && !long_rows));
   if (!fast) {
     HIP_MatDotMultiVec(mat, x, y, start, end, ops);
     ops->MultiVecLocalInnerProd('D', x, y, 0, start, end, host_dots, 1, ops);
@@ -719,8 +723,8 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
   int rc = use_pat
       ? gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, vx->d + start[0], vx->ld, vy->d + start[1],
                               vy->ld, m, dd, dyy, g_stream)
-      : gcge_hip_pad8_spmm_dot(A->nrows, A->d_orp, A->d_pcol, A->d_pval, vx->d + start[0], vx->ld,
-                               vy->d + start[1], vy->ld, m, dd, g_stream);
+      : (gcge_hip_pad8_spmm_dot(A->nrows, A->d_orp, A->d_pcol, A->d_pval, vx->d + start[0], vx->ld,
+                               vy->d + start[1], vy->ld, m, dd, g_stream));
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "spmm_dot: kernel launch");
   if (dyy && !use_pat)   // generic kernels: one more read of y

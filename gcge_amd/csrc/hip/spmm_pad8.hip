@@ -186,8 +186,17 @@ __global__ __launch_bounds__(256) void spmm_pad8_kernel(
 
 using namespace gcge;
 
-static int g_p8_rpw = 8, g_p8_batch = 8, g_p8_store = 1, g_p8_pass = 0;
+static int g_p8_rpw = 8, g_p8_batch = 8, g_p8_store = 1, g_p8_pass = 0, g_p8_user = 0;
+// rows per wave from the average row length (in octets of 8 padded non-zeros), unless a caller has tuned by hand.
+// Measured on the SiO2-like matrix (36 nnz/row, n = 5e6, 64 columns; profiles/r01_spmm_explore/26, 27):
+// rows per wave 8 / 4 / 2 / 1 = 9.87 / 8.33 / 6.95 / 6.81 ms — long rows keep a wave busy on their own, and fewer
+// rows per wave means fewer distinct X rows competing for the L1; on the 7-point stencil (1 octet per row) 8 is best.
+extern "C" void gcge_hip_spmm_pad8_auto(double avg_octets_per_row) {
+  if (g_p8_user) return;
+  g_p8_rpw = avg_octets_per_row >= 4.0 ? 1 : (avg_octets_per_row >= 2.5 ? 2 : (avg_octets_per_row >= 1.5 ? 4 : 8));
+}
 extern "C" void gcge_hip_spmm_pad8_tune(int rows_per_wave, int batch, int store_policy, int col_pass) {
+  g_p8_user = 1;
   if (rows_per_wave >= 1 && rows_per_wave <= 64) g_p8_rpw = rows_per_wave;
   if (batch == 4 || batch == 8 || batch == 16) g_p8_batch = batch;
   if (store_policy >= 0 && store_policy <= 2) g_p8_store = store_policy;
@@ -218,9 +227,10 @@ static void p8_launch(int nrows, const int* orp, const int* pcol, const double* 
 template <int LPR>
 static void p8_launch_dot(int nrows, const int* orp, const int* pcol, const double* pval, const double* x,
                           size_t ldx, double* y, size_t ldy, int m, double* partial, long grid, hipStream_t st) {
-  const long nchunks = ((long)nrows + 15) / 16;
+  const int rpw = 4;   // the kernel keeps the wave's own X rows in 4 register pairs; fewer rows per wave do not pay here
+  const long nchunks = ((long)nrows + 4 * rpw - 1) / (4 * rpw);
   hipLaunchKernelGGL((spmm_pad8_kernel<LPR, 4, 1, 1>), dim3((unsigned)grid), dim3(256), 0, st, nrows, orp, pcol,
-                     pval, x, ldx, y, ldy, m, 4, nchunks, partial, (const int*)nullptr, 0);
+                     pval, x, ldx, y, ldy, m, rpw, nchunks, partial, (const int*)nullptr, 0);
 }
 template <int LPR, int BATCH>
 static void p8_store(int nrows, const int* orp, const int* pcol, const double* pval,
@@ -251,7 +261,8 @@ extern "C" int gcge_hip_pad8_spmm_dot(int nrows, const int* d_orp, const int* d_
   if (nrows <= 0 || ncols <= 0) return 0;
   if (ncols > 128 || (ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15)) return -1;
   hipStream_t st = (hipStream_t)stream;
-  const long nchunks = ((long)nrows + 15) / 16;
+  const int rpw = 4;
+  const long nchunks = ((long)nrows + 4 * rpw - 1) / (4 * rpw);
   const long grid = nchunks < 8192 ? nchunks : 8192;
   double* part = gcge_hip_partial_ws((size_t)grid * ncols);
   if (ncols > 64) p8_launch_dot<64>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st);

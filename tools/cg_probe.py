@@ -5,14 +5,17 @@ import numpy as np
 import torch  # noqa
 from gcge_amd import HipBackend, make_problem
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+kind = sys.argv[2] if len(sys.argv) > 2 else "lap3d"
 hip = HipBackend()
 hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
-A, _ = make_problem("lap3d", N)
+A, _ = make_problem(kind, N, K=60, R0=1.5, R1=2.0, seed=12345)
 mA = hip.matrix(A)
 hip.set_random_mode(1, 7)
 ops = hip.ops
 V = ops.mv_create(256, mA)
 ops.set_random(V, 0, 256)
+if os.environ.get('PAD8'):
+    hip.g.gcge_hip_spmm_pad8_tune(*[int(t) for t in os.environ['PAD8'].split(',')])
 if os.environ.get('CHAIN2_NW') is not None:
     hip.g.gcge_hip_spmm_chain2_tune(int(os.environ['CHAIN2_NW']))
 if os.environ.get('CHAIN_LPR'):

@@ -29,6 +29,8 @@ if os.environ.get('CHAIN2_NW') is not None:
     g.gcge_hip_spmm_chain2_tune(int(os.environ['CHAIN2_NW']))
 if os.environ.get('CHAIN2_XCD') is not None:
     g.gcge_hip_spmm_chain2_xcd(int(os.environ['CHAIN2_XCD']))
+if os.environ.get('PAD8'):
+    g.gcge_hip_spmm_pad8_tune(*[int(t) for t in os.environ['PAD8'].split(',')])
 if os.environ.get('CHAIN_LPR'):
     g.gcge_hip_spmm_chain_tune(int(os.environ['CHAIN_LPR']))
 if os.environ.get('PAT_GRID'):
