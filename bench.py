@@ -128,8 +128,14 @@ def main():
     # memory set-up, like the matrix upload: hipMalloc of the 17-34 GB work blocks costs 0.2-0.3 s each on a fresh
     # process, so the blocks one solve needs (V, eigenvectors, 3 work blocks, 3 CG blocks) are allocated once here and
     # handed back to the back-end's size-keyed pool, from which the solver's MultiVecCreateByMat calls take them
-    warm = [hip.ops.mv_create(c, mat) for c in [args.nevmax + 2 * args.block, args.nevmax] + [args.block] * 6]
-    for c, w in zip([args.nevmax + 2 * args.block, args.nevmax] + [args.block] * 6, warm):
+    cols = [args.nevmax + 2 * args.block, args.nevmax] + [args.block] * 6
+    # + the direction ring of the fused CG (up to 15 more blocks of `block` columns, as memory allows: block_pcg.hip)
+    free_b, _ = torch.cuda.mem_get_info()
+    per_col = 8 * (A.nrows + 2 * dims[0] * dims[1] * (world > 1)) * 1.02
+    spare = free_b - per_col * sum(cols) - (14 << 30)
+    cols += [args.block] * max(0, min(15, int(spare // (per_col * max(64, args.block)))))
+    warm = [hip.ops.mv_create(c, mat) for c in cols]
+    for c, w in zip(cols, warm):
         hip.ops.mv_destroy(w, c)
     hip.sync()
     hip.set_random_mode(1, 20240601)          # device generator: 2e9 rand() calls would dominate at this n

@@ -409,6 +409,8 @@ extern "C" void gcge_hip_pool_release(void) {
   g_pool.clear(); g_pool_bytes = 0;
 }
 extern "C" void gcge_hip_pool_enable(int on) { g_pool_on = on; if (!on) gcge_hip_pool_release(); }
+// bytes the pool holds at the moment (free for MultiVecCreate*, but "used" in hipMemGetInfo)
+extern "C" size_t gcge_hip_pool_cached_bytes(void) { return g_pool_bytes; }
 static void* pool_alloc(size_t bytes) {
   auto it = g_pool.find(bytes);
   if (it != g_pool.end() && !it->second.empty()) {

@@ -10,7 +10,9 @@
 //                                                          (cg_update_all: 4 reads + 3 writes)
 // with beta_j = rho_pred_j / rho_j, rho_pred = alpha^2 wTw - rho (what r_new . r_new is in exact arithmetic for CG
 // directions); the measured rho_j of the sweep drives the next alpha and the stopping test.  7 block streams + the
-// SpMM instead of the 13 + SpMM of the unfused recurrence.  The older two-sweep form (GCGE_CG_TWO_PASS=1, also
+// SpMM instead of the 13 + SpMM of the unfused recurrence.  When memory allows, the x update is taken out of the
+// sweep as well: the directions go into a ring of up to 16 blocks (cg_update_rp: 3 reads + 2 writes) and x is
+// brought up to date every 15 iterations (cg_accum_x): 6.1 block streams per iteration.  The older two-sweep form (GCGE_CG_TWO_PASS=1, also
 // the fallback when a block cannot be walked with 16-byte lanes) needs no prediction:
 //     x += alpha'_j p ; p = r + beta_j p       (cg_update_xp: the x update of the PREVIOUS step is
 //                                               deferred into this pass: 3 reads + 2 writes)
@@ -271,6 +273,83 @@ __global__ __launch_bounds__(256) void cg_update_all(long nrows, const double* _
     partial[(long)blockIdx.x * m + j + 1] = s1;
   }
 }
+
+// ---- p-ring variant of the one-pass step ------------------------------------------------------------------------
+// x is only needed when the solve ends, but x += alpha p costs a read and a write of a whole block in every
+// iteration (2 of the 7 streams).  With memory to spare the directions are kept instead: iteration k reads p_k from
+// ring slot k and writes p_{k+1} to slot k+1 (5 streams: w, r, p_k in; r, p_{k+1} out), and every J iterations one
+// sweep adds the J pending terms to x (J + 2 streams).  J = 15: 6.1 streams per iteration instead of 7.
+template <int UNR>
+__global__ __launch_bounds__(256) void cg_update_rp(long nrows, const double* __restrict__ w, long ldw,
+    double* __restrict__ r, long ldr, const double* __restrict__ pold, double* __restrict__ pnew, long ldp, int m,
+    const double* __restrict__ alpha, const double* __restrict__ beta, const int* __restrict__ flag,
+    double* __restrict__ partial, int tpr) {
+  __shared__ double red[256][2];
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr, rpb = 256 / tpr;
+  const int j = 2 * tx;
+  double s0 = 0.0, s1 = 0.0;
+  const bool mine = j < m;
+  const int f0 = mine ? flag[j] : 0, f1 = mine ? flag[j + 1] : 0;
+  if (mine) {   // retired columns are still COPIED to the next slot (alpha = 0, cr = 0, cb = 1): the ring must stay complete
+    const double a0 = f0 ? alpha[j] : 0.0, a1 = f1 ? alpha[j + 1] : 0.0;
+    const double cr0 = f0 ? 1.0 : 0.0, cr1 = f1 ? 1.0 : 0.0;
+    const double cb0 = f0 ? beta[j] : 1.0, cb1 = f1 ? beta[j + 1] : 1.0;
+    const long step = rpb, group = (long)rpb * UNR;
+    const long slab = (((nrows + gridDim.x - 1) / gridDim.x) + group - 1) / group * group;
+    const long rend = min(nrows, ((long)blockIdx.x + 1) * slab);
+    auto one = [&](long rr, v2d wv, v2d rv, v2d pv) {
+      v2d rn = {fma(-a0, wv.x, rv.x), fma(-a1, wv.y, rv.y)};
+      v2d pn = {fma(cb0, pv.x, cr0 * rn.x), fma(cb1, pv.y, cr1 * rn.y)};
+      __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(r + rr * ldr + j));
+      __builtin_nontemporal_store(pn, reinterpret_cast<v2d*>(pnew + rr * ldp + j));
+      s0 = fma(cr0 * rn.x, rn.x, s0); s1 = fma(cr1 * rn.y, rn.y, s1);
+    };
+    long row = (long)blockIdx.x * slab + ty;
+    for (; row + (UNR - 1) * step < rend; row += step * UNR) {
+      v2d wv[UNR], rv[UNR], pv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long rr = row + u * step;
+        wv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(w + rr * ldw + j));
+        rv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(r + rr * ldr + j));
+        pv[u] = *reinterpret_cast<const v2d*>(pold + rr * ldp + j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) one(row + u * step, wv[u], rv[u], pv[u]);
+    }
+    for (; row < rend; row += step)
+      one(row, *reinterpret_cast<const v2d*>(w + row * ldw + j), *reinterpret_cast<const v2d*>(r + row * ldr + j),
+          *reinterpret_cast<const v2d*>(pold + row * ldp + j));
+  }
+  red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1;
+  __syncthreads();
+  if (ty == 0 && mine) {
+    for (int q = 1; q < rpb; ++q) { s0 += red[q * tpr + tx][0]; s1 += red[q * tpr + tx][1]; }
+    partial[(long)blockIdx.x * m + j] = s0;
+    partial[(long)blockIdx.x * m + j + 1] = s1;
+  }
+}
+
+struct RingPtrs { const double* p[16]; };
+// x[:, j] += sum_{q < cnt} coef[q * m + j] * ring[q][:, j]      (cnt <= 16)
+__global__ __launch_bounds__(256) void cg_accum_x(long nrows, RingPtrs ring, int cnt, long ldp, double* __restrict__ x,
+    long ldx, int m, const double* __restrict__ coef, int tpr) {
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr, rpb = 256 / tpr;
+  const int j = 2 * tx;
+  if (j >= m) return;
+  const long slab = (((nrows + gridDim.x - 1) / gridDim.x) + rpb - 1) / rpb * rpb;
+  const long rend = min(nrows, ((long)blockIdx.x + 1) * slab);
+  for (long row = (long)blockIdx.x * slab + ty; row < rend; row += rpb) {
+    v2d xv = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(x + row * ldx + j));
+#pragma unroll 4
+    for (int q = 0; q < cnt; ++q) {
+      const v2d pv = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(ring.p[q] + row * ldp + j));
+      xv.x = fma(coef[q * m + j], pv.x, xv.x); xv.y = fma(coef[q * m + j + 1], pv.y, xv.y);
+    }
+    __builtin_nontemporal_store(xv, reinterpret_cast<v2d*>(x + row * ldx + j));
+  }
+}
 }  // namespace gcge
 
 using namespace gcge;
@@ -303,12 +382,13 @@ static void launch_update_xp(long n, const double* r, long ldr, double* p, long 
 struct HipBpcg {
   int max_iter; double rate, tol; char tol_type[8];
   void** mv_ws[4];       // r, p, w (+ B p scratch when a shift with B != NULL is active), created lazily
+  void** ring[17]; int ring_len;   // p-ring of the one-pass scheme (ring[0] aliases mv_ws[1])
   int ws_cols, ws_rows;
   int niter; double residual;
   long spmm_calls, spmm_cols;   // statistics for bench.py
   double* d_coef; int* d_flag; double* h_pin; int cap;
 };
-static HipBpcg g_bpcg = {30, 1e-2, 1e-14, "abs", {nullptr, nullptr, nullptr, nullptr}, 0, 0, 0, -1.0, 0, 0, nullptr, nullptr, nullptr, 0};
+static HipBpcg g_bpcg = {30, 1e-2, 1e-14, "abs", {nullptr, nullptr, nullptr, nullptr}, {nullptr}, 0, 0, 0, 0, -1.0, 0, 0, nullptr, nullptr, nullptr, 0};
 
 static void reduce_over_ranks(double* v, int n) {
   GCGE_COMM* c = GCGE_GetComm();
@@ -324,6 +404,8 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
   const int n = gcge_hip_mv_nrows(mv_x);
   if (gcge_hip_mv_nrows(mv_b) != n) { fprintf(stderr, "HIP_BlockPCG: b and x have different row counts\n"); abort(); }
   if (s->ws_cols < nrhs || s->ws_rows != n) {   // (re)create r, p, w for this problem shape
+    for (int i = 1; i < s->ring_len; ++i) if (s->ring[i]) ops->MultiVecDestroy(&s->ring[i], s->ws_cols, ops);
+    s->ring_len = 0;
     for (int i = 0; i < 4; ++i) {
       if (s->mv_ws[i]) ops->MultiVecDestroy(&s->mv_ws[i], s->ws_cols, ops);
       if (i < 3) ops->MultiVecCreateByMultiVec(&s->mv_ws[i], nrhs, mv_x, ops);
@@ -415,17 +497,52 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
   static const bool two_pass = getenv("GCGE_CG_TWO_PASS") != nullptr;
   if (!two_pass && nrhs <= 512 && cg_vec_ok(nrhs, {dw, dr, dp, dx}, {ldw, ldr, ldp, ldx})) {
     std::vector<double> wTw(nrhs), bet(nrhs);
+    // p-ring (see cg_update_rp): as many slots as memory allows, at most 16; fewer than 4 pending terms do not pay
+    static const int ring_max = getenv("GCGE_CG_RING") ? atoi(getenv("GCGE_CG_RING")) : 16;
+    if (s->ring_len == 0 && s->max_iter >= 8 && ring_max >= 5) {
+      size_t fr = 0, tot = 0;
+      GCGE_HIP_CHECK(hipMemGetInfo(&fr, &tot));
+      fr += gcge_hip_pool_cached_bytes();   // blocks parked in the back-end's pool are available to MultiVecCreate*
+      const size_t slot = (size_t)gcge_hip_mv_nrows(s->mv_ws[1]) * (size_t)ldp * sizeof(double) + ((size_t)64 << 20);
+      const size_t keep = (size_t)12 << 30;   // leave room for staging, partial sums and the caller
+      long want = fr > keep ? (long)((fr - keep) / slot) : 0;
+      if (want > ring_max - 1) want = ring_max - 1;
+      if (want > s->max_iter) want = s->max_iter;
+      s->ring[0] = s->mv_ws[1]; s->ring_len = 1;
+      if (want >= 4)
+        for (long i = 0; i < want; ++i) { ops->MultiVecCreateByMultiVec(&s->ring[s->ring_len], s->ws_cols, mv_x, ops); ++s->ring_len; }
+    }
+    const int R = s->ring_len >= 5 ? s->ring_len : 1;        // ring slots; 1: x is updated in every iteration
+    const int J = R - 1;                                     // pending directions before x is brought up to date
+    std::vector<double> ahist((size_t)(J > 0 ? J : 1) * nrhs, 0.0);
+    int npend = 0, first_slot = 0, cur = 0;                  // p_k lives in ring[cur]; pending: slots first_slot .. (npend of them)
+    double* d_ahist = nullptr;
+    auto flush_x = [&]() {
+      if (npend == 0) return;
+      RingPtrs rp;
+      for (int q = 0; q < 16; ++q) { long ldq; rp.p[q] = gcge_hip_mv_device_ptr(s->ring[(first_slot + (q < npend ? q : 0)) % R], &ldq); }
+      d_ahist = gcge_hip_partial_ws((size_t)J * nrhs);
+      GCGE_HIP_CHECK(hipMemcpyAsync(d_ahist, ahist.data(), (size_t)npend * nrhs * sizeof(double), hipMemcpyHostToDevice, st));
+      const int tpr = cg_tpr(nrhs);
+      long g = ((long)n + (256 / tpr) * 8 - 1) / ((256 / tpr) * 8); if (g > 8192) g = 8192; if (g < 1) g = 1;
+      hipLaunchKernelGGL(cg_accum_x, dim3((unsigned)g), dim3(256), 0, st, (long)n, rp, npend, ldp, dx, ldx, nrhs, d_ahist, tpr);
+      GCGE_HIP_CHECK(hipStreamSynchronize(st));   // ahist (pageable) and the partial workspace are reused right away
+      first_slot = (first_slot + npend) % R; npend = 0;
+    };
     if (nact > 0) {   // p0 = r0
       st2[0] = 0; en2[0] = nrhs; st2[1] = 0; en2[1] = nrhs;
-      ops->MultiVecAxpby(1.0, s->mv_ws[0], 0.0, s->mv_ws[1], st2, en2, ops);
+      ops->MultiVecAxpby(1.0, s->mv_ws[0], 0.0, s->ring_len ? s->ring[0] : s->mv_ws[1], st2, en2, ops);
     }
     while (niter < s->max_iter && nact > 0) {
       int alo = 0, ahi = nrhs;
-      while (alo < nrhs && !active[alo]) ++alo;
-      while (ahi > alo && !active[ahi - 1]) --ahi;
+      if (R == 1) {   // (with a ring every column takes part in every step: the slots must stay complete)
+        while (alo < nrhs && !active[alo]) ++alo;
+        while (ahi > alo && !active[ahi - 1]) --ahi;
+      }
       int aw = ahi - alo;
       if (((alo & 1) || (aw & 1))) { alo &= ~1; ahi = (ahi + 1) & ~1; aw = ahi - alo; }   // keep 16-byte column pairs
-      apply(s->mv_ws[1], alo, s->mv_ws[2], alo, aw, pTw.data() + alo, wTw.data() + alo);
+      void** pcur = R > 1 ? s->ring[cur] : s->mv_ws[1];
+      apply(pcur, alo, s->mv_ws[2], alo, aw, pTw.data() + alo, wTw.data() + alo);
       s->spmm_calls++; s->spmm_cols += aw;
       {   // one all-reduce for both sums
         std::vector<double> both(2 * (size_t)aw);
@@ -442,12 +559,22 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
         coef[j] = al; bet[j] = rho_pred / rho2[j];
       }
       upload(alo, aw, bet.data(), coef.data(), flag.data());   // d_coef = [beta | alpha]
-      double* part = gcge_hip_partial_ws((size_t)nb * aw + aw);
-      static const int a_unr = getenv("GCGE_CG_AUNR") ? atoi(getenv("GCGE_CG_AUNR")) : 4;   // tuning hook
+      double* part = gcge_hip_partial_ws((size_t)nb * aw + aw + (size_t)(J > 0 ? J : 0) * nrhs);
+      if (R > 1) {
+        long ldq;
+        const double* pold = gcge_hip_mv_device_ptr(s->ring[cur], &ldq);
+        double* pnew = gcge_hip_mv_device_ptr(s->ring[(cur + 1) % R], &ldq);
+        hipLaunchKernelGGL(cg_update_rp<4>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr,
+                           pold + alo, pnew + alo, ldp, aw, s->d_coef + s->cap, s->d_coef, s->d_flag, part, cg_tpr(aw));
+        for (int j = 0; j < nrhs; ++j) ahist[(size_t)npend * nrhs + j] = (j >= alo && j < ahi && active[j]) ? coef[j] : 0.0;
+        ++npend; cur = (cur + 1) % R;
+      } else {
+        static const int a_unr = getenv("GCGE_CG_AUNR") ? atoi(getenv("GCGE_CG_AUNR")) : 4;   // tuning hook
 #define GCGE_UA(U) hipLaunchKernelGGL(cg_update_all<U>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr, \
                                       dp + alo, ldp, dx + alo, ldx, aw, s->d_coef + s->cap, s->d_coef, s->d_flag, part, cg_tpr(aw))
-      if (a_unr == 2) GCGE_UA(2); else if (a_unr == 3) GCGE_UA(3); else if (a_unr == 6) GCGE_UA(6); else GCGE_UA(4);
+        if (a_unr == 2) GCGE_UA(2); else if (a_unr == 3) GCGE_UA(3); else if (a_unr == 6) GCGE_UA(6); else GCGE_UA(4);
 #undef GCGE_UA
+      }
       gcge_hip_reduce_partials(part, (int)nb, aw, part + (size_t)nb * aw, st);
       GCGE_HIP_CHECK(hipMemcpyAsync(s->h_pin, part + (size_t)nb * aw, aw * sizeof(double), hipMemcpyDeviceToHost, st));
       GCGE_HIP_CHECK(hipStreamSynchronize(st));
@@ -462,7 +589,9 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
         nact += active[j];
       }
       ++niter;
+      if (npend == J && J > 0) flush_x();
     }
+    flush_x();
     s->niter = niter;
     s->residual = last_res[0];
     return;
@@ -560,6 +689,8 @@ extern "C" void gcge_hip_bpcg_stats(long* spmm_calls, long* spmm_cols, int* last
   if (last_niter) *last_niter = g_bpcg.niter;
 }
 extern "C" void gcge_hip_bpcg_release(struct OPS_* ops) {
+  for (int i = 1; i < g_bpcg.ring_len; ++i) if (g_bpcg.ring[i]) ops->MultiVecDestroy(&g_bpcg.ring[i], g_bpcg.ws_cols, ops);
+  g_bpcg.ring_len = 0;
   for (int i = 0; i < 4; ++i)
     if (g_bpcg.mv_ws[i]) ops->MultiVecDestroy(&g_bpcg.mv_ws[i], g_bpcg.ws_cols, ops);
   g_bpcg.ws_cols = 0; g_bpcg.ws_rows = 0;

@@ -14,6 +14,7 @@
 #ifndef GCGE_HIP_H
 #define GCGE_HIP_H
 
+#include <stddef.h>
 #include "gcge_ops.h"
 #include "gcge_problems.h"
 
@@ -96,6 +97,7 @@ int gcge_hip_sell8_spmm (int nrows, const int *d_orp, const int *d_pcol, const d
  *     blocks cost ~0.3 s each); release returns them to the driver, enable(0) switches the cache off            */
 void gcge_hip_pool_release (void);
 void gcge_hip_pool_enable (int on);
+size_t gcge_hip_pool_cached_bytes (void);
 void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > pad-8 > CSR), 1 SELL-8 passes, 2 generic kernels only */
 /*     pattern path (csrc/hip/spmm_pattern.hip): matrices whose rows repeat a few stencils {(col - row, value)} are
  *     additionally kept as 16-bit pattern ids + a table of npat * lt {double value; long offset} entries (span, span2 =
