@@ -51,6 +51,9 @@ struct GCGE_HIP_MAT_ {
   int nsend; int* d_send_rows;                 // local rows other ranks need, grouped by destination rank
   double *sendbuf, *recvbuf; int buf_cols;     // exchange buffers (owned by the caller: torch tensors)
   gcge_halo_exchange_fn exchange; void* exchange_ctx;
+  // optional split exchange (begin posts the transfers and returns, end completes them) and the rows that do not
+  // touch a halo column, [ov_lo, ov_hi): lets the interior product run while the halo is in flight
+  gcge_halo_exchange_fn exchange_begin; void (*exchange_end)(void*); int ov_lo, ov_hi;
 };
 
 __global__ __launch_bounds__(256) void halo_pack(int nsend, const int* __restrict__ rows, const double* __restrict__ x,
@@ -103,6 +106,15 @@ static double* stage_d(size_t len) {
     GCGE_HIP_CHECK(hipMalloc(&g_stage_d, g_stage_d_len * sizeof(double)));
   }
   return g_stage_d;
+}
+static double* g_stage_d2 = nullptr; static size_t g_stage_d2_len = 0;   // second device staging (split products)
+static double* stage_d2(size_t len) {
+  if (len > g_stage_d2_len) {
+    if (g_stage_d2) GCGE_HIP_CHECK(hipFree(g_stage_d2));
+    g_stage_d2_len = len * 2 + 1024;
+    GCGE_HIP_CHECK(hipMalloc(&g_stage_d2, g_stage_d2_len * sizeof(double)));
+  }
+  return g_stage_d2;
 }
 static double* stage_h(size_t len) {
   if (len > g_stage_h_len) {
@@ -350,6 +362,16 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, i
   GCGE_HIP_CHECK(hipMemcpy(A->d_pcol, pc.data(), noct * 8 * sizeof(int), hipMemcpyHostToDevice));
   GCGE_HIP_CHECK(hipMemcpy(A->d_pval, pv.data(), noct * 8 * sizeof(double), hipMemcpyHostToDevice));
   build_patterns(A, nrows, ncols_local, rowptr, colidx, val);
+  // interior rows: none of them references a halo column (slabs: everything but the first and the last plane)
+  A->ov_lo = 0; A->ov_hi = nrows;
+  if (A->nghost > 0) {
+    for (int r = 0; r < nrows; ++r) {
+      bool g = false;
+      for (int k = rowptr[r]; k < rowptr[r + 1] && !g; ++k) g = colidx[k] >= nrows;
+      if (!g) continue;
+      if (r < nrows / 2) A->ov_lo = r + 1; else { A->ov_hi = r; break; }
+    }
+  }
   return A;
 }
 extern "C" GCGE_HIP_MAT* gcge_hip_mat_create(int nrows, int nglobal, int row_begin, const int* rowptr,
@@ -375,6 +397,11 @@ extern "C" void gcge_hip_mat_set_halo(GCGE_HIP_MAT* A, int nglobal, int nsend, c
   if (A->d_send_rows) hipFree(A->d_send_rows);
   GCGE_HIP_CHECK(hipMalloc(&A->d_send_rows, (nsend ? nsend : 1) * sizeof(int)));
   GCGE_HIP_CHECK(hipMemcpy(A->d_send_rows, send_rows, nsend * sizeof(int), hipMemcpyHostToDevice));
+}
+// optional: a split form of the exchange installed by gcge_hip_mat_set_halo — begin(sendbuf, recvbuf, ncols, ctx)
+// posts the transfers of the packed rows and returns, end(ctx) returns when recvbuf is complete
+extern "C" void gcge_hip_mat_set_halo_async(GCGE_HIP_MAT* A, gcge_halo_exchange_fn begin, void (*end)(void*)) {
+  A->exchange_begin = begin; A->exchange_end = end;
 }
 extern "C" void gcge_hip_mat_destroy(GCGE_HIP_MAT* A) {
   if (!A) return;
@@ -642,6 +669,80 @@ static void halo_fetch(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, int m) {
   }
 }
 
+
+__global__ void add3_kernel(double* __restrict__ dst, const double* __restrict__ a, const double* __restrict__ b,
+                            const double* __restrict__ c, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (a[i] + b[i]) + c[i];
+}
+
+// rows [r0, r1) of Y = A X, optionally with the column sums x.y (and y.y) over those rows (d_dots, d_yy: device, m each).
+// want_fused: the caller asked for dots and the matrix/operands qualify for a fused kernel.
+static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long ldx, double* dy, long ldy, int m,
+                     double* d_dots, double* d_yy) {
+  const int nr = (int)(r1 - r0);
+  if (nr <= 0) {
+    if (d_dots) GCGE_HIP_CHECK(hipMemsetAsync(d_dots, 0, m * sizeof(double), g_stream));
+    if (d_yy) GCGE_HIP_CHECK(hipMemsetAsync(d_yy, 0, m * sizeof(double), g_stream));
+    return 0;
+  }
+  double* y = dy + r0 * ldy;
+  int rc = -1;
+  if (A->d_pid != nullptr && g_spmm_path == 0)
+    rc = gcge_hip_pattern_spmm(nr, A->d_pid + r0, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, dx + r0 * ldx, ldx,
+                               y, ldy, m, d_dots, d_yy, g_stream);
+  if (rc != -1) return rc;
+  if (d_dots) {   // generic fused kernel (the caller checked its contract), y.y by a second pass over y
+    rc = gcge_hip_pad8_spmm_dot(nr, A->d_orp + r0, A->d_pcol, A->d_pval, dx, ldx, y, ldy, m, d_dots, g_stream);
+    if (rc == 0 && d_yy) rc = gcge_hip_coldots(nr, y, ldy, y, ldy, m, d_yy, g_stream);
+    return rc;
+  }
+  if (m >= 16 && g_spmm_path == 1) rc = gcge_hip_sell8_spmm(nr, A->d_orp + r0, A->d_pcol, A->d_pval, dx, ldx, y, ldy, m, g_stream);
+  else if (m >= 16) {
+    gcge_hip_spmm_pad8_auto(A->nrows > 0 ? (double)A->noct / A->nrows : 1.0);
+    rc = gcge_hip_pad8_spmm(nr, A->d_orp + r0, A->d_pcol, A->d_pval, dx, ldx, y, ldy, m, g_stream);
+  }
+  if (rc == -1) rc = gcge_hip_csr_spmm(nr, A->d_rowptr + r0, A->d_colidx, A->d_val, dx, ldx, y, ldy, m, g_stream);
+  return rc;
+}
+
+static int g_halo_overlap = 1;
+extern "C" void gcge_hip_set_halo_overlap(int on) { g_halo_overlap = on; }
+
+// Y[:, 0:m) = A X[:, c_begin : c_begin+m) on a row slab, halo included; d_dots / d_yy as in spmm_rows (3 m doubles of
+// scratch behind each when the product is split).  With a split exchange the interior rows are multiplied while the
+// halo rows travel, the two boundary strips follow.
+static int spmm_halo(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, double* dy, long ldy, int m, double* d_dots, double* d_yy) {
+  const double* dx = vx->d + c_begin;
+  const bool split = g_halo_overlap && A->nghost > 0 && A->exchange_begin != nullptr && A->exchange_end != nullptr &&
+                     m <= A->buf_cols && A->ov_hi - A->ov_lo >= A->nrows / 2 && getenv("GCGE_NO_HALO_OVERLAP") == nullptr;
+  if (!split) {
+    halo_fetch(A, vx, c_begin, m);
+    return spmm_rows(A, 0, A->nrows, dx, vx->ld, dy, ldy, m, d_dots, d_yy);
+  }
+  GCGE_REQUIRE(A->buf_cols > 0, "MatDotMultiVec: halo plan installed (gcge_hip_mat_set_halo)");
+  if (A->nsend > 0) {
+    long tot = (long)A->nsend * m, g = (tot + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(halo_pack, dim3((unsigned)g), dim3(256), 0, g_stream, A->nsend, A->d_send_rows, dx, vx->ld, m, A->sendbuf);
+  }
+  A->exchange_begin(A->sendbuf, A->recvbuf, m, A->exchange_ctx);
+  double* d1 = d_dots ? d_dots + m : nullptr; double* d2 = d_dots ? d_dots + 2 * m : nullptr;
+  double* y1 = d_yy ? d_yy + m : nullptr;     double* y2 = d_yy ? d_yy + 2 * m : nullptr;
+  int rc = spmm_rows(A, A->ov_lo, A->ov_hi, dx, vx->ld, dy, ldy, m, d1, y1);          // interior, overlaps the transfers
+  A->exchange_end(A->exchange_ctx);
+  {
+    long tot = (long)A->nghost * m, g = (tot + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(halo_unpack, dim3((unsigned)g), dim3(256), 0, g_stream, A->nghost, A->recvbuf, m,
+                       vx->d + (long)A->nrows * vx->ld + c_begin, vx->ld);
+  }
+  if (rc == 0) rc = spmm_rows(A, 0, A->ov_lo, dx, vx->ld, dy, ldy, m, d2, y2);         // leading boundary strip
+  double* d3 = d_dots ? stage_d2(2 * (size_t)m) : nullptr;
+  if (rc == 0) rc = spmm_rows(A, A->ov_hi, A->nrows, dx, vx->ld, dy, ldy, m, d3, d_yy ? d3 + m : nullptr);   // trailing strip
+  if (d_dots) hipLaunchKernelGGL(add3_kernel, dim3((m + 63) / 64), dim3(64), 0, g_stream, d_dots, d1, d2, d3, m);
+  if (d_yy) hipLaunchKernelGGL(add3_kernel, dim3((m + 63) / 64), dim3(64), 0, g_stream, d_yy, y1, y2, d3 + m, m);
+  return rc;
+}
+
 // app_ccs.c:50-139;  mat == NULL copies (identity B)
 static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* end, struct OPS_* ops) {
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
@@ -657,23 +758,24 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
     gcge_hip_axpby(vy->nrows, 1.0, vx->d + start[0], vx->ld, 0.0, vy->d + start[1], vy->ld, m, g_stream);
     return;
   }
-  const double* dx = vx->d + start[0];
   double* dy = vy->d + start[1];
   int rc = -1;
-  halo_fetch(A, vx, start[0], m);
   SpmmEvent ev;
-  if (g_prof_on) {
+  if (g_prof_on) {   // (on a row slab the interval also holds the halo exchange)
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
     ev.m = m;   // algorithmic bytes: values+indices once, row pointers once, X once, Y once
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
-  if (A->d_pid != nullptr && g_spmm_path == 0)
-    rc = gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, dx, vx->ld, dy, vy->ld, m, nullptr, nullptr, g_stream);
-  if (rc != -1) {}
-  else if (m >= 16 && g_spmm_path == 1) rc = gcge_hip_sell8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream);
-  else if (m >= 16) { gcge_hip_spmm_pad8_auto(A->nrows > 0 ? (double)A->noct / A->nrows : 1.0); rc = gcge_hip_pad8_spmm(A->nrows, A->d_orp, A->d_pcol, A->d_pval, dx, vx->ld, dy, vy->ld, m, g_stream); }
-  if (rc == -1) rc = gcge_hip_csr_spmm(A->nrows, A->d_rowptr, A->d_colidx, A->d_val, dx, vx->ld, dy, vy->ld, m, g_stream);
+  if (A->nghost > 0 && m > A->buf_cols) {   // wider than the exchange buffers: column chunks, one after the other
+    rc = 0;
+    for (int c0 = 0; c0 < m && rc == 0; c0 += A->buf_cols) {
+      const int mc = (m - c0 < A->buf_cols) ? m - c0 : A->buf_cols;
+      rc = spmm_halo(A, vx, start[0] + c0, dy + c0, vy->ld, mc, nullptr, nullptr);
+    }
+  } else {
+    rc = spmm_halo(A, vx, start[0], dy, vy->ld, m, nullptr, nullptr);
+  }
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "MatDotMultiVec: kernel launch");
 }
@@ -699,7 +801,7 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
   // generic matrices with long rows (>= 2.5 octets on average): the plain pad-8 kernel with one or two rows per wave
   // plus separate column dots beats the fused kernel (SiO2-like, 36 nnz/row: 6.8 + 1.5 ms against 11 ms)
   const bool long_rows = A != nullptr && A->nrows > 0 && (double)A->noct / A->nrows >= 2.5;
-  const bool fast = aligned && (use_pat || (m >= 16 && m <= 128 && !long_rows));
+  const bool fast = aligned && (use_pat || (m >= 16 && m <= 128 && !long_rows)) && (A->nghost == 0 || m <= A->buf_cols);
   if (!fast) {
     HIP_MatDotMultiVec(mat, x, y, start, end, ops);
     ops->MultiVecLocalInnerProd('D', x, y, 0, start, end, host_dots, 1, ops);
@@ -712,9 +814,9 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
   GCGE_REQUIRE(vx != vy && vx->nrows == vy->nrows && A->nrows == vy->nrows, "spmm_dot: shapes");
   GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols && start[1] >= 0 && end[1] <= vy->ncols, "spmm_dot: column ranges");
   GCGE_REQUIRE(A->nrows + A->nghost <= vx->nrows_alloc, "spmm_dot: halo rows allocated");
-  halo_fetch(A, vx, start[0], m);
-  double* dd = stage_d(2 * (size_t)m);
-  double* dyy = host_yy ? dd + m : nullptr;
+  GCGE_REQUIRE(A->nghost == 0 || m <= A->buf_cols, "spmm_dot: block wider than the halo buffers");
+  double* dd = stage_d(6 * (size_t)m);            // x.y sums (3 m: total + the strips of a split product), then y.y sums
+  double* dyy = host_yy ? dd + 3 * (size_t)m : nullptr;
   SpmmEvent ev;
   if (g_prof_on) {   // the fused kernel IS the K1 launch of a CG step (same algorithmic bytes: the dots add no HBM traffic)
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
@@ -722,17 +824,12 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
-  int rc = use_pat
-      ? gcge_hip_pattern_spmm(A->nrows, A->d_pid, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, vx->d + start[0], vx->ld, vy->d + start[1],
-                              vy->ld, m, dd, dyy, g_stream)
-      : (gcge_hip_pad8_spmm_dot(A->nrows, A->d_orp, A->d_pcol, A->d_pval, vx->d + start[0], vx->ld,
-                               vy->d + start[1], vy->ld, m, dd, g_stream));
+  int rc = spmm_halo(A, vx, start[0], vy->d + start[1], vy->ld, m, dd, dyy);
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "spmm_dot: kernel launch");
-  if (dyy && !use_pat)   // generic kernels: one more read of y
-    GCGE_REQUIRE(gcge_hip_coldots(A->nrows, vy->d + start[1], vy->ld, vy->d + start[1], vy->ld, m, dyy, g_stream) == 0, "spmm_dot: y.y");
   double* hd = stage_h(2 * (size_t)m);
-  GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, (dyy ? 2 : 1) * m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  if (dyy) GCGE_HIP_CHECK(hipMemcpyAsync(hd + m, dyy, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
   memcpy(host_dots, hd, m * sizeof(double));
   if (host_yy) memcpy(host_yy, hd + m, m * sizeof(double));

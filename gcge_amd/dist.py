@@ -23,6 +23,7 @@ class GcgeComm(C.Structure):
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int, C.c_void_p)
 EXCHANGE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_void_p)
+EXCHANGE_END_FN = C.CFUNCTYPE(None, C.c_void_p)
 
 
 def row_partition(n_global, world):
@@ -34,6 +35,23 @@ def row_partition(n_global, world):
     return part
 
 
+def _loud(fn):
+    """ctypes swallows exceptions raised inside callbacks (the C caller would carry on with stale halo rows or
+    un-reduced sums): print the traceback and take the process down instead."""
+    def wrapped(*a):
+        try:
+            return fn(*a)
+        except BaseException:      # noqa: BLE001 - nothing may escape into the C caller
+            import os
+            import sys
+            import traceback
+            traceback.print_exc()
+            sys.stderr.write("gcge_amd.dist: exception inside a communication callback - aborting\n")
+            sys.stderr.flush()
+            os._exit(70)
+    return wrapped
+
+
 class Comm:
     """Owns the torch.distributed plumbing of one rank and the ctypes callbacks built on it."""
 
@@ -42,7 +60,7 @@ class Comm:
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
         self.device = device                  # torch.device for device-resident exchange buffers, None = host
         self.stage = stage_through_host       # device buffers but a host-only transport (gloo): copy through host
-        self._allreduce_cb = ALLREDUCE_FN(self._allreduce)
+        self._allreduce_cb = ALLREDUCE_FN(_loud(self._allreduce))
         self._keep = []
         self.n_allreduce = 0
 
@@ -131,8 +149,36 @@ class Comm:
             elif not host_buffers:
                 torch.cuda.synchronize()
 
-        cb = EXCHANGE_FN(exchange)
-        self._keep += [cb, send_t, recv_t]
+        # split form for device buffers (gcge_hip_mat_set_halo_async): begin posts, end completes; the back-end multiplies
+        # the interior rows in between.  Over a host-staged transport (gloo rehearsal) begin does everything.
+        pending = []
+
+        def begin(sendbuf, recvbuf, ncols, ctx):
+            if host_buffers or self.stage:
+                exchange(sendbuf, recvbuf, ncols, ctx)
+                return
+            torch.cuda.synchronize()                      # the pack kernel ran on the back-end's stream
+            ops = []
+            for q in range(self.world):
+                if q == self.rank:
+                    continue
+                if send_cnt[q]:
+                    ops.append(self.dist.P2POp(self.dist.isend, send_t[soff[q] * ncols:soff[q + 1] * ncols], q))
+                if recv_cnt[q]:
+                    ops.append(self.dist.P2POp(self.dist.irecv, recv_t[roff[q] * ncols:roff[q + 1] * ncols], q))
+            pending[:] = self.dist.batch_isend_irecv(ops) if ops else []
+
+        def end(ctx):
+            if not pending:
+                return
+            for w in pending:
+                w.wait()                                   # torch's current stream now waits for the transfers ...
+            torch.cuda.current_stream().synchronize()      # ... and the host for that stream (not for the interior product)
+            pending[:] = []
+
+        cb = EXCHANGE_FN(_loud(exchange))
+        self._begin_cb, self._end_cb = EXCHANGE_FN(_loud(begin)), EXCHANGE_END_FN(_loud(end))
+        self._keep += [cb, self._begin_cb, self._end_cb, send_t, recv_t]
         sp = C.cast(send_t.data_ptr(), C.POINTER(C.c_double))
         rp = C.cast(recv_t.data_ptr(), C.POINTER(C.c_double))
         return cb, sp, rp
@@ -174,6 +220,8 @@ def hip_slab_matrix(hip, comm, A, n_global, part, cap_cols=128):
                                         C.POINTER(C.c_double), C.c_int, C.c_void_p, C.c_void_p]
     g.gcge_hip_mat_set_halo(mat, n_global, int(send_rows.size), send_rows.ctypes.data_as(C.POINTER(C.c_int)), sp, rp,
                             cap_cols, C.cast(cb, C.c_void_p), None)
+    g.gcge_hip_mat_set_halo_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    g.gcge_hip_mat_set_halo_async(mat, C.cast(comm._begin_cb, C.c_void_p), C.cast(comm._end_cb, C.c_void_p))
     return mat
 
 

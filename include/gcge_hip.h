@@ -49,6 +49,10 @@ GCGE_HIP_MAT *gcge_hip_mat_create_local (int nrows, int ncols_local, int nglobal
 		const int *rowptr, const int *colidx, const double *val);
 void gcge_hip_mat_set_halo (GCGE_HIP_MAT *A, int nglobal, int nsend, const int *send_rows,
 		double *sendbuf, double *recvbuf, int buf_cols, gcge_halo_exchange_fn fn, void *ctx);
+/*     optional split form of the exchange: begin posts the transfers of the packed rows and returns, end returns
+ *     when recvbuf is complete; the back-end then multiplies the rows that touch no halo column in between      */
+void gcge_hip_mat_set_halo_async (GCGE_HIP_MAT *A, gcge_halo_exchange_fn begin, void (*end) (void *ctx));
+void gcge_hip_set_halo_overlap (int on);
 void gcge_hip_mat_destroy (GCGE_HIP_MAT *A);
 int  gcge_hip_mat_nrows (const GCGE_HIP_MAT *A);
 long gcge_hip_mat_nnz (const GCGE_HIP_MAT *A);
