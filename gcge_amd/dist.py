@@ -77,6 +77,11 @@ class Comm:
             self.dist.all_reduce(t)
         self.n_allreduce += 1
 
+    def _peer(self, q):
+        """torch.distributed rank that owns partition q (identity; the single-GPU RCCL loop-back test maps every
+        partition to rank 0 so that the real transport runs against itself)."""
+        return q
+
     def install(self):
         """GCGE_SetComm: from now on inner products / CG scalars are summed over the ranks."""
         h = host_lib()
@@ -133,13 +138,11 @@ class Comm:
                 torch.cuda.synchronize()
                 s_all, r_all = send_t, recv_t
             ops = []
-            for q in range(self.world):
-                if q == self.rank:
-                    continue
+            for q in range(len(send_cnt)):          # the own rank has zero counts
                 if send_cnt[q]:
-                    ops.append(dist.P2POp(dist.isend, s_all[soff[q] * ncols:soff[q + 1] * ncols], q))
+                    ops.append(dist.P2POp(dist.isend, s_all[soff[q] * ncols:soff[q + 1] * ncols], self._peer(q)))
                 if recv_cnt[q]:
-                    ops.append(dist.P2POp(dist.irecv, r_all[roff[q] * ncols:roff[q + 1] * ncols], q))
+                    ops.append(dist.P2POp(dist.irecv, r_all[roff[q] * ncols:roff[q + 1] * ncols], self._peer(q)))
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
@@ -159,13 +162,11 @@ class Comm:
                 return
             torch.cuda.synchronize()                      # the pack kernel ran on the back-end's stream
             ops = []
-            for q in range(self.world):
-                if q == self.rank:
-                    continue
+            for q in range(len(send_cnt)):
                 if send_cnt[q]:
-                    ops.append(self.dist.P2POp(self.dist.isend, send_t[soff[q] * ncols:soff[q + 1] * ncols], q))
+                    ops.append(self.dist.P2POp(self.dist.isend, send_t[soff[q] * ncols:soff[q + 1] * ncols], self._peer(q)))
                 if recv_cnt[q]:
-                    ops.append(self.dist.P2POp(self.dist.irecv, recv_t[roff[q] * ncols:roff[q + 1] * ncols], q))
+                    ops.append(self.dist.P2POp(self.dist.irecv, recv_t[roff[q] * ncols:roff[q + 1] * ncols], self._peer(q)))
             pending[:] = self.dist.batch_isend_irecv(ops) if ops else []
 
         def end(ctx):

@@ -1,0 +1,99 @@
+"""Single-GPU rehearsal of the production transport (backend "nccl" == RCCL) — worker of
+tests/test_dist.py::test_rccl_loopback_one_gpu.
+
+Two ranks cannot share a GPU under RCCL, so the 2-rank tests run over gloo.  What they cannot see is the part of
+gcge_amd/dist.py that only exists for device buffers on the real transport: P2POps on device tensors posted from inside
+the ctypes callback, the split begin / end form with the interior rows multiplied in between, stream ordering between
+the back-end's stream and RCCL's, and the device round trip of the small all-reduce.  Here a world of ONE rank runs
+exactly that code against itself: rank 0 plays the lower slab of a 2-slab Laplacian and its "neighbour" is itself
+(RCCL allows send/recv to the own rank inside one group), so the ghost plane it receives is its own last plane.  The
+operator this defines is known in closed form: the local block with the diagonal of the last plane reduced by one.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+
+def main():
+    dims = tuple(int(t) for t in (sys.argv[1] if len(sys.argv) > 1 else "8,8,10").split(","))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from gcge_amd import HipBackend
+    from gcge_amd import dist as gdist
+    from gcge_amd.lib import CSR, host_lib, run_gcg
+    from helpers import csr_to_scipy, uniform
+    h = host_lib()
+    nx, ny, nz = dims
+    plane, n_global = nx * ny, nx * ny * nz
+    part = gdist.row_partition(n_global, 2)          # virtual world of two slabs; this process is slab 0
+    n_loc = part[1]
+    assert n_loc % plane == 0
+
+    class LoopbackComm(gdist.Comm):
+        def _peer(self, q):
+            return 0
+
+        def plan_halo(self, ghosts, part_):
+            gh = np.asarray(ghosts, dtype=np.int64)
+            assert gh.size == plane and gh[0] == n_loc, "ghosts of slab 0 = first plane of slab 1"
+            send_rows = (gh - plane).astype(np.int32)         # what slab 1 needs of slab 0: the plane below, same order
+            return np.ascontiguousarray(send_rows), [0, plane], [0, plane]
+
+    be = HipBackend(device=0)
+    comm = LoopbackComm(dist, 0, 1, device=torch.device("cuda", 0))
+    comm.install()
+    A = CSR(); h.gcge_problem_lap3d_box(nx, ny, nz, C.c_int64(0), C.c_int64(n_loc), C.byref(A))
+    S = csr_to_scipy(A).tocsr()[:, :n_loc].tolil()              # global columns -> local block
+    for r in range(n_loc - plane, n_loc):
+        S[r, r] -= 1.0                                        # ghost row (i,j,nz/2) == own row (i,j,nz/2-1), coefficient -1
+    S = S.tocsr()
+    mat = gdist.hip_slab_matrix(be, comm, A, n_global, part, cap_cols=64)
+    be.set_random_mode(1, 777)
+
+    # 1. SpMM through both forms of the exchange (single call / split with the interior rows multiplied in between)
+    m = 24
+    X = uniform(5, (n_loc, m)) - 0.5
+    Yref = S @ X
+    x = be.mv_from_numpy(mat, X)
+    y = be.ops.mv_create(m, mat)
+    be.g.gcge_hip_set_halo_overlap.argtypes = [C.c_int]
+    for overlap in (0, 1):
+        be.g.gcge_hip_set_halo_overlap(overlap)
+        for rep in range(3):          # repeated: a missing stream dependency shows as a stale ghost plane
+            Xr = X * (1.0 + rep)
+            x = be.mv_from_numpy(mat, Xr)
+            be.ops.spmm(mat, x, y, (0, 0), (m, m))
+            got = be.mv_to_numpy(y, n_loc, 0, m)
+            err = np.max(np.abs(got - (1.0 + rep) * Yref))
+            assert err < 1e-12, "loop-back SpMM (overlap=%d, rep=%d) differs: %g" % (overlap, rep, err)
+    be.g.gcge_hip_set_halo_overlap(1)
+    # 2. the small all-reduce over RCCL (world 1: identity, but through the device round trip)
+    ip = be.ops.inner_prod("N", x, x, (0, 1), (3, 5))
+    Xl = 3.0 * X
+    assert np.max(np.abs(ip - Xl[:, 0:3].T @ Xl[:, 1:5])) < 1e-10
+    # 3. whole eigensolve on the loop-back operator (fused device CG: SpMM + dots with the split exchange inside)
+    be.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    be.g.gcge_hip_bpcg_setup(be.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    ev, res = run_gcg(be.ops_handle, mat, None, ["-nevConv", 8, "-gcge_compW_orth_method", "chol"], flag=1)
+    if n_loc <= 4096:
+        exact = np.linalg.eigvalsh(S.toarray())[:res.nevConv]
+    else:
+        import scipy.sparse.linalg as sla
+        exact = np.sort(sla.eigsh(S, k=res.nevConv, sigma=0.0, which="LM", return_eigenvectors=False))
+    rel = np.max(np.abs(ev[:res.nevConv] - exact) / exact)
+    assert res.nevConv >= 8 and rel < 1e-10, (res.nevConv, res.numIter, rel, list(ev[:10]))
+    print("rccl loop-back ok: dims=%s nevConv=%d numIter=%d rel=%.2e allreduces=%d" % (dims, res.nevConv, res.numIter, rel, comm.n_allreduce))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,3 +71,15 @@ def test_row_partition_helpers():
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_hip():
     _run("hip")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", ["8,8,10", "32,32,40"])
+def test_rccl_loopback_one_gpu(dims):
+    """The production transport (backend nccl == RCCL) on device buffers, one rank exchanging its halo with itself:
+    see tests/rccl_loopback_worker.py.  The second size makes the split exchange overlap a real interior product."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_loopback_worker.py"), dims], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "rccl loop-back ok" in p.stdout, p.stdout[-3000:]
