@@ -13,7 +13,7 @@ out=sys.argv[1]; acc=collections.defaultdict(list)
 for f in glob.glob(out+'/p*/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(f)):
         k=r.get('Kernel_Name','')
-        if 'spmm' not in k: continue
+        if "spmm" not in k and "pad8" not in k: continue
         acc[(k[:48],r['Counter_Name'])].append(float(r['Counter_Value']))
 for c,v in sorted(acc.items()): print("%-50s %-30s per-launch mean=%.6g launches=%d"%(c[0],c[1],sum(v)/len(v),len(v)))
 PY

@@ -14,7 +14,8 @@ g.gcge_hip_profile_enable.argtypes = [C.c_int]
 g.gcge_hip_profile_spmm.restype = C.c_long
 g.gcge_hip_profile_spmm.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 g.gcge_hip_mat_patterns.argtypes = [C.c_void_p]
-A, B = make_problem(kind, N, K=60, R0=1.5, R1=2.0, seed=12345)
+K, R0, R1 = (float(t) for t in os.environ.get("SIO2", "60,1.5,2.0").split(","))   # SiO2-like generator: atoms, radius law
+A, B = make_problem(kind, N, K=int(K), R0=R0, R1=R1, seed=12345)
 mA = hip.matrix(A)
 print("n", A.nrows, "nnz", A.nnz, "patterns", g.gcge_hip_mat_patterns(mA))
 hip.set_random_mode(1, 7)
