@@ -10,10 +10,12 @@
 
 #include "gcge_solver.h"
 
-int GCGE_RunGCG(void *A, void *B, int flag, int argc, char *argv[], struct OPS_ *ops,
-		double *eval_out, void ***evec_out, GCGE_RunResult *res)
+/* evec_in != NULL: a block of nevMax columns owned by the caller whose first nevGiven columns are start vectors
+ * (the `nevGiven` argument of ops->EigenSolver, reference src/ops_eig_sol_gcg.c:101-158) */
+static int run_gcg(void *A, void *B, int flag, int argc, char *argv[], struct OPS_ *ops,
+		double *eval_out, void ***evec_out, GCGE_RunResult *res, void **evec_in, int nevGiven)
 {
-	int nevConv = 30, multiMax = 1, nevGiven = 0, block_size, nevMax, nevInit, i;
+	int nevConv = 30, multiMax = 1, block_size, nevMax, nevInit, i;
 	double gapMin = 1e-5, tol_gcg[2] = {1e-1, 1e-8}, *eval, *dbl_ws, t0;
 	int max_iter_gcg = 500, *int_ws, sizeV, length_dbl_ws, length_int_ws;
 	void **evec, **ws[4];
@@ -28,8 +30,11 @@ int GCGE_RunGCG(void *A, void *B, int flag, int argc, char *argv[], struct OPS_ 
 	if (nevInit > nevMax) nevInit = nevMax;
 
 	eval = (double*)calloc(nevMax, sizeof(double));
-	ops->MultiVecCreateByMat(&evec, nevMax, A, ops);
-	ops->MultiVecSetRandomValue(evec, 0, nevMax, ops);
+	if (evec_in != NULL) evec = evec_in;
+	else {
+		ops->MultiVecCreateByMat(&evec, nevMax, A, ops);
+		ops->MultiVecSetRandomValue(evec, 0, nevMax, ops);
+	}
 	ops->MultiVecCreateByMat(&ws[0], nevMax + 2 * block_size, A, ops);
 	ops->MultiVecSetRandomValue(ws[0], 0, nevMax + 2 * block_size, ops);
 	for (i = 1; i < 4; ++i) {
@@ -77,9 +82,22 @@ int GCGE_RunGCG(void *A, void *B, int flag, int argc, char *argv[], struct OPS_ 
 	ops->Printf("eigenvalues\n");
 	for (i = 0; i < nevConv; ++i) ops->Printf("%d: %6.14e\n", i + 1, eval[i]);
 	if (evec_out != NULL) *evec_out = evec;
-	else ops->MultiVecDestroy(&evec, nevMax, ops);
+	else if (evec_in == NULL) ops->MultiVecDestroy(&evec, nevMax, ops);
 	free(eval);
 	return 0;
+}
+
+int GCGE_RunGCG(void *A, void *B, int flag, int argc, char *argv[], struct OPS_ *ops,
+		double *eval_out, void ***evec_out, GCGE_RunResult *res)
+{
+	return run_gcg(A, B, flag, argc, argv, ops, eval_out, evec_out, res, NULL, 0);
+}
+
+int GCGE_RunGCGGiven(void *A, void *B, int flag, int argc, char *argv[], struct OPS_ *ops,
+		double *eval_out, void **evec, int nevGiven, GCGE_RunResult *res)
+{
+	if (evec == NULL || nevGiven < 0) return -1;
+	return run_gcg(A, B, flag, argc, argv, ops, eval_out, NULL, res, evec, nevGiven);
 }
 
 int TestEigenSolverGCG(void *A, void *B, int flag, int argc, char *argv[], struct OPS_ *ops)

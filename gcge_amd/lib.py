@@ -110,9 +110,11 @@ def make_argv(args):
     return len(args), arr
 
 
-def run_gcg(ops, matA, matB, args, flag=0, quiet=True, keep_evec=False):
+def run_gcg(ops, matA, matB, args, flag=0, quiet=True, keep_evec=False, given=None):
     """GCGE_RunGCG through the operator table `ops` (a void* OPS handle).
-    keep_evec: also return the eigenvector multivector handle (nevMax columns; the caller destroys it)."""
+    keep_evec: also return the eigenvector multivector handle (nevMax columns; the caller destroys it).
+    given = (multivector handle with nevMax columns, nevGiven): warm start from its first nevGiven columns
+    (GCGE_RunGCGGiven); the eigenvectors come back in the same block, which stays the caller's."""
     import numpy as np
     h = host_lib()
     args = ["gcge"] + [str(a) for a in args]
@@ -130,6 +132,14 @@ def run_gcg(ops, matA, matB, args, flag=0, quiet=True, keep_evec=False):
     ev = np.zeros(nev_max)
     res = RunResult()
     evec = C.c_void_p()
+    if given is not None:
+        h.GCGE_RunGCGGiven.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p]
+        rc = h.GCGE_RunGCGGiven(matA, matB, flag, argc, C.cast(argv, C.c_void_p), ops,
+                                ev.ctypes.data_as(C.c_void_p), given[0], int(given[1]), C.cast(C.byref(res), C.c_void_p))
+        if rc != 0:
+            raise RuntimeError("GCGE_RunGCGGiven rc=%d" % rc)
+        return ev, res
     rc = h.GCGE_RunGCG(matA, matB, flag, argc, argv, ops,
                        ev.ctypes.data_as(C.POINTER(C.c_double)), C.byref(evec) if keep_evec else None, C.byref(res))
     if rc != 0:

@@ -114,6 +114,11 @@ typedef struct GCGE_RunResult_ {
 } GCGE_RunResult;
 int GCGE_RunGCG (void *A, void *B, int flag, int argc, char *argv[], struct OPS_ *ops,
 		double *eval, void ***evec_out /* NULL: destroy */, GCGE_RunResult *res);
+/* Warm start: evec is a block of nevMax columns (MultiVecCreateByMat) owned by the caller whose first nevGiven
+ * columns are start vectors — the nevGiven argument of ops->EigenSolver (reference src/ops_eig_sol_gcg.c:101-158,
+ * 1253); the eigenvectors are returned in the same block. */
+int GCGE_RunGCGGiven (void *A, void *B, int flag, int argc, char *argv[], struct OPS_ *ops,
+		double *eval, void **evec, int nevGiven, GCGE_RunResult *res);
 
 #ifdef __cplusplus
 }

@@ -81,7 +81,8 @@ def make_ops(quiet=True):
 
 
 def ref_gcg(A, B, nev, nev_max=0, block=0, nev_init=0, abs_tol=1e-1, rel_tol=1e-8, max_iter=500,
-            extra=()):
+            extra=(), given=None):
+    """given: (n, nevGiven) array of start vectors (the nevGiven argument of ops->EigenSolver)."""
     r = ref_lib()
     nm = nev_max if nev_max > 0 else 2 * nev
     ev = np.zeros(nm)
@@ -89,10 +90,14 @@ def ref_gcg(A, B, nev, nev_max=0, block=0, nev_init=0, abs_tol=1e-1, rel_tol=1e-
     argv = (C.c_char_p * max(1, len(extra)))()
     for i, a in enumerate(extra):
         argv[i] = str(a).encode()
-    r.ref_gcg_solve(C.c_int(A.nrows), A.rowptr, A.colidx, A.val,
-                    B.rowptr if B is not None else None, B.colidx if B is not None else None,
-                    B.val if B is not None else None,
-                    nev, nev_max, block, nev_init, C.c_double(abs_tol), C.c_double(rel_tol), max_iter, 0,
-                    len(extra), argv, ev.ctypes.data_as(C.POINTER(C.c_double)), None,
-                    C.byref(conv), C.byref(it), C.byref(sec))
+    ng, gp = 0, None
+    if given is not None:
+        gcm = np.asfortranarray(given, dtype=np.float64)
+        ng, gp = gcm.shape[1], gcm.ctypes.data_as(C.POINTER(C.c_double))
+    r.ref_gcg_solve_given(C.c_int(A.nrows), A.rowptr, A.colidx, A.val,
+                          B.rowptr if B is not None else None, B.colidx if B is not None else None,
+                          B.val if B is not None else None,
+                          nev, nev_max, block, nev_init, C.c_double(abs_tol), C.c_double(rel_tol), max_iter, 0,
+                          len(extra), argv, ev.ctypes.data_as(C.POINTER(C.c_double)), None,
+                          C.byref(conv), C.byref(it), C.byref(sec), ng, gp)
     return ev, conv.value, it.value, sec.value

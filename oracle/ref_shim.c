@@ -60,13 +60,14 @@ void ref_use_foreign_backend(void *foreign_ops) { g_foreign_ops = (OPS*)foreign_
 void *ref_make_ccs_ops(void) { return (void*)make_ops(); }   /* reference app_ccs table, for OUR solver to drive */
 
 /* ---- eigensolver: same parameter flow as test/test_eig_sol_gcg.c:28-169 ---- */
-int ref_gcg_solve(int n, int *a_rowptr, int *a_colidx, double *a_val,
+/* given != NULL: the first nevGiven columns of the eigenvector block (column-major, n x nevGiven) are start vectors */
+int ref_gcg_solve_given(int n, int *a_rowptr, int *a_colidx, double *a_val,
 		int *b_rowptr, int *b_colidx, double *b_val,
 		int nevConv, int nevMax, int block_size, int nevInit,
 		double abs_tol, double rel_tol, int max_iter, int flag,
 		int argc, char **argv,
 		double *eval_out, double *evec_out, int *nevConv_out, int *numIter_out,
-		double *seconds_out)
+		double *seconds_out, int nevGiven, const double *given)
 {
 	OPS *ops;
 	CCSMAT A, B; void *matA, *matB = NULL;
@@ -78,7 +79,7 @@ int ref_gcg_solve(int n, int *a_rowptr, int *a_colidx, double *a_val,
 	set_ccs(&A, n, a_rowptr, a_colidx, a_val); matA = &A;
 	if (b_rowptr != NULL) { set_ccs(&B, n, b_rowptr, b_colidx, b_val); matB = &B; }
 
-	int multiMax = 1; double gapMin = 1e-5; int nevGiven = 0;
+	int multiMax = 1; double gapMin = 1e-5;
 	if (nevMax <= 0) nevMax = 2 * nevConv;
 	if (block_size <= 0) block_size = nevConv < 30 ? (nevMax - nevConv) : nevConv / 5;
 	if (nevInit <= 0 || nevInit > nevMax) nevInit = nevMax;
@@ -86,6 +87,9 @@ int ref_gcg_solve(int n, int *a_rowptr, int *a_colidx, double *a_val,
 	double *eval = calloc(nevMax, sizeof(double)); void **evec;
 	ops->MultiVecCreateByMat(&evec, nevMax, matA, ops);
 	ops->MultiVecSetRandomValue(evec, 0, nevMax, ops);
+	if (given != NULL && nevGiven > 0 && g_foreign_ops == NULL)
+		memcpy(((LAPACKVEC*)evec)->data, given, (size_t)n * nevGiven * sizeof(double));
+	else nevGiven = 0;
 	void **ws[4]; double *dbl_ws; int *int_ws;
 	ops->MultiVecCreateByMat(&ws[0], nevMax + 2 * block_size, matA, ops);
 	ops->MultiVecSetRandomValue(ws[0], 0, nevMax + 2 * block_size, ops);
@@ -138,6 +142,18 @@ int ref_gcg_solve(int n, int *a_rowptr, int *a_colidx, double *a_val,
 	free(dbl_ws); free(int_ws); free(eval);
 	if (g_foreign_ops == NULL) OPS_Destroy(&ops);
 	return 0;
+}
+int ref_gcg_solve(int n, int *a_rowptr, int *a_colidx, double *a_val,
+		int *b_rowptr, int *b_colidx, double *b_val,
+		int nevConv, int nevMax, int block_size, int nevInit,
+		double abs_tol, double rel_tol, int max_iter, int flag,
+		int argc, char **argv,
+		double *eval_out, double *evec_out, int *nevConv_out, int *numIter_out,
+		double *seconds_out)
+{
+	return ref_gcg_solve_given(n, a_rowptr, a_colidx, a_val, b_rowptr, b_colidx, b_val, nevConv, nevMax, block_size,
+			nevInit, abs_tol, rel_tol, max_iter, flag, argc, argv, eval_out, evec_out, nevConv_out, numIter_out,
+			seconds_out, 0, NULL);
 }
 
 /* ---- slot-level calls on plain column-major arrays ---- */

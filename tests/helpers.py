@@ -111,3 +111,18 @@ def lap3d_exact(N, count):
     c = 2.0 * np.cos(np.arange(1, N + 1) * np.pi / (N + 1))
     lam = (6.0 - c[:, None, None] - c[None, :, None] - c[None, None, :]).ravel()
     return np.sort(lam)[:count]
+
+
+def sine_start_block(N, modes, eps, seed):
+    """Deterministic warm-start vectors on an N^3 grid (natural order, i fastest): tensor sine modes (p,q,r) — the exact
+    eigenvectors of the 7-point Laplacian, good approximations for the P1 pair — plus eps * (uniform - 0.5) noise."""
+    t = np.arange(1, N + 1) * np.pi / (N + 1)
+    cols = []
+    for (p, q, r) in modes:
+        v = np.sin(r * t)[:, None, None] * np.sin(q * t)[None, :, None] * np.sin(p * t)[None, None, :]   # [k, j, i]
+        cols.append(v.ravel())
+    X = np.stack(cols, axis=1)
+    return X + eps * (uniform(seed, X.shape) - 0.5)
+
+
+WARM_MODES = [(1, 1, 1), (2, 1, 1), (1, 2, 1), (1, 1, 2), (2, 2, 1), (2, 1, 2)]
