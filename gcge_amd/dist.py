@@ -35,6 +35,33 @@ def row_partition(n_global, world):
     return part
 
 
+def partition_by_nnz(dist, A, part, bucket=None):
+    """Contiguous row partition with (nearly) equal numbers of non-zeros per rank — what SURVEY §8e asks for on the
+    load-imbalanced matrices (rows of very different length).  A: this rank's CSR slab under the current partition
+    `part` (any contiguous one, e.g. row_partition).  Every rank sums its row lengths over buckets of `bucket` global
+    rows, the sums are gathered, and the cuts are put at the bucket boundaries nearest to k/world of the total."""
+    world = len(part) - 1
+    n_global = part[-1]
+    rank = dist.get_rank()
+    if bucket is None:
+        bucket = max(1, n_global // (1024 * world))      # cuts resolved to ~0.1 % of a rank's share
+    rp = np.ctypeslib.as_array(A.rowptr, shape=(A.nrows + 1,)).astype(np.int64)
+    rows = np.arange(part[rank], part[rank + 1])
+    nb = (n_global + bucket - 1) // bucket
+    mine = np.bincount(rows // bucket, weights=np.diff(rp).astype(np.float64), minlength=nb)
+    allb = [None] * world
+    dist.all_gather_object(allb, mine)
+    cum = np.concatenate([[0.0], np.cumsum(np.sum(allb, axis=0))])
+    new = [0]
+    for k in range(1, world):
+        cut = int(np.searchsorted(cum, cum[-1] * k / world))
+        if cut > 0 and abs(cum[cut - 1] - cum[-1] * k / world) < abs(cum[cut] - cum[-1] * k / world):
+            cut -= 1
+        new.append(min(n_global, max(new[-1] + 1, cut * bucket)))
+    new.append(n_global)
+    return new
+
+
 def _loud(fn):
     """ctypes swallows exceptions raised inside callbacks (the C caller would carry on with stale halo rows or
     un-reduced sums): print the traceback and take the process down instead."""

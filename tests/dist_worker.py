@@ -29,15 +29,35 @@ def main():
     from helpers import uniform, csr_to_scipy
     h = host_lib()
     dims = (8, 8, 10)      # planes of 64 rows: the slab matrices qualify for the chain layout of the pattern SpMM
-    if len(sys.argv) > 2:
+    sio2 = None            # "sio2:G": SiO2-like matrix on a G^3 grid (rows of very different length), rows split by nnz
+    if len(sys.argv) > 2 and sys.argv[2].startswith("sio2:"):
+        sio2 = int(sys.argv[2].split(":")[1])
+    elif len(sys.argv) > 2:
         dims = tuple(int(t) for t in sys.argv[2].split(","))
-    n_global = dims[0] * dims[1] * dims[2]
-    part = gdist.row_partition(n_global, world)
+    if sio2:
+        from gcge_amd.lib import make_problem
+        kw = dict(K=40, R0=1.5, R1=3.0, seed=12345)
+        n_global = sio2 ** 3
+        Ag, _ = make_problem("sio2", sio2, **kw)
+        S = csr_to_scipy(Ag)
+        part0 = gdist.row_partition(n_global, world)
+        A0, _ = make_problem("sio2", sio2, row_begin=part0[rank], row_end=part0[rank + 1], **kw)
+        part = gdist.partition_by_nnz(dist, A0, part0)
+        A, _ = make_problem("sio2", sio2, row_begin=part[rank], row_end=part[rank + 1], **kw)
+        nnz_all = [None] * world
+        dist.all_gather_object(nnz_all, int(A.nnz))
+        nnz0 = [None] * world
+        dist.all_gather_object(nnz0, int(A0.nnz))
+        assert max(nnz_all) <= 1.03 * sum(nnz_all) / world, ("partition_by_nnz left an imbalance", nnz_all, nnz0)
+        assert sum(nnz_all) == int(Ag.nnz) and part[0] == 0 and part[-1] == n_global
+    else:
+        n_global = dims[0] * dims[1] * dims[2]
+        part = gdist.row_partition(n_global, world)
+        # the global matrix (for checking) and this rank's slab
+        Ag = CSR(); h.gcge_problem_lap3d_box(dims[0], dims[1], dims[2], C.c_int64(0), C.c_int64(-1), C.byref(Ag))
+        S = csr_to_scipy(Ag)
+        A = CSR(); h.gcge_problem_lap3d_box(dims[0], dims[1], dims[2], C.c_int64(part[rank]), C.c_int64(part[rank + 1]), C.byref(A))
     n_loc = part[rank + 1] - part[rank]
-    # the global matrix (for checking) and this rank's slab
-    Ag = CSR(); h.gcge_problem_lap3d_box(dims[0], dims[1], dims[2], C.c_int64(0), C.c_int64(-1), C.byref(Ag))
-    S = csr_to_scipy(Ag)
-    A = CSR(); h.gcge_problem_lap3d_box(dims[0], dims[1], dims[2], C.c_int64(part[rank]), C.c_int64(part[rank + 1]), C.byref(A))
     X = uniform(5, (n_global, 6)) - 0.5
     Yref = S @ X
 
@@ -65,7 +85,7 @@ def main():
         mat = gdist.hip_slab_matrix(be, comm, A, n_global, part, cap_cols=4)   # small cap: exercises the column chunking
         be.set_random_mode(1, 777)
         be.g.gcge_hip_mat_pattern_chain.argtypes = [C.c_void_p]
-        assert be.g.gcge_hip_mat_pattern_chain(mat) >= 1, "slab matrix with halo columns should keep the chain layout"
+        assert sio2 or be.g.gcge_hip_mat_pattern_chain(mat) >= 1, "slab matrix with halo columns should keep the chain layout"
 
     # 1. distributed SpMM == rows of the global product
     x = be.mv_from_numpy(mat, X[part[rank]:part[rank + 1], :])
@@ -82,7 +102,11 @@ def main():
         be.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
         be.g.gcge_hip_bpcg_setup(be.ops_handle, 30, 1e-2, 1e-14, b"abs")
     ev, res = run_gcg(be.ops_handle, mat, None, ["-nevConv", 8, "-gcge_compW_orth_method", os.environ.get("GCGE_TEST_ORTH", "chol")], flag=1 if mode == "hip" else 0)
-    exact = box_exact(dims, res.nevConv)
+    if sio2:
+        import scipy.sparse.linalg as sla
+        exact = np.sort(sla.eigsh(S.tocsc(), k=res.nevConv, sigma=0.0, which="LM", return_eigenvectors=False))
+    else:
+        exact = box_exact(dims, res.nevConv)
     rel = np.max(np.abs(ev[:res.nevConv] - exact) / exact)
     assert res.nevConv >= 8 and rel < 1e-10, (res.nevConv, res.numIter, rel, list(ev[:10]))
     allc = [None] * world

@@ -16,14 +16,14 @@ def _free_port():
     return p
 
 
-def _run(mode, world=2, timeout=600, dims=None):
+def _run(mode, world=2, timeout=600, dims=None, spec=None):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode]
-                                      + ([",".join(str(d) for d in dims)] if dims else []),
+                                      + ([",".join(str(d) for d in dims)] if dims else ([spec] if spec else [])),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -51,6 +51,11 @@ def test_eight_ranks_gloo_cpu_oracle():
     assert gdist.weak_scaling_box(4, 8) == (8, 8, 8) and gdist.weak_scaling_box(4, 2) == (4, 4, 8)
     assert gdist.weak_scaling_box(4, 4) == (4, 8, 8) and gdist.weak_scaling_box(4, 3) == (4, 4, 12)
     _run("oracle", world=8, dims=gdist.weak_scaling_box(4, 8))
+
+
+def test_three_ranks_gloo_sio2_rows_split_by_nnz():
+    """Load-imbalanced matrix (SiO2-like, rows of 19-200 non-zeros): partition_by_nnz, arbitrary halos, whole solve."""
+    _run("oracle", world=3, spec="sio2:14")
 
 
 def test_row_partition_helpers():
@@ -83,3 +88,8 @@ def test_rccl_loopback_one_gpu(dims):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_loopback_worker.py"), dims], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and "rccl loop-back ok" in p.stdout, p.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_hip_sio2_rows_split_by_nnz():
+    _run("hip", spec="sio2:16")
