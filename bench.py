@@ -41,6 +41,9 @@ def parse():
     return ap.parse_args()
 
 
+PMC_PASS2 = None   # bytes per 64-column launch of the second CG pass at C2 (set from profiles/r01_bench/12_cg_pass_pmc.txt)
+
+
 def cpu_baseline(args):
     """Reference CPU path on a bounded sample: same solver configuration, smaller grid."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -167,10 +170,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    ms, by = C.c_double(), C.c_double()
-    cnt = g.gcge_hip_profile_spmm(args.block, C.byref(ms), C.byref(by))
-    ms_all, by_all = C.c_double(), C.c_double()
-    cnt_all = g.gcge_hip_profile_spmm(0, C.byref(ms_all), C.byref(by_all))
+    # HIP-event intervals the back-end recorded on its own stream, by kind: 0 = MatDotMultiVec products (K1, plain or
+    # with the column sums), 2 / 3 = first / second pass of a block-CG iteration (the product recomputed, never stored)
+    g.gcge_hip_profile_kind.restype = C.c_long
+    g.gcge_hip_profile_kind.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+
+    def prof(kind, ncols):
+        ms_, by_ = C.c_double(), C.c_double()
+        c_ = g.gcge_hip_profile_kind(kind, ncols, C.byref(ms_), C.byref(by_))
+        return int(c_), ms_.value, by_.value
+
+    stats = {k: prof(k, args.block) for k in (0, 2, 3)}
+    spmm_ms_all = sum(prof(k, 0)[1] for k in (0, 2, 3))
     g.gcge_hip_profile_enable(0)
 
     if rank == 0:
@@ -180,22 +191,40 @@ def main():
         cs = [np.sort(2.0 * np.cos(np.arange(1, d + 1) * np.pi / (d + 1)))[::-1][:48] for d in dims]
         small = np.sort((6.0 - cs[0][:, None, None] - cs[1][None, :, None] - cs[2][None, None, :]).ravel())
         rel = float(np.max(np.abs(ev[:res.nevConv] - small[:res.nevConv]) / small[:res.nevConv]))
-        achieved = (by.value / cnt) / (ms.value / cnt * 1e-3) / 1e9 if cnt else 0.0
         npat = g.gcge_hip_mat_patterns(mat)
-        # `achieved` prices every launch at the CSR algorithmic bytes of SURVEY.md 8(d) (12 B per non-zero + X + Y).
-        # On the pattern path the matrix is streamed as 2 B per row instead, so the bytes actually
-        # moved are lower than the algorithmic ones: X and Y (16 n m) dominate either way.
-        # HBM/fabric bytes per launch from separate rocprofv3 --pmc passes of this kernel at this shape (not collected
-        # live: counters need their own runs): TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B, gfx950 correction of
-        # MI355X_MICROARCH.md applied; profiles/r01_spmm_explore/23_chain2_pmc.log
-        traffic, traffic_note = None, "no PMC profile for this shape"
         chain = g.gcge_hip_mat_pattern_chain(mat)
-        if npat > 0 and N == 256 and args.block == 64 and world == 1 and chain == 2:
-            traffic = 4 * (2.35094e7 * 128 + 3.35544e7 * 64)
-            traffic_note = "4 passes x (2.351e7 x 128 B reads + 3.355e7 x 64 B writes), profiles/r01_spmm_explore/23_chain2_pmc.log"
-        kname = ("%s<7> x %d passes of 16 columns + column dots (K1, %d row patterns, m=%d)"
-                 % (("spmm_pattern", "spmm_pattern_chain", "spmm_pattern_chain2")[chain], (args.block + 15) // 16, npat, args.block)
-                 if npat > 0 else "spmm_pad8 (K1 CSR SpMM, m=%d)" % args.block)
+        kbase = ("spmm_pattern", "spmm_pattern_chain", "spmm_pattern_chain2")[chain] if npat > 0 else "spmm_pad8"
+        npass = (args.block + 15) // 16 if npat > 0 else 1
+
+        def roof(kind, what, traffic=None, note="no PMC profile for this shape"):
+            # `achieved` prices a launch at its ALGORITHMIC bytes: kind 0: SURVEY.md 8(d), 12 B per
+            # non-zero + row pointers + X read + Y written; kind 2: matrix + p read; kind 3: matrix + p, r read + r,
+            # p_new written.  On the pattern path the matrix itself is streamed as 2 B per row, so the bytes actually
+            # moved are lower; the block streams (8 n m each) dominate either way.  One "launch" = the `npass` kernel
+            # launches of 16 columns that make up one m-column operation (rocprof lists the 16-column launches).
+            c_, ms_, by_ = stats[kind]
+            if c_ == 0:
+                return None
+            ach = (by_ / c_) / (ms_ / c_ * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": "%s<7,%d> x %d passes of 16 columns: %s (%d row patterns, m=%d)"
+                                              % (kbase, kind if kind else 0, npass, what, npat, args.block),
+                    "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
+                    "traffic_note": note, "launches": c_, "avg_launch_ms": ms_ / c_, "alg_bytes_per_launch": by_ / c_,
+                    "share_of_step": ms_ * 1e-3 / elapsed if elapsed > 0 else None}
+
+        # HBM/fabric bytes per launch from separate rocprofv3 --pmc passes at this shape (not collected live: counters
+        # need their own runs): TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B, gfx950 correction of MI355X_MICROARCH.md
+        pmc_ok = npat > 0 and N == 256 and args.block == 64 and world == 1 and chain == 2
+        r_k1 = roof(0, "Y = A X, K1 (MatDotMultiVec)",
+                    4 * (2.35094e7 * 128 + 3.35544e7 * 64) if pmc_ok else None,
+                    "4 passes x (2.351e7 x 128 B reads + 3.355e7 x 64 B writes), profiles/r01_spmm_explore/23_chain2_pmc.log"
+                    if pmc_ok else "no PMC profile for this shape")
+        r_p1 = roof(2, "CG pass 1, p.Ap and |Ap|^2 without storing Ap")
+        r_p2 = roof(3, "CG pass 2, Ap recomputed + r -= alpha Ap, p' = r + beta p",
+                    PMC_PASS2 if pmc_ok and PMC_PASS2 else None,
+                    "profiles/r01_bench/12_cg_pass_pmc.txt" if pmc_ok and PMC_PASS2 else "no PMC profile for this shape")
+        cands = [r for r in (r_k1, r_p1, r_p2) if r is not None]
+        dominant = max(cands, key=lambda r: r["share_of_step"]) if cands else None
         out = {
             "metric": "converged eigenpairs/sec (GCG, 3D Laplacian n=%d, block=%d)" % (n_global, args.block),
             "value": conv_total / elapsed, "unit": "eigenpairs/s", "n_gpus": world, "steps": args.steps,
@@ -207,12 +236,10 @@ def main():
                        "gcg_iterations": iters, "nev_converged": conv_total,
                        "max_rel_err_vs_closed_form": rel,
                        "phase_seconds": {k: getattr(res.timing, k) for k in ("initX", "checkconv", "compP", "compRR", "compRV", "compW", "linsol", "total")}},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note,
-                         "launches": int(cnt),
-                         "avg_launch_ms": (ms.value / cnt) if cnt else None,
-                         "alg_bytes_per_launch": (by.value / cnt) if cnt else None,
-                         "spmm_share_of_step": (ms_all.value * 1e-3) / elapsed if elapsed > 0 else None},
+            # the dominant kernel of the step; the K1 product alone (the north-star figure) and the other CG pass follow
+            "roofline": dominant,
+            "roofline_k1_spmm": r_k1, "roofline_cg_pass1": r_p1, "roofline_cg_pass2": r_p2,
+            "spmm_share_of_step": spmm_ms_all * 1e-3 / elapsed if elapsed > 0 else None,
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)

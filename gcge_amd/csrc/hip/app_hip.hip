@@ -37,6 +37,11 @@ int gcge_hip_colmajor_to_rowmajor(int nrows, int m, const double* d_src, long ld
 int gcge_hip_rowmajor_to_colmajor(int nrows, int m, const double* d_src, long lds, double* d_dst, long ldd, void* stream);
 }
 
+extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+                                   long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
+                                   long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
+                                   double* d_dots, double* d_dots_yy, void* stream);
+
 struct GCGE_HIP_MAT_ {
   int nrows;      // local rows
   int nglobal;    // global dimension
@@ -155,7 +160,7 @@ extern "C" void gcge_hip_set_random_mode(int mode, unsigned long long seed) { g_
 // ------------------------------------------------------------------ SpMM launch profiling
 // HIP events around every K1 launch on the launch stream (bench.py: roofline.achieved =
 // algorithmic bytes / average launch duration, measured live inside the timed region).
-struct SpmmEvent { hipEvent_t e0, e1; int m; double bytes; };
+struct SpmmEvent { hipEvent_t e0, e1; int m; double bytes; int kind; };   // kind 0: product (plain or with the column sums), 2 / 3: CG passes
 static std::vector<SpmmEvent> g_prof;
 static int g_prof_on = 0;
 extern "C" void gcge_hip_profile_enable(int on) {
@@ -164,11 +169,16 @@ extern "C" void gcge_hip_profile_enable(int on) {
   g_prof_on = on;
 }
 // sums over the recorded launches with exactly `ncols` columns (0: all); returns the count
+// kind 0: MatDotMultiVec products (plain or with the column sums); 2 / 3: first / second pass of the fused CG
+extern "C" long gcge_hip_profile_kind(int kind, int ncols, double* total_ms, double* total_alg_bytes);
 extern "C" long gcge_hip_profile_spmm(int ncols, double* total_ms, double* total_alg_bytes) {
+  return gcge_hip_profile_kind(0, ncols, total_ms, total_alg_bytes);
+}
+extern "C" long gcge_hip_profile_kind(int kind, int ncols, double* total_ms, double* total_alg_bytes) {
   long cnt = 0; double ms = 0.0, by = 0.0;
   GCGE_HIP_CHECK(hipDeviceSynchronize());
   for (auto& e : g_prof) {
-    if (ncols > 0 && e.m != ncols) continue;
+    if (e.kind != kind || (ncols > 0 && e.m != ncols)) continue;
     float t = 0.f;
     GCGE_HIP_CHECK(hipEventElapsedTime(&t, e.e0, e.e1));
     ms += t; by += e.bytes; ++cnt;
@@ -678,13 +688,23 @@ __global__ void add3_kernel(double* __restrict__ dst, const double* __restrict__
 
 // rows [r0, r1) of Y = A X, optionally with the column sums x.y (and y.y) over those rows (d_dots, d_yy: device, m each).
 // want_fused: the caller asked for dots and the matrix/operands qualify for a fused kernel.
+// cg != NULL: one of the two passes of a block-CG iteration instead of the product (pattern matrices only,
+// gcge_hip_pattern_cg): mode 2 = the sums without storing Y, mode 3 = R / P update with the product recomputed.
+struct CgPass { int mode; double* r; long ldr; double* pnew; long ldp; const double *alpha, *beta; const int* flag; };
 static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long ldx, double* dy, long ldy, int m,
-                     double* d_dots, double* d_yy) {
+                     double* d_dots, double* d_yy, const CgPass* cg = nullptr) {
   const int nr = (int)(r1 - r0);
   if (nr <= 0) {
     if (d_dots) GCGE_HIP_CHECK(hipMemsetAsync(d_dots, 0, m * sizeof(double), g_stream));
     if (d_yy) GCGE_HIP_CHECK(hipMemsetAsync(d_yy, 0, m * sizeof(double), g_stream));
     return 0;
+  }
+  if (cg != nullptr) {
+    if (A->d_pid == nullptr || g_spmm_path != 0) return -1;
+    return gcge_hip_pattern_cg(cg->mode, nr, A->d_pid + r0, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2,
+                               dx + r0 * ldx, ldx, cg->r ? cg->r + r0 * cg->ldr : nullptr, cg->ldr,
+                               cg->pnew ? cg->pnew + r0 * cg->ldp : nullptr, cg->ldp, m, cg->alpha, cg->beta, cg->flag,
+                               d_dots, d_yy, g_stream);
   }
   double* y = dy + r0 * ldy;
   int rc = -1;
@@ -712,13 +732,14 @@ extern "C" void gcge_hip_set_halo_overlap(int on) { g_halo_overlap = on; }
 // Y[:, 0:m) = A X[:, c_begin : c_begin+m) on a row slab, halo included; d_dots / d_yy as in spmm_rows (3 m doubles of
 // scratch behind each when the product is split).  With a split exchange the interior rows are multiplied while the
 // halo rows travel, the two boundary strips follow.
-static int spmm_halo(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, double* dy, long ldy, int m, double* d_dots, double* d_yy) {
+static int spmm_halo(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, double* dy, long ldy, int m, double* d_dots, double* d_yy,
+                     const CgPass* cg = nullptr) {
   const double* dx = vx->d + c_begin;
   const bool split = g_halo_overlap && A->nghost > 0 && A->exchange_begin != nullptr && A->exchange_end != nullptr &&
                      m <= A->buf_cols && A->ov_hi - A->ov_lo >= A->nrows / 2 && getenv("GCGE_NO_HALO_OVERLAP") == nullptr;
   if (!split) {
     halo_fetch(A, vx, c_begin, m);
-    return spmm_rows(A, 0, A->nrows, dx, vx->ld, dy, ldy, m, d_dots, d_yy);
+    return spmm_rows(A, 0, A->nrows, dx, vx->ld, dy, ldy, m, d_dots, d_yy, cg);
   }
   GCGE_REQUIRE(A->buf_cols > 0, "MatDotMultiVec: halo plan installed (gcge_hip_mat_set_halo)");
   if (A->nsend > 0) {
@@ -728,16 +749,16 @@ static int spmm_halo(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, double* dy, l
   A->exchange_begin(A->sendbuf, A->recvbuf, m, A->exchange_ctx);
   double* d1 = d_dots ? d_dots + m : nullptr; double* d2 = d_dots ? d_dots + 2 * m : nullptr;
   double* y1 = d_yy ? d_yy + m : nullptr;     double* y2 = d_yy ? d_yy + 2 * m : nullptr;
-  int rc = spmm_rows(A, A->ov_lo, A->ov_hi, dx, vx->ld, dy, ldy, m, d1, y1);          // interior, overlaps the transfers
+  int rc = spmm_rows(A, A->ov_lo, A->ov_hi, dx, vx->ld, dy, ldy, m, d1, y1, cg);      // interior, overlaps the transfers
   A->exchange_end(A->exchange_ctx);
   {
     long tot = (long)A->nghost * m, g = (tot + 255) / 256; if (g > 4096) g = 4096;
     hipLaunchKernelGGL(halo_unpack, dim3((unsigned)g), dim3(256), 0, g_stream, A->nghost, A->recvbuf, m,
                        vx->d + (long)A->nrows * vx->ld + c_begin, vx->ld);
   }
-  if (rc == 0) rc = spmm_rows(A, 0, A->ov_lo, dx, vx->ld, dy, ldy, m, d2, y2);         // leading boundary strip
+  if (rc == 0) rc = spmm_rows(A, 0, A->ov_lo, dx, vx->ld, dy, ldy, m, d2, y2, cg);     // leading boundary strip
   double* d3 = d_dots ? stage_d2(2 * (size_t)m) : nullptr;
-  if (rc == 0) rc = spmm_rows(A, A->ov_hi, A->nrows, dx, vx->ld, dy, ldy, m, d3, d_yy ? d3 + m : nullptr);   // trailing strip
+  if (rc == 0) rc = spmm_rows(A, A->ov_hi, A->nrows, dx, vx->ld, dy, ldy, m, d3, d_yy ? d3 + m : nullptr, cg);   // trailing strip
   if (d_dots) hipLaunchKernelGGL(add3_kernel, dim3((m + 63) / 64), dim3(64), 0, g_stream, d_dots, d1, d2, d3, m);
   if (d_yy) hipLaunchKernelGGL(add3_kernel, dim3((m + 63) / 64), dim3(64), 0, g_stream, d_yy, y1, y2, d3 + m, m);
   return rc;
@@ -763,6 +784,7 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
   SpmmEvent ev;
   if (g_prof_on) {   // (on a row slab the interval also holds the halo exchange)
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
+    ev.kind = 0;
     ev.m = m;   // algorithmic bytes: values+indices once, row pointers once, X once, Y once
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
@@ -820,7 +842,7 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
   SpmmEvent ev;
   if (g_prof_on) {   // the fused kernel IS the K1 launch of a CG step (same algorithmic bytes: the dots add no HBM traffic)
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
-    ev.m = m;
+    ev.m = m; ev.kind = 0;
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
@@ -833,6 +855,73 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
   memcpy(host_dots, hd, m * sizeof(double));
   if (host_yy) memcpy(host_yy, hd + m, m * sizeof(double));
+}
+
+// ---- the two passes of a fused block-CG iteration (block_pcg.hip) on a pattern matrix -----------------------------
+// The product w = A p is formed twice and never stored: pass 1 reads p and returns p.w and w.w (that fixes alpha and
+// beta), pass 2 reads p again, rebuilds w in registers and applies  r -= alpha w ; p_new = r + beta p  on the spot.
+// 1 + 4 block streams per iteration instead of 2 (product) + 5 (update sweep).  Both return -1 without touching
+// anything when the matrix or the operands do not qualify (no pattern form, odd widths, halo wider than the buffers).
+extern "C" int gcge_hip_cg_fusable(void* mat, void** p, int ncols) {
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat; GcgeHipMV* vp = (GcgeHipMV*)p;
+  if (A == nullptr || A->d_pid == nullptr || g_spmm_path != 0 || getenv("GCGE_CG_NO_RECOMPUTE") != nullptr) return 0;
+  if ((ncols & 1) || (vp->ld & 1) || ((uintptr_t)vp->d & 15)) return 0;
+  if (A->nghost > 0 && ncols > A->buf_cols) return 0;
+  return 1;
+}
+// host_pw[j] = sum_r p[r,j] (A p)[r,j], host_ww[j] = sum_r (A p)[r,j]^2 over the LOCAL rows; fetches the halo rows of p
+extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* host_pw, double* host_ww) {
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat; GcgeHipMV* vp = (GcgeHipMV*)p;
+  if (!gcge_hip_cg_fusable(mat, p, m) || (c0 & 1)) return -1;
+  GCGE_REQUIRE(c0 >= 0 && c0 + m <= vp->ncols && A->nrows == vp->nrows && A->nrows + A->nghost <= vp->nrows_alloc, "cg_pass1: shapes");
+  double* dd = stage_d(6 * (size_t)m);
+  double* dyy = dd + 3 * (size_t)m;
+  SpmmEvent ev;
+  if (g_prof_on) {   // algorithmic bytes: matrix once, p once
+    GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
+    ev.m = m; ev.kind = 2;
+    ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 8.0 * (double)A->nrows * m;
+    GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
+  }
+  const CgPass cg = {2, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr};
+  const int rc = spmm_halo(A, vp, c0, nullptr, 0, m, dd, dyy, &cg);
+  if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
+  GCGE_REQUIRE(rc == 0, "cg_pass1: kernel launch");
+  double* hd = stage_h(2 * (size_t)m);
+  GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  GCGE_HIP_CHECK(hipMemcpyAsync(hd + m, dyy, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+  memcpy(host_pw, hd, m * sizeof(double));
+  memcpy(host_ww, hd + m, m * sizeof(double));
+  return 0;
+}
+// r[:, c0:c0+m) -= (A p) diag(alpha); pnew[:, c0:c0+m) = r diag(cr) + p diag(cb); host_rho[j] = sum_r cr_j r[r,j]^2 (local).
+// The halo rows of p must be the ones pass 1 fetched (p unchanged since).  d_alpha / d_beta / d_flag: device, m each.
+extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
+                                    const double* d_beta, const int* d_flag, double* host_rho) {
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
+  GcgeHipMV *vp = (GcgeHipMV*)p, *vr = (GcgeHipMV*)r, *vn = (GcgeHipMV*)pnew;
+  if (!gcge_hip_cg_fusable(mat, p, m) || (c0 & 1) || (vr->ld & 1) || (vn->ld & 1) || ((uintptr_t)vr->d & 15) ||
+      ((uintptr_t)vn->d & 15) || vn == vp) return -1;
+  GCGE_REQUIRE(c0 >= 0 && c0 + m <= vp->ncols && c0 + m <= vr->ncols && c0 + m <= vn->ncols, "cg_pass2: column ranges");
+  GCGE_REQUIRE(A->nrows == vp->nrows && A->nrows == vr->nrows && A->nrows == vn->nrows, "cg_pass2: row counts");
+  double* dd = stage_d(6 * (size_t)m);
+  SpmmEvent ev;
+  if (g_prof_on) {   // algorithmic bytes: matrix once, p and r read, r and p_new written
+    GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
+    ev.m = m; ev.kind = 3;
+    ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 32.0 * (double)A->nrows * m;
+    GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
+  }
+  const CgPass cg = {3, vr->d + c0, vr->ld, vn->d + c0, vn->ld, d_alpha, d_beta, d_flag};
+  const int rc = spmm_rows(A, 0, A->nrows, vp->d + c0, vp->ld, nullptr, 0, m, dd, nullptr, &cg);
+  if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
+  GCGE_REQUIRE(rc == 0, "cg_pass2: kernel launch");
+  double* hd = stage_h((size_t)m);
+  GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+  memcpy(host_rho, hd, m * sizeof(double));
+  return 0;
 }
 
 // app_ccs.c:140-150 — symmetric matrices only

@@ -47,6 +47,10 @@ extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, i
 extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots, struct OPS_* ops);
 extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots, double* host_yy,
                                       struct OPS_* ops);
+extern "C" int gcge_hip_cg_fusable(void* mat, void** p, int ncols);
+extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* host_pw, double* host_ww);
+extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
+                                    const double* d_beta, const int* d_flag, double* host_rho);
 
 namespace gcge {
 
@@ -387,6 +391,7 @@ struct HipBpcg {
   int niter; double residual;
   long spmm_calls, spmm_cols;   // statistics for bench.py
   double* d_coef; int* d_flag; double* h_pin; int cap;
+  long recompute_iters;         // iterations run in the two-pass form with the product recomputed (pattern matrices)
 };
 static HipBpcg g_bpcg = {30, 1e-2, 1e-14, "abs", {nullptr, nullptr, nullptr, nullptr}, {nullptr}, 0, 0, 0, 0, -1.0, 0, 0, nullptr, nullptr, nullptr, 0};
 
@@ -529,6 +534,11 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
       GCGE_HIP_CHECK(hipStreamSynchronize(st));   // ahist (pageable) and the partial workspace are reused right away
       first_slot = (first_slot + npend) % R; npend = 0;
     };
+    // Pattern matrices (stencils) with a ring: the product is formed twice and never stored — pass 1 reads p for
+    // p.w and w.w, pass 2 reads p again and applies the r / p update with w rebuilt in registers (app_hip.hip:
+    // gcge_hip_cg_pass1_mv / pass2_mv): 1 + 4 block streams per iteration instead of 2 + 5.  Same recurrences,
+    // same operands, so alpha, beta and the iterates agree with the stored-w form to rounding of the sums.
+    const bool recompute = R > 1 && sigma == 0.0 && gcge_hip_cg_fusable(mat, s->ring[0], nrhs) && !(nrhs & 1);
     if (nact > 0) {   // p0 = r0
       st2[0] = 0; en2[0] = nrhs; st2[1] = 0; en2[1] = nrhs;
       ops->MultiVecAxpby(1.0, s->mv_ws[0], 0.0, s->ring_len ? s->ring[0] : s->mv_ws[1], st2, en2, ops);
@@ -542,7 +552,11 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
       int aw = ahi - alo;
       if (((alo & 1) || (aw & 1))) { alo &= ~1; ahi = (ahi + 1) & ~1; aw = ahi - alo; }   // keep 16-byte column pairs
       void** pcur = R > 1 ? s->ring[cur] : s->mv_ws[1];
-      apply(pcur, alo, s->mv_ws[2], alo, aw, pTw.data() + alo, wTw.data() + alo);
+      if (recompute) {
+        if (gcge_hip_cg_pass1_mv(mat, pcur, alo, aw, pTw.data() + alo, wTw.data() + alo) != 0) {
+          fprintf(stderr, "HIP_BlockPCG: first CG pass refused operands it had accepted\n"); abort();
+        }
+      } else apply(pcur, alo, s->mv_ws[2], alo, aw, pTw.data() + alo, wTw.data() + alo);
       s->spmm_calls++; s->spmm_cols += aw;
       {   // one all-reduce for both sums
         std::vector<double> both(2 * (size_t)aw);
@@ -559,6 +573,15 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
         coef[j] = al; bet[j] = rho_pred / rho2[j];
       }
       upload(alo, aw, bet.data(), coef.data(), flag.data());   // d_coef = [beta | alpha]
+      std::vector<double> newrho(aw);
+      if (recompute) {
+        if (gcge_hip_cg_pass2_mv(mat, pcur, s->mv_ws[0], s->ring[(cur + 1) % R], alo, aw, s->d_coef + s->cap, s->d_coef,
+                                 s->d_flag, newrho.data()) != 0) {
+          fprintf(stderr, "HIP_BlockPCG: second CG pass refused operands it had accepted\n"); abort();
+        }
+        for (int j = 0; j < nrhs; ++j) ahist[(size_t)npend * nrhs + j] = (j >= alo && j < ahi && active[j]) ? coef[j] : 0.0;
+        ++npend; cur = (cur + 1) % R; ++s->recompute_iters;
+      } else {
       double* part = gcge_hip_partial_ws((size_t)nb * aw + aw + (size_t)(J > 0 ? J : 0) * nrhs);
       if (R > 1) {
         long ldq;
@@ -578,7 +601,8 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
       gcge_hip_reduce_partials(part, (int)nb, aw, part + (size_t)nb * aw, st);
       GCGE_HIP_CHECK(hipMemcpyAsync(s->h_pin, part + (size_t)nb * aw, aw * sizeof(double), hipMemcpyDeviceToHost, st));
       GCGE_HIP_CHECK(hipStreamSynchronize(st));
-      std::vector<double> newrho(s->h_pin, s->h_pin + aw);
+      memcpy(newrho.data(), s->h_pin, aw * sizeof(double));
+      }
       reduce_over_ranks(newrho.data(), aw);
       nact = 0;
       for (int j = alo; j < ahi; ++j) {
@@ -688,6 +712,7 @@ extern "C" void gcge_hip_bpcg_stats(long* spmm_calls, long* spmm_cols, int* last
   if (spmm_cols) *spmm_cols = g_bpcg.spmm_cols;
   if (last_niter) *last_niter = g_bpcg.niter;
 }
+extern "C" long gcge_hip_bpcg_recompute_iters(void) { return g_bpcg.recompute_iters; }
 extern "C" void gcge_hip_bpcg_release(struct OPS_* ops) {
   for (int i = 1; i < g_bpcg.ring_len; ++i) if (g_bpcg.ring[i]) ops->MultiVecDestroy(&g_bpcg.ring[i], g_bpcg.ws_cols, ops);
   g_bpcg.ring_len = 0;

@@ -42,12 +42,33 @@ namespace gcge {
 typedef double v2d __attribute__((ext_vector_type(2)));
 struct PatEntry { double val; long off; };   // 16 bytes: one ds_read_b128
 
-// DOT: also dot_partial[block][j] = sum over the block's rows of X[r,j] * Y[r,j]
-template <int LT, int DOT>
+// MODE (the kernels below share it):
+//   0  Y = A X
+//   1  Y = A X and dot_partial[block][j] = sum over the block's rows of X[r,j] * Y[r,j] (+ Y[r,j]^2 behind yy_offset)
+//   2  the two sums of mode 1 only, nothing is stored (first pass of the block CG, block_pcg.hip)
+//   3  second pass of the block CG: w = A X is recomputed in registers and consumed on the spot,
+//        R[r,j] -= alpha_j w[r,j] ;  PNEW[r,j] = cr_j R[r,j] + cb_j X[r,j] ;  partial: sum_r cr_j R[r,j]^2
+//      with (alpha, cb, cr) = flag_j ? (alpha_j, beta_j, 1) : (0, 1, 0) exactly as cg_update_rp (retired columns are
+//      copied).  X = p_k, PNEW = p_{k+1} must be different blocks: neighbours still read X.
+struct CgArgs { double* r; size_t ldr; double* pnew; size_t ldp; const double* alpha; const double* beta; const int* flag; };
+struct CgCoef { double al0, al1, cb0, cb1, cr0, cr1; };
+__device__ __forceinline__ CgCoef cg_coef(const CgArgs& cg, int j, bool act) {
+  CgCoef c = {0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
+  if (act) {
+    const int f0 = cg.flag[j], f1 = cg.flag[j + 1];
+    if (f0) { c.al0 = cg.alpha[j]; c.cb0 = cg.beta[j]; c.cr0 = 1.0; }
+    if (f1) { c.al1 = cg.alpha[j + 1]; c.cb1 = cg.beta[j + 1]; c.cr1 = 1.0; }
+  }
+  return c;
+}
+
+template <int LT, int MODE>
 __global__ __launch_bounds__(256) void spmm_pattern_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
     const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
-    double* __restrict__ dot_partial, long yy_offset) {
+    double* __restrict__ dot_partial, long yy_offset, CgArgs cg) {
+  constexpr int DOT = MODE != 0;       // the row's own X value rides in buf[LT]
+  constexpr int UPD = MODE == 3;       // its R value in buf[LT + 1]
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
   for (int e = threadIdx.x; e < ntab; e += 256) s_tab[e] = tab[e];
@@ -57,6 +78,8 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
   const int g = lane >> 3, i = lane & 7;
   const bool act = 2 * i < m;
   const double* __restrict__ xl = x + (act ? 2 * i : 0);   // idle lanes of a narrow last pass re-read column 0
+  const double* __restrict__ rl = UPD ? cg.r + (act ? 2 * i : 0) : nullptr;
+  const CgCoef cf = UPD ? cg_coef(cg, 2 * i, act) : CgCoef{0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
   double d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;   // x.y and y.y column sums (DOT)
 
   // tile t = (group of 4 lines q, slice a inside the line); wave w takes line 4q + w
@@ -65,7 +88,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
   if ((long)blockIdx.x < ntiles) {   // block-uniform
     const long cnt = (ntiles - blockIdx.x + G - 1) / G;
     auto row_of = [&](long it) { return min(first_row(blockIdx.x + min(it, cnt - 1) * G) + g, nrows - 1); };   // clamped
-    auto issue = [&](v2d (&buf)[LT + DOT], double (&val)[LT], long row, int p) {
+    auto issue = [&](v2d (&buf)[LT + DOT + UPD], double (&val)[LT], long row, int p) {
 #pragma unroll
       for (int t = 0; t < LT; ++t) {
         const PatEntry e = s_tab[p * LT + t];
@@ -73,24 +96,35 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
         buf[t] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e.off) * ldx);
       }
       if (DOT) buf[LT] = *reinterpret_cast<const v2d*>(xl + (size_t)row * ldx);
+      if (UPD) buf[LT + DOT] = *reinterpret_cast<const v2d*>(rl + (size_t)row * cg.ldr);
     };
-    auto finish = [&](const v2d (&buf)[LT + DOT], const double (&val)[LT], long it) {
+    auto finish = [&](const v2d (&buf)[LT + DOT + UPD], const double (&val)[LT], long it) {
       double a0 = 0.0, a1 = 0.0;
 #pragma unroll
       for (int t = 0; t < LT; ++t) { a0 = fma(val[t], buf[t].x, a0); a1 = fma(val[t], buf[t].y, a1); }
       const long row = first_row(blockIdx.x + it * G) + g;   // unclamped: surplus iterations and tail rows store nothing
       const bool ok = it < cnt && row < nrows && act;
-      if (ok) {
+      if ((MODE <= 1 && ok) || (MODE == 2 && ok && y != nullptr)) {   // MODE 2: y == NULL, see chain2_body
         v2d o = {a0, a1};
         __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(y + (size_t)row * ldy + 2 * i));
       }
-      if (DOT) {
-        const double wgt = ok ? 1.0 : 0.0;
+      const double wgt = ok ? 1.0 : 0.0;
+      if (MODE == 1 || MODE == 2) {
         d0 = fma(a0 * wgt, buf[LT].x, d0); d1 = fma(a1 * wgt, buf[LT].y, d1);
         e0 = fma(a0 * wgt, a0, e0); e1 = fma(a1 * wgt, a1, e1);
       }
+      if (UPD) {
+        const v2d rv = buf[LT + DOT], pv = buf[LT];
+        v2d rn = {fma(-cf.al0, a0, rv.x), fma(-cf.al1, a1, rv.y)};
+        v2d pn = {fma(cf.cb0, pv.x, cf.cr0 * rn.x), fma(cf.cb1, pv.y, cf.cr1 * rn.y)};
+        if (ok) {
+          __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.r + (size_t)row * cg.ldr + 2 * i));
+          __builtin_nontemporal_store(pn, reinterpret_cast<v2d*>(cg.pnew + (size_t)row * cg.ldp + 2 * i));
+        }
+        d0 = fma(cf.cr0 * wgt * rn.x, rn.x, d0); d1 = fma(cf.cr1 * wgt * rn.y, rn.y, d1);
+      }
     };
-    v2d b0[LT + DOT], b1[LT + DOT];
+    v2d b0[LT + DOT + UPD], b1[LT + DOT + UPD];
     double v0[LT], v1[LT];
     int p0 = pid[row_of(0)], p1 = pid[row_of(1)];
     issue(b0, v0, row_of(0), p0);
@@ -263,11 +297,13 @@ __global__ __launch_bounds__(256) void spmm_pattern_chain_kernel(
 // 1 (+S) + 2 (+-1) + 2/NW, against 5 for the chain alone and 7 without it.  The barrier carries no memory fence
 // (raw s_barrier after lgkmcnt(0)): the global loads of the NEXT iteration stay in flight across it.
 // ROLE: 0 lowest wave, 1 inner wave, 2 highest wave (three copies of the loop: no branch near a load).
-template <int LT, int DOT, int NW, int ROLE>
+template <int LT, int MODE, int NW, int ROLE>
 __device__ __forceinline__ void chain2_body(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* s_tab, v2d (*xch)[NW][64],
     const double* __restrict__ xl, size_t ldx, double* __restrict__ y, size_t ldy, bool act, int i, int g, int wave, int lane,
-    long ntiles, long line, int xcd_runs, double& d0, double& d1, double& e0, double& e1) {
+    long ntiles, long line, int xcd_runs, double& d0, double& d1, double& e0, double& e1, const CgArgs& cg, const v2d* s_cf) {
+  constexpr int UPD = MODE == 3;
+  const double* __restrict__ rl = UPD ? cg.r + (act ? 2 * i : 0) : nullptr;
   constexpr int NO = LT - 5;               // slots that are neither chain nor line
   constexpr int NE = (ROLE == 1) ? 0 : 1;  // line row still loaded from memory
   // Tuning hook (off): blocks are dealt round-robin to the 8 XCDs; tiles that are neighbours along a grid line share
@@ -283,15 +319,16 @@ __device__ __forceinline__ void chain2_body(
   auto row_of = [&](long it) { return min(row_at(min(it, cnt - 1)), nrows - 1); };
   // the stencil values are looked up again when the rows are reduced (7 LDS reads) instead of being carried in
   // 2 x LT registers from issue to finish: keeps the kernel at 4 waves per SIMD with the dot accumulators
-  auto issue = [&](v2d& lnew, v2d (&edge)[NE + 1], v2d (&oth)[NO + 1], long row, int p) {
+  auto issue = [&](v2d& lnew, v2d (&edge)[NE + 1], v2d (&oth)[NO + 1 + UPD], long row, int p) {
     const PatEntry* e = s_tab + p * LT;
     lnew = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[2].off) * ldx);
+    if (UPD) oth[NO + UPD] = *reinterpret_cast<const v2d*>(rl + (size_t)row * cg.ldr);   // the row's residual
     if (ROLE == 0) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[3].off) * ldx);
     if (ROLE == 2) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[4].off) * ldx);
 #pragma unroll
     for (int t = 0; t < NO; ++t) oth[t] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[5 + t].off) * ldx);
   };
-  auto finish = [&](const v2d& a, const v2d& b, const v2d& c, const v2d (&edge)[NE + 1], const v2d (&oth)[NO + 1],
+  auto finish = [&](const v2d& a, const v2d& b, const v2d& c, const v2d (&edge)[NE + 1], const v2d (&oth)[NO + 1 + UPD],
                     int p, long it, int buf) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -309,18 +346,31 @@ __device__ __forceinline__ void chain2_body(
     for (int t = 0; t < NO; ++t) { a0 = fma(val[5 + t], oth[t].x, a0); a1 = fma(val[5 + t], oth[t].y, a1); }
     const long row = row_at(it);
     const bool ok = it < cnt && row < nrows && act;
-    if (ok) {
+    // MODE 2 stores nothing (the launcher passes y == NULL), but keeps the never-taken branch: without it hipcc
+    // schedules the straight-line body into 200+ VGPRs / spills (118 with it), measured on the resource remarks
+    if ((MODE <= 1 && ok) || (MODE == 2 && ok && y != nullptr)) {
       v2d o = {a0, a1};
       __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(y + (size_t)row * ldy + 2 * i));
     }
-    if (DOT) {
-      const double wgt = ok ? 1.0 : 0.0;
+    const double wgt = ok ? 1.0 : 0.0;
+    if (MODE == 1 || MODE == 2) {
       d0 = fma(a0 * wgt, b.x, d0); d1 = fma(a1 * wgt, b.y, d1);
       e0 = fma(a0 * wgt, a0, e0); e1 = fma(a1 * wgt, a1, e1);
     }
+    if (UPD) {   // coefficients of this lane's column pair from LDS (kept out of the registers: 4 waves per SIMD)
+      const v2d al = s_cf[i], cb = s_cf[8 + i], cr = s_cf[16 + i];
+      const v2d rv = oth[NO + UPD];
+      v2d rn = {fma(-al.x, a0, rv.x), fma(-al.y, a1, rv.y)};
+      v2d pn = {fma(cb.x, b.x, cr.x * rn.x), fma(cb.y, b.y, cr.y * rn.y)};
+      if (ok) {
+        __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.r + (size_t)row * cg.ldr + 2 * i));
+        __builtin_nontemporal_store(pn, reinterpret_cast<v2d*>(cg.pnew + (size_t)row * cg.ldp + 2 * i));
+      }
+      d0 = fma(cr.x * wgt * rn.x, rn.x, d0); d1 = fma(cr.y * wgt * rn.y, rn.y, d1);
+    }
     xch[buf ^ 1][wave][lane] = c;   // the centre row of my next iteration
   };
-  v2d r0, r1, r2, r3, ed0[NE + 1], ed1[NE + 1], o0[NO + 1], o1[NO + 1];
+  v2d r0, r1, r2, r3, ed0[NE + 1], ed1[NE + 1], o0[NO + 1 + UPD], o1[NO + 1 + UPD];
   int p0 = pid[row_of(0)], p1 = pid[row_of(1)];
   {
     const long row = row_of(0);
@@ -355,15 +405,21 @@ __device__ __forceinline__ void chain2_body(
   }
 }
 
-template <int LT, int DOT, int NW>
+template <int LT, int MODE, int NW>
 __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
     const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
-    double* __restrict__ dot_partial, long yy_offset, int xcd_runs) {
+    double* __restrict__ dot_partial, long yy_offset, int xcd_runs, CgArgs cg) {
+  constexpr int DOT = MODE != 0;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
   __shared__ v2d xch[2][NW][64];
+  __shared__ v2d s_cf[24];   // MODE 3: (alpha, cb, cr) of the 8 column pairs of this pass
   for (int e = threadIdx.x; e < ntab; e += 64 * NW) s_tab[e] = tab[e];
+  if (MODE == 3 && threadIdx.x < 8) {
+    const CgCoef c = cg_coef(cg, 2 * threadIdx.x, 2 * (int)threadIdx.x < m);
+    s_cf[threadIdx.x] = v2d{c.al0, c.al1}; s_cf[8 + threadIdx.x] = v2d{c.cb0, c.cb1}; s_cf[16 + threadIdx.x] = v2d{c.cr0, c.cr1};
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 3, i = lane & 7;
@@ -373,9 +429,9 @@ __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
   const long gq = gridDim.x;
   const long bperm = (gq % 8 == 0 && xcd_runs) ? ((long)(blockIdx.x & 7) * (gq >> 3) + (blockIdx.x >> 3)) : (long)blockIdx.x;
   if (bperm < ntiles) {   // block-uniform: every wave of the block runs the same number of barriers
-    if (wave == 0) chain2_body<LT, DOT, NW, 0>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1);
-    else if (wave == NW - 1) chain2_body<LT, DOT, NW, 2>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1);
-    else chain2_body<LT, DOT, NW, 1>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1);
+    if (wave == 0) chain2_body<LT, MODE, NW, 0>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
+    else if (wave == NW - 1) chain2_body<LT, MODE, NW, 2>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
+    else chain2_body<LT, MODE, NW, 1>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
   }
   if (DOT) {
     auto sx = [](double v, int mask) {
@@ -449,42 +505,45 @@ static long pat_grid(long span, long ntiles) {
   return g < ntiles ? g : ntiles;
 }
 
-template <int LT, int DOT>
+template <int LT, int MODE>
 static long pat_launch(long nrows, const unsigned short* pid, const void* tab, int npat, const double* x, size_t ldx,
                        double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st,
-                       long cline = 0, int nw = 4) {
+                       long cline, int nw, const CgArgs& cg) {
   const int ntab = npat * LT;
   if (cline > 0) {   // chain + line exchange: nw waves per block, lines of `cline` rows
     if (LT < 5) return -1;
     const long nlines = (nrows + cline - 1) / cline, ntl = (nlines + nw - 1) / nw * (cline / 8);
-#define GCGE_C2(NWV) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), DOT, NWV>), dim3((unsigned)nb), dim3(64 * NWV), \
-                       (size_t)ntab * sizeof(PatEntry), st, nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, ntl, cline, partial, yy_off, g_chain2_xcd)
+#define GCGE_C2(NWV) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), MODE, NWV>), dim3((unsigned)nb), dim3(64 * NWV), \
+                       (size_t)ntab * sizeof(PatEntry), st, nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, ntl, cline, partial, yy_off, g_chain2_xcd, cg)
     if (nw == 16) GCGE_C2(16); else if (nw == 8) GCGE_C2(8); else GCGE_C2(4);
 #undef GCGE_C2
     return nb;
   }
   if (line < 0) {   // chain variant: consecutive slices, the caller fixed nb = S / 32
-    const long lpr = -line;   // chain variant: lanes per row is passed as -line (8, 16 or 32)
-    const long tr = 256 / lpr, ntl = (nrows + tr - 1) / tr;
-#define GCGE_CH(L) hipLaunchKernelGGL((spmm_pattern_chain_kernel<LT, DOT, L>), dim3((unsigned)nb), dim3(256), \
+    if constexpr (MODE >= 2) return -1;   // the CG passes exist for the chain2 and the plain kernel
+    else {
+      const long lpr = -line;   // chain variant: lanes per row is passed as -line (8, 16 or 32)
+      const long tr = 256 / lpr, ntl = (nrows + tr - 1) / tr;
+#define GCGE_CH(L) hipLaunchKernelGGL((spmm_pattern_chain_kernel<LT, MODE, L>), dim3((unsigned)nb), dim3(256), \
                        (size_t)ntab * sizeof(PatEntry), st, nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, ntl, partial, yy_off)
-    if (lpr == 32) GCGE_CH(32); else if (lpr == 16) GCGE_CH(16); else GCGE_CH(8);
+      if (lpr == 32) GCGE_CH(32); else if (lpr == 16) GCGE_CH(16); else GCGE_CH(8);
 #undef GCGE_CH
-    return nb;
+      return nb;
+    }
   }
-  hipLaunchKernelGGL((spmm_pattern_kernel<LT, DOT>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
-                     nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, pat_ntiles(nrows, line), line, partial, yy_off);
+  hipLaunchKernelGGL((spmm_pattern_kernel<LT, MODE>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
+                     nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, pat_ntiles(nrows, line), line, partial, yy_off, cg);
   return nb;
 }
 
-template <int DOT>
+template <int MODE>
 static long pat_dispatch(int lt, long nrows, const unsigned short* pid, const void* tab, int npat, const double* x,
                          size_t ldx, double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st,
-                         long cline = 0, int nw = 4) {
+                         long cline = 0, int nw = 4, const CgArgs& cg = CgArgs{}) {
   switch (lt) {
-    case 7: return pat_launch<7, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw);
-    case 8: return pat_launch<8, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw);
-    case 16: return pat_launch<16, DOT>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw);
+    case 7: return pat_launch<7, MODE>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
+    case 8: return pat_launch<8, MODE>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
+    case 16: return pat_launch<16, MODE>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
     default: return -1;
   }
 }
@@ -576,5 +635,47 @@ extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, con
   }
   if (d_dots) gcge_hip_reduce_partials16(part, (int)nb, nb * 16, ncols, d_dots, st);   // all passes in one launch
   if (d_dots && d_dots_yy) gcge_hip_reduce_partials16(part + yyo, (int)nb, nb * 16, ncols, d_dots_yy, st);
+  return (int)hipGetLastError();
+}
+
+// The two passes of a block-CG iteration on a pattern matrix (MODE 2 and 3 above; block_pcg.hip):
+//   mode 2: d_dots[j] = sum_r X[r,j] (A X)[r,j], d_dots_yy[j] = sum_r (A X)[r,j]^2; nothing is stored
+//   mode 3: R -= (A X) diag(alpha); PNEW = R diag(cr) + X diag(cb); d_dots[j] = sum_r cr_j R[r,j]^2  (d_dots_yy unused)
+// Geometry as gcge_hip_pattern_spmm; a chain-layout table without line exchange runs through the plain kernel
+// (its table is a valid generic one).  -1: not applicable (alignment), the caller keeps the unfused recurrence.
+extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+                                   long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
+                                   long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
+                                   double* d_dots, double* d_dots_yy, void* stream) {
+  if (mode != 2 && mode != 3) return -1;
+  if (nrows <= 0 || ncols <= 0) return 0;
+  if ((ncols & 1) || (ldx & 1) || ((uintptr_t)d_x & 15) || d_dots == nullptr) return -1;
+  if (mode == 3 && ((ldr & 1) || (ldp & 1) || ((uintptr_t)d_r & 15) || ((uintptr_t)d_pnew & 15) || d_pnew == d_x)) return -1;
+  if ((size_t)npat * lt * sizeof(PatEntry) > 64 * 1024) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const int npass = (ncols + 15) / 16;
+  int nw = 0;
+  if (span2 <= -8 && (-span2) % 8 == 0 && lt >= 5)
+    for (int cand = g_chain2_nw; cand >= 4; cand /= 2)
+      if (span % (cand * -span2) == 0 && (long)nrows >= cand * -span2) { nw = cand; break; }
+  const long L = -span2;
+  long nb, line = 8, cline = 0;
+  if (nw > 0) { nb = std::min(span / (8L * nw), ((((long)nrows + L - 1) / L + nw - 1) / nw) * (L / 8)); cline = L; }
+  else nb = pat_grid(span, pat_ntiles(nrows, line));
+  double* part = gcge_hip_partial_ws((size_t)nb * 16 * npass * 2);
+  const long yyo = (long)nb * 16 * npass;
+  for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
+    const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
+    double* pp = part + (size_t)ps * nb * 16;
+    long rc;
+    if (mode == 2) rc = pat_dispatch<2>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw);
+    else {
+      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0};
+      rc = pat_dispatch<3>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
+    }
+    if (rc < 0) return -1;
+  }
+  gcge_hip_reduce_partials16(part, (int)nb, nb * 16, ncols, d_dots, st);
+  if (mode == 2 && d_dots_yy) gcge_hip_reduce_partials16(part + yyo, (int)nb, nb * 16, ncols, d_dots_yy, st);
   return (int)hipGetLastError();
 }

@@ -78,11 +78,17 @@ void gcge_hip_set_random_mode (int mode, unsigned long long seed);
  * call this once, then run the harness with flag = 1.                                  */
 void gcge_hip_bpcg_setup (struct OPS_ *ops, int max_iter, double rate, double tol, const char *tol_type);
 void gcge_hip_bpcg_stats (long *spmm_calls, long *spmm_cols, int *last_niter);
+/* iterations the fused solver ran in its recompute form (pattern matrices: the product A p is formed twice per
+ * iteration and never stored, gcge_hip_cg_pass1_mv / gcge_hip_cg_pass2_mv); GCGE_CG_NO_RECOMPUTE=1 switches it off */
+long gcge_hip_bpcg_recompute_iters (void);
 void gcge_hip_bpcg_release (struct OPS_ *ops);
 
 /* ---- live measurement of the K1 launches (HIP events on the launch stream) ---------- */
 void gcge_hip_profile_enable (int on);        /* also clears what was recorded            */
 long gcge_hip_profile_spmm (int ncols, double *total_ms, double *total_alg_bytes);
+/*     by kind: 0 = MatDotMultiVec products (what gcge_hip_profile_spmm returns), 2 / 3 = first / second pass of a
+ *     block-CG iteration in its recompute form (below); ncols == 0: all widths                                    */
+long gcge_hip_profile_kind (int kind, int ncols, double *total_ms, double *total_alg_bytes);
 
 /* ---- raw kernels (what the slots launch; exposed for micro-benchmarks) --------- */
 /* K1  Y[:,0:m) = A X[:,0:m);  x/y point at (row 0, first column); see csrc/hip/spmm*.hip */
@@ -108,6 +114,20 @@ void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > pad-8 > CSR)
  *     longest and second longest |offset| of the interior stencil: launch geometry only); d_dots may be NULL.  gcge_hip_mat_patterns() tells whether a matrix qualified (0: served by the generic kernels).       */
 int gcge_hip_pattern_spmm (int nrows, const unsigned short *d_pid, const void *d_tab, int npat, int lt, long span, long span2,
 		const double *d_x, long ldx, double *d_y, long ldy, int ncols, double *d_dots, double *d_dots_yy, void *stream);
+/*     the two passes of a block-CG iteration on a pattern matrix (reference recurrences: src/ops_lin_sol.c:296-380;
+ *     here w = A p is formed twice and never stored).  mode 2: d_dots[j] = sum_r x[r,j] (A x)[r,j], d_dots_yy[j] =
+ *     sum_r (A x)[r,j]^2, nothing written.  mode 3: r -= (A x) diag(alpha), pnew = r diag(cr) + x diag(cb),
+ *     d_dots[j] = sum_r cr_j r[r,j]^2, with (alpha, cb, cr)_j = flag_j ? (alpha_j, beta_j, 1) : (0, 1, 0); pnew != x.
+ *     -1: operands do not qualify (the caller keeps the stored-w form)                                              */
+int gcge_hip_pattern_cg (int mode, int nrows, const unsigned short *d_pid, const void *d_tab, int npat, int lt,
+		long span, long span2, const double *d_x, long ldx, double *d_r, long ldr, double *d_pnew, long ldp, int ncols,
+		const double *d_alpha, const double *d_beta, const int *d_flag, double *d_dots, double *d_dots_yy, void *stream);
+/*     the same on operator-table objects (halo rows of p fetched by pass 1 and reused by pass 2; sums are the LOCAL
+ *     parts, on the host); gcge_hip_cg_fusable: 1 if (mat, p, ncols) qualify                                        */
+int gcge_hip_cg_fusable (void *mat, void **p, int ncols);
+int gcge_hip_cg_pass1_mv (void *mat, void **p, int c0, int m, double *host_pw, double *host_ww);
+int gcge_hip_cg_pass2_mv (void *mat, void **p, void **r, void **pnew, int c0, int m, const double *d_alpha,
+		const double *d_beta, const int *d_flag, double *host_rho);
 int gcge_hip_pattern_width (int max_row_len);
 int gcge_hip_mat_patterns (const GCGE_HIP_MAT *A);
 int gcge_hip_mat_pattern_chain (const GCGE_HIP_MAT *A);   /* 0 none, 1 chain layout (span2 == -1), 2 chain + line exchange (span2 == -L) */

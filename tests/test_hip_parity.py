@@ -343,3 +343,81 @@ def test_full_size_spmm_properties(hip):
     for hnd in (x, y, ax, ay, ones):
         ops.mv_destroy(hnd)
     hip.free_matrix(mh)
+
+
+@pytest.mark.parametrize("kind,size,which,m", [("lap3d", 16, "A", 22), ("lap3d", 16, "A", 64), ("lap3d", 12, "A", 6),
+                                               ("fe3d", 12, "A", 10), ("fe3d", 12, "B", 16), ("lap3d", 20, "A", 2)])
+def test_cg_recompute_passes_match_numpy(hip, kind, size, which, m):
+    """The two passes of a block-CG iteration in its recompute form (gcge_hip_cg_pass1_mv / pass2_mv: A p formed twice,
+    never stored) against numpy, on the three kernel routes (chain + line exchange, plain pattern kernel with a
+    chain-layout table, plain pattern kernel with 16 slots), ragged widths, retired columns."""
+    import torch
+    from helpers import csr_to_scipy, uniform
+    A, B = make_problem(kind, size)
+    M = A if which == "A" else B
+    S = csr_to_scipy(M)
+    n = M.nrows
+    mat = hip.matrix(M)
+    g = hip.g
+    g.gcge_hip_cg_fusable.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    g.gcge_hip_cg_pass1_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    g.gcge_hip_cg_pass2_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    ncol = m + 4                                   # the passes work on columns [2, 2 + m) of wider blocks
+    P = uniform(11, (n, ncol)) - 0.5
+    R = uniform(12, (n, ncol)) - 0.5
+    p, r = hip.mv_from_numpy(mat, P), hip.mv_from_numpy(mat, R)
+    pn = hip.mv_from_numpy(mat, np.full((n, ncol), 7.0))
+    assert g.gcge_hip_mat_patterns(mat) > 0 and g.gcge_hip_cg_fusable(mat, p, m) == 1
+    W = S @ P[:, 2:2 + m]
+    pw, ww = np.zeros(m), np.zeros(m)
+    assert g.gcge_hip_cg_pass1_mv(mat, p, 2, m, pw.ctypes.data, ww.ctypes.data) == 0
+    np.testing.assert_allclose(pw, np.sum(P[:, 2:2 + m] * W, axis=0), rtol=1e-12, atol=1e-12 * n)
+    np.testing.assert_allclose(ww, np.sum(W * W, axis=0), rtol=1e-12)
+    alpha = uniform(13, (m,)) + 0.5
+    beta = uniform(14, (m,)) + 0.1
+    flag = np.ones(m, dtype=np.int32)
+    flag[1::3] = 0                                  # retired columns: r untouched, p copied
+    d_al, d_be, d_fl = torch.from_numpy(alpha).cuda(), torch.from_numpy(beta).cuda(), torch.from_numpy(flag).cuda()
+    rho = np.zeros(m)
+    assert g.gcge_hip_cg_pass2_mv(mat, p, r, pn, 2, m, d_al.data_ptr(), d_be.data_ptr(), d_fl.data_ptr(), rho.ctypes.data) == 0
+    act = flag.astype(bool)
+    Rn = R[:, 2:2 + m] - W * np.where(act, alpha, 0.0)
+    Pn = np.where(act, 1.0, 0.0) * Rn + np.where(act, beta, 1.0) * P[:, 2:2 + m]
+    got_r, got_p = hip.mv_to_numpy(r, n, 0, ncol), hip.mv_to_numpy(pn, n, 0, ncol)
+    np.testing.assert_allclose(got_r[:, 2:2 + m], Rn, rtol=0, atol=1e-13 * np.abs(W).max() + 1e-15)
+    np.testing.assert_allclose(got_p[:, 2:2 + m], Pn, rtol=0, atol=1e-13 * np.abs(W).max() + 1e-15)
+    assert np.array_equal(got_r[:, 2:2 + m][:, ~act], R[:, 2:2 + m][:, ~act])          # bit-for-bit untouched
+    assert np.array_equal(got_p[:, 2:2 + m][:, ~act], P[:, 2:2 + m][:, ~act])
+    for blk, ref in ((got_r, R), (got_p, np.full((n, ncol), 7.0))):                     # columns outside the window
+        assert np.array_equal(blk[:, :2], ref[:, :2]) and np.array_equal(blk[:, 2 + m:], ref[:, 2 + m:])
+    np.testing.assert_allclose(rho, np.sum(np.where(act, 1.0, 0.0) * Rn * Rn, axis=0), rtol=1e-12)
+    assert np.array_equal(hip.mv_to_numpy(p, n, 0, ncol), P)
+    for v in (p, r, pn):
+        hip.ops.mv_destroy(v, ncol)
+    hip.free_matrix(mat)
+
+
+def test_gcg_recompute_cg_equals_stored_product_cg(hip):
+    """Whole eigensolves with the fused CG in its recompute form and with the product stored (GCGE_CG_NO_RECOMPUTE=1):
+    same recurrences on the same operands, so the same iteration counts and Ritz values to rounding."""
+    import os
+    g = hip.g
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    g.gcge_hip_bpcg_recompute_iters.restype = C.c_long
+    out = {}
+    for tag in ("recompute", "stored"):
+        if tag == "stored":
+            os.environ["GCGE_CG_NO_RECOMPUTE"] = "1"
+        try:
+            g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+            hip.set_random_mode(0)
+            before = g.gcge_hip_bpcg_recompute_iters()
+            ev, res = gcg_on(hip, "lap3d", 16, ["-nevConv", 12, "-nevMax", 24, "-blockSize", 8], flag=1)
+            out[tag] = (ev[:res.nevConv].copy(), res.nevConv, res.numIter, g.gcge_hip_bpcg_recompute_iters() - before)
+        finally:
+            os.environ.pop("GCGE_CG_NO_RECOMPUTE", None)
+    assert out["recompute"][3] > 0 and out["stored"][3] == 0, (out["recompute"][3], out["stored"][3])
+    assert out["recompute"][1] == out["stored"][1] and abs(out["recompute"][2] - out["stored"][2]) <= 1
+    k = out["stored"][1]
+    assert np.max(np.abs(out["recompute"][0][:k] - out["stored"][0][:k]) / np.abs(out["stored"][0][:k])) < 1e-11
