@@ -41,7 +41,10 @@ def parse():
     return ap.parse_args()
 
 
-PMC_PASS2 = None   # bytes per 64-column launch of the second CG pass at C2 (set from profiles/r01_bench/12_cg_pass_pmc.txt)
+# fabric bytes per 64-column launch at C2 (256^3, chain2 kernels) from profiles/r01_bench/12_cg_pass_pmc.txt:
+# 4 passes x (TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B)
+PMC_PASS1 = 4 * (2.33868e7 * 128 + 2048 * 64)
+PMC_PASS2 = 4 * (4.74877e7 * 128 + 6.71114e7 * 64)
 
 
 def cpu_baseline(args):
@@ -219,7 +222,8 @@ def main():
                     4 * (2.35094e7 * 128 + 3.35544e7 * 64) if pmc_ok else None,
                     "4 passes x (2.351e7 x 128 B reads + 3.355e7 x 64 B writes), profiles/r01_spmm_explore/23_chain2_pmc.log"
                     if pmc_ok else "no PMC profile for this shape")
-        r_p1 = roof(2, "CG pass 1, p.Ap and |Ap|^2 without storing Ap")
+        r_p1 = roof(2, "CG pass 1, p.Ap and |Ap|^2 without storing Ap", PMC_PASS1 if pmc_ok else None,
+                    "profiles/r01_bench/12_cg_pass_pmc.txt" if pmc_ok else "no PMC profile for this shape")
         r_p2 = roof(3, "CG pass 2, Ap recomputed + r -= alpha Ap, p' = r + beta p",
                     PMC_PASS2 if pmc_ok and PMC_PASS2 else None,
                     "profiles/r01_bench/12_cg_pass_pmc.txt" if pmc_ok and PMC_PASS2 else "no PMC profile for this shape")
