@@ -924,6 +924,32 @@ extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, 
   return 0;
 }
 
+// Residuals of Ritz pairs of a standard problem in one read of x (GCGE_RESIDUAL_FN, include/gcge_ops.h; kernel MODE 4 of
+// spmm_pattern.hip): res_sq[j] = sum over the local rows of ((A x_j) - lambda_j x_j)^2.  Declines (0) for B != NULL,
+// matrices without pattern form, blocks that cannot be walked in 16-byte column pairs.  Odd column ranges are widened
+// to even ones (the extra columns are computed and dropped).
+static int HIP_ResidualSq(void* mat, void* matB, void** x, int start, int end, const double* lambda, double* res_sq) {
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat; GcgeHipMV* vx = (GcgeHipMV*)x;
+  if (A == nullptr || matB != nullptr || end <= start) return 0;
+  const int c0 = start & ~1, c1 = (end + 1) & ~1, m = c1 - c0;
+  if (c1 > vx->ld || !gcge_hip_cg_fusable(mat, x, m) || A->nrows != vx->nrows) return 0;
+  double* dd = stage_d(7 * (size_t)m);
+  double* d_lam = dd + 6 * (size_t)m;
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));   // the pinned staging may still feed an upload of the previous slot call
+  double* hl = stage_h(2 * (size_t)m);
+  for (int j = 0; j < m; ++j) hl[j] = (c0 + j >= start && c0 + j < end) ? lambda[c0 + j - start] : 0.0;
+  GCGE_HIP_CHECK(hipMemcpyAsync(d_lam, hl, m * sizeof(double), hipMemcpyHostToDevice, g_stream));
+  const CgPass cg = {4, nullptr, 0, nullptr, 0, d_lam, nullptr, nullptr};
+  const int rc = spmm_halo(A, vx, c0, nullptr, 0, m, dd, nullptr, &cg);
+  GCGE_REQUIRE(rc == 0, "residual norms: kernel launch");
+  GCGE_HIP_CHECK(hipMemcpyAsync(hl + m, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+  for (int j = start; j < end; ++j) res_sq[j - start] = hl[m + (j - c0)];
+  return 1;
+}
+
+extern "C" void* gcge_hip_residual_hook(void) { return (void*)HIP_ResidualSq; }   /* for tests */
+
 // app_ccs.c:140-150 — symmetric matrices only
 static void HIP_MatTransDotMultiVec(void* mat, void** x, void** y, int* start, int* end, struct OPS_* ops) {
   HIP_MatDotMultiVec(mat, x, y, start, end, ops);
@@ -947,6 +973,7 @@ extern "C" void OPS_HIP_Set(struct OPS_* ops) {
   ops->MultiVecAxpby            = HIP_MultiVecAxpby;
   ops->MultiVecLinearComb       = HIP_MultiVecLinearComb;
   ops->MatDotMultiVec           = HIP_MatDotMultiVec;
+  GCGE_SetResidualHook(HIP_ResidualSq, (void*)HIP_MatDotMultiVec);   /* used by our GCG driver for this table only */
   ops->MatTransDotMultiVec      = HIP_MatTransDotMultiVec;
   ops->MultiVecQtAP             = nullptr;   // OPS_Setup installs SpMM-into-mv_ws + Gram
 }

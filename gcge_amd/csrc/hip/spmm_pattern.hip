@@ -50,6 +50,8 @@ struct PatEntry { double val; long off; };   // 16 bytes: one ds_read_b128
 //        R[r,j] -= alpha_j w[r,j] ;  PNEW[r,j] = cr_j R[r,j] + cb_j X[r,j] ;  partial: sum_r cr_j R[r,j]^2
 //      with (alpha, cb, cr) = flag_j ? (alpha_j, beta_j, 1) : (0, 1, 0) exactly as cg_update_rp (retired columns are
 //      copied).  X = p_k, PNEW = p_{k+1} must be different blocks: neighbours still read X.
+//   4  residual norms of Ritz pairs (standard problem): partial: sum_r ((A X)[r,j] - lambda_j X[r,j])^2 with
+//      lambda = cg.alpha; nothing is stored (CheckConvergence of the GCG driver, one read of X instead of 11 streams)
 struct CgArgs { double* r; size_t ldr; double* pnew; size_t ldp; const double* alpha; const double* beta; const int* flag; };
 struct CgCoef { double al0, al1, cb0, cb1, cr0, cr1; };
 __device__ __forceinline__ CgCoef cg_coef(const CgArgs& cg, int j, bool act) {
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
     double* __restrict__ dot_partial, long yy_offset, CgArgs cg) {
   constexpr int DOT = MODE != 0;       // the row's own X value rides in buf[LT]
   constexpr int UPD = MODE == 3;       // its R value in buf[LT + 1]
+  constexpr int RES = MODE == 4;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
   for (int e = threadIdx.x; e < ntab; e += 256) s_tab[e] = tab[e];
@@ -79,7 +82,8 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
   const bool act = 2 * i < m;
   const double* __restrict__ xl = x + (act ? 2 * i : 0);   // idle lanes of a narrow last pass re-read column 0
   const double* __restrict__ rl = UPD ? cg.r + (act ? 2 * i : 0) : nullptr;
-  const CgCoef cf = UPD ? cg_coef(cg, 2 * i, act) : CgCoef{0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
+  CgCoef cf = UPD ? cg_coef(cg, 2 * i, act) : CgCoef{0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
+  if (RES && act) { cf.al0 = cg.alpha[2 * i]; cf.al1 = cg.alpha[2 * i + 1]; }   // lambda of this lane's column pair
   double d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;   // x.y and y.y column sums (DOT)
 
   // tile t = (group of 4 lines q, slice a inside the line); wave w takes line 4q + w
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
       for (int t = 0; t < LT; ++t) { a0 = fma(val[t], buf[t].x, a0); a1 = fma(val[t], buf[t].y, a1); }
       const long row = first_row(blockIdx.x + it * G) + g;   // unclamped: surplus iterations and tail rows store nothing
       const bool ok = it < cnt && row < nrows && act;
-      if ((MODE <= 1 && ok) || (MODE == 2 && ok && y != nullptr)) {   // MODE 2: y == NULL, see chain2_body
+      if ((MODE <= 1 && ok) || ((MODE == 2 || RES) && ok && y != nullptr)) {   // MODE 2, 4: y == NULL, see chain2_body
         v2d o = {a0, a1};
         __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(y + (size_t)row * ldy + 2 * i));
       }
@@ -122,6 +126,10 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
           __builtin_nontemporal_store(pn, reinterpret_cast<v2d*>(cg.pnew + (size_t)row * cg.ldp + 2 * i));
         }
         d0 = fma(cf.cr0 * wgt * rn.x, rn.x, d0); d1 = fma(cf.cr1 * wgt * rn.y, rn.y, d1);
+      }
+      if (RES) {
+        const double q0 = fma(-cf.al0, buf[LT].x, a0), q1 = fma(-cf.al1, buf[LT].y, a1);
+        d0 = fma(q0 * wgt, q0, d0); d1 = fma(q1 * wgt, q1, d1);
       }
     };
     v2d b0[LT + DOT + UPD], b1[LT + DOT + UPD];
@@ -348,7 +356,7 @@ __device__ __forceinline__ void chain2_body(
     const bool ok = it < cnt && row < nrows && act;
     // MODE 2 stores nothing (the launcher passes y == NULL), but keeps the never-taken branch: without it hipcc
     // schedules the straight-line body into 200+ VGPRs / spills (118 with it), measured on the resource remarks
-    if ((MODE <= 1 && ok) || (MODE == 2 && ok && y != nullptr)) {
+    if ((MODE <= 1 && ok) || ((MODE == 2 || MODE == 4) && ok && y != nullptr)) {
       v2d o = {a0, a1};
       __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(y + (size_t)row * ldy + 2 * i));
     }
@@ -367,6 +375,11 @@ __device__ __forceinline__ void chain2_body(
         __builtin_nontemporal_store(pn, reinterpret_cast<v2d*>(cg.pnew + (size_t)row * cg.ldp + 2 * i));
       }
       d0 = fma(cr.x * wgt * rn.x, rn.x, d0); d1 = fma(cr.y * wgt * rn.y, rn.y, d1);
+    }
+    if (MODE == 4) {
+      const v2d lam = s_cf[i];
+      const double q0 = fma(-lam.x, b.x, a0), q1 = fma(-lam.y, b.y, a1);
+      d0 = fma(q0 * wgt, q0, d0); d1 = fma(q1 * wgt, q1, d1);
     }
     xch[buf ^ 1][wave][lane] = c;   // the centre row of my next iteration
   };
@@ -420,6 +433,8 @@ __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
     const CgCoef c = cg_coef(cg, 2 * threadIdx.x, 2 * (int)threadIdx.x < m);
     s_cf[threadIdx.x] = v2d{c.al0, c.al1}; s_cf[8 + threadIdx.x] = v2d{c.cb0, c.cb1}; s_cf[16 + threadIdx.x] = v2d{c.cr0, c.cr1};
   }
+  if (MODE == 4 && threadIdx.x < 8)
+    s_cf[threadIdx.x] = (2 * (int)threadIdx.x < m) ? v2d{cg.alpha[2 * threadIdx.x], cg.alpha[2 * threadIdx.x + 1]} : v2d{0.0, 0.0};
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 3, i = lane & 7;
@@ -641,13 +656,14 @@ extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, con
 // The two passes of a block-CG iteration on a pattern matrix (MODE 2 and 3 above; block_pcg.hip):
 //   mode 2: d_dots[j] = sum_r X[r,j] (A X)[r,j], d_dots_yy[j] = sum_r (A X)[r,j]^2; nothing is stored
 //   mode 3: R -= (A X) diag(alpha); PNEW = R diag(cr) + X diag(cb); d_dots[j] = sum_r cr_j R[r,j]^2  (d_dots_yy unused)
+//   mode 4: d_dots[j] = sum_r ((A X)[r,j] - alpha_j X[r,j])^2  (residuals of Ritz pairs, alpha = the Ritz values)
 // Geometry as gcge_hip_pattern_spmm; a chain-layout table without line exchange runs through the plain kernel
 // (its table is a valid generic one).  -1: not applicable (alignment), the caller keeps the unfused recurrence.
 extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                    long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
                                    long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
                                    double* d_dots, double* d_dots_yy, void* stream) {
-  if (mode != 2 && mode != 3) return -1;
+  if (mode != 2 && mode != 3 && mode != 4) return -1;
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || ((uintptr_t)d_x & 15) || d_dots == nullptr) return -1;
   if (mode == 3 && ((ldr & 1) || (ldp & 1) || ((uintptr_t)d_r & 15) || ((uintptr_t)d_pnew & 15) || d_pnew == d_x)) return -1;
@@ -669,7 +685,10 @@ extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_
     double* pp = part + (size_t)ps * nb * 16;
     long rc;
     if (mode == 2) rc = pat_dispatch<2>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw);
-    else {
+    else if (mode == 4) {
+      const CgArgs cg = {nullptr, 0, nullptr, 0, d_alpha + c0, nullptr, nullptr};
+      rc = pat_dispatch<4>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
+    } else {
       const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0};
       rc = pat_dispatch<3>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
     }

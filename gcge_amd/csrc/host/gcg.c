@@ -108,7 +108,13 @@ static int CheckConvergence(Ctx *c, int numCheck, int *offset)
 	struct OPS_ *ops = c->ops; GCGSolver *p = c->p;
 	double *res = c->scratch, *tol = p->tol, *ev = c->ss_eval + c->startN;
 	int s[2], e[2], idx, state, nun, nevConv; double t0 = ops->GetWtime();
-	if (numCheck > 0) {
+	GCGE_RESIDUAL_FN hook = GCGE_GetResidualHook((void*)ops->MatDotMultiVec);
+	if (numCheck > 0 && hook != NULL && getenv("GCGE_NO_RESIDUAL_HOOK") == NULL &&
+			hook(c->A, c->B, c->ritz, c->startN, c->startN + numCheck, ev, res)) {
+		GCGE_COMM *comm = GCGE_GetComm();          /* the back-end summed over its own rows */
+		if (comm != NULL) comm->allreduce_sum(res, numCheck, comm->ctx);
+		for (idx = 0; idx < numCheck; ++idx) res[idx] = sqrt(res[idx]);
+	} else if (numCheck > 0) {
 		s[0] = c->startN; e[0] = c->startN + numCheck; s[1] = 0; e[1] = numCheck;
 		ops->MatDotMultiVec(c->A, c->ritz, c->ws0, s, e, ops);
 		ops->MatDotMultiVec(c->B, c->ritz, c->ws1, s, e, ops);

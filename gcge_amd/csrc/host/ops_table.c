@@ -33,6 +33,10 @@ void GCGE_SetComm(const GCGE_COMM *comm)
 }
 GCGE_COMM *GCGE_GetComm(void) { return g_comm; }
 
+static GCGE_RESIDUAL_FN g_res_hook = NULL; static void *g_res_owner = NULL;
+void GCGE_SetResidualHook(GCGE_RESIDUAL_FN fn, void *owner) { g_res_hook = fn; g_res_owner = owner; }
+GCGE_RESIDUAL_FN GCGE_GetResidualHook(void *owner) { return (g_res_hook != NULL && owner == g_res_owner) ? g_res_hook : NULL; }
+
 static double g_ls_sigma = 0.0; static void *g_ls_matB = NULL;
 void GCGE_SetLinearSolverShift(double sigma, void *matB) { g_ls_sigma = sigma; g_ls_matB = matB; }
 void GCGE_GetLinearSolverShift(double *sigma, void **matB)

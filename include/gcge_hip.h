@@ -125,6 +125,9 @@ int gcge_hip_pattern_cg (int mode, int nrows, const unsigned short *d_pid, const
 /*     the same on operator-table objects (halo rows of p fetched by pass 1 and reused by pass 2; sums are the LOCAL
  *     parts, on the host); gcge_hip_cg_fusable: 1 if (mat, p, ncols) qualify                                        */
 int gcge_hip_cg_fusable (void *mat, void **p, int ncols);
+/*     the GCGE_RESIDUAL_FN (include/gcge_ops.h) OPS_HIP_Set registers: squared residual norms of Ritz pairs of a
+ *     standard problem in one read of x (kernel MODE 4); returned as void* for test harnesses                    */
+void *gcge_hip_residual_hook (void);
 int gcge_hip_cg_pass1_mv (void *mat, void **p, int c0, int m, double *host_pw, double *host_ww);
 int gcge_hip_cg_pass2_mv (void *mat, void **p, void **r, void **pnew, int c0, int m, const double *d_alpha,
 		const double *d_beta, const int *d_flag, double *host_rho);

@@ -146,6 +146,14 @@ GCGE_COMM *GCGE_GetComm (void);
  * drives the REFERENCE's GCG sets a fixed shift itself.  sigma == 0: no shift. */
 void       GCGE_SetLinearSolverShift (double sigma, void *matB);
 void       GCGE_GetLinearSolverShift (double *sigma, void **matB);
+/* Optional fast path of CheckConvergence (src/ops_eig_sol_gcg.c:195-315 forms A x, B x, lambda B x, the difference and
+ * its column norms through five slots = 11 block streams).  A back-end may offer the squared residual norms
+ *   res_sq[j] = sum over its LOCAL rows of ((A x_j) - lambda_j (B x_j))^2 ,  j = start .. end-1  (columns of x)
+ * in one go; it returns 1 if it did, 0 to decline (the driver then takes the slots).  `owner` ties the hook to one
+ * operator table: it is only used when ops->MatDotMultiVec == owner.  The driver sums over ranks (GCGE_COMM). */
+typedef int (*GCGE_RESIDUAL_FN) (void *A, void *B, void **x, int start, int end, const double *lambda, double *res_sq);
+void       GCGE_SetResidualHook (GCGE_RESIDUAL_FN fn, void *owner);
+GCGE_RESIDUAL_FN GCGE_GetResidualHook (void *owner);
 void       GCGE_SetQuiet (OPS *ops, int quiet);   /* silence ops->Printf (and the dense table's) */
 
 #ifdef __cplusplus

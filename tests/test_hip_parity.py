@@ -421,3 +421,45 @@ def test_gcg_recompute_cg_equals_stored_product_cg(hip):
     assert out["recompute"][1] == out["stored"][1] and abs(out["recompute"][2] - out["stored"][2]) <= 1
     k = out["stored"][1]
     assert np.max(np.abs(out["recompute"][0][:k] - out["stored"][0][:k]) / np.abs(out["stored"][0][:k])) < 1e-11
+
+
+@pytest.mark.parametrize("kind,size,start,end", [("lap3d", 16, 3, 14), ("lap3d", 16, 0, 16), ("lap3d", 12, 5, 6), ("lap3d", 20, 1, 24)])
+def test_residual_hook_matches_numpy(hip, kind, size, start, end):
+    """GCGE_RESIDUAL_FN of the HIP back-end (CheckConvergence in one read of x): odd and even column ranges."""
+    from helpers import csr_to_scipy, uniform
+    A, _ = make_problem(kind, size)
+    S = csr_to_scipy(A)
+    n = A.nrows
+    mat = hip.matrix(A)
+    X = uniform(21, (n, 26)) - 0.5
+    x = hip.mv_from_numpy(mat, X)
+    lam = uniform(22, (end - start,)) * 3.0
+    FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+    hip.g.gcge_hip_residual_hook.restype = C.c_void_p
+    fn = FN(hip.g.gcge_hip_residual_hook())
+    out = np.zeros(end - start)
+    assert fn(mat, None, x, start, end, lam.ctypes.data, out.ctypes.data) == 1
+    R = S @ X[:, start:end] - X[:, start:end] * lam
+    np.testing.assert_allclose(out, np.sum(R * R, axis=0), rtol=1e-12)
+    assert fn(mat, mat, x, start, end, lam.ctypes.data, out.ctypes.data) == 0      # generalised problem: declined
+    hip.ops.mv_destroy(x, 26)
+    hip.free_matrix(mat)
+
+
+def test_gcg_residual_hook_equals_slot_path(hip):
+    """Whole eigensolve with CheckConvergence through the hook and through the five slots: same locking decisions."""
+    import os
+    hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    out = {}
+    for tag in ("hook", "slots"):
+        if tag == "slots":
+            os.environ["GCGE_NO_RESIDUAL_HOOK"] = "1"
+        try:
+            hip.g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+            hip.set_random_mode(0)
+            ev, res = gcg_on(hip, "lap3d", 16, ["-nevConv", 12, "-nevMax", 24, "-blockSize", 8], flag=1)
+            out[tag] = (ev[:res.nevConv].copy(), res.nevConv, res.numIter)
+        finally:
+            os.environ.pop("GCGE_NO_RESIDUAL_HOOK", None)
+    assert out["hook"][1:] == out["slots"][1:], (out["hook"][1:], out["slots"][1:])
+    assert np.max(np.abs(out["hook"][0] - out["slots"][0]) / np.abs(out["slots"][0])) < 1e-12
