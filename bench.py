@@ -183,6 +183,9 @@ def main():
         c_ = g.gcge_hip_profile_kind(kind, ncols, C.byref(ms_), C.byref(by_))
         return int(c_), ms_.value, by_.value
 
+    ci, ai = C.c_long(), C.c_long()
+    g.gcge_hip_bpcg_column_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    g.gcge_hip_bpcg_column_stats(C.byref(ci), C.byref(ai))
     stats = {k: prof(k, args.block) for k in (0, 2, 3)}
     spmm_ms_all = sum(prof(k, 0)[1] for k in (0, 2, 3))
     g.gcge_hip_profile_enable(0)
@@ -239,6 +242,7 @@ def main():
                                    % (N, dims[0], dims[1], dims[2], n_global, args.nev, args.block, args.nevmax, args.orth),
                        "gcg_iterations": iters, "nev_converged": conv_total,
                        "max_rel_err_vs_closed_form": rel,
+                       "cg_active_column_fraction": (ai.value / ci.value) if ci.value else None,
                        "phase_seconds": {k: getattr(res.timing, k) for k in ("initX", "checkconv", "compP", "compRR", "compRV", "compW", "linsol", "total")}},
             # the dominant kernel of the step; the K1 product alone (the north-star figure) and the other CG pass follow
             "roofline": dominant,

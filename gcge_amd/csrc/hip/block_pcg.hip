@@ -392,6 +392,7 @@ struct HipBpcg {
   long spmm_calls, spmm_cols;   // statistics for bench.py
   double* d_coef; int* d_flag; double* h_pin; int cap;
   long recompute_iters;         // iterations run in the two-pass form with the product recomputed (pattern matrices)
+  long col_iters, active_col_iters;   // columns streamed per iteration, summed / of which still active (one-pass scheme)
 };
 static HipBpcg g_bpcg = {30, 1e-2, 1e-14, "abs", {nullptr, nullptr, nullptr, nullptr}, {nullptr}, 0, 0, 0, 0, -1.0, 0, 0, nullptr, nullptr, nullptr, 0};
 
@@ -544,6 +545,7 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
       ops->MultiVecAxpby(1.0, s->mv_ws[0], 0.0, s->ring_len ? s->ring[0] : s->mv_ws[1], st2, en2, ops);
     }
     while (niter < s->max_iter && nact > 0) {
+      s->col_iters += nrhs; s->active_col_iters += nact;
       int alo = 0, ahi = nrhs;
       if (R == 1) {   // (with a ring every column takes part in every step: the slots must stay complete)
         while (alo < nrhs && !active[alo]) ++alo;
@@ -713,6 +715,10 @@ extern "C" void gcge_hip_bpcg_stats(long* spmm_calls, long* spmm_cols, int* last
   if (last_niter) *last_niter = g_bpcg.niter;
 }
 extern "C" long gcge_hip_bpcg_recompute_iters(void) { return g_bpcg.recompute_iters; }
+extern "C" void gcge_hip_bpcg_column_stats(long* col_iters, long* active_col_iters) {
+  if (col_iters) *col_iters = g_bpcg.col_iters;
+  if (active_col_iters) *active_col_iters = g_bpcg.active_col_iters;
+}
 extern "C" void gcge_hip_bpcg_release(struct OPS_* ops) {
   for (int i = 1; i < g_bpcg.ring_len; ++i) if (g_bpcg.ring[i]) ops->MultiVecDestroy(&g_bpcg.ring[i], g_bpcg.ws_cols, ops);
   g_bpcg.ring_len = 0;

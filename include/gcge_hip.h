@@ -81,6 +81,8 @@ void gcge_hip_bpcg_stats (long *spmm_calls, long *spmm_cols, int *last_niter);
 /* iterations the fused solver ran in its recompute form (pattern matrices: the product A p is formed twice per
  * iteration and never stored, gcge_hip_cg_pass1_mv / gcge_hip_cg_pass2_mv); GCGE_CG_NO_RECOMPUTE=1 switches it off */
 long gcge_hip_bpcg_recompute_iters (void);
+/* columns the fused solver streamed, summed over its iterations, and how many of them were still active */
+void gcge_hip_bpcg_column_stats (long *col_iters, long *active_col_iters);
 void gcge_hip_bpcg_release (struct OPS_ *ops);
 
 /* ---- live measurement of the K1 launches (HIP events on the launch stream) ---------- */
