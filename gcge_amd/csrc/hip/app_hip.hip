@@ -869,6 +869,16 @@ extern "C" int gcge_hip_cg_fusable(void* mat, void** p, int ncols) {
   if (A->nghost > 0 && ncols > A->buf_cols) return 0;
   return 1;
 }
+// Does forming the product twice pay?  Only where the product kernel is bound by HBM: the chain kernel with line exchange
+// (about 3 loads per row).  The plain pattern kernel issues 7+ cache-served loads per row and is bound by those, so a
+// second product costs more than the two block streams it saves (FE pair n = 10^6: 2.3 against 1.9 ms per iteration).
+// GCGE_CG_RECOMPUTE=1 forces the recompute form wherever it is possible.
+extern "C" int gcge_hip_cg_recompute_pays(void* mat) {
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
+  if (A == nullptr || A->d_pid == nullptr) return 0;
+  if (getenv("GCGE_CG_RECOMPUTE") != nullptr) return 1;
+  return gcge_hip_mat_pattern_chain(A) == 2;
+}
 // host_pw[j] = sum_r p[r,j] (A p)[r,j], host_ww[j] = sum_r (A p)[r,j]^2 over the LOCAL rows; fetches the halo rows of p
 extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* host_pw, double* host_ww) {
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat; GcgeHipMV* vp = (GcgeHipMV*)p;

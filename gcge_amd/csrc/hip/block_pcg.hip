@@ -48,6 +48,7 @@ extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, 
 extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots, double* host_yy,
                                       struct OPS_* ops);
 extern "C" int gcge_hip_cg_fusable(void* mat, void** p, int ncols);
+extern "C" int gcge_hip_cg_recompute_pays(void* mat);
 extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* host_pw, double* host_ww);
 extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
                                     const double* d_beta, const int* d_flag, double* host_rho);
@@ -539,7 +540,7 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
     // p.w and w.w, pass 2 reads p again and applies the r / p update with w rebuilt in registers (app_hip.hip:
     // gcge_hip_cg_pass1_mv / pass2_mv): 1 + 4 block streams per iteration instead of 2 + 5.  Same recurrences,
     // same operands, so alpha, beta and the iterates agree with the stored-w form to rounding of the sums.
-    const bool recompute = R > 1 && sigma == 0.0 && gcge_hip_cg_fusable(mat, s->ring[0], nrhs) && !(nrhs & 1);
+    const bool recompute = R > 1 && sigma == 0.0 && gcge_hip_cg_recompute_pays(mat) && gcge_hip_cg_fusable(mat, s->ring[0], nrhs) && !(nrhs & 1);
     if (nact > 0) {   // p0 = r0
       st2[0] = 0; en2[0] = nrhs; st2[1] = 0; en2[1] = nrhs;
       ops->MultiVecAxpby(1.0, s->mv_ws[0], 0.0, s->ring_len ? s->ring[0] : s->mv_ws[1], st2, en2, ops);

@@ -127,6 +127,7 @@ int gcge_hip_pattern_cg (int mode, int nrows, const unsigned short *d_pid, const
 /*     the same on operator-table objects (halo rows of p fetched by pass 1 and reused by pass 2; sums are the LOCAL
  *     parts, on the host); gcge_hip_cg_fusable: 1 if (mat, p, ncols) qualify                                        */
 int gcge_hip_cg_fusable (void *mat, void **p, int ncols);
+int gcge_hip_cg_recompute_pays (void *mat);   /* 1: chain + line-exchange layout (HBM-bound product); GCGE_CG_RECOMPUTE=1 forces */
 /*     the GCGE_RESIDUAL_FN (include/gcge_ops.h) OPS_HIP_Set registers: squared residual norms of Ritz pairs of a
  *     standard problem in one read of x (kernel MODE 4); returned as void* for test harnesses                    */
 void *gcge_hip_residual_hook (void);
