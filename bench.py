@@ -44,7 +44,7 @@ def parse():
 # fabric bytes per 64-column launch at C2 (256^3, chain2 kernels) from profiles/r01_bench/12_cg_pass_pmc.txt:
 # 4 passes x (TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B)
 PMC_PASS1 = 4 * (2.33868e7 * 128 + 2048 * 64)
-PMC_PASS2 = 4 * (4.74877e7 * 128 + 6.71114e7 * 64)
+PMC_PASS2 = 4 * (4.16776e7 * 128 + 6.7111e7 * 64)      # 15_cg_pass_pmc_nt_residual_loads.txt (r read non-temporally)
 
 
 def cpu_baseline(args):
@@ -229,7 +229,7 @@ def main():
                     "profiles/r01_bench/12_cg_pass_pmc.txt" if pmc_ok else "no PMC profile for this shape")
         r_p2 = roof(3, "CG pass 2, Ap recomputed + r -= alpha Ap, p' = r + beta p",
                     PMC_PASS2 if pmc_ok and PMC_PASS2 else None,
-                    "profiles/r01_bench/12_cg_pass_pmc.txt" if pmc_ok and PMC_PASS2 else "no PMC profile for this shape")
+                    "profiles/r01_bench/15_cg_pass_pmc_nt_residual_loads.txt" if pmc_ok and PMC_PASS2 else "no PMC profile for this shape")
         cands = [r for r in (r_k1, r_p1, r_p2) if r is not None]
         dominant = max(cands, key=lambda r: r["share_of_step"]) if cands else None
         out = {

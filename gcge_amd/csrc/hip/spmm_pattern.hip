@@ -330,7 +330,7 @@ __device__ __forceinline__ void chain2_body(
   auto issue = [&](v2d& lnew, v2d (&edge)[NE + 1], v2d (&oth)[NO + 1 + UPD], long row, int p) {
     const PatEntry* e = s_tab + p * LT;
     lnew = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[2].off) * ldx);
-    if (UPD) oth[NO + UPD] = *reinterpret_cast<const v2d*>(rl + (size_t)row * cg.ldr);   // the row's residual
+    if (UPD) oth[NO + UPD] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(rl + (size_t)row * cg.ldr));   // the row's residual
     if (ROLE == 0) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[3].off) * ldx);
     if (ROLE == 2) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[4].off) * ldx);
 #pragma unroll
