@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--ref", action="store_true", help="also run the CPU reference (oracle/_ref) on the same input")
     ap.add_argument("--petsc", nargs="+", default=None, metavar="FILE",
                     help="PETSc binary Mat file(s): A [B] (the reference's -filename_matA / -filename_matB) instead of a generator")
+    ap.add_argument("--box", default=None, metavar="NX,NY,NZ",
+                    help="7-point Laplacian on an NX x NY x NZ grid instead of --kind/--size (e.g. 512,512,64: the slab one of 8 ranks owns at BASELINE config 4)")
     ap.add_argument("--extra", nargs="*", default=[])
     a = ap.parse_args()
 
@@ -42,7 +44,14 @@ def main():
     import torch  # noqa: F401  (one libamdhip64 for torch and the extension)
     from gcge_amd import HipBackend, load_petsc_binary, make_problem, run_gcg
     t0 = time.perf_counter()
-    if a.petsc:
+    if a.box:
+        from gcge_amd.lib import CSR, host_lib
+        nx, ny, nz = (int(t) for t in a.box.split(","))
+        A, B = CSR(), None
+        if host_lib().gcge_problem_lap3d_box(C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int64(0), C.c_int64(-1), C.byref(A)) != 0:
+            raise RuntimeError("gcge_problem_lap3d_box failed")
+        a.kind, a.size = "lap3d_box:" + a.box, A.nrows
+    elif a.petsc:
         A = load_petsc_binary(a.petsc[0])
         B = load_petsc_binary(a.petsc[1]) if len(a.petsc) > 1 else None
         a.kind, a.size = "petsc:" + os.path.basename(a.petsc[0]), A.nrows
