@@ -1,9 +1,9 @@
-"""GPU robustness sweep: GCG with the fused one-pass block CG (flag 1) against the reference-form BlockPCG over the
+"""(script, not collected by pytest: python tests/sweep_fused_cg.py)  GPU robustness sweep: GCG with the fused one-pass block CG (flag 1) against the reference-form BlockPCG over the
 HIP slots (flag 0) — converged count, iteration count, Ritz values — over problem kinds, sizes and block shapes."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):     # tests/helpers.py loads the oracle
+    sys.path.insert(0, _p)
 import numpy as np
 import torch  # noqa
 from gcge_amd import HipBackend

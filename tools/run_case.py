@@ -1,13 +1,13 @@
 """Run one eigenproblem through the HIP operator table and check it independently.
 
     python tools/run_case.py --kind fe3d --size 100 --nev 100 --block 128 --nevmax 256      # BASELINE config 3
-    python tools/run_case.py --kind lap3d --size 50 --nev 20 --block 20 --ref                # config 1, vs the CPU reference
+    python tests/case_vs_reference.py --kind lap3d --size 50 --nev 20 --block 20 --rng 0   # config 1 next to the CPU reference
     python tools/run_case.py --kind sio2 --size 86 --nev 100 --block 64 --K 60              # config 5 shape on one GPU
 
 Prints one JSON line: timing by phase, converged count, the relative residuals
-||A x - lambda B x|| / (lambda ||B x||) recomputed through the slots (not taken from the solver), and with
---ref the relative difference of the Ritz values to the reference CPU path (oracle/_ref, same input).
-This is a measurement/parity tool, not part of the product path."""
+||A x - lambda B x|| / (lambda ||B x||) recomputed through the slots (not taken from the solver).
+A measurement tool, not part of the product path; it never touches oracle/ — tests/case_vs_reference.py wraps it and adds
+the run of the compiled reference on the same input."""
 import argparse
 import ctypes as C
 import json
@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(argv=None, post=None):
+    """post(out, a, A, B, ev, k): optional hook that may add entries to the result dictionary before it is printed."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--kind", default="fe3d")
     ap.add_argument("--size", type=int, default=100)
@@ -32,13 +33,12 @@ def main():
     ap.add_argument("--K", type=int, default=6)
     ap.add_argument("--R0", type=float, default=1.5)
     ap.add_argument("--R1", type=float, default=2.0)
-    ap.add_argument("--ref", action="store_true", help="also run the CPU reference (oracle/_ref) on the same input")
     ap.add_argument("--petsc", nargs="+", default=None, metavar="FILE",
                     help="PETSc binary Mat file(s): A [B] (the reference's -filename_matA / -filename_matB) instead of a generator")
     ap.add_argument("--box", default=None, metavar="NX,NY,NZ",
                     help="7-point Laplacian on an NX x NY x NZ grid instead of --kind/--size (e.g. 512,512,64: the slab one of 8 ranks owns at BASELINE config 4)")
     ap.add_argument("--extra", nargs="*", default=[])
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
 
     import numpy as np
     import torch  # noqa: F401  (one libamdhip64 for torch and the extension)
@@ -95,16 +95,8 @@ def main():
            "phase_seconds": {q: getattr(res.timing, q) for q in ("initX", "checkconv", "compP", "compRR", "compRV", "compW", "linsol", "total")},
            "lambda_first": ev[:3].tolist(), "lambda_last": float(ev[k - 1]),
            "max_rel_residual_recomputed": float(relres.max())}
-    if a.ref:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import pyoracle as po
-        if po.ref_lib() is None:
-            out["ref"] = "oracle/_ref not built"
-        else:
-            rv, conv, it, sec = po.ref_gcg(A, B, a.nev, nev_max=a.nevmax, block=a.block)
-            kk = min(conv, k)
-            out["ref"] = {"nev_converged": conv, "gcg_iterations": it, "seconds": sec,
-                          "max_rel_diff_ritz_values": float(np.max(np.abs(ev[:kk] - rv[:kk]) / np.abs(rv[:kk])))}
+    if post is not None:
+        post(out, a, A, B, ev, k)
     print(json.dumps(out))
 
 
