@@ -40,7 +40,7 @@ int gcge_hip_rowmajor_to_colmajor(int nrows, int m, const double* d_src, long ld
 extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                    long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
                                    long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
-                                   double* d_dots, double* d_dots_yy, void* stream);
+                                   double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb);
 
 struct GCGE_HIP_MAT_ {
   int nrows;      // local rows
@@ -690,7 +690,7 @@ __global__ void add3_kernel(double* __restrict__ dst, const double* __restrict__
 // want_fused: the caller asked for dots and the matrix/operands qualify for a fused kernel.
 // cg != NULL: one of the two passes of a block-CG iteration instead of the product (pattern matrices only,
 // gcge_hip_pattern_cg): mode 2 = the sums without storing Y, mode 3 = R / P update with the product recomputed.
-struct CgPass { int mode; double* r; long ldr; double* pnew; long ldp; const double *alpha, *beta; const int* flag; };
+struct CgPass { int mode; double* r; long ldr; double* pnew; long ldp; const double *alpha, *beta; const int* flag; const double* b; long ldb; };
 static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long ldx, double* dy, long ldy, int m,
                      double* d_dots, double* d_yy, const CgPass* cg = nullptr) {
   const int nr = (int)(r1 - r0);
@@ -704,7 +704,7 @@ static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long 
     return gcge_hip_pattern_cg(cg->mode, nr, A->d_pid + r0, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2,
                                dx + r0 * ldx, ldx, cg->r ? cg->r + r0 * cg->ldr : nullptr, cg->ldr,
                                cg->pnew ? cg->pnew + r0 * cg->ldp : nullptr, cg->ldp, m, cg->alpha, cg->beta, cg->flag,
-                               d_dots, d_yy, g_stream);
+                               d_dots, d_yy, g_stream, cg->b ? cg->b + r0 * cg->ldb : nullptr, cg->ldb);
   }
   double* y = dy + r0 * ldy;
   int rc = -1;
@@ -893,7 +893,7 @@ extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* 
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 8.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
-  const CgPass cg = {2, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr};
+  const CgPass cg = {2, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
   const int rc = spmm_halo(A, vp, c0, nullptr, 0, m, dd, dyy, &cg);
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "cg_pass1: kernel launch");
@@ -923,10 +923,36 @@ extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, 
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 32.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
-  const CgPass cg = {3, vr->d + c0, vr->ld, vn->d + c0, vn->ld, d_alpha, d_beta, d_flag};
+  const CgPass cg = {3, vr->d + c0, vr->ld, vn->d + c0, vn->ld, d_alpha, d_beta, d_flag, nullptr, 0};
   const int rc = spmm_rows(A, 0, A->nrows, vp->d + c0, vp->ld, nullptr, 0, m, dd, nullptr, &cg);
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "cg_pass2: kernel launch");
+  double* hd = stage_h((size_t)m);
+  GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+  memcpy(host_rho, hd, m * sizeof(double));
+  return 0;
+}
+
+// Start of the block CG in one sweep (kernel MODE 5): r[:, rc0:rc0+m) = b[:, bc0:bc0+m) - A x[:, xc0:xc0+m), p0 = r (same
+// columns rc0.. of the block p0), host_rho[j] = sum over the LOCAL rows of r[r,j]^2.  Fetches the halo rows of x.
+// -1 without touching anything when matrix or operands do not qualify.
+extern "C" int gcge_hip_cg_start_mv(void* mat, void** x, int xc0, void** b, int bc0, void** r, void** p0, int rc0, int m,
+                                    double* host_rho) {
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
+  GcgeHipMV *vx = (GcgeHipMV*)x, *vb = (GcgeHipMV*)b, *vr = (GcgeHipMV*)r, *vp = (GcgeHipMV*)p0;
+  if (A == nullptr || A->d_pid == nullptr || g_spmm_path != 0 || getenv("GCGE_CG_NO_RECOMPUTE") != nullptr) return -1;
+  if ((m & 1) || (xc0 & 1) || (bc0 & 1) || (rc0 & 1) || (vx->ld & 1) || (vb->ld & 1) || (vr->ld & 1) || (vp->ld & 1)) return -1;
+  if (((uintptr_t)vx->d & 15) || ((uintptr_t)vb->d & 15) || ((uintptr_t)vr->d & 15) || ((uintptr_t)vp->d & 15)) return -1;
+  if (vr == vx || vp == vx || (A->nghost > 0 && m > A->buf_cols)) return -1;
+  GCGE_REQUIRE(xc0 >= 0 && xc0 + m <= vx->ncols && bc0 >= 0 && bc0 + m <= vb->ncols && rc0 >= 0 && rc0 + m <= vr->ncols &&
+               rc0 + m <= vp->ncols, "cg_start: column ranges");
+  GCGE_REQUIRE(A->nrows == vx->nrows && A->nrows == vb->nrows && A->nrows == vr->nrows && A->nrows == vp->nrows &&
+               A->nrows + A->nghost <= vx->nrows_alloc, "cg_start: shapes");
+  double* dd = stage_d(6 * (size_t)m);
+  const CgPass cg = {5, vr->d + rc0, vr->ld, vp->d + rc0, vp->ld, nullptr, nullptr, nullptr, vb->d + bc0, vb->ld};
+  const int rc = spmm_halo(A, vx, xc0, nullptr, 0, m, dd, nullptr, &cg);
+  GCGE_REQUIRE(rc == 0, "cg_start: kernel launch");
   double* hd = stage_h((size_t)m);
   GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
@@ -949,7 +975,7 @@ static int HIP_ResidualSq(void* mat, void* matB, void** x, int start, int end, c
   double* hl = stage_h(2 * (size_t)m);
   for (int j = 0; j < m; ++j) hl[j] = (c0 + j >= start && c0 + j < end) ? lambda[c0 + j - start] : 0.0;
   GCGE_HIP_CHECK(hipMemcpyAsync(d_lam, hl, m * sizeof(double), hipMemcpyHostToDevice, g_stream));
-  const CgPass cg = {4, nullptr, 0, nullptr, 0, d_lam, nullptr, nullptr};
+  const CgPass cg = {4, nullptr, 0, nullptr, 0, d_lam, nullptr, nullptr, nullptr, 0};
   const int rc = spmm_halo(A, vx, c0, nullptr, 0, m, dd, nullptr, &cg);
   GCGE_REQUIRE(rc == 0, "residual norms: kernel launch");
   GCGE_HIP_CHECK(hipMemcpyAsync(hl + m, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));

@@ -49,6 +49,8 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
                                       struct OPS_* ops);
 extern "C" int gcge_hip_cg_fusable(void* mat, void** p, int ncols);
 extern "C" int gcge_hip_cg_recompute_pays(void* mat);
+extern "C" int gcge_hip_cg_start_mv(void* mat, void** x, int xc0, void** b, int bc0, void** r, void** p0, int rc0, int m,
+                                    double* host_rho);
 extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* host_pw, double* host_ww);
 extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
                                     const double* d_beta, const int* d_flag, double* host_rho);
@@ -468,13 +470,21 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
   } else {
     for (int i = 0; i < nrhs; ++i) norm_b[i] = 1.0;   // "abs" ("user" scales are a BlockPCG-internal feature)
   }
-  // r = b - A x ; rho2 = diag(r^T r)
-  apply(mv_x, start_bx[1], s->mv_ws[0], 0, nrhs, nullptr);
+  // r = b - A x ; rho2 = diag(r^T r) ; p0 = r.  On pattern matrices in one sweep (kernel MODE 5) when the operands
+  // allow it; otherwise product, axpby, column dots (and the copy p0 = r further down)
+  bool p0_done = false;
+  if (sigma == 0.0 && gcge_hip_cg_recompute_pays(mat) &&
+      gcge_hip_cg_start_mv(mat, mv_x, start_bx[1], mv_b, start_bx[0], s->mv_ws[0], s->mv_ws[1], 0, nrhs, rho2.data()) == 0) {
+    reduce_over_ranks(rho2.data(), nrhs);
+    p0_done = true;
+  } else {
+    apply(mv_x, start_bx[1], s->mv_ws[0], 0, nrhs, nullptr);
+    st2[0] = start_bx[0]; en2[0] = end_bx[0]; st2[1] = 0; en2[1] = nrhs;
+    ops->MultiVecAxpby(1.0, mv_b, -1.0, s->mv_ws[0], st2, en2, ops);
+    st2[0] = 0; en2[0] = nrhs; st2[1] = 0; en2[1] = nrhs;
+    ops->MultiVecInnerProd('D', s->mv_ws[0], s->mv_ws[0], 0, st2, en2, rho2.data(), 1, ops);
+  }
   s->spmm_calls++; s->spmm_cols += nrhs;
-  st2[0] = start_bx[0]; en2[0] = end_bx[0]; st2[1] = 0; en2[1] = nrhs;
-  ops->MultiVecAxpby(1.0, mv_b, -1.0, s->mv_ws[0], st2, en2, ops);
-  st2[0] = 0; en2[0] = nrhs; st2[1] = 0; en2[1] = nrhs;
-  ops->MultiVecInnerProd('D', s->mv_ws[0], s->mv_ws[0], 0, st2, en2, rho2.data(), 1, ops);
   int nact = 0;
   for (int i = 0; i < nrhs; ++i) {
     init_res[i] = sqrt(rho2[i]); last_res[i] = init_res[i];
@@ -541,7 +551,7 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
     // gcge_hip_cg_pass1_mv / pass2_mv): 1 + 4 block streams per iteration instead of 2 + 5.  Same recurrences,
     // same operands, so alpha, beta and the iterates agree with the stored-w form to rounding of the sums.
     const bool recompute = R > 1 && sigma == 0.0 && gcge_hip_cg_recompute_pays(mat) && gcge_hip_cg_fusable(mat, s->ring[0], nrhs) && !(nrhs & 1);
-    if (nact > 0) {   // p0 = r0
+    if (nact > 0 && !p0_done) {   // p0 = r0  (ring[0] is mv_ws[1])
       st2[0] = 0; en2[0] = nrhs; st2[1] = 0; en2[1] = nrhs;
       ops->MultiVecAxpby(1.0, s->mv_ws[0], 0.0, s->ring_len ? s->ring[0] : s->mv_ws[1], st2, en2, ops);
     }

@@ -50,9 +50,11 @@ struct PatEntry { double val; long off; };   // 16 bytes: one ds_read_b128
 //        R[r,j] -= alpha_j w[r,j] ;  PNEW[r,j] = cr_j R[r,j] + cb_j X[r,j] ;  partial: sum_r cr_j R[r,j]^2
 //      with (alpha, cb, cr) = flag_j ? (alpha_j, beta_j, 1) : (0, 1, 0) exactly as cg_update_rp (retired columns are
 //      copied).  X = p_k, PNEW = p_{k+1} must be different blocks: neighbours still read X.
+//   5  start of the block CG: R[r,j] = B[r,j] - (A X)[r,j], PNEW = R (p_0 = r_0), partial: sum_r R[r,j]^2, with
+//      B = cg.b the right-hand sides and X the initial guess: one sweep instead of product, axpby, column dots and copy
 //   4  residual norms of Ritz pairs (standard problem): partial: sum_r ((A X)[r,j] - lambda_j X[r,j])^2 with
 //      lambda = cg.alpha; nothing is stored (CheckConvergence of the GCG driver, one read of X instead of 11 streams)
-struct CgArgs { double* r; size_t ldr; double* pnew; size_t ldp; const double* alpha; const double* beta; const int* flag; };
+struct CgArgs { double* r; size_t ldr; double* pnew; size_t ldp; const double* alpha; const double* beta; const int* flag; const double* b; size_t ldb; };
 struct CgCoef { double al0, al1, cb0, cb1, cr0, cr1; };
 __device__ __forceinline__ CgCoef cg_coef(const CgArgs& cg, int j, bool act) {
   CgCoef c = {0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
     const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
     double* __restrict__ dot_partial, long yy_offset, CgArgs cg) {
   constexpr int DOT = MODE != 0;       // the row's own X value rides in buf[LT]
-  constexpr int UPD = MODE == 3;       // its R value in buf[LT + 1]
+  constexpr int UPD = MODE == 3 || MODE == 5;   // its R value (MODE 5: right-hand side) in buf[LT + 1]
   constexpr int RES = MODE == 4;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
@@ -81,8 +83,9 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
   const int g = lane >> 3, i = lane & 7;
   const bool act = 2 * i < m;
   const double* __restrict__ xl = x + (act ? 2 * i : 0);   // idle lanes of a narrow last pass re-read column 0
-  const double* __restrict__ rl = UPD ? cg.r + (act ? 2 * i : 0) : nullptr;
-  CgCoef cf = UPD ? cg_coef(cg, 2 * i, act) : CgCoef{0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
+  const double* __restrict__ rl = UPD ? (MODE == 5 ? cg.b : cg.r) + (act ? 2 * i : 0) : nullptr;
+  const size_t ldrl = MODE == 5 ? cg.ldb : cg.ldr;
+  CgCoef cf = MODE == 3 ? cg_coef(cg, 2 * i, act) : CgCoef{0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
   if (RES && act) { cf.al0 = cg.alpha[2 * i]; cf.al1 = cg.alpha[2 * i + 1]; }   // lambda of this lane's column pair
   double d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;   // x.y and y.y column sums (DOT)
 
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
         buf[t] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e.off) * ldx);
       }
       if (DOT) buf[LT] = *reinterpret_cast<const v2d*>(xl + (size_t)row * ldx);
-      if (UPD) buf[LT + DOT] = *reinterpret_cast<const v2d*>(rl + (size_t)row * cg.ldr);
+      if (UPD) buf[LT + DOT] = *reinterpret_cast<const v2d*>(rl + (size_t)row * ldrl);
     };
     auto finish = [&](const v2d (&buf)[LT + DOT + UPD], const double (&val)[LT], long it) {
       double a0 = 0.0, a1 = 0.0;
@@ -117,7 +120,16 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
         d0 = fma(a0 * wgt, buf[LT].x, d0); d1 = fma(a1 * wgt, buf[LT].y, d1);
         e0 = fma(a0 * wgt, a0, e0); e1 = fma(a1 * wgt, a1, e1);
       }
-      if (UPD) {
+      if (MODE == 5) {
+        const v2d rv = buf[LT + DOT];
+        v2d rn = {rv.x - a0, rv.y - a1};
+        if (ok) {
+          __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.r + (size_t)row * cg.ldr + 2 * i));
+          __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.pnew + (size_t)row * cg.ldp + 2 * i));
+        }
+        d0 = fma(wgt * rn.x, rn.x, d0); d1 = fma(wgt * rn.y, rn.y, d1);
+      }
+      if (MODE == 3) {
         const v2d rv = buf[LT + DOT], pv = buf[LT];
         v2d rn = {fma(-cf.al0, a0, rv.x), fma(-cf.al1, a1, rv.y)};
         v2d pn = {fma(cf.cb0, pv.x, cf.cr0 * rn.x), fma(cf.cb1, pv.y, cf.cr1 * rn.y)};
@@ -310,8 +322,9 @@ __device__ __forceinline__ void chain2_body(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* s_tab, v2d (*xch)[NW][64],
     const double* __restrict__ xl, size_t ldx, double* __restrict__ y, size_t ldy, bool act, int i, int g, int wave, int lane,
     long ntiles, long line, int xcd_runs, double& d0, double& d1, double& e0, double& e1, const CgArgs& cg, const v2d* s_cf) {
-  constexpr int UPD = MODE == 3;
-  const double* __restrict__ rl = UPD ? cg.r + (act ? 2 * i : 0) : nullptr;
+  constexpr int UPD = MODE == 3 || MODE == 5;
+  const double* __restrict__ rl = UPD ? (MODE == 5 ? cg.b : cg.r) + (act ? 2 * i : 0) : nullptr;
+  const size_t ldrl = MODE == 5 ? cg.ldb : cg.ldr;
   constexpr int NO = LT - 5;               // slots that are neither chain nor line
   constexpr int NE = (ROLE == 1) ? 0 : 1;  // line row still loaded from memory
   // Tuning hook (off): blocks are dealt round-robin to the 8 XCDs; tiles that are neighbours along a grid line share
@@ -330,7 +343,7 @@ __device__ __forceinline__ void chain2_body(
   auto issue = [&](v2d& lnew, v2d (&edge)[NE + 1], v2d (&oth)[NO + 1 + UPD], long row, int p) {
     const PatEntry* e = s_tab + p * LT;
     lnew = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[2].off) * ldx);
-    if (UPD) oth[NO + UPD] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(rl + (size_t)row * cg.ldr));   // the row's residual
+    if (UPD) oth[NO + UPD] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(rl + (size_t)row * ldrl));   // the row's residual / right-hand side
     if (ROLE == 0) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[3].off) * ldx);
     if (ROLE == 2) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[4].off) * ldx);
 #pragma unroll
@@ -365,7 +378,16 @@ __device__ __forceinline__ void chain2_body(
       d0 = fma(a0 * wgt, b.x, d0); d1 = fma(a1 * wgt, b.y, d1);
       e0 = fma(a0 * wgt, a0, e0); e1 = fma(a1 * wgt, a1, e1);
     }
-    if (UPD) {   // coefficients of this lane's column pair from LDS (kept out of the registers: 4 waves per SIMD)
+    if (MODE == 5) {
+      const v2d rv = oth[NO + UPD];
+      v2d rn = {rv.x - a0, rv.y - a1};
+      if (ok) {
+        __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.r + (size_t)row * cg.ldr + 2 * i));
+        __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.pnew + (size_t)row * cg.ldp + 2 * i));
+      }
+      d0 = fma(wgt * rn.x, rn.x, d0); d1 = fma(wgt * rn.y, rn.y, d1);
+    }
+    if (MODE == 3) {   // coefficients of this lane's column pair from LDS (kept out of the registers: 4 waves per SIMD)
       const v2d al = s_cf[i], cb = s_cf[8 + i], cr = s_cf[16 + i];
       const v2d rv = oth[NO + UPD];
       v2d rn = {fma(-al.x, a0, rv.x), fma(-al.y, a1, rv.y)};
@@ -657,16 +679,18 @@ extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, con
 //   mode 2: d_dots[j] = sum_r X[r,j] (A X)[r,j], d_dots_yy[j] = sum_r (A X)[r,j]^2; nothing is stored
 //   mode 3: R -= (A X) diag(alpha); PNEW = R diag(cr) + X diag(cb); d_dots[j] = sum_r cr_j R[r,j]^2  (d_dots_yy unused)
 //   mode 4: d_dots[j] = sum_r ((A X)[r,j] - alpha_j X[r,j])^2  (residuals of Ritz pairs, alpha = the Ritz values)
+//   mode 5: R = B - A X; PNEW = R; d_dots[j] = sum_r R[r,j]^2  (start of the CG; d_b / ldb: the right-hand sides)
 // Geometry as gcge_hip_pattern_spmm; a chain-layout table without line exchange runs through the plain kernel
 // (its table is a valid generic one).  -1: not applicable (alignment), the caller keeps the unfused recurrence.
 extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                    long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
                                    long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
-                                   double* d_dots, double* d_dots_yy, void* stream) {
-  if (mode != 2 && mode != 3 && mode != 4) return -1;
+                                   double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb) {
+  if (mode != 2 && mode != 3 && mode != 4 && mode != 5) return -1;
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || ((uintptr_t)d_x & 15) || d_dots == nullptr) return -1;
-  if (mode == 3 && ((ldr & 1) || (ldp & 1) || ((uintptr_t)d_r & 15) || ((uintptr_t)d_pnew & 15) || d_pnew == d_x)) return -1;
+  if ((mode == 3 || mode == 5) && ((ldr & 1) || (ldp & 1) || ((uintptr_t)d_r & 15) || ((uintptr_t)d_pnew & 15) || d_pnew == d_x || d_r == d_x)) return -1;
+  if (mode == 5 && (d_b == nullptr || (ldb & 1) || ((uintptr_t)d_b & 15))) return -1;
   if ((size_t)npat * lt * sizeof(PatEntry) > 64 * 1024) return -1;
   hipStream_t st = (hipStream_t)stream;
   const int npass = (ncols + 15) / 16;
@@ -686,10 +710,13 @@ extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_
     long rc;
     if (mode == 2) rc = pat_dispatch<2>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw);
     else if (mode == 4) {
-      const CgArgs cg = {nullptr, 0, nullptr, 0, d_alpha + c0, nullptr, nullptr};
+      const CgArgs cg = {nullptr, 0, nullptr, 0, d_alpha + c0, nullptr, nullptr, nullptr, 0};
       rc = pat_dispatch<4>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
+    } else if (mode == 5) {
+      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, nullptr, nullptr, nullptr, d_b + c0, (size_t)ldb};
+      rc = pat_dispatch<5>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
     } else {
-      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0};
+      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0, nullptr, 0};
       rc = pat_dispatch<3>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
     }
     if (rc < 0) return -1;

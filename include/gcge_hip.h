@@ -123,7 +123,10 @@ int gcge_hip_pattern_spmm (int nrows, const unsigned short *d_pid, const void *d
  *     -1: operands do not qualify (the caller keeps the stored-w form)                                              */
 int gcge_hip_pattern_cg (int mode, int nrows, const unsigned short *d_pid, const void *d_tab, int npat, int lt,
 		long span, long span2, const double *d_x, long ldx, double *d_r, long ldr, double *d_pnew, long ldp, int ncols,
-		const double *d_alpha, const double *d_beta, const int *d_flag, double *d_dots, double *d_dots_yy, void *stream);
+		const double *d_alpha, const double *d_beta, const int *d_flag, double *d_dots, double *d_dots_yy, void *stream,
+		const double *d_b, long ldb);
+/*     mode 4: d_dots[j] = sum_r ((A x)[r,j] - alpha_j x[r,j])^2 (residual norms of Ritz pairs);  mode 5: r = b - A x,
+ *     pnew = r, d_dots[j] = sum_r r[r,j]^2 (start of the CG; d_b / ldb only used here)                              */
 /*     the same on operator-table objects (halo rows of p fetched by pass 1 and reused by pass 2; sums are the LOCAL
  *     parts, on the host); gcge_hip_cg_fusable: 1 if (mat, p, ncols) qualify                                        */
 int gcge_hip_cg_fusable (void *mat, void **p, int ncols);
@@ -132,6 +135,8 @@ int gcge_hip_cg_recompute_pays (void *mat);   /* 1: chain + line-exchange layout
  *     standard problem in one read of x (kernel MODE 4); returned as void* for test harnesses                    */
 void *gcge_hip_residual_hook (void);
 int gcge_hip_cg_pass1_mv (void *mat, void **p, int c0, int m, double *host_pw, double *host_ww);
+int gcge_hip_cg_start_mv (void *mat, void **x, int xc0, void **b, int bc0, void **r, void **p0, int rc0, int m,
+		double *host_rho);   /* r = b - A x, p0 = r, rho = column sums of r^2 (local rows) in one sweep */
 int gcge_hip_cg_pass2_mv (void *mat, void **p, void **r, void **pnew, int c0, int m, const double *d_alpha,
 		const double *d_beta, const int *d_flag, double *host_rho);
 int gcge_hip_pattern_width (int max_row_len);

@@ -463,3 +463,33 @@ def test_gcg_residual_hook_equals_slot_path(hip):
             os.environ.pop("GCGE_NO_RESIDUAL_HOOK", None)
     assert out["hook"][1:] == out["slots"][1:], (out["hook"][1:], out["slots"][1:])
     assert np.max(np.abs(out["hook"][0] - out["slots"][0]) / np.abs(out["slots"][0])) < 1e-12
+
+
+@pytest.mark.parametrize("kind,size,m", [("lap3d", 16, 24), ("lap3d", 12, 6), ("fe3d", 12, 16)])
+def test_cg_start_sweep_matches_numpy(hip, kind, size, m):
+    """r = b - A x, p0 = r, rho = diag(r^T r) in one sweep (gcge_hip_cg_start_mv, kernel MODE 5), both kernel routes."""
+    from helpers import csr_to_scipy, uniform
+    A, _ = make_problem(kind, size)
+    S = csr_to_scipy(A)
+    n = A.nrows
+    mat = hip.matrix(A)
+    g = hip.g
+    g.gcge_hip_cg_start_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_void_p]
+    X = uniform(31, (n, m + 6)) - 0.5
+    Bm = uniform(32, (n, m + 2)) - 0.5
+    x, b = hip.mv_from_numpy(mat, X), hip.mv_from_numpy(mat, Bm)
+    r = hip.mv_from_numpy(mat, np.full((n, m), 3.0))
+    p0 = hip.mv_from_numpy(mat, np.full((n, m), 5.0))
+    rho = np.zeros(m)
+    assert g.gcge_hip_cg_start_mv(mat, x, 4, b, 2, r, p0, 0, m, rho.ctypes.data) == 0
+    R = Bm[:, 2:2 + m] - S @ X[:, 4:4 + m]
+    tol = 1e-13 * (np.abs(R).max() + 1.0)
+    np.testing.assert_allclose(hip.mv_to_numpy(r, n, 0, m), R, rtol=0, atol=tol)
+    assert np.array_equal(hip.mv_to_numpy(p0, n, 0, m), hip.mv_to_numpy(r, n, 0, m))
+    np.testing.assert_allclose(rho, np.sum(R * R, axis=0), rtol=1e-12)
+    assert np.array_equal(hip.mv_to_numpy(x, n, 0, m + 6), X) and np.array_equal(hip.mv_to_numpy(b, n, 0, m + 2), Bm)
+    assert g.gcge_hip_cg_start_mv(mat, x, 3, b, 2, r, p0, 0, m, rho.ctypes.data) == -1        # odd column offset: declined
+    for v, k in ((x, m + 6), (b, m + 2), (r, m), (p0, m)):
+        hip.ops.mv_destroy(v, k)
+    hip.free_matrix(mat)
