@@ -12,7 +12,13 @@
 // directions); the measured rho_j of the sweep drives the next alpha and the stopping test.  7 block streams + the
 // SpMM instead of the 13 + SpMM of the unfused recurrence.  When memory allows, the x update is taken out of the
 // sweep as well: the directions go into a ring of up to 16 blocks (cg_update_rp: 3 reads + 2 writes) and x is
-// brought up to date every 15 iterations (cg_accum_x): 6.1 block streams per iteration.  The older two-sweep form (GCGE_CG_TWO_PASS=1, also
+// brought up to date every 15 iterations (cg_accum_x): 6.1 block streams per iteration + the SpMM's two.
+// Recompute form (pattern matrices in chain + line-exchange layout, no shift, ring available): w is never stored.
+//     pass 1: pTw_j, wTw_j from one read of p                       (spmm_pattern.hip MODE 2, gcge_hip_cg_pass1_mv)
+//     pass 2: w rebuilt in the SpMM kernel's registers, r -= alpha_j w ; p' = r + beta_j p ; rho_j
+//             (reads p, r; writes r, p' into the next ring slot)    (MODE 3, gcge_hip_cg_pass2_mv)
+// 1 + 4 + 1.1 = 6.1 block streams per iteration in total; the start r = b - A x, p0 = r, rho is one sweep too (MODE 5).
+// The older two-sweep form (GCGE_CG_TWO_PASS=1, also
 // the fallback when a block cannot be walked with 16-byte lanes) needs no prediction:
 //     x += alpha'_j p ; p = r + beta_j p       (cg_update_xp: the x update of the PREVIOUS step is
 //                                               deferred into this pass: 3 reads + 2 writes)
