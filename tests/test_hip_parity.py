@@ -493,3 +493,60 @@ def test_cg_start_sweep_matches_numpy(hip, kind, size, m):
     for v, k in ((x, m + 6), (b, m + 2), (r, m), (p0, m)):
         hip.ops.mv_destroy(v, k)
     hip.free_matrix(mat)
+
+
+def test_full_size_cg_passes_properties(hip):
+    """BASELINE config 2 shape (Lap3D 256^3 x 64): the recompute passes of the block CG, the CG start sweep and the
+    residual hook against the SAME quantities assembled from independent kernels (plain product, axpby, column scaling,
+    column dots) — identities that hold for any size instead of a CPU recomputation."""
+    import torch
+    N, m = 256, 64
+    A, _ = make_problem("lap3d", N)
+    mh = hip.matrix(A)
+    ops, g = hip.ops, hip.g
+    g.gcge_hip_cg_pass1_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    g.gcge_hip_cg_pass2_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    g.gcge_hip_cg_start_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_void_p]
+    g.gcge_hip_residual_hook.restype = C.c_void_p
+    hook = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p)(g.gcge_hip_residual_hook())
+    p, r, r0, w, pn, t = (ops.mv_create(m, mh) for _ in range(6))
+    hip.set_random_mode(1, 4711)
+    ops.set_random(p, 0, m); ops.set_random(r, 0, m)
+    hip.set_random_mode(0)
+    full = ((0, 0), (m, m))
+    ops.axpby(1.0, r, 0.0, r0, *full)                                   # keep the old residual
+    ops.spmm(mh, p, w, *full)
+    pw_ref = ops.inner_prod("D", p, w, *full); ww_ref = ops.inner_prod("D", w, w, *full)
+    pw, ww = np.zeros(m), np.zeros(m)
+    assert g.gcge_hip_cg_pass1_mv(mh, p, 0, m, pw.ctypes.data, ww.ctypes.data) == 0
+    np.testing.assert_allclose(pw, pw_ref, rtol=1e-12); np.testing.assert_allclose(ww, ww_ref, rtol=1e-12)
+    # residual hook: ||A p - lambda p||^2 = w.w - 2 lambda p.w + lambda^2 p.p
+    lam = np.linspace(0.5, 3.0, m)
+    pp_ref = ops.inner_prod("D", p, p, *full)
+    res = np.zeros(m)
+    assert hook(mh, None, p, 0, m, lam.ctypes.data, res.ctypes.data) == 1
+    np.testing.assert_allclose(res, ww_ref - 2.0 * lam * pw_ref + lam * lam * pp_ref, rtol=1e-10)
+    # pass 2: r' + w diag(alpha) - r_old = 0 and p' - r' - p diag(beta) = 0, rho = r'.r'
+    alpha = np.linspace(0.01, 0.2, m); beta = np.linspace(0.3, 0.9, m); flag = np.ones(m, dtype=np.int32)
+    d_al, d_be, d_fl = torch.from_numpy(alpha).cuda(), torch.from_numpy(beta).cuda(), torch.from_numpy(flag).cuda()
+    rho = np.zeros(m)
+    assert g.gcge_hip_cg_pass2_mv(mh, p, r, pn, 0, m, d_al.data_ptr(), d_be.data_ptr(), d_fl.data_ptr(), rho.ctypes.data) == 0
+    np.testing.assert_allclose(rho, ops.inner_prod("D", r, r, *full), rtol=1e-12)
+    ops.axpby(1.0, w, 0.0, t, *full); ops.lincomb(None, t, *full, None, 0, beta=alpha, incb=1)     # t = w diag(alpha)
+    ops.axpby(1.0, r, 1.0, t, *full); ops.axpby(-1.0, r0, 1.0, t, *full)                          # t = r' + w alpha - r_old
+    assert np.max(ops.inner_prod("D", t, t, *full) / ops.inner_prod("D", r0, r0, *full)) < 1e-28
+    ops.axpby(1.0, p, 0.0, t, *full); ops.lincomb(None, t, *full, None, 0, beta=beta, incb=1)      # t = p diag(beta)
+    ops.axpby(1.0, r, 1.0, t, *full); ops.axpby(-1.0, pn, 1.0, t, *full)                          # t = r' + p beta - p'
+    assert np.max(ops.inner_prod("D", t, t, *full) / ops.inner_prod("D", pn, pn, *full)) < 1e-28
+    # CG start: r = b - A x with b = r0, x = p; p0 = r
+    assert g.gcge_hip_cg_start_mv(mh, p, 0, r0, 0, r, pn, 0, m, rho.ctypes.data) == 0
+    np.testing.assert_allclose(rho, ops.inner_prod("D", r, r, *full), rtol=1e-12)
+    ops.axpby(1.0, r, 0.0, t, *full); ops.axpby(1.0, w, 1.0, t, *full); ops.axpby(-1.0, r0, 1.0, t, *full)   # r + A x - b
+    assert np.max(ops.inner_prod("D", t, t, *full) / ops.inner_prod("D", r0, r0, *full)) < 1e-28
+    ops.axpby(-1.0, r, 1.0, pn, *full)
+    assert np.max(ops.inner_prod("D", pn, pn, *full)) == 0.0
+    for hnd in (p, r, r0, w, pn, t):
+        ops.mv_destroy(hnd, m)
+    hip.free_matrix(mh)
