@@ -90,6 +90,7 @@ class Comm:
         self._allreduce_cb = ALLREDUCE_FN(_loud(self._allreduce))
         self._keep = []
         self.n_allreduce = 0
+        self._ar_cap, self._ar_pin, self._ar_dev = 0, None, None
 
     # ---- small-result all-reduce (host buffer in, host buffer out) -------------------------------
     def _allreduce(self, buf, n, ctx):
@@ -97,9 +98,18 @@ class Comm:
         arr = np.ctypeslib.as_array(buf, shape=(n,))
         t = torch.from_numpy(arr)
         if self.device is not None and not self.stage:
-            td = t.to(self.device)
-            self.dist.all_reduce(td)
-            t.copy_(td.cpu())
+            # persistent pinned + device staging: two asynchronous copies and one stream synchronisation per call
+            if self._ar_cap < n:
+                self._ar_cap = max(1024, 2 * n)
+                self._ar_pin = torch.empty(self._ar_cap, dtype=torch.float64).pin_memory()
+                self._ar_dev = torch.empty(self._ar_cap, dtype=torch.float64, device=self.device)
+            pin, dev = self._ar_pin[:n], self._ar_dev[:n]
+            pin.copy_(t)
+            dev.copy_(pin, non_blocking=True)
+            self.dist.all_reduce(dev)
+            pin.copy_(dev, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            t.copy_(pin)
         else:
             self.dist.all_reduce(t)
         self.n_allreduce += 1
