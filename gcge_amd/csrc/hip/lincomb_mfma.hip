@@ -36,23 +36,29 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int LC_KT = 32;          // k-tile
 constexpr int LC_XS = LC_KT + 2;   // LDS row stride of the X tile (doubles)
 
-template <int NT>  // NT 16-column output fragments per wave: m <= 16 NT
+// NT 16-column output fragments per wave: m <= 16 NT.  RF 16-row fragments per wave: a block owns 64 RF rows and every
+// coefficient fragment read from LDS feeds RF MFMAs (RF = 2: 8 MFMAs per 6 LDS reads at m = 64 instead of 4 per 5; PMC
+// showed the RF = 1 form issuing MFMAs at 52-62 % of the pipe rate, profiles/r01_dense/10).
+template <int NT, int RF>
 __global__ __launch_bounds__(256) void lincomb_kernel(long nrows, const double* x, long ldx, int k,
     const double* __restrict__ cpad, int m, const double* __restrict__ beta, double* y, long ldy, int cs) {
   extern __shared__ __align__(16) double lds[];
-  double* xs = lds;                 // [64][LC_XS]
-  double* cst = lds + 64 * LC_XS;   // [LC_KT][cs]
+  constexpr int BR = 64 * RF;       // rows per block
+  double* xs = lds;                 // [BR][LC_XS]
+  double* cst = lds + BR * LC_XS;   // [LC_KT][cs]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, kk = lane >> 4;
-  const long r0 = (long)blockIdx.x * 64;
+  const long r0 = (long)blockIdx.x * BR;
 
-  v4d acc[NT];
+  v4d acc[RF][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int f = 0; f < RF; ++f)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[f][t] = (v4d){0.0, 0.0, 0.0, 0.0};
 
   // register double-buffering: the next k-tile is fetched from global memory while the MFMAs of the
   // current one run; it is written to LDS after the barrier that ends the current tile
-  constexpr int XE = 64 * LC_KT / 256;            // X elements per thread and tile (8)
+  constexpr int XE = BR * LC_KT / 256;            // X elements per thread and tile (8 RF)
   constexpr int CE = LC_KT * 16 * NT / 256;       // C elements per thread and tile (2 NT)
   double xr[XE], cr[CE];
   auto fetch = [&](int k0) {
@@ -85,38 +91,45 @@ __global__ __launch_bounds__(256) void lincomb_kernel(long nrows, const double* 
     if (k0 + LC_KT < k) fetch(k0 + LC_KT);
 #pragma unroll
     for (int s = 0; s < LC_KT; s += 4) {
-      const double a = xs[(16 * wave + li) * LC_XS + s + kk];
+      double a[RF];
+#pragma unroll
+      for (int f = 0; f < RF; ++f) a[f] = xs[(16 * RF * wave + 16 * f + li) * LC_XS + s + kk];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const double b = cst[(s + kk) * cs + 16 * t + li];
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < RF; ++f) acc[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[f], b, acc[f][t], 0, 0, 0);
       }
     }
     __syncthreads();
   }
   // epilogue: Y = acc + beta_j * Y.  The old Y values are fetched with clamped (row, column) and no
   // predicate so that all 4 NT loads of a lane are in flight together; only the stores are guarded.
-  if (beta != nullptr) {
-    double yv[NT][4], bj[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int colc = min(16 * t + li, m - 1);
-      bj[t] = beta[colc];
+  for (int f = 0; f < RF; ++f) {
+    const long rw = r0 + 16 * RF * wave + 16 * f;     // first row of this fragment
+    if (beta != nullptr) {
+      double yv[NT][4], bj[NT];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) yv[t][u] = y[min(r0 + 16 * wave + 4 * u + kk, nrows - 1) * ldy + colc];
+      for (int t = 0; t < NT; ++t) {
+        const int colc = min(16 * t + li, m - 1);
+        bj[t] = beta[colc];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) yv[t][u] = y[min(rw + 4 * u + kk, nrows - 1) * ldy + colc];
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[f][t][u] = fma(bj[t], yv[t][u], acc[f][t][u]);
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      const int col = 16 * t + li;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[t][u] = fma(bj[t], yv[t][u], acc[t][u]);
-  }
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int col = 16 * t + li;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long row = r0 + 16 * wave + 4 * u + kk;
-      if (col < m && row < nrows) y[row * ldy + col] = acc[t][u];
+      for (int u = 0; u < 4; ++u) {
+        const long row = rw + 4 * u + kk;
+        if (col < m && row < nrows) y[row * ldy + col] = acc[f][t][u];
+      }
     }
   }
 }
@@ -136,6 +149,8 @@ using namespace gcge;
 
 static double* g_cpad = nullptr;
 static size_t g_cpad_len = 0;
+static int g_lc_rf = 0;   // row fragments per wave: 0 automatic, 1 / 2 forced (tuning)
+extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 0 && row_fragments <= 2) g_lc_rf = row_fragments; }
 
 template <int NT>
 static int lc_launch(int nrows, const double* x, long ldx, int k, const double* c, int m,
@@ -148,10 +163,18 @@ static int lc_launch(int nrows, const double* x, long ldx, int k, const double* 
   }
   hipLaunchKernelGGL(lincomb_pad_c, dim3((kp * mp + 255) / 256), dim3(256), 0, st, c, k, m, g_cpad, kp, mp);
   const int cs = (16 * NT + 31) / 32 * 32 + 16;  // row stride of the C tile: 16 mod 32 doubles
-  const size_t shmem = (size_t)(64 * LC_XS + LC_KT * cs) * sizeof(double);
-  const unsigned grid = (unsigned)(((long)nrows + 63) / 64);
-  hipLaunchKernelGGL((lincomb_kernel<NT>), dim3(grid), dim3(256), shmem, st, (long)nrows, x, ldx, k, g_cpad, m, beta,
-                     y, ldy, cs);
+  // two row fragments per wave for the 128-column panels once there are enough rows to fill the chip with 128-row
+  // blocks several times over (n = 2^24, k = 256: m = 128 27.1 -> 24.1 ms = 45.6 TF; at m = 64 the 212 VGPRs of that
+  // form leave one wave per SIMD and it loses, 12.0 -> 14.2 ms)
+  const int rf = (g_lc_rf == 0) ? ((NT == 8 && (long)nrows >= 128L * 256 * 8) ? 2 : 1) : g_lc_rf;
+  const size_t shmem = (size_t)(64 * rf * LC_XS + LC_KT * cs) * sizeof(double);
+  const unsigned grid = (unsigned)(((long)nrows + 64 * rf - 1) / (64 * rf));
+  if (rf == 2)
+    hipLaunchKernelGGL((lincomb_kernel<NT, 2>), dim3(grid), dim3(256), shmem, st, (long)nrows, x, ldx, k, g_cpad, m, beta,
+                       y, ldy, cs);
+  else
+    hipLaunchKernelGGL((lincomb_kernel<NT, 1>), dim3(grid), dim3(256), shmem, st, (long)nrows, x, ldx, k, g_cpad, m, beta,
+                       y, ldy, cs);
   return 0;
 }
 

@@ -148,6 +148,7 @@ int gcge_hip_coldots (int nrows, const double *d_x, long ldx, const double *d_y,
 /* K3  Y[:,0:m) = X[:,0:k) C + Y diag(beta);  d_c row-major k x m; d_beta NULL => overwrite */
 int gcge_hip_lincomb (int nrows, const double *d_x, long ldx, int k, const double *d_c, int m,
 		const double *d_beta, double *d_y, long ldy, void *stream);
+void gcge_hip_lincomb_tune (int row_fragments);   /* 0 automatic (2 for m > 64 on large blocks), 1, 2: 16-row fragments per wave */
 /* K4  Y[:,0:m) = alpha X[:,0:m) + beta Y   (d_x NULL: scale only; beta == 0: no read of Y) */
 int gcge_hip_axpby (int nrows, double alpha, const double *d_x, long ldx, double beta,
 		double *d_y, long ldy, int m, void *stream);

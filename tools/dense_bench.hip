@@ -7,6 +7,7 @@
 #include "gcge_hip_internal.h"
 extern "C" int gcge_hip_gram(int, const double*, long, int, const double*, long, int, double*, void*);
 extern "C" void gcge_hip_gram_tune(int);
+extern "C" void gcge_hip_lincomb_tune(int);
 extern "C" int gcge_hip_lincomb(int, const double*, long, int, const double*, int, const double*, double*, long, void*);
 __global__ void fillk(double* x, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) void mfma_peak(double* out, int iters, double 
 }
 int main(int argc, char** argv) {
   long n = argc > 1 ? atol(argv[1]) : 16777216; int reps = 3;
+  if (getenv("LC_RF")) gcge_hip_lincomb_tune(atoi(getenv("LC_RF")));   // row fragments per wave of the panel update
   const long ldv = 256, ldw = 128;
   double *V, *W, *G, *C;
   GCGE_HIP_CHECK(hipMalloc(&V, n * ldv * 8)); GCGE_HIP_CHECK(hipMalloc(&W, n * ldw * 8));
