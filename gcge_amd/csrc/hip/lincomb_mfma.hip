@@ -40,7 +40,7 @@ constexpr int LC_XS = LC_KT + 2;   // LDS row stride of the X tile (doubles)
 // coefficient fragment read from LDS feeds RF MFMAs (RF = 2: 8 MFMAs per 6 LDS reads at m = 64 instead of 4 per 5; PMC
 // showed the RF = 1 form issuing MFMAs at 52-62 % of the pipe rate, profiles/r01_dense/10).
 template <int NT, int RF>
-__global__ __launch_bounds__(256) void lincomb_kernel(long nrows, const double* x, long ldx, int k,
+__global__ __launch_bounds__(256, (RF == 2 && NT <= 4) ? 2 : 1) void lincomb_kernel(long nrows, const double* x, long ldx, int k,
     const double* __restrict__ cpad, int m, const double* __restrict__ beta, double* y, long ldy, int cs) {
   extern __shared__ __align__(16) double lds[];
   constexpr int BR = 64 * RF;       // rows per block
@@ -163,10 +163,10 @@ static int lc_launch(int nrows, const double* x, long ldx, int k, const double* 
   }
   hipLaunchKernelGGL(lincomb_pad_c, dim3((kp * mp + 255) / 256), dim3(256), 0, st, c, k, m, g_cpad, kp, mp);
   const int cs = (16 * NT + 31) / 32 * 32 + 16;  // row stride of the C tile: 16 mod 32 doubles
-  // two row fragments per wave for the 128-column panels once there are enough rows to fill the chip with 128-row
-  // blocks several times over (n = 2^24, k = 256: m = 128 27.1 -> 24.1 ms = 45.6 TF; at m = 64 the 212 VGPRs of that
-  // form leave one wave per SIMD and it loses, 12.0 -> 14.2 ms)
-  const int rf = (g_lc_rf == 0) ? ((NT == 8 && (long)nrows >= 128L * 256 * 8) ? 2 : 1) : g_lc_rf;
+  // two row fragments per wave once there are enough rows to fill the chip with 128-row blocks several times over
+  // and enough MFMA work per tile to pay for the larger register set (n = 2^24, k = 256: m = 128 27.1 -> 23.9 ms =
+  // 46 TF, m = 64 12.0 -> 11.3 ms = 48.5 TF with two waves per SIMD; k = 64 and narrower panels: no gain)
+  const int rf = (g_lc_rf == 0) ? (((NT == 8 || (NT == 4 && k >= 128)) && (long)nrows >= 128L * 256 * 8) ? 2 : 1) : g_lc_rf;
   const size_t shmem = (size_t)(64 * rf * LC_XS + LC_KT * cs) * sizeof(double);
   const unsigned grid = (unsigned)(((long)nrows + 64 * rf - 1) / (64 * rf));
   if (rf == 2)
