@@ -474,7 +474,7 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
     ops->MultiVecInnerProd('D', mv_b, mv_b, 0, st2, en2, norm_b.data(), 1, ops);
     for (int i = 0; i < nrhs; ++i) norm_b[i] = sqrt(norm_b[i]);
   } else {
-    for (int i = 0; i < nrhs; ++i) norm_b[i] = 1.0;   // "abs" ("user" scales are a BlockPCG-internal feature)
+    for (int i = 0; i < nrhs; ++i) norm_b[i] = 1.0;   // "abs" (gcge_hip_bpcg_setup refuses anything but "abs" / "rel")
   }
   // r = b - A x ; rho2 = diag(r^T r) ; p0 = r.  On pattern matrices in one sweep (kernel MODE 5) when the operands
   // allow it; otherwise product, axpby, column dots (and the copy p0 = r further down)
@@ -522,7 +522,7 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
     std::vector<double> wTw(nrhs), bet(nrhs);
     // p-ring (see cg_update_rp): as many slots as memory allows, at most 16; fewer than 4 pending terms do not pay
     static const int ring_max = getenv("GCGE_CG_RING") ? atoi(getenv("GCGE_CG_RING")) : 16;
-    if (s->ring_len == 0 && s->max_iter >= 8 && ring_max >= 5) {
+    if (s->ring_len == 0 && s->max_iter >= 8) {   // (every rank gets here in the same call: the vote below is collective)
       size_t fr = 0, tot = 0;
       GCGE_HIP_CHECK(hipMemGetInfo(&fr, &tot));
       fr += gcge_hip_pool_cached_bytes();   // blocks parked in the back-end's pool are available to MultiVecCreate*
@@ -530,7 +530,20 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
       const size_t keep = (size_t)12 << 30;   // leave room for staging, partial sums and the caller
       long want = fr > keep ? (long)((fr - keep) / slot) : 0;
       if (want > ring_max - 1) want = ring_max - 1;
+      if (want < 4) want = 0;                   // fewer than 4 pending terms do not pay
       if (want > s->max_iter) want = s->max_iter;
+      // Row-partitioned runs: the ring length decides the column window [alo, ahi) and with it the LENGTH of the two
+      // all-reduces of an iteration, so every rank must use the same one — the minimum over the ranks (free memory
+      // differs between slabs cut by non-zeros and between ranks sharing a device).  GCGE_COMM only sums: rank r's
+      // "can hold at least q+1 extra slots" indicators are summed, the agreed length is the count of unanimous entries.
+      if (GCGE_COMM* c = GCGE_GetComm()) {
+        double vote[16];
+        for (int q = 0; q < 16; ++q) vote[q] = q < want ? 1.0 : 0.0;
+        c->allreduce_sum(vote, 16, c->ctx);
+        long agreed = 0;
+        while (agreed < 16 && vote[agreed] > (double)c->size - 0.5) ++agreed;
+        want = agreed;
+      }
       s->ring[0] = s->mv_ws[1]; s->ring_len = 1;
       if (want >= 4)
         for (long i = 0; i < want; ++i) { ops->MultiVecCreateByMultiVec(&s->ring[s->ring_len], s->ws_cols, mv_x, ops); ++s->ring_len; }
@@ -721,6 +734,12 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
 
 // C-ABI: install the fused solver (GCG: pass flag = 1 to the harness / -gcge_user_defined_multi_lin_sol 1)
 extern "C" void gcge_hip_bpcg_setup(struct OPS_* ops, int max_iter, double rate, double tol, const char* tol_type) {
+  // "user" (caller-stored residual scales in BlockPCG's dbl_ws, src/ops_lin_sol.c:186-192) has no counterpart in this
+  // interface: refuse it instead of silently solving to a different stopping rule
+  if (tol_type != nullptr && strcmp(tol_type, "abs") != 0 && strcmp(tol_type, "rel") != 0) {
+    fprintf(stderr, "gcge_hip_bpcg_setup: tol_type \"%s\" is not supported by the fused solver (\"abs\" or \"rel\")\n", tol_type);
+    abort();
+  }
   g_bpcg.max_iter = max_iter; g_bpcg.rate = rate; g_bpcg.tol = tol;
   strncpy(g_bpcg.tol_type, tol_type ? tol_type : "abs", 7); g_bpcg.tol_type[7] = 0;
   ops->multi_linear_solver_workspace = (void*)&g_bpcg;

@@ -60,25 +60,15 @@ void ref_use_foreign_backend(void *foreign_ops) { g_foreign_ops = (OPS*)foreign_
 void *ref_make_ccs_ops(void) { return (void*)make_ops(); }   /* reference app_ccs table, for OUR solver to drive */
 
 /* ---- eigensolver: same parameter flow as test/test_eig_sol_gcg.c:28-169 ---- */
-/* given != NULL: the first nevGiven columns of the eigenvector block (column-major, n x nevGiven) are start vectors */
-int ref_gcg_solve_given(int n, int *a_rowptr, int *a_colidx, double *a_val,
-		int *b_rowptr, int *b_colidx, double *b_val,
+/* core: any operator table + the matrix handles of ITS back-end.  given != NULL (app_ccs tables only): the first
+ * nevGiven columns of the eigenvector block (column-major, n x nevGiven) are start vectors */
+static int gcg_solve_core(OPS *ops, int own_ops, void *matA, void *matB, int n,
 		int nevConv, int nevMax, int block_size, int nevInit,
 		double abs_tol, double rel_tol, int max_iter, int flag,
 		int argc, char **argv,
 		double *eval_out, double *evec_out, int *nevConv_out, int *numIter_out,
 		double *seconds_out, int nevGiven, const double *given)
 {
-	OPS *ops;
-	CCSMAT A, B; void *matA, *matB = NULL;
-	if (g_foreign_ops != NULL) {
-		ops = g_foreign_ops;
-		OPS_Setup(ops);                       /* the reference back-fills lapack_ops, QtAP, InnerProd */
-		if (!g_verbose) { ops->Printf = quiet_printf; ops->lapack_ops->Printf = quiet_printf; }
-	} else ops = make_ops();
-	set_ccs(&A, n, a_rowptr, a_colidx, a_val); matA = &A;
-	if (b_rowptr != NULL) { set_ccs(&B, n, b_rowptr, b_colidx, b_val); matB = &B; }
-
 	int multiMax = 1; double gapMin = 1e-5;
 	if (nevMax <= 0) nevMax = 2 * nevConv;
 	if (block_size <= 0) block_size = nevConv < 30 ? (nevMax - nevConv) : nevConv / 5;
@@ -87,7 +77,7 @@ int ref_gcg_solve_given(int n, int *a_rowptr, int *a_colidx, double *a_val,
 	double *eval = calloc(nevMax, sizeof(double)); void **evec;
 	ops->MultiVecCreateByMat(&evec, nevMax, matA, ops);
 	ops->MultiVecSetRandomValue(evec, 0, nevMax, ops);
-	if (given != NULL && nevGiven > 0 && g_foreign_ops == NULL)
+	if (given != NULL && nevGiven > 0 && own_ops)
 		memcpy(((LAPACKVEC*)evec)->data, given, (size_t)n * nevGiven * sizeof(double));
 	else nevGiven = 0;
 	void **ws[4]; double *dbl_ws; int *int_ws;
@@ -115,9 +105,8 @@ int ref_gcg_solve_given(int n, int *a_rowptr, int *a_colidx, double *a_val,
 			30, 1e-2, 1e-14, "abs", 0,
 			-1, gapMin, 2 * DBL_EPSILON, ops);
 	if (argc > 0) {
-		int quiet_usage = 0, k, has = 0;
+		int k, has = 0;
 		for (k = 0; k < argc; ++k) if (0 == strcmp(argv[k], "-gcge_print_usage")) has = 1;
-		(void)quiet_usage;
 		if (has) EigenSolverSetParametersFromCommandLine_GCG(argc, argv, ops);
 		else {
 			char **av = malloc((argc + 2) * sizeof(char*));
@@ -134,14 +123,54 @@ int ref_gcg_solve_given(int n, int *a_rowptr, int *a_colidx, double *a_val,
 	if (numIter_out) *numIter_out = ((GCGSolver*)ops->eigen_solver_workspace)->numIter;
 	if (nevConv_out) *nevConv_out = conv;
 	memcpy(eval_out, eval, nevMax * sizeof(double));
-	if (evec_out && g_foreign_ops == NULL) memcpy(evec_out, ((LAPACKVEC*)evec)->data, (size_t)n * nevMax * sizeof(double));
+	if (evec_out && own_ops) memcpy(evec_out, ((LAPACKVEC*)evec)->data, (size_t)n * nevMax * sizeof(double));
 
 	ops->MultiVecDestroy(&ws[0], nevMax + 2 * block_size, ops);
 	for (i = 1; i < 4; ++i) ops->MultiVecDestroy(&ws[i], block_size, ops);
 	ops->MultiVecDestroy(&evec, nevMax, ops);
 	free(dbl_ws); free(int_ws); free(eval);
-	if (g_foreign_ops == NULL) OPS_Destroy(&ops);
 	return 0;
+}
+int ref_gcg_solve_given(int n, int *a_rowptr, int *a_colidx, double *a_val,
+		int *b_rowptr, int *b_colidx, double *b_val,
+		int nevConv, int nevMax, int block_size, int nevInit,
+		double abs_tol, double rel_tol, int max_iter, int flag,
+		int argc, char **argv,
+		double *eval_out, double *evec_out, int *nevConv_out, int *numIter_out,
+		double *seconds_out, int nevGiven, const double *given)
+{
+	OPS *ops;
+	CCSMAT A, B; void *matA, *matB = NULL;
+	if (g_foreign_ops != NULL) {
+		ops = g_foreign_ops;
+		OPS_Setup(ops);                       /* the reference back-fills lapack_ops, QtAP, InnerProd */
+		if (!g_verbose) { ops->Printf = quiet_printf; ops->lapack_ops->Printf = quiet_printf; }
+	} else ops = make_ops();
+	set_ccs(&A, n, a_rowptr, a_colidx, a_val); matA = &A;
+	if (b_rowptr != NULL) { set_ccs(&B, n, b_rowptr, b_colidx, b_val); matB = &B; }
+	int rc = gcg_solve_core(ops, g_foreign_ops == NULL, matA, matB, n, nevConv, nevMax, block_size, nevInit, abs_tol,
+			rel_tol, max_iter, flag, argc, argv, eval_out, evec_out, nevConv_out, numIter_out, seconds_out, nevGiven, given);
+	if (g_foreign_ops == NULL) OPS_Destroy(&ops);
+	return rc;
+}
+/* The literal drop-in: `foreign_ops` was created and filled by ANOTHER back-end's OPS_xxx_Set (OPS_HIP_Set of
+ * libgcge_hip.so), matA / matB are that back-end's own matrix handles.  The reference's OPS_Setup back-fills every
+ * default (src/ops.c:60-149), then the reference's GCG / ModifiedGramSchmidt / BlockPCG run over the foreign slots.
+ * flag = 1: the table's own ops->MultiLinearSolver is used for the W systems (ops_eig_sol_gcg.c:584-618). */
+int ref_gcg_solve_foreign(void *foreign_ops, void *matA, void *matB,
+		int nevConv, int nevMax, int block_size, int nevInit,
+		double abs_tol, double rel_tol, int max_iter, int flag,
+		double *eval_out, int *nevConv_out, int *numIter_out, double *seconds_out)
+{
+	OPS *ops = (OPS*)foreign_ops;
+	void (*lin_sol)(void*, void**, void**, int*, int*, struct OPS_*) = ops->MultiLinearSolver;
+	void *lin_ws = ops->multi_linear_solver_workspace;
+	OPS_Setup(ops);
+	ops->MultiLinearSolver = lin_sol; ops->multi_linear_solver_workspace = lin_ws;
+	if (!g_verbose) { ops->Printf = quiet_printf; ops->lapack_ops->Printf = quiet_printf; }
+	ops->GetWtime = wall_now;
+	return gcg_solve_core(ops, 0, matA, matB, 0, nevConv, nevMax, block_size, nevInit, abs_tol, rel_tol, max_iter,
+			flag, 0, NULL, eval_out, NULL, nevConv_out, numIter_out, seconds_out, 0, NULL);
 }
 int ref_gcg_solve(int n, int *a_rowptr, int *a_colidx, double *a_val,
 		int *b_rowptr, int *b_colidx, double *b_val,

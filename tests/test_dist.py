@@ -16,12 +16,13 @@ def _free_port():
     return p
 
 
-def _run(mode, world=2, timeout=600, dims=None, spec=None):
+def _run(mode, world=2, timeout=600, dims=None, spec=None, rank_env=None):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update((rank_env or {}).get(r, {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode]
                                       + ([",".join(str(d) for d in dims)] if dims else ([spec] if spec else [])),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -93,3 +94,12 @@ def test_rccl_loopback_one_gpu(dims):
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_hip_sio2_rows_split_by_nnz():
     _run("hip", spec="sio2:16")
+
+
+@pytest.mark.gpu
+def test_two_ranks_disagree_on_the_cg_ring_length():
+    """The fused CG's direction ring is sized from each rank's own free memory (or GCGE_CG_RING); the length decides
+    the column window and with it the length of the per-iteration all-reduces, so the ranks must settle on one
+    value (block_pcg.hip: vote over GCGE_COMM).  Rank 0 may take 15 extra slots, rank 1 none: both must run without a
+    ring, with matching all-reduce counts, to the same Ritz values."""
+    _run("hip", rank_env={0: {"GCGE_CG_RING": "16"}, 1: {"GCGE_CG_RING": "3"}})

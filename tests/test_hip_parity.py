@@ -550,3 +550,70 @@ def test_full_size_cg_passes_properties(hip):
     for hnd in (p, r, r0, w, pn, t):
         ops.mv_destroy(hnd, m)
     hip.free_matrix(mh)
+
+
+@pytest.mark.parametrize("rf", [1, 2])
+def test_lincomb_row_fragment_variants_vs_oracle(both, rf):
+    """The panel update with one and with two 16-row fragments per wave (gcge_hip_lincomb_tune; the automatic choice
+    takes two only for n >= 2.6e5, which no small parity case reaches): ragged row count (2197 = 17 x 128 + 21),
+    k not a multiple of the 32-column tile, m not a multiple of 16, all three beta modes, x == y in place."""
+    hip, ora = both
+    A, mh, mo = _pair_mats(both, "lap3d", 13)
+    n = A.nrows
+    X = uniform(47, (n, 270)) - 0.5
+    hip.g.gcge_hip_lincomb_tune(rf)
+    try:
+        for k, m, s0, s1 in [(1, 65, 0, 0), (33, 100, 2, 1), (100, 128, 0, 3), (260, 65, 1, 0), (260, 128, 2, 2), (64, 17, 0, 5),
+                             (130, 33, 3, 3)]:
+            Y0 = uniform(48, (n, 140))
+            xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
+            coef = np.asfortranarray(uniform(49, (k + 1, m)) - 0.5)
+            beta = uniform(50, (m,)) * 2 - 1
+            for bmode in ("none", "scalar", "vec"):
+                yh, yo = hip.mv_from_numpy(mh, Y0), ora.mv_from_numpy(mo, Y0)
+                b, incb = (None, 0) if bmode == "none" else ((beta, 0) if bmode == "scalar" else (beta, 1))
+                hip.ops.lincomb(xh, yh, (s0, s1), (s0 + k, s1 + m), coef, k + 1, b, incb)
+                ora.ops.lincomb(xo, yo, (s0, s1), (s0 + k, s1 + m), coef, k + 1, b, incb)
+                _close(hip.mv_to_numpy(yh, n, 0, 140), ora.mv_to_numpy(yo, n, 0, 140), tol=1e-12,
+                       what="lincomb rf=%d k=%d m=%d %s" % (rf, k, m, bmode))
+                hip.ops.mv_destroy(yh); ora.ops.mv_destroy(yo)
+            hip.ops.mv_destroy(xh); ora.ops.mv_destroy(xo)
+        # in place: y[:, 150:215) += y[:, 0:140) C  (x == y, disjoint column ranges: ops_orth.c:253,347)
+        Y0 = uniform(51, (n, 220)) - 0.5
+        yh, yo = hip.mv_from_numpy(mh, Y0), ora.mv_from_numpy(mo, Y0)
+        coef = np.asfortranarray(uniform(52, (140, 65)) - 0.5); one = np.array([1.0])
+        hip.ops.lincomb(yh, yh, (0, 150), (140, 215), coef, 140, one, 0)
+        ora.ops.lincomb(yo, yo, (0, 150), (140, 215), coef, 140, one, 0)
+        _close(hip.mv_to_numpy(yh, n, 0, 220), ora.mv_to_numpy(yo, n, 0, 220), tol=1e-12, what="lincomb in place rf=%d" % rf)
+    finally:
+        hip.g.gcge_hip_lincomb_tune(0)
+
+
+def test_fused_cg_workspace_follows_the_problem_shape(hip):
+    """The fused solver keeps its r / p / w blocks (and the direction ring) in a static workspace that outlives a
+    solve.  Solves of different row counts and widths back to back in one process — fewer rows then more rows than
+    the workspace was created for, wider and narrower right-hand sides — must each get blocks of their own shape
+    (block_pcg.hip keys the workspace on (rows, columns); every slot checks row counts on the host).  This is the
+    sequence that ended in a GPU memory-access fault in the first, uncommitted build of the solver
+    (gpurun_out/gputest3.log of round 1: a 125-row slot case followed by an 8000-row eigensolve)."""
+    import scipy.sparse.linalg as sla
+    g = hip.g
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    for kind, size, nrhs in [("lap3d", 5, 4), ("lap3d", 20, 20), ("fe3d", 12, 10), ("lap3d", 12, 12), ("lap3d", 20, 6),
+                             ("lap3d", 5, 8)]:
+        A, _ = make_problem(kind, size)
+        S = csr_to_scipy(A)
+        n = A.nrows
+        mat = hip.matrix(A)
+        Bm = uniform(61, (n, nrhs + 2)) - 0.5
+        b = hip.mv_from_numpy(mat, Bm)
+        x = hip.mv_from_numpy(mat, np.zeros((n, nrhs + 4)))
+        g.gcge_hip_bpcg_setup(hip.ops_handle, 400, 1e-12, 1e-14, b"abs")
+        hip.ops.multi_linear_solver(mat, b, x, (1, 2), (1 + nrhs, 2 + nrhs))
+        got = hip.mv_to_numpy(x, n, 0, nrhs + 4)
+        ref = sla.spsolve(S.tocsc(), Bm[:, 1:1 + nrhs]).reshape(n, nrhs)
+        assert np.max(np.abs(got[:, 2:2 + nrhs] - ref)) < 1e-8 * np.max(np.abs(ref)), (kind, size, nrhs)
+        assert np.array_equal(got[:, :2], np.zeros((n, 2))) and np.array_equal(got[:, 2 + nrhs:], np.zeros((n, 2)))
+        hip.ops.mv_destroy(b, nrhs + 2); hip.ops.mv_destroy(x, nrhs + 4)
+        hip.free_matrix(mat)
+    g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
