@@ -42,24 +42,6 @@ extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_
                                    long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
                                    double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb);
 
-struct GCGE_HIP_MAT_ {
-  int nrows;      // local rows
-  int nglobal;    // global dimension
-  int row_begin;  // first global row
-  int nghost;     // halo rows appended to every block of vectors
-  long nnz;
-  int *d_rowptr, *d_colidx; double* d_val;    // CSR, LOCAL column indices (ghosts >= nrows)
-  int *d_orp, *d_pcol; double* d_pval;        // pad-8 copy for the 16-byte-lane kernel
-  long noct;
-  unsigned short* d_pid; void* d_tab; int npat, pat_lt; long pat_span, pat_span2;   // pattern format (spmm_pattern.hip); d_pid == NULL: not applicable
-  // halo plan of a row-partitioned matrix (one process per GPU); nghost == 0 on a single rank
-  int nsend; int* d_send_rows;                 // local rows other ranks need, grouped by destination rank
-  double *sendbuf, *recvbuf; int buf_cols;     // exchange buffers (owned by the caller: torch tensors)
-  gcge_halo_exchange_fn exchange; void* exchange_ctx;
-  // optional split exchange (begin posts the transfers and returns, end completes them) and the rows that do not
-  // touch a halo column, [ov_lo, ov_hi): lets the interior product run while the halo is in flight
-  gcge_halo_exchange_fn exchange_begin; void (*exchange_end)(void*); int ov_lo, ov_hi;
-};
 
 __global__ __launch_bounds__(256) void halo_pack(int nsend, const int* __restrict__ rows, const double* __restrict__ x,
     long ldx, int m, double* __restrict__ buf) {
@@ -419,6 +401,7 @@ extern "C" void gcge_hip_mat_destroy(GCGE_HIP_MAT* A) {
   hipFree(A->d_orp); hipFree(A->d_pcol); hipFree(A->d_pval);
   if (A->d_pid) { hipFree(A->d_pid); hipFree(A->d_tab); }
   if (A->d_send_rows) hipFree(A->d_send_rows);
+  if (A->native_halo != nullptr) gcge_hip_halo_native_free(A);   // RCCL plan + the exchange buffers it owns (rccl_comm.hip)
   free(A);
 }
 extern "C" int gcge_hip_mat_nrows(const GCGE_HIP_MAT* A) { return A->nrows; }

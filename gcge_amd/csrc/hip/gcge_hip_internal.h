@@ -15,4 +15,30 @@
     }                                                                                 \
   } while (0)
 
+#ifdef __cplusplus
+#include "gcge_hip.h"
+// sparse matrix handle (CCSMAT counterpart): shared by app_hip.hip (the slots) and rccl_comm.hip (the halo plan)
+struct GCGE_HIP_MAT_ {
+  int nrows;      // local rows
+  int nglobal;    // global dimension
+  int row_begin;  // first global row
+  int nghost;     // halo rows appended to every block of vectors
+  long nnz;
+  int *d_rowptr, *d_colidx; double* d_val;    // CSR, LOCAL column indices (ghosts >= nrows)
+  int *d_orp, *d_pcol; double* d_pval;        // pad-8 copy for the 16-byte-lane kernel
+  long noct;
+  unsigned short* d_pid; void* d_tab; int npat, pat_lt; long pat_span, pat_span2;   // pattern format (spmm_pattern.hip); d_pid == NULL: not applicable
+  // halo plan of a row-partitioned matrix (one process per GPU); nghost == 0 on a single rank
+  int nsend; int* d_send_rows;                 // local rows other ranks need, grouped by destination rank
+  double *sendbuf, *recvbuf; int buf_cols;     // exchange buffers (owned by the caller: torch tensors)
+  gcge_halo_exchange_fn exchange; void* exchange_ctx;
+  // optional split exchange (begin posts the transfers and returns, end completes them) and the rows that do not
+  // touch a halo column, [ov_lo, ov_hi): lets the interior product run while the halo is in flight
+  gcge_halo_exchange_fn exchange_begin; void (*exchange_end)(void*); int ov_lo, ov_hi;
+  void* native_halo;   // RCCL plan of gcge_hip_mat_set_halo_rccl (rccl_comm.hip); it then owns sendbuf / recvbuf
+};
+extern "C" void gcge_hip_halo_native_free(struct GCGE_HIP_MAT_* A);
+
+#endif
+
 #endif

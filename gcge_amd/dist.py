@@ -8,6 +8,11 @@ src/ops_multi_vec.c:206-228).  Two exchanges exist on the hot path (SURVEY.md §
     row blocks (RCCL send/recv), planned once per matrix by plan_halo().
 
 Python is plumbing: planning happens once, the callbacks only move buffers.
+
+Production path on the GPUs (NativeComm below): both exchanges live in libgcge_hip.so (csrc/hip/rccl_comm.hip —
+ncclAllReduce and grouped ncclSend/ncclRecv on the back-end's own streams, planned in C); Python only hands rank 0's
+RCCL id to the other ranks.  The callback classes further down remain for what RCCL cannot do: the CPU oracle over
+gloo and several ranks sharing one GPU (the rehearsals of tests/test_dist.py).
 """
 import ctypes as C
 
@@ -222,6 +227,47 @@ class Comm:
         return cb, sp, rp
 
 
+class NativeComm:
+    """RCCL inside the back-end (include/gcge_hip.h "multi-GPU from C").  `dist` (any initialised torch.distributed
+    backend) is used once, to broadcast the 128-byte communicator id."""
+
+    def __init__(self, hip, dist, rank, world):
+        self.hip, self.rank, self.world = hip, rank, world
+        g = hip.g
+        g.gcge_hip_comm_unique_id.argtypes = [C.c_void_p]
+        g.gcge_hip_comm_init.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        g.gcge_hip_mat_create_slab.restype = C.c_void_p
+        g.gcge_hip_mat_create_slab.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                               C.POINTER(C.c_double), C.c_int]
+        g.gcge_hip_comm_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        ident = C.create_string_buffer(128)
+        if rank == 0 and g.gcge_hip_comm_unique_id(ident) != 0:
+            raise RuntimeError("gcge_hip_comm_unique_id failed")
+        box = [ident.raw]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        rc = g.gcge_hip_comm_init(rank, world, box[0])
+        if rc != 0:
+            raise RuntimeError("gcge_hip_comm_init failed: %d" % rc)
+
+    @property
+    def n_allreduce(self):
+        a, e = C.c_long(), C.c_long()
+        self.hip.g.gcge_hip_comm_stats(C.byref(a), C.byref(e))
+        return a.value
+
+    def slab_matrix(self, A, part, cap_cols=128):
+        """A: CSR slab with GLOBAL column indices (rows part[rank] .. part[rank+1]).  Collective."""
+        parr = (C.c_long * (self.world + 1))(*part)
+        m = self.hip.g.gcge_hip_mat_create_slab(parr, A.rowptr, A.colidx, A.val, cap_cols)
+        if not m:
+            raise RuntimeError("gcge_hip_mat_create_slab failed")
+        return C.c_void_p(m)
+
+    def finalize(self):
+        self.hip.g.gcge_hip_comm_finalize()
+
+
 def localize_slab(A):
     """A: CSR slab with GLOBAL columns.  Returns the ascending ghost list; A is rewritten to local numbering."""
     h = host_lib()
@@ -274,7 +320,8 @@ def weak_scaling_box(N, world):
 
 
 def lap3d_slab(hip, dims, rank, world, comm=None):
-    """Slab of the 7-point Laplacian on an Nx x Ny x Nz grid: rank r owns Nz/world planes (rows in natural order)."""
+    """Slab of the 7-point Laplacian on an Nx x Ny x Nz grid: rank r owns Nz/world planes (rows in natural order).
+    comm: NativeComm (RCCL in the back-end) or Comm (torch.distributed callbacks)."""
     h = host_lib()
     nx, ny, nz = dims
     n_global = nx * ny * nz
@@ -284,5 +331,8 @@ def lap3d_slab(hip, dims, rank, world, comm=None):
                                   C.c_int64(part[rank + 1]), C.byref(A))
     if rc != 0:
         raise RuntimeError("gcge_problem_lap3d_box failed")
-    mat = hip_slab_matrix(hip, comm, A, n_global, part)
+    if isinstance(comm, NativeComm):
+        mat = comm.slab_matrix(A, part)
+    else:
+        mat = hip_slab_matrix(hip, comm, A, n_global, part)
     return A, mat

@@ -57,6 +57,34 @@ void gcge_hip_mat_destroy (GCGE_HIP_MAT *A);
 int  gcge_hip_mat_nrows (const GCGE_HIP_MAT *A);
 long gcge_hip_mat_nnz (const GCGE_HIP_MAT *A);
 
+/* ---- multi-GPU from C: RCCL inside the back-end (csrc/hip/rccl_comm.hip) ------------------------------------
+ * One process per GPU.  Replaces what the reference does with MPI in its solver layers — MPI_Allreduce of every
+ * Gram / dot result (src/ops_multi_vec.c:206-228, src/ops_lin_sol.c:313-321,361-369) — and in its distributed
+ * back-ends (off-process part of X inside MatDotMultiVec, app/app_phg.c:292-359).
+ *   rank 0:  gcge_hip_comm_unique_id(id);  hand the 128 bytes to every rank (MPI_Bcast, a file, torch.distributed ...)
+ *   all:     gcge_hip_init(local_device); gcge_hip_comm_init(rank, world, id);   // also installs GCGE_COMM (gcge_ops.h)
+ *            A = gcge_hip_mat_create_slab(part, rowptr, colidx_global, val, block_columns);   // collective
+ *            OPS_HIP_Set(ops); ... the solver as on one GPU ...; gcge_hip_comm_finalize();                        */
+#define GCGE_HIP_COMM_ID_BYTES 128
+int  gcge_hip_comm_unique_id (void *id128);
+int  gcge_hip_comm_init (int rank, int world, const void *id128);
+void gcge_hip_comm_finalize (void);
+int  gcge_hip_comm_rank (void);
+int  gcge_hip_comm_size (void);
+void gcge_hip_comm_stats (long *n_allreduce, long *n_exchange);
+/*     in-place sum over the ranks of n doubles in DEVICE memory on the back-end's stream, nothing waited for      */
+int  gcge_hip_comm_allreduce_device (double *d_buf, int n);
+/*     rows [part[rank], part[rank+1]) of a symmetric matrix, GLOBAL column indices (host CSR); part has world + 1
+ *     entries.  Collective: builds the ghost list, the local numbering and the halo plan (who needs which rows) over
+ *     RCCL; products then move buf_cols columns of halo rows per grouped ncclSend/ncclRecv, event-ordered            */
+GCGE_HIP_MAT *gcge_hip_mat_create_slab (const long *part, const int *rowptr, const int *colidx_global,
+		const double *val, int buf_cols);
+/*     the same for a slab matrix that already has LOCAL column indices (gcge_hip_mat_create_local) and a plan computed
+ *     elsewhere: npeer slabs, peer[q] = communicator rank owning slab q, rows shipped to / received from it, the
+ *     local rows to ship grouped by destination slab                                                               */
+int  gcge_hip_mat_set_halo_rccl (GCGE_HIP_MAT *A, int nglobal, int npeer, const int *peer, const int *send_cnt,
+		const int *recv_cnt, const int *send_rows, int buf_cols);
+
 /* ---- block-of-vectors transfers (tests, final eigenvectors) ------------------- */
 /* columns [c0,c1) <-> host column-major array with leading dimension ldh (>= nrows) */
 void gcge_hip_mv_to_host   (void **mv, int c0, int c1, double *host, long ldh);

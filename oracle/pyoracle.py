@@ -47,9 +47,24 @@ def oracle_lib():
     return _oracle
 
 
-def ref_lib():
-    """The real reference; None when it has not been built (e.g. no /root/reference)."""
-    global _ref
+_ref_omp = None
+
+
+def ref_lib(omp=False):
+    """The real reference; None when it has not been built (e.g. no /root/reference).
+    omp=True: the OPS_USE_OMP build (oracle/Makefile target ref_omp) — app_ccs.c:117-131 threaded over the block
+    columns with OMP_NUM_THREADS threads (read at run time); needs MKL_THREADING_LAYER=GNU, set above."""
+    global _ref, _ref_omp
+    if omp:
+        if _ref_omp is None:
+            path = os.path.join(_HERE, "_ref", "libgcge_ref_omp.so")
+            if not os.path.exists(path):
+                return None
+            try:
+                _ref_omp = C.CDLL(path, mode=C.RTLD_LOCAL)
+            except OSError:
+                return None
+        return _ref_omp
     if _ref is None:
         path = os.path.join(_HERE, "_ref", "libgcge_ref.so")
         if not os.path.exists(path):
@@ -81,9 +96,9 @@ def make_ops(quiet=True):
 
 
 def ref_gcg(A, B, nev, nev_max=0, block=0, nev_init=0, abs_tol=1e-1, rel_tol=1e-8, max_iter=500,
-            extra=(), given=None):
+            extra=(), given=None, omp=False):
     """given: (n, nevGiven) array of start vectors (the nevGiven argument of ops->EigenSolver)."""
-    r = ref_lib()
+    r = ref_lib(omp)
     nm = nev_max if nev_max > 0 else 2 * nev
     ev = np.zeros(nm)
     conv, it, sec = C.c_int(), C.c_int(), C.c_double()

@@ -8,6 +8,10 @@ the back-end's stream and RCCL's, and the device round trip of the small all-red
 exactly that code against itself: rank 0 plays the lower slab of a 2-slab Laplacian and its "neighbour" is itself
 (RCCL allows send/recv to the own rank inside one group), so the ghost plane it receives is its own last plane.  The
 operator this defines is known in closed form: the local block with the diagonal of the last plane reduced by one.
+
+argv[2] == "native": the production path — RCCL called from C inside libgcge_hip.so (csrc/hip/rccl_comm.hip:
+gcge_hip_comm_init, gcge_hip_mat_set_halo_rccl with both virtual slabs mapped to rank 0, all-reduces through
+GCGE_COMM -> ncclAllReduce); torch.distributed is not initialised at all.  Otherwise: the torch.distributed callbacks.
 """
 import ctypes as C
 import os
@@ -22,10 +26,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 def main():
     dims = tuple(int(t) for t in (sys.argv[1] if len(sys.argv) > 1 else "8,8,10").split(","))
+    native = len(sys.argv) > 2 and sys.argv[2] == "native"
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    if not native:
+        dist.init_process_group("nccl", rank=0, world_size=1)
     from gcge_amd import HipBackend
     from gcge_amd import dist as gdist
     from gcge_amd.lib import CSR, host_lib, run_gcg
@@ -48,14 +54,28 @@ def main():
             return np.ascontiguousarray(send_rows), [0, plane], [0, plane]
 
     be = HipBackend(device=0)
-    comm = LoopbackComm(dist, 0, 1, device=torch.device("cuda", 0))
-    comm.install()
+    if native:
+        comm = gdist.NativeComm(be, None, 0, 1)
+    else:
+        comm = LoopbackComm(dist, 0, 1, device=torch.device("cuda", 0))
+        comm.install()
     A = CSR(); h.gcge_problem_lap3d_box(nx, ny, nz, C.c_int64(0), C.c_int64(n_loc), C.byref(A))
     S = csr_to_scipy(A).tocsr()[:, :n_loc].tolil()              # global columns -> local block
     for r in range(n_loc - plane, n_loc):
         S[r, r] -= 1.0                                        # ghost row (i,j,nz/2) == own row (i,j,nz/2-1), coefficient -1
     S = S.tocsr()
-    mat = gdist.hip_slab_matrix(be, comm, A, n_global, part, cap_cols=64)
+    if native:
+        ghosts = gdist.localize_slab(A)
+        assert ghosts.size == plane and ghosts[0] == n_loc
+        mat = be.matrix(A)
+        ip_ = C.POINTER(C.c_int)
+        send_rows = np.ascontiguousarray(ghosts - plane, dtype=np.int32)       # slab 1 wants the plane below its first one
+        peer, scnt, rcnt = (C.c_int * 2)(0, 0), (C.c_int * 2)(0, plane), (C.c_int * 2)(0, plane)
+        be.g.gcge_hip_mat_set_halo_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, ip_, ip_, ip_, ip_, C.c_int]
+        rc = be.g.gcge_hip_mat_set_halo_rccl(mat, n_global, 2, peer, scnt, rcnt, send_rows.ctypes.data_as(ip_), 64)
+        assert rc == 0, rc
+    else:
+        mat = gdist.hip_slab_matrix(be, comm, A, n_global, part, cap_cols=64)
     be.set_random_mode(1, 777)
 
     # 1. SpMM through both forms of the exchange (single call / split with the interior rows multiplied in between)
@@ -90,9 +110,30 @@ def main():
         exact = np.sort(sla.eigsh(S, k=res.nevConv, sigma=0.0, which="LM", return_eigenvectors=False))
     rel = np.max(np.abs(ev[:res.nevConv] - exact) / exact)
     assert res.nevConv >= 8 and rel < 1e-10, (res.nevConv, res.numIter, rel, list(ev[:10]))
-    print("rccl loop-back ok: dims=%s nevConv=%d numIter=%d rel=%.2e allreduces=%d" % (dims, res.nevConv, res.numIter, rel, comm.n_allreduce))
-    dist.barrier()
-    dist.destroy_process_group()
+    note = ""
+    if native:
+        # latency of the small all-reduce (host buffer in, host buffer out) through the C path
+        import time
+        x3 = be.mv_from_numpy(mat, X[:, :4])
+        be.ops.inner_prod("D", x3, x3, (0, 0), (4, 4))
+        t0 = time.perf_counter()
+        for _ in range(200):
+            be.ops.inner_prod("D", x3, x3, (0, 0), (4, 4))
+        t_with = (time.perf_counter() - t0) / 200
+        n0 = comm.n_allreduce
+        be.h.GCGE_SetComm(None)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            be.ops.inner_prod("D", x3, x3, (0, 0), (4, 4))
+        t_without = (time.perf_counter() - t0) / 200
+        note = " allreduce_us=%.1f (dot with %.1f us, without %.1f us)" % (1e6 * (t_with - t_without), 1e6 * t_with, 1e6 * t_without)
+        assert n0 > 0
+        be.free_matrix(mat)
+        comm.finalize()
+    print("rccl loop-back ok: dims=%s nevConv=%d numIter=%d rel=%.2e allreduces=%d%s" % (dims, res.nevConv, res.numIter, rel, comm.n_allreduce if not native else n0, note))
+    if not native:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -81,6 +81,19 @@ def test_two_ranks_on_one_gpu_hip():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dims", ["8,8,10", "32,32,40"])
+def test_rccl_native_loopback_one_gpu(dims):
+    """The production multi-GPU path: RCCL called from C inside libgcge_hip.so (gcge_hip_comm_init, grouped
+    ncclSend/ncclRecv halo exchange on the back-end's streams, ncclAllReduce behind GCGE_COMM), one rank exchanging
+    its halo with itself.  No torch.distributed in the process."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_loopback_worker.py"), dims, "native"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "rccl loop-back ok" in p.stdout, p.stdout[-3000:]
+    print(p.stdout[-300:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", ["8,8,10", "32,32,40"])
 def test_rccl_loopback_one_gpu(dims):
     """The production transport (backend nccl == RCCL) on device buffers, one rank exchanging its halo with itself:
     see tests/rccl_loopback_worker.py.  The second size makes the split exchange overlap a real interior product."""
@@ -103,3 +116,17 @@ def test_two_ranks_disagree_on_the_cg_ring_length():
     value (block_pcg.hip: vote over GCGE_COMM).  Rank 0 may take 15 extra slots, rank 1 none: both must run without a
     ring, with matching all-reduce counts, to the same Ritz values."""
     _run("hip", rank_env={0: {"GCGE_CG_RING": "16"}, 1: {"GCGE_CG_RING": "3"}})
+
+
+@pytest.mark.gpu
+def test_c_host_drives_the_backend_with_rccl(tmp_path):
+    """tools/test_app_hip_multi.c: a plain-C program (no Python, no torch, no MPI) that initialises RCCL through the
+    C ABI, builds its slab with gcge_hip_mat_create_slab and solves — here as a world of one rank on the one GPU."""
+    exe = str(tmp_path / "test_app_hip_multi")
+    lib = os.path.join(ROOT, "gcge_amd", "lib")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "test_app_hip_multi.c"),
+                    "-o", exe, "-L" + lib, "-lgcge_hip", "-lgcge_host", "-Wl,-rpath," + lib, "-lm"], check=True)
+    env = dict(os.environ, GCGE_RANK="0", GCGE_WORLD="1", GCGE_LOCAL_DEVICE="0", GCGE_ID_FILE=str(tmp_path / "id"),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([exe, "16", "10"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and " OK" in p.stdout, p.stdout[-2000:]
