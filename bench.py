@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the GCG hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config c2|c4]
 
-A "step" is ONE full eigensolve (GCG to convergence) of BASELINE.json config 2:
-3-D 7-point Laplacian 256^3 (n = 16 777 216, CSR), nev = 50, block = 64, nevMax = 128,
-standard problem, harness-default parameters (test/test_eig_sol_gcg.c:33-49,98-115 of
-the reference), fused device block-CG behind ops->MultiLinearSolver, matrix and all
-blocks of vectors resident in HBM before the timed region starts.
+A "step" is ONE full eigensolve (GCG to convergence).  Default workload = BASELINE.json config 2: 3-D 7-point
+Laplacian 256^3 (n = 16 777 216, CSR), nev = 50, block = 64, nevMax = 128, standard problem, harness-default
+parameters (test/test_eig_sol_gcg.c:33-49,98-115 of the reference), fused device block-CG behind
+ops->MultiLinearSolver, matrix and all blocks of vectors resident in HBM before the timed region starts.  With
+--gpus N every rank owns 256^3 rows of a box that stays as cube-like as N allows (weak scaling; N = 8: 512^3 =
+the grid of BASELINE config 4); --config c4 additionally switches the solver shape to config 4's (nev 200,
+block 128, nevMax 400).  Multi-GPU data path: RCCL called from C inside libgcge_hip.so (csrc/hip/rccl_comm.hip);
+torch.distributed only hands rank 0's RCCL id to the other ranks and synchronises the timed region.
   value    = converged eigenpairs per second over the K timed solves (whole job)
-  roofline = K1 CSR SpMM: algorithmic bytes (12 nnz + 4(n+1) + 16 n m) of the m = block
-             launches / their average duration from HIP events inside the timed region
-  cpu_baseline = the reference's own CPU path (oracle/_ref, kind "reference") or our C
-             restatement (kind "port") on a bounded sample of the same workload.
+  roofline = the HBM-bound kernel with the largest share of the step (the second pass of a block-CG iteration);
+             roofline_k1_spmm = the plain product K1 (MatDotMultiVec), roofline_cg_pass1/2 = the two CG passes.
+             achieved = algorithmic bytes / average launch duration from HIP events on the launch stream inside the
+             timed region; frac_required prices the same launches at the bytes the kernel must move on the
+             pattern path (2 B per row for the matrix instead of 12 B per non-zero);
+             traffic = fabric bytes per launch from rocprofv3 PMC passes (tools/pmc_traffic.py ->
+             profiles/pmc_traffic.json), quoted only while the HIP sources hash to what was profiled.
+  cpu_baseline = the reference's own CPU path, OpenMP build (oracle/_ref/libgcge_ref_omp.so: app_ccs.c:117-131
+             under OPS_USE_OMP), all host cores, on BASELINE config 1 (Lap3D 50^3, nev 20, block 20) — with the
+             GPU's time on that SAME config beside it (gpu_same_config); kind "port" = our C restatement when the
+             compiled reference is absent.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -35,47 +45,107 @@ def parse():
     ap.add_argument("--nev", type=int, default=50)
     ap.add_argument("--block", type=int, default=64)
     ap.add_argument("--nevmax", type=int, default=128)
-    ap.add_argument("--cpu-size", type=int, default=40, help="grid size of the CPU-baseline sample")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"],
+                    help="solver shape: c2 = nev 50 / block 64 / nevMax 128 (BASELINE config 2), c4 = nev 200 / block 128 / nevMax 400")
+    ap.add_argument("--cpu-size", type=int, default=50, help="grid size of the CPU baseline (50 = BASELINE config 1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--orth", default="chol", help="block orthonormalisation scheme for X and W: chol | mgs | bgs")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.config == "c4":
+        a.nev, a.block, a.nevmax = 200, 128, 400
+    return a
 
 
-# fabric bytes per 64-column launch at C2 (256^3, chain2 kernels) from profiles/r01_bench/12_cg_pass_pmc.txt:
-# 4 passes x (TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B)
-PMC_PASS1 = 4 * (2.33868e7 * 128 + 2048 * 64)
-PMC_PASS2 = 4 * (4.16776e7 * 128 + 6.7111e7 * 64)      # 15_cg_pass_pmc_nt_residual_loads.txt (r read non-temporally)
+def host_cores():
+    """Cores this process may use: the affinity mask, cut by a cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = max(1, min(n, int(float(q[0]) / float(q[1]) + 0.5)))
+    except (OSError, ValueError, IndexError):
+        pass
+    return n
 
 
-def cpu_baseline(args):
-    """Reference CPU path on a bounded sample: same solver configuration, smaller grid."""
+def hip_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gcge_amd", "csrc", "hip")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic(kernel, N, m):
+    """(bytes per m-column operation, note) from profiles/pmc_traffic.json, or (None, why not)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "no profiles/pmc_traffic.json"
+    if t.get("source_sha256") != hip_source_hash():
+        return None, "profiles/pmc_traffic.json was measured on other kernel sources (hash differs): not quoted"
+    sh = t.get("shape", {})
+    if sh.get("N") != N or sh.get("m") != m:
+        return None, "profiles/pmc_traffic.json holds N=%s m=%s" % (sh.get("N"), sh.get("m"))
+    k = t.get("kernels", {}).get(kernel)
+    if not k or "fabric_bytes_per_block_operation" not in k:
+        return None, "kernel %s not in profiles/pmc_traffic.json" % kernel
+    return k["fabric_bytes_per_block_operation"], "profiles/pmc_traffic.json (%s; sources %s)" % (t.get("bytes_rule", ""), t["source_sha256"][:12])
+
+
+def cpu_baseline(args, hip):
+    """The reference's CPU path on BASELINE config 1 (Lap3D 50^3, nev 20, block 20, nevMax 40), OpenMP build, all
+    host cores; and the GPU on that same config."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle as po
     from gcge_amd.lib import make_problem, run_gcg
-    N = args.cpu_size
+    N, nev = args.cpu_size, 20
     A, _ = make_problem("lap3d", N)
-    sample = "Lap3D %d^3 (n=%d), nev=%d, block=%d, nevMax=%d, same parameters" % (N, A.nrows, args.nev, args.block, args.nevmax)
-    ref = po.ref_lib()
+    cores = host_cores()
+    sample = "BASELINE config 1: Lap3D %d^3 (n=%d), nev=20, block=20, nevMax=40, harness parameters" % (N, A.nrows)
+    # the GPU on the same config (same start vectors: the reference's rand() stream; chol orthonormalisation + fused CG)
+    g = hip.g
+    mat = hip.matrix(A)
+    hip.set_random_mode(0)
+    g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    sargs = ["-nevConv", nev, "-gcge_initX_orth_method", args.orth, "-gcge_compW_orth_method", args.orth]
+    run_gcg(hip.ops_handle, mat, None, sargs, flag=1)
+    C.CDLL(None).srand(0)
+    ev_g, res_g = run_gcg(hip.ops_handle, mat, None, sargs, flag=1)
+    hip.free_matrix(mat)
+    gpu = {"value": res_g.nevConv / res_g.seconds, "unit": "eigenpairs/s", "seconds": res_g.seconds,
+           "gcg_iterations": res_g.numIter, "nev_converged": res_g.nevConv}
+    ref = po.ref_lib(omp=True)
     if ref is not None:
-        # the reference is serial C over threaded MKL; more than ~16 threads only adds fork/join cost to its
-        # skinny BLAS calls, so pin the count and report exactly that as `cores`
-        cores = min(16, os.cpu_count() or 1)
+        try:                                   # libgomp was initialised when torch was imported: set the team size now
+            C.CDLL("libgomp.so.1").omp_set_num_threads(C.c_int(cores))
+        except OSError:
+            pass
         try:
             mkl = C.CDLL("libmkl_rt.so.1", mode=C.RTLD_GLOBAL)
             mkl.MKL_Set_Num_Threads(C.c_int(cores))
-            cores = int(mkl.MKL_Get_Max_Threads())
         except (OSError, AttributeError):
-            cores = os.cpu_count() or 1
-        ev, conv, it, sec = po.ref_gcg(A, None, args.nev, nev_max=args.nevmax, block=args.block)
+            pass
+        ev, conv, it, sec = po.ref_gcg(A, None, nev, omp=True)
+        import numpy as np
+        k = min(conv, res_g.nevConv)
+        gpu["max_rel_diff_vs_cpu_reference"] = float(np.max(np.abs(ev_g[:k] - ev[:k]) / np.abs(ev[:k])))
         return {"value": conv / sec, "unit": "eigenpairs/s", "cores": cores, "kind": "reference",
-                "sample": sample + "; stock serial app_ccs build, threaded MKL BLAS/LAPACK; %d GCG its, %.1f s" % (it, sec)}
+                "sample": sample + "; OPS_USE_OMP build of app_ccs/app_lapack (oracle/Makefile ref_omp), OMP_NUM_THREADS = MKL threads = %d, "
+                                   "MKL_THREADING_LAYER=GNU; %d GCG its, %d pairs, %.1f s" % (cores, it, conv, sec),
+                "gpu_same_config": gpu}
     ops = po.make_ops()
-    po.oracle_lib().oracle_set_threads(os.cpu_count() or 1)
+    po.oracle_lib().oracle_set_threads(cores)
     m = po.ccs_from_csr(A)
-    ev, res = run_gcg(ops, C.byref(m), None, ["-nevConv", args.nev, "-nevMax", args.nevmax, "-blockSize", args.block])
-    return {"value": res.nevConv / res.seconds, "unit": "eigenpairs/s", "cores": os.cpu_count() or 1, "kind": "port",
-            "sample": sample + "; oracle/cpu_backend.c, OpenMP over block columns; %d GCG its, %.1f s" % (res.numIter, res.seconds)}
+    ev, res = run_gcg(ops, C.byref(m), None, ["-nevConv", nev])
+    return {"value": res.nevConv / res.seconds, "unit": "eigenpairs/s", "cores": cores, "kind": "port",
+            "sample": sample + "; oracle/cpu_backend.c, OpenMP over block columns; %d GCG its, %.1f s" % (res.numIter, res.seconds),
+            "gpu_same_config": gpu}
 
 
 def main():
@@ -116,7 +186,9 @@ def main():
     # (1: N^3, 2: N x N x 2N, 4: N x 2N x 2N, 8: (2N)^3 = BASELINE config 4), cut into slabs along the last index
     dims = gdist.weak_scaling_box(N, world)
     if world > 1:
-        comm = gdist.install(hip, dist, rank, world, stage_through_host=rehearse)
+        # data path: RCCL inside the back-end (NativeComm); the rehearsal on one shared GPU cannot use RCCL and falls
+        # back to the torch.distributed callbacks staged through the host
+        comm = gdist.install(hip, dist, rank, world, stage_through_host=True) if rehearse else gdist.NativeComm(hip, dist, rank, world)
         A, mat = gdist.lap3d_slab(hip, dims, rank, world, comm)
         n_global = dims[0] * dims[1] * dims[2]
     else:
@@ -158,6 +230,8 @@ def main():
     for _ in range(args.warmup):
         run_gcg(hip.ops_handle, mat, None, solver_args, flag=1)
     g.gcge_hip_profile_enable(1)
+    g.gcge_hip_bpcg_time_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_double), C.c_int]
+    g.gcge_hip_bpcg_time_stats(None, None, 1)
     barrier()
     t0 = time.perf_counter()
     conv_total, iters, last = 0, 0, None
@@ -186,6 +260,9 @@ def main():
     ci, ai = C.c_long(), C.c_long()
     g.gcge_hip_bpcg_column_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
     g.gcge_hip_bpcg_column_stats(C.byref(ci), C.byref(ai))
+    cg_its, cg_sec = C.c_long(), C.c_double()
+    g.gcge_hip_bpcg_time_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_double), C.c_int]
+    g.gcge_hip_bpcg_time_stats(C.byref(cg_its), C.byref(cg_sec), 0)
     stats = {k: prof(k, args.block) for k in (0, 2, 3)}
     spmm_ms_all = sum(prof(k, 0)[1] for k in (0, 2, 3))
     g.gcge_hip_profile_enable(0)
@@ -202,34 +279,30 @@ def main():
         kbase = ("spmm_pattern", "spmm_pattern_chain", "spmm_pattern_chain2")[chain] if npat > 0 else "spmm_pad8"
         npass = (args.block + 15) // 16 if npat > 0 else 1
 
-        def roof(kind, what, traffic=None, note="no PMC profile for this shape"):
+        def roof(kind, what, streams):
             # `achieved` prices a launch at its ALGORITHMIC bytes: kind 0: SURVEY.md 8(d), 12 B per
             # non-zero + row pointers + X read + Y written; kind 2: matrix + p read; kind 3: matrix + p, r read + r,
-            # p_new written.  On the pattern path the matrix itself is streamed as 2 B per row, so the bytes actually
-            # moved are lower; the block streams (8 n m each) dominate either way.  One "launch" = the `npass` kernel
-            # launches of 16 columns that make up one m-column operation (rocprof lists the 16-column launches).
+            # p_new written.  `required` is what the pattern kernels must move at least: `streams` block streams of
+            # 8 n m bytes + 2 B of pattern id per row and 16-column pass (the matrix is not read as CSR there).
+            # One "launch" = the `npass` kernel launches of 16 columns that make up one m-column operation (rocprof
+            # lists the 16-column launches).
             c_, ms_, by_ = stats[kind]
             if c_ == 0:
                 return None
             ach = (by_ / c_) / (ms_ / c_ * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": "%s<7,%d> x %d passes of 16 columns: %s (%d row patterns, m=%d)"
-                                              % (kbase, kind if kind else 0, npass, what, npat, args.block),
+            kname = "%s<7,%d,16>" % (kbase, kind)
+            traffic, note = pmc_traffic(kname, N, args.block) if (npat > 0 and world == 1) else (None, "no PMC profile for this shape")
+            req = (8.0 * streams * args.block + 2.0 * npass) * A.nrows if npat > 0 else by_ / c_
+            return {"bound": "hbm", "kernel": "%s x %d passes of 16 columns: %s (%d row patterns, m=%d)"
+                                              % (kname, npass, what, npat, args.block),
                     "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                     "traffic_note": note, "launches": c_, "avg_launch_ms": ms_ / c_, "alg_bytes_per_launch": by_ / c_,
+                    "required_bytes_per_launch": req, "frac_required": req / (ms_ / c_ * 1e-3) / 1e9 / 8000.0,
                     "share_of_step": ms_ * 1e-3 / elapsed if elapsed > 0 else None}
 
-        # HBM/fabric bytes per launch from separate rocprofv3 --pmc passes at this shape (not collected live: counters
-        # need their own runs): TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B, gfx950 correction of MI355X_MICROARCH.md
-        pmc_ok = npat > 0 and N == 256 and args.block == 64 and world == 1 and chain == 2
-        r_k1 = roof(0, "Y = A X, K1 (MatDotMultiVec)",
-                    4 * (2.35094e7 * 128 + 3.35544e7 * 64) if pmc_ok else None,
-                    "4 passes x (2.351e7 x 128 B reads + 3.355e7 x 64 B writes), profiles/r01_spmm_explore/23_chain2_pmc.log"
-                    if pmc_ok else "no PMC profile for this shape")
-        r_p1 = roof(2, "CG pass 1, p.Ap and |Ap|^2 without storing Ap", PMC_PASS1 if pmc_ok else None,
-                    "profiles/r01_bench/12_cg_pass_pmc.txt" if pmc_ok else "no PMC profile for this shape")
-        r_p2 = roof(3, "CG pass 2, Ap recomputed + r -= alpha Ap, p' = r + beta p",
-                    PMC_PASS2 if pmc_ok and PMC_PASS2 else None,
-                    "profiles/r01_bench/15_cg_pass_pmc_nt_residual_loads.txt" if pmc_ok and PMC_PASS2 else "no PMC profile for this shape")
+        r_k1 = roof(0, "Y = A X, K1 (MatDotMultiVec)", 2)
+        r_p1 = roof(2, "CG pass 1, p.Ap and |Ap|^2 without storing Ap", 1)
+        r_p2 = roof(3, "CG pass 2, Ap recomputed + r -= alpha Ap, p' = r + beta p", 4)
         cands = [r for r in (r_k1, r_p1, r_p2) if r is not None]
         dominant = max(cands, key=lambda r: r["share_of_step"]) if cands else None
         out = {
@@ -243,6 +316,7 @@ def main():
                        "gcg_iterations": iters, "nev_converged": conv_total,
                        "max_rel_err_vs_closed_form": rel,
                        "cg_active_column_fraction": (ai.value / ci.value) if ci.value else None,
+                       "cg_iterations": cg_its.value, "ms_per_cg_iteration": 1e3 * cg_sec.value / cg_its.value if cg_its.value else None,
                        "phase_seconds": {k: getattr(res.timing, k) for k in ("initX", "checkconv", "compP", "compRR", "compRV", "compW", "linsol", "total")}},
             # the dominant kernel of the step; the K1 product alone (the north-star figure) and the other CG pass follow
             "roofline": dominant,
@@ -250,7 +324,7 @@ def main():
             "spmm_share_of_step": spmm_ms_all * 1e-3 / elapsed if elapsed > 0 else None,
         }
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, hip)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

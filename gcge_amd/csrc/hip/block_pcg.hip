@@ -402,6 +402,7 @@ struct HipBpcg {
   double* d_coef; int* d_flag; double* h_pin; int cap;
   long recompute_iters;         // iterations run in the two-pass form with the product recomputed (pattern matrices)
   long col_iters, active_col_iters;   // columns streamed per iteration, summed / of which still active (one-pass scheme)
+  long total_iters; double total_seconds;   // CG iterations and host wall time over all calls (bench.py: ms per CG iteration)
 };
 static HipBpcg g_bpcg = {30, 1e-2, 1e-14, "abs", {nullptr, nullptr, nullptr, nullptr}, {nullptr}, 0, 0, 0, 0, -1.0, 0, 0, nullptr, nullptr, nullptr, 0};
 
@@ -410,7 +411,15 @@ static void reduce_over_ranks(double* v, int n) {
   if (c != nullptr && n > 0) c->allreduce_sum(v, n, c->ctx);
 }
 
+static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx, int* end_bx, struct OPS_* ops);
 static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int* end_bx, struct OPS_* ops) {
+  HipBpcg* s = (HipBpcg*)ops->multi_linear_solver_workspace;
+  const double t0 = ops->GetWtime ? ops->GetWtime() : 0.0;
+  HIP_BlockPCG_run(mat, mv_b, mv_x, start_bx, end_bx, ops);
+  s->total_iters += s->niter;
+  if (ops->GetWtime) s->total_seconds += ops->GetWtime() - t0;
+}
+static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx, int* end_bx, struct OPS_* ops) {
   HipBpcg* s = (HipBpcg*)ops->multi_linear_solver_workspace;
   hipStream_t st = (hipStream_t)gcge_hip_stream();
   const int nrhs = end_bx[0] - start_bx[0];
@@ -751,6 +760,11 @@ extern "C" void gcge_hip_bpcg_stats(long* spmm_calls, long* spmm_cols, int* last
   if (last_niter) *last_niter = g_bpcg.niter;
 }
 extern "C" long gcge_hip_bpcg_recompute_iters(void) { return g_bpcg.recompute_iters; }
+extern "C" void gcge_hip_bpcg_time_stats(long* iters, double* seconds, int reset) {
+  if (iters) *iters = g_bpcg.total_iters;
+  if (seconds) *seconds = g_bpcg.total_seconds;
+  if (reset) { g_bpcg.total_iters = 0; g_bpcg.total_seconds = 0.0; }
+}
 extern "C" void gcge_hip_bpcg_column_stats(long* col_iters, long* active_col_iters) {
   if (col_iters) *col_iters = g_bpcg.col_iters;
   if (active_col_iters) *active_col_iters = g_bpcg.active_col_iters;

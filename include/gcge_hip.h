@@ -111,6 +111,8 @@ void gcge_hip_bpcg_stats (long *spmm_calls, long *spmm_cols, int *last_niter);
 long gcge_hip_bpcg_recompute_iters (void);
 /* columns the fused solver streamed, summed over its iterations, and how many of them were still active */
 void gcge_hip_bpcg_column_stats (long *col_iters, long *active_col_iters);
+/* CG iterations and host wall time spent inside the fused solver since the last reset (ms per CG iteration) */
+void gcge_hip_bpcg_time_stats (long *iters, double *seconds, int reset);
 void gcge_hip_bpcg_release (struct OPS_ *ops);
 
 /* ---- live measurement of the K1 launches (HIP events on the launch stream) ---------- */
