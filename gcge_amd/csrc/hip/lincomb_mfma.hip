@@ -134,6 +134,159 @@ __global__ __launch_bounds__(256, (RF == 2 && NT <= 4) ? 2 : 1) void lincomb_ker
   }
 }
 
+
+// ---- direct form: A fragments straight from global memory, accumulators pinned to AGPRs ------------------------------
+// The X tile does not go through LDS at all.  Lane (li = l & 15, kk = l >> 4) of a wave loads 16 bytes
+//     X[r + li][k0 + 8 j + 2 kk + {0,1}],  j = 0..3:   four loads cover the 32 columns of a k-tile for 16 rows,
+// and because the k index of an MFMA operand is just a summation index, the two halves of such a load feed two
+// MFMAs whose B fragments are the matching coefficient rows 8 j + 2 kk + h (h = 0, 1) — any assignment of the 32
+// k values of a tile to (j, kk, h) is a valid one.  What this removes against lincomb_kernel above: the register ->
+// LDS -> register round trip of X (16 ds_write_b64 + 2 barriers per tile) and the 8-byte global loads (an 8-byte lane
+// load costs the address path as much as a 16-byte one).  Only the coefficient tile (32 x 16 NT doubles, L2-resident)
+// is staged through LDS, double-buffered: one barrier per k-tile.  A wave owns RF = 2 row fragments (32 rows) and all
+// NT column fragments; the 2 NT accumulator tiles live in a[0 : 16 NT) by name (agpr_tiles.inc), so no v_accvgpr
+// shuttling.  k odd: the pair (k-1, k) would read one column past the operand; the last k-tile therefore blends the
+// second half of its loads with 0 by an integer mask (after the loads have been issued: no predicate near them).
+#include "agpr_tiles.inc"
+typedef double v2d_lc __attribute__((ext_vector_type(2)));
+
+template <int NT>
+__global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void lincomb_direct_kernel(long nrows, const double* __restrict__ x, long ldx, int k,
+    const double* __restrict__ cpad, int m, const double* __restrict__ beta, double* y, long ldy, int cs) {
+  extern __shared__ __align__(16) double lds[];       // [2][LC_KT][cs]
+  constexpr int RF = 2;
+  constexpr int CE = LC_KT * 16 * NT / 256;            // coefficient elements per thread and tile (2 NT)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int li = lane & 15, kk = lane >> 4;
+  const long r0 = (long)blockIdx.x * (64 * RF) + 32 * wave;
+#pragma unroll
+  for (int T = 0; T < RF * NT; ++T) agpr_tile_zero(T);
+
+  // per-lane row bases (clamped: rows past the end feed output rows that are never stored)
+  const double* xr[RF];
+#pragma unroll
+  for (int f = 0; f < RF; ++f) xr[f] = x + min(r0 + 16 * f + li, nrows - 1) * ldx + 2 * kk;
+  const int kpairs = (k + 1) / 2;                      // 16-byte column pairs that hold at least one valid column
+  auto fetch_a = [&](v2d_lc (&a)[RF][4], int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pr = min((k0 + 8 * j) / 2 + kk, kpairs - 1) - kk;   // pair index, clamped into the operand (meets a zero coefficient row)
+#pragma unroll
+      for (int f = 0; f < RF; ++f) a[f][j] = *reinterpret_cast<const v2d_lc*>(xr[f] + 2 * pr);
+    }
+  };
+  double cr[CE];
+  auto fetch_c = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < CE; ++q) {
+      const int e = threadIdx.x + 256 * q, row = e / (16 * NT), col = e % (16 * NT);
+      cr[q] = cpad[(long)(k0 + row) * (16 * NT) + col];
+    }
+  };
+  auto stash_c = [&](int buf) {
+    double* cst = lds + buf * LC_KT * cs;
+#pragma unroll
+    for (int q = 0; q < CE; ++q) {
+      const int e = threadIdx.x + 256 * q, row = e / (16 * NT), col = e % (16 * NT);
+      cst[row * cs + col] = cr[q];
+    }
+  };
+  auto mfmas = [&](const v2d_lc (&a)[RF][4], int buf) {
+    const double* cst = lds + buf * LC_KT * cs + li;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const double b = cst[(8 * j + 2 * kk + h) * cs + 16 * t];
+#pragma unroll
+          for (int f = 0; f < RF; ++f) agpr_tile_mfma(f * NT + t, h ? a[f][j].y : a[f][j].x, b);
+        }
+  };
+  const int ntile = (k + LC_KT - 1) / LC_KT;
+  v2d_lc a0[RF][4], a1[RF][4];
+  fetch_c(0);
+  fetch_a(a0, 0);
+  stash_c(0);
+  __syncthreads();
+  // tiles in pairs with two register sets (no copy, no branch inside); the last tile is peeled for the odd-k blend
+  int tl = 0;
+  for (; tl + 2 < ntile; tl += 2) {
+    fetch_a(a1, (tl + 1) * LC_KT); fetch_c((tl + 1) * LC_KT);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    stash_c(1);
+    __syncthreads();
+    fetch_a(a0, (tl + 2) * LC_KT); fetch_c((tl + 2) * LC_KT);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    stash_c(0);
+    __syncthreads();
+  }
+  // here: a0 / LDS buffer 0 hold tile tl; 1 or 2 tiles remain
+  const long odd_mask = (k & 1) ? 0L : -1L;            // all ones: keep the second half of the last valid pair
+  auto blend_last = [&](v2d_lc (&a)[RF][4], int k0) {   // zero x[.., k] where the pair (k-1, k) straddles the end
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool straddles = 2 * ((k0 + 8 * j) / 2 + kk) + 1 >= k;
+      const long keep = straddles ? odd_mask : -1L;
+#pragma unroll
+      for (int f = 0; f < RF; ++f) a[f][j].y = __longlong_as_double(__double_as_longlong(a[f][j].y) & keep);
+    }
+  };
+  if (tl + 2 == ntile) {
+    fetch_a(a1, (tl + 1) * LC_KT); fetch_c((tl + 1) * LC_KT);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    stash_c(1);
+    __syncthreads();
+    blend_last(a1, (tl + 1) * LC_KT);
+    mfmas(a1, 1);
+  } else {
+    blend_last(a0, tl * LC_KT);
+    mfmas(a0, 0);
+  }
+  // the MFMAs are inline asm, invisible to the hazard recogniser: let the last ones retire before the tiles are read
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int f = 0; f < RF; ++f) {
+    const long rw = r0 + 16 * f;
+    double acc[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[t][u] = agpr_tile_read(f * NT + t, u);
+    if (beta != nullptr) {
+      double yv[NT][4], bj[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int colc = min(16 * t + li, m - 1);
+        bj[t] = beta[colc];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) yv[t][u] = y[min(rw + 4 * u + kk, nrows - 1) * ldy + colc];
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = fma(bj[t], yv[t][u], acc[t][u]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = 16 * t + li;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long row = rw + 4 * u + kk;
+        if (col < m && row < nrows) y[row * ldy + col] = acc[t][u];
+      }
+    }
+  }
+}
+
 }  // namespace gcge
 
 // cpad (kp x mp, row-major, zero outside k x m) <- c (k x m, row-major)
@@ -149,8 +302,9 @@ using namespace gcge;
 
 static double* g_cpad = nullptr;
 static size_t g_cpad_len = 0;
-static int g_lc_rf = 0;   // row fragments per wave: 0 automatic, 1 / 2 forced (tuning)
-extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 0 && row_fragments <= 2) g_lc_rf = row_fragments; }
+static int g_lc_rf = 0;   // 0 automatic (the direct form where the operand allows 16-byte loads); 1 / 2: the LDS-staged kernel with
+                          // that many row fragments per wave; 3: the direct form forced (falls back when x is not 16-byte aligned)
+extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 0 && row_fragments <= 3) g_lc_rf = row_fragments; }
 
 template <int NT>
 static int lc_launch(int nrows, const double* x, long ldx, int k, const double* c, int m,
@@ -162,11 +316,19 @@ static int lc_launch(int nrows, const double* x, long ldx, int k, const double* 
     GCGE_HIP_CHECK(hipMalloc(&g_cpad, g_cpad_len * sizeof(double)));
   }
   hipLaunchKernelGGL(lincomb_pad_c, dim3((kp * mp + 255) / 256), dim3(256), 0, st, c, k, m, g_cpad, kp, mp);
+  // direct form: X read with 16-byte lane loads straight into MFMA operands (needs a 16-byte aligned operand)
+  if ((g_lc_rf == 0 || g_lc_rf == 3) && (((uintptr_t)x & 15) == 0) && (ldx % 2 == 0) && k >= 2) {
+    const int csd = 16 * NT + 8;   // coefficient rows 2 apart land on the other half of the 64 LDS banks
+    const size_t shd = (size_t)2 * LC_KT * csd * sizeof(double);
+    const unsigned gridd = (unsigned)(((long)nrows + 127) / 128);
+    hipLaunchKernelGGL((lincomb_direct_kernel<NT>), dim3(gridd), dim3(256), shd, st, (long)nrows, x, ldx, k, g_cpad, m, beta, y, ldy, csd);
+    return 0;
+  }
   const int cs = (16 * NT + 31) / 32 * 32 + 16;  // row stride of the C tile: 16 mod 32 doubles
   // two row fragments per wave once there are enough rows to fill the chip with 128-row blocks several times over
   // and enough MFMA work per tile to pay for the larger register set (n = 2^24, k = 256: m = 128 27.1 -> 23.9 ms =
   // 46 TF, m = 64 12.0 -> 11.3 ms = 48.5 TF with two waves per SIMD; k = 64 and narrower panels: no gain)
-  const int rf = (g_lc_rf == 0) ? (((NT == 8 || (NT == 4 && k >= 128)) && (long)nrows >= 128L * 256 * 8) ? 2 : 1) : g_lc_rf;
+  const int rf = (g_lc_rf == 0 || g_lc_rf == 3) ? (((NT == 8 || (NT == 4 && k >= 128)) && (long)nrows >= 128L * 256 * 8) ? 2 : 1) : g_lc_rf;
   const size_t shmem = (size_t)(64 * rf * LC_XS + LC_KT * cs) * sizeof(double);
   const unsigned grid = (unsigned)(((long)nrows + 64 * rf - 1) / (64 * rf));
   if (rf == 2)

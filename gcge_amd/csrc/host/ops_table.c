@@ -28,7 +28,9 @@ static GCGE_COMM *g_comm = NULL;
 
 void GCGE_SetComm(const GCGE_COMM *comm)
 {
-	if (comm == NULL || comm->size <= 1) { g_comm = NULL; return; }
+	/* a communicator of one rank is dropped (nothing to sum) unless GCGE_COMM_KEEP_SINGLE is set: the single-GPU
+	 * loop-back tests route every reduction through the real transport that way */
+	if (comm == NULL || (comm->size <= 1 && getenv("GCGE_COMM_KEEP_SINGLE") == NULL)) { g_comm = NULL; return; }
 	g_comm_storage = *comm; g_comm = &g_comm_storage;
 }
 GCGE_COMM *GCGE_GetComm(void) { return g_comm; }

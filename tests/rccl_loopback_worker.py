@@ -27,6 +27,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 def main():
     dims = tuple(int(t) for t in (sys.argv[1] if len(sys.argv) > 1 else "8,8,10").split(","))
     native = len(sys.argv) > 2 and sys.argv[2] == "native"
+    os.environ["GCGE_COMM_KEEP_SINGLE"] = "1"      # a world of one rank: keep the all-reduces on the transport
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
