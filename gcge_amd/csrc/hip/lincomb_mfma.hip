@@ -27,6 +27,7 @@
 // Roofline: 2 n k m flops (FP64 MFMA) vs 8 n (k + m [+ m]) bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "gcge_hip_internal.h"
 
 namespace gcge {
@@ -302,7 +303,7 @@ using namespace gcge;
 
 static double* g_cpad = nullptr;
 static size_t g_cpad_len = 0;
-static int g_lc_rf = 0;   // 0 automatic (the direct form where the operand allows 16-byte loads); 1 / 2: the LDS-staged kernel with
+static int g_lc_rf = getenv("GCGE_LINCOMB_RF") ? atoi(getenv("GCGE_LINCOMB_RF")) : 0;   // 0 automatic (the direct form where the operand allows 16-byte loads); 1 / 2: the LDS-staged kernel with
                           // that many row fragments per wave; 3: the direct form forced (falls back when x is not 16-byte aligned)
 extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 0 && row_fragments <= 3) g_lc_rf = row_fragments; }
 

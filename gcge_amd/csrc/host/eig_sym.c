@@ -182,7 +182,23 @@ static int ql_implicit(int n, double *d, double *e, double *q, double *cs, int n
  * triangle named by uplo is read).  w: eigenvalues ascending; z (ld ldz): the
  * matching orthonormal eigenvectors.  a is NOT modified.  work: >= 2n doubles.
  * Returns 0 on success (-1: out of memory). */
+/* A back-end may offer the same computation on its device for n >= min_n (GCGE_SetSymEigHook, gcge_solver.h): the HIP
+ * back-end registers csrc/hip/eig_device.hip.  GCGE_EIG_HOST=1 keeps everything on the host. */
+static GCGE_SYMEIG_FN g_eig_hook = NULL; static int g_eig_hook_min_n = 0;
+void GCGE_SetSymEigHook(GCGE_SYMEIG_FN fn, int min_n) { g_eig_hook = fn; g_eig_hook_min_n = min_n; }
+int GCGE_SymEigHost(char uplo, int n, const double *a, int lda, double *w, double *z, int ldz, double *work);
+
 int GCGE_SymEig(char uplo, int n, const double *a, int lda, double *w,
+		double *z, int ldz, double *work)
+{
+	if (g_eig_hook != NULL && n >= g_eig_hook_min_n && getenv("GCGE_EIG_HOST") == NULL) {
+		const int info = g_eig_hook(uplo, n, a, lda, w, z, ldz);
+		if (info == 0) return 0;            /* otherwise: fall through to the host solver */
+	}
+	return GCGE_SymEigHost(uplo, n, a, lda, w, z, ldz, work);
+}
+
+int GCGE_SymEigHost(char uplo, int n, const double *a, int lda, double *w,
 		double *z, int ldz, double *work)
 {
 	int i, j, info, nt;

@@ -122,6 +122,12 @@ long gcge_hip_profile_spmm (int ncols, double *total_ms, double *total_alg_bytes
  *     block-CG iteration in its recompute form (below); ncols == 0: all widths                                    */
 long gcge_hip_profile_kind (int kind, int ncols, double *total_ms, double *total_alg_bytes);
 
+/* ---- K7: small dense symmetric eigensolver on the device (replaces dsyevx, src/ops_eig_sol_gcg.c:1201-1203) ------
+ * all eigenpairs of the symmetric n x n matrix a (HOST, column-major, ld lda; triangle `uplo` is read): w ascending,
+ * z (HOST, ld ldz) orthonormal eigenvectors.  Householder tridiagonalisation and the accumulation of Q on the device,
+ * implicit QL on the host with recorded rotations, replayed on the device (csrc/hip/eig_device.hip).  0 on success.  */
+int gcge_hip_symeig (char uplo, int n, const double *a, int lda, double *w, double *z, int ldz);
+
 /* ---- raw kernels (what the slots launch; exposed for micro-benchmarks) --------- */
 /* K1  Y[:,0:m) = A X[:,0:m);  x/y point at (row 0, first column); see csrc/hip/spmm*.hip */
 int gcge_hip_csr_spmm  (int nrows, const int *d_rowptr, const int *d_colidx, const double *d_val,

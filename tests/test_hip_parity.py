@@ -552,10 +552,11 @@ def test_full_size_cg_passes_properties(hip):
     hip.free_matrix(mh)
 
 
-@pytest.mark.parametrize("rf", [1, 2])
+@pytest.mark.parametrize("rf", [1, 2, 3])
 def test_lincomb_row_fragment_variants_vs_oracle(both, rf):
-    """The panel update with one and with two 16-row fragments per wave (gcge_hip_lincomb_tune; the automatic choice
-    takes two only for n >= 2.6e5, which no small parity case reaches): ragged row count (2197 = 17 x 128 + 21),
+    """The panel update in its three forms (gcge_hip_lincomb_tune): X staged through LDS with one or two 16-row fragments
+    per wave, and (3) the direct form — X fragments from global memory with 16-byte loads, the default wherever the
+    operand is 16-byte aligned; odd column offsets fall back to the staged kernel: ragged row count (2197 = 17 x 128 + 21),
     k not a multiple of the 32-column tile, m not a multiple of 16, all three beta modes, x == y in place."""
     hip, ora = both
     A, mh, mo = _pair_mats(both, "lap3d", 13)
@@ -617,3 +618,55 @@ def test_fused_cg_workspace_follows_the_problem_shape(hip):
         hip.ops.mv_destroy(b, nrhs + 2); hip.ops.mv_destroy(x, nrhs + 4)
         hip.free_matrix(mat)
     g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+
+
+@pytest.mark.parametrize("n,kind", [(2, "rand"), (3, "rand"), (17, "rand"), (64, "cluster"), (130, "diag"), (320, "rand"),
+                                    (512, "cluster"), (656, "rand"), (656, "projected")])
+def test_device_symmetric_eigensolver(hip, n, kind):
+    """K7 on the device (gcge_hip_symeig: Householder tridiagonalisation + Q on the GPU, QL on the host with recorded
+    rotations, replay on the GPU) against numpy.linalg.eigh and the host solver GCGE_SymEig it replaces: eigenvalues
+    to 1e-13 ||A||, residuals and orthonormality to 1e-12, clustered spectra (multiplicities as on the Laplacian),
+    a diagonal matrix (nothing to annihilate), only the named triangle read, lda > n."""
+    import time
+    rng = np.random.default_rng(100 + n)
+    if kind == "rand":
+        A = rng.standard_normal((n, n)); A = (A + A.T) * 0.5 + np.diag(np.arange(n) * 0.01)
+    elif kind == "cluster":
+        lam = np.repeat(np.arange(1, n // 4 + 2, dtype=float), 4)[:n] * (1.0 + 1e-13 * rng.standard_normal(n))
+        Qr, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        A = (Qr * lam) @ Qr.T; A = (A + A.T) * 0.5
+    elif kind == "diag":
+        A = np.diag(rng.standard_normal(n))
+    else:   # the shape of the Rayleigh-Ritz matrix: diag(old Ritz values) + a dense border of the P / W blocks
+        A = np.diag(np.sort(rng.random(n)) * 3.0)
+        b = 256
+        Bd = rng.standard_normal((n, b)) * 0.1
+        A[:, n - b:] += Bd; A[n - b:, :] += Bd.T
+        A = (A + A.T) * 0.5
+    lda = n + 3
+    g = hip.g
+    g.gcge_hip_symeig.argtypes = [C.c_char, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    ref_w = np.linalg.eigvalsh(A)
+    nrm = max(np.abs(ref_w).max(), 1e-300)
+    for uplo in (b"U", b"L"):
+        a = np.full((lda, n), np.nan, order="F")                     # column-major with padding rows
+        tri = np.triu(A) if uplo == b"U" else np.tril(A)
+        mask = np.triu(np.ones((n, n), bool)) if uplo == b"U" else np.tril(np.ones((n, n), bool))
+        a[:n, :][mask] = tri[mask]
+        w = np.zeros(n); z = np.zeros((n, n), order="F")
+        t0 = time.perf_counter()
+        assert g.gcge_hip_symeig(uplo, n, a.ctypes.data, lda, w.ctypes.data, z.ctypes.data, n) == 0
+        dt = time.perf_counter() - t0
+        assert np.all(np.diff(w) >= 0)
+        assert np.max(np.abs(w - ref_w)) <= 1e-13 * nrm * max(1.0, n / 64), (n, kind, np.max(np.abs(w - ref_w)) / nrm)
+        assert np.max(np.abs(A @ z - z * w)) <= 1e-12 * nrm * max(1.0, n / 64)
+        assert np.max(np.abs(z.T @ z - np.eye(n))) <= 1e-12 * max(1.0, n / 64)
+    # the host solver on the same input, and both timings
+    hw = np.zeros(n); hz = np.zeros((n, n), order="F"); work = np.zeros(4 * n)
+    af = np.asfortranarray(A)
+    hip.h.GCGE_SymEigHost.argtypes = [C.c_char, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    t0 = time.perf_counter()
+    assert hip.h.GCGE_SymEigHost(b"U", n, af.ctypes.data, n, hw.ctypes.data, hz.ctypes.data, n, work.ctypes.data) == 0
+    th = time.perf_counter() - t0
+    assert np.max(np.abs(hw - w)) <= 1e-13 * nrm * max(1.0, n / 64)
+    print("symeig n=%d %s: device %.1f ms, host %.1f ms" % (n, kind, 1e3 * dt, 1e3 * th))
