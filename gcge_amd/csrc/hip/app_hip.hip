@@ -996,7 +996,7 @@ extern "C" void OPS_HIP_Set(struct OPS_* ops) {
   GCGE_SetResidualHook(HIP_ResidualSq, (void*)HIP_MatDotMultiVec);   /* used by our GCG driver for this table only */
   {   // K7 on the device for the projected matrices where the host solver dominates an outer iteration (eig_device.hip)
     const char* mn = getenv("GCGE_EIG_DEVICE_MIN_N");
-    GCGE_SetSymEigHook(gcge_hip_symeig, mn ? atoi(mn) : 320);
+    GCGE_SetSymEigHook(gcge_hip_symeig, mn ? atoi(mn) : 192);
   }
   ops->MatTransDotMultiVec      = HIP_MatTransDotMultiVec;
   ops->MultiVecQtAP             = nullptr;   // OPS_Setup installs SpMM-into-mv_ws + Gram

@@ -16,7 +16,7 @@
 //      the (c, s) pairs arrive through scalar loads).
 //   5. Ascending sort on the host, columns gathered while they are copied back.
 // Hooked into the GCG driver of libgcge_host.so through GCGE_SetSymEigHook (include/gcge_ops.h); OPS_HIP_Set registers
-// it for N >= 320 (below that the launch count, ~4 N, costs more than the host's 9-20 ms).  The reference's own stack
+// it for N >= 192 (below that the launch count, ~4 N, costs more than the host solver).  The reference's own stack
 // keeps calling its LAPACK.
 #include <hip/hip_runtime.h>
 #include <float.h>
@@ -25,6 +25,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <algorithm>
 #include <vector>
 
 #include "gcge_hip.h"
@@ -169,12 +171,85 @@ __global__ __launch_bounds__(64) void eig_replay(int n, double* __restrict__ q, 
   }
 }
 
+
+// ---- fused replay: EIG_K consecutive sweeps in one pass over the columns ---------------------------------------------
+// The plain replay above is latency-bound (one L2 round trip per eight rotations: 62 ms for the 4.3e5 rotations of
+// N = 656).  Rotation p of sweep j (columns hi_c - p, hi_c - p + 1 of the group's padded range) depends only on
+// rotation p - 1 of the same sweep and rotation p + 1 of the previous one, so at "time" t = p + 2 j the rotations
+// (j, t - 2 j), j = 0 .. K-1, touch disjoint column pairs: a lane carries a window of 2 K columns of its row in
+// registers, per time step takes ONE new column, applies K independent rotations and retires ONE finished column.
+// Sweeps of a group are padded with identity rotations to a common column range; the coefficients come time-major.
+// Columns and coefficients move between memory and LDS in chunks of EIG_TC time steps (64 independent loads per lane
+// issued back to back, then 64 stores), so the stepping loop itself only touches LDS: a first version that loaded and
+// stored one column per step from global memory ran at 1900 cycles per step — loads and stores share vmcnt on this
+// target, every prefetched load waited for the stores issued after it, and the wave-uniform coefficient loads (SMEM
+// returns out of order) forced lgkmcnt(0) in every step.  Register roles rotate with period 2 K: the loop is unrolled
+// by that, every index is a compile-time constant.  One wave per block: no barriers, LDS traffic of a wave is ordered.
+constexpr int EIG_K = 8, EIG_W = 2 * EIG_K, EIG_TC = 64;
+struct EigGroup { int hi_c, R; long off; };      // columns hi_c + 1 - x, x = 0 .. R; coefficients at cs[off ..), Tpad steps x 2 K
+__global__ __launch_bounds__(64) void eig_replay_fused(int n, double* __restrict__ q, const EigGroup* __restrict__ grp, int ngroup,
+    const double* __restrict__ cs) {
+  __shared__ double colb[EIG_TC][64];            // chunk of columns: read at its step, overwritten with the retired column
+  __shared__ double cfb[EIG_TC][2 * EIG_K];      // (c, s) of the chunk's time steps
+  const int lane = threadIdx.x;
+  const int r = blockIdx.x * 64 + lane;
+  const bool live = r < n;
+  double* qr = q + (live ? r : n - 1);           // surplus lanes shadow the last row and never store
+  for (int g = 0; g < ngroup; ++g) {
+    const int hi_c = grp[g].hi_c, R = grp[g].R;
+    const double* coef = cs + grp[g].off;
+    const int Tp = R + 2 * EIG_K - 1;             // the host pads the coefficient block to a multiple of EIG_TC steps
+    double w[EIG_W];
+#pragma unroll
+    for (int u = 0; u < EIG_W; ++u) w[u] = 0.0;
+    w[0] = qr[(size_t)(hi_c + 1) * n];            // x = 0
+    for (int tc = 0; tc < Tp; tc += EIG_TC) {
+      // chunk in: columns x = tc + 1 + c (clamped into the range: the surplus meets identity rotations), coefficients
+#pragma unroll 16
+      for (int c = 0; c < EIG_TC; ++c) colb[c][lane] = qr[(size_t)(hi_c + 1 - min(tc + 1 + c, R)) * n];
+      {
+        const double* src = coef + (size_t)(tc + lane) * (2 * EIG_K);
+#pragma unroll
+        for (int e = 0; e < 2 * EIG_K; ++e) cfb[lane][e] = src[e];
+      }
+      for (int c0 = 0; c0 < EIG_TC; c0 += EIG_W) {
+#pragma unroll
+        for (int u = 0; u < EIG_W; ++u) {
+          const int c = c0 + u;                   // t = tc + c;  t mod 2K == u because tc and c0 are multiples of 2K
+          w[(u + 1) % EIG_W] = colb[c][lane];
+#pragma unroll
+          for (int j = 0; j < EIG_K; ++j) {
+            const int ih = ((u - 2 * j) % EIG_W + EIG_W) % EIG_W, il = ((u - 2 * j + 1) % EIG_W + EIG_W) % EIG_W;
+            const double cc = cfb[c][2 * j], ss = cfb[c][2 * j + 1];
+            const double hv = w[ih], lv = w[il];
+            w[ih] = fma(ss, lv, cc * hv);
+            w[il] = fma(cc, lv, -ss * hv);
+          }
+          colb[c][lane] = w[((u - 2 * EIG_K + 2) % EIG_W + EIG_W) % EIG_W];   // column x = t - 2K + 2 is final
+        }
+      }
+      // chunk out
+#pragma unroll 16
+      for (int c = 0; c < EIG_TC; ++c) {
+        const int xo = tc + c - 2 * EIG_K + 2;
+        if (xo >= 0 && xo <= R && live) qr[(size_t)(hi_c + 1 - xo) * n] = colb[c][lane];
+      }
+    }
+  }
+}
+
 }  // namespace gcge
 
 using namespace gcge;
 
 // implicit QL on the tridiagonal (d, e), e[k] couples k and k+1 — the iteration of csrc/host/eig_sym.c with the
 // rotations recorded (descending column index inside a sweep) instead of applied.  0, or l+1 if eigenvalue l failed.
+// sqrt(f^2 + g^2); the libm hypot (over/underflow-proof, ~50 ns) only outside the range where the squares are safe
+static inline double pythag(double f, double g) {
+  const double af = fabs(f), ag = fabs(g), mx = af > ag ? af : ag;
+  if (mx < 1e150 && mx > 1e-150) return sqrt(f * f + g * g);
+  return hypot(f, g);
+}
 static int ql_record(int n, double* d, double* e, std::vector<EigSweep>& sweeps, std::vector<double>& cs) {
   for (int l = 0; l < n; ++l) {
     int iter = 0, m;
@@ -194,7 +269,7 @@ static int ql_record(int n, double* d, double* e, std::vector<EigSweep>& sweeps,
         for (i = m - 1; i >= l; --i) {
           double f = s * e[i];
           const double b = c * e[i];
-          e[i + 1] = r = hypot(f, g);
+          e[i + 1] = r = pythag(f, g);
           if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
           s = f / r; c = g / r;
           g = d[i + 1] - p;
@@ -212,7 +287,7 @@ static int ql_record(int n, double* d, double* e, std::vector<EigSweep>& sweeps,
   return 0;
 }
 
-struct EigWs { double *m, *q, *d, *e, *betas, *v, *p, *cs; EigSweep* sw; int cap_n; size_t cap_cs, cap_sw; double* h_pin; size_t cap_pin; };
+struct EigWs { double *m, *q, *d, *e, *betas, *v, *p, *cs; EigSweep* sw; int cap_n; size_t cap_cs, cap_sw; double* h_pin; size_t cap_pin; double* h_cs; size_t cap_hcs; };
 static EigWs g_eig = {};
 
 // All eigenpairs of the symmetric n x n matrix a (column-major, ld lda; only the triangle `uplo` is read).
@@ -249,6 +324,9 @@ extern "C" int gcge_hip_symeig(char uplo, int n, const double* a, int lda, doubl
       g.h_pin[(size_t)j * n + i] = t; g.h_pin[(size_t)i * n + j] = t;
     }
   GCGE_HIP_CHECK(hipMemcpyAsync(g.m, g.h_pin, nn * sizeof(double), hipMemcpyHostToDevice, st));
+  static const bool timing = getenv("GCGE_EIG_TIMING") != nullptr;   // phase times on stderr (tuning aid)
+  hipEvent_t tev[5];
+  if (timing) { for (auto& ev_ : tev) GCGE_HIP_CHECK(hipEventCreate(&ev_)); GCGE_HIP_CHECK(hipEventRecord(tev[0], st)); }
   // 1. tridiagonal reduction
   for (int k = 0; k < n - 2; ++k) {
     const int len = n - k - 1;
@@ -259,6 +337,7 @@ extern "C" int gcge_hip_symeig(char uplo, int n, const double* a, int lda, doubl
   hipLaunchKernelGGL(eig_tail, dim3(1), dim3(64), 0, st, n, g.m, g.d, g.e);
   GCGE_HIP_CHECK(hipMemcpyAsync(g.h_pin, g.d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
   GCGE_HIP_CHECK(hipMemcpyAsync(g.h_pin + n, g.e, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (timing) GCGE_HIP_CHECK(hipEventRecord(tev[1], st));
   // 2. Q (runs while the host works on the tridiagonal matrix)
   hipLaunchKernelGGL(eig_identity, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, n, g.q);
   hipEvent_t ev_de;
@@ -268,25 +347,82 @@ extern "C" int gcge_hip_symeig(char uplo, int n, const double* a, int lda, doubl
     const int len = n - k - 1;
     hipLaunchKernelGGL(eig_apply_q, dim3((len + 3) / 4), dim3(256), 0, st, n, k, g.m, g.betas, g.q);
   }
+  if (timing) GCGE_HIP_CHECK(hipEventRecord(tev[2], st));
   GCGE_HIP_CHECK(hipEventSynchronize(ev_de));
   GCGE_HIP_CHECK(hipEventDestroy(ev_de));
   // 3. QL on the host, rotations recorded
+  auto wall = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return 1e3 * ts.tv_sec + 1e-6 * ts.tv_nsec; };
+  const double w0 = wall();
   std::vector<double> d(g.h_pin, g.h_pin + n), e(g.h_pin + n, g.h_pin + 2 * n);
   std::vector<EigSweep> sweeps; std::vector<double> cs;
   cs.reserve((size_t)4 * n * n);
   const int info = ql_record(n, d.data(), e.data(), sweeps, cs);
   if (info != 0) { GCGE_HIP_CHECK(hipStreamSynchronize(st)); return info; }
-  // 4. replay on the device
-  if (!sweeps.empty()) {
+  const double w1 = wall();
+  // 4. replay on the device: groups of EIG_K consecutive sweeps, padded to a common column range, coefficients time-major
+  static const bool plain_replay = getenv("GCGE_EIG_PLAIN_REPLAY") != nullptr;
+  size_t n_rot = cs.size() / 2;
+  if (!sweeps.empty() && !plain_replay) {
+    std::vector<EigGroup> groups;
+    size_t total = 0;
+    for (size_t a = 0; a < sweeps.size(); a += EIG_K) {
+      const size_t bnd = std::min(sweeps.size(), a + EIG_K);
+      int hi_c = 0, lo_c = n;
+      for (size_t q = a; q < bnd; ++q) { hi_c = std::max(hi_c, sweeps[q].first); lo_c = std::min(lo_c, sweeps[q].last); }
+      const int R = hi_c - lo_c + 1;
+      groups.push_back(EigGroup{hi_c, R, (long)total});
+      total += (size_t)((R + 2 * EIG_K - 1 + EIG_TC - 1) / EIG_TC * EIG_TC) * (2 * EIG_K);
+    }
+    if (total > g.cap_hcs) {
+      GCGE_HIP_CHECK(hipStreamSynchronize(st));
+      if (g.h_cs) hipHostFree(g.h_cs);
+      g.cap_hcs = total * 2;
+      GCGE_HIP_CHECK(hipHostMalloc(&g.h_cs, g.cap_hcs * sizeof(double)));
+    }
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      const EigGroup& G = groups[gi];
+      double* co = g.h_cs + G.off;
+      const int Tp = (G.R + 2 * EIG_K - 1 + EIG_TC - 1) / EIG_TC * EIG_TC;
+      for (int t = 0; t < Tp; ++t)
+        for (int j = 0; j < EIG_K; ++j) { co[(size_t)t * 2 * EIG_K + 2 * j] = 1.0; co[(size_t)t * 2 * EIG_K + 2 * j + 1] = 0.0; }
+      for (int j = 0; j < EIG_K && gi * EIG_K + j < sweeps.size(); ++j) {
+        const EigSweep& S = sweeps[gi * EIG_K + j];
+        for (int i = S.first; i >= S.last; --i) {
+          const int pp = G.hi_c - i, t = pp + 2 * j;
+          co[(size_t)t * 2 * EIG_K + 2 * j] = cs[2 * (S.off + S.first - i)];
+          co[(size_t)t * 2 * EIG_K + 2 * j + 1] = cs[2 * (S.off + S.first - i) + 1];
+        }
+      }
+    }
+    if (total > g.cap_cs) { if (g.cs) { GCGE_HIP_CHECK(hipStreamSynchronize(st)); hipFree(g.cs); } g.cap_cs = total * 2; GCGE_HIP_CHECK(hipMalloc(&g.cs, g.cap_cs * sizeof(double))); }
+    const size_t gbytes = groups.size() * sizeof(EigGroup);
+    if (groups.size() > g.cap_sw) { if (g.sw) { GCGE_HIP_CHECK(hipStreamSynchronize(st)); hipFree(g.sw); } g.cap_sw = groups.size() * 2; GCGE_HIP_CHECK(hipMalloc(&g.sw, g.cap_sw * sizeof(EigGroup))); }
+    GCGE_HIP_CHECK(hipMemcpyAsync(g.cs, g.h_cs, total * sizeof(double), hipMemcpyHostToDevice, st));
+    GCGE_HIP_CHECK(hipMemcpyAsync(g.sw, groups.data(), gbytes, hipMemcpyHostToDevice, st));
+    if (timing) GCGE_HIP_CHECK(hipEventRecord(tev[3], st));
+    hipLaunchKernelGGL(eig_replay_fused, dim3((n + 63) / 64), dim3(64), 0, st, n, g.q, (const EigGroup*)g.sw, (int)groups.size(), g.cs);
+    if (timing) GCGE_HIP_CHECK(hipEventRecord(tev[4], st));
+    GCGE_HIP_CHECK(hipStreamSynchronize(st));          // `groups` is pageable and leaves scope here
+  } else if (!sweeps.empty()) {
     if (cs.size() > g.cap_cs) { if (g.cs) { GCGE_HIP_CHECK(hipStreamSynchronize(st)); hipFree(g.cs); } g.cap_cs = cs.size() * 2; GCGE_HIP_CHECK(hipMalloc(&g.cs, g.cap_cs * sizeof(double))); }
     if (sweeps.size() > g.cap_sw) { if (g.sw) { GCGE_HIP_CHECK(hipStreamSynchronize(st)); hipFree(g.sw); } g.cap_sw = sweeps.size() * 2; GCGE_HIP_CHECK(hipMalloc(&g.sw, g.cap_sw * sizeof(EigSweep))); }
     GCGE_HIP_CHECK(hipMemcpyAsync(g.cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice, st));
     GCGE_HIP_CHECK(hipMemcpyAsync(g.sw, sweeps.data(), sweeps.size() * sizeof(EigSweep), hipMemcpyHostToDevice, st));
+    if (timing) GCGE_HIP_CHECK(hipEventRecord(tev[3], st));
     hipLaunchKernelGGL(eig_replay, dim3((n + 63) / 64), dim3(64), 0, st, n, g.q, g.sw, (int)sweeps.size(), g.cs);
+    if (timing) GCGE_HIP_CHECK(hipEventRecord(tev[4], st));
   }
   // 5. back to the host, ascending
   GCGE_HIP_CHECK(hipMemcpyAsync(g.h_pin, g.q, nn * sizeof(double), hipMemcpyDeviceToHost, st));
   GCGE_HIP_CHECK(hipStreamSynchronize(st));          // (also: cs / sweeps are pageable and leave scope below)
+  if (timing) {
+    float t01 = 0, t12 = 0, t34 = 0;
+    hipEventElapsedTime(&t01, tev[0], tev[1]); hipEventElapsedTime(&t12, tev[1], tev[2]);
+    if (!sweeps.empty()) hipEventElapsedTime(&t34, tev[3], tev[4]);
+    fprintf(stderr, "gcge_hip_symeig n=%d: tridiagonalisation %.2f ms, Q %.2f ms, replay of %zu rotations in %zu sweeps %.2f ms; host QL %.2f ms, "
+            "QL end -> results on the host %.2f ms\n", n, t01, t12, n_rot, sweeps.size(), t34, w1 - w0, wall() - w1);
+    for (auto& ev_ : tev) hipEventDestroy(ev_);
+  }
   std::vector<int> perm(n);
   for (int i = 0; i < n; ++i) perm[i] = i;
   for (int i = 1; i < n; ++i) {                      // stable insertion on the permutation, as the host solver

@@ -161,8 +161,22 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void lincomb_direct_kernel(lo
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int li = lane & 15, kk = lane >> 4;
   const long r0 = (long)blockIdx.x * (64 * RF) + 32 * wave;
+  // Accumulators.  NT >= 4: 8 or 16 tiles pinned to AGPRs by name and driven by inline-asm MFMAs; a tile is then
+  // touched again only 7 or 15 MFMAs later.  NT <= 2 has 2 or 4 tiles, i.e. dependent MFMAs one or three instructions
+  // apart: the hardware does NOT interlock a DGEMM MFMA reading SrcC against the previous one still writing it (the
+  // compiler's hazard recogniser inserts the wait states for the builtin, but it does not see inline asm — measured:
+  // results with stale low/high words).  Those widths are bandwidth-bound anyway and take the builtin.
+  constexpr bool PIN = NT >= 4;
+  v4d accv[PIN ? 1 : RF][PIN ? 1 : NT];
+  if constexpr (PIN) {
 #pragma unroll
-  for (int T = 0; T < RF * NT; ++T) agpr_tile_zero(T);
+    for (int T = 0; T < RF * NT; ++T) agpr_tile_zero(T);
+  } else {
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) accv[f][t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
 
   // per-lane row bases (clamped: rows past the end feed output rows that are never stored)
   const double* xr[RF];
@@ -203,7 +217,10 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void lincomb_direct_kernel(lo
         for (int t = 0; t < NT; ++t) {
           const double b = cst[(8 * j + 2 * kk + h) * cs + 16 * t];
 #pragma unroll
-          for (int f = 0; f < RF; ++f) agpr_tile_mfma(f * NT + t, h ? a[f][j].y : a[f][j].x, b);
+          for (int f = 0; f < RF; ++f) {
+            if constexpr (PIN) agpr_tile_mfma(f * NT + t, h ? a[f][j].y : a[f][j].x, b);
+            else accv[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(h ? a[f][j].y : a[f][j].x, b, accv[f][t], 0, 0, 0);
+          }
         }
   };
   const int ntile = (k + LC_KT - 1) / LC_KT;
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void lincomb_direct_kernel(lo
     mfmas(a0, 0);
   }
   // the MFMAs are inline asm, invisible to the hazard recogniser: let the last ones retire before the tiles are read
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  if constexpr (PIN) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
   for (int f = 0; f < RF; ++f) {
     const long rw = r0 + 16 * f;
@@ -261,7 +278,10 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void lincomb_direct_kernel(lo
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[t][u] = agpr_tile_read(f * NT + t, u);
+      for (int u = 0; u < 4; ++u) {
+        if constexpr (PIN) acc[t][u] = agpr_tile_read(f * NT + t, u);
+        else acc[t][u] = accv[f][t][u];
+      }
     if (beta != nullptr) {
       double yv[NT][4], bj[NT];
 #pragma unroll
@@ -318,7 +338,9 @@ static int lc_launch(int nrows, const double* x, long ldx, int k, const double* 
   }
   hipLaunchKernelGGL(lincomb_pad_c, dim3((kp * mp + 255) / 256), dim3(256), 0, st, c, k, m, g_cpad, kp, mp);
   // direct form: X read with 16-byte lane loads straight into MFMA operands (needs a 16-byte aligned operand)
-  if ((g_lc_rf == 0 || g_lc_rf == 3) && (((uintptr_t)x & 15) == 0) && (ldx % 2 == 0) && k >= 2) {
+  // Measured at n = 2^24, k = 256 (profiles/r02_dense): m = 128 direct 47.2 TF vs 45.9 staged; m = 64 direct 45.8 vs 48.4
+  // staged with two row fragments — the automatic choice takes the direct form for the 128-column panels only.
+  if (((g_lc_rf == 0 && NT == 8) || g_lc_rf == 3) && (((uintptr_t)x & 15) == 0) && (ldx % 2 == 0) && k >= 2) {
     const int csd = 16 * NT + 8;   // coefficient rows 2 apart land on the other half of the 64 LDS banks
     const size_t shd = (size_t)2 * LC_KT * csd * sizeof(double);
     const unsigned gridd = (unsigned)(((long)nrows + 127) / 128);
