@@ -863,12 +863,13 @@ extern "C" int gcge_hip_cg_recompute_pays(void* mat) {
   if (getenv("GCGE_CG_RECOMPUTE") != nullptr) return 1;
   return gcge_hip_mat_pattern_chain(A) == 2;
 }
-// host_pw[j] = sum_r p[r,j] (A p)[r,j], host_ww[j] = sum_r (A p)[r,j]^2 over the LOCAL rows; fetches the halo rows of p
-extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* host_pw, double* host_ww) {
+// d_out[0, m) = sum_r p[r,j] (A p)[r,j], d_out[m, 2m) = sum_r (A p)[r,j]^2 over the LOCAL rows, left on the DEVICE (d_out holds
+// >= 6 m doubles, the rest is scratch of the split product); fetches the halo rows of p; nothing is waited for
+extern "C" int gcge_hip_cg_pass1_dev(void* mat, void** p, int c0, int m, double* d_out) {
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat; GcgeHipMV* vp = (GcgeHipMV*)p;
   if (!gcge_hip_cg_fusable(mat, p, m) || (c0 & 1)) return -1;
   GCGE_REQUIRE(c0 >= 0 && c0 + m <= vp->ncols && A->nrows == vp->nrows && A->nrows + A->nghost <= vp->nrows_alloc, "cg_pass1: shapes");
-  double* dd = stage_d(6 * (size_t)m);
+  double* dd = d_out;
   double* dyy = dd + 3 * (size_t)m;
   SpmmEvent ev;
   if (g_prof_on) {   // algorithmic bytes: matrix once, p once
@@ -881,25 +882,30 @@ extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* 
   const int rc = spmm_halo(A, vp, c0, nullptr, 0, m, dd, dyy, &cg);
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "cg_pass1: kernel launch");
+  GCGE_HIP_CHECK(hipMemcpyAsync(dd + m, dyy, m * sizeof(double), hipMemcpyDeviceToDevice, g_stream));   // both sums side by side
+  return 0;
+}
+// the same with the sums returned to the host (one stream synchronisation)
+extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* host_pw, double* host_ww) {
+  double* dd = stage_d(6 * (size_t)m);
+  if (gcge_hip_cg_pass1_dev(mat, p, c0, m, dd) != 0) return -1;
   double* hd = stage_h(2 * (size_t)m);
-  GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
-  GCGE_HIP_CHECK(hipMemcpyAsync(hd + m, dyy, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, 2 * (size_t)m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
   memcpy(host_pw, hd, m * sizeof(double));
   memcpy(host_ww, hd + m, m * sizeof(double));
   return 0;
 }
-// r[:, c0:c0+m) -= (A p) diag(alpha); pnew[:, c0:c0+m) = r diag(cr) + p diag(cb); host_rho[j] = sum_r cr_j r[r,j]^2 (local).
-// The halo rows of p must be the ones pass 1 fetched (p unchanged since).  d_alpha / d_beta / d_flag: device, m each.
-extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
-                                    const double* d_beta, const int* d_flag, double* host_rho) {
+// r[:, c0:c0+m) -= (A p) diag(alpha); pnew[:, c0:c0+m) = r diag(cr) + p diag(cb); d_rho[j] = sum_r cr_j r[r,j]^2 (local), left on
+// the DEVICE.  The halo rows of p must be the ones pass 1 fetched (p unchanged since).  d_alpha / d_beta / d_flag: device, m each.
+extern "C" int gcge_hip_cg_pass2_dev(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
+                                     const double* d_beta, const int* d_flag, double* d_rho) {
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
   GcgeHipMV *vp = (GcgeHipMV*)p, *vr = (GcgeHipMV*)r, *vn = (GcgeHipMV*)pnew;
   if (!gcge_hip_cg_fusable(mat, p, m) || (c0 & 1) || (vr->ld & 1) || (vn->ld & 1) || ((uintptr_t)vr->d & 15) ||
       ((uintptr_t)vn->d & 15) || vn == vp) return -1;
   GCGE_REQUIRE(c0 >= 0 && c0 + m <= vp->ncols && c0 + m <= vr->ncols && c0 + m <= vn->ncols, "cg_pass2: column ranges");
   GCGE_REQUIRE(A->nrows == vp->nrows && A->nrows == vr->nrows && A->nrows == vn->nrows, "cg_pass2: row counts");
-  double* dd = stage_d(6 * (size_t)m);
   SpmmEvent ev;
   if (g_prof_on) {   // algorithmic bytes: matrix once, p and r read, r and p_new written
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
@@ -908,9 +914,15 @@ extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, 
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
   const CgPass cg = {3, vr->d + c0, vr->ld, vn->d + c0, vn->ld, d_alpha, d_beta, d_flag, nullptr, 0};
-  const int rc = spmm_rows(A, 0, A->nrows, vp->d + c0, vp->ld, nullptr, 0, m, dd, nullptr, &cg);
+  const int rc = spmm_rows(A, 0, A->nrows, vp->d + c0, vp->ld, nullptr, 0, m, d_rho, nullptr, &cg);
   if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
   GCGE_REQUIRE(rc == 0, "cg_pass2: kernel launch");
+  return 0;
+}
+extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
+                                    const double* d_beta, const int* d_flag, double* host_rho) {
+  double* dd = stage_d(6 * (size_t)m);
+  if (gcge_hip_cg_pass2_dev(mat, p, r, pnew, c0, m, d_alpha, d_beta, d_flag, dd) != 0) return -1;
   double* hd = stage_h((size_t)m);
   GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));

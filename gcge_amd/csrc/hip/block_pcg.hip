@@ -58,6 +58,9 @@ extern "C" int gcge_hip_cg_recompute_pays(void* mat);
 extern "C" int gcge_hip_cg_start_mv(void* mat, void** x, int xc0, void** b, int bc0, void** r, void** p0, int rc0, int m,
                                     double* host_rho);
 extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* host_pw, double* host_ww);
+extern "C" int gcge_hip_cg_pass1_dev(void* mat, void** p, int c0, int m, double* d_out);
+extern "C" int gcge_hip_cg_pass2_dev(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
+                                     const double* d_beta, const int* d_flag, double* d_rho);
 extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
                                     const double* d_beta, const int* d_flag, double* host_rho);
 
@@ -363,6 +366,47 @@ __global__ __launch_bounds__(256) void cg_accum_x(long nrows, RingPtrs ring, int
     __builtin_nontemporal_store(xv, reinterpret_cast<v2d*>(x + row * ldx + j));
   }
 }
+
+// ---- the scalars of an iteration on the device (recompute form) ---------------------------------------------------
+// alpha_j = rho_j / (p_j . A p_j); beta_j = rho_pred_j / rho_j with rho_pred = alpha^2 |A p|^2 - rho (clamped at 0: the
+// column restarts from r); retired columns get flag 0 / alpha 0 so the passes leave them bit-for-bit untouched.
+// ahist: this iteration's row of the pending-x-update coefficients (cg_accum_x).
+__global__ __launch_bounds__(256) void cg_scalars_a(int m, const double* __restrict__ rho2, const double* __restrict__ pw_ww,
+    const int* __restrict__ active, double* __restrict__ alpha, double* __restrict__ beta, int* __restrict__ flag,
+    double* __restrict__ ahist) {
+  for (int j = threadIdx.x; j < m; j += 256) {
+    double al = 0.0, be = 0.0; int fl = 0;
+    if (active[j]) {
+      al = rho2[j] / pw_ww[j];
+      double pred = al * al * pw_ww[m + j] - rho2[j];
+      if (!(pred > 0.0) || !isfinite(pred)) pred = 0.0;
+      be = pred / rho2[j]; fl = 1;
+    }
+    alpha[j] = al; beta[j] = be; flag[j] = fl; ahist[j] = al;
+  }
+}
+// rho_j <- measured r_j . r_j of the sweep, stopping test of src/ops_lin_sol.c:372-380 per column; the number of columns
+// still active goes to nact_out (host-mapped memory: the host reads it one iteration later)
+__global__ __launch_bounds__(256) void cg_scalars_b(int m, const double* __restrict__ newrho, double rate, double tol,
+    const double* __restrict__ norm_b, const double* __restrict__ init_res, double* __restrict__ rho2, int* __restrict__ active,
+    double* __restrict__ last_res, int* __restrict__ nact_out) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    if (!active[j]) continue;
+    const double rv = newrho[j];
+    rho2[j] = rv;
+    const double lr = sqrt(rv);
+    last_res[j] = lr;
+    const int a = (lr > rate * init_res[j]) && (lr > tol * norm_b[j]);
+    active[j] = a; mine += a;
+  }
+  if (mine) atomicAdd(&cnt, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) { *nact_out = cnt; __threadfence_system(); }
+}
 }  // namespace gcge
 
 using namespace gcge;
@@ -403,6 +447,8 @@ struct HipBpcg {
   long recompute_iters;         // iterations run in the two-pass form with the product recomputed (pattern matrices)
   long col_iters, active_col_iters;   // columns streamed per iteration, summed / of which still active (one-pass scheme)
   long total_iters; double total_seconds;   // CG iterations and host wall time over all calls (bench.py: ms per CG iteration)
+  double* d_sc; int* d_sci; int* h_nact; int sc_cap; hipEvent_t ev_it[2];   // device-side scalars of the recompute form
+  long dev_scalar_iters;
 };
 static HipBpcg g_bpcg = {30, 1e-2, 1e-14, "abs", {nullptr, nullptr, nullptr, nullptr}, {nullptr}, 0, 0, 0, 0, -1.0, 0, 0, nullptr, nullptr, nullptr, 0};
 
@@ -583,6 +629,89 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       st2[0] = 0; en2[0] = nrhs; st2[1] = 0; en2[1] = nrhs;
       ops->MultiVecAxpby(1.0, s->mv_ws[0], 0.0, s->ring_len ? s->ring[0] : s->mv_ws[1], st2, en2, ops);
     }
+    // ---- recompute form with the scalars on the device: no host round trip inside an iteration ----------------------
+    // pass 1 -> [all-reduce] -> cg_scalars_a -> pass 2 -> [all-reduce] -> cg_scalars_b, all on the back-end's stream; the
+    // host only learns, one iteration late, how many columns are still active.  The iteration it enqueued in the
+    // meantime is a no-op on the data when that number was 0 (all flags 0: r untouched, p copied, zero coefficients for
+    // the pending x update).  Over ranks the sums are reduced on the device by RCCL (gcge_hip_comm_allreduce_device); a
+    // callback transport (torch.distributed rehearsals) keeps the host-scalar loop below.  GCGE_CG_HOST_SCALARS=1: off.
+    GCGE_COMM* comm_now = GCGE_GetComm();
+    const bool host_scalars = getenv("GCGE_CG_HOST_SCALARS") != nullptr;
+    if (recompute && !host_scalars && nact > 0 && s->max_iter <= 4000 && (comm_now == nullptr || gcge_hip_comm_is_native(comm_now))) {
+      if (s->sc_cap < nrhs) {
+        GCGE_HIP_CHECK(hipStreamSynchronize(st));
+        if (s->d_sc) { hipFree(s->d_sc); hipFree(s->d_sci); hipHostFree(s->h_nact); }
+        else { GCGE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_it[0], hipEventDisableTiming)); GCGE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_it[1], hipEventDisableTiming)); }
+        s->sc_cap = nrhs + 64;
+        GCGE_HIP_CHECK(hipMalloc(&s->d_sc, (size_t)(30 + 16) * s->sc_cap * sizeof(double)));
+        GCGE_HIP_CHECK(hipMalloc(&s->d_sci, (size_t)2 * s->sc_cap * sizeof(int)));
+        GCGE_HIP_CHECK(hipHostMalloc(&s->h_nact, 4096 * sizeof(int)));
+      }
+      const size_t cap = (size_t)s->sc_cap;
+      double *d_rho2 = s->d_sc, *d_init = d_rho2 + cap, *d_normb = d_init + cap, *d_last = d_normb + cap, *d_alpha = d_last + cap,
+             *d_beta = d_alpha + cap, *d_sums = d_beta + cap /* 6 cap */, *d_newrho = d_sums + 6 * cap /* 6 cap */,
+             *d_ahist2 = d_newrho + 6 * cap /* 16 cap, starts at 18 cap: (30 + 16) cap in total */;
+      int *d_active = s->d_sci, *d_flag2 = d_active + cap;
+      {   // start values (rho, initial residuals, scales, active flags were computed on the host above)
+        std::vector<double> up(3 * (size_t)nrhs);
+        memcpy(up.data(), rho2.data(), nrhs * sizeof(double)); memcpy(up.data() + nrhs, init_res.data(), nrhs * sizeof(double));
+        memcpy(up.data() + 2 * nrhs, norm_b.data(), nrhs * sizeof(double));
+        GCGE_HIP_CHECK(hipMemcpyAsync(d_rho2, up.data(), nrhs * sizeof(double), hipMemcpyHostToDevice, st));
+        GCGE_HIP_CHECK(hipMemcpyAsync(d_init, up.data() + nrhs, nrhs * sizeof(double), hipMemcpyHostToDevice, st));
+        GCGE_HIP_CHECK(hipMemcpyAsync(d_normb, up.data() + 2 * nrhs, nrhs * sizeof(double), hipMemcpyHostToDevice, st));
+        GCGE_HIP_CHECK(hipMemcpyAsync(d_last, up.data() + nrhs, nrhs * sizeof(double), hipMemcpyHostToDevice, st));
+        GCGE_HIP_CHECK(hipMemcpyAsync(d_active, active.data(), nrhs * sizeof(int), hipMemcpyHostToDevice, st));
+        GCGE_HIP_CHECK(hipStreamSynchronize(st));   // `up` leaves scope
+      }
+      const bool reduce = comm_now != nullptr;
+      auto flush_x_dev = [&]() {
+        if (npend == 0) return;
+        RingPtrs rp;
+        for (int q = 0; q < 16; ++q) { long ldq; rp.p[q] = gcge_hip_mv_device_ptr(s->ring[(first_slot + (q < npend ? q : 0)) % R], &ldq); }
+        const int tpr = cg_tpr(nrhs);
+        long g = ((long)n + (256 / tpr) * 8 - 1) / ((256 / tpr) * 8); if (g > 8192) g = 8192; if (g < 1) g = 1;
+        hipLaunchKernelGGL(cg_accum_x, dim3((unsigned)g), dim3(256), 0, st, (long)n, rp, npend, ldp, dx, ldx, nrhs, d_ahist2, tpr);
+        first_slot = (first_slot + npend) % R; npend = 0;
+      };
+      int enq = 0;            // iterations enqueued
+      int done = -1;          // index of the last iteration whose active count the host has seen
+      int stop_at = -1;       // first iteration that found no active column at its start
+      while (enq < s->max_iter && enq < 4096) {
+        void** pcur = s->ring[cur];
+        if (gcge_hip_cg_pass1_dev(mat, pcur, 0, nrhs, d_sums) != 0) { fprintf(stderr, "HIP_BlockPCG: first CG pass refused operands it had accepted\n"); abort(); }
+        if (reduce) gcge_hip_comm_allreduce_device(d_sums, 2 * nrhs);
+        hipLaunchKernelGGL(cg_scalars_a, dim3(1), dim3(256), 0, st, nrhs, d_rho2, d_sums, d_active, d_alpha, d_beta, d_flag2,
+                           d_ahist2 + (size_t)npend * nrhs);
+        if (gcge_hip_cg_pass2_dev(mat, pcur, s->mv_ws[0], s->ring[(cur + 1) % R], 0, nrhs, d_alpha, d_beta, d_flag2, d_newrho) != 0) {
+          fprintf(stderr, "HIP_BlockPCG: second CG pass refused operands it had accepted\n"); abort();
+        }
+        if (reduce) gcge_hip_comm_allreduce_device(d_newrho, nrhs);
+        hipLaunchKernelGGL(cg_scalars_b, dim3(1), dim3(256), 0, st, nrhs, d_newrho, s->rate, s->tol, d_normb, d_init, d_rho2, d_active,
+                           d_last, s->h_nact + enq);
+        GCGE_HIP_CHECK(hipEventRecord(s->ev_it[enq & 1], st));
+        ++npend; cur = (cur + 1) % R; ++s->recompute_iters; ++s->dev_scalar_iters; s->spmm_calls++; s->spmm_cols += nrhs;
+        ++enq;
+        if (npend == J) flush_x_dev();
+        if (enq >= 2) {   // what did iteration enq - 2 leave?  (iteration enq - 1 is already in the queue)
+          GCGE_HIP_CHECK(hipEventSynchronize(s->ev_it[(enq - 2) & 1]));
+          done = enq - 2;
+          if (s->h_nact[done] == 0) { stop_at = done + 1; break; }
+        }
+      }
+      GCGE_HIP_CHECK(hipStreamSynchronize(st));
+      if (stop_at < 0) {      // the queue ran dry at max_iter (or the last iterations have not been looked at yet)
+        stop_at = enq;
+        for (int q = done + 1; q < enq; ++q) if (s->h_nact[q] == 0) { stop_at = q + 1; break; }
+      }
+      niter = stop_at;        // iterations that started with at least one active column, as the reference counts them
+      flush_x_dev();
+      GCGE_HIP_CHECK(hipMemcpyAsync(s->h_pin, d_last, sizeof(double), hipMemcpyDeviceToHost, st));
+      GCGE_HIP_CHECK(hipStreamSynchronize(st));
+      s->col_iters += (long)nrhs * niter; s->active_col_iters += (long)nrhs * niter;   // (per-iteration active counts stay on the device)
+      s->niter = niter;
+      s->residual = s->h_pin[0];
+      return;
+    }
     while (niter < s->max_iter && nact > 0) {
       s->col_iters += nrhs; s->active_col_iters += nact;
       int alo = 0, ahi = nrhs;
@@ -760,6 +889,7 @@ extern "C" void gcge_hip_bpcg_stats(long* spmm_calls, long* spmm_cols, int* last
   if (last_niter) *last_niter = g_bpcg.niter;
 }
 extern "C" long gcge_hip_bpcg_recompute_iters(void) { return g_bpcg.recompute_iters; }
+extern "C" long gcge_hip_bpcg_device_scalar_iters(void) { return g_bpcg.dev_scalar_iters; }
 extern "C" void gcge_hip_bpcg_time_stats(long* iters, double* seconds, int reset) {
   if (iters) *iters = g_bpcg.total_iters;
   if (seconds) *seconds = g_bpcg.total_seconds;

@@ -83,6 +83,10 @@ extern "C" int gcge_hip_comm_allreduce_device(double* d_buf, int n) {
   return 0;
 }
 
+extern "C" int gcge_hip_comm_is_native(const GCGE_COMM* comm) {
+  return g_nccl != nullptr && comm != nullptr && comm->allreduce_sum == rccl_allreduce_host;
+}
+
 extern "C" int gcge_hip_comm_init(int rank, int world, const void* id128) {
   if (g_nccl != nullptr) { fprintf(stderr, "gcge_hip_comm_init: communicator exists already\n"); return -1; }
   if (world < 1 || rank < 0 || rank >= world || id128 == nullptr) return -2;

@@ -74,6 +74,8 @@ int  gcge_hip_comm_size (void);
 void gcge_hip_comm_stats (long *n_allreduce, long *n_exchange);
 /*     in-place sum over the ranks of n doubles in DEVICE memory on the back-end's stream, nothing waited for      */
 int  gcge_hip_comm_allreduce_device (double *d_buf, int n);
+/*     1 if `comm` (GCGE_GetComm()) is the one gcge_hip_comm_init installed, i.e. device-side all-reduces are possible  */
+int  gcge_hip_comm_is_native (const GCGE_COMM *comm);
 /*     rows [part[rank], part[rank+1]) of a symmetric matrix, GLOBAL column indices (host CSR); part has world + 1
  *     entries.  Collective: builds the ghost list, the local numbering and the halo plan (who needs which rows) over
  *     RCCL; products then move buf_cols columns of halo rows per grouped ncclSend/ncclRecv, event-ordered            */
@@ -109,6 +111,9 @@ void gcge_hip_bpcg_stats (long *spmm_calls, long *spmm_cols, int *last_niter);
 /* iterations the fused solver ran in its recompute form (pattern matrices: the product A p is formed twice per
  * iteration and never stored, gcge_hip_cg_pass1_mv / gcge_hip_cg_pass2_mv); GCGE_CG_NO_RECOMPUTE=1 switches it off */
 long gcge_hip_bpcg_recompute_iters (void);
+/* of those, iterations whose scalars (alpha, beta, stopping test) were computed on the device, without a host round trip
+ * inside the iteration (single rank or RCCL inside the back-end; GCGE_CG_HOST_SCALARS=1 switches it off)            */
+long gcge_hip_bpcg_device_scalar_iters (void);
 /* columns the fused solver streamed, summed over its iterations, and how many of them were still active */
 void gcge_hip_bpcg_column_stats (long *col_iters, long *active_col_iters);
 /* CG iterations and host wall time spent inside the fused solver since the last reset (ms per CG iteration) */
@@ -175,6 +180,11 @@ int gcge_hip_cg_start_mv (void *mat, void **x, int xc0, void **b, int bc0, void 
 		double *host_rho);   /* r = b - A x, p0 = r, rho = column sums of r^2 (local rows) in one sweep */
 int gcge_hip_cg_pass2_mv (void *mat, void **p, void **r, void **pnew, int c0, int m, const double *d_alpha,
 		const double *d_beta, const int *d_flag, double *host_rho);
+/*     the same two passes with the column sums left on the DEVICE and nothing waited for (the fused CG computes its
+ *     scalars there): pass 1: d_out[0,m) = p.(A p), d_out[m,2m) = |A p|^2 (d_out: >= 6 m doubles); pass 2: d_rho[0,m) */
+int gcge_hip_cg_pass1_dev (void *mat, void **p, int c0, int m, double *d_out);
+int gcge_hip_cg_pass2_dev (void *mat, void **p, void **r, void **pnew, int c0, int m, const double *d_alpha,
+		const double *d_beta, const int *d_flag, double *d_rho);
 int gcge_hip_pattern_width (int max_row_len);
 int gcge_hip_mat_patterns (const GCGE_HIP_MAT *A);
 int gcge_hip_mat_pattern_chain (const GCGE_HIP_MAT *A);   /* 0 none, 1 chain layout (span2 == -1), 2 chain + line exchange (span2 == -L) */

@@ -670,3 +670,52 @@ def test_device_symmetric_eigensolver(hip, n, kind):
     th = time.perf_counter() - t0
     assert np.max(np.abs(hw - w)) <= 1e-13 * nrm * max(1.0, n / 64)
     print("symeig n=%d %s: device %.1f ms, host %.1f ms" % (n, kind, 1e3 * dt, 1e3 * th))
+
+
+def test_fused_cg_device_scalars_equal_host_scalars(hip):
+    """The recompute form of the fused CG computes alpha, beta and the stopping test on the device and lets the host look
+    at the active count one iteration late (block_pcg.hip); GCGE_CG_HOST_SCALARS=1 keeps the scalars on the host with two
+    synchronisations per iteration.  Same recurrences: same CG iteration counts, same solutions to rounding, same
+    eigensolve — including right-hand sides that retire at different iterations and a solve that stops early."""
+    import os
+    import scipy.sparse.linalg as sla
+    g = hip.g
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    g.gcge_hip_bpcg_device_scalar_iters.restype = C.c_long
+    A, _ = make_problem("lap3d", 16)
+    S = csr_to_scipy(A); n = A.nrows
+    mat = hip.matrix(A)
+    nrhs = 12
+    Bm = uniform(71, (n, nrhs)) - 0.5
+    Bm[:, 3] *= 1e-9          # this column meets the absolute tolerance at once ...
+    Bm[:, 7] = S @ (uniform(72, (n,)) - 0.5) * 1e-3    # ... and this one converges faster than the rest
+    out = {}
+    for tag in ("device", "host"):
+        if tag == "host":
+            os.environ["GCGE_CG_HOST_SCALARS"] = "1"
+        try:
+            for max_iter, rate in ((25, 1e-3), (400, 1e-10)):
+                g.gcge_hip_bpcg_setup(hip.ops_handle, max_iter, rate, 1e-10, b"abs")
+                b = hip.mv_from_numpy(mat, Bm); x = hip.mv_from_numpy(mat, np.zeros((n, nrhs)))
+                before = g.gcge_hip_bpcg_device_scalar_iters()
+                hip.ops.multi_linear_solver(mat, b, x, (0, 0), (nrhs, nrhs))
+                it = C.c_int(); g.gcge_hip_bpcg_stats(None, None, C.byref(it))
+                out[(tag, max_iter)] = (hip.mv_to_numpy(x, n, 0, nrhs), it.value, g.gcge_hip_bpcg_device_scalar_iters() - before)
+                hip.ops.mv_destroy(b, nrhs); hip.ops.mv_destroy(x, nrhs)
+            g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+            hip.set_random_mode(0)
+            ev, res = gcg_on(hip, "lap3d", 16, ["-nevConv", 12, "-nevMax", 24, "-blockSize", 8], flag=1)
+            out[(tag, "gcg")] = (ev[:res.nevConv].copy(), res.nevConv, res.numIter)
+        finally:
+            os.environ.pop("GCGE_CG_HOST_SCALARS", None)
+    for mi in (25, 400):
+        xd, itd, nd = out[("device", mi)]; xh, ith, nh = out[("host", mi)]
+        assert nd >= itd > 0 and nh == 0, (nd, itd, nh)           # (the device loop may enqueue one no-op iteration)
+        assert itd == ith, (mi, itd, ith)
+        assert np.max(np.abs(xd - xh)) <= 1e-12 * np.max(np.abs(xh))
+    ref = sla.spsolve(S.tocsc(), Bm)
+    assert np.max(np.abs(out[("device", 400)][0] - ref)) < 1e-7 * np.max(np.abs(ref))
+    assert out[("device", 400)][1] < 400                             # stopped on the residual, not on the iteration cap
+    assert out[("device", "gcg")][1:] == out[("host", "gcg")][1:]
+    assert np.max(np.abs(out[("device", "gcg")][0] - out[("host", "gcg")][0]) / np.abs(out[("host", "gcg")][0])) < 1e-12
+    hip.free_matrix(mat)
