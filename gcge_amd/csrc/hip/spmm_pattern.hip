@@ -27,7 +27,6 @@
 //     surplus iterations re-do the wave's last slice and only their stores are predicated.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include <algorithm>
 #include "gcge_hip_internal.h"
 
@@ -318,7 +317,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_chain_kernel(
 // 1 (+S) + 2 (+-1) + 2/NW, against 5 for the chain alone and 7 without it.  The barrier carries no memory fence
 // (raw s_barrier after lgkmcnt(0)): the global loads of the NEXT iteration stay in flight across it.
 // ROLE: 0 lowest wave, 1 inner wave, 2 highest wave (three copies of the loop: no branch near a load).
-template <int LT, int MODE, int NW, int ROLE, bool DEEP = false>
+template <int LT, int MODE, int NW, int ROLE>
 __device__ __forceinline__ void chain2_body(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* s_tab, v2d (*xch)[NW][64],
     const double* __restrict__ xl, size_t ldx, double* __restrict__ y, size_t ldy, bool act, int i, int g, int wave, int lane,
@@ -406,88 +405,6 @@ __device__ __forceinline__ void chain2_body(
     }
     xch[buf ^ 1][wave][lane] = c;   // the centre row of my next iteration
   };
-  if constexpr (DEEP) {
-    // Two chain loads in flight.  A pass that only READS (MODE 2: the first pass of a CG iteration) keeps one 1-KB
-    // HBM request per wave in flight with the loop below — 16 KB per CU, about half of what the memory system needs to
-    // run at its rate (measured 3.6 TB/s against 5.4-5.7 TB/s for the passes that also write).  Here the "+S" row is
-    // requested TWO iterations ahead: ring of 5 row registers (a, b, c of the current row, c of the next, c of the one
-    // after).  The cache-served +-1 / edge rows stay one iteration ahead and are SINGLE-buffered: a step first folds the
-    // current row's +-1 / edge rows into the partial sums, re-issues those loads for the next row into the same
-    // registers, and only then waits at the barrier for the neighbours' centre rows (one register set less than the
-    // loop below).  Unrolled by 5: register roles are compile-time constants, the parity of the exchange buffer is a run-time
-    // LDS offset (unrolling by 10 to make it static as well costs 80 more spilled registers).  MODE 2 only (nothing is stored).
-    static_assert(MODE == 2, "deep chain prefetch is built for the read-only pass");
-    // the launcher only takes this variant when the grid is a multiple of the slices per line: the rows of a wave are
-    // then an arithmetic sequence (one chain stride apart) and need no division per iteration
-    const long rowb = row_at(0), rstep = row_at(cnt > 1 ? 1 : 0) - rowb;
-    auto rowq = [&](long it) { return min(rowb + min(it, cnt - 1) * rstep, nrows - 1); };
-    v2d rg[5], ed[NE + 1], ot[NO + 1];
-    int pp[5];
-    auto issue_chain = [&](v2d& lnew, long row, int p) {
-      lnew = *reinterpret_cast<const v2d*>(xl + (size_t)(row + s_tab[p * LT + 2].off) * ldx);
-    };
-    auto issue_rest = [&](long row, int p) {
-      const PatEntry* e = s_tab + p * LT;
-      if (ROLE == 0) ed[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[3].off) * ldx);
-      if (ROLE == 2) ed[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[4].off) * ldx);
-#pragma unroll
-      for (int t = 0; t < NO; ++t) ot[t] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[5 + t].off) * ldx);
-    };
-    auto step = [&](const v2d& a, const v2d& b, const v2d& c, int p, int pnext, long it, int buf) {
-      const PatEntry* e = s_tab + p * LT;
-      double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-      for (int t = 0; t < NO; ++t) { const double v = e[5 + t].val; a0 = fma(v, ot[t].x, a0); a1 = fma(v, ot[t].y, a1); }
-      if (ROLE == 0) { const double v = e[3].val; a0 = fma(v, ed[0].x, a0); a1 = fma(v, ed[0].y, a1); }
-      if (ROLE == 2) { const double v = e[4].val; a0 = fma(v, ed[0].x, a0); a1 = fma(v, ed[0].y, a1); }
-      const double v0 = e[0].val, v1 = e[1].val, v2 = e[2].val, v3 = e[3].val, v4 = e[4].val;
-      __builtin_amdgcn_sched_barrier(0);
-      issue_rest(rowq(it + 1), pnext);                 // the next row's, into the registers just consumed
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      a0 = fma(v0, a.x, a0); a1 = fma(v0, a.y, a1);
-      a0 = fma(v1, b.x, a0); a1 = fma(v1, b.y, a1);
-      a0 = fma(v2, c.x, a0); a1 = fma(v2, c.y, a1);
-      if (ROLE != 0) { const v2d vm = xch[buf][wave - (ROLE == 0 ? 0 : 1)][lane]; a0 = fma(v3, vm.x, a0); a1 = fma(v3, vm.y, a1); }
-      if (ROLE != 2) { const v2d vp = xch[buf][wave + (ROLE == 2 ? 0 : 1)][lane]; a0 = fma(v4, vp.x, a0); a1 = fma(v4, vp.y, a1); }
-      const long row = rowb + it * rstep;
-      const bool ok = it < cnt && row < nrows && act;
-      // nothing is stored (the launcher passes y == NULL), but the never-taken branch stays: without it hipcc schedules
-      // the straight-line body into 200+ VGPRs and spills (see finish() below)
-      if (ok && y != nullptr) {
-        v2d o = {a0, a1};
-        __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(y + (size_t)row * ldy + 2 * i));
-      }
-      const double wgt = ok ? 1.0 : 0.0;
-      d0 = fma(a0 * wgt, b.x, d0); d1 = fma(a1 * wgt, b.y, d1);
-      e0 = fma(a0 * wgt, a0, e0); e1 = fma(a1 * wgt, a1, e1);
-      xch[buf ^ 1][wave][lane] = c;                      // the centre row of my next iteration
-    };
-    pp[0] = pid[rowq(0)]; pp[1] = pid[rowq(1)]; pp[2] = pid[rowq(2)];
-    {
-      const long row = rowq(0);
-      const PatEntry* e = s_tab + pp[0] * LT;
-      rg[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[0].off) * ldx);
-      rg[1] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[1].off) * ldx);
-      xch[0][wave][lane] = rg[1];
-    }
-    issue_chain(rg[2], rowq(0), pp[0]);
-    issue_chain(rg[3], rowq(1), pp[1]);
-    issue_rest(rowq(0), pp[0]);
-    for (long it0 = 0; it0 < cnt; it0 += 5) {
-#pragma unroll
-      for (int u = 0; u < 5; ++u) {
-        const long it = it0 + u;
-        pp[(u + 3) % 5] = pid[rowq(it + 3)];
-        issue_chain(rg[(u + 4) % 5], rowq(it + 2), pp[(u + 2) % 5]);
-        __builtin_amdgcn_sched_barrier(0);
-        step(rg[u % 5], rg[(u + 1) % 5], rg[(u + 2) % 5], pp[u % 5], pp[(u + 1) % 5], it, (int)(it & 1));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    return;
-  }
   v2d r0, r1, r2, r3, ed0[NE + 1], ed1[NE + 1], o0[NO + 1 + UPD], o1[NO + 1 + UPD];
   int p0 = pid[row_of(0)], p1 = pid[row_of(1)];
   {
@@ -523,7 +440,7 @@ __device__ __forceinline__ void chain2_body(
   }
 }
 
-template <int LT, int MODE, int NW, bool DEEP = false>
+template <int LT, int MODE, int NW>
 __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
     const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
@@ -549,9 +466,9 @@ __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
   const long gq = gridDim.x;
   const long bperm = (gq % 8 == 0 && xcd_runs) ? ((long)(blockIdx.x & 7) * (gq >> 3) + (blockIdx.x >> 3)) : (long)blockIdx.x;
   if (bperm < ntiles) {   // block-uniform: every wave of the block runs the same number of barriers
-    if (wave == 0) chain2_body<LT, MODE, NW, 0, DEEP>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
-    else if (wave == NW - 1) chain2_body<LT, MODE, NW, 2, DEEP>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
-    else chain2_body<LT, MODE, NW, 1, DEEP>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
+    if (wave == 0) chain2_body<LT, MODE, NW, 0>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
+    else if (wave == NW - 1) chain2_body<LT, MODE, NW, 2>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
+    else chain2_body<LT, MODE, NW, 1>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
   }
   if (DOT) {
     auto sx = [](double v, int mask) {
@@ -602,8 +519,6 @@ static long pat_ntiles(long nrows, long line) {
 // enough for the +-N rows to still be in the 32 KB L1.  Default: 4 consecutive slices (line = 8).
 // chain + line exchange: most waves per block to try (16, 8, 4; measured 3.20 / 3.37 / 3.67 ms at 256^3 x 64);
 // 0: use the plain chain kernel
-static int g_chain2_deep = getenv("GCGE_CHAIN2_DEEP") ? atoi(getenv("GCGE_CHAIN2_DEEP")) : 1;   // MODE 2 with two chain loads in flight
-extern "C" void gcge_hip_spmm_chain2_deep(int on) { g_chain2_deep = on; }
 static int g_chain2_nw = 16;
 static int g_chain2_xcd = 0;   // 1: contiguous tile runs per XCD (see chain2_body); measured slower: 3.43 vs 3.19 ms at 256^3
 extern "C" void gcge_hip_spmm_chain2_xcd(int on) { g_chain2_xcd = on; }
@@ -635,12 +550,9 @@ static long pat_launch(long nrows, const unsigned short* pid, const void* tab, i
   if (cline > 0) {   // chain + line exchange: nw waves per block, lines of `cline` rows
     if (LT < 5) return -1;
     const long nlines = (nrows + cline - 1) / cline, ntl = (nlines + nw - 1) / nw * (cline / 8);
-#define GCGE_C2(NWV, DP) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), MODE, NWV, DP>), dim3((unsigned)nb), dim3(64 * NWV), \
+#define GCGE_C2(NWV) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), MODE, NWV>), dim3((unsigned)nb), dim3(64 * NWV), \
                        (size_t)ntab * sizeof(PatEntry), st, nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, ntl, cline, partial, yy_off, g_chain2_xcd, cg)
-    if constexpr (MODE == 2) {   // the read-only pass: two chain loads in flight (chain2_body, DEEP) unless switched off
-      if (g_chain2_deep && nb % (cline / 8) == 0) { if (nw == 16) GCGE_C2(16, true); else if (nw == 8) GCGE_C2(8, true); else GCGE_C2(4, true); return nb; }
-    }
-    if (nw == 16) GCGE_C2(16, false); else if (nw == 8) GCGE_C2(8, false); else GCGE_C2(4, false);
+    if (nw == 16) GCGE_C2(16); else if (nw == 8) GCGE_C2(8); else GCGE_C2(4);
 #undef GCGE_C2
     return nb;
   }

