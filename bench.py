@@ -150,6 +150,11 @@ def cpu_baseline(args, hip):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: libraries that greet on stdout (RCCL prints a version banner when a
+    # communicator is created) go to stderr for the duration of the run
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -191,6 +196,12 @@ def main():
         comm = gdist.install(hip, dist, rank, world, stage_through_host=True) if rehearse else gdist.NativeComm(hip, dist, rank, world)
         A, mat = gdist.lap3d_slab(hip, dims, rank, world, comm)
         n_global = dims[0] * dims[1] * dims[2]
+    elif os.environ.get("GCGE_BENCH_FORCE_COMM") == "1":
+        # one-GPU rehearsal of the production multi-GPU plumbing: a communicator of ONE rank, the matrix built through
+        # gcge_hip_mat_create_slab, every reduction routed through ncclAllReduce (numbers from it are one-GPU numbers)
+        os.environ["GCGE_COMM_KEEP_SINGLE"] = "1"
+        comm = gdist.NativeComm(hip, None, 0, 1)
+        A, mat = gdist.lap3d_slab(hip, dims, 0, 1, comm)
     else:
         A, _ = make_problem("lap3d", N)
         mat = hip.matrix(A)
@@ -325,8 +336,13 @@ def main():
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, hip)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
+        if not rehearse:
+            comm.finalize()
         dist.destroy_process_group()
 
 
