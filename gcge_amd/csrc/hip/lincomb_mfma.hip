@@ -151,22 +151,21 @@ __global__ __launch_bounds__(256, (RF == 2 && NT <= 4) ? 2 : 1) void lincomb_ker
 #include "agpr_tiles.inc"
 typedef double v2d_lc __attribute__((ext_vector_type(2)));
 
-template <int NT>
-__global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void lincomb_direct_kernel(long nrows, const double* __restrict__ x, long ldx, int k,
+template <int NT, int RF, int MINB>
+__global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, const double* __restrict__ x, long ldx, int k,
     const double* __restrict__ cpad, int m, const double* __restrict__ beta, double* y, long ldy, int cs) {
   extern __shared__ __align__(16) double lds[];       // [2][LC_KT][cs]
-  constexpr int RF = 2;
   constexpr int CE = LC_KT * 16 * NT / 256;            // coefficient elements per thread and tile (2 NT)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int li = lane & 15, kk = lane >> 4;
-  const long r0 = (long)blockIdx.x * (64 * RF) + 32 * wave;
+  const long r0 = (long)blockIdx.x * (64 * RF) + 16 * RF * wave;
   // Accumulators.  NT >= 4: 8 or 16 tiles pinned to AGPRs by name and driven by inline-asm MFMAs; a tile is then
   // touched again only 7 or 15 MFMAs later.  NT <= 2 has 2 or 4 tiles, i.e. dependent MFMAs one or three instructions
   // apart: the hardware does NOT interlock a DGEMM MFMA reading SrcC against the previous one still writing it (the
   // compiler's hazard recogniser inserts the wait states for the builtin, but it does not see inline asm — measured:
   // results with stale low/high words).  Those widths are bandwidth-bound anyway and take the builtin.
-  constexpr bool PIN = NT >= 4;
+  constexpr bool PIN = RF * NT >= 8;
   v4d accv[PIN ? 1 : RF][PIN ? 1 : NT];
   if constexpr (PIN) {
 #pragma unroll
@@ -210,7 +209,8 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void lincomb_direct_kernel(lo
   auto mfmas = [&](const v2d_lc (&a)[RF][4], int buf) {
     const double* cst = lds + buf * LC_KT * cs + li;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      if (j > 0) __builtin_amdgcn_sched_barrier(0);   // keeps the coefficient reads of later groups from being hoisted (registers)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256, NT <= 4 ? 2 : 1) void lincomb_direct_kernel(lo
             else accv[f][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(h ? a[f][j].y : a[f][j].x, b, accv[f][t], 0, 0, 0);
           }
         }
+    }
   };
   const int ntile = (k + LC_KT - 1) / LC_KT;
   v2d_lc a0[RF][4], a1[RF][4];
@@ -325,7 +326,7 @@ static double* g_cpad = nullptr;
 static size_t g_cpad_len = 0;
 static int g_lc_rf = getenv("GCGE_LINCOMB_RF") ? atoi(getenv("GCGE_LINCOMB_RF")) : 0;   // 0 automatic (the direct form where the operand allows 16-byte loads); 1 / 2: the LDS-staged kernel with
                           // that many row fragments per wave; 3: the direct form forced (falls back when x is not 16-byte aligned)
-extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 0 && row_fragments <= 3) g_lc_rf = row_fragments; }
+extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 0 && row_fragments <= 6) g_lc_rf = row_fragments; }
 
 template <int NT>
 static int lc_launch(int nrows, const double* x, long ldx, int k, const double* c, int m,
@@ -340,18 +341,26 @@ static int lc_launch(int nrows, const double* x, long ldx, int k, const double* 
   // direct form: X read with 16-byte lane loads straight into MFMA operands (needs a 16-byte aligned operand)
   // Measured at n = 2^24, k = 256 (profiles/r02_dense): m = 128 direct 47.2 TF vs 45.9 staged; m = 64 direct 45.8 vs 48.4
   // staged with two row fragments — the automatic choice takes the direct form for the 128-column panels only.
-  if (((g_lc_rf == 0 && NT == 8) || g_lc_rf == 3) && (((uintptr_t)x & 15) == 0) && (ldx % 2 == 0) && k >= 2) {
+  if (((g_lc_rf == 0 && NT == 8) || g_lc_rf >= 3) && (((uintptr_t)x & 15) == 0) && (ldx % 2 == 0) && k >= 2) {
     const int csd = 16 * NT + 8;   // coefficient rows 2 apart land on the other half of the 64 LDS banks
     const size_t shd = (size_t)2 * LC_KT * csd * sizeof(double);
-    const unsigned gridd = (unsigned)(((long)nrows + 127) / 128);
-    hipLaunchKernelGGL((lincomb_direct_kernel<NT>), dim3(gridd), dim3(256), shd, st, (long)nrows, x, ldx, k, g_cpad, m, beta, y, ldy, csd);
+#define GCGE_LCD(RFV, MB) hipLaunchKernelGGL((lincomb_direct_kernel<NT, RFV, MB>), dim3((unsigned)(((long)nrows + 64 * RFV - 1) / (64 * RFV))), dim3(256), \
+                                             shd, st, (long)nrows, x, ldx, k, g_cpad, m, beta, y, ldy, csd)
+    // tuning codes (gcge_hip_lincomb_tune / GCGE_LINCOMB_RF): 3 = two row fragments per wave, 4 = the same at three waves per
+    // SIMD, 5 / 6 = one row fragment at four / three waves per SIMD (NT = 8 keeps two fragments at one block per CU)
+    if constexpr (NT == 8) GCGE_LCD(2, 1);
+    else if (g_lc_rf == 4) GCGE_LCD(2, 3);
+    else if (g_lc_rf == 5) GCGE_LCD(1, 4);
+    else if (g_lc_rf == 6) GCGE_LCD(1, 3);
+    else GCGE_LCD(2, 2);
+#undef GCGE_LCD
     return 0;
   }
   const int cs = (16 * NT + 31) / 32 * 32 + 16;  // row stride of the C tile: 16 mod 32 doubles
   // two row fragments per wave once there are enough rows to fill the chip with 128-row blocks several times over
   // and enough MFMA work per tile to pay for the larger register set (n = 2^24, k = 256: m = 128 27.1 -> 23.9 ms =
   // 46 TF, m = 64 12.0 -> 11.3 ms = 48.5 TF with two waves per SIMD; k = 64 and narrower panels: no gain)
-  const int rf = (g_lc_rf == 0 || g_lc_rf == 3) ? (((NT == 8 || (NT == 4 && k >= 128)) && (long)nrows >= 128L * 256 * 8) ? 2 : 1) : g_lc_rf;
+  const int rf = (g_lc_rf == 0 || g_lc_rf >= 3) ? (((NT == 8 || (NT == 4 && k >= 128)) && (long)nrows >= 128L * 256 * 8) ? 2 : 1) : g_lc_rf;
   const size_t shmem = (size_t)(64 * rf * LC_XS + LC_KT * cs) * sizeof(double);
   const unsigned grid = (unsigned)(((long)nrows + 64 * rf - 1) / (64 * rf));
   if (rf == 2)
