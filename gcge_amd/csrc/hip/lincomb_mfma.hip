@@ -346,11 +346,11 @@ static int lc_launch(int nrows, const double* x, long ldx, int k, const double* 
     const size_t shd = (size_t)2 * LC_KT * csd * sizeof(double);
 #define GCGE_LCD(RFV, MB) hipLaunchKernelGGL((lincomb_direct_kernel<NT, RFV, MB>), dim3((unsigned)(((long)nrows + 64 * RFV - 1) / (64 * RFV))), dim3(256), \
                                              shd, st, (long)nrows, x, ldx, k, g_cpad, m, beta, y, ldy, csd)
-    // tuning codes (gcge_hip_lincomb_tune / GCGE_LINCOMB_RF): 3 = two row fragments per wave, 4 = the same at three waves per
-    // SIMD, 5 / 6 = one row fragment at four / three waves per SIMD (NT = 8 keeps two fragments at one block per CU)
+    // tuning codes (gcge_hip_lincomb_tune / GCGE_LINCOMB_RF): 3 = two row fragments per wave at two waves per SIMD, 6 = one
+    // row fragment at three waves per SIMD (NT = 8 keeps two fragments at one block per CU).  Measured at k = 256, m = 64
+    // (profiles/r02_dense/03): 46.4 / 46.9 TF; forcing two fragments into three waves per SIMD or one fragment into four
+    // spills (32 / 36 TF) — every form lands at 46-48 TF with the MFMA pipes 58-62 % busy (profiles/r02_dense/04).
     if constexpr (NT == 8) GCGE_LCD(2, 1);
-    else if (g_lc_rf == 4) GCGE_LCD(2, 3);
-    else if (g_lc_rf == 5) GCGE_LCD(1, 4);
     else if (g_lc_rf == 6) GCGE_LCD(1, 3);
     else GCGE_LCD(2, 2);
 #undef GCGE_LCD

@@ -30,6 +30,13 @@ __global__ __launch_bounds__(256) void mfma_peak(double* out, int iters, double 
   for (int t = 0; t < 16; ++t) s += agpr_tile_read(t, 0);
   if (s == 1.2345) out[0] = s;
 }
+// streams `bytes` of HBM traffic (read + write) with 16-byte lanes, `reps` times
+__global__ __launch_bounds__(256) void hbm_stream(const double2* __restrict__ src, double2* __restrict__ dst, size_t n2, int reps) {
+  for (int r = 0; r < reps; ++r)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+      double2 v = src[i]; v.x += 1e-30; dst[i] = v;
+    }
+}
 int main(int argc, char** argv) {
   long n = argc > 1 ? atol(argv[1]) : 16777216; int reps = 3;
   if (getenv("LC_RF")) gcge_hip_lincomb_tune(atoi(getenv("LC_RF")));   // row fragments per wave of the panel update
@@ -46,6 +53,24 @@ int main(int argc, char** argv) {
     hipEventRecord(e0); mfma_peak<<<blocks, 256>>>(G, iters, 0.37); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("mfma f64 16x16x4 register-only: %d blocks x 4 waves, %.2f ms -> %.1f TF\n", blocks, ms, 2048.0 * 16 * iters * blocks * 4 / ms * 1e-9);
+  }
+  {   // Does the FP64 MFMA rate survive concurrent HBM traffic?  Register-only loop (2 waves per SIMD) alone, and next to a
+      // copy kernel on a second stream that moves ~4-5 TB/s.  (If it does not, the 46-50 TF of the Gram / panel-update
+      // kernels are a chip-level limit under combined load, not a property of the kernels.)
+    hipStream_t sa, sb; hipStreamCreate(&sa); hipStreamCreate(&sb);
+    const int iters = 20000, blocks = 2048;
+    const size_t n2 = (size_t)n * 64 / 2;     // 8.6 GB read + 8.6 GB written per repetition
+    hipEvent_t a0, a1, b0, b1; hipEventCreate(&a0); hipEventCreate(&a1); hipEventCreate(&b0); hipEventCreate(&b1);
+    hbm_stream<<<1024, 256, 0, sb>>>((const double2*)V, (double2*)W, n2, 1); hipDeviceSynchronize();
+    hipEventRecord(b0, sb); hbm_stream<<<1024, 256, 0, sb>>>((const double2*)V, (double2*)W, n2, 4); hipEventRecord(b1, sb);
+    hipEventSynchronize(b1); float tb; hipEventElapsedTime(&tb, b0, b1);
+    printf("copy alone: %.2f ms -> %.0f GB/s\n", tb, 4 * 2.0 * n2 * 16 / tb * 1e-6);
+    hipEventRecord(b0, sb); hbm_stream<<<1024, 256, 0, sb>>>((const double2*)V, (double2*)W, n2, 24); hipEventRecord(b1, sb);
+    hipEventRecord(a0, sa); mfma_peak<<<blocks, 256, 0, sa>>>(G, iters, 0.37); hipEventRecord(a1, sa);
+    hipEventSynchronize(a1); hipEventSynchronize(b1);
+    float ta; hipEventElapsedTime(&ta, a0, a1); hipEventElapsedTime(&tb, b0, b1);
+    printf("mfma f64 16x16x4 register-only NEXT TO an HBM copy: %.2f ms -> %.1f TF  (copy: 24 reps in %.2f ms -> %.0f GB/s while both ran)\n",
+           ta, 2048.0 * 16 * iters * blocks * 4 / ta * 1e-9, tb, 24 * 2.0 * n2 * 16 / tb * 1e-6);
   }
   int gk[] = {256, 192, 128, 64, 64}, gm[] = {64, 64, 64, 64, 1};
   for (int ms = 1; ms <= 4; ms *= 2)
