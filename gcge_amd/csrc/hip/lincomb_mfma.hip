@@ -151,11 +151,12 @@ __global__ __launch_bounds__(256, (RF == 2 && NT <= 4) ? 2 : 1) void lincomb_ker
 #include "agpr_tiles.inc"
 typedef double v2d_lc __attribute__((ext_vector_type(2)));
 
-template <int NT, int RF, int MINB>
+template <int NT, int RF, int MINB, int KTD>
 __global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, const double* __restrict__ x, long ldx, int k,
     const double* __restrict__ cpad, int m, const double* __restrict__ beta, double* y, long ldy, int cs) {
-  extern __shared__ __align__(16) double lds[];       // [2][LC_KT][cs]
-  constexpr int CE = LC_KT * 16 * NT / 256;            // coefficient elements per thread and tile (2 NT)
+  extern __shared__ __align__(16) double lds[];       // [2][KTD][cs]
+  constexpr int NJ = KTD / 8;                          // 16-byte loads per row fragment and k-tile
+  constexpr int CE = KTD * 16 * NT / 256;              // coefficient elements per thread and tile
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int li = lane & 15, kk = lane >> 4;
@@ -182,9 +183,9 @@ __global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, c
 #pragma unroll
   for (int f = 0; f < RF; ++f) xr[f] = x + min(r0 + 16 * f + li, nrows - 1) * ldx + 2 * kk;
   const int kpairs = (k + 1) / 2;                      // 16-byte column pairs that hold at least one valid column
-  auto fetch_a = [&](v2d_lc (&a)[RF][4], int k0) {
+  auto fetch_a = [&](v2d_lc (&a)[RF][NJ], int k0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int pr = min((k0 + 8 * j) / 2 + kk, kpairs - 1) - kk;   // pair index, clamped into the operand (meets a zero coefficient row)
 #pragma unroll
       for (int f = 0; f < RF; ++f) a[f][j] = *reinterpret_cast<const v2d_lc*>(xr[f] + 2 * pr);
@@ -199,17 +200,17 @@ __global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, c
     }
   };
   auto stash_c = [&](int buf) {
-    double* cst = lds + buf * LC_KT * cs;
+    double* cst = lds + buf * KTD * cs;
 #pragma unroll
     for (int q = 0; q < CE; ++q) {
       const int e = threadIdx.x + 256 * q, row = e / (16 * NT), col = e % (16 * NT);
       cst[row * cs + col] = cr[q];
     }
   };
-  auto mfmas = [&](const v2d_lc (&a)[RF][4], int buf) {
-    const double* cst = lds + buf * LC_KT * cs + li;
+  auto mfmas = [&](const v2d_lc (&a)[RF][NJ], int buf) {
+    const double* cst = lds + buf * KTD * cs + li;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       if (j > 0) __builtin_amdgcn_sched_barrier(0);   // keeps the coefficient reads of later groups from being hoisted (registers)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -224,8 +225,8 @@ __global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, c
         }
     }
   };
-  const int ntile = (k + LC_KT - 1) / LC_KT;
-  v2d_lc a0[RF][4], a1[RF][4];
+  const int ntile = (k + KTD - 1) / KTD;
+  v2d_lc a0[RF][NJ], a1[RF][NJ];
   fetch_c(0);
   fetch_a(a0, 0);
   stash_c(0);
@@ -233,13 +234,13 @@ __global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, c
   // tiles in pairs with two register sets (no copy, no branch inside); the last tile is peeled for the odd-k blend
   int tl = 0;
   for (; tl + 2 < ntile; tl += 2) {
-    fetch_a(a1, (tl + 1) * LC_KT); fetch_c((tl + 1) * LC_KT);
+    fetch_a(a1, (tl + 1) * KTD); fetch_c((tl + 1) * KTD);
     __builtin_amdgcn_sched_barrier(0);
     mfmas(a0, 0);
     __builtin_amdgcn_sched_barrier(0);
     stash_c(1);
     __syncthreads();
-    fetch_a(a0, (tl + 2) * LC_KT); fetch_c((tl + 2) * LC_KT);
+    fetch_a(a0, (tl + 2) * KTD); fetch_c((tl + 2) * KTD);
     __builtin_amdgcn_sched_barrier(0);
     mfmas(a1, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -248,9 +249,9 @@ __global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, c
   }
   // here: a0 / LDS buffer 0 hold tile tl; 1 or 2 tiles remain
   const long odd_mask = (k & 1) ? 0L : -1L;            // all ones: keep the second half of the last valid pair
-  auto blend_last = [&](v2d_lc (&a)[RF][4], int k0) {   // zero x[.., k] where the pair (k-1, k) straddles the end
+  auto blend_last = [&](v2d_lc (&a)[RF][NJ], int k0) {   // zero x[.., k] where the pair (k-1, k) straddles the end
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const bool straddles = 2 * ((k0 + 8 * j) / 2 + kk) + 1 >= k;
       const long keep = straddles ? odd_mask : -1L;
 #pragma unroll
@@ -258,16 +259,16 @@ __global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, c
     }
   };
   if (tl + 2 == ntile) {
-    fetch_a(a1, (tl + 1) * LC_KT); fetch_c((tl + 1) * LC_KT);
+    fetch_a(a1, (tl + 1) * KTD); fetch_c((tl + 1) * KTD);
     __builtin_amdgcn_sched_barrier(0);
     mfmas(a0, 0);
     __builtin_amdgcn_sched_barrier(0);
     stash_c(1);
     __syncthreads();
-    blend_last(a1, (tl + 1) * LC_KT);
+    blend_last(a1, (tl + 1) * KTD);
     mfmas(a1, 1);
   } else {
-    blend_last(a0, tl * LC_KT);
+    blend_last(a0, tl * KTD);
     mfmas(a0, 0);
   }
   // the MFMAs are inline asm, invisible to the hazard recogniser: let the last ones retire before the tiles are read
@@ -324,9 +325,9 @@ using namespace gcge;
 
 static double* g_cpad = nullptr;
 static size_t g_cpad_len = 0;
-static int g_lc_rf = getenv("GCGE_LINCOMB_RF") ? atoi(getenv("GCGE_LINCOMB_RF")) : 0;   // 0 automatic (the direct form where the operand allows 16-byte loads); 1 / 2: the LDS-staged kernel with
-                          // that many row fragments per wave; 3: the direct form forced (falls back when x is not 16-byte aligned)
-extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 0 && row_fragments <= 6) g_lc_rf = row_fragments; }
+static int g_lc_rf = getenv("GCGE_LINCOMB_RF") ? atoi(getenv("GCGE_LINCOMB_RF")) : 0;   // 0 automatic (the direct form for panels of >= 33 columns where the operand allows 16-byte loads);
+                          // 1 / 2: the LDS-staged kernel with that many row fragments per wave; >= 3: the direct form forced, see lc_launch
+extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 0 && row_fragments <= 12) g_lc_rf = row_fragments; }
 
 template <int NT>
 static int lc_launch(int nrows, const double* x, long ldx, int k, const double* c, int m,
@@ -339,20 +340,28 @@ static int lc_launch(int nrows, const double* x, long ldx, int k, const double* 
   }
   hipLaunchKernelGGL(lincomb_pad_c, dim3((kp * mp + 255) / 256), dim3(256), 0, st, c, k, m, g_cpad, kp, mp);
   // direct form: X read with 16-byte lane loads straight into MFMA operands (needs a 16-byte aligned operand)
-  // Measured at n = 2^24, k = 256 (profiles/r02_dense): m = 128 direct 47.2 TF vs 45.9 staged; m = 64 direct 45.8 vs 48.4
-  // staged with two row fragments — the automatic choice takes the direct form for the 128-column panels only.
-  if (((g_lc_rf == 0 && NT == 8) || g_lc_rf >= 3) && (((uintptr_t)x & 15) == 0) && (ldx % 2 == 0) && k >= 2) {
+  // Measured at n = 2^24 (profiles/r02_dense/06): what decides is waves per SIMD, and short k-tiles buy them — the operand
+  // registers of a k-tile shrink with it while the accumulator tiles (AGPRs) stay.  k = 256, m = 128: k-tiles of 32 at one
+  // wave per SIMD 47.2 TF, of 16 at two waves 55.5, of 8 at two waves 57.9 (staged form 45.9; the vendor GEMM 63.8);
+  // m = 64: k-tiles of 32 at two waves 46.4, of 16 at three waves 52.5, of 8 at four waves 52.4 (staged 49.4; vendor 30.5).
+  // Panels of <= 32 columns are bandwidth-bound and stay with the staged kernel.
+  if (((g_lc_rf == 0 && NT >= 4) || g_lc_rf >= 3) && (((uintptr_t)x & 15) == 0) && (ldx % 2 == 0) && k >= 2) {
     const int csd = 16 * NT + 8;   // coefficient rows 2 apart land on the other half of the 64 LDS banks
-    const size_t shd = (size_t)2 * LC_KT * csd * sizeof(double);
-#define GCGE_LCD(RFV, MB) hipLaunchKernelGGL((lincomb_direct_kernel<NT, RFV, MB>), dim3((unsigned)(((long)nrows + 64 * RFV - 1) / (64 * RFV))), dim3(256), \
-                                             shd, st, (long)nrows, x, ldx, k, g_cpad, m, beta, y, ldy, csd)
-    // tuning codes (gcge_hip_lincomb_tune / GCGE_LINCOMB_RF): 3 = two row fragments per wave at two waves per SIMD, 6 = one
-    // row fragment at three waves per SIMD (NT = 8 keeps two fragments at one block per CU).  Measured at k = 256, m = 64
-    // (profiles/r02_dense/03): 46.4 / 46.9 TF; forcing two fragments into three waves per SIMD or one fragment into four
-    // spills (32 / 36 TF) — every form lands at 46-48 TF with the MFMA pipes 58-62 % busy (profiles/r02_dense/04).
-    if constexpr (NT == 8) GCGE_LCD(2, 1);
-    else if (g_lc_rf == 6) GCGE_LCD(1, 3);
-    else GCGE_LCD(2, 2);
+#define GCGE_LCD(RFV, MB, KTV) hipLaunchKernelGGL((lincomb_direct_kernel<NT, RFV, MB, KTV>), dim3((unsigned)(((long)nrows + 64 * RFV - 1) / (64 * RFV))), dim3(256), \
+                                             (size_t)2 * KTV * csd * sizeof(double), st, (long)nrows, x, ldx, k, g_cpad, m, beta, y, ldy, csd)
+    // tuning codes (gcge_hip_lincomb_tune / GCGE_LINCOMB_RF) >= 3 force the direct form; 7: k-tiles of 32 at one wave per
+    // SIMD (m = 128); 6 / 8 / 10 / 11 / 12: other (row fragments, waves per SIMD, k-tile) combinations for m = 64
+    if constexpr (NT == 8) { if (g_lc_rf == 7) GCGE_LCD(2, 1, 32); else if (g_lc_rf == 10) GCGE_LCD(2, 2, 16); else GCGE_LCD(2, 2, 8); }
+    else if constexpr (NT == 4) {
+      if (g_lc_rf == 11) GCGE_LCD(2, 4, 8);
+      else if (g_lc_rf == 12) GCGE_LCD(2, 3, 8);
+      else if (g_lc_rf == 6) GCGE_LCD(1, 3, 32);
+      else if (g_lc_rf == 10) GCGE_LCD(2, 2, 16);
+      else if (g_lc_rf == 7) GCGE_LCD(2, 2, 32);
+      else GCGE_LCD(2, 3, 16);
+    } else {
+      GCGE_LCD(2, 2, 16);
+    }
 #undef GCGE_LCD
     return 0;
   }
