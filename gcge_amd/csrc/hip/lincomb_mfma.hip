@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, (RF == 2 && NT <= 4) ? 2 : 1) void lincomb_ker
 #include "agpr_tiles.inc"
 typedef double v2d_lc __attribute__((ext_vector_type(2)));
 
-template <int NT, int RF, int MINB, int KTD>
+template <int NT, int RF, int MINB, int KTD, bool ASM = true>
 __global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, const double* __restrict__ x, long ldx, int k,
     const double* __restrict__ cpad, int m, const double* __restrict__ beta, double* y, long ldy, int cs) {
   extern __shared__ __align__(16) double lds[];       // [2][KTD][cs]
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, c
   // apart: the hardware does NOT interlock a DGEMM MFMA reading SrcC against the previous one still writing it (the
   // compiler's hazard recogniser inserts the wait states for the builtin, but it does not see inline asm — measured:
   // results with stale low/high words).  Those widths are bandwidth-bound anyway and take the builtin.
-  constexpr bool PIN = RF * NT >= 8;
+  constexpr bool PIN = ASM && RF * NT >= 8;
   v4d accv[PIN ? 1 : RF][PIN ? 1 : NT];
   if constexpr (PIN) {
 #pragma unroll
@@ -327,7 +327,7 @@ static double* g_cpad = nullptr;
 static size_t g_cpad_len = 0;
 static int g_lc_rf = getenv("GCGE_LINCOMB_RF") ? atoi(getenv("GCGE_LINCOMB_RF")) : 0;   // 0 automatic (the direct form for panels of >= 33 columns where the operand allows 16-byte loads);
                           // 1 / 2: the LDS-staged kernel with that many row fragments per wave; >= 3: the direct form forced, see lc_launch
-extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 0 && row_fragments <= 12) g_lc_rf = row_fragments; }
+extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 0 && row_fragments <= 14) g_lc_rf = row_fragments; }
 
 template <int NT>
 static int lc_launch(int nrows, const double* x, long ldx, int k, const double* c, int m,
@@ -341,26 +341,32 @@ static int lc_launch(int nrows, const double* x, long ldx, int k, const double* 
   hipLaunchKernelGGL(lincomb_pad_c, dim3((kp * mp + 255) / 256), dim3(256), 0, st, c, k, m, g_cpad, kp, mp);
   // direct form: X read with 16-byte lane loads straight into MFMA operands (needs a 16-byte aligned operand)
   // Measured at n = 2^24 (profiles/r02_dense/06): what decides is waves per SIMD, and short k-tiles buy them — the operand
-  // registers of a k-tile shrink with it while the accumulator tiles (AGPRs) stay.  k = 256, m = 128: k-tiles of 32 at one
-  // wave per SIMD 47.2 TF, of 16 at two waves 55.5, of 8 at two waves 57.9 (staged form 45.9; the vendor GEMM 63.8);
-  // m = 64: k-tiles of 32 at two waves 46.4, of 16 at three waves 52.5, of 8 at four waves 52.4 (staged 49.4; vendor 30.5).
-  // Panels of <= 32 columns are bandwidth-bound and stay with the staged kernel.
+  // registers of a k-tile shrink with it while the accumulator tiles stay.  k = 256, m = 128: k-tiles of 32 at one wave per
+  // SIMD 47.2 TF, of 16 at two waves 56.2, of 8 at two waves 57.9 (staged form 45.9; the vendor GEMM 63.8); m = 64:
+  // k-tiles of 32 at two waves 46.4, of 16 at two waves 50.9, of 8 at three waves with compiler-managed accumulators 53.2
+  // (staged 49.4; vendor 30.5).  Panels of <= 32 columns are bandwidth-bound and stay with the staged kernel.
+  // Accumulators pinned to AGPRs BY NAME are only used where the compiler is not short of registers: the clobber lists
+  // keep it from holding values in a named tile ACROSS a statement that uses it, not from parking a temporary there
+  // BETWEEN two such statements — the m = 64 variants at three / four waves per SIMD (84 / 64 VGPRs) did exactly that and
+  // returned wrong panels (caught by test_lincomb_row_fragment_variants_vs_oracle at k = 192, m = 64).  Those widths take
+  // the builtin MFMA (the compiler owns the accumulators); m = 128 at two waves per SIMD keeps the named tiles and is
+  // covered by the same test with all 16 tiles live.
   if (((g_lc_rf == 0 && NT >= 4) || g_lc_rf >= 3) && (((uintptr_t)x & 15) == 0) && (ldx % 2 == 0) && k >= 2) {
     const int csd = 16 * NT + 8;   // coefficient rows 2 apart land on the other half of the 64 LDS banks
-#define GCGE_LCD(RFV, MB, KTV) hipLaunchKernelGGL((lincomb_direct_kernel<NT, RFV, MB, KTV>), dim3((unsigned)(((long)nrows + 64 * RFV - 1) / (64 * RFV))), dim3(256), \
+#define GCGE_LCD(RFV, MB, KTV, ASMV) hipLaunchKernelGGL((lincomb_direct_kernel<NT, RFV, MB, KTV, ASMV>), dim3((unsigned)(((long)nrows + 64 * RFV - 1) / (64 * RFV))), dim3(256), \
                                              (size_t)2 * KTV * csd * sizeof(double), st, (long)nrows, x, ldx, k, g_cpad, m, beta, y, ldy, csd)
-    // tuning codes (gcge_hip_lincomb_tune / GCGE_LINCOMB_RF) >= 3 force the direct form; 7: k-tiles of 32 at one wave per
-    // SIMD (m = 128); 6 / 8 / 10 / 11 / 12: other (row fragments, waves per SIMD, k-tile) combinations for m = 64
-    if constexpr (NT == 8) { if (g_lc_rf == 7) GCGE_LCD(2, 1, 32); else if (g_lc_rf == 10) GCGE_LCD(2, 2, 16); else GCGE_LCD(2, 2, 8); }
-    else if constexpr (NT == 4) {
-      if (g_lc_rf == 11) GCGE_LCD(2, 4, 8);
-      else if (g_lc_rf == 12) GCGE_LCD(2, 3, 8);
-      else if (g_lc_rf == 6) GCGE_LCD(1, 3, 32);
-      else if (g_lc_rf == 10) GCGE_LCD(2, 2, 16);
-      else if (g_lc_rf == 7) GCGE_LCD(2, 2, 32);
-      else GCGE_LCD(2, 3, 16);
+    // tuning codes (gcge_hip_lincomb_tune / GCGE_LINCOMB_RF): 3 the automatic direct form also for narrow panels;
+    // 7: k-tiles of 32 (named tiles); 10: k-tiles of 16 at two waves per SIMD (named tiles); 13 / 14: builtin, k-tiles of 8 / 16
+    if constexpr (NT == 8) {
+      if (g_lc_rf == 7) GCGE_LCD(2, 1, 32, true); else if (g_lc_rf == 10) GCGE_LCD(2, 2, 16, true);
+      else if (g_lc_rf == 13) GCGE_LCD(2, 2, 8, false); else if (g_lc_rf == 14) GCGE_LCD(2, 2, 16, false);
+      else GCGE_LCD(2, 2, 8, true);
+    } else if constexpr (NT == 4) {
+      if (g_lc_rf == 7) GCGE_LCD(2, 2, 32, true); else if (g_lc_rf == 10) GCGE_LCD(2, 2, 16, true);
+      else if (g_lc_rf == 14) GCGE_LCD(2, 3, 16, false);
+      else GCGE_LCD(2, 3, 8, false);
     } else {
-      GCGE_LCD(2, 2, 16);
+      GCGE_LCD(2, 2, 16, false);
     }
 #undef GCGE_LCD
     return 0;

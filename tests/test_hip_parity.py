@@ -552,11 +552,14 @@ def test_full_size_cg_passes_properties(hip):
     hip.free_matrix(mh)
 
 
-@pytest.mark.parametrize("rf", [1, 2, 3])
+@pytest.mark.parametrize("rf", [1, 2, 3, 7, 10, 13, 14])
 def test_lincomb_row_fragment_variants_vs_oracle(both, rf):
-    """The panel update in its three forms (gcge_hip_lincomb_tune): X staged through LDS with one or two 16-row fragments
-    per wave, and (3) the direct form — X fragments from global memory with 16-byte loads, the default wherever the
-    operand is 16-byte aligned; odd column offsets fall back to the staged kernel: ragged row count (2197 = 17 x 128 + 21),
+    """The panel update in all its forms (gcge_hip_lincomb_tune): X staged through LDS with one or two 16-row fragments
+    per wave (1, 2), and the direct form — X fragments from global memory with 16-byte loads, the default for panels of
+    more than 32 columns wherever the operand is 16-byte aligned — in its automatic configuration (3) and with other
+    k-tiles / accumulator ownership (7, 10: tiles named in AGPRs; 13, 14: compiler-managed); odd column offsets fall back to
+    the staged kernel.  Full-width panels (m = 64, 128: every accumulator tile live) at the solver's k, and the solver's
+    in-place update W -= V C, are the cases that caught a variant whose named tiles the compiler had used as scratch: ragged row count (2197 = 17 x 128 + 21),
     k not a multiple of the 32-column tile, m not a multiple of 16, all three beta modes, x == y in place."""
     hip, ora = both
     A, mh, mo = _pair_mats(both, "lap3d", 13)
@@ -565,7 +568,8 @@ def test_lincomb_row_fragment_variants_vs_oracle(both, rf):
     hip.g.gcge_hip_lincomb_tune(rf)
     try:
         for k, m, s0, s1 in [(1, 65, 0, 0), (33, 100, 2, 1), (100, 128, 0, 3), (260, 65, 1, 0), (260, 128, 2, 2), (64, 17, 0, 5),
-                             (130, 33, 3, 3)]:
+                             (130, 33, 3, 3), (192, 64, 0, 0), (256, 64, 2, 6), (255, 64, 0, 2), (64, 64, 4, 0), (256, 128, 0, 0),
+                             (24, 48, 0, 0), (8, 64, 0, 0)]:
             Y0 = uniform(48, (n, 140))
             xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
             coef = np.asfortranarray(uniform(49, (k + 1, m)) - 0.5)
@@ -586,6 +590,14 @@ def test_lincomb_row_fragment_variants_vs_oracle(both, rf):
         hip.ops.lincomb(yh, yh, (0, 150), (140, 215), coef, 140, one, 0)
         ora.ops.lincomb(yo, yo, (0, 150), (140, 215), coef, 140, one, 0)
         _close(hip.mv_to_numpy(yh, n, 0, 220), ora.mv_to_numpy(yo, n, 0, 220), tol=1e-12, what="lincomb in place rf=%d" % rf)
+        # the orthonormalisation update of the solver: W -= V coef with W = the 64 columns right behind the k columns of V
+        for kk in (192, 131):
+            Y0 = uniform(53, (n, 264)) - 0.5
+            yh, yo = hip.mv_from_numpy(mh, Y0), ora.mv_from_numpy(mo, Y0)
+            coef = np.asfortranarray(uniform(54, (kk, 64)) - 0.5)
+            hip.ops.lincomb(yh, yh, (0, kk), (kk, kk + 64), coef, kk, one, 0)
+            ora.ops.lincomb(yo, yo, (0, kk), (kk, kk + 64), coef, kk, one, 0)
+            _close(hip.mv_to_numpy(yh, n, 0, 264), ora.mv_to_numpy(yo, n, 0, 264), tol=1e-12, what="lincomb W -= V C in place k=%d rf=%d" % (kk, rf))
     finally:
         hip.g.gcge_hip_lincomb_tune(0)
 
