@@ -131,13 +131,18 @@ def cpu_baseline(args, hip):
             mkl.MKL_Set_Num_Threads(C.c_int(cores))
         except (OSError, AttributeError):
             pass
+        # the host of a GPU box is shared: the faster of two runs (3.5 s and 12.6 s have both been seen for the same run)
         ev, conv, it, sec = po.ref_gcg(A, None, nev, omp=True)
+        ev2, conv2, it2, sec2 = po.ref_gcg(A, None, nev, omp=True)
+        secs = (sec, sec2)
+        if sec2 < sec:
+            ev, conv, it, sec = ev2, conv2, it2, sec2
         import numpy as np
         k = min(conv, res_g.nevConv)
         gpu["max_rel_diff_vs_cpu_reference"] = float(np.max(np.abs(ev_g[:k] - ev[:k]) / np.abs(ev[:k])))
         return {"value": conv / sec, "unit": "eigenpairs/s", "cores": cores, "kind": "reference",
                 "sample": sample + "; OPS_USE_OMP build of app_ccs/app_lapack (oracle/Makefile ref_omp), OMP_NUM_THREADS = MKL threads = %d, "
-                                   "MKL_THREADING_LAYER=GNU; %d GCG its, %d pairs, %.1f s" % (cores, it, conv, sec),
+                                   "MKL_THREADING_LAYER=GNU; %d GCG its, %d pairs, %.1f s (faster of two runs: %.1f / %.1f s)" % (cores, it, conv, sec, secs[0], secs[1]),
                 "gpu_same_config": gpu}
     ops = po.make_ops()
     po.oracle_lib().oracle_set_threads(cores)
