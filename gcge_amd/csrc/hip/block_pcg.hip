@@ -585,7 +585,14 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       const size_t keep = (size_t)12 << 30;   // leave room for staging, partial sums and the caller
       long want = fr > keep ? (long)((fr - keep) / slot) : 0;
       if (want > ring_max - 1) want = ring_max - 1;
-      if (want < 4) want = 0;                   // fewer than 4 pending terms do not pay
+      // smallest ring worth having: with the product recomputed (1 + 4 streams per iteration) even two extra slots pay —
+      // x then costs (2 + 2) / 2 = 2 streams per iteration, 7 in all against 8.1 of the stored-w form; that is the case of
+      // BASELINE config 4's shape, where 244 of 288 GB are taken by the solver's own blocks (GCGE_CG_MIN_RING overrides)
+      // (with the product stored — generic matrices, shifts — a ring only pays from 4 extra slots on: 2 + 5 + (J + 2) / J
+      // streams against the 9 of the ring-less sweep)
+      static const int min_ring_env = getenv("GCGE_CG_MIN_RING") ? atoi(getenv("GCGE_CG_MIN_RING")) : 0;
+      const int min_ring = min_ring_env > 0 ? min_ring_env : ((sigma == 0.0 && gcge_hip_cg_recompute_pays(mat)) ? 2 : 4);
+      if (want < min_ring) want = 0;
       if (want > s->max_iter) want = s->max_iter;
       // Row-partitioned runs: the ring length decides the column window [alo, ahi) and with it the LENGTH of the two
       // all-reduces of an iteration, so every rank must use the same one — the minimum over the ranks (free memory
@@ -600,10 +607,10 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
         want = agreed;
       }
       s->ring[0] = s->mv_ws[1]; s->ring_len = 1;
-      if (want >= 4)
+      if (want >= 1)
         for (long i = 0; i < want; ++i) { ops->MultiVecCreateByMultiVec(&s->ring[s->ring_len], s->ws_cols, mv_x, ops); ++s->ring_len; }
     }
-    const int R = s->ring_len >= 5 ? s->ring_len : 1;        // ring slots; 1: x is updated in every iteration
+    const int R = s->ring_len >= 2 ? s->ring_len : 1;        // ring slots; 1: x is updated in every iteration
     const int J = R - 1;                                     // pending directions before x is brought up to date
     std::vector<double> ahist((size_t)(J > 0 ? J : 1) * nrhs, 0.0);
     int npend = 0, first_slot = 0, cur = 0;                  // p_k lives in ring[cur]; pending: slots first_slot .. (npend of them)
