@@ -576,7 +576,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
   if (!two_pass && nrhs <= 512 && cg_vec_ok(nrhs, {dw, dr, dp, dx}, {ldw, ldr, ldp, ldx})) {
     std::vector<double> wTw(nrhs), bet(nrhs);
     // p-ring (see cg_update_rp): as many slots as memory allows, at most 16; fewer than 4 pending terms do not pay
-    static const int ring_max = getenv("GCGE_CG_RING") ? atoi(getenv("GCGE_CG_RING")) : 16;
+    const int ring_max = getenv("GCGE_CG_RING") ? atoi(getenv("GCGE_CG_RING")) : 16;   // (read when a ring is created)
     if (s->ring_len == 0 && s->max_iter >= 8) {   // (every rank gets here in the same call: the vote below is collective)
       size_t fr = 0, tot = 0;
       GCGE_HIP_CHECK(hipMemGetInfo(&fr, &tot));

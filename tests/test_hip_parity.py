@@ -732,3 +732,38 @@ def test_fused_cg_device_scalars_equal_host_scalars(hip):
     assert out[("device", "gcg")][1] == out[("host", "gcg")][1] and abs(out[("device", "gcg")][2] - out[("host", "gcg")][2]) <= 2
     assert np.max(np.abs(out[("device", "gcg")][0] - out[("host", "gcg")][0]) / np.abs(out[("host", "gcg")][0])) < 1e-10
     hip.free_matrix(mat)
+
+
+def test_fused_cg_small_direction_ring(hip):
+    """Direction rings of 2 extra slots (what is left at BASELINE config 4's shape, where the solver's own blocks take 244 of
+    288 GB) against the full ring and against no ring at all (GCGE_CG_RING caps the slots): x is brought up to date every
+    2nd / 15th / every iteration, the iterates are the same — same iteration counts, same solutions to rounding."""
+    import os
+    g = hip.g
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    g.gcge_hip_bpcg_release.argtypes = [C.c_void_p]
+    A, _ = make_problem("lap3d", 16)
+    n = A.nrows
+    mat = hip.matrix(A)
+    nrhs = 8
+    Bm = uniform(81, (n, nrhs)) - 0.5
+    out = {}
+    try:
+        for cap in ("16", "3", "1"):
+            os.environ["GCGE_CG_RING"] = cap
+            g.gcge_hip_bpcg_release(hip.ops_handle)          # the ring is created with the workspace
+            g.gcge_hip_bpcg_setup(hip.ops_handle, 37, 1e-9, 1e-12, b"abs")
+            b = hip.mv_from_numpy(mat, Bm); x = hip.mv_from_numpy(mat, np.zeros((n, nrhs)))
+            hip.ops.multi_linear_solver(mat, b, x, (0, 0), (nrhs, nrhs))
+            it = C.c_int(); g.gcge_hip_bpcg_stats(None, None, C.byref(it))
+            out[cap] = (hip.mv_to_numpy(x, n, 0, nrhs), it.value)
+            hip.ops.mv_destroy(b, nrhs); hip.ops.mv_destroy(x, nrhs)
+    finally:
+        os.environ.pop("GCGE_CG_RING", None)
+        g.gcge_hip_bpcg_release(hip.ops_handle)
+        g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    assert out["16"][1] == out["3"][1] == out["1"][1] == 37 or out["16"][1] == out["3"][1] == out["1"][1]
+    scale = np.max(np.abs(out["16"][0]))
+    assert np.max(np.abs(out["3"][0] - out["16"][0])) <= 1e-11 * scale
+    assert np.max(np.abs(out["1"][0] - out["16"][0])) <= 1e-9 * scale      # (no ring: the stored-w form, other rounding)
+    hip.free_matrix(mat)

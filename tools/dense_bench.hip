@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void hbm_stream(const double2* __restrict__ sr
 int main(int argc, char** argv) {
   long n = argc > 1 ? atol(argv[1]) : 16777216; int reps = 3;
   if (getenv("LC_RF")) gcge_hip_lincomb_tune(atoi(getenv("LC_RF")));   // row fragments per wave of the panel update
-  const long ldv = 256, ldw = 128;
+  const long ldv = getenv("DB_LDV") ? atol(getenv("DB_LDV")) : 256, ldw = 128;
   double *V, *W, *G, *C;
   GCGE_HIP_CHECK(hipMalloc(&V, n * ldv * 8)); GCGE_HIP_CHECK(hipMalloc(&W, n * ldw * 8));
   GCGE_HIP_CHECK(hipMalloc(&G, 656 * 656 * 8)); GCGE_HIP_CHECK(hipMalloc(&C, 656 * 128 * 8));
@@ -72,9 +72,10 @@ int main(int argc, char** argv) {
     printf("mfma f64 16x16x4 register-only NEXT TO an HBM copy: %.2f ms -> %.1f TF  (copy: 24 reps in %.2f ms -> %.0f GB/s while both ran)\n",
            ta, 2048.0 * 16 * iters * blocks * 4 / ta * 1e-9, tb, 24 * 2.0 * n2 * 16 / tb * 1e-6);
   }
-  int gk[] = {256, 192, 128, 64, 64}, gm[] = {64, 64, 64, 64, 1};
+  int gk[] = {256, 192, 128, 64, 64, 256, 512, 512}, gm[] = {64, 64, 64, 64, 1, 128, 128, 64};
   for (int ms = 1; ms <= 4; ms *= 2)
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < 8; ++i) {
+    if (gk[i] > ldv) continue;
     int k = gk[i], m = gm[i];
     gcge_hip_gram_tune(ms); if (i == 0) printf("gram MS=%d\n", ms);
     gcge_hip_gram((int)n, V, ldv, k, W, ldw, m, G, 0); hipDeviceSynchronize();
@@ -82,8 +83,9 @@ int main(int argc, char** argv) {
     hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     printf("gram    k=%3d m=%3d  %8.3f ms  %6.1f TF  %7.1f GB/s (min traffic)\n", k, m, ms, 2.0 * n * k * m / ms * 1e-9, 8.0 * n * (k + m) / ms * 1e-6);
   }
-  int lk[] = {256, 256, 192, 64, 1}, lm[] = {128, 64, 64, 64, 63};
-  for (int i = 0; i < 5; ++i) {
+  int lk[] = {256, 256, 192, 64, 1, 512, 512}, lm[] = {128, 64, 64, 64, 63, 128, 64};
+  for (int i = 0; i < 7; ++i) {
+    if (lk[i] > ldv) continue;
     int k = lk[i], m = lm[i];
     gcge_hip_lincomb((int)n, V, ldv, k, C, m, nullptr, W, ldw, 0); hipDeviceSynchronize();
     hipEventRecord(e0); for (int r = 0; r < reps; ++r) gcge_hip_lincomb((int)n, V, ldv, k, C, m, nullptr, W, ldw, 0);
