@@ -60,6 +60,47 @@ __global__ __launch_bounds__(256) void axpby2_kernel(long nrows, double alpha,
   }
 }
 
+
+// The same in the form the streaming kernels of block_pcg.hip use: `tpr` threads walk a row (two columns each), a block owns
+// a contiguous slab of rows, four rows are in flight per thread before the first is consumed, and the mode is a template
+// parameter — no index division and no mode branch per element (the grid-stride form above moves a 64-column copy at
+// 4.5 TB/s).  m2 <= 256 column pairs.
+typedef double v2d_ax __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ __launch_bounds__(256) void axpby2_rows_kernel(long nrows, double alpha, const double* __restrict__ x, long ldx,
+    double beta, double* y, long ldy, int m2, int tpr) {
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr, rpb = 256 / tpr;
+  if (tx >= m2) return;
+  const int j = 2 * tx;
+  const long slab = (((nrows + gridDim.x - 1) / gridDim.x) + rpb - 1) / rpb * rpb;
+  const long rend = min(nrows, ((long)blockIdx.x + 1) * slab);
+  long row = (long)blockIdx.x * slab + ty;
+  auto one = [&](long r, v2d_ax a, v2d_ax b) {
+    v2d_ax v;
+    if (MODE == 0) { v.x = alpha * a.x + beta * b.x; v.y = alpha * a.y + beta * b.y; }
+    else if (MODE == 1) { v.x = alpha * a.x; v.y = alpha * a.y; }
+    else { v.x = beta * b.x; v.y = beta * b.y; }
+    __builtin_nontemporal_store(v, reinterpret_cast<v2d_ax*>(y + r * ldy + j));
+  };
+  for (; row + 3L * rpb < rend; row += 4L * rpb) {
+    v2d_ax a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long r = row + (long)u * rpb;
+      if (MODE != 2) a[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d_ax*>(x + r * ldx + j)); else a[u] = v2d_ax{0.0, 0.0};
+      if (MODE != 1) b[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d_ax*>(y + r * ldy + j)); else b[u] = v2d_ax{0.0, 0.0};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(row + (long)u * rpb, a[u], b[u]);
+  }
+  for (; row < rend; row += rpb) {
+    v2d_ax a = v2d_ax{0.0, 0.0}, b = v2d_ax{0.0, 0.0};
+    if (MODE != 2) a = *reinterpret_cast<const v2d_ax*>(x + row * ldx + j);
+    if (MODE != 1) b = *reinterpret_cast<const v2d_ax*>(y + row * ldy + j);
+    one(row, a, b);
+  }
+}
+
 __global__ __launch_bounds__(256) void colscale_kernel(long nrows, double* y, long ldy, int m,
     const double* __restrict__ s) {
   const long total = nrows * (long)m;
@@ -189,7 +230,17 @@ extern "C" int gcge_hip_axpby(int nrows, double alpha, const double* d_x, long l
   }
   const bool vec2 = (m % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)d_y & 15) == 0) &&
                     (mode >= 2 || ((ldx % 2 == 0) && (((uintptr_t)d_x & 15) == 0)));
-  if (vec2)
+  // x == y with different column ranges (column copies inside one block) is fine for the row form as well: a thread reads
+  // and writes only its own (row, column pair)
+  if (vec2 && mode <= 2 && m / 2 <= 256 && (long)nrows >= 1024) {
+    const int m2 = m / 2;
+    int tpr = 1; while (tpr < m2) tpr *= 2;
+    const int rpb = 256 / tpr;
+    long g = ((long)nrows + (long)rpb * 8 - 1) / ((long)rpb * 8); if (g > 8192) g = 8192; if (g < 1) g = 1;
+    if (mode == 0) hipLaunchKernelGGL(axpby2_rows_kernel<0>, dim3((unsigned)g), dim3(256), 0, st, (long)nrows, alpha, d_x, ldx, beta, d_y, ldy, m2, tpr);
+    else if (mode == 1) hipLaunchKernelGGL(axpby2_rows_kernel<1>, dim3((unsigned)g), dim3(256), 0, st, (long)nrows, alpha, d_x, ldx, beta, d_y, ldy, m2, tpr);
+    else hipLaunchKernelGGL(axpby2_rows_kernel<2>, dim3((unsigned)g), dim3(256), 0, st, (long)nrows, alpha, d_x, ldx, beta, d_y, ldy, m2, tpr);
+  } else if (vec2)
     hipLaunchKernelGGL(axpby2_kernel, dim3(grid_for((long)nrows * (m / 2))), dim3(256), 0, st, (long)nrows,
                        alpha, d_x, ldx, beta, d_y, ldy, m / 2, mode);
   else
