@@ -38,10 +38,10 @@ int gcge_hip_colmajor_to_rowmajor(int nrows, int m, const double* d_src, long ld
 int gcge_hip_rowmajor_to_colmajor(int nrows, int m, const double* d_src, long lds, double* d_dst, long ldd, void* stream);
 }
 
-extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                    long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
                                    long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
-                                   double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb);
+                                   double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, int near);
 
 
 __global__ __launch_bounds__(256) void halo_pack(int nsend, const int* __restrict__ rows, const double* __restrict__ x,
@@ -177,7 +177,7 @@ extern "C" long gcge_hip_profile_kind(int kind, int ncols, double* total_ms, dou
 // hundred rows, so the scan costs nothing there).
 struct PatEntryH { double val; long off; };
 static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val) {
-  A->d_pid = nullptr; A->d_tab = nullptr; A->npat = 0; A->pat_lt = 0;
+  A->d_pid = nullptr; A->d_tab = nullptr; A->npat = 0; A->pat_lt = 0; A->pat_near = 0;
   int maxlen = 0;
   for (int r = 0; r < nrows; ++r) maxlen = std::max(maxlen, rowptr[r + 1] - rowptr[r]);
   const int lt = gcge_hip_pattern_width(maxlen);
@@ -311,6 +311,7 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const in
     if (!ok) break;
     tab.swap(ctab); pid.swap(cpid);
     A->npat = (int)(tab.size() / lt); A->pat_span2 = Lline ? -Lline : -1;
+    A->pat_near = Lline && lt == 7 && nslot_used == 7 && slot[5] == -1 && slot[6] == 1;
   } while (0);
   GCGE_HIP_CHECK(hipMalloc(&A->d_pid, (size_t)nrows * sizeof(unsigned short)));
   GCGE_HIP_CHECK(hipMalloc(&A->d_tab, tab.size() * sizeof(PatEntryH)));
@@ -685,10 +686,10 @@ static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long 
   }
   if (cg != nullptr) {
     if (A->d_pid == nullptr || g_spmm_path != 0) return -1;
-    return gcge_hip_pattern_cg(cg->mode, nr, A->d_pid + r0, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2,
+    return gcge_hip_pattern_cg_near(cg->mode, nr, A->d_pid + r0, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2,
                                dx + r0 * ldx, ldx, cg->r ? cg->r + r0 * cg->ldr : nullptr, cg->ldr,
                                cg->pnew ? cg->pnew + r0 * cg->ldp : nullptr, cg->ldp, m, cg->alpha, cg->beta, cg->flag,
-                               d_dots, d_yy, g_stream, cg->b ? cg->b + r0 * cg->ldb : nullptr, cg->ldb);
+                               d_dots, d_yy, g_stream, cg->b ? cg->b + r0 * cg->ldb : nullptr, cg->ldb, A->pat_near);
   }
   double* y = dy + r0 * ldy;
   int rc = -1;

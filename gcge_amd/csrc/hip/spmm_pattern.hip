@@ -36,6 +36,9 @@ extern "C" void gcge_hip_reduce_partials16(const double* d_partial, int nblocks,
                                            void* stream);
 extern "C" void gcge_hip_reduce_partials_slabs(const double* d_partial, int nblocks, long slab_stride, int cpp, int ncols,
                                                double* d_out, void* stream);
+extern "C" int gcge_hip_ring_pass(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, long L, int nw,
+                                  long nb, const double* d_x, long ldx, int m, double* part, long yyo,
+                                  const double* d_lambda, void* stream);
 
 namespace gcge {
 
@@ -682,10 +685,12 @@ extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, con
 //   mode 5: R = B - A X; PNEW = R; d_dots[j] = sum_r R[r,j]^2  (start of the CG; d_b / ldb: the right-hand sides)
 // Geometry as gcge_hip_pattern_spmm; a chain-layout table without line exchange runs through the plain kernel
 // (its table is a valid generic one).  -1: not applicable (alignment), the caller keeps the unfused recurrence.
-extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
-                                   long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
-                                   long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
-                                   double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb) {
+// near: the table's slots are [-S, 0, +S, -L, +L, -1, +1] (7-point stencil; GCGE_HIP_MAT_::pat_near): modes 2 and 4 may
+// take the LDS-ring sweep of spmm_ring.hip.
+extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+                                        long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
+                                        long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
+                                        double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, int near) {
   if (mode != 2 && mode != 3 && mode != 4 && mode != 5) return -1;
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || ((uintptr_t)d_x & 15) || d_dots == nullptr) return -1;
@@ -704,10 +709,16 @@ extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_
   else nb = pat_grid(span, pat_ntiles(nrows, line));
   double* part = gcge_hip_partial_ws((size_t)nb * 16 * npass * 2);
   const long yyo = (long)nb * 16 * npass;
+  // read-only passes on a [-S, 0, +S, -L, +L, -1, +1] table: the LDS-ring sweep (spmm_ring.hip), same geometry and workspace
+  bool ring = near && lt == 7 && nw >= 4 && (mode == 2 || mode == 4);
   for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
     const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
     double* pp = part + (size_t)ps * nb * 16;
     long rc;
+    if (ring) {
+      if (gcge_hip_ring_pass(mode, nrows, d_pid, d_tab, npat, L, nw, nb, d_x + c0, ldx, m, pp, yyo, mode == 4 ? d_alpha + c0 : nullptr, st) == 0) continue;
+      ring = false;   // declined (first pass): the chain2 kernel below
+    }
     if (mode == 2) rc = pat_dispatch<2>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw);
     else if (mode == 4) {
       const CgArgs cg = {nullptr, 0, nullptr, 0, d_alpha + c0, nullptr, nullptr, nullptr, 0};
@@ -724,4 +735,11 @@ extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_
   gcge_hip_reduce_partials16(part, (int)nb, nb * 16, ncols, d_dots, st);
   if (mode == 2 && d_dots_yy) gcge_hip_reduce_partials16(part + yyo, (int)nb, nb * 16, ncols, d_dots_yy, st);
   return (int)hipGetLastError();
+}
+extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+                                   long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
+                                   long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
+                                   double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb) {
+  return gcge_hip_pattern_cg_near(mode, nrows, d_pid, d_tab, npat, lt, span, span2, d_x, ldx, d_r, ldr, d_pnew, ldp, ncols, d_alpha,
+                                  d_beta, d_flag, d_dots, d_dots_yy, stream, d_b, ldb, 0);
 }

@@ -767,3 +767,50 @@ def test_fused_cg_small_direction_ring(hip):
     assert np.max(np.abs(out["3"][0] - out["16"][0])) <= 1e-11 * scale
     assert np.max(np.abs(out["1"][0] - out["16"][0])) <= 1e-9 * scale      # (no ring: the stored-w form, other rounding)
     hip.free_matrix(mat)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,m,depth", [(16, 16, 3), (16, 22, 2), (24, 64, 3), (32, 16, 3), (40, 6, 3), (48, 34, 2), (64, 64, 3)])
+def test_ring_sweep_equals_chain_kernel_and_numpy(hip, size, m, depth):
+    """Read-only CG passes through the LDS ring (spmm_ring.hip: X rows several planes ahead by LDS-DMA) against the
+    chain + line-exchange kernel and numpy: first pass (mode 2) and residual norms (mode 4); block geometries of
+    16, 8 and 4 waves, ragged column counts, both ring depths."""
+    from helpers import csr_to_scipy, uniform
+    A, _ = make_problem("lap3d", size)
+    S = csr_to_scipy(A)
+    n = A.nrows
+    mat = hip.matrix(A)
+    g = hip.g
+    g.gcge_hip_cg_pass1_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    g.gcge_hip_spmm_ring_launches.restype = C.c_long
+    g.gcge_hip_spmm_ring_tune.argtypes = [C.c_int, C.c_int]
+    FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+    g.gcge_hip_residual_hook.restype = C.c_void_p
+    hook = FN(g.gcge_hip_residual_hook())
+    ncol = m + 4
+    P = uniform(31, (n, ncol)) - 0.5
+    p = hip.mv_from_numpy(mat, P)
+    W = S @ P[:, 2:2 + m]
+    lam = uniform(32, (m,)) * 3.0
+    Rz = W - P[:, 2:2 + m] * lam
+    out = {}
+    try:
+        for on in (1, 0):
+            g.gcge_hip_spmm_ring_tune(on, depth)
+            n0 = g.gcge_hip_spmm_ring_launches()
+            pw, ww, rs = np.zeros(m), np.zeros(m), np.zeros(m)
+            assert g.gcge_hip_cg_pass1_mv(mat, p, 2, m, pw.ctypes.data, ww.ctypes.data) == 0
+            assert hook(mat, None, p, 2, 2 + m, lam.ctypes.data, rs.ctypes.data) == 1
+            took = g.gcge_hip_spmm_ring_launches() - n0
+            assert took == (2 * ((m + 15) // 16) if on else 0), took
+            np.testing.assert_allclose(pw, np.sum(P[:, 2:2 + m] * W, axis=0), rtol=1e-12, atol=1e-12 * n)
+            np.testing.assert_allclose(ww, np.sum(W * W, axis=0), rtol=1e-12)
+            np.testing.assert_allclose(rs, np.sum(Rz * Rz, axis=0), rtol=1e-12)
+            out[on] = (pw, ww, rs)
+        for a, b in zip(out[1], out[0]):
+            np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-13 * n)
+        assert np.array_equal(hip.mv_to_numpy(p, n, 0, ncol), P)
+    finally:
+        g.gcge_hip_spmm_ring_tune(1, 3)
+    hip.ops.mv_destroy(p, ncol)
+    hip.free_matrix(mat)
