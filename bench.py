@@ -314,6 +314,8 @@ def main():
         chain = g.gcge_hip_mat_pattern_chain(mat)
         kbase = ("spmm_pattern", "spmm_pattern_chain", "spmm_pattern_chain2")[chain] if npat > 0 else "spmm_pad8"
         npass = (args.block + 15) // 16 if npat > 0 else 1
+        g.gcge_hip_spmm_ring_launches.restype = C.c_long
+        ring_launches = g.gcge_hip_spmm_ring_launches()
 
         def roof(kind, what, streams):
             # `achieved` prices a launch at its ALGORITHMIC bytes: kind 0: SURVEY.md 8(d), 12 B per
@@ -327,6 +329,8 @@ def main():
                 return None
             ach = (by_ / c_) / (ms_ / c_ * 1e-3) / 1e9
             kname = "%s<7,%d,16>" % (kbase, kind)
+            if kind == 2 and ring_launches > 0:   # the read-only pass ran the LDS-ring sweep (spmm_ring.hip), 3 planes ahead
+                kname = "spmm_ring<2,16,3>"
             traffic, note = pmc_traffic(kname, N, args.block) if (npat > 0 and world == 1) else (None, "no PMC profile for this shape")
             req = (8.0 * streams * args.block + 2.0 * npass) * A.nrows if npat > 0 else by_ / c_
             return {"bound": "hbm", "kernel": "%s x %d passes of 16 columns: %s (%d row patterns, m=%d)"

@@ -41,7 +41,7 @@ int gcge_hip_rowmajor_to_colmajor(int nrows, int m, const double* d_src, long ld
 extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                    long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
                                    long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
-                                   double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, int near);
+                                   double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, long near);
 
 
 __global__ __launch_bounds__(256) void halo_pack(int nsend, const int* __restrict__ rows, const double* __restrict__ x,
@@ -311,7 +311,9 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const in
     if (!ok) break;
     tab.swap(ctab); pid.swap(cpid);
     A->npat = (int)(tab.size() / lt); A->pat_span2 = Lline ? -Lline : -1;
-    A->pat_near = Lline && lt == 7 && nslot_used == 7 && slot[5] == -1 && slot[6] == 1;
+    A->pat_near = 0;
+    if (Lline && lt == 7 && nslot_used == 7 && slot[5] == -1 && slot[6] == 1)
+      for (const PatEntryH& e : tab) A->pat_near = std::max(A->pat_near, e.off < 0 ? -e.off : e.off);
   } while (0);
   GCGE_HIP_CHECK(hipMalloc(&A->d_pid, (size_t)nrows * sizeof(unsigned short)));
   GCGE_HIP_CHECK(hipMalloc(&A->d_tab, tab.size() * sizeof(PatEntryH)));

@@ -38,7 +38,7 @@ extern "C" void gcge_hip_reduce_partials_slabs(const double* d_partial, int nblo
                                                double* d_out, void* stream);
 extern "C" int gcge_hip_ring_pass(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, long L, int nw,
                                   long nb, const double* d_x, long ldx, int m, double* part, long yyo,
-                                  const double* d_lambda, void* stream);
+                                  const double* d_lambda, void* stream, long maxoff);
 
 namespace gcge {
 
@@ -685,12 +685,12 @@ extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, con
 //   mode 5: R = B - A X; PNEW = R; d_dots[j] = sum_r R[r,j]^2  (start of the CG; d_b / ldb: the right-hand sides)
 // Geometry as gcge_hip_pattern_spmm; a chain-layout table without line exchange runs through the plain kernel
 // (its table is a valid generic one).  -1: not applicable (alignment), the caller keeps the unfused recurrence.
-// near: the table's slots are [-S, 0, +S, -L, +L, -1, +1] (7-point stencil; GCGE_HIP_MAT_::pat_near): modes 2 and 4 may
-// take the LDS-ring sweep of spmm_ring.hip.
+// near > 0: the table's slots are [-S, 0, +S, -L, +L, -1, +1] (7-point stencil) and near is the largest |offset| in it
+// (GCGE_HIP_MAT_::pat_near): modes 2 and 4 may take the LDS-ring sweep of spmm_ring.hip.
 extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                         long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
                                         long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
-                                        double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, int near) {
+                                        double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, long near) {
   if (mode != 2 && mode != 3 && mode != 4 && mode != 5) return -1;
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || ((uintptr_t)d_x & 15) || d_dots == nullptr) return -1;
@@ -716,7 +716,7 @@ extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned shor
     double* pp = part + (size_t)ps * nb * 16;
     long rc;
     if (ring) {
-      if (gcge_hip_ring_pass(mode, nrows, d_pid, d_tab, npat, L, nw, nb, d_x + c0, ldx, m, pp, yyo, mode == 4 ? d_alpha + c0 : nullptr, st) == 0) continue;
+      if (gcge_hip_ring_pass(mode, nrows, d_pid, d_tab, npat, L, nw, nb, d_x + c0, ldx, m, pp, yyo, mode == 4 ? d_alpha + c0 : nullptr, st, near) == 0) continue;
       ring = false;   // declined (first pass): the chain2 kernel below
     }
     if (mode == 2) rc = pat_dispatch<2>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw);

@@ -48,11 +48,40 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-// The pieces of one batch in ONE statement (M0 saved once, the partial pieces under an exec mask set here):
+// The pieces of one batch in ONE statement (M0 saved once, the partial pieces under an exec mask set here), addressed as
+// scalar base + 32-bit lane offset: sb = X + (first row of the slice) - 2 GiB, sq = the slice's ids; the lane offsets
+// (2 GiB + row / column / stencil offset) change only when the lane's pattern does, so a batch costs no vector ALU work:
 //   rows (64 lanes x 16 B) -> lm;  ROLE != 1: the -L / +L row -> le;  lanes 0-15: the two fringe rows -> lf;
 //   lanes 0-3: the 8 ids of a later slice (4 B each) -> lq
 template <int ROLE>
-__device__ __forceinline__ void batch_pieces(const void* am, const void* ae, const void* af, const void* aq,
+__device__ __forceinline__ void batch_pieces(const char* sb, const char* sq, unsigned vm, unsigned ve, unsigned vf, unsigned vq,
+                                             unsigned lm, unsigned le, unsigned lf, unsigned lq) {
+  unsigned keep; unsigned long sv;
+  if (ROLE == 1)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[lm]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vm], %[sb]\n\t"
+                 "s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[lf]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vf], %[sb]\n\t"
+                 "s_mov_b64 exec, 0xf\n\ts_mov_b32 m0, %[lq]\n\ts_nop 0\n\tglobal_load_lds_dword %[vq], %[sq]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep), [sv] "=&s"(sv)
+                 : [sb] "s"(sb), [sq] "s"(sq), [vm] "v"(vm), [vf] "v"(vf), [vq] "v"(vq), [lm] "s"(lm), [lf] "s"(lf), [lq] "s"(lq)
+                 : "memory");
+  else
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[lm]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vm], %[sb]\n\t"
+                 "s_mov_b32 m0, %[le]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[ve], %[sb]\n\t"
+                 "s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, 0xffff\n\ts_mov_b32 m0, %[lf]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vf], %[sb]\n\t"
+                 "s_mov_b64 exec, 0xf\n\ts_mov_b32 m0, %[lq]\n\ts_nop 0\n\tglobal_load_lds_dword %[vq], %[sq]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep), [sv] "=&s"(sv)
+                 : [sb] "s"(sb), [sq] "s"(sq), [vm] "v"(vm), [ve] "v"(ve), [vf] "v"(vf), [vq] "v"(vq), [lm] "s"(lm), [le] "s"(le),
+                   [lf] "s"(lf), [lq] "s"(lq)
+                 : "memory");
+}
+
+// The same with 64-bit lane addresses (tables whose byte offsets do not fit the 32-bit lane offset: WIDE):
+//   rows (64 lanes x 16 B) -> lm;  ROLE != 1: the -L / +L row -> le;  lanes 0-15: the two fringe rows -> lf;
+//   lanes 0-3: the 8 ids of a later slice (4 B each) -> lq
+template <int ROLE>
+__device__ __forceinline__ void batch_pieces64(const void* am, const void* ae, const void* af, const void* aq,
                                              unsigned lm, unsigned le, unsigned lf, unsigned lq) {
   unsigned keep; unsigned long sv;
   if (ROLE == 1)
@@ -84,17 +113,17 @@ constexpr int RI = 16;
 // MODE 2 / 4 as in spmm_pattern.hip.  ROLE: 0 lowest wave, 1 inner, 2 highest (they differ in the pieces per plane).
 // Geometry (host-checked): tile t of the block = tile b0 + t G of the sweep, and consecutive tiles of a block lie
 // `step_rows` rows apart (one grid plane; 0 when every block has a single tile).
-template <int MODE, int NW, int DP, int ROLE>
+template <int MODE, int NW, int DP, int ROLE, bool WIDE>
 __device__ __forceinline__ void ring_body(
-    long nrows, const unsigned short* __restrict__ pid, const RPat* s_pat, char* ring, const double* __restrict__ xl,
-    size_t ldx, bool act, int i, int g, int wave, int lane, int ntiles, long line, long step_rows,
+    long nrows, const unsigned short* __restrict__ pid, const RPat* s_pat, char* ring, const double* __restrict__ xblk,
+    const double* __restrict__ xl, size_t ldx, bool act, int i, int g, int wave, int lane, int ntiles, long line, long step_rows, int b0,
     double& d0, double& d1, double& e0, double& e1, const v2d* s_cf) {
   constexpr int R = DP + 3;                                  // planes in the ring
   constexpr unsigned PB = Plane<NW>::PB;
   constexpr int K = (ROLE == 1) ? 3 : 4;                     // LDS-DMA pieces per batch
   static_assert(2 * DP + 5 <= RI, "id ring");
   const unsigned ring0 = (unsigned)(uintptr_t)ring;          // LDS byte address (low half of the flat address)
-  const int G = gridDim.x, b0 = blockIdx.x;
+  const int G = gridDim.x;
   const int cnt = __builtin_amdgcn_readfirstlane((ntiles - b0 + G - 1) / G);
   const long ldxb = (long)ldx * 8;
   // rows of this wave: slice at rb0 + k * step_rows, k = 0 .. cnt - 1; the slices beyond the matrix (k > kv) and the
@@ -137,12 +166,28 @@ __device__ __forceinline__ void ring_body(
     glds16(xg + rowsB + e->offb[1], ring0 + (1 + wave) * 1024);
   }
   unsigned si = 0, ei = 0;   // plane slot / id entry of the batch being issued (byte offsets)
+  // The byte offsets a batch needs (slot 2 of the row's pattern, slot 3 / 4 for the outer waves, slot 5 / 6 of the slice's
+  // first / last row for the fringe lanes) stay in registers and are looked up again only by the lanes whose pattern
+  // changed: along a sweep (one (x, y) position, plane after plane) a lane's pattern changes at the first and last plane
+  // only, so the look-ups (LDS bandwidth is what bounds this kernel) all but disappear.
+  int pb_c = -1, pbf_c = -1;
+  unsigned vo_s = 0, vo_e = 0, vo_f = 0;                      // lane offsets of the row, edge and fringe pieces (see batch_pieces)
+  long ob_s = 0, ob_e = 0, ob_f = 0;                          // WIDE: the byte offsets themselves
+  const long lane0 = (1L << 31) + (xl - xblk) * 8;            // 2 GiB bias + this lane's column pair
+  const unsigned vo_g = (unsigned)(lane0 + g * ldxb), vo_x = (unsigned)(lane0 + (lane < 8 ? 0 : 7) * ldxb), vo_q = 4 * (lane & 3);
+  const char* xb = reinterpret_cast<const char*>(xblk) - (1L << 31);
   auto batch = [&](int pb, int pbf) {
-    const RPat* e = s_pat + pb;
+    if (pb != pb_c) {
+      const RPat* e = s_pat + pb;
+      ob_s = e->offb[2]; if (ROLE != 1) ob_e = e->offb[ROLE == 0 ? 3 : 4];
+      vo_s = vo_g + (unsigned)ob_s; vo_e = vo_g + (unsigned)ob_e;
+      pb_c = pb;
+    }
+    if (pbf != pbf_c) { ob_f = s_pat[pbf].offb[fslot]; vo_f = vo_x + (unsigned)ob_f; pbf_c = pbf; }
     const unsigned si1 = si + PB == R * PB ? 0 : si + PB;
-    batch_pieces<ROLE>(xg + rowsB + e->offb[2], xg + rowsB + e->offb[ROLE == 0 ? 3 : 4], xf + rowsB + s_pat[pbf].offb[fslot],
-                       pidl + idsB, ring0 + si1 + (1 + wave) * 1024, ring0 + si + (ROLE == 0 ? 0 : (NW + 1) * 1024),
-                       ring0 + si + o_fr, ring0 + idr + sq);
+    const unsigned lm = ring0 + si1 + (1 + wave) * 1024, le = ring0 + si + (ROLE == 0 ? 0 : (NW + 1) * 1024);
+    if (WIDE) batch_pieces64<ROLE>(xg + rowsB + ob_s, xg + rowsB + ob_e, xf + rowsB + ob_f, pidl + idsB, lm, le, ring0 + si + o_fr, ring0 + idr + sq);
+    else batch_pieces<ROLE>(xb + rowsB, reinterpret_cast<const char*>(pid) + idsB, vo_s, vo_e, vo_f, vo_q, lm, le, ring0 + si + o_fr, ring0 + idr + sq);
     si = si1; ei = (ei + 16) & (RI * 16 - 1); sq = (sq + 16) & (RI * 16 - 1);
     if (ki < kmax) { rowsB += stepB; } ++ki;
     if (kq < kmax) { idsB += stepI; } ++kq;
@@ -161,19 +206,25 @@ __device__ __forceinline__ void ring_body(
   unsigned sf = 0, ef = 0;               // plane slot / id entry of the iteration being reduced (byte offsets)
   int pfin = id_at(o_idg), pb = id_at(o_idg + ei), pbf = id_at(o_idf + ei);   // patterns: rows reduced now / requested now
   const double wact = act ? 1.0 : 0.0;
+  int pfin_c = -1;            // the pattern whose values sit in val[] (same caching as in batch)
+  double val[LT];
+#pragma unroll
+  for (int t = 0; t < LT; ++t) val[t] = 0.0;
   for (int j = 0; j < cnt; ++j) {
     // ---- everything iteration j reads from LDS, up front: the rows, the table entries, the ids of the NEXT iteration
     const unsigned sf1 = sf + PB == R * PB ? 0 : sf + PB;
     const char* pj = ring + sf;
-    const RPat* e = s_pat + pfin;
     const v2d c  = *reinterpret_cast<const v2d*>(ring + sf1 + o_own);
     const v2d vm = *reinterpret_cast<const v2d*>(pj + o_lo);
     const v2d vp = *reinterpret_cast<const v2d*>(pj + o_hi);
     const v2d m1 = *reinterpret_cast<const v2d*>(pj + o_m1);
     const v2d p1 = *reinterpret_cast<const v2d*>(pj + o_p1);
-    double val[LT];
+    if (pfin != pfin_c) {
+      const RPat* e = s_pat + pfin;
 #pragma unroll
-    for (int t = 0; t < LT; ++t) val[t] = e->val[t];
+      for (int t = 0; t < LT; ++t) val[t] = e->val[t];
+      pfin_c = pfin;
+    }
     ef = (ef + 16) & (RI * 16 - 1);
     const int pfin_n = id_at(o_idg + ef);
     double a0 = val[0] * a.x, a1 = val[0] * a.y;
@@ -204,10 +255,10 @@ __device__ __forceinline__ void ring_body(
   vm_wait<0>();               // no LDS-DMA may land after the block has released its LDS
 }
 
-template <int MODE, int NW, int DP>
+template <int MODE, int NW, int DP, bool WIDE>
 __global__ __launch_bounds__(64 * NW) void spmm_ring_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
-    const double* __restrict__ x, size_t ldx, int m, int ntiles, long line, long step_rows,
+    const double* __restrict__ x, size_t ldx, int m, int ntiles, long line, long step_rows, int xcd_runs,
     double* __restrict__ dot_partial, long yy_offset, const double* __restrict__ lambda) {
   static_assert(MODE == 2 || MODE == 4, "read-only passes");
   constexpr int R = DP + 3;
@@ -229,10 +280,14 @@ __global__ __launch_bounds__(64 * NW) void spmm_ring_kernel(
   const bool act = 2 * i < m;
   const double* __restrict__ xl = x + (act ? 2 * i : 0);
   double d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;
-  if ((int)blockIdx.x < ntiles) {   // block-uniform
-    if (wave == 0) ring_body<MODE, NW, DP, 0>(nrows, pid, s_pat, ring, xl, ldx, act, i, g, wave, lane, ntiles, line, step_rows, d0, d1, e0, e1, s_cf);
-    else if (wave == NW - 1) ring_body<MODE, NW, DP, 2>(nrows, pid, s_pat, ring, xl, ldx, act, i, g, wave, lane, ntiles, line, step_rows, d0, d1, e0, e1, s_cf);
-    else ring_body<MODE, NW, DP, 1>(nrows, pid, s_pat, ring, xl, ldx, act, i, g, wave, lane, ntiles, line, step_rows, d0, d1, e0, e1, s_cf);
+  // Blocks are dealt round-robin to the 8 XCDs.  xcd_runs: XCD k takes the k-th eighth of the sweep's tiles, so the
+  // slices that share fringe rows (neighbours along a grid line) and the line groups that share +-L rows meet in ONE L2
+  const int G = gridDim.x;
+  const int b0 = (xcd_runs && G % 8 == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (b0 < ntiles) {   // block-uniform
+    if (wave == 0) ring_body<MODE, NW, DP, 0, WIDE>(nrows, pid, s_pat, ring, x, xl, ldx, act, i, g, wave, lane, ntiles, line, step_rows, b0, d0, d1, e0, e1, s_cf);
+    else if (wave == NW - 1) ring_body<MODE, NW, DP, 2, WIDE>(nrows, pid, s_pat, ring, x, xl, ldx, act, i, g, wave, lane, ntiles, line, step_rows, b0, d0, d1, e0, e1, s_cf);
+    else ring_body<MODE, NW, DP, 1, WIDE>(nrows, pid, s_pat, ring, x, xl, ldx, act, i, g, wave, lane, ntiles, line, step_rows, b0, d0, d1, e0, e1, s_cf);
   }
   auto sx = [](double v, int mask) {
     int lo = __shfl_xor(__double2loint(v), mask, 64), hi = __shfl_xor(__double2hiint(v), mask, 64);
@@ -261,9 +316,13 @@ using namespace gcge_ring;
 
 static int g_ring_on = 1;      // 0: keep spmm_pattern_chain2_kernel for the read-only passes (tuning / A-B measurements)
 static int g_ring_depth = 3;   // planes requested ahead (2 or 3)
+static int g_ring_wide = 0;    // 1: always 64-bit lane addresses (tests)
+extern "C" void gcge_hip_spmm_ring_wide(int on) { g_ring_wide = on; }
+static int g_ring_xcd = 0;     // 1: contiguous tile runs per XCD
+extern "C" void gcge_hip_spmm_ring_xcd(int on) { g_ring_xcd = on; }
 extern "C" void gcge_hip_spmm_ring_tune(int on, int depth) { g_ring_on = on; if (depth == 2 || depth == 3) g_ring_depth = depth; }
 
-template <int MODE, int NW, int DP>
+template <int MODE, int NW, int DP, bool WIDE>
 static int ring_launch(long nb, hipStream_t st, long nrows, const unsigned short* pid, const void* tab, int ntab, const double* x,
                        size_t ldx, int m, long ntl, long line, double* part, long yyo, const double* lambda) {
   constexpr unsigned PB = Plane<NW>::PB;
@@ -276,12 +335,12 @@ static int ring_launch(long nb, hipStream_t st, long nrows, const unsigned short
   if (lds > 160 * 1024) return -1;
   static size_t granted = 0;   // per instantiation
   if (lds > granted) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_ring_kernel<MODE, NW, DP>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_ring_kernel<MODE, NW, DP, WIDE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return -1; }
     granted = lds;
   }
-  hipLaunchKernelGGL((spmm_ring_kernel<MODE, NW, DP>), dim3((unsigned)nb), dim3(64 * NW), lds, st, nrows, pid,
-                     (const PatEntry*)tab, ntab, x, ldx, m, (int)ntl, line, step_rows, part, yyo, lambda);
+  hipLaunchKernelGGL((spmm_ring_kernel<MODE, NW, DP, WIDE>), dim3((unsigned)nb), dim3(64 * NW), lds, st, nrows, pid,
+                     (const PatEntry*)tab, ntab, x, ldx, m, (int)ntl, line, step_rows, g_ring_xcd, part, yyo, lambda);
   return 0;
 }
 
@@ -290,31 +349,37 @@ static int ring_launch(long nb, hipStream_t st, long nrows, const unsigned short
 static long g_ring_launches = 0;
 extern "C" long gcge_hip_spmm_ring_launches(void) { return g_ring_launches; }
 
-template <int NW>
+template <int NW, bool WIDE>
 static int ring_pass_nw(int mode, long nb, hipStream_t st, long nrows, const unsigned short* pid, const void* tab, int ntab,
                         const double* x, size_t ldx, int m, long ntl, long L, double* part, long yyo, const double* lambda) {
   int rc = -1;
   if (g_ring_depth == 3)
-    rc = mode == 2 ? ring_launch<2, NW, 3>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, nullptr)
-                   : ring_launch<4, NW, 3>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda);
+    rc = mode == 2 ? ring_launch<2, NW, 3, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, nullptr)
+                   : ring_launch<4, NW, 3, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda);
   if (rc != 0)
-    rc = mode == 2 ? ring_launch<2, NW, 2>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, nullptr)
-                   : ring_launch<4, NW, 2>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda);
+    rc = mode == 2 ? ring_launch<2, NW, 2, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, nullptr)
+                   : ring_launch<4, NW, 2, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda);
   return rc;
 }
 
+// maxoff: the largest |column offset| (rows) in the table: decides between 32-bit lane offsets and 64-bit addresses
 extern "C" int gcge_hip_ring_pass(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, long L, int nw,
                                   long nb, const double* d_x, long ldx, int m, double* part, long yyo,
-                                  const double* d_lambda, void* stream) {
+                                  const double* d_lambda, void* stream, long maxoff) {
   if (!g_ring_on || (mode != 2 && mode != 4) || (nrows & 7) || nrows < 8 || ((uintptr_t)d_pid & 15) || L % 8 || L < 8) return -1;
   if (((uintptr_t)d_x & 15) || (ldx & 1)) return -1;
   const long nlines = ((long)nrows + L - 1) / L, ntl = (nlines + nw - 1) / nw * (L / 8);
   hipStream_t st = (hipStream_t)stream;
   const int ntab = npat * LT;
   int rc = -1;
-  if (nw == 16) rc = ring_pass_nw<16>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda);
-  else if (nw == 8) rc = ring_pass_nw<8>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda);
-  else if (nw == 4) rc = ring_pass_nw<4>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda);
+  // lane offset = 2 GiB + (row in slice, column pair) + stencil offset, as an unsigned 32-bit number
+  const bool wide = g_ring_wide || (double)(maxoff + 16) * (double)ldx * 8.0 >= 2147483648.0 - 4096.0;
+#define GCGE_RING_NW(N) (wide ? ring_pass_nw<N, true>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda) \
+                              : ring_pass_nw<N, false>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda))
+  if (nw == 16) rc = GCGE_RING_NW(16);
+  else if (nw == 8) rc = GCGE_RING_NW(8);
+  else if (nw == 4) rc = GCGE_RING_NW(4);
+#undef GCGE_RING_NW
   if (rc == 0) ++g_ring_launches;
   return rc;
 }

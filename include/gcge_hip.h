@@ -168,14 +168,17 @@ int gcge_hip_pattern_cg (int mode, int nrows, const unsigned short *d_pid, const
 		const double *d_b, long ldb);
 /*     mode 4: d_dots[j] = sum_r ((A x)[r,j] - alpha_j x[r,j])^2 (residual norms of Ritz pairs);  mode 5: r = b - A x,
  *     pnew = r, d_dots[j] = sum_r r[r,j]^2 (start of the CG; d_b / ldb only used here)                              */
-/*     near = 1: the caller knows the table's slots are [-S, 0, +S, -L, +L, -1, +1] (7-point stencil); the passes that
+/*     near > 0: the caller knows the table's slots are [-S, 0, +S, -L, +L, -1, +1] (7-point stencil) and passes the
+ *     largest |offset| in the table; the passes that
  *     store nothing (modes 2, 4) then run the LDS-ring sweep of csrc/hip/spmm_ring.hip (X rows several grid planes
  *     ahead by LDS-DMA); gcge_hip_spmm_ring_tune(on, planes_ahead) switches it off / picks 2 or 3 planes            */
 int gcge_hip_pattern_cg_near (int mode, int nrows, const unsigned short *d_pid, const void *d_tab, int npat, int lt,
 		long span, long span2, const double *d_x, long ldx, double *d_r, long ldr, double *d_pnew, long ldp, int ncols,
 		const double *d_alpha, const double *d_beta, const int *d_flag, double *d_dots, double *d_dots_yy, void *stream,
-		const double *d_b, long ldb, int near);
+		const double *d_b, long ldb, long near);
 void gcge_hip_spmm_ring_tune (int on, int planes_ahead);
+void gcge_hip_spmm_ring_wide (int on);      /* 1: 64-bit lane addresses even where 32-bit lane offsets would do (tests) */
+void gcge_hip_spmm_ring_xcd (int on);       /* 1: contiguous tile runs per XCD (fabric reads 12.0 -> 9.9 GB per 64 columns at 256^3, same time) */
 long gcge_hip_spmm_ring_launches (void);   /* 16-column launches the ring sweep has taken so far */
 /*     the same on operator-table objects (halo rows of p fetched by pass 1 and reused by pass 2; sums are the LOCAL
  *     parts, on the host); gcge_hip_cg_fusable: 1 if (mat, p, ncols) qualify                                        */

@@ -770,11 +770,13 @@ def test_fused_cg_small_direction_ring(hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size,m,depth", [(16, 16, 3), (16, 22, 2), (24, 64, 3), (32, 16, 3), (40, 6, 3), (48, 34, 2), (64, 64, 3)])
-def test_ring_sweep_equals_chain_kernel_and_numpy(hip, size, m, depth):
+@pytest.mark.parametrize("size,m,depth,wide", [(16, 16, 3, 0), (16, 22, 2, 1), (24, 64, 3, 0), (32, 16, 3, 1), (40, 6, 3, 0),
+                                               (48, 34, 2, 0), (64, 64, 3, 0), (64, 64, 3, 1)])
+def test_ring_sweep_equals_chain_kernel_and_numpy(hip, size, m, depth, wide):
     """Read-only CG passes through the LDS ring (spmm_ring.hip: X rows several planes ahead by LDS-DMA) against the
     chain + line-exchange kernel and numpy: first pass (mode 2) and residual norms (mode 4); block geometries of
-    16, 8 and 4 waves, ragged column counts, both ring depths."""
+    16, 8 and 4 waves, ragged column counts, both ring depths, both addressing forms (scalar base + 32-bit lane offset,
+    64-bit lane addresses for tables whose offsets exceed 2 GiB)."""
     from helpers import csr_to_scipy, uniform
     A, _ = make_problem("lap3d", size)
     S = csr_to_scipy(A)
@@ -795,6 +797,7 @@ def test_ring_sweep_equals_chain_kernel_and_numpy(hip, size, m, depth):
     Rz = W - P[:, 2:2 + m] * lam
     out = {}
     try:
+        g.gcge_hip_spmm_ring_wide(wide)
         for on in (1, 0):
             g.gcge_hip_spmm_ring_tune(on, depth)
             n0 = g.gcge_hip_spmm_ring_launches()
@@ -812,5 +815,6 @@ def test_ring_sweep_equals_chain_kernel_and_numpy(hip, size, m, depth):
         assert np.array_equal(hip.mv_to_numpy(p, n, 0, ncol), P)
     finally:
         g.gcge_hip_spmm_ring_tune(1, 3)
+        g.gcge_hip_spmm_ring_wide(0)
     hip.ops.mv_destroy(p, ncol)
     hip.free_matrix(mat)
