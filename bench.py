@@ -330,7 +330,7 @@ def main():
             ach = (by_ / c_) / (ms_ / c_ * 1e-3) / 1e9
             kname = "%s<7,%d,16>" % (kbase, kind)
             if kind == 2 and ring_launches > 0:   # the read-only pass ran the LDS-ring sweep (spmm_ring.hip), 3 planes ahead
-                kname = "spmm_ring<2,16,3>"
+                kname = "spmm_ring<2,16,3,false>"
             traffic, note = pmc_traffic(kname, N, args.block) if (npat > 0 and world == 1) else (None, "no PMC profile for this shape")
             req = (8.0 * streams * args.block + 2.0 * npass) * A.nrows if npat > 0 else by_ / c_
             return {"bound": "hbm", "kernel": "%s x %d passes of 16 columns: %s (%d row patterns, m=%d)"

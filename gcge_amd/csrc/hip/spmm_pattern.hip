@@ -334,7 +334,11 @@ __device__ __forceinline__ void chain2_body(
   // the rows at their common edge, so one could give each XCD a CONTIGUOUS run of the G tiles of a sweep (block b
   // takes tile (b % 8) * G/8 + b / 8).  Measured: slower (3.43 vs 3.19 ms at 256^3), same at 240^3.
   const long G = gridDim.x, asl = line / 8;
-  const long b0 = (G % 8 == 0 && xcd_runs) ? ((long)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3)) : (long)blockIdx.x;
+  // xcd_runs == 2: runs of 4 consecutive tiles (neighbours along a grid line) per XCD, the runs dealt round-robin:
+  // tile = 32 (b / 32) + 4 (b % 8) + (b / 8) % 4; tiles 32 apart (the +-L neighbours at 256-row lines) stay on one XCD
+  const long bx = blockIdx.x;
+  const long b0 = (xcd_runs == 2 && G % 32 == 0) ? ((bx & ~31L) | ((bx & 7) << 2) | ((bx >> 3) & 3))
+                : (G % 8 == 0 && xcd_runs == 1) ? ((bx & 7) * (G >> 3) + (bx >> 3)) : bx;
   const long cnt = (ntiles - b0 + G - 1) / G;
   auto row_at = [&](long it) {
     const long t = b0 + it * G, q = t / asl, a = t - q * asl;
@@ -467,7 +471,9 @@ __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
   const double* __restrict__ xl = x + (act ? 2 * i : 0);
   double d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;
   const long gq = gridDim.x;
-  const long bperm = (gq % 8 == 0 && xcd_runs) ? ((long)(blockIdx.x & 7) * (gq >> 3) + (blockIdx.x >> 3)) : (long)blockIdx.x;
+  const long bq = blockIdx.x;
+  const long bperm = (xcd_runs == 2 && gq % 32 == 0) ? ((bq & ~31L) | ((bq & 7) << 2) | ((bq >> 3) & 3))
+                   : (gq % 8 == 0 && xcd_runs == 1) ? ((bq & 7) * (gq >> 3) + (bq >> 3)) : bq;
   if (bperm < ntiles) {   // block-uniform: every wave of the block runs the same number of barriers
     if (wave == 0) chain2_body<LT, MODE, NW, 0>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
     else if (wave == NW - 1) chain2_body<LT, MODE, NW, 2>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
@@ -523,7 +529,8 @@ static long pat_ntiles(long nrows, long line) {
 // chain + line exchange: most waves per block to try (16, 8, 4; measured 3.20 / 3.37 / 3.67 ms at 256^3 x 64);
 // 0: use the plain chain kernel
 static int g_chain2_nw = 16;
-static int g_chain2_xcd = 0;   // 1: contiguous tile runs per XCD (see chain2_body); measured slower: 3.43 vs 3.19 ms at 256^3
+static int g_chain2_xcd = 2;   // 2: runs of 4 neighbouring tiles per XCD (pass 2 6.50 -> 6.42 ms, fabric reads down); 1: one contiguous eighth of
+                               // the tiles per XCD (slower: 3.43 vs 3.19 ms at 256^3); 0: tiles in block order
 extern "C" void gcge_hip_spmm_chain2_xcd(int on) { g_chain2_xcd = on; }
 extern "C" void gcge_hip_spmm_chain2_tune(int waves) { if (waves == 0 || waves == 4 || waves == 8 || waves == 16) g_chain2_nw = waves; }
 static int g_chain_lpr = 8;    // chain variant: lanes per row = half the columns per pass (8, 16, 32)
