@@ -1009,6 +1009,9 @@ extern "C" void OPS_HIP_Set(struct OPS_* ops) {
   ops->MultiVecLinearComb       = HIP_MultiVecLinearComb;
   ops->MatDotMultiVec           = HIP_MatDotMultiVec;
   GCGE_SetResidualHook(HIP_ResidualSq, (void*)HIP_MatDotMultiVec);   /* used by our GCG driver for this table only */
+  // panel updates work row by row on the row-major blocks (lincomb_mfma.hip: a block / wave reads only the rows it
+  // writes, and writes them after its last read): one panel of <= 128 output columns may be updated in place
+  GCGE_SetInplaceLinearComb((void*)HIP_MultiVecLinearComb, 128);
   {   // K7 on the device for the projected matrices where the host solver dominates an outer iteration (eig_device.hip)
     const char* mn = getenv("GCGE_EIG_DEVICE_MIN_N");
     GCGE_SetSymEigHook(gcge_hip_symeig, mn ? atoi(mn) : 192);

@@ -22,8 +22,10 @@
 // (k rounded to 32) x (16 NT) workspace, so a clamped X column meets a zero coefficient row and a
 // clamped X row only feeds output rows that are never stored.
 //
-// In-place use (x == y with disjoint column ranges, ops_orth.c:70,90,253) is safe:
-// a block reads and writes only its own 64 rows and never the same columns.
+// In-place use is safe, with disjoint column ranges (ops_orth.c:70,90,253) and with the output columns INSIDE the
+// input range (X = X R^-1, P = V[:, N..W) coef; declared to the solver stack by GCGE_SetInplaceLinearComb): a block /
+// wave reads only the rows it writes (rows past the end are clamped to the last row, but feed output rows that are
+// never stored) and stores them after its last read of them; x is therefore NOT __restrict__.
 // Roofline: 2 n k m flops (FP64 MFMA) vs 8 n (k + m [+ m]) bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256, (RF == 2 && NT <= 4) ? 2 : 1) void lincomb_ker
 typedef double v2d_lc __attribute__((ext_vector_type(2)));
 
 template <int NT, int RF, int MINB, int KTD, bool ASM = true>
-__global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, const double* __restrict__ x, long ldx, int k,
+__global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, const double* x, long ldx, int k,
     const double* __restrict__ cpad, int m, const double* __restrict__ beta, double* y, long ldy, int cs) {
   extern __shared__ __align__(16) double lds[];       // [2][KTD][cs]
   constexpr int NJ = KTD / 8;                          // 16-byte loads per row fragment and k-tile

@@ -197,10 +197,17 @@ static void ComputeP(Ctx *c, int *offset)
 	c->startP = sP + c->sizeC; c->endP = eP + c->sizeC; c->sizeP = c->endP - c->startP;
 	/* P = V[:, N..W) * coef, staged through a work block */
 	coef = evec + (size_t)N * (c->sizeX - c->sizeC);
-	s[0] = c->startN; e[0] = c->endW; s[1] = 0; e[1] = c->sizeP;
-	ops->MultiVecLinearComb(c->V, c->ws0, 0, s, e, coef, N, NULL, 0, ops);
-	s[0] = 0; e[0] = c->sizeP; s[1] = c->startP; e[1] = c->endP;
-	ops->MultiVecAxpby(1.0, c->ws0, 0.0, c->V, s, e, ops);
+	if (c->sizeP <= GCGE_InplaceLinearCombCols((void*)ops->MultiVecLinearComb) &&
+			c->startP >= c->startN && c->endP <= c->endW) {
+		/* the P columns lie inside [N, W): a back-end that works row by row writes them in place */
+		s[0] = c->startN; e[0] = c->endW; s[1] = c->startP; e[1] = c->endP;
+		ops->MultiVecLinearComb(c->V, c->V, 0, s, e, coef, N, NULL, 0, ops);
+	} else {
+		s[0] = c->startN; e[0] = c->endW; s[1] = 0; e[1] = c->sizeP;
+		ops->MultiVecLinearComb(c->V, c->ws0, 0, s, e, coef, N, NULL, 0, ops);
+		s[0] = 0; e[0] = c->sizeP; s[1] = c->startP; e[1] = c->endP;
+		ops->MultiVecAxpby(1.0, c->ws0, 0.0, c->V, s, e, ops);
+	}
 	g_timing.compP += ops->GetWtime() - t0;
 }
 

@@ -38,6 +38,12 @@ GCGE_COMM *GCGE_GetComm(void) { return g_comm; }
 static GCGE_RESIDUAL_FN g_res_hook = NULL; static void *g_res_owner = NULL;
 void GCGE_SetResidualHook(GCGE_RESIDUAL_FN fn, void *owner) { g_res_hook = fn; g_res_owner = owner; }
 GCGE_RESIDUAL_FN GCGE_GetResidualHook(void *owner) { return (g_res_hook != NULL && owner == g_res_owner) ? g_res_hook : NULL; }
+static void *g_inplace_owner = NULL; static int g_inplace_cols = 0;
+void GCGE_SetInplaceLinearComb(void *owner, int max_cols) { g_inplace_owner = owner; g_inplace_cols = max_cols; }
+int GCGE_InplaceLinearCombCols(void *owner)
+{
+	return (g_inplace_owner != NULL && owner == g_inplace_owner && getenv("GCGE_NO_INPLACE_LINCOMB") == NULL) ? g_inplace_cols : 0;
+}
 
 static double g_ls_sigma = 0.0; static void *g_ls_matB = NULL;
 void GCGE_SetLinearSolverShift(double sigma, void *matB) { g_ls_sigma = sigma; g_ls_matB = matB; }

@@ -236,10 +236,15 @@ static void orth_self_chol(void **x, int b0, int *b1, void *B, int max_reorth, d
 			return;
 		}
 		invert_upper(m, R, Ri);
-		start[0] = b0; end[0] = *b1; start[1] = 0; end[1] = m;
-		ops->MultiVecLinearComb(x, mv_ws, 0, start, end, Ri, m, NULL, 0, ops);      /* ws = X R^-1 */
-		start[0] = 0; end[0] = m; start[1] = b0; end[1] = *b1;
-		ops->MultiVecAxpby(1.0, mv_ws, 0.0, x, start, end, ops);
+		if (m <= GCGE_InplaceLinearCombCols((void*)ops->MultiVecLinearComb)) {       /* X = X R^-1 row by row, in place */
+			start[0] = b0; end[0] = *b1; start[1] = b0; end[1] = *b1;
+			ops->MultiVecLinearComb(x, x, 0, start, end, Ri, m, NULL, 0, ops);
+		} else {
+			start[0] = b0; end[0] = *b1; start[1] = 0; end[1] = m;
+			ops->MultiVecLinearComb(x, mv_ws, 0, start, end, Ri, m, NULL, 0, ops);      /* ws = X R^-1 */
+			start[0] = 0; end[0] = m; start[1] = b0; end[1] = *b1;
+			ops->MultiVecAxpby(1.0, mv_ws, 0.0, x, start, end, ops);
+		}
 		++pass;
 		if (dev < 1e-8) return;   /* deviation after this pass is O(dev^2 + eps) */
 	}

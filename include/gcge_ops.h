@@ -154,6 +154,14 @@ void       GCGE_GetLinearSolverShift (double *sigma, void **matB);
 typedef int (*GCGE_RESIDUAL_FN) (void *A, void *B, void **x, int start, int end, const double *lambda, double *res_sq);
 void       GCGE_SetResidualHook (GCGE_RESIDUAL_FN fn, void *owner);
 GCGE_RESIDUAL_FN GCGE_GetResidualHook (void *owner);
+/* Optional capability: a back-end whose MultiVecLinearComb works ROW BY ROW (row-major blocks: every output row is
+ * formed from the same row of x and written after that row has been read) may declare panel updates IN PLACE safe:
+ * y == x with the output columns inside the input column range, at most `max_cols` output columns per call.  The
+ * block orthonormalisation and ComputeP of this solver stack then skip the work block + copy back the reference's
+ * LAPACKVEC layout needs (src/ops_orth.c, src/ops_eig_sol_gcg.c:624-640): same arithmetic, same results, two block
+ * streams less per update.  `owner` = the table's MultiVecLinearComb; 0 columns: not declared. */
+void       GCGE_SetInplaceLinearComb (void *owner, int max_cols);
+int        GCGE_InplaceLinearCombCols (void *owner);
 void       GCGE_SetQuiet (OPS *ops, int quiet);   /* silence ops->Printf (and the dense table's) */
 
 #ifdef __cplusplus

@@ -598,8 +598,44 @@ def test_lincomb_row_fragment_variants_vs_oracle(both, rf):
             hip.ops.lincomb(yh, yh, (0, kk), (kk, kk + 64), coef, kk, one, 0)
             ora.ops.lincomb(yo, yo, (0, kk), (kk, kk + 64), coef, kk, one, 0)
             _close(hip.mv_to_numpy(yh, n, 0, 264), ora.mv_to_numpy(yo, n, 0, 264), tol=1e-12, what="lincomb W -= V C in place k=%d rf=%d" % (kk, rf))
+        # output columns INSIDE the input range (what GCGE_SetInplaceLinearComb declares safe: X = X R^-1 of the block
+        # orthonormalisation, P = V[:, N..W) coef): bit-identical to the same update staged through another block
+        for (x0, kk, y0, mm) in [(4, 64, 4, 64), (0, 192, 64, 64), (2, 128, 2, 128), (6, 48, 22, 16), (0, 131, 100, 31), (1, 33, 1, 33)]:
+            Y0 = uniform(55, (n, 200)) - 0.5
+            yh, zh = hip.mv_from_numpy(mh, Y0), hip.mv_from_numpy(mh, np.zeros((n, 200)))
+            coef = np.asfortranarray(uniform(56, (kk, mm)) - 0.5)
+            hip.ops.lincomb(yh, zh, (x0, y0), (x0 + kk, y0 + mm), coef, kk, None, 0)          # staged: z = y C
+            hip.ops.lincomb(yh, yh, (x0, y0), (x0 + kk, y0 + mm), coef, kk, None, 0)          # in place
+            got, ref = hip.mv_to_numpy(yh, n, 0, 200), hip.mv_to_numpy(zh, n, 0, 200)
+            assert np.array_equal(got[:, y0:y0 + mm], ref[:, y0:y0 + mm]), ("in place, overlapping", rf, x0, kk, y0, mm)
+            keep = np.ones(200, dtype=bool); keep[y0:y0 + mm] = False
+            assert np.array_equal(got[:, keep], Y0[:, keep])
+            _close(got[:, y0:y0 + mm], Y0[:, x0:x0 + kk] @ coef, tol=1e-12, what="lincomb in place, overlapping rf=%d" % rf)
+            hip.ops.mv_destroy(yh); hip.ops.mv_destroy(zh)
     finally:
         hip.g.gcge_hip_lincomb_tune(0)
+
+
+def test_gcg_inplace_panel_updates_equal_staged_ones(hip):
+    """The solver stack skips the work block + copy back of X = X R^-1 (block orthonormalisation) and of ComputeP when the
+    back-end declares row-wise panel updates in place safe (GCGE_SetInplaceLinearComb): same arithmetic, so the
+    eigensolve is identical bit for bit to the staged form (GCGE_NO_INPLACE_LINCOMB=1)."""
+    import os
+    hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    hip.g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    hip.set_random_mode(0)
+    args = ["-nevConv", 20, "-blockSize", 16, "-nevMax", 48, "-gcge_initX_orth_method", "chol", "-gcge_compW_orth_method", "chol"]
+    out = {}
+    for staged in (0, 1):
+        if staged:
+            os.environ["GCGE_NO_INPLACE_LINCOMB"] = "1"
+        try:
+            ev, res = gcg_on(hip, "lap3d", 24, args, flag=1)
+        finally:
+            os.environ.pop("GCGE_NO_INPLACE_LINCOMB", None)
+        out[staged] = (np.array(ev[:res.nevConv]), res.nevConv, res.numIter)
+    assert out[0][1] >= 20 and out[0][1] == out[1][1] and out[0][2] == out[1][2], (out[0][1:], out[1][1:])
+    assert np.array_equal(out[0][0], out[1][0])
 
 
 def test_fused_cg_workspace_follows_the_problem_shape(hip):
