@@ -314,13 +314,13 @@ __global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, c
 
 }  // namespace gcge
 
-// cpad (kp x mp, row-major, zero outside k x m) <- c (k x m, row-major)
+// cpad (kp x mp, row-major, zero outside rows [shift, shift + k) x columns [0, m)) <- c (k x m, row-major)
 __global__ __launch_bounds__(256) void lincomb_pad_c(const double* __restrict__ c, int k, int m, double* __restrict__ cpad,
-                                                     int kp, int mp) {
+                                                     int kp, int mp, int shift) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= kp * mp) return;
-  const int row = e / mp, col = e % mp;
-  cpad[e] = (row < k && col < m) ? c[(long)row * m + col] : 0.0;
+  const int row = e / mp - shift, col = e % mp;
+  cpad[e] = (row >= 0 && row < k && col < m) ? c[(long)row * m + col] : 0.0;
 }
 
 using namespace gcge;
@@ -334,13 +334,19 @@ extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 
 template <int NT>
 static int lc_launch(int nrows, const double* x, long ldx, int k, const double* c, int m,
                      const double* beta, double* y, long ldy, hipStream_t st) {
+  // An operand that starts on an odd column of a 16-byte aligned block (the solver's X / P / W ranges move with the
+  // number of converged pairs) is widened by the column in front of it, which meets a zero coefficient row: the direct
+  // form's 16-byte loads stay aligned (the staged kernel it fell back to: 25.0 against 19.5 ms at k = 192, m = 128).
+  // That column belongs to the same block of vectors (blocks are zero-filled at creation: finite).
+  int shift = 0;
+  if ((((uintptr_t)x & 15) == 8) && (ldx % 2 == 0) && ((g_lc_rf == 0 && NT >= 4) || g_lc_rf >= 3)) { shift = 1; x -= 1; k += 1; }
   const int kp = (k + LC_KT - 1) / LC_KT * LC_KT, mp = 16 * NT;
   if ((size_t)kp * mp > g_cpad_len) {   // grows rarely; freeing synchronises with kernels still reading the old one
     if (g_cpad) GCGE_HIP_CHECK(hipFree(g_cpad));
     g_cpad_len = (size_t)kp * mp * 2;
     GCGE_HIP_CHECK(hipMalloc(&g_cpad, g_cpad_len * sizeof(double)));
   }
-  hipLaunchKernelGGL(lincomb_pad_c, dim3((kp * mp + 255) / 256), dim3(256), 0, st, c, k, m, g_cpad, kp, mp);
+  hipLaunchKernelGGL(lincomb_pad_c, dim3((kp * mp + 255) / 256), dim3(256), 0, st, c, k - shift, m, g_cpad, kp, mp, shift);
   // direct form: X read with 16-byte lane loads straight into MFMA operands (needs a 16-byte aligned operand)
   // Measured at n = 2^24 (profiles/r02_dense/06): what decides is waves per SIMD, and short k-tiles buy them — the operand
   // registers of a k-tile shrink with it while the accumulator tiles stay.  k = 256, m = 128: k-tiles of 32 at one wave per
