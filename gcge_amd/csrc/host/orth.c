@@ -36,19 +36,43 @@ static void negate(double *v, int n) { int i; for (i = 0; i < n; ++i) v[i] = -v[
  * (saves one n x k x m panel update per call).  NOT safe in general: the test is absolute, and when the
  * columns being projected are tiny (W blocks close to convergence are ~1e-9 of the basis vectors) a
  * coefficient of 1e-14 is a relative 1e-5 that the subsequent normalisation blows up — an 8-rank run on an
- * 8^3 grid stagnated at 7 of 8 pairs with it (tests/test_dist.py). */
+ * 8^3 grid stagnated at 7 of 8 pairs with it (tests/test_dist.py).
+ * lazy = 2 (the Cholesky-QR scheme, B == NULL): every pass is applied as in the reference, but whether ANOTHER pass
+ * follows is decided relative to the columns ("twice is enough", Kahan / Parlett): after pass p >= 1, if
+ * ||c_j|| <= 0.1 ||w_j|| for every column (c_j this pass's coefficients, w_j the column as it entered the pass), what
+ * the pass removed was a small fraction of the column, the update was computed without cancellation and the result is
+ * orthogonal to the basis to rounding — a further pass would remove O(eps ||w_j||).  The reference's absolute test
+ * (|c| < 50 eps) asks for a third Gram product + panel update whenever the second pass's coefficients exceed 1e-14 in
+ * absolute terms, which they do for columns of norm ~1.  Costs one column-norm sweep after the first pass. */
 static void project_out(void **x, int s0, int e0, int s1, int e1, void *B,
 		int max_reorth, double reorth_tol, int lazy, void **mv_ws, double *coef, struct OPS_ *ops)
 {
-	int pass, start[2], end[2], k = e0 - s0, m = e1 - s1; double one = 1.0;
+	int pass, start[2], end[2], k = e0 - s0, m = e1 - s1, i, j; double one = 1.0;
+	const int kahan = lazy == 2 && B == NULL && getenv("GCGE_ORTH_ABSOLUTE_TEST") == NULL;
+	double *wn = NULL;   /* squared norms of the columns as they enter the next pass */
 	if (k <= 0 || m <= 0) return;
 	for (pass = 0; pass < 1 + max_reorth; ++pass) {
 		start[0] = s0; end[0] = e0; start[1] = s1; end[1] = e1;
 		ops->MultiVecQtAP('S', 'N', x, B, x, 0, start, end, coef, k, mv_ws, ops);
-		if (lazy && pass > 0 && max_abs(coef, k * m) < reorth_tol) break;
+		if (lazy == 1 && pass > 0 && max_abs(coef, k * m) < reorth_tol) break;
 		negate(coef, k * m);
 		ops->MultiVecLinearComb(x, x, 0, start, end, coef, k, &one, 0, ops);
 		if (max_abs(coef, k * m) < reorth_tol) break;
+		if (kahan && pass + 1 < 1 + max_reorth) {
+			if (pass >= 1) {                 /* was this pass a small correction for every column? */
+				int small = 1;
+				for (j = 0; j < m && small; ++j) {
+					double c2 = 0.0;
+					for (i = 0; i < k; ++i) c2 += coef[(size_t)k * j + i] * coef[(size_t)k * j + i];
+					if (!(c2 <= 0.01 * wn[j])) small = 0;     /* also catches wn = 0 and NaN */
+				}
+				if (small) break;
+			}
+			/* the columns as the next pass will see them (coef is free again: the norms go behind it) */
+			wn = coef + (size_t)k * m;
+			start[0] = s1; end[0] = e1; start[1] = s1; end[1] = e1;
+			ops->MultiVecInnerProd('D', x, x, 0, start, end, wn, 1, ops);
+		}
 	}
 }
 
@@ -256,7 +280,7 @@ static void CholeskyQR(void **x, int start_x, int *end_x, void *B, struct OPS_ *
 	double *coef = p->dbl_ws;
 	int block, b0, b1, start[2], end[2];
 	if (*end_x <= start_x) return;
-	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, 0, p->mv_ws, coef, ops);
+	project_out(x, 0, start_x, start_x, *end_x, B, p->max_reorth, p->reorth_tol, 2, p->mv_ws, coef, ops);
 	b0 = start_x;
 	block = p->block_size;
 	if (block <= 0) block = *end_x - b0;
