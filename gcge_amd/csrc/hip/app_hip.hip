@@ -959,6 +959,33 @@ extern "C" int gcge_hip_cg_start_mv(void* mat, void** x, int xc0, void** b, int 
   return 0;
 }
 
+// The same start for right-hand sides b_j = scale_j x_j (x = the initial guess): the GCG driver's systems
+// A w = (lambda + sigma) x start from w = x, so b is never formed and never read (kernel MODE 6).  host_scale: m factors.
+extern "C" int gcge_hip_cg_start_scaled_mv(void* mat, void** x, int xc0, const double* host_scale, void** r, void** p0, int rc0,
+                                           int m, double* host_rho) {
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
+  GcgeHipMV *vx = (GcgeHipMV*)x, *vr = (GcgeHipMV*)r, *vp = (GcgeHipMV*)p0;
+  if (A == nullptr || A->d_pid == nullptr || g_spmm_path != 0 || getenv("GCGE_CG_NO_RECOMPUTE") != nullptr) return -1;
+  if ((m & 1) || (xc0 & 1) || (rc0 & 1) || (vx->ld & 1) || (vr->ld & 1) || (vp->ld & 1)) return -1;
+  if (((uintptr_t)vx->d & 15) || ((uintptr_t)vr->d & 15) || ((uintptr_t)vp->d & 15)) return -1;
+  if (vr == vx || vp == vx || (A->nghost > 0 && m > A->buf_cols)) return -1;
+  GCGE_REQUIRE(xc0 >= 0 && xc0 + m <= vx->ncols && rc0 >= 0 && rc0 + m <= vr->ncols && rc0 + m <= vp->ncols, "cg_start: column ranges");
+  GCGE_REQUIRE(A->nrows == vx->nrows && A->nrows == vr->nrows && A->nrows == vp->nrows &&
+               A->nrows + A->nghost <= vx->nrows_alloc, "cg_start: shapes");
+  double* dd = stage_d(7 * (size_t)m);           // [0, 6 m): sums (3 m of scratch behind them when the product is split), [6 m, 7 m): scale
+  double* hs = stage_h(2 * (size_t)m);
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));   // the staging buffers are reused
+  memcpy(hs, host_scale, m * sizeof(double));
+  GCGE_HIP_CHECK(hipMemcpyAsync(dd + 6 * (size_t)m, hs, m * sizeof(double), hipMemcpyHostToDevice, g_stream));
+  const CgPass cg = {6, vr->d + rc0, vr->ld, vp->d + rc0, vp->ld, dd + 6 * (size_t)m, nullptr, nullptr, nullptr, 0};
+  const int rc = spmm_halo(A, vx, xc0, nullptr, 0, m, dd, nullptr, &cg);
+  if (rc != 0) return -1;
+  GCGE_HIP_CHECK(hipMemcpyAsync(hs + m, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+  memcpy(host_rho, hs + m, m * sizeof(double));
+  return 0;
+}
+
 // Residuals of Ritz pairs of a standard problem in one read of x (GCGE_RESIDUAL_FN, include/gcge_ops.h; kernel MODE 4 of
 // spmm_pattern.hip): res_sq[j] = sum over the local rows of ((A x_j) - lambda_j x_j)^2.  Declines (0) for B != NULL,
 // matrices without pattern form, blocks that cannot be walked in 16-byte column pairs.  Odd column ranges are widened

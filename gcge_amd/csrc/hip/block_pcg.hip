@@ -55,6 +55,8 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
                                       struct OPS_* ops);
 extern "C" int gcge_hip_cg_fusable(void* mat, void** p, int ncols);
 extern "C" int gcge_hip_cg_recompute_pays(void* mat);
+extern "C" int gcge_hip_cg_start_scaled_mv(void* mat, void** x, int xc0, const double* host_scale, void** r, void** p0, int rc0,
+                                           int m, double* host_rho);
 extern "C" int gcge_hip_cg_start_mv(void* mat, void** x, int xc0, void** b, int bc0, void** r, void** p0, int rc0, int m,
                                     double* host_rho);
 extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* host_pw, double* host_ww);
@@ -524,6 +526,24 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
   std::vector<double> norm_b(nrhs), rho1(nrhs), rho2(nrhs), pTw(nrhs), init_res(nrhs), last_res(nrhs), coef(nrhs);
   std::vector<int> active(nrhs), flag(nrhs);
   int st2[2], en2[2];
+  // The caller may have declared b = x diag(scale) without forming it (GCGE_SetLinearSolverRhsScale: our GCG driver's
+  // systems A w = (lambda + sigma) x, started from w = x).  The one-sweep start below then takes the scale factors
+  // and neither reads nor needs b; every other route forms b first, here, on the device.
+  const double* rhs_scale = GCGE_GetLinearSolverRhsScale();
+  bool p0_done = false;
+  if (rhs_scale != nullptr) {
+    if (0 != strcmp(s->tol_type, "rel") && sigma == 0.0 && gcge_hip_cg_recompute_pays(mat) &&
+        gcge_hip_cg_start_scaled_mv(mat, mv_x, start_bx[1], rhs_scale, s->mv_ws[0], s->mv_ws[1], 0, nrhs, rho2.data()) == 0) {
+      reduce_over_ranks(rho2.data(), nrhs);
+      p0_done = true;
+    } else {
+      st2[0] = start_bx[1]; en2[0] = end_bx[1]; st2[1] = start_bx[0]; en2[1] = end_bx[0];
+      ops->MultiVecAxpby(1.0, mv_x, 0.0, mv_b, st2, en2, ops);
+      std::vector<double> sc(rhs_scale, rhs_scale + nrhs);
+      ops->MultiVecLinearComb(NULL, mv_b, 0, st2, en2, NULL, 0, sc.data(), 1, ops);
+      rhs_scale = nullptr;
+    }
+  }
   if (0 == strcmp(s->tol_type, "rel")) {
     st2[0] = start_bx[0]; en2[0] = end_bx[0]; st2[1] = start_bx[0]; en2[1] = end_bx[0];
     ops->MultiVecInnerProd('D', mv_b, mv_b, 0, st2, en2, norm_b.data(), 1, ops);
@@ -533,8 +553,9 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
   }
   // r = b - A x ; rho2 = diag(r^T r) ; p0 = r.  On pattern matrices in one sweep (kernel MODE 5) when the operands
   // allow it; otherwise product, axpby, column dots (and the copy p0 = r further down)
-  bool p0_done = false;
-  if (sigma == 0.0 && gcge_hip_cg_recompute_pays(mat) &&
+  if (p0_done) {
+    // started from the scale factors above
+  } else if (sigma == 0.0 && gcge_hip_cg_recompute_pays(mat) &&
       gcge_hip_cg_start_mv(mat, mv_x, start_bx[1], mv_b, start_bx[0], s->mv_ws[0], s->mv_ws[1], 0, nrhs, rho2.data()) == 0) {
     reduce_over_ranks(rho2.data(), nrhs);
     p0_done = true;
@@ -889,6 +910,7 @@ extern "C" void gcge_hip_bpcg_setup(struct OPS_* ops, int max_iter, double rate,
   strncpy(g_bpcg.tol_type, tol_type ? tol_type : "abs", 7); g_bpcg.tol_type[7] = 0;
   ops->multi_linear_solver_workspace = (void*)&g_bpcg;
   ops->MultiLinearSolver = HIP_BlockPCG;
+  GCGE_SetRhsScaleCapability((void*)HIP_BlockPCG);   // b = x diag(scale) need not be formed (see HIP_BlockPCG_run)
 }
 extern "C" void gcge_hip_bpcg_stats(long* spmm_calls, long* spmm_cols, int* last_niter) {
   if (spmm_calls) *spmm_calls = g_bpcg.spmm_calls;

@@ -55,6 +55,8 @@ struct PatEntry { double val; long off; };   // 16 bytes: one ds_read_b128
 //      copied).  X = p_k, PNEW = p_{k+1} must be different blocks: neighbours still read X.
 //   5  start of the block CG: R[r,j] = B[r,j] - (A X)[r,j], PNEW = R (p_0 = r_0), partial: sum_r R[r,j]^2, with
 //      B = cg.b the right-hand sides and X the initial guess: one sweep instead of product, axpby, column dots and copy
+//   6  mode 5 with the right-hand side B = X diag(scale) (scale = cg.alpha) formed on the fly from the row's own X value:
+//      the GCG driver's systems A w = (lambda + sigma) x start from w = x, so neither B nor a second read is needed
 //   4  residual norms of Ritz pairs (standard problem): partial: sum_r ((A X)[r,j] - lambda_j X[r,j])^2 with
 //      lambda = cg.alpha; nothing is stored (CheckConvergence of the GCG driver, one read of X instead of 11 streams)
 struct CgArgs { double* r; size_t ldr; double* pnew; size_t ldp; const double* alpha; const double* beta; const int* flag; const double* b; size_t ldb; };
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
   const double* __restrict__ rl = UPD ? (MODE == 5 ? cg.b : cg.r) + (act ? 2 * i : 0) : nullptr;
   const size_t ldrl = MODE == 5 ? cg.ldb : cg.ldr;
   CgCoef cf = MODE == 3 ? cg_coef(cg, 2 * i, act) : CgCoef{0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
-  if (RES && act) { cf.al0 = cg.alpha[2 * i]; cf.al1 = cg.alpha[2 * i + 1]; }   // lambda of this lane's column pair
+  if ((RES || MODE == 6) && act) { cf.al0 = cg.alpha[2 * i]; cf.al1 = cg.alpha[2 * i + 1]; }   // lambda / rhs scale of this lane's column pair
   double d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;   // x.y and y.y column sums (DOT)
 
   // tile t = (group of 4 lines q, slice a inside the line); wave w takes line 4q + w
@@ -123,8 +125,13 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
         d0 = fma(a0 * wgt, buf[LT].x, d0); d1 = fma(a1 * wgt, buf[LT].y, d1);
         e0 = fma(a0 * wgt, a0, e0); e1 = fma(a1 * wgt, a1, e1);
       }
-      if (MODE == 5) {
-        const v2d rv = buf[LT + DOT];
+      if (MODE == 5 || MODE == 6) {
+        // MODE 6: the product is rounded on its own (as the column scaling that used to form B did), then subtracted
+        v2d rv = buf[LT + DOT + UPD - 1];
+        if (MODE == 6) {
+#pragma clang fp contract(off)   // no fma(scale, x, -Ax): __dmul_rn is a plain product in the HIP headers and would be contracted
+          rv = v2d{cf.al0 * buf[LT].x, cf.al1 * buf[LT].y};
+        }
         v2d rn = {rv.x - a0, rv.y - a1};
         if (ok) {
           __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.r + (size_t)row * cg.ldr + 2 * i));
@@ -385,8 +392,13 @@ __device__ __forceinline__ void chain2_body(
       d0 = fma(a0 * wgt, b.x, d0); d1 = fma(a1 * wgt, b.y, d1);
       e0 = fma(a0 * wgt, a0, e0); e1 = fma(a1 * wgt, a1, e1);
     }
-    if (MODE == 5) {
-      const v2d rv = oth[NO + UPD];
+    if (MODE == 5 || MODE == 6) {
+      v2d rv;
+      if (MODE == 5) rv = oth[NO + UPD];
+      else {   // B = X diag(scale), rounded like the column scaling (no contraction into fma(scale, x, -Ax))
+#pragma clang fp contract(off)
+        const v2d sc = s_cf[i]; rv = v2d{sc.x * b.x, sc.y * b.y};
+      }
       v2d rn = {rv.x - a0, rv.y - a1};
       if (ok) {
         __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.r + (size_t)row * cg.ldr + 2 * i));
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
     const CgCoef c = cg_coef(cg, 2 * threadIdx.x, 2 * (int)threadIdx.x < m);
     s_cf[threadIdx.x] = v2d{c.al0, c.al1}; s_cf[8 + threadIdx.x] = v2d{c.cb0, c.cb1}; s_cf[16 + threadIdx.x] = v2d{c.cr0, c.cr1};
   }
-  if (MODE == 4 && threadIdx.x < 8)
+  if ((MODE == 4 || MODE == 6) && threadIdx.x < 8)
     s_cf[threadIdx.x] = (2 * (int)threadIdx.x < m) ? v2d{cg.alpha[2 * threadIdx.x], cg.alpha[2 * threadIdx.x + 1]} : v2d{0.0, 0.0};
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -698,10 +710,11 @@ extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned shor
                                         long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
                                         long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
                                         double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, long near) {
-  if (mode != 2 && mode != 3 && mode != 4 && mode != 5) return -1;
+  if (mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 6) return -1;
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || ((uintptr_t)d_x & 15) || d_dots == nullptr) return -1;
-  if ((mode == 3 || mode == 5) && ((ldr & 1) || (ldp & 1) || ((uintptr_t)d_r & 15) || ((uintptr_t)d_pnew & 15) || d_pnew == d_x || d_r == d_x)) return -1;
+  if (mode == 6 && d_alpha == nullptr) return -1;
+  if ((mode == 3 || mode == 5 || mode == 6) && ((ldr & 1) || (ldp & 1) || ((uintptr_t)d_r & 15) || ((uintptr_t)d_pnew & 15) || d_pnew == d_x || d_r == d_x)) return -1;
   if (mode == 5 && (d_b == nullptr || (ldb & 1) || ((uintptr_t)d_b & 15))) return -1;
   if ((size_t)npat * lt * sizeof(PatEntry) > 64 * 1024) return -1;
   hipStream_t st = (hipStream_t)stream;
@@ -733,6 +746,9 @@ extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned shor
     } else if (mode == 5) {
       const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, nullptr, nullptr, nullptr, d_b + c0, (size_t)ldb};
       rc = pat_dispatch<5>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
+    } else if (mode == 6) {
+      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, nullptr, nullptr, nullptr, 0};
+      rc = pat_dispatch<6>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
     } else {
       const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0, nullptr, 0};
       rc = pat_dispatch<3>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);

@@ -232,6 +232,9 @@ static void ComputeW(Ctx *c, int *offset)
 	p->sigma = sigma = p->compW_cg_shift + sigma;
 	assert(p->compW_cg_auto_shift == 0 || p->user_defined_multi_linear_solver == 0);
 
+	/* B == NULL and a solver that takes "b = x diag(scale)" (GCGE_SetRhsScaleCapability): b is not formed */
+	const int scaled_rhs = p->user_defined_multi_linear_solver == 1 && c->B == NULL &&
+			GCGE_HasRhsScaleCapability((void*)ops->MultiLinearSolver);
 	c->startW = c->endP;
 	for (idx = 0; idx < offset[0]; ++idx) {
 		int lo = offset[idx * 2 + 1], hi = offset[idx * 2 + 2], len = hi - lo;
@@ -239,10 +242,12 @@ static void ComputeW(Ctx *c, int *offset)
 		s[0] = lo; e[0] = hi; s[1] = c->startW + blk; e[1] = s[1] + len;
 		ops->MultiVecAxpby(1.0, c->ritz, 0.0, c->V, s, e, ops);
 		/* right-hand side (lambda + sigma) B x, packed from column offset[1] of ritz_vec */
-		s[0] = lo; e[0] = hi; s[1] = offset[1] + blk; e[1] = s[1] + len;
-		ops->MatDotMultiVec(c->B, c->V, b, s, e, ops);
 		for (i = 0; i < len; ++i) scales[blk + i] = c->ss_eval[lo + i] + sigma;
-		ops->MultiVecLinearComb(NULL, b, 0, s, e, NULL, 0, scales + blk, 1, ops);
+		if (!scaled_rhs) {
+			s[0] = lo; e[0] = hi; s[1] = offset[1] + blk; e[1] = s[1] + len;
+			ops->MatDotMultiVec(c->B, c->V, b, s, e, ops);
+			ops->MultiVecLinearComb(NULL, b, 0, s, e, NULL, 0, scales + blk, 1, ops);
+		}
 		blk += len;
 	}
 	c->endW = c->startW + blk;
@@ -266,7 +271,9 @@ static void ComputeW(Ctx *c, int *offset)
 		}
 	}
 	if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverShift(sigma, c->B);
+	if (scaled_rhs) GCGE_SetLinearSolverRhsScale(scales);
 	ops->MultiLinearSolver(c->A, b, c->V, s, e, ops);
+	if (scaled_rhs) GCGE_SetLinearSolverRhsScale(NULL);
 	if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverShift(0.0, NULL);
 	if (sigma != 0.0 && c->B != NULL && ops->MatAxpby != NULL
 			&& p->user_defined_multi_linear_solver != 1)

@@ -38,6 +38,14 @@ GCGE_COMM *GCGE_GetComm(void) { return g_comm; }
 static GCGE_RESIDUAL_FN g_res_hook = NULL; static void *g_res_owner = NULL;
 void GCGE_SetResidualHook(GCGE_RESIDUAL_FN fn, void *owner) { g_res_hook = fn; g_res_owner = owner; }
 GCGE_RESIDUAL_FN GCGE_GetResidualHook(void *owner) { return (g_res_hook != NULL && owner == g_res_owner) ? g_res_hook : NULL; }
+static void *g_rhs_scale_owner = NULL; static const double *g_rhs_scale = NULL;
+void GCGE_SetRhsScaleCapability(void *owner) { g_rhs_scale_owner = owner; }
+int GCGE_HasRhsScaleCapability(void *owner)
+{
+	return g_rhs_scale_owner != NULL && owner == g_rhs_scale_owner && getenv("GCGE_NO_RHS_SCALE") == NULL;
+}
+void GCGE_SetLinearSolverRhsScale(const double *scale) { g_rhs_scale = scale; }
+const double *GCGE_GetLinearSolverRhsScale(void) { return g_rhs_scale; }
 static void *g_inplace_owner = NULL; static int g_inplace_cols = 0;
 void GCGE_SetInplaceLinearComb(void *owner, int max_cols) { g_inplace_owner = owner; g_inplace_cols = max_cols; }
 int GCGE_InplaceLinearCombCols(void *owner)

@@ -154,6 +154,16 @@ void       GCGE_GetLinearSolverShift (double *sigma, void **matB);
 typedef int (*GCGE_RESIDUAL_FN) (void *A, void *B, void **x, int start, int end, const double *lambda, double *res_sq);
 void       GCGE_SetResidualHook (GCGE_RESIDUAL_FN fn, void *owner);
 GCGE_RESIDUAL_FN GCGE_GetResidualHook (void *owner);
+/* Optional capability of a user-defined MultiLinearSolver: the driver's systems A w = (lambda + sigma) B x are started
+ * from w = x, so for B == NULL the right-hand side is the initial guess scaled column by column.  A solver that
+ * declared the capability (owner = its function pointer, as installed in ops->MultiLinearSolver) is called with the x
+ * block holding the initial guess, GCGE_GetLinearSolverRhsScale() returning the factors and the b block NOT filled in
+ * (it may use that block as scratch).  The reference forms b through MatDotMultiVec + MultiVecLinearComb
+ * (src/ops_eig_sol_gcg.c:560-577): two block sweeps and a third read at the start of the solve. */
+void       GCGE_SetRhsScaleCapability (void *owner);
+int        GCGE_HasRhsScaleCapability (void *owner);
+void       GCGE_SetLinearSolverRhsScale (const double *scale);   /* NULL: b is an ordinary right-hand side */
+const double *GCGE_GetLinearSolverRhsScale (void);
 /* Optional capability: a back-end whose MultiVecLinearComb works ROW BY ROW (row-major blocks: every output row is
  * formed from the same row of x and written after that row has been read) may declare panel updates IN PLACE safe:
  * y == x with the output columns inside the input column range, at most `max_cols` output columns per call.  The

@@ -854,3 +854,65 @@ def test_ring_sweep_equals_chain_kernel_and_numpy(hip, size, m, depth, wide):
         g.gcge_hip_spmm_ring_wide(0)
     hip.ops.mv_destroy(p, ncol)
     hip.free_matrix(mat)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,m", [(32, 16), (24, 64), (20, 8), (16, 22)])
+def test_cg_start_from_scale_factors_equals_start_from_formed_rhs(hip, size, m):
+    """r = b - A x, p0 = r, rho = r.r in one sweep with b = x diag(s) given as the scale factors (kernel MODE 6: the
+    driver's systems A w = (lambda + sigma) x started from w = x) against the same sweep reading a formed b (MODE 5):
+    identical bit for bit (the product is rounded before the subtraction, as the column scaling did) — chain + line
+    exchange layout with 16 and 8 waves, the plain pattern kernel, a ragged column count."""
+    from helpers import uniform
+    A, _ = make_problem("lap3d", size)
+    mat = hip.matrix(A)
+    n = A.nrows
+    g = hip.g
+    X = uniform(61, (n, m)) - 0.5
+    s = uniform(62, (m,)) * 0.2 + 0.01
+    x, b = hip.mv_from_numpy(mat, X), hip.mv_from_numpy(mat, X * s)
+    blk = [hip.mv_from_numpy(mat, np.zeros((n, m))) for _ in range(4)]
+    g.gcge_hip_cg_start_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    g.gcge_hip_cg_start_scaled_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    rho1, rho2 = np.zeros(m), np.zeros(m)
+    assert g.gcge_hip_cg_start_mv(mat, x, 0, b, 0, blk[0], blk[1], 0, m, rho1.ctypes.data) == 0
+    assert g.gcge_hip_cg_start_scaled_mv(mat, x, 0, s.ctypes.data, blk[2], blk[3], 0, m, rho2.ctypes.data) == 0
+    R1, P1, R2, P2 = (hip.mv_to_numpy(v, n, 0, m) for v in blk)
+    assert np.array_equal(R1, R2) and np.array_equal(P1, P2) and np.array_equal(rho1, rho2)
+    from helpers import csr_to_scipy
+    np.testing.assert_allclose(R2, X * s - csr_to_scipy(A) @ X, rtol=0, atol=1e-13 * np.abs(X).max() * 8)
+    for v in [x, b] + blk:
+        hip.ops.mv_destroy(v, m)
+    hip.free_matrix(mat)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra_env", [{}, {"GCGE_CG_NO_RECOMPUTE": "1"}])
+def test_gcg_scaled_rhs_start_equals_formed_rhs(hip, extra_env):
+    """B == NULL: the driver hands the fused solver b = x diag(lambda + sigma) as scale factors instead of forming it
+    (GCGE_SetLinearSolverRhsScale).  Same eigensolve: counts equal, Ritz values to rounding (where the formed b sits on
+    an odd column the old start took the unfused route, so the two runs are not bit-identical); where the one-sweep
+    start does not apply (here: recompute form switched off) the solver forms b itself."""
+    import os
+    hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    hip.g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    hip.set_random_mode(0)
+    args = ["-nevConv", 20, "-blockSize", 16, "-nevMax", 48, "-gcge_initX_orth_method", "chol", "-gcge_compW_orth_method", "chol"]
+    out = {}
+    os.environ.update(extra_env)
+    try:
+        for formed in (0, 1):
+            if formed:
+                os.environ["GCGE_NO_RHS_SCALE"] = "1"
+            try:
+                ev, res = gcg_on(hip, "lap3d", 32, args, flag=1)
+            finally:
+                os.environ.pop("GCGE_NO_RHS_SCALE", None)
+            out[formed] = (np.array(ev[:res.nevConv]), res.nevConv, res.numIter)
+    finally:
+        for k in extra_env:
+            os.environ.pop(k, None)
+    assert out[0][1] >= 20 and out[0][1] == out[1][1] and abs(out[0][2] - out[1][2]) <= 1, (out[0][1:], out[1][1:])
+    assert np.max(np.abs(out[0][0] - out[1][0]) / np.abs(out[1][0])) < 1e-11
+    exact = lap3d_exact(32, out[0][1])
+    assert np.max(np.abs(out[0][0] - exact) / exact) < 1e-9
