@@ -38,6 +38,9 @@ int gcge_hip_colmajor_to_rowmajor(int nrows, int m, const double* d_src, long ld
 int gcge_hip_rowmajor_to_colmajor(int nrows, int m, const double* d_src, long lds, double* d_dst, long ldd, void* stream);
 }
 
+extern "C" int gcge_hip_pattern_spmm_near(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2,
+                                          const double* d_x, long ldx, double* d_y, long ldy, int ncols, double* d_dots, double* d_dots_yy,
+                                          void* stream, long near);
 extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                    long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
                                    long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
@@ -696,8 +699,8 @@ static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long 
   double* y = dy + r0 * ldy;
   int rc = -1;
   if (A->d_pid != nullptr && g_spmm_path == 0)
-    rc = gcge_hip_pattern_spmm(nr, A->d_pid + r0, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, dx + r0 * ldx, ldx,
-                               y, ldy, m, d_dots, d_yy, g_stream);
+    rc = gcge_hip_pattern_spmm_near(nr, A->d_pid + r0, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, dx + r0 * ldx, ldx,
+                                    y, ldy, m, d_dots, d_yy, g_stream, A->pat_near);
   if (rc != -1) return rc;
   if (d_dots) {   // generic fused kernel (the caller checked its contract), y.y by a second pass over y
     rc = gcge_hip_pad8_spmm_dot(nr, A->d_orp + r0, A->d_pcol, A->d_pval, dx, ldx, y, ldy, m, d_dots, g_stream);

@@ -38,7 +38,7 @@ extern "C" void gcge_hip_reduce_partials_slabs(const double* d_partial, int nblo
                                                double* d_out, void* stream);
 extern "C" int gcge_hip_ring_pass(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, long L, int nw,
                                   long nb, const double* d_x, long ldx, int m, double* part, long yyo,
-                                  const double* d_lambda, void* stream, long maxoff);
+                                  const double* d_lambda, void* stream, long maxoff, double* d_y, long ldy);
 
 namespace gcge {
 
@@ -622,9 +622,18 @@ extern "C" int gcge_hip_pattern_width(int max_row_len) {
 // CHAIN layout (slots 0,1,2 = offsets -span, 0, +span; see spmm_pattern_chain_kernel) and span is a multiple of 32;
 // span2 == -L <= -8: additionally slots 3,4 = offsets -L, +L (spmm_pattern_chain2_kernel).
 // -1: alignment contract not met.
+extern "C" int gcge_hip_pattern_spmm_near(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+                                          long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
+                                          double* d_dots, double* d_dots_yy, void* stream, long near);
 extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                      long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
                                      double* d_dots, double* d_dots_yy, void* stream) {
+  return gcge_hip_pattern_spmm_near(nrows, d_pid, d_tab, npat, lt, span, span2, d_x, ldx, d_y, ldy, ncols, d_dots, d_dots_yy, stream, 0);
+}
+// near > 0: as in gcge_hip_pattern_cg_near — the product may take the LDS-ring sweep (spmm_ring.hip)
+extern "C" int gcge_hip_pattern_spmm_near(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+                                          long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
+                                          double* d_dots, double* d_dots_yy, void* stream, long near) {
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15)) return -1;
   if ((size_t)npat * lt * sizeof(PatEntry) > 64 * 1024) return -1;
@@ -644,9 +653,15 @@ extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, con
     hipStream_t stc = (hipStream_t)stream;
     double* partc = d_dots ? gcge_hip_partial_ws((size_t)nbc * 16 * npassc * 2) : nullptr;
     const long yyc = (long)nbc * 16 * npassc;
+    bool ring = near > 0 && lt == 7 && d_x != d_y;
     for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
       const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
       double* pp = partc ? partc + (size_t)ps * nbc * 16 : nullptr;
+      if (ring) {
+        if (gcge_hip_ring_pass(d_dots ? 1 : 0, nrows, d_pid, d_tab, npat, L, nw, nbc, d_x + c0, ldx, m, pp, yyc, nullptr, stc, near,
+                               d_y + c0, ldy) == 0) continue;
+        ring = false;   // declined (first pass): the chain2 kernel below
+      }
       long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyc, nbc, 8, stc, L, nw)
                         : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nbc, 8, stc, L, nw);
       if (rcl < 0) return -1;
@@ -736,7 +751,7 @@ extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned shor
     double* pp = part + (size_t)ps * nb * 16;
     long rc;
     if (ring) {
-      if (gcge_hip_ring_pass(mode, nrows, d_pid, d_tab, npat, L, nw, nb, d_x + c0, ldx, m, pp, yyo, mode == 4 ? d_alpha + c0 : nullptr, st, near) == 0) continue;
+      if (gcge_hip_ring_pass(mode, nrows, d_pid, d_tab, npat, L, nw, nb, d_x + c0, ldx, m, pp, yyo, mode == 4 ? d_alpha + c0 : nullptr, st, near, nullptr, 0) == 0) continue;
       ring = false;   // declined (first pass): the chain2 kernel below
     }
     if (mode == 2) rc = pat_dispatch<2>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw);

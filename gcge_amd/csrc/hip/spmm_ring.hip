@@ -21,6 +21,7 @@
 // Reference operation: app/app_ccs.c:50-139 (MatDotMultiVec) inside src/ops_lin_sol.c:256-405 (BlockPCG).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <algorithm>
 #include "gcge_hip_internal.h"
 
@@ -117,10 +118,11 @@ template <int MODE, int NW, int DP, int ROLE, bool WIDE>
 __device__ __forceinline__ void ring_body(
     long nrows, const unsigned short* __restrict__ pid, const RPat* s_pat, char* ring, const double* __restrict__ xblk,
     const double* __restrict__ xl, size_t ldx, bool act, int i, int g, int wave, int lane, int ntiles, long line, long step_rows, int b0,
-    double& d0, double& d1, double& e0, double& e1, const v2d* s_cf) {
+    double& d0, double& d1, double& e0, double& e1, const v2d* s_cf, double* __restrict__ y, size_t ldy) {
   constexpr int R = DP + 3;                                  // planes in the ring
   constexpr unsigned PB = Plane<NW>::PB;
   constexpr int K = (ROLE == 1) ? 3 : 4;                     // LDS-DMA pieces per batch
+  constexpr int S = (MODE <= 1) ? 1 : 0;                     // stores per iteration (they share vmcnt with the pieces, in order)
   static_assert(2 * DP + 5 <= RI, "id ring");
   const unsigned ring0 = (unsigned)(uintptr_t)ring;          // LDS byte address (low half of the flat address)
   const int G = gridDim.x;
@@ -206,6 +208,10 @@ __device__ __forceinline__ void ring_body(
   unsigned sf = 0, ef = 0;               // plane slot / id entry of the iteration being reduced (byte offsets)
   int pfin = id_at(o_idg), pb = id_at(o_idg + ei), pbf = id_at(o_idf + ei);   // patterns: rows reduced now / requested now
   const double wact = act ? 1.0 : 0.0;
+  // MODE 0 / 1: this lane's place in Y (the host only takes these modes when every slice of the sweep is inside the
+  // matrix: each wave then issues exactly one store per iteration, which the counted waits below rely on)
+  char* yl = MODE <= 1 ? reinterpret_cast<char*>(y + (size_t)(rb0 + g) * ldy + 2 * i) : nullptr;
+  const long stepY = step_rows * (long)ldy * 8;
   int pfin_c = -1;            // the pattern whose values sit in val[] (same caching as in batch)
   double val[LT];
 #pragma unroll
@@ -235,10 +241,14 @@ __device__ __forceinline__ void ring_body(
     a0 = fma(val[5], m1.x, a0); a1 = fma(val[5], m1.y, a1);
     a0 = fma(val[6], p1.x, a0); a1 = fma(val[6], p1.y, a1);
     const double wgt = j <= kv ? wact : 0.0;                  // j < cnt by the loop bound
-    if (MODE == 2) {
+    if (MODE <= 1) {
+      if (act) { v2d o = {a0, a1}; __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(yl)); }
+      yl += stepY;
+    }
+    if (MODE == 1 || MODE == 2) {
       d0 = fma(a0 * wgt, b.x, d0); d1 = fma(a1 * wgt, b.y, d1);
       e0 = fma(a0 * wgt, a0, e0);  e1 = fma(a1 * wgt, a1, e1);
-    } else {
+    } else if (MODE == 4) {
       const v2d lam = s_cf[i];
       const double q0 = fma(-lam.x, b.x, a0), q1 = fma(-lam.y, b.y, a1);
       d0 = fma(q0 * wgt, q0, d0); d1 = fma(q1 * wgt, q1, d1);
@@ -248,7 +258,9 @@ __device__ __forceinline__ void ring_body(
     //      iteration j + 2 DP + 3 (read one iteration before their batch goes out)
     batch(pb, pbf);
     pb = id_at(o_idg + ei); pbf = id_at(o_idf + ei);
-    vm_wait<DP * K>();        // everything up to the batch of iteration j + 1 has landed
+    // everything up to the batch of iteration j + 1 has landed: behind it in the queue are DP batches and, once the loop
+    // has run DP times, DP x S stores (before that fewer: the stricter count is the safe one)
+    if (S == 0 || j < DP) vm_wait<DP * K>(); else vm_wait<DP * (K + S)>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS reads above are done before anybody overwrites them
     __builtin_amdgcn_s_barrier();
   }
@@ -259,8 +271,8 @@ template <int MODE, int NW, int DP, bool WIDE>
 __global__ __launch_bounds__(64 * NW) void spmm_ring_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
     const double* __restrict__ x, size_t ldx, int m, int ntiles, long line, long step_rows, int xcd_runs,
-    double* __restrict__ dot_partial, long yy_offset, const double* __restrict__ lambda) {
-  static_assert(MODE == 2 || MODE == 4, "read-only passes");
+    double* __restrict__ dot_partial, long yy_offset, const double* __restrict__ lambda, double* __restrict__ y, size_t ldy) {
+  static_assert(MODE == 0 || MODE == 1 || MODE == 2 || MODE == 4, "product (with sums) and the passes that store nothing");
   constexpr int R = DP + 3;
   constexpr unsigned PB = Plane<NW>::PB;
   extern __shared__ __align__(16) unsigned char smem_raw[];   // ONE LDS object: ring | table | coefficients | reduction
@@ -287,10 +299,11 @@ __global__ __launch_bounds__(64 * NW) void spmm_ring_kernel(
   const int b0 = (xcd_runs == 2 && G % 32 == 0) ? ((bx & ~31) | ((bx & 7) << 2) | ((bx >> 3) & 3))   // runs of 4 tiles, see spmm_pattern.hip
                : (xcd_runs == 1 && G % 8 == 0) ? (bx & 7) * (G >> 3) + (bx >> 3) : bx;
   if (b0 < ntiles) {   // block-uniform
-    if (wave == 0) ring_body<MODE, NW, DP, 0, WIDE>(nrows, pid, s_pat, ring, x, xl, ldx, act, i, g, wave, lane, ntiles, line, step_rows, b0, d0, d1, e0, e1, s_cf);
-    else if (wave == NW - 1) ring_body<MODE, NW, DP, 2, WIDE>(nrows, pid, s_pat, ring, x, xl, ldx, act, i, g, wave, lane, ntiles, line, step_rows, b0, d0, d1, e0, e1, s_cf);
-    else ring_body<MODE, NW, DP, 1, WIDE>(nrows, pid, s_pat, ring, x, xl, ldx, act, i, g, wave, lane, ntiles, line, step_rows, b0, d0, d1, e0, e1, s_cf);
+    if (wave == 0) ring_body<MODE, NW, DP, 0, WIDE>(nrows, pid, s_pat, ring, x, xl, ldx, act, i, g, wave, lane, ntiles, line, step_rows, b0, d0, d1, e0, e1, s_cf, y, ldy);
+    else if (wave == NW - 1) ring_body<MODE, NW, DP, 2, WIDE>(nrows, pid, s_pat, ring, x, xl, ldx, act, i, g, wave, lane, ntiles, line, step_rows, b0, d0, d1, e0, e1, s_cf, y, ldy);
+    else ring_body<MODE, NW, DP, 1, WIDE>(nrows, pid, s_pat, ring, x, xl, ldx, act, i, g, wave, lane, ntiles, line, step_rows, b0, d0, d1, e0, e1, s_cf, y, ldy);
   }
+  if (MODE == 0) return;   // no column sums
   auto sx = [](double v, int mask) {
     int lo = __shfl_xor(__double2loint(v), mask, 64), hi = __shfl_xor(__double2hiint(v), mask, 64);
     return __hiloint2double(hi, lo);
@@ -318,6 +331,11 @@ using namespace gcge_ring;
 
 static int g_ring_on = 1;      // 0: keep spmm_pattern_chain2_kernel for the read-only passes (tuning / A-B measurements)
 static int g_ring_depth = 3;   // planes requested ahead (2 or 3)
+// Y = A X through the ring: off by default — measured 3.44 ms against 3.43-3.46 ms of the chain2 kernel at 256^3 x 64 (the
+// product is bound by its read + write traffic, 18.2 GB at 5.3 TB/s, not by rows in flight); kept, and tested, because it
+// shows the counted waits with stores in the queue (what a ring form of the second CG pass would need)
+static int g_ring_product = getenv("GCGE_RING_PRODUCT") ? atoi(getenv("GCGE_RING_PRODUCT")) : 0;
+extern "C" void gcge_hip_spmm_ring_product(int on) { g_ring_product = on; }
 static int g_ring_wide = 0;    // 1: always 64-bit lane addresses (tests)
 extern "C" void gcge_hip_spmm_ring_wide(int on) { g_ring_wide = on; }
 static int g_ring_xcd = 2;     // 2: runs of 4 neighbouring tiles per XCD (1.75 -> 1.71 ms); 1: one contiguous eighth per XCD; 0: block order
@@ -326,7 +344,7 @@ extern "C" void gcge_hip_spmm_ring_tune(int on, int depth) { g_ring_on = on; if 
 
 template <int MODE, int NW, int DP, bool WIDE>
 static int ring_launch(long nb, hipStream_t st, long nrows, const unsigned short* pid, const void* tab, int ntab, const double* x,
-                       size_t ldx, int m, long ntl, long line, double* part, long yyo, const double* lambda) {
+                       size_t ldx, int m, long ntl, long line, double* part, long yyo, const double* lambda, double* y, size_t ldy) {
   constexpr unsigned PB = Plane<NW>::PB;
   if (ntl > 0x7fffffffL) return -1;
   // tiles of a block: b0, b0 + nb, ... — one grid plane apart when nb is a whole number of line groups
@@ -342,42 +360,55 @@ static int ring_launch(long nb, hipStream_t st, long nrows, const unsigned short
     granted = lds;
   }
   hipLaunchKernelGGL((spmm_ring_kernel<MODE, NW, DP, WIDE>), dim3((unsigned)nb), dim3(64 * NW), lds, st, nrows, pid,
-                     (const PatEntry*)tab, ntab, x, ldx, m, (int)ntl, line, step_rows, g_ring_xcd, part, yyo, lambda);
+                     (const PatEntry*)tab, ntab, x, ldx, m, (int)ntl, line, step_rows, g_ring_xcd, part, yyo, lambda, y, ldy);
   return 0;
 }
 
-// Mode 2 / 4 of gcge_hip_pattern_cg for a [-S, 0, +S, -L, +L, -1, +1] table; same geometry (nb blocks of nw waves,
-// lines of L rows) and the same partial-sum workspace as the chain2 kernel.  -1: not applicable, the caller goes on.
 static long g_ring_launches = 0;
 extern "C" long gcge_hip_spmm_ring_launches(void) { return g_ring_launches; }
 
-template <int NW, bool WIDE>
-static int ring_pass_nw(int mode, long nb, hipStream_t st, long nrows, const unsigned short* pid, const void* tab, int ntab,
-                        const double* x, size_t ldx, int m, long ntl, long L, double* part, long yyo, const double* lambda) {
+template <int MODE, int NW, bool WIDE>
+static int ring_pass_mode(long nb, hipStream_t st, long nrows, const unsigned short* pid, const void* tab, int ntab, const double* x,
+                          size_t ldx, int m, long ntl, long L, double* part, long yyo, const double* lambda, double* y, size_t ldy) {
   int rc = -1;
-  if (g_ring_depth == 3)
-    rc = mode == 2 ? ring_launch<2, NW, 3, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, nullptr)
-                   : ring_launch<4, NW, 3, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda);
-  if (rc != 0)
-    rc = mode == 2 ? ring_launch<2, NW, 2, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, nullptr)
-                   : ring_launch<4, NW, 2, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda);
+  if (g_ring_depth == 3) rc = ring_launch<MODE, NW, 3, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda, y, ldy);
+  if (rc != 0) rc = ring_launch<MODE, NW, 2, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda, y, ldy);
   return rc;
 }
+template <int NW, bool WIDE>
+static int ring_pass_nw(int mode, long nb, hipStream_t st, long nrows, const unsigned short* pid, const void* tab, int ntab,
+                        const double* x, size_t ldx, int m, long ntl, long L, double* part, long yyo, const double* lambda,
+                        double* y, size_t ldy) {
+  switch (mode) {
+    case 0: return ring_pass_mode<0, NW, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, nullptr, 0, nullptr, y, ldy);
+    case 1: return ring_pass_mode<1, NW, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, nullptr, y, ldy);
+    case 2: return ring_pass_mode<2, NW, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, nullptr, nullptr, 0);
+    case 4: return ring_pass_mode<4, NW, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda, nullptr, 0);
+  }
+  return -1;
+}
 
-// maxoff: the largest |column offset| (rows) in the table: decides between 32-bit lane offsets and 64-bit addresses
+// One 16-column launch of the ring sweep on a [-S, 0, +S, -L, +L, -1, +1] table; same geometry (nb blocks of nw waves,
+// lines of L rows) and the same partial-sum workspace as the chain2 kernel.  mode 2 / 4: the passes that store nothing
+// (gcge_hip_pattern_cg); mode 0 / 1: Y = A X (with the column sums) — only when every slice of the sweep lies inside the
+// matrix (the counted waits rely on one store per wave and iteration).  -1: not applicable, the caller goes on.
+// maxoff: the largest |column offset| (rows) in the table: decides between 32-bit lane offsets and 64-bit addresses.
 extern "C" int gcge_hip_ring_pass(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, long L, int nw,
                                   long nb, const double* d_x, long ldx, int m, double* part, long yyo,
-                                  const double* d_lambda, void* stream, long maxoff) {
-  if (!g_ring_on || (mode != 2 && mode != 4) || (nrows & 7) || nrows < 8 || ((uintptr_t)d_pid & 15) || L % 8 || L < 8) return -1;
+                                  const double* d_lambda, void* stream, long maxoff, double* d_y, long ldy) {
+  if (!g_ring_on || (mode != 0 && mode != 1 && mode != 2 && mode != 4) || (nrows & 7) || nrows < 8 || ((uintptr_t)d_pid & 15) || L % 8 || L < 8) return -1;
   if (((uintptr_t)d_x & 15) || (ldx & 1)) return -1;
   const long nlines = ((long)nrows + L - 1) / L, ntl = (nlines + nw - 1) / nw * (L / 8);
+  if (mode <= 1) {
+    if (!g_ring_product || d_y == nullptr || ((uintptr_t)d_y & 15) || (ldy & 1) || ntl * nw * 8 != (long)nrows) return -1;
+  }
   hipStream_t st = (hipStream_t)stream;
   const int ntab = npat * LT;
   int rc = -1;
   // lane offset = 2 GiB + (row in slice, column pair) + stencil offset, as an unsigned 32-bit number
   const bool wide = g_ring_wide || (double)(maxoff + 16) * (double)ldx * 8.0 >= 2147483648.0 - 4096.0;
-#define GCGE_RING_NW(N) (wide ? ring_pass_nw<N, true>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda) \
-                              : ring_pass_nw<N, false>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda))
+#define GCGE_RING_NW(N) (wide ? ring_pass_nw<N, true>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda, d_y, (size_t)ldy) \
+                              : ring_pass_nw<N, false>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda, d_y, (size_t)ldy))
   if (nw == 16) rc = GCGE_RING_NW(16);
   else if (nw == 8) rc = GCGE_RING_NW(8);
   else if (nw == 4) rc = GCGE_RING_NW(4);

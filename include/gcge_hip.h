@@ -176,7 +176,10 @@ int gcge_hip_pattern_cg_near (int mode, int nrows, const unsigned short *d_pid, 
 		long span, long span2, const double *d_x, long ldx, double *d_r, long ldr, double *d_pnew, long ldp, int ncols,
 		const double *d_alpha, const double *d_beta, const int *d_flag, double *d_dots, double *d_dots_yy, void *stream,
 		const double *d_b, long ldb, long near);
+int gcge_hip_pattern_spmm_near (int nrows, const unsigned short *d_pid, const void *d_tab, int npat, int lt, long span, long span2,
+		const double *d_x, long ldx, double *d_y, long ldy, int ncols, double *d_dots, double *d_dots_yy, void *stream, long near);
 void gcge_hip_spmm_ring_tune (int on, int planes_ahead);
+void gcge_hip_spmm_ring_product (int on);    /* 1: Y = A X through the ring as well (default 0: measured no faster, the product is bound by its read + write traffic) */
 void gcge_hip_spmm_ring_wide (int on);      /* 1: 64-bit lane addresses even where 32-bit lane offsets would do (tests) */
 void gcge_hip_spmm_ring_xcd (int on);       /* 1: contiguous tile runs per XCD (fabric reads 12.0 -> 9.9 GB per 64 columns at 256^3, same time) */
 long gcge_hip_spmm_ring_launches (void);   /* 16-column launches the ring sweep has taken so far */

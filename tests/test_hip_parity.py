@@ -831,9 +831,10 @@ def test_ring_sweep_equals_chain_kernel_and_numpy(hip, size, m, depth, wide):
     W = S @ P[:, 2:2 + m]
     lam = uniform(32, (m,)) * 3.0
     Rz = W - P[:, 2:2 + m] * lam
-    out = {}
+    out, prod = {}, {}
     try:
         g.gcge_hip_spmm_ring_wide(wide)
+        g.gcge_hip_spmm_ring_product(1)                   # Y = A X through the ring too (off by default: no faster)
         for on in (1, 0):
             g.gcge_hip_spmm_ring_tune(on, depth)
             n0 = g.gcge_hip_spmm_ring_launches()
@@ -842,16 +843,29 @@ def test_ring_sweep_equals_chain_kernel_and_numpy(hip, size, m, depth, wide):
             assert hook(mat, None, p, 2, 2 + m, lam.ctypes.data, rs.ctypes.data) == 1
             took = g.gcge_hip_spmm_ring_launches() - n0
             assert took == (2 * ((m + 15) // 16) if on else 0), took
+            # Y = A X through the same sweep (one store per wave and iteration, counted with the LDS-DMA pieces)
+            yv = hip.mv_from_numpy(mat, np.full((n, ncol), 3.0))
+            n1 = g.gcge_hip_spmm_ring_launches()
+            hip.ops.spmm(mat, p, yv, (2, 2), (2 + m, 2 + m))
+            took = g.gcge_hip_spmm_ring_launches() - n1
+            assert took == ((m + 15) // 16 if on else 0), took
+            Y = hip.mv_to_numpy(yv, n, 0, ncol)
+            np.testing.assert_allclose(Y[:, 2:2 + m], W, rtol=0, atol=1e-13 * np.abs(W).max())
+            assert np.all(Y[:, :2] == 3.0) and np.all(Y[:, 2 + m:] == 3.0)
+            hip.ops.mv_destroy(yv, ncol)
+            prod[on] = Y[:, 2:2 + m]
             np.testing.assert_allclose(pw, np.sum(P[:, 2:2 + m] * W, axis=0), rtol=1e-12, atol=1e-12 * n)
             np.testing.assert_allclose(ww, np.sum(W * W, axis=0), rtol=1e-12)
             np.testing.assert_allclose(rs, np.sum(Rz * Rz, axis=0), rtol=1e-12)
             out[on] = (pw, ww, rs)
         for a, b in zip(out[1], out[0]):
             np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-13 * n)
+        assert np.array_equal(prod[1], prod[0])          # same sums in the same order: the product is bit-identical
         assert np.array_equal(hip.mv_to_numpy(p, n, 0, ncol), P)
     finally:
         g.gcge_hip_spmm_ring_tune(1, 3)
         g.gcge_hip_spmm_ring_wide(0)
+        g.gcge_hip_spmm_ring_product(0)
     hip.ops.mv_destroy(p, ncol)
     hip.free_matrix(mat)
 

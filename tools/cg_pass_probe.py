@@ -24,6 +24,8 @@ if os.environ.get("RING"):          # "0": chain2 kernel for the read-only passe
     rr = [int(v) for v in os.environ["RING"].split(",")] + [3]
     g.gcge_hip_spmm_ring_tune.argtypes = [C.c_int, C.c_int]
     g.gcge_hip_spmm_ring_tune(rr[0], rr[1])
+if os.environ.get("RING_PRODUCT"):
+    g.gcge_hip_spmm_ring_product(int(os.environ["RING_PRODUCT"]))
 if os.environ.get("RING_WIDE"):
     g.gcge_hip_spmm_ring_wide(int(os.environ["RING_WIDE"]))
 if os.environ.get("RING_XCD"):
@@ -56,4 +58,4 @@ t0 = run(0, lambda: ops.spmm(mA, p, w, (0, 0), (m, m)))
 t2 = run(2, lambda: g.gcge_hip_cg_pass1_mv(mA, p, 0, m, pw.ctypes.data, ww.ctypes.data))
 t3 = run(3, lambda: g.gcge_hip_cg_pass2_mv(mA, p, r, pn, 0, m, al.data_ptr(), be.data_ptr(), fl.data_ptr(), rho.ctypes.data))
 print("N=%d m=%d ld(p)=%d ld(r)=%d nw=%s xcd=%s ring=%s:  product %.3f ms (%.0f GB/s)   pass1 %.3f ms (%.0f GB/s)   pass2 %.3f ms (%.0f GB/s)"
-      % (N, m, vc, vr, os.environ.get("CHAIN2_NW", "16"), os.environ.get("CHAIN2_XCD", "0"), os.environ.get("RING", "1,3") + "/x" + os.environ.get("RING_XCD", "0") + "/w" + os.environ.get("RING_WIDE", "0"), t0[0], t0[1], t2[0], t2[1], t3[0], t3[1]), flush=True)
+      % (N, m, vc, vr, os.environ.get("CHAIN2_NW", "16"), os.environ.get("CHAIN2_XCD", "0"), os.environ.get("RING", "1,3") + "/x" + os.environ.get("RING_XCD", "0") + "/w" + os.environ.get("RING_WIDE", "0") + "/p" + os.environ.get("RING_PRODUCT", "1"), t0[0], t0[1], t2[0], t2[1], t3[0], t3[1]), flush=True)
