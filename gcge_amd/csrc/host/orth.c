@@ -51,6 +51,7 @@ static void project_out(void **x, int s0, int e0, int s1, int e1, void *B,
 	const int kahan = lazy == 2 && B == NULL && getenv("GCGE_ORTH_ABSOLUTE_TEST") == NULL;
 	double *wn = NULL;   /* squared norms of the columns as they enter the next pass */
 	if (k <= 0 || m <= 0) return;
+	if (kahan) wn = (double*)malloc((size_t)m * sizeof(double));   /* (not carved from coef: callers size that as k x m) */
 	for (pass = 0; pass < 1 + max_reorth; ++pass) {
 		start[0] = s0; end[0] = e0; start[1] = s1; end[1] = e1;
 		ops->MultiVecQtAP('S', 'N', x, B, x, 0, start, end, coef, k, mv_ws, ops);
@@ -68,12 +69,12 @@ static void project_out(void **x, int s0, int e0, int s1, int e1, void *B,
 				}
 				if (small) break;
 			}
-			/* the columns as the next pass will see them (coef is free again: the norms go behind it) */
-			wn = coef + (size_t)k * m;
+			/* the columns as the next pass will see them */
 			start[0] = s1; end[0] = e1; start[1] = s1; end[1] = e1;
 			ops->MultiVecInnerProd('D', x, x, 0, start, end, wn, 1, ops);
 		}
 	}
+	free(wn);
 }
 
 /* Column-by-column modified Gram–Schmidt inside x[:, start:*end) in the B inner product. */
