@@ -631,7 +631,18 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       if (want >= 1)
         for (long i = 0; i < want; ++i) { ops->MultiVecCreateByMultiVec(&s->ring[s->ring_len], s->ws_cols, mv_x, ops); ++s->ring_len; }
     }
-    const int R = s->ring_len >= 2 ? s->ring_len : 1;        // ring slots; 1: x is updated in every iteration
+    // Pattern matrices (stencils) with a ring: the product is formed twice and never stored — pass 1 reads p for
+    // p.w and w.w, pass 2 reads p again and applies the r / p update with w rebuilt in registers (app_hip.hip:
+    // gcge_hip_cg_pass1_mv / pass2_mv): 1 + 4 block streams per iteration instead of 2 + 5.  Same recurrences,
+    // same operands, so alpha, beta and the iterates agree with the stored-w form to rounding of the sums.
+    const int R0 = s->ring_len >= 2 ? s->ring_len : 1;
+    const bool recompute = R0 > 1 && sigma == 0.0 && gcge_hip_cg_recompute_pays(mat) && gcge_hip_cg_fusable(mat, s->ring[0], nrhs) && !(nrhs & 1);
+    // the slots of this call: the ring, plus the w block — which the recompute form never writes — as one more slot
+    // (matters where memory is short: at BASELINE config 4's shape a ring of 3 becomes one of 4, x costs 5/3 instead of
+    // 2 block streams per iteration)
+    void** slots[17]; int R = R0;                            // ring slots; 1: x is updated in every iteration
+    for (int q = 0; q < R0; ++q) slots[q] = R0 > 1 ? s->ring[q] : s->mv_ws[1];
+    if (recompute && R < 16 && getenv("GCGE_CG_NO_W_SLOT") == nullptr) slots[R++] = s->mv_ws[2];
     const int J = R - 1;                                     // pending directions before x is brought up to date
     std::vector<double> ahist((size_t)(J > 0 ? J : 1) * nrhs, 0.0);
     int npend = 0, first_slot = 0, cur = 0;                  // p_k lives in ring[cur]; pending: slots first_slot .. (npend of them)
@@ -639,7 +650,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
     auto flush_x = [&]() {
       if (npend == 0) return;
       RingPtrs rp;
-      for (int q = 0; q < 16; ++q) { long ldq; rp.p[q] = gcge_hip_mv_device_ptr(s->ring[(first_slot + (q < npend ? q : 0)) % R], &ldq); }
+      for (int q = 0; q < 16; ++q) { long ldq; rp.p[q] = gcge_hip_mv_device_ptr(slots[(first_slot + (q < npend ? q : 0)) % R], &ldq); }
       d_ahist = gcge_hip_partial_ws((size_t)J * nrhs);
       GCGE_HIP_CHECK(hipMemcpyAsync(d_ahist, ahist.data(), (size_t)npend * nrhs * sizeof(double), hipMemcpyHostToDevice, st));
       const int tpr = cg_tpr(nrhs);
@@ -648,11 +659,6 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       GCGE_HIP_CHECK(hipStreamSynchronize(st));   // ahist (pageable) and the partial workspace are reused right away
       first_slot = (first_slot + npend) % R; npend = 0;
     };
-    // Pattern matrices (stencils) with a ring: the product is formed twice and never stored — pass 1 reads p for
-    // p.w and w.w, pass 2 reads p again and applies the r / p update with w rebuilt in registers (app_hip.hip:
-    // gcge_hip_cg_pass1_mv / pass2_mv): 1 + 4 block streams per iteration instead of 2 + 5.  Same recurrences,
-    // same operands, so alpha, beta and the iterates agree with the stored-w form to rounding of the sums.
-    const bool recompute = R > 1 && sigma == 0.0 && gcge_hip_cg_recompute_pays(mat) && gcge_hip_cg_fusable(mat, s->ring[0], nrhs) && !(nrhs & 1);
     if (nact > 0 && !p0_done) {   // p0 = r0  (ring[0] is mv_ws[1])
       st2[0] = 0; en2[0] = nrhs; st2[1] = 0; en2[1] = nrhs;
       ops->MultiVecAxpby(1.0, s->mv_ws[0], 0.0, s->ring_len ? s->ring[0] : s->mv_ws[1], st2, en2, ops);
@@ -695,7 +701,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       auto flush_x_dev = [&]() {
         if (npend == 0) return;
         RingPtrs rp;
-        for (int q = 0; q < 16; ++q) { long ldq; rp.p[q] = gcge_hip_mv_device_ptr(s->ring[(first_slot + (q < npend ? q : 0)) % R], &ldq); }
+        for (int q = 0; q < 16; ++q) { long ldq; rp.p[q] = gcge_hip_mv_device_ptr(slots[(first_slot + (q < npend ? q : 0)) % R], &ldq); }
         const int tpr = cg_tpr(nrhs);
         long g = ((long)n + (256 / tpr) * 8 - 1) / ((256 / tpr) * 8); if (g > 8192) g = 8192; if (g < 1) g = 1;
         hipLaunchKernelGGL(cg_accum_x, dim3((unsigned)g), dim3(256), 0, st, (long)n, rp, npend, ldp, dx, ldx, nrhs, d_ahist2, tpr);
@@ -705,12 +711,12 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       int done = -1;          // index of the last iteration whose active count the host has seen
       int stop_at = -1;       // first iteration that found no active column at its start
       while (enq < s->max_iter && enq < 4096) {
-        void** pcur = s->ring[cur];
+        void** pcur = slots[cur];
         if (gcge_hip_cg_pass1_dev(mat, pcur, 0, nrhs, d_sums) != 0) { fprintf(stderr, "HIP_BlockPCG: first CG pass refused operands it had accepted\n"); abort(); }
         if (reduce) gcge_hip_comm_allreduce_device(d_sums, 2 * nrhs);
         hipLaunchKernelGGL(cg_scalars_a, dim3(1), dim3(256), 0, st, nrhs, d_rho2, d_sums, d_active, d_alpha, d_beta, d_flag2,
                            d_ahist2 + (size_t)npend * nrhs);
-        if (gcge_hip_cg_pass2_dev(mat, pcur, s->mv_ws[0], s->ring[(cur + 1) % R], 0, nrhs, d_alpha, d_beta, d_flag2, d_newrho) != 0) {
+        if (gcge_hip_cg_pass2_dev(mat, pcur, s->mv_ws[0], slots[(cur + 1) % R], 0, nrhs, d_alpha, d_beta, d_flag2, d_newrho) != 0) {
           fprintf(stderr, "HIP_BlockPCG: second CG pass refused operands it had accepted\n"); abort();
         }
         if (reduce) gcge_hip_comm_allreduce_device(d_newrho, nrhs);
@@ -749,7 +755,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       }
       int aw = ahi - alo;
       if (((alo & 1) || (aw & 1))) { alo &= ~1; ahi = (ahi + 1) & ~1; aw = ahi - alo; }   // keep 16-byte column pairs
-      void** pcur = R > 1 ? s->ring[cur] : s->mv_ws[1];
+      void** pcur = slots[cur];
       if (recompute) {
         if (gcge_hip_cg_pass1_mv(mat, pcur, alo, aw, pTw.data() + alo, wTw.data() + alo) != 0) {
           fprintf(stderr, "HIP_BlockPCG: first CG pass refused operands it had accepted\n"); abort();
@@ -773,7 +779,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       upload(alo, aw, bet.data(), coef.data(), flag.data());   // d_coef = [beta | alpha]
       std::vector<double> newrho(aw);
       if (recompute) {
-        if (gcge_hip_cg_pass2_mv(mat, pcur, s->mv_ws[0], s->ring[(cur + 1) % R], alo, aw, s->d_coef + s->cap, s->d_coef,
+        if (gcge_hip_cg_pass2_mv(mat, pcur, s->mv_ws[0], slots[(cur + 1) % R], alo, aw, s->d_coef + s->cap, s->d_coef,
                                  s->d_flag, newrho.data()) != 0) {
           fprintf(stderr, "HIP_BlockPCG: second CG pass refused operands it had accepted\n"); abort();
         }
@@ -783,8 +789,8 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       double* part = gcge_hip_partial_ws((size_t)nb * aw + aw + (size_t)(J > 0 ? J : 0) * nrhs);
       if (R > 1) {
         long ldq;
-        const double* pold = gcge_hip_mv_device_ptr(s->ring[cur], &ldq);
-        double* pnew = gcge_hip_mv_device_ptr(s->ring[(cur + 1) % R], &ldq);
+        const double* pold = gcge_hip_mv_device_ptr(slots[cur], &ldq);
+        double* pnew = gcge_hip_mv_device_ptr(slots[(cur + 1) % R], &ldq);
         hipLaunchKernelGGL(cg_update_rp<4>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr,
                            pold + alo, pnew + alo, ldp, aw, s->d_coef + s->cap, s->d_coef, s->d_flag, part, cg_tpr(aw));
         for (int j = 0; j < nrhs; ++j) ahist[(size_t)npend * nrhs + j] = (j >= alo && j < ahi && active[j]) ? coef[j] : 0.0;
