@@ -643,6 +643,21 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
     void** slots[17]; int R = R0;                            // ring slots; 1: x is updated in every iteration
     for (int q = 0; q < R0; ++q) slots[q] = R0 > 1 ? s->ring[q] : s->mv_ws[1];
     if (recompute && R < 16 && getenv("GCGE_CG_NO_W_SLOT") == nullptr) slots[R++] = s->mv_ws[2];
+    // ... and the blocks the caller declared idle for the duration of the solve (GCGE_SetLinearSolverIdleBlocks), where
+    // they have the shape of the ring's own blocks (same rows, same leading dimension, 16-byte aligned, room for the halo)
+    if (recompute && getenv("GCGE_CG_NO_IDLE_SLOTS") == nullptr) {
+      int nidle = 0; void*** idle = GCGE_GetLinearSolverIdleBlocks(&nidle);
+      for (int q = 0; q < nidle && R < 16; ++q) {
+        void** hb = idle[q];
+        if (hb == nullptr || hb == mv_x || hb == mv_b || gcge_hip_mv_nrows(hb) != n) continue;
+        bool dup = false;
+        for (int t = 0; t < R; ++t) dup |= slots[t] == hb;
+        for (int t = 0; t < 4; ++t) dup |= s->mv_ws[t] == hb;
+        long ldq = 0;
+        if (dup || gcge_hip_mv_device_ptr(hb, &ldq) == nullptr || ldq != ldp || !gcge_hip_cg_fusable(mat, hb, nrhs)) continue;
+        slots[R++] = hb;
+      }
+    }
     const int J = R - 1;                                     // pending directions before x is brought up to date
     std::vector<double> ahist((size_t)(J > 0 ? J : 1) * nrhs, 0.0);
     int npend = 0, first_slot = 0, cur = 0;                  // p_k lives in ring[cur]; pending: slots first_slot .. (npend of them)

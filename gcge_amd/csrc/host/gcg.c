@@ -272,7 +272,12 @@ static void ComputeW(Ctx *c, int *offset)
 	}
 	if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverShift(sigma, c->B);
 	if (scaled_rhs) GCGE_SetLinearSolverRhsScale(scales);
+	if (p->user_defined_multi_linear_solver == 1) {   /* the work blocks are idle until the orthonormalisation below */
+		cg_ws[0] = c->ws0; cg_ws[1] = c->ws1; cg_ws[2] = c->ws2;
+		GCGE_SetLinearSolverIdleBlocks(cg_ws, 3);
+	}
 	ops->MultiLinearSolver(c->A, b, c->V, s, e, ops);
+	GCGE_SetLinearSolverIdleBlocks(NULL, 0);
 	if (scaled_rhs) GCGE_SetLinearSolverRhsScale(NULL);
 	if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverShift(0.0, NULL);
 	if (sigma != 0.0 && c->B != NULL && ops->MatAxpby != NULL

@@ -46,6 +46,9 @@ int GCGE_HasRhsScaleCapability(void *owner)
 }
 void GCGE_SetLinearSolverRhsScale(const double *scale) { g_rhs_scale = scale; }
 const double *GCGE_GetLinearSolverRhsScale(void) { return g_rhs_scale; }
+static void ***g_idle_blocks = NULL; static int g_idle_count = 0;
+void GCGE_SetLinearSolverIdleBlocks(void ***blocks, int count) { g_idle_blocks = blocks; g_idle_count = blocks != NULL ? count : 0; }
+void ***GCGE_GetLinearSolverIdleBlocks(int *count) { if (count != NULL) *count = g_idle_count; return g_idle_blocks; }
 static void *g_inplace_owner = NULL; static int g_inplace_cols = 0;
 void GCGE_SetInplaceLinearComb(void *owner, int max_cols) { g_inplace_owner = owner; g_inplace_cols = max_cols; }
 int GCGE_InplaceLinearCombCols(void *owner)

@@ -164,6 +164,12 @@ void       GCGE_SetRhsScaleCapability (void *owner);
 int        GCGE_HasRhsScaleCapability (void *owner);
 void       GCGE_SetLinearSolverRhsScale (const double *scale);   /* NULL: b is an ordinary right-hand side */
 const double *GCGE_GetLinearSolverRhsScale (void);
+/* Blocks of vectors the driver does not need while MultiLinearSolver runs (its orthonormalisation / residual work
+ * blocks: contents dead across the call).  A solver may use them as scratch — the fused HIP solver takes those that
+ * match its own work blocks as additional slots of its direction ring, which is what limits it when HBM is nearly
+ * full (BASELINE config 4's shape: 244 of 288 GB are the solver stack's own blocks).  Valid only during the call. */
+void       GCGE_SetLinearSolverIdleBlocks (void ***blocks, int count);
+void    ***GCGE_GetLinearSolverIdleBlocks (int *count);
 /* Optional capability: a back-end whose MultiVecLinearComb works ROW BY ROW (row-major blocks: every output row is
  * formed from the same row of x and written after that row has been read) may declare panel updates IN PLACE safe:
  * y == x with the output columns inside the input column range, at most `max_cols` output columns per call.  The
