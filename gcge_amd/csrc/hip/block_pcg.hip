@@ -649,7 +649,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       int nidle = 0; void*** idle = GCGE_GetLinearSolverIdleBlocks(&nidle);
       for (int q = 0; q < nidle && R < 16; ++q) {
         void** hb = idle[q];
-        if (hb == nullptr || hb == mv_x || hb == mv_b || gcge_hip_mv_nrows(hb) != n) continue;
+        if (hb == nullptr || hb == mv_x || hb == mv_b || gcge_hip_mv_nrows(hb) != n || gcge_hip_mv_ncols(hb) < nrhs) continue;
         bool dup = false;
         for (int t = 0; t < R; ++t) dup |= slots[t] == hb;
         for (int t = 0; t < 4; ++t) dup |= s->mv_ws[t] == hb;

@@ -805,6 +805,38 @@ def test_fused_cg_small_direction_ring(hip):
     hip.free_matrix(mat)
 
 
+def test_gcg_small_ring_takes_the_idle_blocks(hip):
+    """With the ring capped at 3 (GCGE_CG_RING: what memory leaves at BASELINE config 4's shape) the fused solver adds its
+    never-written w block and the blocks the driver declares idle (GCGE_SetLinearSolverIdleBlocks) as further slots: x is
+    then brought up to date every 6th instead of every 2nd iteration — same eigensolve; with those extras switched off
+    (GCGE_CG_NO_W_SLOT, GCGE_CG_NO_IDLE_SLOTS) likewise."""
+    import os
+    g = hip.g
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    g.gcge_hip_bpcg_release.argtypes = [C.c_void_p]
+    hip.set_random_mode(0)
+    args = ["-nevConv", 20, "-blockSize", 16, "-nevMax", 48, "-gcge_initX_orth_method", "chol", "-gcge_compW_orth_method", "chol"]
+    out = {}
+    try:
+        for name, env in (("full", {}), ("ring3", {"GCGE_CG_RING": "3"}),
+                          ("ring3 plain", {"GCGE_CG_RING": "3", "GCGE_CG_NO_W_SLOT": "1", "GCGE_CG_NO_IDLE_SLOTS": "1"})):
+            os.environ.update(env)
+            g.gcge_hip_bpcg_release(hip.ops_handle)          # the ring is created with the workspace
+            g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+            try:
+                ev, res = gcg_on(hip, "lap3d", 32, args, flag=1)
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+            out[name] = (np.array(ev[:res.nevConv]), res.nevConv, res.numIter)
+    finally:
+        g.gcge_hip_bpcg_release(hip.ops_handle)
+        g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    for name in ("ring3", "ring3 plain"):
+        assert out[name][1] == out["full"][1] >= 20 and abs(out[name][2] - out["full"][2]) <= 1, (name, out[name][1:], out["full"][1:])
+        assert np.max(np.abs(out[name][0] - out["full"][0]) / np.abs(out["full"][0])) < 1e-10
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("size,m,depth,wide", [(16, 16, 3, 0), (16, 22, 2, 1), (24, 64, 3, 0), (32, 16, 3, 1), (40, 6, 3, 0),
                                                (48, 34, 2, 0), (64, 64, 3, 0), (64, 64, 3, 1)])
