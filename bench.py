@@ -316,11 +316,13 @@ def main():
         npass = (args.block + 15) // 16 if npat > 0 else 1
         g.gcge_hip_spmm_ring_launches.restype = C.c_long
         ring_launches = g.gcge_hip_spmm_ring_launches()
+        g.gcge_hip_bpcg_implicit_r_iters.restype = C.c_long
+        implicit_r = g.gcge_hip_bpcg_implicit_r_iters()
 
         def roof(kind, what, streams):
             # `achieved` prices a launch at its ALGORITHMIC bytes: kind 0: SURVEY.md 8(d), 12 B per
             # non-zero + row pointers + X read + Y written; kind 2: matrix + p read; kind 3: matrix + p, r read + r,
-            # p_new written.  `required` is what the pattern kernels must move at least: `streams` block streams of
+            # p_new written — or, without a stored residual (kernel MODE 7), matrix + p, p_prev read + p_new written.  `required` is what the pattern kernels must move at least: `streams` block streams of
             # 8 n m bytes + 2 B of pattern id per row and 16-column pass (the matrix is not read as CSR there).
             # One "launch" = the `npass` kernel launches of 16 columns that make up one m-column operation (rocprof
             # lists the 16-column launches).
@@ -331,6 +333,9 @@ def main():
             kname = "%s<7,%d,16>" % (kbase, kind)
             if kind == 2 and ring_launches > 0:   # the read-only pass ran the LDS-ring sweep (spmm_ring.hip), 3 planes ahead
                 kname = "spmm_ring<2,16,3,false>"
+            if kind == 3 and implicit_r > 0:      # second pass without a stored residual (kernel MODE 7): 3 block streams
+                kname = "%s<7,7,16>" % kbase
+                streams = 3
             traffic, note = pmc_traffic(kname, N, args.block) if (npat > 0 and world == 1) else (None, "no PMC profile for this shape")
             req = (8.0 * streams * args.block + 2.0 * npass) * A.nrows if npat > 0 else by_ / c_
             return {"bound": "hbm", "kernel": "%s x %d passes of 16 columns: %s (%d row patterns, m=%d)"
@@ -342,7 +347,8 @@ def main():
 
         r_k1 = roof(0, "Y = A X, K1 (MatDotMultiVec)", 2)
         r_p1 = roof(2, "CG pass 1, p.Ap and |Ap|^2 without storing Ap", 1)
-        r_p2 = roof(3, "CG pass 2, Ap recomputed + r -= alpha Ap, p' = r + beta p", 4)
+        r_p2 = roof(3, "CG pass 2, Ap recomputed + r = p - beta_prev p_prev - alpha Ap (no stored residual), p' = r + beta p" if implicit_r > 0
+                    else "CG pass 2, Ap recomputed + r -= alpha Ap, p' = r + beta p", 4)
         cands = [r for r in (r_k1, r_p1, r_p2) if r is not None]
         dominant = max(cands, key=lambda r: r["share_of_step"]) if cands else None
         out = {

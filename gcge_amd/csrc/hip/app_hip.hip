@@ -936,6 +936,42 @@ extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, 
   return 0;
 }
 
+// The same second pass WITHOUT a stored residual (kernel MODE 7): r_k = p_k - beta_{k-1} p_{k-1} is rebuilt from the previous
+// direction (pprev, read only; d_betaprev: the beta that formed p_k — zeros in the first iteration, where pprev may be p
+// itself), pnew[:, c0:c0+m) = r' diag(cr) + p diag(cb) with r' = r_k - (A p) diag(alpha), d_rho[j] = sum_r cr_j r'[r,j]^2.
+// Reads p, pprev, writes pnew: 3 block streams instead of 4.
+extern "C" int gcge_hip_cg_pass2i_dev(void* mat, void** p, void** pprev, void** pnew, int c0, int m, const double* d_alpha,
+                                      const double* d_beta, const int* d_flag, const double* d_betaprev, double* d_rho) {
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
+  GcgeHipMV *vp = (GcgeHipMV*)p, *vq = (GcgeHipMV*)pprev, *vn = (GcgeHipMV*)pnew;
+  if (!gcge_hip_cg_fusable(mat, p, m) || (c0 & 1) || (vq->ld & 1) || (vn->ld & 1) || ((uintptr_t)vq->d & 15) ||
+      ((uintptr_t)vn->d & 15) || vn == vp || vn == vq || d_betaprev == nullptr) return -1;
+  GCGE_REQUIRE(c0 >= 0 && c0 + m <= vp->ncols && c0 + m <= vq->ncols && c0 + m <= vn->ncols, "cg_pass2i: column ranges");
+  GCGE_REQUIRE(A->nrows == vp->nrows && A->nrows == vq->nrows && A->nrows == vn->nrows, "cg_pass2i: row counts");
+  SpmmEvent ev;
+  if (g_prof_on) {   // algorithmic bytes: matrix once, p and p_prev read, p_new written
+    GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
+    ev.m = m; ev.kind = 3;
+    ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 24.0 * (double)A->nrows * m;
+    GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
+  }
+  const CgPass cg = {7, vq->d + c0, vq->ld, vn->d + c0, vn->ld, d_alpha, d_beta, d_flag, d_betaprev, 0};
+  const int rc = spmm_rows(A, 0, A->nrows, vp->d + c0, vp->ld, nullptr, 0, m, d_rho, nullptr, &cg);
+  if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
+  GCGE_REQUIRE(rc == 0, "cg_pass2i: kernel launch");
+  return 0;
+}
+extern "C" int gcge_hip_cg_pass2i_mv(void* mat, void** p, void** pprev, void** pnew, int c0, int m, const double* d_alpha,
+                                     const double* d_beta, const int* d_flag, const double* d_betaprev, double* host_rho) {
+  double* dd = stage_d(6 * (size_t)m);
+  if (gcge_hip_cg_pass2i_dev(mat, p, pprev, pnew, c0, m, d_alpha, d_beta, d_flag, d_betaprev, dd) != 0) return -1;
+  double* hd = stage_h((size_t)m);
+  GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+  memcpy(host_rho, hd, m * sizeof(double));
+  return 0;
+}
+
 // Start of the block CG in one sweep (kernel MODE 5): r[:, rc0:rc0+m) = b[:, bc0:bc0+m) - A x[:, xc0:xc0+m), p0 = r (same
 // columns rc0.. of the block p0), host_rho[j] = sum over the LOCAL rows of r[r,j]^2.  Fetches the halo rows of x.
 // -1 without touching anything when matrix or operands do not qualify.

@@ -55,6 +55,8 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
                                       struct OPS_* ops);
 extern "C" int gcge_hip_cg_fusable(void* mat, void** p, int ncols);
 extern "C" int gcge_hip_cg_recompute_pays(void* mat);
+extern "C" int gcge_hip_cg_pass2i_dev(void* mat, void** p, void** pprev, void** pnew, int c0, int m, const double* d_alpha,
+                                      const double* d_beta, const int* d_flag, const double* d_betaprev, double* d_rho);
 extern "C" int gcge_hip_cg_start_scaled_mv(void* mat, void** x, int xc0, const double* host_scale, void** r, void** p0, int rc0,
                                            int m, double* host_rho);
 extern "C" int gcge_hip_cg_start_mv(void* mat, void** x, int xc0, void** b, int bc0, void** r, void** p0, int rc0, int m,
@@ -451,6 +453,7 @@ struct HipBpcg {
   long total_iters; double total_seconds;   // CG iterations and host wall time over all calls (bench.py: ms per CG iteration)
   double* d_sc; int* d_sci; int* h_nact; int sc_cap; hipEvent_t ev_it[2];   // device-side scalars of the recompute form
   long dev_scalar_iters;
+  long implicit_r_iters;    // iterations of the device-scalar loop that rebuilt r from two directions (no stored residual)
 };
 static HipBpcg g_bpcg = {30, 1e-2, 1e-14, "abs", {nullptr, nullptr, nullptr, nullptr}, {nullptr}, 0, 0, 0, 0, -1.0, 0, 0, nullptr, nullptr, nullptr, 0};
 
@@ -701,6 +704,18 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
              *d_beta = d_alpha + cap, *d_sums = d_beta + cap /* 6 cap */, *d_newrho = d_sums + 6 * cap /* 6 cap */,
              *d_ahist2 = d_newrho + 6 * cap /* 16 cap, starts at 18 cap: (30 + 16) cap in total */;
       int *d_active = s->d_sci, *d_flag2 = d_active + cap;
+      // The residual is not stored (GCGE_CG_EXPLICIT_R=1: it is): r_k = p_k - beta_{k-1} p_{k-1} is rebuilt in the second
+      // pass from the previous direction, which the ring still holds (3 slots suffice: p_{k-1}, p_k, p_{k+1}) — the pass
+      // then reads p_k, p_{k-1} and writes p_{k+1}: 3 block streams instead of 4, 5.1 instead of 6.1 per iteration.  Same
+      // recurrence in exact arithmetic; in floating point the rebuilt r_k carries a rounding error of eps |p_k| instead
+      // of eps |r_k| — immaterial for systems solved to a relative 1e-2 (kernel MODE 7, spmm_pattern.hip).
+      static const bool explicit_r = getenv("GCGE_CG_EXPLICIT_R") != nullptr;
+      const bool implicit_r = R >= 3 && !explicit_r;
+      double* d_betaB = d_ahist2 + 16 * cap;   // second beta buffer: beta_k and beta_{k-1} alternate between the two
+      if (implicit_r) {
+        GCGE_HIP_CHECK(hipMemsetAsync(d_beta, 0, cap * sizeof(double), st));
+        GCGE_HIP_CHECK(hipMemsetAsync(d_betaB, 0, cap * sizeof(double), st));
+      }
       {   // start values (rho, initial residuals, scales, active flags were computed on the host above)
         std::vector<double> up(3 * (size_t)nrhs);
         memcpy(up.data(), rho2.data(), nrhs * sizeof(double)); memcpy(up.data() + nrhs, init_res.data(), nrhs * sizeof(double));
@@ -729,11 +744,17 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
         void** pcur = slots[cur];
         if (gcge_hip_cg_pass1_dev(mat, pcur, 0, nrhs, d_sums) != 0) { fprintf(stderr, "HIP_BlockPCG: first CG pass refused operands it had accepted\n"); abort(); }
         if (reduce) gcge_hip_comm_allreduce_device(d_sums, 2 * nrhs);
-        hipLaunchKernelGGL(cg_scalars_a, dim3(1), dim3(256), 0, st, nrhs, d_rho2, d_sums, d_active, d_alpha, d_beta, d_flag2,
+        double* bcur = (implicit_r && (enq & 1)) ? d_betaB : d_beta;
+        const double* bprev = (enq & 1) ? d_beta : d_betaB;
+        hipLaunchKernelGGL(cg_scalars_a, dim3(1), dim3(256), 0, st, nrhs, d_rho2, d_sums, d_active, d_alpha, bcur, d_flag2,
                            d_ahist2 + (size_t)npend * nrhs);
-        if (gcge_hip_cg_pass2_dev(mat, pcur, s->mv_ws[0], slots[(cur + 1) % R], 0, nrhs, d_alpha, d_beta, d_flag2, d_newrho) != 0) {
-          fprintf(stderr, "HIP_BlockPCG: second CG pass refused operands it had accepted\n"); abort();
-        }
+        int rc2;
+        if (implicit_r) {
+          rc2 = gcge_hip_cg_pass2i_dev(mat, pcur, enq == 0 ? pcur : slots[(cur + R - 1) % R], slots[(cur + 1) % R], 0, nrhs, d_alpha, bcur,
+                                       d_flag2, bprev, d_newrho);
+          ++s->implicit_r_iters;
+        } else rc2 = gcge_hip_cg_pass2_dev(mat, pcur, s->mv_ws[0], slots[(cur + 1) % R], 0, nrhs, d_alpha, d_beta, d_flag2, d_newrho);
+        if (rc2 != 0) { fprintf(stderr, "HIP_BlockPCG: second CG pass refused operands it had accepted\n"); abort(); }
         if (reduce) gcge_hip_comm_allreduce_device(d_newrho, nrhs);
         hipLaunchKernelGGL(cg_scalars_b, dim3(1), dim3(256), 0, st, nrhs, d_newrho, s->rate, s->tol, d_normb, d_init, d_rho2, d_active,
                            d_last, s->h_nact + enq);
@@ -940,6 +961,7 @@ extern "C" void gcge_hip_bpcg_stats(long* spmm_calls, long* spmm_cols, int* last
 }
 extern "C" long gcge_hip_bpcg_recompute_iters(void) { return g_bpcg.recompute_iters; }
 extern "C" long gcge_hip_bpcg_device_scalar_iters(void) { return g_bpcg.dev_scalar_iters; }
+extern "C" long gcge_hip_bpcg_implicit_r_iters(void) { return g_bpcg.implicit_r_iters; }
 extern "C" void gcge_hip_bpcg_time_stats(long* iters, double* seconds, int reset) {
   if (iters) *iters = g_bpcg.total_iters;
   if (seconds) *seconds = g_bpcg.total_seconds;

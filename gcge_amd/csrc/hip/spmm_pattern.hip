@@ -53,6 +53,9 @@ struct PatEntry { double val; long off; };   // 16 bytes: one ds_read_b128
 //        R[r,j] -= alpha_j w[r,j] ;  PNEW[r,j] = cr_j R[r,j] + cb_j X[r,j] ;  partial: sum_r cr_j R[r,j]^2
 //      with (alpha, cb, cr) = flag_j ? (alpha_j, beta_j, 1) : (0, 1, 0) exactly as cg_update_rp (retired columns are
 //      copied).  X = p_k, PNEW = p_{k+1} must be different blocks: neighbours still read X.
+//   7  mode 3 without a stored residual: the block passed as R holds p_{k-1}, cg.b the previous iteration's beta, and
+//      r_k = p_k - beta_{k-1} p_{k-1} is rebuilt on the spot (p_k = r_k + beta_{k-1} p_{k-1} is how p_k was formed); only
+//      PNEW is written: 3 block streams instead of 4.  Retired columns (flag 0) are copied as in mode 3.
 //   5  start of the block CG: R[r,j] = B[r,j] - (A X)[r,j], PNEW = R (p_0 = r_0), partial: sum_r R[r,j]^2, with
 //      B = cg.b the right-hand sides and X the initial guess: one sweep instead of product, axpby, column dots and copy
 //   6  mode 5 with the right-hand side B = X diag(scale) (scale = cg.alpha) formed on the fly from the row's own X value:
@@ -60,9 +63,9 @@ struct PatEntry { double val; long off; };   // 16 bytes: one ds_read_b128
 //   4  residual norms of Ritz pairs (standard problem): partial: sum_r ((A X)[r,j] - lambda_j X[r,j])^2 with
 //      lambda = cg.alpha; nothing is stored (CheckConvergence of the GCG driver, one read of X instead of 11 streams)
 struct CgArgs { double* r; size_t ldr; double* pnew; size_t ldp; const double* alpha; const double* beta; const int* flag; const double* b; size_t ldb; };
-struct CgCoef { double al0, al1, cb0, cb1, cr0, cr1; };
+struct CgCoef { double al0, al1, cb0, cb1, cr0, cr1, bp0, bp1; };
 __device__ __forceinline__ CgCoef cg_coef(const CgArgs& cg, int j, bool act) {
-  CgCoef c = {0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
+  CgCoef c = {0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0};
   if (act) {
     const int f0 = cg.flag[j], f1 = cg.flag[j + 1];
     if (f0) { c.al0 = cg.alpha[j]; c.cb0 = cg.beta[j]; c.cr0 = 1.0; }
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
     const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
     double* __restrict__ dot_partial, long yy_offset, CgArgs cg) {
   constexpr int DOT = MODE != 0;       // the row's own X value rides in buf[LT]
-  constexpr int UPD = MODE == 3 || MODE == 5;   // its R value (MODE 5: right-hand side) in buf[LT + 1]
+  constexpr int UPD = MODE == 3 || MODE == 5 || MODE == 7;   // its R value (MODE 5: right-hand side, MODE 7: p_{k-1}) in buf[LT + 1]
   constexpr int RES = MODE == 4;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
@@ -90,7 +93,8 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
   const double* __restrict__ xl = x + (act ? 2 * i : 0);   // idle lanes of a narrow last pass re-read column 0
   const double* __restrict__ rl = UPD ? (MODE == 5 ? cg.b : cg.r) + (act ? 2 * i : 0) : nullptr;
   const size_t ldrl = MODE == 5 ? cg.ldb : cg.ldr;
-  CgCoef cf = MODE == 3 ? cg_coef(cg, 2 * i, act) : CgCoef{0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
+  CgCoef cf = (MODE == 3 || MODE == 7) ? cg_coef(cg, 2 * i, act) : CgCoef{0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0};
+  if (MODE == 7 && act) { cf.bp0 = cg.b[2 * i]; cf.bp1 = cg.b[2 * i + 1]; }   // beta of the previous iteration
   if ((RES || MODE == 6) && act) { cf.al0 = cg.alpha[2 * i]; cf.al1 = cg.alpha[2 * i + 1]; }   // lambda / rhs scale of this lane's column pair
   double d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;   // x.y and y.y column sums (DOT)
 
@@ -139,12 +143,14 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
         }
         d0 = fma(wgt * rn.x, rn.x, d0); d1 = fma(wgt * rn.y, rn.y, d1);
       }
-      if (MODE == 3) {
-        const v2d rv = buf[LT + DOT], pv = buf[LT];
+      if (MODE == 3 || MODE == 7) {
+        const v2d pv = buf[LT];
+        v2d rv = buf[LT + DOT];
+        if (MODE == 7) rv = v2d{fma(-cf.bp0, rv.x, pv.x), fma(-cf.bp1, rv.y, pv.y)};   // r_k = p_k - beta_{k-1} p_{k-1}
         v2d rn = {fma(-cf.al0, a0, rv.x), fma(-cf.al1, a1, rv.y)};
         v2d pn = {fma(cf.cb0, pv.x, cf.cr0 * rn.x), fma(cf.cb1, pv.y, cf.cr1 * rn.y)};
         if (ok) {
-          __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.r + (size_t)row * cg.ldr + 2 * i));
+          if (MODE == 3) __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.r + (size_t)row * cg.ldr + 2 * i));
           __builtin_nontemporal_store(pn, reinterpret_cast<v2d*>(cg.pnew + (size_t)row * cg.ldp + 2 * i));
         }
         d0 = fma(cf.cr0 * wgt * rn.x, rn.x, d0); d1 = fma(cf.cr1 * wgt * rn.y, rn.y, d1);
@@ -332,7 +338,7 @@ __device__ __forceinline__ void chain2_body(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* s_tab, v2d (*xch)[NW][64],
     const double* __restrict__ xl, size_t ldx, double* __restrict__ y, size_t ldy, bool act, int i, int g, int wave, int lane,
     long ntiles, long line, int xcd_runs, double& d0, double& d1, double& e0, double& e1, const CgArgs& cg, const v2d* s_cf) {
-  constexpr int UPD = MODE == 3 || MODE == 5;
+  constexpr int UPD = MODE == 3 || MODE == 5 || MODE == 7;
   const double* __restrict__ rl = UPD ? (MODE == 5 ? cg.b : cg.r) + (act ? 2 * i : 0) : nullptr;
   const size_t ldrl = MODE == 5 ? cg.ldb : cg.ldr;
   constexpr int NO = LT - 5;               // slots that are neither chain nor line
@@ -406,13 +412,14 @@ __device__ __forceinline__ void chain2_body(
       }
       d0 = fma(wgt * rn.x, rn.x, d0); d1 = fma(wgt * rn.y, rn.y, d1);
     }
-    if (MODE == 3) {   // coefficients of this lane's column pair from LDS (kept out of the registers: 4 waves per SIMD)
+    if (MODE == 3 || MODE == 7) {   // coefficients of this lane's column pair from LDS (kept out of the registers: 4 waves per SIMD)
       const v2d al = s_cf[i], cb = s_cf[8 + i], cr = s_cf[16 + i];
-      const v2d rv = oth[NO + UPD];
+      v2d rv = oth[NO + UPD];
+      if (MODE == 7) { const v2d bp = s_cf[24 + i]; rv = v2d{fma(-bp.x, rv.x, b.x), fma(-bp.y, rv.y, b.y)}; }   // r_k = p_k - beta_{k-1} p_{k-1}
       v2d rn = {fma(-al.x, a0, rv.x), fma(-al.y, a1, rv.y)};
       v2d pn = {fma(cb.x, b.x, cr.x * rn.x), fma(cb.y, b.y, cr.y * rn.y)};
       if (ok) {
-        __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.r + (size_t)row * cg.ldr + 2 * i));
+        if (MODE == 3) __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.r + (size_t)row * cg.ldr + 2 * i));
         __builtin_nontemporal_store(pn, reinterpret_cast<v2d*>(cg.pnew + (size_t)row * cg.ldp + 2 * i));
       }
       d0 = fma(cr.x * wgt * rn.x, rn.x, d0); d1 = fma(cr.y * wgt * rn.y, rn.y, d1);
@@ -468,11 +475,12 @@ __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
   __shared__ v2d xch[2][NW][64];
-  __shared__ v2d s_cf[24];   // MODE 3: (alpha, cb, cr) of the 8 column pairs of this pass
+  __shared__ v2d s_cf[32];   // MODE 3 / 7: (alpha, cb, cr [, previous beta]) of the 8 column pairs of this pass
   for (int e = threadIdx.x; e < ntab; e += 64 * NW) s_tab[e] = tab[e];
-  if (MODE == 3 && threadIdx.x < 8) {
+  if ((MODE == 3 || MODE == 7) && threadIdx.x < 8) {
     const CgCoef c = cg_coef(cg, 2 * threadIdx.x, 2 * (int)threadIdx.x < m);
     s_cf[threadIdx.x] = v2d{c.al0, c.al1}; s_cf[8 + threadIdx.x] = v2d{c.cb0, c.cb1}; s_cf[16 + threadIdx.x] = v2d{c.cr0, c.cr1};
+    if (MODE == 7) s_cf[24 + threadIdx.x] = (2 * (int)threadIdx.x < m) ? v2d{cg.b[2 * threadIdx.x], cg.b[2 * threadIdx.x + 1]} : v2d{0.0, 0.0};
   }
   if ((MODE == 4 || MODE == 6) && threadIdx.x < 8)
     s_cf[threadIdx.x] = (2 * (int)threadIdx.x < m) ? v2d{cg.alpha[2 * threadIdx.x], cg.alpha[2 * threadIdx.x + 1]} : v2d{0.0, 0.0};
@@ -725,10 +733,11 @@ extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned shor
                                         long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
                                         long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
                                         double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, long near) {
-  if (mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 6) return -1;
+  if (mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 6 && mode != 7) return -1;
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || ((uintptr_t)d_x & 15) || d_dots == nullptr) return -1;
   if (mode == 6 && d_alpha == nullptr) return -1;
+  if (mode == 7 && (d_b == nullptr || (ldr & 1) || (ldp & 1) || ((uintptr_t)d_r & 15) || ((uintptr_t)d_pnew & 15) || d_pnew == d_x || d_pnew == d_r)) return -1;
   if ((mode == 3 || mode == 5 || mode == 6) && ((ldr & 1) || (ldp & 1) || ((uintptr_t)d_r & 15) || ((uintptr_t)d_pnew & 15) || d_pnew == d_x || d_r == d_x)) return -1;
   if (mode == 5 && (d_b == nullptr || (ldb & 1) || ((uintptr_t)d_b & 15))) return -1;
   if ((size_t)npat * lt * sizeof(PatEntry) > 64 * 1024) return -1;
@@ -764,6 +773,9 @@ extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned shor
     } else if (mode == 6) {
       const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, nullptr, nullptr, nullptr, 0};
       rc = pat_dispatch<6>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
+    } else if (mode == 7) {   // d_r: p_{k-1} (read only), d_b: the previous iteration's beta
+      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0, d_b + c0, 0};
+      rc = pat_dispatch<7>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
     } else {
       const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0, nullptr, 0};
       rc = pat_dispatch<3>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);

@@ -198,6 +198,13 @@ int gcge_hip_cg_pass2_mv (void *mat, void **p, void **r, void **pnew, int c0, in
 /*     the same two passes with the column sums left on the DEVICE and nothing waited for (the fused CG computes its
  *     scalars there): pass 1: d_out[0,m) = p.(A p), d_out[m,2m) = |A p|^2 (d_out: >= 6 m doubles); pass 2: d_rho[0,m) */
 int gcge_hip_cg_pass1_dev (void *mat, void **p, int c0, int m, double *d_out);
+/*     second pass without a stored residual (kernel MODE 7): r_k = p_k - beta_{k-1} p_{k-1} rebuilt from the previous
+ *     direction pprev (d_betaprev: zeros in the first iteration, where pprev may be p); reads p, pprev, writes pnew */
+int gcge_hip_cg_pass2i_dev (void *mat, void **p, void **pprev, void **pnew, int c0, int m, const double *d_alpha,
+		const double *d_beta, const int *d_flag, const double *d_betaprev, double *d_rho);
+int gcge_hip_cg_pass2i_mv (void *mat, void **p, void **pprev, void **pnew, int c0, int m, const double *d_alpha,
+		const double *d_beta, const int *d_flag, const double *d_betaprev, double *host_rho);
+long gcge_hip_bpcg_implicit_r_iters (void);   /* CG iterations that ran without a stored residual */
 int gcge_hip_cg_pass2_dev (void *mat, void **p, void **r, void **pnew, int c0, int m, const double *d_alpha,
 		const double *d_beta, const int *d_flag, double *d_rho);
 int gcge_hip_pattern_width (int max_row_len);

@@ -56,6 +56,10 @@ def run(kind, fn, reps=6):
 
 t0 = run(0, lambda: ops.spmm(mA, p, w, (0, 0), (m, m)))
 t2 = run(2, lambda: g.gcge_hip_cg_pass1_mv(mA, p, 0, m, pw.ctypes.data, ww.ctypes.data))
-t3 = run(3, lambda: g.gcge_hip_cg_pass2_mv(mA, p, r, pn, 0, m, al.data_ptr(), be.data_ptr(), fl.data_ptr(), rho.ctypes.data))
+g.gcge_hip_cg_pass2i_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+if os.environ.get("PASS2_STORED_R"):     # the second pass with a stored residual (reads p, r; writes r, p'): 4 block streams
+    t3 = run(3, lambda: g.gcge_hip_cg_pass2_mv(mA, p, r, pn, 0, m, al.data_ptr(), be.data_ptr(), fl.data_ptr(), rho.ctypes.data))
+else:                                     # what the solver runs: r rebuilt from the previous direction (here: the block r), 3 block streams
+    t3 = run(3, lambda: g.gcge_hip_cg_pass2i_mv(mA, p, r, pn, 0, m, al.data_ptr(), be.data_ptr(), fl.data_ptr(), be.data_ptr(), rho.ctypes.data))
 print("N=%d m=%d ld(p)=%d ld(r)=%d nw=%s xcd=%s ring=%s:  product %.3f ms (%.0f GB/s)   pass1 %.3f ms (%.0f GB/s)   pass2 %.3f ms (%.0f GB/s)"
       % (N, m, vc, vr, os.environ.get("CHAIN2_NW", "16"), os.environ.get("CHAIN2_XCD", "0"), os.environ.get("RING", "1,3") + "/x" + os.environ.get("RING_XCD", "0") + "/w" + os.environ.get("RING_WIDE", "0") + "/p" + os.environ.get("RING_PRODUCT", "1"), t0[0], t0[1], t2[0], t2[1], t3[0], t3[1]), flush=True)
