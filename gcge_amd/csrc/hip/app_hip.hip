@@ -422,6 +422,15 @@ extern "C" int gcge_hip_mat_pattern_chain(const GCGE_HIP_MAT* A) {
   return A->pat_span2 <= -8 ? 2 : 1;
 }
 
+// which K1 form MatDotMultiVec takes for this matrix at block widths >= 16 (bench.py names the kernel in its roofline)
+extern "C" const char* gcge_hip_mat_spmm_form(const GCGE_HIP_MAT* A) {
+  if (A->d_pid != nullptr && g_spmm_path == 0) {
+    const int ch = gcge_hip_mat_pattern_chain(A);
+    return ch == 2 ? "spmm_pattern_chain2" : ch == 1 ? "spmm_pattern_chain" : "spmm_pattern";
+  }
+  return g_spmm_path == 1 ? "spmm_sell8" : "spmm_pad8";
+}
+
 // ------------------------------------------------------------------ device buffer pool
 // hipMalloc / hipFree of the multi-GB blocks cost 0.25-0.3 s each on this stack (page-table set-up; hipFree also
 // synchronises the device): ~1.9 s of a 21 s solve.  Freed blocks are kept by exact size and handed out again —

@@ -209,6 +209,7 @@ int gcge_hip_cg_pass2_dev (void *mat, void **p, void **r, void **pnew, int c0, i
 		const double *d_beta, const int *d_flag, double *d_rho);
 int gcge_hip_pattern_width (int max_row_len);
 int gcge_hip_mat_patterns (const GCGE_HIP_MAT *A);
+const char *gcge_hip_mat_spmm_form (const GCGE_HIP_MAT *A);   /* name of the K1 kernel family MatDotMultiVec takes for this matrix */
 int gcge_hip_mat_pattern_chain (const GCGE_HIP_MAT *A);   /* 0 none, 1 chain layout (span2 == -1), 2 chain + line exchange (span2 == -L) */
 /*     d_out[j] = sum_r x[r,j] y[r,j] */
 int gcge_hip_coldots (int nrows, const double *d_x, long ldx, const double *d_y, long ldy, int m,
