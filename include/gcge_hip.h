@@ -151,7 +151,17 @@ int gcge_hip_sell8_spmm (int nrows, const int *d_orp, const int *d_pcol, const d
 void gcge_hip_pool_release (void);
 void gcge_hip_pool_enable (int on);
 size_t gcge_hip_pool_cached_bytes (void);
-void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > pad-8 > CSR), 1 SELL-8 passes, 2 generic kernels only */
+void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > X tiles > pad-8 > CSR), 1 SELL-8 passes, 2 no pattern kernels, 3 pad-8 / CSR only */
+/*     tile path (csrc/hip/spmm_tile.hip): matrices without a pattern form whose rows are long enough (>= 12 entries on
+ *     average) are additionally kept as row tiles (bricks of a detected grid, or runs of rows) with 16-bit positions into
+ *     the tile's list of X rows, which the kernel stages in LDS once per 16-column pass.  mode: 0 automatic, 1 every
+ *     matrix without a pattern form, 2 every matrix, -1 never (takes effect at the next gcge_hip_mat_create*)          */
+void gcge_hip_spmm_tile_mode (int mode);
+/*     host-only structural self-check of that upload (no device needed): expands the tiles back into (row, column,
+ *     value) triples and compares with the CSR arrays bit for bit; returns the number of differences (0 = identical),
+ *     the X rows staged per matrix row, the ELL entries per non-zero and the grid strides it detected (0: none)       */
+long gcge_hip_tile_selfcheck (int nrows, int ncols_local, const int *rowptr, const int *colidx, const double *val,
+		double *xrows_per_row, double *ell_per_nnz, long *strides);
 /*     pattern path (csrc/hip/spmm_pattern.hip): matrices whose rows repeat a few stencils {(col - row, value)} are
  *     additionally kept as 16-bit pattern ids + a table of npat * lt {double value; long offset} entries (span, span2 =
  *     longest and second longest |offset| of the interior stencil: launch geometry only); d_dots may be NULL.  gcge_hip_mat_patterns() tells whether a matrix qualified (0: served by the generic kernels).       */

@@ -78,3 +78,35 @@ def test_host_library_exports_solver_api():
               "EigenSolverSetParametersFromCommandLine_GCG", "TestEigenSolverGCG", "GCGE_RunGCG", "GCGE_SetComm",
               "gcge_problem_lap3d", "gcge_problem_fe3d", "gcge_problem_fe1d", "gcge_problem_sio2_like", "gcge_dist_ghosts"):
         assert hasattr(lib, n), n
+
+
+def test_tile_upload_reproduces_the_csr_arrays():
+    """Host half of the tile path (csrc/hip/spmm_tile.hip; no device call): tiles -> chunks -> ELL steps expanded back
+    into (row, column, value) triples equal the CSR arrays bit for bit — bricks of a detected grid (SiO2-like: strides G
+    and G^2 read off the offset histogram), multi-chunk unions, a slab with halo columns, a matrix without structure."""
+    import ctypes as C
+    import numpy as np
+    from gcge_amd.lib import hip_lib, make_problem
+    from gcge_amd import dist as gdist
+    g = hip_lib()
+    g.gcge_hip_tile_selfcheck.restype = C.c_long
+    xr, el, st = C.c_double(), C.c_double(), (C.c_long * 2)()
+
+    def check(M):
+        return g.gcge_hip_tile_selfcheck(M.nrows, M.ncols, M.rowptr, M.colidx, M.val, C.byref(xr), C.byref(el), st)
+    A, _ = make_problem("sio2", 24, K=8, R0=1.5, R1=3.0)
+    assert check(A) == 0 and list(st) == [24, 576] and xr.value < 9.0 and el.value < 1.3, (list(st), xr.value, el.value)
+    A, _ = make_problem("sio2", 20, K=20, R0=2.0, R1=5.0)          # atoms wider than a brick: several chunks per tile
+    assert check(A) == 0 and list(st) == [20, 400]
+    A, _ = make_problem("sio2", 16, K=6, R0=2.0, R1=3.0, row_begin=1000, row_end=3000)   # a slab: global columns -> local + halo
+    gdist.localize_slab(A)
+    assert check(A) == 0
+    _, Bm = make_problem("fe3d", 12)
+    assert check(Bm) == 0 and list(st) == [12, 144]
+    import scipy.sparse as sp
+    from helpers import csr_from_scipy
+    rng = np.random.default_rng(5)
+    S = sp.random(3000, 3000, density=0.01, random_state=rng, format="csr")
+    S = (S + S.T + sp.identity(3000)).tocsr()
+    M, keep = csr_from_scipy(S)
+    assert check(M) == 0 and list(st) == [0, 0]

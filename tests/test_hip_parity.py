@@ -1005,3 +1005,74 @@ def test_gcg_scaled_rhs_start_equals_formed_rhs(hip, extra_env):
     assert np.max(np.abs(out[0][0] - out[1][0]) / np.abs(out[1][0])) < 1e-11
     exact = lap3d_exact(32, out[0][1])
     assert np.max(np.abs(out[0][0] - exact) / exact) < 1e-9
+
+
+def _random_symmetric_csr(n, per_row, seed):
+    """A matrix WITHOUT grid structure: random symmetric pattern, rows of very different length (a few dense-ish rows)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    S = sp.random(n, n, density=per_row / n / 2.0, random_state=rng, format="csr", data_rvs=lambda k: rng.uniform(-1.0, 1.0, k))
+    heavy = rng.choice(n, size=12, replace=False)
+    H = sp.lil_matrix((n, n))
+    for r in heavy:
+        cols = rng.choice(n, size=int(rng.integers(200, 1500)), replace=False)
+        H[r, cols] = rng.uniform(-1.0, 1.0, cols.size)
+    S = S + S.T + H.tocsr() + H.tocsr().T + sp.identity(n) * 4.0
+    return S.tocsr()
+
+
+@pytest.mark.parametrize("case", ["sio2_24", "sio2_20_big_atoms", "random_5000", "fe3d_forced", "lap3d_forced"])
+def test_tile_spmm_vs_oracle(both, case):
+    """K1, tile path (spmm_tile.hip: row tiles with LDS-staged X rows) against the CPU oracle and scipy: grid bricks with
+    single- and multi-chunk unions, a matrix without grid structure (runs of consecutive rows, rows of 200-1500 entries),
+    ragged widths and odd column offsets (those fall back to the generic kernels — same results), tiles with fewer than
+    128 rows, and the pad-8 kernel on the same matrix as a second witness."""
+    from helpers import csr_from_scipy
+    hip, ora = both
+    g = hip.g
+    g.gcge_hip_spmm_tile_mode.argtypes = [C.c_int]
+    g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+    g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+    keep = None
+    g.gcge_hip_spmm_tile_mode(2 if case.endswith("_forced") else 1)   # 1: every matrix without a pattern form, whatever its size; 2: every matrix
+    try:
+        if case == "sio2_24":
+            A, _ = make_problem("sio2", 24, K=8, R0=1.5, R1=3.0)
+        elif case == "sio2_20_big_atoms":
+            A, _ = make_problem("sio2", 20, K=20, R0=2.0, R1=5.0)       # atoms of up to 7 cells: unions of several chunks
+        elif case == "random_5000":
+            A, keep = csr_from_scipy(_random_symmetric_csr(5000, 30, 3))
+        elif case == "fe3d_forced":
+            _, A = make_problem("fe3d", 14)                               # the 15-point mass matrix
+        else:
+            A, _ = make_problem("lap3d", 19)
+        if case.endswith("_forced"):
+            g.gcge_hip_set_spmm_path(2)   # products skip the pattern kernels these stencil matrices would otherwise take
+        mh, mo = hip.matrix(A), ora.matrix(A)
+        n = A.nrows
+        S = csr_to_scipy(A)
+        X = uniform(11, (n, 72)) - 0.5
+        xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
+        form = g.gcge_hip_mat_spmm_form(mh).decode()
+        assert form == "spmm_tile", form
+        for m, s0, s1 in [(64, 0, 0), (16, 2, 4), (2, 0, 0), (30, 4, 2), (66, 6, 0), (17, 1, 0), (16, 1, 2), (48, 8, 16)]:
+            Y0 = uniform(8, (n, 72))
+            yh, yo = hip.mv_from_numpy(mh, Y0), ora.mv_from_numpy(mo, Y0)
+            hip.ops.spmm(mh, xh, yh, (s0, s1), (s0 + m, s1 + m))
+            ora.ops.spmm(mo, xo, yo, (s0, s1), (s0 + m, s1 + m))
+            got = hip.mv_to_numpy(yh, n, 0, 72)
+            _close(got, ora.mv_to_numpy(yo, n, 0, 72), tol=1e-12, what="tile spmm m=%d" % m)
+            _close(got[:, s1:s1 + m], S @ X[:, s0:s0 + m], tol=1e-12, what="tile spmm vs scipy m=%d" % m)
+            hip.ops.mv_destroy(yh); ora.ops.mv_destroy(yo)
+        # the same product through the pad-8 / CSR kernels
+        yh = hip.mv_from_numpy(mh, np.zeros((n, 64)))
+        hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
+        a = hip.mv_to_numpy(yh, n, 0, 64)
+        g.gcge_hip_set_spmm_path(3)
+        assert g.gcge_hip_mat_spmm_form(mh).decode() == "spmm_pad8"
+        hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
+        _close(a, hip.mv_to_numpy(yh, n, 0, 64), tol=1e-12, what="tile vs pad-8")
+        hip.free_matrix(mh)
+    finally:
+        g.gcge_hip_set_spmm_path(0)
+        g.gcge_hip_spmm_tile_mode(0)

@@ -1,0 +1,43 @@
+"""Time MatDotMultiVec on a matrix without a pattern form: tile path (spmm_tile.hip) against the pad-8 kernel. Tuning aid.
+   python tools/tile_probe.py G K [m]      (SiO2-like matrix on a G^3 grid with K atoms, R = 2 + 5 u1 u2)"""
+import ctypes as C, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa
+from gcge_amd import HipBackend, make_problem
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 354
+m = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+hip = HipBackend(); g = hip.g
+g.gcge_hip_profile_enable.argtypes = [C.c_int]
+g.gcge_hip_profile_spmm.restype = C.c_long
+g.gcge_hip_profile_spmm.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+t0 = time.time()
+A, B = make_problem("sio2", G, K=K, R0=2.0, R1=5.0, seed=12345)
+t1 = time.time()
+mA = hip.matrix(A)
+t2 = time.time()
+print("n", A.nrows, "nnz", A.nnz, "gen %.1f s upload %.1f s" % (t1 - t0, t2 - t1), "form", g.gcge_hip_mat_spmm_form(mA).decode(), flush=True)
+hip.set_random_mode(1, 7)
+ops = hip.ops
+V = ops.mv_create(2 * m, mA); ops.set_random(V, 0, 2 * m)
+W1 = ops.mv_create(m, mA); W2 = ops.mv_create(m, mA)
+res = {}
+for path in (0, 3):
+    g.gcge_hip_set_spmm_path(path)
+    Wv = W1 if path == 0 else W2
+    ops.spmm(mA, V, Wv, (m, 0), (2 * m, m)); hip.sync()
+    g.gcge_hip_profile_enable(1)
+    for _ in range(5):
+        ops.spmm(mA, V, Wv, (m, 0), (2 * m, m))
+    hip.sync()
+    ms, by = C.c_double(), C.c_double()
+    cnt = g.gcge_hip_profile_spmm(m, C.byref(ms), C.byref(by))
+    g.gcge_hip_profile_enable(0)
+    t = ms.value / cnt
+    print("path %d (%s) m=%d: %.3f ms  %.1f GB/s on CSR bytes (%.1f%% of 8 TB/s)" % (path, g.gcge_hip_mat_spmm_form(mA).decode(), m, t, by.value / cnt / t * 1e-6, by.value / cnt / t * 1e-6 / 80), flush=True)
+g.gcge_hip_set_spmm_path(0)
+a = hip.mv_to_numpy(W1, A.nrows, 0, 4); b = hip.mv_to_numpy(W2, A.nrows, 0, 4)
+print("max |tile - pad8| / max|pad8| =", float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
