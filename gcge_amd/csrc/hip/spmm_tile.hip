@@ -338,11 +338,14 @@ extern "C" long gcge_hip_tile_selfcheck(int nrows, int ncols_local, const int* r
         }
       }
       std::sort(got.begin(), got.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+      std::vector<std::pair<int, double>> want;      // the row as stored (slabs: halo columns need not be ascending)
+      for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) want.emplace_back(colidx[p], val[p]);
+      std::sort(want.begin(), want.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
       size_t g = 0;
-      for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) {
-        uint64_t vb; memcpy(&vb, &val[p], 8);
-        if (vb == 0) { if (g < got.size() && got[g].first == colidx[p] && got[g].second == 0.0) ++g; continue; }
-        if (g >= got.size() || got[g].first != colidx[p] || memcmp(&got[g].second, &val[p], 8) != 0) { ++bad; continue; }
+      for (const auto& w : want) {
+        uint64_t vb; memcpy(&vb, &w.second, 8);
+        if (vb == 0) { if (g < got.size() && got[g].first == w.first && got[g].second == 0.0) ++g; continue; }
+        if (g >= got.size() || got[g].first != w.first || memcmp(&got[g].second, &w.second, 8) != 0) { ++bad; continue; }
         ++g;
       }
       if (g != got.size()) ++bad;
