@@ -32,6 +32,9 @@ int gcge_hip_pattern_width(int max_row_len);
 void* gcge_hip_tile_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val);
 void gcge_hip_tile_free(void* tm);
 int gcge_hip_spmm_tile_mode_get(void);
+void* gcge_hip_dense_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val);
+void gcge_hip_dense_free(void* dm);
+int gcge_hip_dense_spmm(const void* dm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream, int which);
 int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
 int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2, const double* d_x, long ldx,
                           double* d_y, long ldy, int ncols, double* d_dots, double* d_dots_yy, void* stream);
@@ -90,7 +93,7 @@ static hipStream_t g_stream = nullptr;
 static int g_inited = 0;
 static double* g_stage_d = nullptr; static size_t g_stage_d_len = 0;   // device staging (doubles)
 static double* g_stage_h = nullptr; static size_t g_stage_h_len = 0;   // pinned host staging
-static int g_spmm_path = 0;   // 0: automatic (pattern > X tiles > pad-8 > CSR), 1: SELL-8 passes, 2: no pattern path, 3: pad-8 / CSR only
+static int g_spmm_path = 0;   // 0: automatic (pattern > X tiles > pad-8 > CSR), 1: SELL-8 passes, 2: no pattern path, 3: pad-8 / CSR only, 4: no block form (tile form if present)
 extern "C" void gcge_hip_set_spmm_path(int path) { g_spmm_path = path; }
 static int g_rand_mode = 0; static unsigned long long g_rand_seed = 0x5DEECE66Dull;
 
@@ -365,7 +368,9 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, i
   GCGE_HIP_CHECK(hipMemcpy(A->d_pcol, pc.data(), noct * 8 * sizeof(int), hipMemcpyHostToDevice));
   GCGE_HIP_CHECK(hipMemcpy(A->d_pval, pv.data(), noct * 8 * sizeof(double), hipMemcpyHostToDevice));
   build_patterns(A, nrows, ncols_local, rowptr, colidx, val);
-  // matrices without a pattern form and with rows long enough to pay for it: row tiles with LDS-staged X rows
+  // matrices without a pattern form: dense row blocks (supernodes) on MFMA + remainder CSR, where such blocks exist
+  A->dense = A->d_pid == nullptr ? gcge_hip_dense_build(nrows, ncols_local, rowptr, colidx, val) : nullptr;
+  // ... and, where switched on, row tiles with LDS-staged X rows
   A->tile = (A->d_pid == nullptr || gcge_hip_spmm_tile_mode_get() == 2) ? gcge_hip_tile_build(nrows, ncols_local, rowptr, colidx, val) : nullptr;
   // interior rows: none of them references a halo column (slabs: everything but the first and the last plane)
   A->ov_lo = 0; A->ov_hi = nrows;
@@ -415,6 +420,7 @@ extern "C" void gcge_hip_mat_destroy(GCGE_HIP_MAT* A) {
   if (A->d_pid) { hipFree(A->d_pid); hipFree(A->d_tab); }
   if (A->d_send_rows) hipFree(A->d_send_rows);
   if (A->tile != nullptr) gcge_hip_tile_free(A->tile);
+  if (A->dense != nullptr) gcge_hip_dense_free(A->dense);
   if (A->native_halo != nullptr) gcge_hip_halo_native_free(A);   // RCCL plan + the exchange buffers it owns (rccl_comm.hip)
   free(A);
 }
@@ -435,6 +441,7 @@ extern "C" const char* gcge_hip_mat_spmm_form(const GCGE_HIP_MAT* A) {
     const int ch = gcge_hip_mat_pattern_chain(A);
     return ch == 2 ? "spmm_pattern_chain2" : ch == 1 ? "spmm_pattern_chain" : "spmm_pattern";
   }
+  if (A->dense != nullptr && g_spmm_path != 1 && g_spmm_path != 3 && g_spmm_path != 4) return "spmm_dense+spmm_pad8";
   if (A->tile != nullptr && g_spmm_path != 1 && g_spmm_path != 3) return "spmm_tile";
   return g_spmm_path == 1 ? "spmm_sell8" : "spmm_pad8";
 }
@@ -719,6 +726,10 @@ static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long 
     rc = gcge_hip_pattern_spmm_near(nr, A->d_pid + r0, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, dx + r0 * ldx, ldx,
                                     y, ldy, m, d_dots, d_yy, g_stream, A->pat_near);
   if (rc != -1) return rc;
+  // whole-matrix products only from here: neither the rows of a block nor those of a tile are a row range
+  if (A->dense != nullptr && d_dots == nullptr && r0 == 0 && r1 == A->nrows && g_spmm_path != 1 && g_spmm_path != 3 && g_spmm_path != 4)
+    rc = gcge_hip_dense_spmm(A->dense, dx, ldx, dy, ldy, m, g_stream, 0);
+  if (rc != -1) return rc;
   if (A->tile != nullptr && d_dots == nullptr && r0 == 0 && r1 == A->nrows && g_spmm_path != 1 && g_spmm_path != 3)
     rc = gcge_hip_tile_spmm(A->tile, dx, ldx, dy, ldy, m, g_stream);   // whole-matrix products only: a tile's rows are not a row range
   if (rc != -1) return rc;
@@ -747,7 +758,7 @@ static int spmm_halo(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, double* dy, l
   const double* dx = vx->d + c_begin;
   const bool split = g_halo_overlap && A->nghost > 0 && A->exchange_begin != nullptr && A->exchange_end != nullptr &&
                      m <= A->buf_cols && A->ov_hi - A->ov_lo >= A->nrows / 2 && getenv("GCGE_NO_HALO_OVERLAP") == nullptr &&
-                     A->tile == nullptr;   // (the tile form multiplies whole matrices, not row strips)
+                     A->tile == nullptr && A->dense == nullptr;   // (the block and tile forms multiply whole matrices, not row strips)
   if (!split) {
     halo_fetch(A, vx, c_begin, m);
     return spmm_rows(A, 0, A->nrows, dx, vx->ld, dy, ldy, m, d_dots, d_yy, cg);

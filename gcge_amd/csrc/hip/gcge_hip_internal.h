@@ -36,6 +36,7 @@ struct GCGE_HIP_MAT_ {
   // optional split exchange (begin posts the transfers and returns, end completes them) and the rows that do not
   // touch a halo column, [ov_lo, ov_hi): lets the interior product run while the halo is in flight
   gcge_halo_exchange_fn exchange_begin; void (*exchange_end)(void*); int ov_lo, ov_hi;
+  void* dense;         // supernode form (spmm_dense.hip): dense row blocks on MFMA + remainder CSR; NULL: no blocks found
   void* tile;          // LDS-staged X-tile form (spmm_tile.hip) of a matrix without a pattern form; NULL: generic kernels
   void* native_halo;   // RCCL plan of gcge_hip_mat_set_halo_rccl (rccl_comm.hip); it then owns sendbuf / recvbuf
 };

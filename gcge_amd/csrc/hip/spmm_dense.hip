@@ -1,0 +1,350 @@
+// K1 (supernode path) — dense row blocks of a sparse matrix on FP64 MFMA, the rest through the generic CSR kernels.
+//
+// Same contract as spmm.hip / spmm_pad8.hip (Y[:, 0:m) = A X[:, 0:m), reference app/app_ccs.c:50-139).  Matrices like
+// BASELINE config 5's (real-space DFT Hamiltonians: a high-order stencil plus one dense block per atom — non-local
+// projectors — test_eig_sol_SiO2_MAT.c of the reference) keep HALF of their non-zeros in 8 % of their rows: rows of
+// 500-2000 entries that share their column set with a few hundred other rows.  The generic kernels gather one X row
+// per non-zero for them (13 % of the HBM roofline, ten times the algorithmic bytes through L1).  Here such
+// SUPERNODES — row sets R whose rows all reference (most of) one column set C — are found at upload and stored as
+// dense |R| x |C| blocks in MFMA fragment order (8 B per entry, no indices); the product Y[R] += D X[C] then is a
+// small dense contraction on v_mfma_f64_16x16x4_f64: one wave per 32 rows of a block holds 32 x 64 results in
+// registers, an X row fetched for a k-step feeds 2 row fragments (32 rows), so the block's X rows cross L1 |R| / 32
+// times instead of |R| times, and the values stream through once for all (up to) 64 columns of a pass.
+// What does not belong to a block (the stencil part, rows near block borders) stays a CSR matrix — the REMAINDER —
+// and takes the pad-8 kernel first (Y = A_rem X); no row lies in two blocks, so the second launch adds into Y without
+// atomics and the result is bit-reproducible.
+//
+// Detection (host, O(nnz of the long rows)): seeds = rows of >= min_len entries, longest first; the seed's columns
+// are the candidate set C0; structural symmetry makes the rows whose INDEX lies in C0 the candidate rows; a
+// candidate joins when at least half of its own entries and a quarter of C0 are shared; columns used by fewer
+// than a quarter of the joined rows are dropped again; blocks below 16 rows, 32 columns or 35 % fill are not formed.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <time.h>
+#include <algorithm>
+#include <vector>
+#include "gcge_hip_internal.h"
+
+extern "C" int gcge_hip_pad8_spmm(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval, const double* d_x,
+                                  long ldx, double* d_y, long ldy, int ncols, void* stream);
+extern "C" void gcge_hip_spmm_pad8_auto(double avg_octets_per_row);
+extern "C" void* gcge_hip_tile_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val);
+extern "C" void gcge_hip_tile_free(void* tm);
+extern "C" int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
+extern "C" int gcge_hip_spmm_tile_mode_get(void);
+
+namespace gcge {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct DenseSn { int row_off, nrows, col_off, ng; long val_off; };   // ng: groups of 4 columns (even), rows padded to 32 with -1
+struct DenseItem { int sn, block; };
+
+struct DenseMat {
+  int nsn, nitems, nrows; long dense_entries, dense_nnz, rem_nnz;
+  DenseSn* d_sn; DenseItem* d_items; int* d_rows; int* d_cols; double* d_vals;
+  int* d_orp; int* d_pcol; double* d_pval; long noct;   // remainder, pad-8 form
+  void* rem_tile;                                        // remainder in tile form (spmm_tile.hip) when that path is switched on
+};
+
+struct DenseHost {
+  std::vector<DenseSn> sn; std::vector<DenseItem> items; std::vector<int> rows, cols; std::vector<double> vals;
+  std::vector<int> rem_rowptr, rem_col; std::vector<double> rem_val;
+  long dense_nnz = 0;
+};
+
+// One wave per 32 rows of a block and pass of up to 64 columns.
+//   A fragment (values): lane l holds D[row 16 f + (l & 15)][column 4 g + (l >> 4)]   — stored in exactly this order
+//   B fragment (X rows): lane l holds X[C[4 g + (l >> 4)]][c0 + 16 cf + (l & 15)]
+//   accumulators:        lane l, register t of tile (f, cf): row 16 f + 4 t + (l >> 4), column c0 + 16 cf + (l & 15)
+__global__ __launch_bounds__(256) void spmm_dense_kernel(
+    const DenseItem* __restrict__ items, int nitems, const DenseSn* __restrict__ sns, const int* __restrict__ rows,
+    const int* __restrict__ cols, const double* __restrict__ vals, const double* __restrict__ x, size_t ldx,
+    double* __restrict__ y, size_t ldy, int m) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= nitems) return;
+  const DenseItem it = items[item];
+  const DenseSn S = sns[it.sn];
+  const int li = lane & 15, kk = lane >> 4;
+  const int ng = S.ng;
+  const double* __restrict__ vp = vals + S.val_off + (size_t)it.block * ng * 128 + lane;
+  const int* __restrict__ cp = cols + S.col_off + kk;
+  const int* __restrict__ rp = rows + S.row_off + 32 * it.block;
+  for (int c0 = 0; c0 < m; c0 += 64) {
+    const double* xc[4];
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf) { const int c = c0 + 16 * cf + li; xc[cf] = x + (c < m ? c : 0); }
+    v4d acc[2][4];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) acc[f][cf] = v4d{0.0, 0.0, 0.0, 0.0};
+    double a0[2], b0[4], a1[2], b1[4];
+    auto load = [&](double (&a)[2], double (&b)[4], int g, int col) {
+      a[0] = vp[(size_t)g * 128]; a[1] = vp[(size_t)g * 128 + 64];
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) b[cf] = xc[cf][(size_t)col * ldx];
+    };
+    auto mfma = [&](const double (&a)[2], const double (&b)[4]) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) acc[f][cf] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[f], b[cf], acc[f][cf], 0, 0, 0);
+    };
+    // two register sets, column indices two groups ahead; ng is even (padded at upload), loads beyond the end are
+    // clamped re-reads whose results are never used
+    int colA = cp[0], colB = cp[4 * min(1, ng - 1)];
+    load(a0, b0, 0, colA);
+    colA = cp[4 * min(2, ng - 1)];
+    for (int g = 0; g < ng; g += 2) {
+      load(a1, b1, g + 1, colB);
+      colB = cp[4 * min(g + 3, ng - 1)];
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(a0, b0, min(g + 2, ng - 1), colA);
+      colA = cp[4 * min(g + 4, ng - 1)];
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // Y[R] += block: every row belongs to one block only and the remainder kernel has finished (stream order)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = rp[16 * f + 4 * t + kk];
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+          const int c = c0 + 16 * cf + li;
+          if (r >= 0 && c < m) { double* q = y + (size_t)r * ldy + c; *q += acc[f][cf][t]; }
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ detection (host)
+static bool dense_build_host(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, int min_len,
+                             DenseHost* H) {
+  std::vector<int> seeds;
+  for (int r = 0; r < nrows; ++r) if (rowptr[r + 1] - rowptr[r] >= min_len) seeds.push_back(r);
+  if (seeds.empty()) return false;
+  std::stable_sort(seeds.begin(), seeds.end(), [&](int a, int b) { return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b]; });
+  std::vector<int> assigned((size_t)nrows, -1), stamp((size_t)ncols_local, -1), pos((size_t)ncols_local, 0), cnt;
+  std::vector<int> cand, R, C;
+  int id = 0;
+  for (int r0 : seeds) {
+    if (assigned[r0] != -1) continue;
+    const int n0 = rowptr[r0 + 1] - rowptr[r0];
+    ++id;
+    for (int q = rowptr[r0]; q < rowptr[r0 + 1]; ++q) stamp[colidx[q]] = id;
+    // candidate rows: the rows whose index is a column of the seed (structural symmetry), not yet in a block
+    R.clear();
+    for (int q = rowptr[r0]; q < rowptr[r0 + 1]; ++q) {
+      const int r = colidx[q];
+      if (r >= nrows || assigned[r] != -1) continue;
+      const int len = rowptr[r + 1] - rowptr[r];
+      if (2 * len < min_len) continue;
+      int ov = 0;
+      for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) ov += stamp[colidx[p]] == id;
+      if (2 * ov >= len && 4 * ov >= n0) R.push_back(r);
+    }
+    if ((int)R.size() < 16) { assigned[r0] = -2; continue; }
+    // columns of the seed that at least a quarter of the joined rows use
+    C.clear(); cnt.assign((size_t)n0, 0);
+    for (int q = rowptr[r0]; q < rowptr[r0 + 1]; ++q) { pos[colidx[q]] = q - rowptr[r0]; }
+    for (int r : R) for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) if (stamp[colidx[p]] == id) ++cnt[pos[colidx[p]]];
+    long filled = 0;
+    for (int q = rowptr[r0]; q < rowptr[r0 + 1]; ++q)
+      if (4L * cnt[q - rowptr[r0]] >= (long)R.size()) { C.push_back(colidx[q]); filled += cnt[q - rowptr[r0]]; }
+      else stamp[colidx[q]] = -1;   // dropped
+    if ((int)C.size() < 32 || (double)filled < 0.35 * (double)R.size() * (double)C.size()) { assigned[r0] = -2; continue; }
+    std::sort(R.begin(), R.end()); std::sort(C.begin(), C.end());
+    const int sn = (int)H->sn.size();
+    const int nb = ((int)R.size() + 31) / 32;
+    int ng = ((int)C.size() + 3) / 4; ng += ng & 1;
+    DenseSn S = {(int)H->rows.size(), (int)R.size(), (int)H->cols.size(), ng, (long)H->vals.size()};
+    for (int i = 0; i < 32 * nb; ++i) H->rows.push_back(i < (int)R.size() ? R[i] : -1);
+    for (int k = 0; k < 4 * ng; ++k) H->cols.push_back(k < (int)C.size() ? C[k] : C[0]);   // padding: a valid column, zero values
+    for (size_t k = 0; k < C.size(); ++k) pos[C[k]] = (int)k;
+    H->vals.resize(H->vals.size() + (size_t)nb * ng * 128, 0.0);
+    double* D = H->vals.data() + S.val_off;
+    for (size_t ir = 0; ir < R.size(); ++ir) {
+      const int r = R[ir]; assigned[r] = sn;
+      const size_t b = ir / 32, f = (ir % 32) / 16, i = ir % 16;
+      for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+        const int c = colidx[p];
+        if (stamp[c] != id) continue;
+        const size_t k = (size_t)pos[c], g = k / 4, kq = k % 4;
+        D[((b * ng + g) * 2 + f) * 64 + kq * 16 + i] = val[p];
+        ++H->dense_nnz;
+      }
+    }
+    // the remainder of these rows is written below, against the same stamps: keep them alive under a per-block id
+    H->sn.push_back(S);
+    for (int b = 0; b < nb; ++b) H->items.push_back(DenseItem{sn, b});
+  }
+  if (H->sn.empty()) return false;
+  // remainder: every entry that is not inside its row's block
+  H->rem_rowptr.assign((size_t)nrows + 1, 0);
+  std::fill(stamp.begin(), stamp.end(), -1);
+  std::vector<std::vector<int>> members(H->sn.size());
+  for (int r = 0; r < nrows; ++r) if (assigned[r] >= 0) members[assigned[r]].push_back(r);
+  std::vector<char> in_block((size_t)rowptr[nrows], 0);
+  for (size_t s = 0; s < H->sn.size(); ++s) {
+    const DenseSn& S = H->sn[s];
+    for (int k = 0; k < 4 * S.ng; ++k) stamp[H->cols[(size_t)S.col_off + k]] = (int)s;
+    for (int r : members[s]) for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) if (stamp[colidx[p]] == (int)s) in_block[p] = 1;
+  }
+  for (int r = 0; r < nrows; ++r) {
+    int c = 0;
+    for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) c += !in_block[p];
+    H->rem_rowptr[r + 1] = H->rem_rowptr[r] + c;
+  }
+  H->rem_col.resize((size_t)H->rem_rowptr[nrows]); H->rem_val.resize((size_t)H->rem_rowptr[nrows]);
+  for (int r = 0; r < nrows; ++r) {
+    int o = H->rem_rowptr[r];
+    for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) if (!in_block[p]) { H->rem_col[o] = colidx[p]; H->rem_val[o] = val[p]; ++o; }
+  }
+  return true;
+}
+
+}  // namespace gcge
+
+using namespace gcge;
+
+static int g_dense_mode = 0;     // 0 automatic, 1 rows of >= 24 entries may seed a block (tests), -1 never
+static int g_dense_min_len = 96;
+extern "C" void gcge_hip_spmm_dense_mode(int mode) { g_dense_mode = mode; }
+extern "C" int gcge_hip_spmm_dense_mode_get(void) { return g_dense_mode; }
+
+// Host-only structural self-check of the split (tests; no device needed): blocks + remainder, expanded back into (row,
+// column, value) triples, equal the CSR arrays bit for bit and no row lies in two blocks.  Returns the number of
+// differences (0 = identical), -1 when no block was found; also the number of blocks, the share of the non-zeros they
+// hold and their fill.
+extern "C" long gcge_hip_dense_selfcheck(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val,
+                                         int min_len, long* nblocks, double* share, double* fill) {
+  DenseHost H;
+  const clock_t t0 = clock();
+  if (!dense_build_host(nrows, ncols_local, rowptr, colidx, val, min_len, &H)) return -1;
+  if (getenv("GCGE_DENSE_TIMING")) fprintf(stderr, "dense_build_host: %.2f s\n", (double)(clock() - t0) / CLOCKS_PER_SEC);
+  long bad = 0, entries = 0;
+  std::vector<std::vector<std::pair<int, double>>> got((size_t)nrows);
+  std::vector<int> owner((size_t)nrows, -1);
+  for (size_t s = 0; s < H.sn.size(); ++s) {
+    const DenseSn& S = H.sn[s];
+    const int nb = (S.nrows + 31) / 32;
+    entries += (long)S.nrows * 4 * S.ng;
+    for (int ir = 0; ir < 32 * nb; ++ir) {
+      const int r = H.rows[(size_t)S.row_off + ir];
+      if (ir >= S.nrows) { if (r != -1) ++bad; continue; }
+      if (r < 0 || r >= nrows) { ++bad; continue; }
+      if (owner[r] != -1) ++bad;
+      owner[r] = (int)s;
+      const size_t b = ir / 32, f = (ir % 32) / 16, i = ir % 16;
+      for (int k = 0; k < 4 * S.ng; ++k) {
+        const double v = H.vals[(size_t)S.val_off + ((b * S.ng + k / 4) * 2 + f) * 64 + (k % 4) * 16 + i];
+        uint64_t bits; memcpy(&bits, &v, 8);
+        if (bits != 0) got[r].emplace_back(H.cols[(size_t)S.col_off + k], v);
+      }
+    }
+  }
+  for (int r = 0; r < nrows; ++r) {
+    for (int p = H.rem_rowptr[r]; p < H.rem_rowptr[r + 1]; ++p) got[r].emplace_back(H.rem_col[p], H.rem_val[p]);
+    std::vector<std::pair<int, double>> want;
+    for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) want.emplace_back(colidx[p], val[p]);
+    auto less = [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; };
+    std::sort(got[r].begin(), got[r].end(), less); std::sort(want.begin(), want.end(), less);
+    // explicit zeros of the CSR arrays that fell inside a block are indistinguishable from the block's padding: skip them
+    size_t g = 0;
+    for (const auto& w : want) {
+      if (g < got[r].size() && got[r][g].first == w.first) { if (memcmp(&got[r][g].second, &w.second, 8) != 0) ++bad; ++g; }
+      else if (w.second != 0.0) ++bad;
+    }
+    if (g != got[r].size()) ++bad;
+  }
+  if (nblocks) *nblocks = (long)H.sn.size();
+  if (share) *share = (double)H.dense_nnz / (double)rowptr[nrows];
+  if (fill) *fill = entries ? (double)H.dense_nnz / (double)entries : 0.0;
+  return bad;
+}
+
+extern "C" void gcge_hip_dense_free(void* dm) {
+  DenseMat* D = (DenseMat*)dm;
+  if (!D) return;
+  hipFree(D->d_sn); hipFree(D->d_items); hipFree(D->d_rows); hipFree(D->d_cols); hipFree(D->d_vals);
+  hipFree(D->d_orp); hipFree(D->d_pcol); hipFree(D->d_pval);
+  if (D->rem_tile) gcge_hip_tile_free(D->rem_tile);
+  delete D;
+}
+
+template <class T>
+static T* to_device(const std::vector<T>& v) {
+  T* d = nullptr;
+  GCGE_HIP_CHECK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  if (!v.empty()) GCGE_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+// NULL: no block worth forming (the matrix keeps the generic kernels alone)
+extern "C" void* gcge_hip_dense_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val) {
+  if (g_dense_mode < 0 || nrows <= 0) return nullptr;
+  const int min_len = g_dense_mode == 1 ? 24 : g_dense_min_len;
+  DenseHost H;
+  if (!dense_build_host(nrows, ncols_local, rowptr, colidx, val, min_len, &H)) return nullptr;
+  const long nnz = rowptr[nrows];
+  if (g_dense_mode == 0 && 10 * H.dense_nnz < nnz) return nullptr;   // blocks hold less than a tenth of the matrix: not worth a second launch
+  DenseMat* D = new DenseMat();
+  D->nsn = (int)H.sn.size(); D->nitems = (int)H.items.size(); D->nrows = nrows;
+  D->dense_entries = (long)H.vals.size(); D->dense_nnz = H.dense_nnz; D->rem_nnz = H.rem_rowptr[nrows];
+  D->d_sn = to_device(H.sn); D->d_items = to_device(H.items); D->d_rows = to_device(H.rows); D->d_cols = to_device(H.cols);
+  D->d_vals = to_device(H.vals);
+  std::vector<double>().swap(H.vals);
+  // remainder in pad-8 form: every row padded to a multiple of 8 entries with (own column, 0.0)
+  std::vector<int> orp((size_t)nrows + 1);
+  size_t noct = 0;
+  for (int r = 0; r < nrows; ++r) { orp[r] = (int)noct; noct += ((size_t)(H.rem_rowptr[r + 1] - H.rem_rowptr[r]) + 7) / 8; }
+  orp[nrows] = (int)noct;
+  std::vector<int> pc(noct * 8); std::vector<double> pv(noct * 8);
+  for (int r = 0; r < nrows; ++r) {
+    size_t o = (size_t)orp[r] * 8;
+    for (int k = H.rem_rowptr[r]; k < H.rem_rowptr[r + 1]; ++k, ++o) { pc[o] = H.rem_col[k]; pv[o] = H.rem_val[k]; }
+    for (; o < (size_t)orp[r + 1] * 8; ++o) { pc[o] = r; pv[o] = 0.0; }
+  }
+  D->noct = (long)noct;
+  D->d_orp = to_device(orp); D->d_pcol = to_device(pc); D->d_pval = to_device(pv);
+  D->rem_tile = gcge_hip_spmm_tile_mode_get() >= 1 ? gcge_hip_tile_build(nrows, ncols_local, H.rem_rowptr.data(), H.rem_col.data(), H.rem_val.data()) : nullptr;
+  return D;
+}
+
+extern "C" void gcge_hip_dense_stats(const void* dm, long* nblocks, long* items, long* dense_nnz, long* dense_entries, long* rem_nnz) {
+  const DenseMat* D = (const DenseMat*)dm;
+  if (nblocks) *nblocks = D->nsn;
+  if (items) *items = D->nitems;
+  if (dense_nnz) *dense_nnz = D->dense_nnz;
+  if (dense_entries) *dense_entries = D->dense_entries;
+  if (rem_nnz) *rem_nnz = D->rem_nnz;
+}
+
+// Y[:, 0:ncols) = A X[:, 0:ncols): remainder through the pad-8 kernel, then the blocks.  -1: alignment contract of the
+// pad-8 kernel not met (the caller keeps the CSR kernel on the full matrix).  which: 0 both, 1 remainder only, 2 blocks only (measurements)
+extern "C" int gcge_hip_dense_spmm(const void* dm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream, int which) {
+  const DenseMat* D = (const DenseMat*)dm;
+  if (ncols <= 0) return 0;
+  if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15) || d_x == d_y) return -1;
+  if (which != 2 && D->rem_tile != nullptr) {
+    const int rc = gcge_hip_tile_spmm(D->rem_tile, d_x, ldx, d_y, ldy, ncols, stream);
+    if (rc != 0) return rc;
+  } else if (which != 2) {
+    gcge_hip_spmm_pad8_auto(D->nrows > 0 ? (double)D->noct / D->nrows : 1.0);
+    const int rc = gcge_hip_pad8_spmm(D->nrows, D->d_orp, D->d_pcol, D->d_pval, d_x, ldx, d_y, ldy, ncols, stream);
+    if (rc != 0) return rc;
+  }
+  if (which != 1 && D->nitems > 0)
+    hipLaunchKernelGGL(spmm_dense_kernel, dim3((unsigned)((D->nitems + 3) / 4)), dim3(256), 0, (hipStream_t)stream, D->d_items, D->nitems,
+                       D->d_sn, D->d_rows, D->d_cols, D->d_vals, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols);
+  return (int)hipGetLastError();
+}

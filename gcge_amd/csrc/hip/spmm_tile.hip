@@ -11,9 +11,9 @@
 //     16-bit POSITION in that list instead of a 32-bit column (10 B per non-zero instead of 12); unions longer than the
 //     LDS tile are cut into chunks, most frequently used columns first, and the rows' partial sums stay in registers
 //     from chunk to chunk — no remainder matrix, no second kernel;
-//   * one workgroup per tile and 16-column pass: the chunk's X rows are staged in LDS ONCE (coalesced 128-byte
-//     segments, swizzled so that neighbouring positions fall on different banks), then every non-zero is one
-//     LDS read instead of one L1/L2 gather.  Rows are laid out 32 to a wave (two lanes per row, 8 columns each,
+//   * one workgroup per tile; per 8-column pass the chunk's X rows are staged in LDS ONCE (coalesced 64-byte
+//     segments, swizzled so that neighbouring positions fall on different banks; double-buffered: the next pass is
+//     in flight while this one is multiplied), then every non-zero is one LDS read instead of one L1/L2 gather.  Rows are laid out 32 to a wave (two lanes per row, 4 columns each,
 //     ELL inside a 32-row slice), so the (value, position) stream is read with coalesced loads and nothing is reduced
 //     across lanes: the dense atom blocks broadcast (all rows of a slice read the same position), stencil rows read
 //     consecutive positions — both conflict-free under the swizzle.
@@ -32,7 +32,7 @@ namespace gcge {
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int TILE_ROWS = 128;    // rows per tile: 4 slices of 32
-constexpr int TILE_CAP = 1088;    // X rows per chunk in LDS (136 KB at 16 columns); 8x4x4 brick of a +-6 star stencil: exactly 1088
+constexpr int TILE_CAP = 1088;    // X rows per chunk in LDS (2 buffers x 68 KB at 8 columns); 8x4x4 brick of a +-6 star stencil: exactly 1088
 constexpr int STEP_DOUBLES = 40;  // one ELL step of a slice: 32 values + 32 16-bit positions = 320 B
 
 struct TileHdr { int row_off, nrows, chunk_off, nchunks; };
@@ -44,102 +44,132 @@ struct TileMat {
   long nchunks;
 };
 
-// one workgroup (8 waves) per tile; wave w: slice w & 3, k-half w >> 2
-__global__ __launch_bounds__(512) void spmm_tile_kernel(
+// One workgroup (16 waves) per tile; wave w: slice w & 3, quarter w >> 2 of the slice's ELL steps.
+// A tile is a sequence of STAGES (pass of 8 columns) x (chunk of the union); the X rows of stage s + 1 are requested
+// into registers before stage s is computed from one LDS buffer and written into the other buffer afterwards, and the
+// (value, position) steps are requested one group of four ahead — so neither the HBM latency of the staging nor that of
+// the matrix stream is exposed, with ONE workgroup per CU (the two X buffers and the Y tile fill the LDS).
+// LDS image: position p, column pair c (0..3) at p*4 + (c ^ ((p >> 2) & 1)) (16-byte units): the 16 lanes a
+// ds_read_b128 serves together hold 8 rows x 2 halves and hit 16 different bank quads when the rows read neighbouring
+// positions (stencil rows) or the same one (atom rows).
+__global__ __launch_bounds__(1024) void spmm_tile_kernel(
     const TileHdr* __restrict__ th, const ChunkHdr* __restrict__ ch, const int* __restrict__ rows,
     const int* __restrict__ ucols, const double* __restrict__ steps, const double* __restrict__ x, size_t ldx,
     double* __restrict__ y, size_t ldy, int ncols, int ntiles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  v2d* xt = reinterpret_cast<v2d*>(smem_raw);        // TILE_CAP rows x 8 column pairs, pair c of position p at p*8 + (c ^ ((p >> 1) & 7))
-  v2d* yt = xt + (size_t)TILE_CAP * 8;               // TILE_ROWS rows x 8 column pairs
+  v2d* xt = reinterpret_cast<v2d*>(smem_raw);        // 2 buffers x TILE_CAP positions x 4 column pairs
+  v2d* yt = xt + (size_t)2 * TILE_CAP * 4;           // 2 regions x TILE_ROWS rows x 4 column pairs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row32 = lane >> 1, h = lane & 1, slice = wave & 3, kh = wave >> 2;
+  const int row32 = lane >> 1, h = lane & 1, slice = wave & 3, kq = wave >> 2;
   // blocks are dealt round-robin to the 8 XCDs: every XCD walks one contiguous eighth of the tiles, so bricks that
   // share halo rows run on the same L2 at about the same time
   const int per = (ntiles + 7) >> 3;
   const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (tile >= ntiles) return;
   const TileHdr T = th[tile];
-  const int su = tid >> 3, si = tid & 7;
-  for (int c0 = 0; c0 < ncols; c0 += 16) {
-    const bool sact = c0 + 2 * si < ncols;
-    const double* __restrict__ xs = x + c0 + (sact ? 2 * si : 0);
-    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int j = 0; j < T.nchunks; ++j) {
-      const ChunkHdr* __restrict__ C = ch + T.chunk_off + j;
-      const int nu = C->nu;
-      const int* __restrict__ uc = ucols + C->ucol_off;
-      __syncthreads();   // the previous chunk / pass no longer reads the X tile
-      // stage: 64 positions per round, 8 lanes x 16 B per position; four rounds in flight
-      for (int u0 = su; u0 < nu; u0 += 256) {
-        int col[4]; v2d v[4];
+  const int su = tid >> 2, si = tid & 3;             // staging: position su + 256 q, 16-byte part si
+  const int nch = T.nchunks, npass = (ncols + 7) >> 3, nst = npass * nch;
+  const ChunkHdr* __restrict__ CH = ch + T.chunk_off;
+  int col[5]; v2d sv[5];
+  auto load_cols = [&](int chunk) {
+    const int nu = CH[chunk].nu;
+    const int* __restrict__ uc = ucols + CH[chunk].ucol_off;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) col[q] = uc[min(u0 + 64 * q, nu - 1)];
+    for (int q = 0; q < 5; ++q) col[q] = uc[min(su + 256 * q, nu - 1)];
+  };
+  auto load_x = [&](int pass) {
+    const int c = 8 * pass + 2 * si;
+    const double* __restrict__ xs = x + (c < ncols ? c : 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const v2d*>(xs + (size_t)col[q] * ldx);
+    for (int q = 0; q < 5; ++q) sv[q] = *reinterpret_cast<const v2d*>(xs + (size_t)col[q] * ldx);
+  };
+  auto store_x = [&](int chunk, int buf) {
+    const int nu = CH[chunk].nu;
+    v2d* dst = xt + (size_t)buf * TILE_CAP * 4;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int u = su + 256 * q;
+      if (u < nu) dst[u * 4 + (si ^ ((u >> 2) & 1))] = sv[q];
+    }
+  };
+  load_cols(0);
+  load_x(0);
+  store_x(0, 0);
+  __syncthreads();
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  int pass = 0, chunk = 0;
+  for (int s = 0; s < nst; ++s) {
+    int npass_ = pass, nchunk = chunk + 1;
+    if (nchunk == nch) { nchunk = 0; ++npass_; }
+    const bool more = s + 1 < nst;
+    if (more) {                       // block-uniform
+      if (nch > 1) load_cols(nchunk);   // single-chunk tiles keep their column list in registers from pass to pass
+      load_x(npass_);
+    }
+    // ---- compute stage s from buffer s & 1
+    {
+      const ChunkHdr* __restrict__ C = CH + chunk;
+      const v2d* __restrict__ xb = xt + (size_t)(s & 1) * TILE_CAP * 4;
+      const int W = C->width[slice];
+      const int k0 = (W * kq) >> 2, k1 = (W * (kq + 1)) >> 2;
+      if (k0 < k1) {                  // wave-uniform
+        const double* __restrict__ sb = steps + (size_t)C->step_off[slice] * STEP_DOUBLES;
+        double cv[4], nv[4]; unsigned cp[4], np[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int u = u0 + 64 * q;
-          if (u < nu) xt[u * 8 + (si ^ ((u >> 1) & 7))] = v[q];
+          const double* sp = sb + (size_t)min(k0 + q, k1 - 1) * STEP_DOUBLES;
+          cv[q] = sp[row32]; cp[q] = reinterpret_cast<const unsigned short*>(sp + 32)[row32];
         }
+        for (int k = k0; k < k1; k += 4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {   // the next group of four steps (clamped: the last group re-reads the last step)
+            const double* sp = sb + (size_t)min(k + 4 + q, k1 - 1) * STEP_DOUBLES;
+            nv[q] = sp[row32]; np[q] = reinterpret_cast<const unsigned short*>(sp + 32)[row32];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double v = (k + q < k1) ? cv[q] : 0.0;
+            const v2d* xr = xb + cp[q] * 4;
+            const unsigned sw = (cp[q] >> 2) & 1;
+            const v2d x0 = xr[(2 * h) ^ sw], x1 = xr[(2 * h + 1) ^ sw];
+            acc[0] = fma(v, x0.x, acc[0]); acc[1] = fma(v, x0.y, acc[1]);
+            acc[2] = fma(v, x1.x, acc[2]); acc[3] = fma(v, x1.y, acc[3]);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { cv[q] = nv[q]; cp[q] = np[q]; }
+        }
+      }
+    }
+    if (more) store_x(nchunk, (s + 1) & 1);   // that buffer was last read in stage s - 1, which every wave has left
+    if (chunk == nch - 1) {
+      // end of a pass: the four quarters of a slice meet in the Y tile in a fixed order ((q0 + q2) + (q1 + q3)), then the
+      // tile's rows leave as 64-byte segments
+      const int r = slice * 32 + row32;
+      v2d* y0 = yt + (size_t)r * 4 + 2 * h;
+      v2d* y1 = y0 + (size_t)TILE_ROWS * 4;
+      if (kq >= 2) { v2d* d = kq == 2 ? y0 : y1; d[0] = v2d{acc[0], acc[1]}; d[1] = v2d{acc[2], acc[3]}; }
+      __syncthreads();
+      if (kq < 2) {
+        v2d* d = kq == 0 ? y0 : y1;
+        const v2d a = d[0], b = d[1];
+        acc[0] += a.x; acc[1] += a.y; acc[2] += b.x; acc[3] += b.y;
+        if (kq == 1) { d[0] = v2d{acc[0], acc[1]}; d[1] = v2d{acc[2], acc[3]}; }
       }
       __syncthreads();
-      const int W = C->width[slice], half = (W + 1) >> 1;
-      const int k0 = kh ? half : 0, k1 = kh ? W : half;
-      const double* __restrict__ sp = steps + ((size_t)C->step_off[slice] + k0) * STEP_DOUBLES;
-      int k = k0;
-      for (; k + 4 <= k1; k += 4, sp += 4 * STEP_DOUBLES) {
-        double val[4]; unsigned pos[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          val[q] = sp[q * STEP_DOUBLES + row32];
-          pos[q] = reinterpret_cast<const unsigned short*>(sp + q * STEP_DOUBLES + 32)[row32];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const v2d* xr = xt + pos[q] * 8;
-          const unsigned sw = (pos[q] >> 1) & 7;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const v2d xv = xr[(4 * h + c) ^ sw];
-            acc[2 * c] = fma(val[q], xv.x, acc[2 * c]); acc[2 * c + 1] = fma(val[q], xv.y, acc[2 * c + 1]);
-          }
-        }
+      if (kq == 0) {
+        const v2d a = y1[0], b = y1[1];
+        y0[0] = v2d{acc[0] + a.x, acc[1] + a.y}; y0[1] = v2d{acc[2] + b.x, acc[3] + b.y};
       }
-      for (; k < k1; ++k, sp += STEP_DOUBLES) {
-        const double val = sp[row32];
-        const unsigned pos = reinterpret_cast<const unsigned short*>(sp + 32)[row32];
-        const v2d* xr = xt + pos * 8;
-        const unsigned sw = (pos >> 1) & 7;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const v2d xv = xr[(4 * h + c) ^ sw];
-          acc[2 * c] = fma(val, xv.x, acc[2 * c]); acc[2 * c + 1] = fma(val, xv.y, acc[2 * c + 1]);
-        }
+      __syncthreads();
+      if (tid < 512) {
+        const int rr = tid >> 2, c = 8 * pass + 2 * si;
+        if (rr < T.nrows && c < ncols)
+          __builtin_nontemporal_store(yt[rr * 4 + si], reinterpret_cast<v2d*>(y + (size_t)rows[T.row_off + rr] * ldy + c));
       }
-    }
-    // the two k-halves of a slice meet in the Y tile (fixed order: second half stored, first half added), then the
-    // tile's rows leave as 128-byte segments
-    const int r = slice * 32 + row32;
-    if (kh == 1) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) yt[r * 8 + 4 * h + c] = v2d{acc[2 * c], acc[2 * c + 1]};
+      acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
     }
     __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const v2d o = yt[r * 8 + 4 * h + c];
-        yt[r * 8 + 4 * h + c] = v2d{acc[2 * c] + o.x, acc[2 * c + 1] + o.y};
-      }
-    }
-    __syncthreads();
-    for (int rr = su; rr < T.nrows; rr += 64) {
-      if (sact) {
-        const v2d o = yt[rr * 8 + si];
-        __builtin_nontemporal_store(o, reinterpret_cast<v2d*>(y + (size_t)rows[T.row_off + rr] * ldy + c0 + 2 * si));
-      }
-    }
+    pass = npass_; chunk = nchunk;
   }
 }
 
@@ -237,7 +267,7 @@ static void build_range(int t0, int t1, const std::vector<int>& trow_off, const 
 
 using namespace gcge;
 
-static int g_tile_mode = 0;   // 0 automatic, 1 every matrix without a pattern form, 2 every matrix (tests: next to a pattern form), -1 never
+static int g_tile_mode = 0;   // 0 off, 1 every matrix without a pattern form, 2 every matrix (tests: next to a pattern form), -1 never
 extern "C" void gcge_hip_spmm_tile_mode(int mode) { g_tile_mode = mode; }
 extern "C" int gcge_hip_spmm_tile_mode_get(void) { return g_tile_mode; }
 
@@ -358,9 +388,8 @@ extern "C" long gcge_hip_tile_selfcheck(int nrows, int ncols_local, const int* r
 
 // NULL: the matrix keeps the generic kernels (short rows, tiny matrices, more than 2^31 ELL steps).
 extern "C" void* gcge_hip_tile_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val) {
-  if (g_tile_mode < 0 || nrows <= 0) return nullptr;
+  if (g_tile_mode <= 0 || nrows <= 0) return nullptr;   // measured slower than the pad-8 kernel so far (profiles/r03_spmm_generic): only on request
   const long nnz = rowptr[nrows];
-  if (g_tile_mode == 0 && (nnz < 12L * nrows || nrows < 4096)) return nullptr;   // short rows: a gather per non-zero is as cheap as staging
   TileHost H;
   if (!tile_build_host(nrows, ncols_local, rowptr, colidx, val, &H)) return nullptr;
   size_t nth_ = 0, nch = 0, nuc = 0, nst = 0;
@@ -405,13 +434,13 @@ extern "C" int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, d
   if (ncols <= 0 || T->ntiles == 0) return 0;
   if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15) || d_x == d_y) return -1;
   static bool attr_set = false;
-  const size_t lds = (size_t)(TILE_CAP + TILE_ROWS) * 8 * sizeof(v2d);
+  const size_t lds = (size_t)(2 * TILE_CAP + 2 * TILE_ROWS) * 4 * sizeof(v2d);
   if (!attr_set) {
     GCGE_HIP_CHECK(hipFuncSetAttribute((const void*)spmm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   const int per = (T->ntiles + 7) / 8;
-  hipLaunchKernelGGL(spmm_tile_kernel, dim3((unsigned)(8 * per)), dim3(512), lds, (hipStream_t)stream, T->d_th, T->d_ch, T->d_rows,
+  hipLaunchKernelGGL(spmm_tile_kernel, dim3((unsigned)(8 * per)), dim3(1024), lds, (hipStream_t)stream, T->d_th, T->d_ch, T->d_rows,
                      T->d_ucols, T->d_steps, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, T->ntiles);
   return (int)hipGetLastError();
 }

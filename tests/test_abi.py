@@ -110,3 +110,22 @@ def test_tile_upload_reproduces_the_csr_arrays():
     S = (S + S.T + sp.identity(3000)).tocsr()
     M, keep = csr_from_scipy(S)
     assert check(M) == 0 and list(st) == [0, 0]
+
+
+def test_supernode_split_reproduces_the_csr_arrays():
+    """Host half of the supernode path (csrc/hip/spmm_dense.hip; no device call): dense blocks + remainder expanded back
+    into (row, column, value) triples equal the CSR arrays bit for bit, and no row lies in two blocks."""
+    import ctypes as C
+    from gcge_amd.lib import hip_lib, make_problem
+    g = hip_lib()
+    g.gcge_hip_dense_selfcheck.restype = C.c_long
+    nb, sh, fl = C.c_long(), C.c_double(), C.c_double()
+
+    def check(M, min_len):
+        return g.gcge_hip_dense_selfcheck(M.nrows, M.ncols, M.rowptr, M.colidx, M.val, min_len, C.byref(nb), C.byref(sh), C.byref(fl))
+    A, _ = make_problem("sio2", 24, K=8, R0=1.5, R1=3.0)
+    assert check(A, 24) == 0 and nb.value >= 2 and fl.value > 0.8
+    A, _ = make_problem("sio2", 32, K=30, R0=2.0, R1=5.0)          # overlapping atoms of up to 7 cells
+    assert check(A, 96) == 0 and nb.value >= 5 and sh.value > 0.2 and fl.value > 0.6, (nb.value, sh.value, fl.value)
+    A, _ = make_problem("lap3d", 12)
+    assert check(A, 24) == -1                                        # no long rows: no blocks

@@ -1076,3 +1076,69 @@ def test_tile_spmm_vs_oracle(both, case):
     finally:
         g.gcge_hip_set_spmm_path(0)
         g.gcge_hip_spmm_tile_mode(0)
+
+
+def _blocky_symmetric_csr(n, nblocks, seed):
+    """Random sparse background + dense symmetric blocks on scattered index sets (the shape of real-space DFT matrices)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    S = sp.random(n, n, density=6.0 / n, random_state=rng, format="csr", data_rvs=lambda k: rng.uniform(-1.0, 1.0, k))
+    S = S + S.T + sp.identity(n) * 8.0
+    rows, cols, vals = [], [], []
+    for _ in range(nblocks):
+        idx = np.sort(rng.choice(n, size=int(rng.integers(40, 300)), replace=False))
+        u = rng.uniform(0.1, 1.0, idx.size)
+        rows.append(np.repeat(idx, idx.size)); cols.append(np.tile(idx, idx.size)); vals.append(np.outer(u, u).ravel())
+    D = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+    return (S + D).tocsr()
+
+
+@pytest.mark.parametrize("case", ["sio2_24", "sio2_20_big_atoms", "blocky_4000"])
+def test_dense_block_spmm_vs_oracle(both, case):
+    """K1, supernode path (spmm_dense.hip: dense row blocks on FP64 MFMA + remainder through the pad-8 kernel) against the
+    CPU oracle, scipy and the pad-8 kernel on the whole matrix: overlapping blocks, blocks whose row count is not a
+    multiple of 32 / column count not a multiple of 8, ragged widths (m = 2 ... 130, more than one 64-column pass) and odd
+    column offsets (those take the CSR kernel on the full matrix — same results)."""
+    from helpers import csr_from_scipy
+    hip, ora = both
+    g = hip.g
+    g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
+    g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+    g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+    g.gcge_hip_spmm_dense_mode(1)         # rows of >= 24 entries may seed a block, however small the share of the blocks
+    keep = None
+    try:
+        if case == "sio2_24":
+            A, _ = make_problem("sio2", 24, K=8, R0=1.5, R1=3.0)
+        elif case == "sio2_20_big_atoms":
+            A, _ = make_problem("sio2", 20, K=20, R0=2.0, R1=5.0)
+        else:
+            A, keep = csr_from_scipy(_blocky_symmetric_csr(4000, 25, 9))
+        mh, mo = hip.matrix(A), ora.matrix(A)
+        assert g.gcge_hip_mat_spmm_form(mh).decode() == "spmm_dense+spmm_pad8"
+        n = A.nrows
+        S = csr_to_scipy(A)
+        X = uniform(12, (n, 136)) - 0.5
+        xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
+        for m, s0, s1 in [(64, 0, 0), (16, 2, 4), (2, 0, 0), (30, 4, 2), (66, 6, 0), (130, 0, 2), (17, 1, 0), (16, 1, 2), (48, 8, 16)]:
+            Y0 = uniform(8, (n, 136))
+            yh, yo = hip.mv_from_numpy(mh, Y0), ora.mv_from_numpy(mo, Y0)
+            hip.ops.spmm(mh, xh, yh, (s0, s1), (s0 + m, s1 + m))
+            ora.ops.spmm(mo, xo, yo, (s0, s1), (s0 + m, s1 + m))
+            got = hip.mv_to_numpy(yh, n, 0, 136)
+            _close(got, ora.mv_to_numpy(yo, n, 0, 136), tol=1e-12, what="block spmm m=%d" % m)
+            _close(got[:, s1:s1 + m], S @ X[:, s0:s0 + m], tol=1e-12, what="block spmm vs scipy m=%d" % m)
+            hip.ops.mv_destroy(yh); ora.ops.mv_destroy(yo)
+        yh = hip.mv_from_numpy(mh, np.zeros((n, 64)))
+        hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
+        a = hip.mv_to_numpy(yh, n, 0, 64)
+        hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
+        assert np.array_equal(a, hip.mv_to_numpy(yh, n, 0, 64)), "the block path is not reproducible from run to run"
+        g.gcge_hip_set_spmm_path(3)
+        assert g.gcge_hip_mat_spmm_form(mh).decode() == "spmm_pad8"
+        hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
+        _close(a, hip.mv_to_numpy(yh, n, 0, 64), tol=1e-12, what="blocks + remainder vs pad-8 on the whole matrix")
+        hip.free_matrix(mh)
+    finally:
+        g.gcge_hip_set_spmm_path(0)
+        g.gcge_hip_spmm_dense_mode(0)

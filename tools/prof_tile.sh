@@ -1,0 +1,34 @@
+#!/bin/bash
+# SQ / cache counters of the tile SpMM kernel (spmm_tile.hip) next to the pad-8 kernel on the SiO2-like matrix.
+#   tools/prof_tile.sh <outdir> [G K m]        (run on the GPU box)
+OUT=$GRAFT_REPO_ROOT/$1; G=${2:-96}; K=${3:-354}; M=${4:-64}
+mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" \
+           "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" \
+           "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_EA0_WRREQ_sum TCP_TA_DATA_STALL_CYCLES_sum"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/tile_probe.py $G $K $M > $OUT/log$i.txt 2>&1
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tools/tile_probe.py $G $K $M > $OUT/log_trace.txt 2>&1
+python3 - "$OUT" <<'PY'
+import csv,glob,sys,collections
+out=sys.argv[1]; acc=collections.defaultdict(list)
+for f in glob.glob(out+'/p*/**/*counter_collection.csv',recursive=True):
+    for r in csv.DictReader(open(f)):
+        k=r.get('Kernel_Name','')
+        if 'spmm_tile' in k: tag='tile'
+        elif 'spmm_pad8' in k: tag='pad8'
+        else: continue
+        acc[(tag,r['Counter_Name'])].append(float(r['Counter_Value']))
+with open(out+'/summary.txt','w') as fo:
+    for c,v in sorted(acc.items()):
+        line="%-5s %-34s per-launch mean=%.6g launches=%d"%(c[0],c[1],sum(v)/len(v),len(v))
+        print(line); fo.write(line+"\n")
+    for f in glob.glob(out+'/trace/**/*kernel_stats.csv',recursive=True):
+        for r in csv.DictReader(open(f)):
+            if 'spmm' in r.get('Name',''):
+                line="stats %s calls=%s avg_ns=%s"%(r['Name'][:60],r.get('Calls'),r.get('AverageNs'))
+                print(line); fo.write(line+"\n")
+PY

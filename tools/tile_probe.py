@@ -1,4 +1,5 @@
-"""Time MatDotMultiVec on a matrix without a pattern form: tile path (spmm_tile.hip) against the pad-8 kernel. Tuning aid.
+"""Time MatDotMultiVec on a matrix without a pattern form: supernode blocks on MFMA + remainder (spmm_dense.hip), the tile
+path (spmm_tile.hip, TILE_MODE=1) and the pad-8 kernel. Tuning aid.
    python tools/tile_probe.py G K [m]      (SiO2-like matrix on a G^3 grid with K atoms, R = 2 + 5 u1 u2)"""
 import ctypes as C, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +10,12 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 354
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 hip = HipBackend(); g = hip.g
+g.gcge_hip_spmm_tile_mode.argtypes = [C.c_int]
+g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
+if os.environ.get("TILE_MODE"):
+    g.gcge_hip_spmm_tile_mode(int(os.environ["TILE_MODE"]))      # 1: also keep the tile form (of the remainder when blocks exist)
+if os.environ.get("DENSE_MODE"):
+    g.gcge_hip_spmm_dense_mode(int(os.environ["DENSE_MODE"]))    # -1: no supernode blocks
 g.gcge_hip_profile_enable.argtypes = [C.c_int]
 g.gcge_hip_profile_spmm.restype = C.c_long
 g.gcge_hip_profile_spmm.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -25,9 +32,9 @@ ops = hip.ops
 V = ops.mv_create(2 * m, mA); ops.set_random(V, 0, 2 * m)
 W1 = ops.mv_create(m, mA); W2 = ops.mv_create(m, mA)
 res = {}
-for path in (0, 3):
+for path in (0, 4, 3):
     g.gcge_hip_set_spmm_path(path)
-    Wv = W1 if path == 0 else W2
+    Wv = W1 if path != 3 else W2
     ops.spmm(mA, V, Wv, (m, 0), (2 * m, m)); hip.sync()
     g.gcge_hip_profile_enable(1)
     for _ in range(5):
