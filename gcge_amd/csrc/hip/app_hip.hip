@@ -34,6 +34,7 @@ void gcge_hip_tile_free(void* tm);
 int gcge_hip_spmm_tile_mode_get(void);
 void* gcge_hip_dense_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val);
 void gcge_hip_dense_free(void* dm);
+int gcge_hip_dense_remainder_is_tiled(const void* dm);
 int gcge_hip_dense_spmm(const void* dm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream, int which);
 int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
 int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2, const double* d_x, long ldx,
@@ -441,7 +442,7 @@ extern "C" const char* gcge_hip_mat_spmm_form(const GCGE_HIP_MAT* A) {
     const int ch = gcge_hip_mat_pattern_chain(A);
     return ch == 2 ? "spmm_pattern_chain2" : ch == 1 ? "spmm_pattern_chain" : "spmm_pattern";
   }
-  if (A->dense != nullptr && g_spmm_path != 1 && g_spmm_path != 3 && g_spmm_path != 4) return "spmm_dense+spmm_pad8";
+  if (A->dense != nullptr && g_spmm_path != 1 && g_spmm_path != 3 && g_spmm_path != 4) return gcge_hip_dense_remainder_is_tiled(A->dense) ? "spmm_dense+spmm_tile" : "spmm_dense+spmm_pad8";
   if (A->tile != nullptr && g_spmm_path != 1 && g_spmm_path != 3) return "spmm_tile";
   return g_spmm_path == 1 ? "spmm_sell8" : "spmm_pad8";
 }

@@ -266,6 +266,11 @@ extern "C" long gcge_hip_dense_selfcheck(int nrows, int ncols_local, const int* 
     }
     if (g != got[r].size()) ++bad;
   }
+  if (getenv("GCGE_DENSE_TIMING")) {
+    long mx = 0, over64 = 0, over48 = 0, nnz_over = 0;
+    for (int r = 0; r < nrows; ++r) { const long l = H.rem_rowptr[r + 1] - H.rem_rowptr[r]; mx = std::max(mx, l); over64 += l > 64; over48 += l > 48; if (l > 64) nnz_over += l; }
+    fprintf(stderr, "remainder: nnz %d, longest row %ld, rows > 48: %ld, > 64: %ld (holding %ld entries)\n", H.rem_rowptr[nrows], mx, over48, over64, nnz_over);
+  }
   if (nblocks) *nblocks = (long)H.sn.size();
   if (share) *share = (double)H.dense_nnz / (double)rowptr[nrows];
   if (fill) *fill = entries ? (double)H.dense_nnz / (double)entries : 0.0;
@@ -320,6 +325,7 @@ extern "C" void* gcge_hip_dense_build(int nrows, int ncols_local, const int* row
   return D;
 }
 
+extern "C" int gcge_hip_dense_remainder_is_tiled(const void* dm) { return ((const DenseMat*)dm)->rem_tile != nullptr; }
 extern "C" void gcge_hip_dense_stats(const void* dm, long* nblocks, long* items, long* dense_nnz, long* dense_entries, long* rem_nnz) {
   const DenseMat* D = (const DenseMat*)dm;
   if (nblocks) *nblocks = D->nsn;

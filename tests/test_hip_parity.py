@@ -1015,18 +1015,19 @@ def _random_symmetric_csr(n, per_row, seed):
     heavy = rng.choice(n, size=12, replace=False)
     H = sp.lil_matrix((n, n))
     for r in heavy:
-        cols = rng.choice(n, size=int(rng.integers(200, 1500)), replace=False)
+        cols = rng.choice(n, size=int(rng.integers(100, 450)), replace=False)
         H[r, cols] = rng.uniform(-1.0, 1.0, cols.size)
     S = S + S.T + H.tocsr() + H.tocsr().T + sp.identity(n) * 4.0
     return S.tocsr()
 
 
-@pytest.mark.parametrize("case", ["sio2_24", "sio2_20_big_atoms", "random_5000", "fe3d_forced", "lap3d_forced"])
+@pytest.mark.parametrize("case", ["sio2_24", "sio2_20_big_atoms_remainder", "random_5000", "fe3d_forced", "lap3d_forced"])
 def test_tile_spmm_vs_oracle(both, case):
-    """K1, tile path (spmm_tile.hip: row tiles with LDS-staged X rows) against the CPU oracle and scipy: grid bricks with
-    single- and multi-chunk unions, a matrix without grid structure (runs of consecutive rows, rows of 200-1500 entries),
-    ragged widths and odd column offsets (those fall back to the generic kernels — same results), tiles with fewer than
-    128 rows, and the pad-8 kernel on the same matrix as a second witness."""
+    """K1, tile path (spmm_tile.hip: row tiles with LDS-staged X rows, the entries in registers) against the CPU oracle and
+    scipy: grid bricks, bricks split because their union exceeds the LDS tile, rows with more than 40 entries (overflow
+    list), the remainder of a matrix whose long rows went into dense blocks, a matrix without grid structure (runs of
+    consecutive rows), ragged widths and odd column offsets (those fall back to the generic kernels — same results),
+    tiles with fewer than 128 rows, and the pad-8 kernel on the same matrix as a second witness."""
     from helpers import csr_from_scipy
     hip, ora = both
     g = hip.g
@@ -1034,12 +1035,15 @@ def test_tile_spmm_vs_oracle(both, case):
     g.gcge_hip_mat_spmm_form.restype = C.c_char_p
     g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
     keep = None
+    g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
     g.gcge_hip_spmm_tile_mode(2 if case.endswith("_forced") else 1)   # 1: every matrix without a pattern form, whatever its size; 2: every matrix
+    g.gcge_hip_spmm_dense_mode(1 if case.endswith("_remainder") else -1)
+    want_form = "spmm_dense+spmm_tile" if case.endswith("_remainder") else "spmm_tile"
     try:
         if case == "sio2_24":
             A, _ = make_problem("sio2", 24, K=8, R0=1.5, R1=3.0)
-        elif case == "sio2_20_big_atoms":
-            A, _ = make_problem("sio2", 20, K=20, R0=2.0, R1=5.0)       # atoms of up to 7 cells: unions of several chunks
+        elif case == "sio2_20_big_atoms_remainder":
+            A, _ = make_problem("sio2", 20, K=20, R0=2.0, R1=5.0)       # atoms of up to 7 cells: rows of up to 1400 entries
         elif case == "random_5000":
             A, keep = csr_from_scipy(_random_symmetric_csr(5000, 30, 3))
         elif case == "fe3d_forced":
@@ -1054,7 +1058,7 @@ def test_tile_spmm_vs_oracle(both, case):
         X = uniform(11, (n, 72)) - 0.5
         xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
         form = g.gcge_hip_mat_spmm_form(mh).decode()
-        assert form == "spmm_tile", form
+        assert form == want_form, form
         for m, s0, s1 in [(64, 0, 0), (16, 2, 4), (2, 0, 0), (30, 4, 2), (66, 6, 0), (17, 1, 0), (16, 1, 2), (48, 8, 16)]:
             Y0 = uniform(8, (n, 72))
             yh, yo = hip.mv_from_numpy(mh, Y0), ora.mv_from_numpy(mo, Y0)
@@ -1076,6 +1080,7 @@ def test_tile_spmm_vs_oracle(both, case):
     finally:
         g.gcge_hip_set_spmm_path(0)
         g.gcge_hip_spmm_tile_mode(0)
+        g.gcge_hip_spmm_dense_mode(0)
 
 
 def _blocky_symmetric_csr(n, nblocks, seed):
