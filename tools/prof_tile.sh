@@ -1,13 +1,13 @@
 #!/bin/bash
-# SQ / cache counters of the tile SpMM kernel (spmm_tile.hip) next to the pad-8 kernel on the SiO2-like matrix.
-#   tools/prof_tile.sh <outdir> [G K m]        (run on the GPU box)
+# SQ / cache counters of the K1 kernels for matrices without a pattern form (spmm_tile.hip, spmm_dense.hip, spmm_pad8.hip)
+# on the SiO2-like matrix.    tools/prof_tile.sh <outdir> [G K m]        (run on the GPU box; TILE_MODE / DENSE_MODE as tools/tile_probe.py)
 OUT=$GRAFT_REPO_ROOT/$1; G=${2:-96}; K=${3:-354}; M=${4:-64}
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" \
            "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" \
            "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
-           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_EA0_WRREQ_sum TCP_TA_DATA_STALL_CYCLES_sum"; do
+           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/tile_probe.py $G $K $M > $OUT/log$i.txt 2>&1
 done
@@ -18,8 +18,9 @@ out=sys.argv[1]; acc=collections.defaultdict(list)
 for f in glob.glob(out+'/p*/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(f)):
         k=r.get('Kernel_Name','')
-        if 'spmm_tile' in k: tag='tile'
+        if 'spmm_tile_kernel' in k: tag='tile'
         elif 'spmm_pad8' in k: tag='pad8'
+        elif 'spmm_dense' in k: tag='dense'
         else: continue
         acc[(tag,r['Counter_Name'])].append(float(r['Counter_Value']))
 with open(out+'/summary.txt','w') as fo:
