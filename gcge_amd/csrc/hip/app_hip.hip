@@ -46,6 +46,14 @@ int gcge_hip_colmajor_to_rowmajor(int nrows, int m, const double* d_src, long ld
 int gcge_hip_rowmajor_to_colmajor(int nrows, int m, const double* d_src, long lds, double* d_dst, long ldd, void* stream);
 }
 
+extern "C" int gcge_hip_pattern_spmm_vals(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2,
+                                          const double* d_x, long ldx, double* d_y, long ldy, int ncols, double* d_dots, double* d_dots_yy,
+                                          void* stream, long near, const double* d_rowval);
+extern "C" int gcge_hip_pattern_cg_vals(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+                                   long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
+                                   long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
+                                   double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, long near,
+                                   const double* d_rowval);
 extern "C" int gcge_hip_pattern_spmm_near(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2,
                                           const double* d_x, long ldx, double* d_y, long ldy, int ncols, double* d_dots, double* d_dots_yy,
                                           void* stream, long near);
@@ -96,6 +104,8 @@ static double* g_stage_d = nullptr; static size_t g_stage_d_len = 0;   // device
 static double* g_stage_h = nullptr; static size_t g_stage_h_len = 0;   // pinned host staging
 static int g_spmm_path = 0;   // 0: automatic (pattern > X tiles > pad-8 > CSR), 1: SELL-8 passes, 2: no pattern path, 3: pad-8 / CSR only, 4: no block form (tile form if present)
 extern "C" void gcge_hip_set_spmm_path(int path) { g_spmm_path = path; }
+static int g_offset_patterns = 1;   // 1: stencils with row-dependent coefficients take the pattern kernels with streamed values
+extern "C" void gcge_hip_set_offset_patterns(int on) { g_offset_patterns = on; }
 static int g_rand_mode = 0; static unsigned long long g_rand_seed = 0x5DEECE66Dull;
 
 static double* stage_d(size_t len) {
@@ -187,12 +197,16 @@ extern "C" long gcge_hip_profile_kind(int kind, int ncols, double* total_ms, dou
 // A->d_pid == NULL when the matrix has too many distinct rows (irregular matrices give up after a few
 // hundred rows, so the scan costs nothing there).
 struct PatEntryH { double val; long off; };
-static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val) {
-  A->d_pid = nullptr; A->d_tab = nullptr; A->npat = 0; A->pat_lt = 0; A->pat_near = 0;
+// by_offsets: rows are compared by their column offsets only; the table then carries 1.0 for every present entry and the
+// values travel per row (A->d_rowval: 8 doubles per row in table-slot order, tables of at most 8 slots): stencils with
+// variable coefficients keep the pattern kernels at 64 more bytes per row and 16-column pass.
+static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val,
+                           bool by_offsets = false) {
+  A->d_pid = nullptr; A->d_tab = nullptr; A->npat = 0; A->pat_lt = 0; A->pat_near = 0; A->d_rowval = nullptr;
   int maxlen = 0;
   for (int r = 0; r < nrows; ++r) maxlen = std::max(maxlen, rowptr[r + 1] - rowptr[r]);
   const int lt = gcge_hip_pattern_width(maxlen);
-  if (lt == 0 || nrows == 0) return;
+  if (lt == 0 || nrows == 0 || (by_offsets && lt > 8)) return;
   const int maxpat = std::min(65535, (int)(64 * 1024 / (lt * sizeof(PatEntryH))));
   std::vector<PatEntryH> tab;
   std::unordered_map<uint64_t, std::vector<int>> byhash;
@@ -202,7 +216,8 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const in
     const int len = rowptr[r + 1] - rowptr[r];
     for (int k = 0; k < len; ++k) {
       const int q = rowptr[r] + k;
-      if (e[k].off != (long)colidx[q] - r || memcmp(&e[k].val, &val[q], sizeof(double)) != 0) return false;
+      if (e[k].off != (long)colidx[q] - r || (!by_offsets && memcmp(&e[k].val, &val[q], sizeof(double)) != 0)) return false;
+      if (by_offsets && e[k].val == 0.0) return false;   // (a padding slot: the table row is shorter)
     }
     for (int k = len; k < lt; ++k) if (e[k].off != 0 || e[k].val != 0.0) return false;
     return true;
@@ -213,6 +228,7 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const in
     uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)(rowptr[r + 1] - rowptr[r]);
     for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
       uint64_t vb; memcpy(&vb, &val[q], 8);
+      if (by_offsets) vb = 1;
       h = (h ^ (uint64_t)((long)colidx[q] - r)) * 0xBF58476D1CE4E5B9ull; h ^= h >> 29;
       h = (h ^ vb) * 0x94D049BB133111EBull; h ^= h >> 32;
     }
@@ -225,7 +241,7 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const in
       for (int k = 0; k < lt; ++k) {
         const int q = rowptr[r] + k;
         PatEntryH e = {0.0, 0};
-        if (q < rowptr[r + 1]) { e.val = val[q]; e.off = (long)colidx[q] - r; }
+        if (q < rowptr[r + 1]) { e.val = by_offsets ? 1.0 : val[q]; e.off = (long)colidx[q] - r; }
         tab.push_back(e);
       }
       cand.push_back(found);
@@ -326,6 +342,29 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const in
     if (Lline && lt == 7 && nslot_used == 7 && slot[5] == -1 && slot[6] == 1)
       for (const PatEntryH& e : tab) A->pat_near = std::max(A->pat_near, e.off < 0 ? -e.off : e.off);
   } while (0);
+  if (by_offsets) {
+    // the row's values in the slot order of ITS table row: an entry sits in the slot that carries its offset (the
+    // diagonal in slot 1 of a chain-layout table, where slots whose address would leave the block also read offset 0)
+    const bool chain_layout = A->pat_span2 <= -1;
+    std::vector<double> rv((size_t)nrows * 8, 0.0);
+    bool ok = true;
+    for (int r = 0; r < nrows && ok; ++r) {
+      const PatEntryH* e = &tab[(size_t)pid[r] * lt];
+      unsigned used = 0;
+      for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
+        const long off = (long)colidx[q] - r;
+        int slot = -1;
+        if (chain_layout && off == 0) slot = 1;
+        else for (int k = 0; k < lt; ++k) if (!(used >> k & 1) && e[k].off == off && e[k].val != 0.0 && !(chain_layout && off == 0 && k != 1)) { slot = k; break; }
+        if (slot < 0 || (used >> slot & 1)) { ok = false; break; }
+        used |= 1u << slot;
+        rv[(size_t)r * 8 + slot] = val[q];
+      }
+    }
+    if (!ok) { A->npat = 0; return; }   // (cannot happen for tables built above; the matrix then keeps the generic kernels)
+    GCGE_HIP_CHECK(hipMalloc(&A->d_rowval, rv.size() * sizeof(double)));
+    GCGE_HIP_CHECK(hipMemcpy(A->d_rowval, rv.data(), rv.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   GCGE_HIP_CHECK(hipMalloc(&A->d_pid, (size_t)nrows * sizeof(unsigned short)));
   GCGE_HIP_CHECK(hipMalloc(&A->d_tab, tab.size() * sizeof(PatEntryH)));
   GCGE_HIP_CHECK(hipMemcpy(A->d_pid, pid.data(), (size_t)nrows * sizeof(unsigned short), hipMemcpyHostToDevice));
@@ -369,6 +408,7 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, i
   GCGE_HIP_CHECK(hipMemcpy(A->d_pcol, pc.data(), noct * 8 * sizeof(int), hipMemcpyHostToDevice));
   GCGE_HIP_CHECK(hipMemcpy(A->d_pval, pv.data(), noct * 8 * sizeof(double), hipMemcpyHostToDevice));
   build_patterns(A, nrows, ncols_local, rowptr, colidx, val);
+  if (A->d_pid == nullptr && g_offset_patterns) build_patterns(A, nrows, ncols_local, rowptr, colidx, val, true);   // same stencil, other coefficients in every row
   // matrices without a pattern form: dense row blocks (supernodes) on MFMA + remainder CSR, where such blocks exist
   A->dense = A->d_pid == nullptr ? gcge_hip_dense_build(nrows, ncols_local, rowptr, colidx, val) : nullptr;
   // ... and, where switched on, row tiles with LDS-staged X rows
@@ -419,6 +459,7 @@ extern "C" void gcge_hip_mat_destroy(GCGE_HIP_MAT* A) {
   hipFree(A->d_rowptr); hipFree(A->d_colidx); hipFree(A->d_val);
   hipFree(A->d_orp); hipFree(A->d_pcol); hipFree(A->d_pval);
   if (A->d_pid) { hipFree(A->d_pid); hipFree(A->d_tab); }
+  if (A->d_rowval) hipFree(A->d_rowval);
   if (A->d_send_rows) hipFree(A->d_send_rows);
   if (A->tile != nullptr) gcge_hip_tile_free(A->tile);
   if (A->dense != nullptr) gcge_hip_dense_free(A->dense);
@@ -440,6 +481,7 @@ extern "C" int gcge_hip_mat_pattern_chain(const GCGE_HIP_MAT* A) {
 extern "C" const char* gcge_hip_mat_spmm_form(const GCGE_HIP_MAT* A) {
   if (A->d_pid != nullptr && g_spmm_path == 0) {
     const int ch = gcge_hip_mat_pattern_chain(A);
+    if (A->d_rowval != nullptr) return ch == 2 ? "spmm_pattern_chain2+values" : "spmm_pattern+values";   // offsets-only table, values per row
     return ch == 2 ? "spmm_pattern_chain2" : ch == 1 ? "spmm_pattern_chain" : "spmm_pattern";
   }
   if (A->dense != nullptr && g_spmm_path != 1 && g_spmm_path != 3 && g_spmm_path != 4) return gcge_hip_dense_remainder_is_tiled(A->dense) ? "spmm_dense+spmm_tile" : "spmm_dense+spmm_pad8";
@@ -716,16 +758,17 @@ static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long 
   }
   if (cg != nullptr) {
     if (A->d_pid == nullptr || g_spmm_path != 0) return -1;
-    return gcge_hip_pattern_cg_near(cg->mode, nr, A->d_pid + r0, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2,
+    return gcge_hip_pattern_cg_vals(cg->mode, nr, A->d_pid + r0, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2,
                                dx + r0 * ldx, ldx, cg->r ? cg->r + r0 * cg->ldr : nullptr, cg->ldr,
                                cg->pnew ? cg->pnew + r0 * cg->ldp : nullptr, cg->ldp, m, cg->alpha, cg->beta, cg->flag,
-                               d_dots, d_yy, g_stream, cg->b ? cg->b + r0 * cg->ldb : nullptr, cg->ldb, A->pat_near);
+                               d_dots, d_yy, g_stream, cg->b ? cg->b + r0 * cg->ldb : nullptr, cg->ldb, A->pat_near,
+                               A->d_rowval ? A->d_rowval + 8 * r0 : nullptr);
   }
   double* y = dy + r0 * ldy;
   int rc = -1;
   if (A->d_pid != nullptr && g_spmm_path == 0)
-    rc = gcge_hip_pattern_spmm_near(nr, A->d_pid + r0, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, dx + r0 * ldx, ldx,
-                                    y, ldy, m, d_dots, d_yy, g_stream, A->pat_near);
+    rc = gcge_hip_pattern_spmm_vals(nr, A->d_pid + r0, A->d_tab, A->npat, A->pat_lt, A->pat_span, A->pat_span2, dx + r0 * ldx, ldx,
+                                    y, ldy, m, d_dots, d_yy, g_stream, A->pat_near, A->d_rowval ? A->d_rowval + 8 * r0 : nullptr);
   if (rc != -1) return rc;
   // whole-matrix products only from here: neither the rows of a block nor those of a tile are a row range
   if (A->dense != nullptr && d_dots == nullptr && r0 == 0 && r1 == A->nrows && g_spmm_path != 1 && g_spmm_path != 3 && g_spmm_path != 4)

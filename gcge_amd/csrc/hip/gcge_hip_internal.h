@@ -28,6 +28,7 @@ struct GCGE_HIP_MAT_ {
   int *d_orp, *d_pcol; double* d_pval;        // pad-8 copy for the 16-byte-lane kernel
   long noct;
   unsigned short* d_pid; void* d_tab; int npat, pat_lt; long pat_span, pat_span2;   // pattern format (spmm_pattern.hip); d_pid == NULL: not applicable
+  double* d_rowval;   // patterns by OFFSETS only: the rows' values, 8 doubles per row in table-slot order (NULL: values in the table)
   long pat_near;  // > 0: chain + line table with slots [-S, 0, +S, -L, +L, -1, +1], the largest |offset| in it (spmm_ring.hip)
   // halo plan of a row-partitioned matrix (one process per GPU); nghost == 0 on a single rank
   int nsend; int* d_send_rows;                 // local rows other ranks need, grouped by destination rank

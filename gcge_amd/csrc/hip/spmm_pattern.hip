@@ -62,7 +62,8 @@ struct PatEntry { double val; long off; };   // 16 bytes: one ds_read_b128
 //      the GCG driver's systems A w = (lambda + sigma) x start from w = x, so neither B nor a second read is needed
 //   4  residual norms of Ritz pairs (standard problem): partial: sum_r ((A X)[r,j] - lambda_j X[r,j])^2 with
 //      lambda = cg.alpha; nothing is stored (CheckConvergence of the GCG driver, one read of X instead of 11 streams)
-struct CgArgs { double* r; size_t ldr; double* pnew; size_t ldp; const double* alpha; const double* beta; const int* flag; const double* b; size_t ldb; };
+struct CgArgs { double* r; size_t ldr; double* pnew; size_t ldp; const double* alpha; const double* beta; const int* flag; const double* b; size_t ldb;
+                const double* rowval; };   // rowval != NULL (kernels built with VALS): the table holds offsets only, the values of row r are rowval[8 r + slot]
 struct CgCoef { double al0, al1, cb0, cb1, cr0, cr1, bp0, bp1; };
 __device__ __forceinline__ CgCoef cg_coef(const CgArgs& cg, int j, bool act) {
   CgCoef c = {0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0};
@@ -74,7 +75,13 @@ __device__ __forceinline__ CgCoef cg_coef(const CgArgs& cg, int j, bool act) {
   return c;
 }
 
-template <int LT, int MODE>
+// VALS: lane (g, i) of an 8-lane row group holds the value of table slot i of its row; slot t for the whole group
+__device__ __forceinline__ double group_bcast(double v, int lane, int t) {
+  const int src = (lane & ~7) | t;
+  return __hiloint2double(__shfl(__double2hiint(v), src, 64), __shfl(__double2loint(v), src, 64));
+}
+
+template <int LT, int MODE, bool VALS = false>
 __global__ __launch_bounds__(256) void spmm_pattern_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
     const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
@@ -105,10 +112,11 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
     const long cnt = (ntiles - blockIdx.x + G - 1) / G;
     auto row_of = [&](long it) { return min(first_row(blockIdx.x + min(it, cnt - 1) * G) + g, nrows - 1); };   // clamped
     auto issue = [&](v2d (&buf)[LT + DOT + UPD], double (&val)[LT], long row, int p) {
+      if (VALS) val[0] = cg.rowval[(size_t)row * 8 + i];   // my slot's value; finish() hands the slots round the row group
 #pragma unroll
       for (int t = 0; t < LT; ++t) {
         const PatEntry e = s_tab[p * LT + t];
-        val[t] = e.val;
+        if (!VALS) val[t] = e.val;
         buf[t] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e.off) * ldx);
       }
       if (DOT) buf[LT] = *reinterpret_cast<const v2d*>(xl + (size_t)row * ldx);
@@ -117,7 +125,10 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
     auto finish = [&](const v2d (&buf)[LT + DOT + UPD], const double (&val)[LT], long it) {
       double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-      for (int t = 0; t < LT; ++t) { a0 = fma(val[t], buf[t].x, a0); a1 = fma(val[t], buf[t].y, a1); }
+      for (int t = 0; t < LT; ++t) {
+        const double vt = VALS ? group_bcast(val[0], lane, t) : val[t];
+        a0 = fma(vt, buf[t].x, a0); a1 = fma(vt, buf[t].y, a1);
+      }
       const long row = first_row(blockIdx.x + it * G) + g;   // unclamped: surplus iterations and tail rows store nothing
       const bool ok = it < cnt && row < nrows && act;
       if ((MODE <= 1 && ok) || ((MODE == 2 || RES) && ok && y != nullptr)) {   // MODE 2, 4: y == NULL, see chain2_body
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_chain_kernel(
 // 1 (+S) + 2 (+-1) + 2/NW, against 5 for the chain alone and 7 without it.  The barrier carries no memory fence
 // (raw s_barrier after lgkmcnt(0)): the global loads of the NEXT iteration stay in flight across it.
 // ROLE: 0 lowest wave, 1 inner wave, 2 highest wave (three copies of the loop: no branch near a load).
-template <int LT, int MODE, int NW, int ROLE>
+template <int LT, int MODE, int NW, int ROLE, bool VALS>
 __device__ __forceinline__ void chain2_body(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* s_tab, v2d (*xch)[NW][64],
     const double* __restrict__ xl, size_t ldx, double* __restrict__ y, size_t ldy, bool act, int i, int g, int wave, int lane,
@@ -360,9 +371,10 @@ __device__ __forceinline__ void chain2_body(
   auto row_of = [&](long it) { return min(row_at(min(it, cnt - 1)), nrows - 1); };
   // the stencil values are looked up again when the rows are reduced (7 LDS reads) instead of being carried in
   // 2 x LT registers from issue to finish: keeps the kernel at 4 waves per SIMD with the dot accumulators
-  auto issue = [&](v2d& lnew, v2d (&edge)[NE + 1], v2d (&oth)[NO + 1 + UPD], long row, int p) {
+  auto issue = [&](v2d& lnew, v2d (&edge)[NE + 1], v2d (&oth)[NO + 1 + UPD], long row, int p, double& vv) {
     const PatEntry* e = s_tab + p * LT;
     lnew = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[2].off) * ldx);
+    if (VALS) vv = cg.rowval[(size_t)row * 8 + i];   // the values of this row, one slot per lane of its group (LT <= 8)
     if (UPD) oth[NO + UPD] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(rl + (size_t)row * ldrl));   // the row's residual / right-hand side
     if (ROLE == 0) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[3].off) * ldx);
     if (ROLE == 2) edge[0] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[4].off) * ldx);
@@ -370,12 +382,12 @@ __device__ __forceinline__ void chain2_body(
     for (int t = 0; t < NO; ++t) oth[t] = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[5 + t].off) * ldx);
   };
   auto finish = [&](const v2d& a, const v2d& b, const v2d& c, const v2d (&edge)[NE + 1], const v2d (&oth)[NO + 1 + UPD],
-                    int p, long it, int buf) {
+                    int p, long it, int buf, double vv) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     double val[LT];
 #pragma unroll
-    for (int t = 0; t < LT; ++t) val[t] = s_tab[p * LT + t].val;
+    for (int t = 0; t < LT; ++t) val[t] = VALS ? group_bcast(vv, lane, t) : s_tab[p * LT + t].val;
     const v2d vm = (ROLE == 0) ? edge[0] : xch[buf][wave - (ROLE == 0 ? 0 : 1)][lane];
     const v2d vp = (ROLE == 2) ? edge[0] : xch[buf][wave + (ROLE == 2 ? 0 : 1)][lane];
     double a0 = val[0] * a.x, a1 = val[0] * a.y;
@@ -432,6 +444,7 @@ __device__ __forceinline__ void chain2_body(
     xch[buf ^ 1][wave][lane] = c;   // the centre row of my next iteration
   };
   v2d r0, r1, r2, r3, ed0[NE + 1], ed1[NE + 1], o0[NO + 1 + UPD], o1[NO + 1 + UPD];
+  double vv0 = 0.0, vv1 = 0.0;
   int p0 = pid[row_of(0)], p1 = pid[row_of(1)];
   {
     const long row = row_of(0);
@@ -440,33 +453,33 @@ __device__ __forceinline__ void chain2_body(
     r3 = *reinterpret_cast<const v2d*>(xl + (size_t)(row + e[1].off) * ldx);
     xch[0][wave][lane] = r3;
   }
-  issue(r0, ed0, o0, row_of(0), p0);
+  issue(r0, ed0, o0, row_of(0), p0, vv0);
   for (long it = 0; it < cnt; it += 4) {   // pattern ids: p0 = row(it), p1 = row(it+1)
     const int p2 = pid[row_of(it + 2)];
-    issue(r1, ed1, o1, row_of(it + 1), p1);
+    issue(r1, ed1, o1, row_of(it + 1), p1, vv1);
     __builtin_amdgcn_sched_barrier(0);
-    finish(r2, r3, r0, ed0, o0, p0, it, 0);
+    finish(r2, r3, r0, ed0, o0, p0, it, 0, vv0);
     __builtin_amdgcn_sched_barrier(0);
     const int p3 = pid[row_of(it + 3)];
-    issue(r2, ed0, o0, row_of(it + 2), p2);
+    issue(r2, ed0, o0, row_of(it + 2), p2, vv0);
     __builtin_amdgcn_sched_barrier(0);
-    finish(r3, r0, r1, ed1, o1, p1, it + 1, 1);
+    finish(r3, r0, r1, ed1, o1, p1, it + 1, 1, vv1);
     __builtin_amdgcn_sched_barrier(0);
     const int p4 = pid[row_of(it + 4)];
-    issue(r3, ed1, o1, row_of(it + 3), p3);
+    issue(r3, ed1, o1, row_of(it + 3), p3, vv1);
     __builtin_amdgcn_sched_barrier(0);
-    finish(r0, r1, r2, ed0, o0, p2, it + 2, 0);
+    finish(r0, r1, r2, ed0, o0, p2, it + 2, 0, vv0);
     __builtin_amdgcn_sched_barrier(0);
     const int p5 = pid[row_of(it + 5)];
-    issue(r0, ed0, o0, row_of(it + 4), p4);
+    issue(r0, ed0, o0, row_of(it + 4), p4, vv0);
     __builtin_amdgcn_sched_barrier(0);
-    finish(r1, r2, r3, ed1, o1, p3, it + 3, 1);
+    finish(r1, r2, r3, ed1, o1, p3, it + 3, 1, vv1);
     __builtin_amdgcn_sched_barrier(0);
     p0 = p4; p1 = p5;
   }
 }
 
-template <int LT, int MODE, int NW>
+template <int LT, int MODE, int NW, bool VALS = false>
 __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
     const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
@@ -495,9 +508,9 @@ __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
   const long bperm = (xcd_runs == 2 && gq % 32 == 0) ? ((bq & ~31L) | ((bq & 7) << 2) | ((bq >> 3) & 3))
                    : (gq % 8 == 0 && xcd_runs == 1) ? ((bq & 7) * (gq >> 3) + (bq >> 3)) : bq;
   if (bperm < ntiles) {   // block-uniform: every wave of the block runs the same number of barriers
-    if (wave == 0) chain2_body<LT, MODE, NW, 0>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
-    else if (wave == NW - 1) chain2_body<LT, MODE, NW, 2>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
-    else chain2_body<LT, MODE, NW, 1>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
+    if (wave == 0) chain2_body<LT, MODE, NW, 0, VALS>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
+    else if (wave == NW - 1) chain2_body<LT, MODE, NW, 2, VALS>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
+    else chain2_body<LT, MODE, NW, 1, VALS>(nrows, pid, s_tab, xch, xl, ldx, y, ldy, act, i, g, wave, lane, ntiles, line, xcd_runs, d0, d1, e0, e1, cg, s_cf);
   }
   if (DOT) {
     auto sx = [](double v, int mask) {
@@ -572,7 +585,7 @@ static long pat_grid(long span, long ntiles) {
   return g < ntiles ? g : ntiles;
 }
 
-template <int LT, int MODE>
+template <int LT, int MODE, bool VALS>
 static long pat_launch(long nrows, const unsigned short* pid, const void* tab, int npat, const double* x, size_t ldx,
                        double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st,
                        long cline, int nw, const CgArgs& cg) {
@@ -580,14 +593,14 @@ static long pat_launch(long nrows, const unsigned short* pid, const void* tab, i
   if (cline > 0) {   // chain + line exchange: nw waves per block, lines of `cline` rows
     if (LT < 5) return -1;
     const long nlines = (nrows + cline - 1) / cline, ntl = (nlines + nw - 1) / nw * (cline / 8);
-#define GCGE_C2(NWV) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), MODE, NWV>), dim3((unsigned)nb), dim3(64 * NWV), \
+#define GCGE_C2(NWV) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), MODE, NWV, VALS>), dim3((unsigned)nb), dim3(64 * NWV), \
                        (size_t)ntab * sizeof(PatEntry), st, nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, ntl, cline, partial, yy_off, g_chain2_xcd, cg)
     if (nw == 16) GCGE_C2(16); else if (nw == 8) GCGE_C2(8); else GCGE_C2(4);
 #undef GCGE_C2
     return nb;
   }
   if (line < 0) {   // chain variant: consecutive slices, the caller fixed nb = S / 32
-    if constexpr (MODE >= 2) return -1;   // the CG passes exist for the chain2 and the plain kernel
+    if constexpr (MODE >= 2 || VALS) return -1;   // the CG passes and the streamed values exist for the chain2 and the plain kernel
     else {
       const long lpr = -line;   // chain variant: lanes per row is passed as -line (8, 16 or 32)
       const long tr = 256 / lpr, ntl = (nrows + tr - 1) / tr;
@@ -598,7 +611,7 @@ static long pat_launch(long nrows, const unsigned short* pid, const void* tab, i
       return nb;
     }
   }
-  hipLaunchKernelGGL((spmm_pattern_kernel<LT, MODE>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
+  hipLaunchKernelGGL((spmm_pattern_kernel<LT, MODE, VALS>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
                      nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, pat_ntiles(nrows, line), line, partial, yy_off, cg);
   return nb;
 }
@@ -607,10 +620,17 @@ template <int MODE>
 static long pat_dispatch(int lt, long nrows, const unsigned short* pid, const void* tab, int npat, const double* x,
                          size_t ldx, double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st,
                          long cline = 0, int nw = 4, const CgArgs& cg = CgArgs{}) {
+  if (cg.rowval != nullptr) {   // offsets-only table, values streamed per row (tables of at most 8 slots)
+    switch (lt) {
+      case 7: return pat_launch<7, MODE, true>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
+      case 8: return pat_launch<8, MODE, true>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
+      default: return -1;
+    }
+  }
   switch (lt) {
-    case 7: return pat_launch<7, MODE>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
-    case 8: return pat_launch<8, MODE>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
-    case 16: return pat_launch<16, MODE>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
+    case 7: return pat_launch<7, MODE, false>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
+    case 8: return pat_launch<8, MODE, false>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
+    case 16: return pat_launch<16, MODE, false>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
     default: return -1;
   }
 }
@@ -630,19 +650,28 @@ extern "C" int gcge_hip_pattern_width(int max_row_len) {
 // CHAIN layout (slots 0,1,2 = offsets -span, 0, +span; see spmm_pattern_chain_kernel) and span is a multiple of 32;
 // span2 == -L <= -8: additionally slots 3,4 = offsets -L, +L (spmm_pattern_chain2_kernel).
 // -1: alignment contract not met.
+extern "C" int gcge_hip_pattern_spmm_vals(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+                                          long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
+                                          double* d_dots, double* d_dots_yy, void* stream, long near, const double* d_rowval);
 extern "C" int gcge_hip_pattern_spmm_near(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                           long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
-                                          double* d_dots, double* d_dots_yy, void* stream, long near);
+                                          double* d_dots, double* d_dots_yy, void* stream, long near) {
+  return gcge_hip_pattern_spmm_vals(nrows, d_pid, d_tab, npat, lt, span, span2, d_x, ldx, d_y, ldy, ncols, d_dots, d_dots_yy, stream, near, nullptr);
+}
 extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                      long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
                                      double* d_dots, double* d_dots_yy, void* stream) {
   return gcge_hip_pattern_spmm_near(nrows, d_pid, d_tab, npat, lt, span, span2, d_x, ldx, d_y, ldy, ncols, d_dots, d_dots_yy, stream, 0);
 }
 // near > 0: as in gcge_hip_pattern_cg_near — the product may take the LDS-ring sweep (spmm_ring.hip)
-extern "C" int gcge_hip_pattern_spmm_near(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+// d_rowval != NULL: the table was built from the rows' OFFSETS only and the values of row r are d_rowval[8 r + slot]
+// (app_hip.hip build_patterns, by_offsets): chain + line-exchange tables and plain tables of at most 8 slots
+extern "C" int gcge_hip_pattern_spmm_vals(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                           long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
-                                          double* d_dots, double* d_dots_yy, void* stream, long near) {
+                                          double* d_dots, double* d_dots_yy, void* stream, long near, const double* d_rowval) {
   if (nrows <= 0 || ncols <= 0) return 0;
+  if (d_rowval != nullptr && lt > 8) return -1;
+  CgArgs cgv = CgArgs{}; cgv.rowval = d_rowval;
   if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15)) return -1;
   if ((size_t)npat * lt * sizeof(PatEntry) > 64 * 1024) return -1;
   hipStream_t st = (hipStream_t)stream;
@@ -661,7 +690,7 @@ extern "C" int gcge_hip_pattern_spmm_near(int nrows, const unsigned short* d_pid
     hipStream_t stc = (hipStream_t)stream;
     double* partc = d_dots ? gcge_hip_partial_ws((size_t)nbc * 16 * npassc * 2) : nullptr;
     const long yyc = (long)nbc * 16 * npassc;
-    bool ring = near > 0 && lt == 7 && d_x != d_y;
+    bool ring = near > 0 && lt == 7 && d_x != d_y && d_rowval == nullptr;
     for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
       const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
       double* pp = partc ? partc + (size_t)ps * nbc * 16 : nullptr;
@@ -670,15 +699,15 @@ extern "C" int gcge_hip_pattern_spmm_near(int nrows, const unsigned short* d_pid
                                d_y + c0, ldy) == 0) continue;
         ring = false;   // declined (first pass): the chain2 kernel below
       }
-      long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyc, nbc, 8, stc, L, nw)
-                        : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nbc, 8, stc, L, nw);
+      long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyc, nbc, 8, stc, L, nw, cgv)
+                        : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nbc, 8, stc, L, nw, cgv);
       if (rcl < 0) return -1;
     }
     if (d_dots) gcge_hip_reduce_partials16(partc, (int)nbc, nbc * 16, ncols, d_dots, stc);
     if (d_dots && d_dots_yy) gcge_hip_reduce_partials16(partc + yyc, (int)nbc, nbc * 16, ncols, d_dots_yy, stc);
     return (int)hipGetLastError();
   }
-  if (span2 <= -1) {   // chain layout: the wave stride must be exactly `span` rows
+  if (span2 <= -1 && d_rowval == nullptr) {   // chain layout: the wave stride must be exactly `span` rows (streamed values: the plain kernel below)
     if (span % 32 != 0 || lt < 4) return -1;
     // pass width: 16, 32 or 64 columns (lanes per row 8 / 16 / 32); the wave stride must stay exactly `span` rows
     int lpr = g_chain_lpr;
@@ -701,7 +730,7 @@ extern "C" int gcge_hip_pattern_spmm_near(int nrows, const unsigned short* d_pid
     if (d_dots && d_dots_yy) gcge_hip_reduce_partials_slabs(partc + yyc, (int)nbc, nbc * cpp, cpp, ncols, d_dots_yy, stc);
     return (int)hipGetLastError();
   }
-  if (g_pat_line < 0 && span2 >= 8 && span2 % 8 == 0 && span > span2 && span % (4 * span2) == 0) line = span2;
+  if (g_pat_line < 0 && span2 >= 8 && span2 % 8 == 0 && span > span2 && span % (4 * span2) == 0) line = span2;   // (span2 < 0 here: chain-layout table with streamed values, plain kernel)
   if (g_pat_line >= 8 && g_pat_line % 8 == 0) line = g_pat_line;
   const long nb = pat_grid(span, pat_ntiles(nrows, line));
   double* part = d_dots ? gcge_hip_partial_ws((size_t)nb * 16 * npass * 2) : nullptr;
@@ -710,8 +739,8 @@ extern "C" int gcge_hip_pattern_spmm_near(int nrows, const unsigned short* d_pid
     const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
     if (d_dots) {
       double* pp = part + (size_t)ps * nb * 16;
-      if (pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyo, nb, line, st) < 0) return -1;
-    } else if (pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nb, line, st) < 0) {
+      if (pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyo, nb, line, st, 0, 4, cgv) < 0) return -1;
+    } else if (pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nb, line, st, 0, 4, cgv) < 0) {
       return -1;
     }
   }
@@ -729,10 +758,24 @@ extern "C" int gcge_hip_pattern_spmm_near(int nrows, const unsigned short* d_pid
 // (its table is a valid generic one).  -1: not applicable (alignment), the caller keeps the unfused recurrence.
 // near > 0: the table's slots are [-S, 0, +S, -L, +L, -1, +1] (7-point stencil) and near is the largest |offset| in it
 // (GCGE_HIP_MAT_::pat_near): modes 2 and 4 may take the LDS-ring sweep of spmm_ring.hip.
+extern "C" int gcge_hip_pattern_cg_vals(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+                                        long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
+                                        long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
+                                        double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, long near,
+                                        const double* d_rowval);
 extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                         long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
                                         long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
                                         double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, long near) {
+  return gcge_hip_pattern_cg_vals(mode, nrows, d_pid, d_tab, npat, lt, span, span2, d_x, ldx, d_r, ldr, d_pnew, ldp, ncols, d_alpha, d_beta,
+                                  d_flag, d_dots, d_dots_yy, stream, d_b, ldb, near, nullptr);
+}
+extern "C" int gcge_hip_pattern_cg_vals(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
+                                        long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
+                                        long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
+                                        double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, long near,
+                                        const double* d_rowval) {
+  if (d_rowval != nullptr && lt > 8) return -1;
   if (mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 6 && mode != 7) return -1;
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || ((uintptr_t)d_x & 15) || d_dots == nullptr) return -1;
@@ -754,7 +797,7 @@ extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned shor
   double* part = gcge_hip_partial_ws((size_t)nb * 16 * npass * 2);
   const long yyo = (long)nb * 16 * npass;
   // read-only passes on a [-S, 0, +S, -L, +L, -1, +1] table: the LDS-ring sweep (spmm_ring.hip), same geometry and workspace
-  bool ring = near && lt == 7 && nw >= 4 && (mode == 2 || mode == 4);
+  bool ring = near && lt == 7 && nw >= 4 && (mode == 2 || mode == 4) && d_rowval == nullptr;
   for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
     const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
     double* pp = part + (size_t)ps * nb * 16;
@@ -763,21 +806,21 @@ extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned shor
       if (gcge_hip_ring_pass(mode, nrows, d_pid, d_tab, npat, L, nw, nb, d_x + c0, ldx, m, pp, yyo, mode == 4 ? d_alpha + c0 : nullptr, st, near, nullptr, 0) == 0) continue;
       ring = false;   // declined (first pass): the chain2 kernel below
     }
-    if (mode == 2) rc = pat_dispatch<2>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw);
+    if (mode == 2) { CgArgs cg = CgArgs{}; cg.rowval = d_rowval; rc = pat_dispatch<2>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg); }
     else if (mode == 4) {
-      const CgArgs cg = {nullptr, 0, nullptr, 0, d_alpha + c0, nullptr, nullptr, nullptr, 0};
+      const CgArgs cg = {nullptr, 0, nullptr, 0, d_alpha + c0, nullptr, nullptr, nullptr, 0, d_rowval};
       rc = pat_dispatch<4>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
     } else if (mode == 5) {
-      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, nullptr, nullptr, nullptr, d_b + c0, (size_t)ldb};
+      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, nullptr, nullptr, nullptr, d_b + c0, (size_t)ldb, d_rowval};
       rc = pat_dispatch<5>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
     } else if (mode == 6) {
-      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, nullptr, nullptr, nullptr, 0};
+      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, nullptr, nullptr, nullptr, 0, d_rowval};
       rc = pat_dispatch<6>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
     } else if (mode == 7) {   // d_r: p_{k-1} (read only), d_b: the previous iteration's beta
-      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0, d_b + c0, 0};
+      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0, d_b + c0, 0, d_rowval};
       rc = pat_dispatch<7>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
     } else {
-      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0, nullptr, 0};
+      const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0, nullptr, 0, d_rowval};
       rc = pat_dispatch<3>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
     }
     if (rc < 0) return -1;

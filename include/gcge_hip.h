@@ -157,6 +157,17 @@ void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > X tiles > pa
  *     the tile's list of X rows, which the kernel stages in LDS once per 16-column pass.  mode: 0 automatic, 1 every
  *     matrix without a pattern form, 2 every matrix, -1 never (takes effect at the next gcge_hip_mat_create*)          */
 void gcge_hip_spmm_tile_mode (int mode);
+/*     supernode path (csrc/hip/spmm_dense.hip): row sets that share a column set (the dense blocks real-space DFT
+ *     Hamiltonians keep per atom) are found at upload and multiplied as dense blocks on FP64 MFMA, the rest of the
+ *     matrix through the generic kernels.  mode: 0 automatic (seeds: rows of >= 96 entries, blocks must hold >= 10 % of
+ *     the non-zeros), 1 rows of >= 24 entries may seed (tests), -1 never                                                */
+void gcge_hip_spmm_dense_mode (int mode);
+long gcge_hip_dense_selfcheck (int nrows, int ncols_local, const int *rowptr, const int *colidx, const double *val,
+		int min_len, long *nblocks, double *share, double *fill);   /* host-only: blocks + remainder == CSR, bit for bit */
+/*     stencils whose coefficients differ from row to row: the pattern table is then built from the rows' column OFFSETS
+ *     only and the values are streamed per row (8 doubles per row), so such matrices keep the pattern kernels (tables of
+ *     at most 8 slots); 0 switches that off (takes effect at the next gcge_hip_mat_create*)                             */
+void gcge_hip_set_offset_patterns (int on);
 /*     host-only structural self-check of that upload (no device needed): expands the tiles back into (row, column,
  *     value) triples and compares with the CSR arrays bit for bit; returns the number of differences (0 = identical),
  *     the X rows staged per matrix row, the ELL entries per non-zero and the grid strides it detected (0: none)       */

@@ -126,3 +126,19 @@ def sine_start_block(N, modes, eps, seed):
 
 
 WARM_MODES = [(1, 1, 1), (2, 1, 1), (1, 2, 1), (1, 1, 2), (2, 2, 1), (2, 1, 2)]
+
+
+def perturbed_stencil(kind, size, seed, which="A"):
+    """The matrix of make_problem(kind, size) with the same pattern and DIFFERENT coefficients in every row (symmetric,
+    strictly diagonally dominant: SPD): a_ij = -(1 + 0.2 w_i w_j) |a_ij(orig)| off the diagonal, a_ii = sum_j |a_ij| + 0.1.
+    Returns (CSR struct, keepalive)."""
+    import scipy.sparse as sp
+    A, B = make_problem(kind, size)
+    S = csr_to_scipy(A if which == "A" else B).tocoo()
+    w = uniform(seed, (S.shape[0],))
+    off = S.row != S.col
+    data = np.where(off, -(1.0 + 0.2 * w[S.row] * w[S.col]) * np.abs(S.data), 0.0)
+    M = sp.coo_matrix((data, (S.row, S.col)), shape=S.shape).tocsr()
+    d = np.asarray(np.abs(M).sum(axis=1)).ravel() + 0.1
+    M = (M + sp.diags(d)).tocsr()
+    return csr_from_scipy(M)

@@ -1147,3 +1147,132 @@ def test_dense_block_spmm_vs_oracle(both, case):
     finally:
         g.gcge_hip_set_spmm_path(0)
         g.gcge_hip_spmm_dense_mode(0)
+
+
+@pytest.mark.parametrize("kind,size,form", [("lap3d", 16, "spmm_pattern_chain2+values"), ("lap3d", 32, "spmm_pattern_chain2+values"),
+                                            ("lap3d", 13, "spmm_pattern+values")])
+def test_offset_pattern_spmm_vs_oracle(both, kind, size, form):
+    """K1 on stencils with row-dependent coefficients (patterns by OFFSETS only, values streamed per row: 8 doubles per row
+    next to the 16-bit pattern id) against the CPU oracle, scipy and the pad-8 kernel: the chain + line-exchange kernel
+    (grid lines tile a plane) and the plain pattern kernel, ragged widths, odd column offsets, the fused column sums."""
+    from helpers import perturbed_stencil
+    hip, ora = both
+    g = hip.g
+    g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+    g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+    A, keep = perturbed_stencil(kind, size, 21)
+    mh, mo = hip.matrix(A), ora.matrix(A)
+    assert g.gcge_hip_mat_spmm_form(mh).decode() == form, g.gcge_hip_mat_spmm_form(mh).decode()
+    n = A.nrows
+    S = csr_to_scipy(A)
+    X = uniform(11, (n, 136)) - 0.5
+    xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
+    for m, s0, s1 in [(64, 0, 0), (16, 2, 4), (2, 0, 0), (30, 4, 2), (66, 6, 0), (130, 0, 2), (17, 1, 0), (16, 1, 2), (48, 8, 16), (1, 0, 0)]:
+        Y0 = uniform(8, (n, 136))
+        yh, yo = hip.mv_from_numpy(mh, Y0), ora.mv_from_numpy(mo, Y0)
+        hip.ops.spmm(mh, xh, yh, (s0, s1), (s0 + m, s1 + m))
+        ora.ops.spmm(mo, xo, yo, (s0, s1), (s0 + m, s1 + m))
+        got = hip.mv_to_numpy(yh, n, 0, 136)
+        _close(got, ora.mv_to_numpy(yo, n, 0, 136), tol=1e-13, what="offset-pattern spmm m=%d" % m)
+        _close(got[:, s1:s1 + m], S @ X[:, s0:s0 + m], tol=1e-13, what="offset-pattern spmm vs scipy m=%d" % m)
+        hip.ops.mv_destroy(yh); ora.ops.mv_destroy(yo)
+    yh = hip.mv_from_numpy(mh, np.zeros((n, 64)))
+    hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
+    a = hip.mv_to_numpy(yh, n, 0, 64)
+    g.gcge_hip_set_spmm_path(3)
+    try:
+        hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
+        _close(a, hip.mv_to_numpy(yh, n, 0, 64), tol=1e-13, what="streamed values vs pad-8")
+    finally:
+        g.gcge_hip_set_spmm_path(0)
+    hip.free_matrix(mh)
+
+
+@pytest.mark.parametrize("size,m", [(16, 22), (16, 64), (13, 6)])
+def test_offset_pattern_cg_passes_match_numpy(hip, size, m):
+    """The passes of the fused CG (recompute form, no stored residual, start sweep, residual norms) on a stencil with
+    row-dependent coefficients against numpy."""
+    import torch
+    from helpers import perturbed_stencil
+    A, keep = perturbed_stencil("lap3d", size, 5)
+    S = csr_to_scipy(A)
+    n = A.nrows
+    mat = hip.matrix(A)
+    g = hip.g
+    g.gcge_hip_cg_fusable.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    g.gcge_hip_cg_pass1_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    g.gcge_hip_cg_pass2_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    g.gcge_hip_cg_pass2i_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    g.gcge_hip_cg_start_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    ncol = m + 4
+    P = uniform(11, (n, ncol)) - 0.5
+    R = uniform(12, (n, ncol)) - 0.5
+    Q = uniform(15, (n, ncol)) - 0.5
+    p, r, q = hip.mv_from_numpy(mat, P), hip.mv_from_numpy(mat, R), hip.mv_from_numpy(mat, Q)
+    pn = hip.mv_from_numpy(mat, np.full((n, ncol), 7.0))
+    assert g.gcge_hip_cg_fusable(mat, p, m) == 1
+    W = S @ P[:, 2:2 + m]
+    pw, ww = np.zeros(m), np.zeros(m)
+    assert g.gcge_hip_cg_pass1_mv(mat, p, 2, m, pw.ctypes.data, ww.ctypes.data) == 0
+    np.testing.assert_allclose(pw, np.sum(P[:, 2:2 + m] * W, axis=0), rtol=1e-12, atol=1e-12 * n)
+    np.testing.assert_allclose(ww, np.sum(W * W, axis=0), rtol=1e-12)
+    alpha, beta, bprev = uniform(13, (m,)) + 0.5, uniform(14, (m,)) + 0.1, uniform(16, (m,)) + 0.2
+    flag = np.ones(m, dtype=np.int32)
+    flag[1::3] = 0
+    act = flag.astype(bool)
+    d_al, d_be, d_fl, d_bp = (torch.from_numpy(v).cuda() for v in (alpha, beta, flag, bprev))
+    rho = np.zeros(m)
+    # stored residual
+    assert g.gcge_hip_cg_pass2_mv(mat, p, r, pn, 2, m, d_al.data_ptr(), d_be.data_ptr(), d_fl.data_ptr(), rho.ctypes.data) == 0
+    Rn = R[:, 2:2 + m] - W * np.where(act, alpha, 0.0)
+    Pn = np.where(act, 1.0, 0.0) * Rn + np.where(act, beta, 1.0) * P[:, 2:2 + m]
+    tol = 1e-13 * np.abs(W).max() + 1e-15
+    np.testing.assert_allclose(hip.mv_to_numpy(r, n, 2, 2 + m), Rn, rtol=0, atol=tol)
+    np.testing.assert_allclose(hip.mv_to_numpy(pn, n, 2, 2 + m), Pn, rtol=0, atol=tol)
+    np.testing.assert_allclose(rho, np.sum(np.where(act, 1.0, 0.0) * Rn * Rn, axis=0), rtol=1e-12)
+    # no stored residual: r_k = p_k - beta_prev p_prev rebuilt on the spot (q plays p_prev)
+    assert g.gcge_hip_cg_pass2i_mv(mat, p, q, pn, 2, m, d_al.data_ptr(), d_be.data_ptr(), d_fl.data_ptr(), d_bp.data_ptr(), rho.ctypes.data) == 0
+    Rk = P[:, 2:2 + m] - bprev * Q[:, 2:2 + m]
+    Rn = Rk - W * np.where(act, alpha, 0.0)
+    Pn = np.where(act, 1.0, 0.0) * Rn + np.where(act, beta, 1.0) * P[:, 2:2 + m]
+    np.testing.assert_allclose(hip.mv_to_numpy(pn, n, 2, 2 + m), Pn, rtol=0, atol=tol)
+    np.testing.assert_allclose(rho, np.sum(np.where(act, 1.0, 0.0) * Rn * Rn, axis=0), rtol=1e-12)
+    # start sweep: r = b - A x, p0 = r
+    rho0 = np.zeros(m)
+    assert g.gcge_hip_cg_start_mv(mat, p, 2, q, 2, r, pn, 2, m, rho0.ctypes.data) == 0
+    R0 = Q[:, 2:2 + m] - W
+    np.testing.assert_allclose(hip.mv_to_numpy(r, n, 2, 2 + m), R0, rtol=0, atol=tol)
+    np.testing.assert_allclose(hip.mv_to_numpy(pn, n, 2, 2 + m), R0, rtol=0, atol=tol)
+    np.testing.assert_allclose(rho0, np.sum(R0 * R0, axis=0), rtol=1e-12)
+    for v in (p, r, q, pn):
+        hip.ops.mv_destroy(v, ncol)
+    hip.free_matrix(mat)
+
+
+def test_gcg_on_variable_coefficient_stencil_matches_oracle(both):
+    """Whole eigensolve (fused CG, Cholesky-QR orthonormalisation) on a 7-point stencil with row-dependent coefficients —
+    pattern kernels with streamed values throughout — against the CPU oracle's run of the same solver: Ritz values
+    <= 1e-10 relative."""
+    from helpers import perturbed_stencil
+    from gcge_amd.lib import run_gcg
+    hip, ora = both
+    g = hip.g
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    g.gcge_hip_bpcg_recompute_iters.restype = C.c_long
+    A, keep = perturbed_stencil("lap3d", 16, 33)
+    mh, mo = hip.matrix(A), ora.matrix(A)
+    g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    hip.set_random_mode(0)
+    C.CDLL(None).srand(0)
+    before = g.gcge_hip_bpcg_recompute_iters()
+    args = ["-nevConv", 10, "-gcge_initX_orth_method", "chol", "-gcge_compW_orth_method", "chol"]
+    ev_h, res_h = run_gcg(hip.ops_handle, mh, None, args, flag=1)
+    assert g.gcge_hip_bpcg_recompute_iters() > before, "the fused CG did not take the recompute form on the offset-pattern matrix"
+    C.CDLL(None).srand(0)
+    ev_o, res_o = run_gcg(ora.ops_handle, mo, None, ["-nevConv", 10])
+    k = min(res_h.nevConv, res_o.nevConv)
+    assert k >= 10
+    assert np.max(np.abs(ev_h[:k] - ev_o[:k]) / np.abs(ev_o[:k])) < 1e-10
+    hip.free_matrix(mh)
