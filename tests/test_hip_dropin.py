@@ -34,7 +34,7 @@ def _ref_stack_on_hip(hip, c, flag):
         hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
         hip.g.gcge_hip_bpcg_setup(ops, 30, 1e-2, 1e-14, b"abs")
     hip.set_random_mode(0)
-    A, B = make_problem(c["kind"], c["size"])
+    A, B = make_problem(c["kind"], c["size"], **c.get("kw", {}))
     mA = hip.matrix(A)
     mB = hip.matrix(B) if B is not None else None
     ref.ref_gcg_solve_foreign.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -85,13 +85,18 @@ def test_reference_stack_drives_hip_slots_c2_shape(hip):
 
 @pytest.mark.parametrize("key,variant", [("c2shape_lap3d_24", "mgs"), ("c2shape_lap3d_24", "chol+fused"),
                                          ("c3shape_fe3d_20", "mgs"), ("c3shape_fe3d_20", "chol+fused"),
-                                         ("c4shape_lap3d_28", "chol+fused")])
+                                         ("c4shape_lap3d_28", "chol+fused"),
+                                         ("c5shape_sio2_24", "mgs"), ("c5shape_sio2_24", "chol+fused"),
+                                         ("c1_lap3d_50", "mgs"), ("c1_lap3d_50", "chol+fused")])
 def test_gcg_on_hip_at_baseline_solver_shapes(hip, key, variant):
-    """Our driver over the HIP slots at the block / nevMax of BASELINE configs 2-4 (reduced grids), against the
-    reference's own runs at those shapes: default column-wise MGS + host-scalar BlockPCG, and what bench.py runs
-    (block Cholesky-QR + fused device CG)."""
+    """Our driver over the HIP slots at the block / nevMax of BASELINE configs 2-5 (reduced grids; config 5: the
+    SiO2-like matrix, dense-block + remainder SpMM) and BASELINE config 1 at FULL size (Lap3D 50^3, nev 20, harness
+    defaults: the values SURVEY 8c lists), against the reference's own runs at those shapes: default column-wise MGS +
+    host-scalar BlockPCG, and what bench.py runs (block Cholesky-QR + fused device CG)."""
     c = SHAPES[key]
-    args = ["-nevConv", c["nev"], "-nevMax", c["nev_max"], "-blockSize", c["block"]]
+    args = ["-nevConv", c["nev"]]
+    if c["nev_max"]:
+        args += ["-nevMax", c["nev_max"], "-blockSize", c["block"]]
     flag = 0
     if variant == "chol+fused":
         hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
@@ -99,7 +104,7 @@ def test_gcg_on_hip_at_baseline_solver_shapes(hip, key, variant):
         args += ["-gcge_initX_orth_method", "chol", "-gcge_compW_orth_method", "chol"]
         flag = 1
     hip.set_random_mode(0)
-    A, B = make_problem(c["kind"], c["size"])
+    A, B = make_problem(c["kind"], c["size"], **c.get("kw", {}))
     mA = hip.matrix(A)
     mB = hip.matrix(B) if B is not None else None
     ev, res = run_gcg(hip.ops_handle, mA, mB, args, flag=flag)

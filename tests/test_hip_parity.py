@@ -207,7 +207,10 @@ GCG = load_golden("gcg.json")
 @pytest.mark.parametrize("key", ["lap3d_12_nev10", "lap3d_20_nev20", "lap3d_16_nev12_b8", "fe3d_12_nev10",
                                  "fe3d_20_nev20", "fe1d_807_nev30", "sio2_12_nev10", "fe3d_14_nev20_init30",
                                  "lap3d_16_nev20_init24", "lap3d_12_nev10_shift1", "fe3d_12_nev10_autoshift",
-                                 "fe3d_12_nev10_order2", "lap3d_16_nev12_b8_order2_shift"])
+                                 "fe3d_12_nev10_order2", "lap3d_16_nev12_b8_order2_shift",
+                                 # a12 on the GPU: -gcge_compP_orth_method bqr (DenseMatOrth, app_lapack.c:653-699) and bgs for X
+                                 # (ops_eig_sol_gcg.c:373-414) through the HIP table; auto-shift and the second-order W on the Laplacian
+                                 "lap3d_12_nev10_bqrP", "lap3d_12_nev10_bgsX", "lap3d_12_nev10_autoshift", "lap3d_12_nev10_order2"])
 def test_gcg_on_hip_matches_reference_run(hip, key):
     c = GCG[key]
     args = ["-nevConv", c["nev"]]

@@ -70,7 +70,7 @@ def test_gcg_driver_at_baseline_solver_shapes(oracle, key):
     at these widths, so the converged count at exit depends on the iteration the wanted count is reached in; the
     wanted count, the iteration count and every commonly converged value are pinned (the C4 shape runs on the GPU)."""
     c = SHAPES[key]
-    ev, res = gcg_on(oracle, c["kind"], c["size"], ["-nevConv", c["nev"], "-nevMax", c["nev_max"], "-blockSize", c["block"]])
+    ev, res = gcg_on(oracle, c["kind"], c["size"], ["-nevConv", c["nev"], "-nevMax", c["nev_max"], "-blockSize", c["block"]], **c.get("kw", {}))
     assert res.nevConv >= c["nev"] and abs(res.numIter - c["numIter"]) <= 2, (res.nevConv, res.numIter, c["numIter"])
     k = min(res.nevConv, c["nevConv"])
     ref = np.array(c["eval"][:k])

@@ -29,6 +29,7 @@ hip.set_random_mode(1, 7)
 ops = hip.ops
 for label, offs in (("offset patterns + streamed values", 1), ("generic kernels", 0)):
     g.gcge_hip_set_offset_patterns(offs)
+    hip.set_random_mode(1, 7)          # the same start block for both forms
     mA = hip.matrix(A)
     V = ops.mv_create(2 * m, mA); ops.set_random(V, 0, 2 * m)
     Wv = ops.mv_create(m, mA)
