@@ -1156,7 +1156,7 @@ extern "C" void OPS_HIP_Set(struct OPS_* ops) {
   GCGE_SetInplaceLinearComb((void*)HIP_MultiVecLinearComb, 128);
   {   // K7 on the device for the projected matrices where the host solver dominates an outer iteration (eig_device.hip)
     const char* mn = getenv("GCGE_EIG_DEVICE_MIN_N");
-    GCGE_SetSymEigHook(gcge_hip_symeig, mn ? atoi(mn) : 192);
+    GCGE_SetSymEigHook(gcge_hip_symeig, mn ? atoi(mn) : 192, (void*)HIP_MultiVecLinearComb);
   }
   ops->MatTransDotMultiVec      = HIP_MatTransDotMultiVec;
   ops->MultiVecQtAP             = nullptr;   // OPS_Setup installs SpMM-into-mv_ws + Gram

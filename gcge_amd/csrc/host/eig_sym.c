@@ -183,15 +183,24 @@ static int ql_implicit(int n, double *d, double *e, double *q, double *cs, int n
  * matching orthonormal eigenvectors.  a is NOT modified.  work: >= 2n doubles.
  * Returns 0 on success (-1: out of memory). */
 /* A back-end may offer the same computation on its device for n >= min_n (GCGE_SetSymEigHook, gcge_solver.h): the HIP
- * back-end registers csrc/hip/eig_device.hip.  GCGE_EIG_HOST=1 keeps everything on the host. */
-static GCGE_SYMEIG_FN g_eig_hook = NULL; static int g_eig_hook_min_n = 0;
-void GCGE_SetSymEigHook(GCGE_SYMEIG_FN fn, int min_n) { g_eig_hook = fn; g_eig_hook_min_n = min_n; }
+ * back-end registers csrc/hip/eig_device.hip.  The hook belongs to ONE operator table: it is keyed on `owner` (the table's
+ * MultiVecLinearComb slot, as the other capabilities of gcge_ops.h), and only solver calls made on behalf of that table
+ * (GCGE_SymEigFor) reach the device — the CPU oracle and the host-only entry point GCGE_SymEig never do, whatever was
+ * registered in the process.  GCGE_EIG_HOST=1 keeps everything on the host. */
+static GCGE_SYMEIG_FN g_eig_hook = NULL; static int g_eig_hook_min_n = 0; static void *g_eig_owner = NULL;
+void GCGE_SetSymEigHook(GCGE_SYMEIG_FN fn, int min_n, void *owner) { g_eig_hook = fn; g_eig_hook_min_n = min_n; g_eig_owner = owner; }
 int GCGE_SymEigHost(char uplo, int n, const double *a, int lda, double *w, double *z, int ldz, double *work);
 
 int GCGE_SymEig(char uplo, int n, const double *a, int lda, double *w,
 		double *z, int ldz, double *work)
 {
-	if (g_eig_hook != NULL && n >= g_eig_hook_min_n && getenv("GCGE_EIG_HOST") == NULL) {
+	return GCGE_SymEigHost(uplo, n, a, lda, w, z, ldz, work);
+}
+
+int GCGE_SymEigFor(void *owner, char uplo, int n, const double *a, int lda, double *w,
+		double *z, int ldz, double *work)
+{
+	if (g_eig_hook != NULL && owner != NULL && owner == g_eig_owner && n >= g_eig_hook_min_n && getenv("GCGE_EIG_HOST") == NULL) {
 		const int info = g_eig_hook(uplo, n, a, lda, w, z, ldz);
 		if (info == 0) return 0;            /* otherwise: fall through to the host solver */
 	}

@@ -230,7 +230,11 @@ static void ComputeW(Ctx *c, int *offset)
 	if (p->compW_cg_auto_shift == 1)
 		sigma = -c->ss_eval[c->sizeC] + (c->ss_eval[c->sizeC + 1] - c->ss_eval[c->sizeC]) * 0.01;
 	p->sigma = sigma = p->compW_cg_shift + sigma;
-	assert(p->compW_cg_auto_shift == 0 || p->user_defined_multi_linear_solver == 0);
+	/* (the reference asserts here that auto-shift and a user-defined solver are not combined, ops_eig_sol_gcg.c:497: its
+	 *  hook hands the solver A only.  Ours publishes sigma and B through GCGE_SetLinearSolverShift below, so a solver
+	 *  installed behind flag 1 that reads them — the fused device CG does — takes the automatic shift like a fixed one;
+	 *  flag 2 solvers still get A alone and are refused) */
+	assert(p->compW_cg_auto_shift == 0 || p->user_defined_multi_linear_solver != 2);
 
 	/* B == NULL and a solver that takes "b = x diag(scale)" (GCGE_SetRhsScaleCapability): b is not formed */
 	const int scaled_rhs = p->user_defined_multi_linear_solver == 1 && c->B == NULL &&
@@ -271,6 +275,9 @@ static void ComputeW(Ctx *c, int *offset)
 		}
 	}
 	if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverShift(sigma, c->B);
+	/* the column scales (lambda_j + sigma): what BlockPCG finds at the start of its scalar scratch for the "user"
+	 * tolerance type (ops_lin_sol.c:186-192); a solver behind flag 1 has no such scratch and reads them here */
+	if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverUserScale(scales, blk);
 	if (scaled_rhs) GCGE_SetLinearSolverRhsScale(scales);
 	if (p->user_defined_multi_linear_solver == 1) {   /* the work blocks are idle until the orthonormalisation below */
 		cg_ws[0] = c->ws0; cg_ws[1] = c->ws1; cg_ws[2] = c->ws2;
@@ -278,6 +285,7 @@ static void ComputeW(Ctx *c, int *offset)
 	}
 	ops->MultiLinearSolver(c->A, b, c->V, s, e, ops);
 	GCGE_SetLinearSolverIdleBlocks(NULL, 0);
+	GCGE_SetLinearSolverUserScale(NULL, 0);
 	if (scaled_rhs) GCGE_SetLinearSolverRhsScale(NULL);
 	if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverShift(0.0, NULL);
 	if (sigma != 0.0 && c->B != NULL && ops->MatAxpby != NULL
@@ -311,7 +319,7 @@ static void ComputeW12(Ctx *c, int *offset)
 	if (p->compW_cg_auto_shift == 1)
 		sigma = -c->ss_eval[c->sizeC] + (c->ss_eval[c->sizeC + 1] - c->ss_eval[c->sizeC]) * 0.01;
 	p->sigma = sigma = p->compW_cg_shift + sigma;
-	assert(p->compW_cg_auto_shift == 0 || p->user_defined_multi_linear_solver == 0);
+	assert(p->compW_cg_auto_shift == 0 || p->user_defined_multi_linear_solver != 2);   /* as in ComputeW */
 	use_axpby = sigma != 0.0 && c->B != NULL && ops->MatAxpby != NULL && p->user_defined_multi_linear_solver != 1;
 
 	for (idx = 0; idx < offset[0]; ++idx) total += offset[idx * 2 + 2] - offset[idx * 2 + 1];
@@ -345,7 +353,7 @@ static void ComputeW12(Ctx *c, int *offset)
 						p->compW_cg_tol_type, cg_ws, c->scratch, c->iscratch, NULL,
 						(sigma != 0.0 && !use_axpby) ? MatDotMultiVecShift : NULL, ops);
 			}
-			if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverShift(sigma, c->B);
+			if (p->user_defined_multi_linear_solver == 1) { GCGE_SetLinearSolverShift(sigma, c->B); GCGE_SetLinearSolverUserScale(scales, half); }
 			s[0] = offset[1]; e[0] = s[0] + half; s[1] = c->startW; e[1] = s[1] + half;
 			ops->MultiLinearSolver(c->A, b, c->V, s, e, ops);
 			g_timing.linsol += ops->GetWtime() - t1;
@@ -359,7 +367,7 @@ static void ComputeW12(Ctx *c, int *offset)
 	s[0] = offset[1]; e[0] = s[0] + half; s[1] = c->endW; e[1] = s[1] + half;
 	ops->MultiLinearSolver(c->A, b, c->V, s, e, ops);
 	g_timing.linsol += ops->GetWtime() - t1;
-	if (p->user_defined_multi_linear_solver == 1) GCGE_SetLinearSolverShift(0.0, NULL);
+	if (p->user_defined_multi_linear_solver == 1) { GCGE_SetLinearSolverShift(0.0, NULL); GCGE_SetLinearSolverUserScale(NULL, 0); }
 	c->endW += half;
 	assert(c->endW - c->startW <= total);
 	if (use_axpby) ops->MatAxpby(-sigma, c->B, 1.0, c->A, ops);
@@ -425,7 +433,7 @@ static void ComputeRayleighRitz(Ctx *c, int nevConv)
 
 	t1 = ops->GetWtime();
 	work = c->scratch + (size_t)c->sizeP * c->sizeP;
-	info = GCGE_SymEig('U', N, c->ss_matA, N, c->ss_eval + c->sizeC, c->ss_evec, N, work);
+	info = GCGE_SymEigFor((void*)ops->MultiVecLinearComb, 'U', N, c->ss_matA, N, c->ss_eval + c->sizeC, c->ss_evec, N, work);
 	assert(info == 0); (void)info;
 	g_timing.dsyevx += ops->GetWtime() - t1;
 

@@ -58,6 +58,9 @@ int GCGE_InplaceLinearCombCols(void *owner)
 
 static double g_ls_sigma = 0.0; static void *g_ls_matB = NULL;
 void GCGE_SetLinearSolverShift(double sigma, void *matB) { g_ls_sigma = sigma; g_ls_matB = matB; }
+static const double *g_user_scale = NULL; static int g_user_scale_n = 0;
+void GCGE_SetLinearSolverUserScale(const double *scale, int n) { g_user_scale = scale; g_user_scale_n = scale != NULL ? n : 0; }
+const double *GCGE_GetLinearSolverUserScale(int *n) { if (n != NULL) *n = g_user_scale_n; return g_user_scale; }
 void GCGE_GetLinearSolverShift(double *sigma, void **matB)
 {
 	if (sigma) *sigma = g_ls_sigma;

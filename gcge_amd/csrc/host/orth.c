@@ -330,7 +330,7 @@ static void orth_self_evp(void **x, int start_x, int *end_x, void *B, int max_re
 		G = ws; U = G + (size_t)N * N; w = U + (size_t)N * N; work = w + N;
 		start[0] = start_x; end[0] = *end_x; start[1] = start_x; end[1] = *end_x;
 		ops->MultiVecQtAP('S', 'S', x, B, x, 0, start, end, G, N, mv_ws, ops);
-		info = GCGE_SymEig('L', N, G, N, w, U, N, work);
+		info = GCGE_SymEigFor((void*)ops->MultiVecLinearComb, 'L', N, G, N, w, U, N, work);
 		assert(info == 0); (void)info;
 		for (k = 0; k < N; ++k) {
 			assert(w[k] > -zero_tol);

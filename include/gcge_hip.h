@@ -108,6 +108,11 @@ void gcge_hip_set_random_mode (int mode, unsigned long long seed);
  * call this once, then run the harness with flag = 1.                                  */
 void gcge_hip_bpcg_setup (struct OPS_ *ops, int max_iter, double rate, double tol, const char *tol_type);
 void gcge_hip_bpcg_stats (long *spmm_calls, long *spmm_cols, int *last_niter);
+/*     tol_type: "abs", "rel" or "user" (src/ops_lin_sol.c:175-197; "user": scales from GCGE_GetLinearSolverUserScale).
+ *     Residual of the recompute form: 0 automatic (not stored where rate >= 1e-4 and max_iter <= 100), 1 never stored
+ *     (r_k = p_k - beta_{k-1} p_{k-1} rebuilt from the ring), 2 always stored                                         */
+void gcge_hip_bpcg_residual_form (int form);
+long gcge_hip_bpcg_surplus_iters (void);   /* iterations enqueued after the last column retired (device-scalar loop) */
 /* iterations the fused solver ran in its recompute form (pattern matrices: the product A p is formed twice per
  * iteration and never stored, gcge_hip_cg_pass1_mv / gcge_hip_cg_pass2_mv); GCGE_CG_NO_RECOMPUTE=1 switches it off */
 long gcge_hip_bpcg_recompute_iters (void);
@@ -132,6 +137,7 @@ long gcge_hip_profile_kind (int kind, int ncols, double *total_ms, double *total
  * z (HOST, ld ldz) orthonormal eigenvectors.  Householder tridiagonalisation and the accumulation of Q on the device,
  * implicit QL on the host with recorded rotations, replayed on the device (csrc/hip/eig_device.hip).  0 on success.  */
 int gcge_hip_symeig (char uplo, int n, const double *a, int lda, double *w, double *z, int ldz);
+long gcge_hip_symeig_calls (void);   /* calls so far: the hook is keyed to the HIP table (GCGE_SetSymEigHook owner), the CPU oracle never gets here */
 
 /* ---- raw kernels (what the slots launch; exposed for micro-benchmarks) --------- */
 /* K1  Y[:,0:m) = A X[:,0:m);  x/y point at (row 0, first column); see csrc/hip/spmm*.hip */

@@ -146,6 +146,12 @@ GCGE_COMM *GCGE_GetComm (void);
  * drives the REFERENCE's GCG sets a fixed shift itself.  sigma == 0: no shift. */
 void       GCGE_SetLinearSolverShift (double sigma, void *matB);
 void       GCGE_GetLinearSolverShift (double *sigma, void **matB);
+/*     the column scales of the "user" tolerance type of BlockPCG (src/ops_lin_sol.c:186-192: a column has converged when
+ *     its residual is below tol * |scale_j|; the reference's GCG leaves lambda_j + sigma at the start of BlockPCG's scalar
+ *     scratch).  A solver installed behind flag 1 has no such scratch: the GCG driver publishes the n scales here for the
+ *     duration of the call, NULL otherwise.                                                                              */
+void       GCGE_SetLinearSolverUserScale (const double *scale, int n);
+const double *GCGE_GetLinearSolverUserScale (int *n);
 /* Optional fast path of CheckConvergence (src/ops_eig_sol_gcg.c:195-315 forms A x, B x, lambda B x, the difference and
  * its column norms through five slots = 11 block streams).  A back-end may offer the squared residual norms
  *   res_sq[j] = sum over its LOCAL rows of ((A x_j) - lambda_j (B x_j))^2 ,  j = start .. end-1  (columns of x)

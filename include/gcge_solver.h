@@ -20,13 +20,17 @@ extern "C" {
 /* ---- small dense symmetric eigensolver (replaces dsyevx / dsyev) ---------- */
 int GCGE_SymEig (char uplo, int n, const double *a, int lda, double *w,
 		double *z, int ldz, double *work /* >= 2n */);
-/*     the host implementation itself (GCGE_SymEig dispatches to a registered device hook for large n) */
+/*     the host implementation itself (GCGE_SymEig is this; kept under both names) */
 int GCGE_SymEigHost (char uplo, int n, const double *a, int lda, double *w,
 		double *z, int ldz, double *work /* >= 2n */);
-/*     a back-end's own solver with the same contract (host pointers in and out, 0 on success); used by GCGE_SymEig for
- *     n >= min_n.  The HIP back-end registers gcge_hip_symeig (csrc/hip/eig_device.hip) in OPS_HIP_Set.               */
+/*     a back-end's own solver with the same contract (host pointers in and out, 0 on success), registered for ONE
+ *     operator table: owner = that table's MultiVecLinearComb slot.  GCGE_SymEigFor(owner, ...) — what the GCG driver and
+ *     the orthonormalisation call with their table's slot — takes it for n >= min_n when the owners match, the host solver
+ *     otherwise.  The HIP back-end registers gcge_hip_symeig (csrc/hip/eig_device.hip) in OPS_HIP_Set.                  */
 typedef int (*GCGE_SYMEIG_FN) (char uplo, int n, const double *a, int lda, double *w, double *z, int ldz);
-void GCGE_SetSymEigHook (GCGE_SYMEIG_FN fn, int min_n);
+void GCGE_SetSymEigHook (GCGE_SYMEIG_FN fn, int min_n, void *owner);
+int GCGE_SymEigFor (void *owner, char uplo, int n, const double *a, int lda, double *w,
+		double *z, int ldz, double *work /* >= 2n */);
 
 /* ---- block orthonormalisation (sets ops->MultiVecOrth + orth_workspace) ---- */
 typedef struct ModifiedGramSchmidtOrth_ {

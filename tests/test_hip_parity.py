@@ -1279,3 +1279,135 @@ def test_gcg_on_variable_coefficient_stencil_matches_oracle(both):
     assert k >= 10
     assert np.max(np.abs(ev_h[:k] - ev_o[:k]) / np.abs(ev_o[:k])) < 1e-10
     hip.free_matrix(mh)
+
+
+def test_device_eigensolver_serves_the_hip_table_only(both):
+    """the K7 hook is keyed to the table OPS_HIP_Set filled — a GCG run of the CPU oracle in the same process
+    (projected problems of 256 > 192 rows: BASELINE config 2's solver shape) never reaches the device solver, the same
+    run over the HIP table does."""
+    hip, ora = both
+    g = hip.g
+    g.gcge_hip_symeig_calls.restype = C.c_long
+    c = load_golden("gcg_shapes.json")["c2shape_lap3d_24"]
+    args = ["-nevConv", c["nev"], "-nevMax", c["nev_max"], "-blockSize", c["block"]]
+    before = g.gcge_hip_symeig_calls()
+    ev_o, res_o = gcg_on(ora, c["kind"], c["size"], args)
+    assert g.gcge_hip_symeig_calls() == before, "the oracle's projected eigenproblems went to the device"
+    hip.set_random_mode(0)
+    ev_h, res_h = gcg_on(hip, c["kind"], c["size"], args)
+    assert g.gcge_hip_symeig_calls() > before
+    k = min(res_o.nevConv, res_h.nevConv)
+    assert k >= c["nev"] and np.max(np.abs(ev_h[:k] - ev_o[:k]) / np.abs(ev_o[:k])) < 1e-10
+
+
+@pytest.mark.parametrize("size", [16, 24])
+def test_fused_cg_tight_tolerances(hip, size):
+    """VERDICT r2 weak #2 / ADVICE r2: the fused CG in the regime the GCG harness never enters — reductions of 1e-8 and
+    1e-13 in hundreds of iterations — with the residual NOT stored (r_k = p_k - beta_{k-1} p_{k-1} rebuilt from the ring:
+    rounding error eps |p_k| instead of eps |r_k|), stored (gcge_hip_bpcg_residual_form(2)) and as the automatic rule
+    picks (stored, because rate < 1e-4), against a direct solve: TRUE residuals |b - A x| / |b| and iteration counts.
+    The beta of the recompute form comes from alpha^2 |A p|^2 - rho (a difference of nearly equal numbers near
+    convergence), so both are checked where that matters."""
+    import scipy.sparse.linalg as sla
+    g = hip.g
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    g.gcge_hip_bpcg_residual_form.argtypes = [C.c_int]
+    g.gcge_hip_bpcg_implicit_r_iters.restype = C.c_long
+    A, _ = make_problem("lap3d", size)
+    S = csr_to_scipy(A); n = A.nrows
+    mat = hip.matrix(A)
+    nrhs = 8
+    Bm = uniform(81, (n, nrhs)) - 0.5
+    ref = sla.spsolve(S.tocsc(), Bm)
+    nb = np.linalg.norm(Bm, axis=0)
+    res = {}
+    try:
+        for rate in (1e-2, 1e-8, 1e-13):
+            for form in (1, 2, 0):
+                g.gcge_hip_bpcg_residual_form(form)
+                g.gcge_hip_bpcg_setup(hip.ops_handle, 2000, rate, 1e-300, b"abs")
+                b = hip.mv_from_numpy(mat, Bm); x = hip.mv_from_numpy(mat, np.zeros((n, nrhs)))
+                before = g.gcge_hip_bpcg_implicit_r_iters()
+                hip.ops.multi_linear_solver(mat, b, x, (0, 0), (nrhs, nrhs))
+                it = C.c_int(); g.gcge_hip_bpcg_stats(None, None, C.byref(it))
+                X = hip.mv_to_numpy(x, n, 0, nrhs)
+                true_res = np.linalg.norm(Bm - S @ X, axis=0) / nb
+                res[(rate, form)] = (it.value, true_res.max(), g.gcge_hip_bpcg_implicit_r_iters() - before,
+                                     np.max(np.abs(X - ref)) / np.max(np.abs(ref)))
+                hip.ops.mv_destroy(b, nrhs); hip.ops.mv_destroy(x, nrhs)
+    finally:
+        g.gcge_hip_bpcg_residual_form(0)
+        g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    for rate in (1e-2, 1e-8, 1e-13):
+        it1, tr1, ni1, e1 = res[(rate, 1)]; it2, tr2, ni2, e2 = res[(rate, 2)]; it0, tr0, ni0, e0 = res[(rate, 0)]
+        assert ni1 > 0 and ni2 == 0 and ni0 == 0, (ni1, ni2, ni0)       # 2000 iterations allowed: the automatic rule stores r
+        assert it0 == it2 and tr0 == tr2
+        # the recursive residual the solver stops on and the true one: within a factor 10 of the requested reduction, or at
+        # the attainable accuracy of CG in double precision on this operator (kappa ~ 1e2-1e3: ~1e-13)
+        for tr in (tr1, tr2):
+            assert tr <= max(10.0 * rate, 5e-13), (rate, tr)
+        assert abs(it1 - it2) <= max(2, it2 // 50), ("iteration counts of the two residual forms", rate, it1, it2)
+        assert tr1 <= max(3.0 * tr2, 5e-13), ("true residual without a stored r", rate, tr1, tr2)
+    assert res[(1e-13, 1)][3] < 1e-10 and res[(1e-13, 2)][3] < 1e-10
+    hip.free_matrix(mat)
+
+
+def test_fused_cg_user_tolerance_and_active_column_statistics(hip):
+    """tol_type "user" of BlockPCG (src/ops_lin_sol.c:186-192: a column stops at tol * |scale_j|, the scales published
+    through GCGE_SetLinearSolverUserScale as the GCG driver does with lambda_j + sigma) against the host-scalar BlockPCG
+    of libgcge_host on the same operands; and the column statistics of the device-scalar loop (they were a
+    constant): columns that retire early lower the active share, surplus iterations are counted apart."""
+    from solver_setup import bpcg_setup
+    g, h = hip.g, hip.h
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    g.gcge_hip_bpcg_column_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    g.gcge_hip_bpcg_surplus_iters.restype = C.c_long
+    h.GCGE_SetLinearSolverUserScale.argtypes = [C.POINTER(C.c_double), C.c_int]
+    A, _ = make_problem("lap3d", 16)
+    S = csr_to_scipy(A); n = A.nrows
+    mat = hip.matrix(A)
+    nrhs = 8
+    Bm = uniform(91, (n, nrhs)) - 0.5
+    scale = np.array([1.0, 1e3, 1e-3, 50.0, 1.0, 1e2, 1e-2, 10.0])
+    sc = (C.c_double * nrhs)(*scale)
+    ci0, ai0 = C.c_long(), C.c_long(); g.gcge_hip_bpcg_column_stats(C.byref(ci0), C.byref(ai0)); sp0 = g.gcge_hip_bpcg_surplus_iters()
+    g.gcge_hip_bpcg_setup(hip.ops_handle, 400, 1e-30, 1e-6, b"user")
+    b = hip.mv_from_numpy(mat, Bm); x = hip.mv_from_numpy(mat, np.zeros((n, nrhs)))
+    h.GCGE_SetLinearSolverUserScale(sc, nrhs)
+    try:
+        hip.ops.multi_linear_solver(mat, b, x, (0, 0), (nrhs, nrhs))
+    finally:
+        h.GCGE_SetLinearSolverUserScale(None, 0)
+    it = C.c_int(); g.gcge_hip_bpcg_stats(None, None, C.byref(it))
+    X = hip.mv_to_numpy(x, n, 0, nrhs)
+    true_res = np.linalg.norm(Bm - S @ X, axis=0)
+    # every column stopped at ITS scale: below 1e-6 |scale_j| (up to the drift of the recursive residual) and, for the
+    # columns with a loose scale, far above the tightest one
+    assert np.all(true_res <= 2e-6 * scale), (true_res, scale)
+    assert true_res[1] > 1e2 * true_res[2]
+    ci, ai = C.c_long(), C.c_long(); g.gcge_hip_bpcg_column_stats(C.byref(ci), C.byref(ai))
+    dci, dai, dsp = ci.value - ci0.value, ai.value - ai0.value, g.gcge_hip_bpcg_surplus_iters() - sp0
+    assert dci >= nrhs * it.value and 0 < dai < nrhs * it.value, (dci, dai, it.value)   # columns retired at different iterations
+    assert 0 <= dsp <= 2 and dci == nrhs * (it.value + dsp)
+    hip.ops.mv_destroy(b, nrhs); hip.ops.mv_destroy(x, nrhs)
+    g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    hip.free_matrix(mat)
+
+
+@pytest.mark.parametrize("key", ["lap3d_12_nev10_autoshift", "fe3d_12_nev10_autoshift"])
+def test_gcg_auto_shift_with_the_fused_solver(hip, key):
+    """f1: -gcge_compW_cg_auto_shift 1 together with the back-end's own solver behind flag 1 — the combination the
+    reference asserts away (ops_eig_sol_gcg.c:497) because its hook hands the solver A only; here sigma (computed as
+    :483-492) travels through GCGE_SetLinearSolverShift and the fused CG solves (A + sigma B) w = (lambda + sigma) B x.
+    Same converged count and Ritz values as the reference's run with its own BlockPCG."""
+    g = hip.g
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    c = load_golden("gcg.json")[key]
+    g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    hip.set_random_mode(0)
+    args = ["-nevConv", c["nev"]] + c["extra"]
+    assert "-gcge_compW_cg_auto_shift" in [str(a) for a in args]
+    ev, res = gcg_on(hip, c["kind"], c["size"], args, flag=1)
+    assert res.nevConv == c["nevConv"]
+    ref = np.array(c["eval"])
+    assert np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref)) < 1e-10
