@@ -1132,6 +1132,50 @@ static void HIP_MatTransDotMultiVec(void* mat, void** x, void** y, int* start, i
   HIP_MatDotMultiVec(mat, x, y, start, end, ops);
 }
 
+// Local part + sum over the ranks of the communicator registered at call time (GCGE_GetComm(): RCCL inside the back-end,
+// csrc/hip/rccl_comm.hip, or a caller's transport); results packed for the reduction when ld != rows.  Own functions
+// (not the Default* of a solver library): whichever OPS_Setup completes the table — ours or the reference's, whose
+// default of the same name only reduces under OPS_USE_MPI, src/ops_multi_vec.c:202-230 — finds these slots filled.
+static void HIP_MultiVecInnerProd(char nsd, void** x, void** y, int is_vec, int* start, int* end, double* ip, int ldIP,
+                                  struct OPS_* ops) {
+  int nr = end[0] - start[0];
+  const int nc = end[1] - start[1];
+  HIP_MultiVecLocalInnerProd(nsd, x, y, is_vec, start, end, ip, ldIP, ops);
+  GCGE_COMM* comm = GCGE_GetComm();
+  if (comm == nullptr || nr <= 0 || nc <= 0) return;
+  if (nsd == 'D') nr = 1;   // one value per column, stride ldIP
+  if (nr == ldIP) { comm->allreduce_sum(ip, nr * nc, comm->ctx); return; }
+  std::vector<double> pack((size_t)nr * nc);
+  for (int c = 0; c < nc; ++c) memcpy(pack.data() + (size_t)c * nr, ip + (size_t)c * ldIP, nr * sizeof(double));
+  comm->allreduce_sum(pack.data(), nr * nc, comm->ctx);
+  for (int c = 0; c < nc; ++c) memcpy(ip + (size_t)c * ldIP, pack.data() + (size_t)c * nr, nr * sizeof(double));
+}
+// src/ops_multi_vec.c:351-411: qAp = Q[:, s0:e0)^T A P[:, s1:e1); A != NULL leaves A P in mv_ws[:, 0:m) (the
+// orthonormalisation re-uses it); 'T' stores the transpose (m x k)
+static void HIP_MultiVecQtAP(char ntsA, char ntsd, void** mvQ, void* matA, void** mvP, int is_vec, int* startQP, int* endQP,
+                             double* qAp, int ldQAP, void** mv_ws, struct OPS_* ops) {
+  int s[2], e[2];
+  const int k = endQP[0] - startQP[0], m = endQP[1] - startQP[1];
+  if (k <= 0 || m <= 0) return;
+  if (matA == nullptr) {
+    if (ntsd == 'T') {
+      s[0] = startQP[1]; e[0] = endQP[1]; s[1] = startQP[0]; e[1] = endQP[0];
+      ops->MultiVecInnerProd('N', mvP, mvQ, is_vec, s, e, qAp, ldQAP, ops);
+    } else ops->MultiVecInnerProd(ntsd, mvQ, mvP, is_vec, startQP, endQP, qAp, ldQAP, ops);
+    return;
+  }
+  s[0] = startQP[1]; e[0] = endQP[1]; s[1] = 0; e[1] = m;
+  if (ntsA == 'T') ops->MatTransDotMultiVec(matA, mvP, mv_ws, s, e, ops);
+  else ops->MatDotMultiVec(matA, mvP, mv_ws, s, e, ops);
+  if (ntsd == 'T') {
+    s[0] = 0; e[0] = m; s[1] = startQP[0]; e[1] = endQP[0];
+    ops->MultiVecInnerProd('N', mv_ws, mvQ, is_vec, s, e, qAp, ldQAP, ops);
+  } else {
+    s[0] = startQP[0]; e[0] = endQP[0]; s[1] = 0; e[1] = m;
+    ops->MultiVecInnerProd(ntsd, mvQ, mv_ws, is_vec, s, e, qAp, ldQAP, ops);
+  }
+}
+
 extern "C" void OPS_HIP_Set(struct OPS_* ops) {
   if (gcge_hip_init(-1) != 0) {
     fprintf(stderr, "OPS_HIP_Set: HIP back-end unavailable (no GPU): aborting — there is no CPU fallback\n");
@@ -1145,7 +1189,7 @@ extern "C" void OPS_HIP_Set(struct OPS_* ops) {
   ops->MultiVecDestroy          = HIP_MultiVecDestroy;
   ops->MultiVecView             = HIP_MultiVecView;
   ops->MultiVecLocalInnerProd   = HIP_MultiVecLocalInnerProd;
-  ops->MultiVecInnerProd        = nullptr;   // OPS_Setup installs Local + all-reduce
+  ops->MultiVecInnerProd        = HIP_MultiVecInnerProd;   // installed HERE, not left to OPS_Setup: see above
   ops->MultiVecSetRandomValue   = HIP_MultiVecSetRandomValue;
   ops->MultiVecAxpby            = HIP_MultiVecAxpby;
   ops->MultiVecLinearComb       = HIP_MultiVecLinearComb;
@@ -1159,5 +1203,5 @@ extern "C" void OPS_HIP_Set(struct OPS_* ops) {
     GCGE_SetSymEigHook(gcge_hip_symeig, mn ? atoi(mn) : 192, (void*)HIP_MultiVecLinearComb);
   }
   ops->MatTransDotMultiVec      = HIP_MatTransDotMultiVec;
-  ops->MultiVecQtAP             = nullptr;   // OPS_Setup installs SpMM-into-mv_ws + Gram
+  ops->MultiVecQtAP             = HIP_MultiVecQtAP;
 }

@@ -109,10 +109,35 @@ def main():
         exact = box_exact(dims, res.nevConv)
     rel = np.max(np.abs(ev[:res.nevConv] - exact) / exact)
     assert res.nevConv >= 8 and rel < 1e-10, (res.nevConv, res.numIter, rel, list(ev[:10]))
+    note = ""
+    if mode == "hip" and not sio2:
+        # 4. the REFERENCE's compiled GCG / orthonormalisation (oracle/_ref, its own OPS_Setup, flag 1 = the back-end's
+        # solver) over a table only OPS_HIP_Set has touched, on the same slab matrices: OPS_HIP_Set installs
+        # MultiVecInnerProd / MultiVecQtAP with the all-reduce, so no line of the reference's src/ is edited (its own
+        # default would not reduce without OPS_USE_MPI, src/ops_multi_vec.c:202-230)
+        import pyoracle as po
+        ref = po.ref_lib()
+        if ref is not None:
+            ops2 = C.c_void_p()
+            be.h.OPS_Create(C.byref(ops2))
+            be.g.OPS_HIP_Set(ops2)
+            be.g.gcge_hip_bpcg_setup(ops2, 30, 1e-2, 1e-14, b"abs")
+            be.set_random_mode(1, 778)
+            ref.ref_gcg_solve_foreign.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+            ev2 = np.zeros(16)
+            conv2, it2, sec2 = C.c_int(), C.c_int(), C.c_double()
+            rc = ref.ref_gcg_solve_foreign(ops2, mat, None, 8, 16, 0, 0, 1e-1, 1e-8, 500, 1, ev2.ctypes.data_as(C.POINTER(C.c_double)),
+                                           C.byref(conv2), C.byref(it2), C.byref(sec2))
+            assert rc == 0 and conv2.value >= 8, (rc, conv2.value)
+            rel2 = np.max(np.abs(ev2[:conv2.value] - box_exact(dims, conv2.value)) / box_exact(dims, conv2.value))
+            assert rel2 < 1e-10, ("reference stack over the HIP slots, %d ranks" % world, rel2, list(ev2[:conv2.value]))
+            note = " refstack: nevConv=%d numIter=%d rel=%.2e" % (conv2.value, it2.value, rel2)
     allc = [None] * world
     dist.all_gather_object(allc, (res.nevConv, res.numIter, float(ev[0])))
     assert all(a[:2] == allc[0][:2] for a in allc), "ranks disagree: %r" % (allc,)
-    print("rank %d ok: nevConv=%d numIter=%d rel=%.2e allreduces=%d" % (rank, res.nevConv, res.numIter, rel, comm.n_allreduce))
+    print("rank %d ok: nevConv=%d numIter=%d rel=%.2e allreduces=%d%s" % (rank, res.nevConv, res.numIter, rel, comm.n_allreduce, note))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -112,6 +112,31 @@ def main():
     rel = np.max(np.abs(ev[:res.nevConv] - exact) / exact)
     assert res.nevConv >= 8 and rel < 1e-10, (res.nevConv, res.numIter, rel, list(ev[:10]))
     note = ""
+    # 4. the REFERENCE's compiled stack (oracle/_ref: its GCG, its OPS_Setup, flag 1) over a table only OPS_HIP_Set has
+    # touched, on the same loop-back matrix and communicator: the back-end's own MultiVecInnerProd / MultiVecQtAP reduce,
+    # nothing of the reference's src/ is edited
+    import pyoracle as po
+    ref = po.ref_lib()
+    if ref is not None:
+        ops2 = C.c_void_p()
+        be.h.OPS_Create(C.byref(ops2))
+        be.g.OPS_HIP_Set(ops2)
+        be.g.gcge_hip_bpcg_setup(ops2, 30, 1e-2, 1e-14, b"abs")
+        ref.ref_gcg_solve_foreign.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        ev2 = np.zeros(16)
+        conv2, it2, sec2 = C.c_int(), C.c_int(), C.c_double()
+        a0 = comm.n_allreduce
+        rc = ref.ref_gcg_solve_foreign(ops2, mat, None, 8, 16, 0, 0, 1e-1, 1e-8, 500, 1, ev2.ctypes.data_as(C.POINTER(C.c_double)),
+                                       C.byref(conv2), C.byref(it2), C.byref(sec2))
+        assert rc == 0 and conv2.value >= 8, (rc, conv2.value)
+        k2 = conv2.value
+        ex2 = np.linalg.eigvalsh(S.toarray())[:k2] if n_loc <= 4096 else np.sort(__import__("scipy.sparse.linalg", fromlist=["eigsh"]).eigsh(S, k=k2, sigma=0.0, which="LM", return_eigenvectors=False))
+        rel2 = np.max(np.abs(ev2[:k2] - ex2) / ex2)
+        assert rel2 < 1e-10, ("reference stack over the HIP slots through the communicator", rel2)
+        assert comm.n_allreduce > a0, "the reference stack's inner products did not go through the communicator"
+        note = " refstack nevConv=%d numIter=%d rel=%.2e" % (k2, it2.value, rel2)
     if native:
         # latency of the small all-reduce (host buffer in, host buffer out) through the C path
         import time
@@ -127,7 +152,7 @@ def main():
         for _ in range(200):
             be.ops.inner_prod("D", x3, x3, (0, 0), (4, 4))
         t_without = (time.perf_counter() - t0) / 200
-        note = " allreduce_us=%.1f (dot with %.1f us, without %.1f us)" % (1e6 * (t_with - t_without), 1e6 * t_with, 1e6 * t_without)
+        note += " allreduce_us=%.1f (dot with %.1f us, without %.1f us)" % (1e6 * (t_with - t_without), 1e6 * t_with, 1e6 * t_without)
         assert n0 > 0
         be.free_matrix(mat)
         comm.finalize()
