@@ -108,6 +108,40 @@ static int g_offset_patterns = 1;   // 1: stencils with row-dependent coefficien
 extern "C" void gcge_hip_set_offset_patterns(int on) { g_offset_patterns = on; }
 static int g_rand_mode = 0; static unsigned long long g_rand_seed = 0x5DEECE66Dull;
 
+// ------------------------------------------------------------------ per-slot wall time (measurement aid, off by default)
+// gcge_hip_slot_timing(1): every slot call is followed by a stream synchronisation and its wall time is added to a bucket
+// (slot, width class of the column range it worked on); gcge_hip_slot_timing_report prints the buckets.  Used to see where
+// a solver stack that was NOT written for this layout spends its time (tests/refstack_on_hip.py).
+#include <chrono>
+#include <map>
+#include <string>
+static int g_slot_timing = 0;
+static std::map<std::string, std::pair<long, double>> g_slot_time;
+struct SlotTimer {
+  const char* name; int cols; std::chrono::steady_clock::time_point t0; bool on;
+  SlotTimer(const char* n, int c) : name(n), cols(c), on(g_slot_timing != 0) { if (on) t0 = std::chrono::steady_clock::now(); }
+  ~SlotTimer() {
+    if (!on) return;
+    hipStreamSynchronize(g_stream);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const char* cls = cols <= 1 ? "1 col" : cols <= 8 ? "2-8 cols" : cols <= 32 ? "9-32 cols" : "> 32 cols";
+    auto& b = g_slot_time[std::string(name) + " [" + cls + "]"];
+    b.first += 1; b.second += dt;
+  }
+};
+extern "C" void gcge_hip_slot_timing(int on) { g_slot_timing = on; if (on) g_slot_time.clear(); }
+extern "C" int gcge_hip_slot_timing_report(char* buf, int len) {
+  std::string out;
+  for (auto& kv : g_slot_time) {
+    char line[256];
+    snprintf(line, sizeof line, "%-44s calls %8ld  %9.3f s  %8.3f ms/call\n", kv.first.c_str(), kv.second.first, kv.second.second,
+             1e3 * kv.second.second / (double)kv.second.first);
+    out += line;
+  }
+  if (buf != nullptr && len > 0) { strncpy(buf, out.c_str(), (size_t)len - 1); buf[len - 1] = 0; }
+  return (int)out.size();
+}
+
 static double* stage_d(size_t len) {
   if (len > g_stage_d_len) {
     if (g_stage_d) GCGE_HIP_CHECK(hipFree(g_stage_d));
@@ -634,6 +668,7 @@ static void HIP_MultiVecSetRandomValue(void** x, int start, int end, struct OPS_
 static void HIP_MultiVecAxpby(double alpha, void** x, double beta, void** y, int* start, int* end, struct OPS_* ops) {
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int m = end[1] - start[1];
+  SlotTimer tm_(x ? "MultiVecAxpby" : "MultiVecAxpby (scale)", m);
   GCGE_REQUIRE(end[0] - start[0] == m, "MultiVecAxpby: equal column counts");
   if (m <= 0 || vy->nrows == 0) return;
   GCGE_REQUIRE(start[1] >= 0 && end[1] <= vy->ncols, "MultiVecAxpby: y column range");
@@ -650,6 +685,7 @@ static void HIP_MultiVecLinearComb(void** x, void** y, int is_vec, int* start, i
                                    double* beta, int incb, struct OPS_* ops) {
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int k = end[0] - start[0], m = end[1] - start[1];
+  SlotTimer tm_(k == 1 ? "MultiVecLinearComb (rank 1)" : "MultiVecLinearComb", m);
   if (k == 0 || m == 0 || vy->nrows == 0) return;
   GCGE_REQUIRE(start[1] >= 0 && end[1] <= vy->ncols && m > 0, "MultiVecLinearComb: y column range");
   if (vx != nullptr && coef != nullptr) {
@@ -689,6 +725,7 @@ static void HIP_MultiVecLocalInnerProd(char nsd, void** x, void** y, int is_vec,
                                        double* ip, int ldIP, struct OPS_* ops) {
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int k = end[0] - start[0], m = end[1] - start[1];
+  SlotTimer tm_(m == 1 ? "MultiVecLocalInnerProd (k x 1)" : "MultiVecLocalInnerProd", m == 1 ? k : m);
   if (k <= 0 || m <= 0) return;
   GCGE_REQUIRE(vx->nrows == vy->nrows, "MultiVecInnerProd: equal row counts");
   GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols && start[1] >= 0 && end[1] <= vy->ncols, "MultiVecInnerProd: column ranges");
@@ -835,6 +872,7 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int m = end[0] - start[0];
+  SlotTimer tm_(mat ? "MatDotMultiVec" : "MatDotMultiVec (copy)", m);
   GCGE_REQUIRE(m == end[1] - start[1], "MatDotMultiVec: equal column counts");
   if (m <= 0) return;
   GCGE_REQUIRE(vx != vy || end[0] <= start[1] || end[1] <= start[0], "MatDotMultiVec: x and y ranges must not overlap");

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--nevmax", type=int, default=128)
     ap.add_argument("--flag", type=int, default=1)
     ap.add_argument("--rng", type=int, default=1)
+    ap.add_argument("--slot-timing", action="store_true", help="synchronise after every slot call and report wall time per slot and width class (stderr)")
     a = ap.parse_args()
     import numpy as np
     import torch  # noqa: F401
@@ -47,11 +48,18 @@ def main():
     ref.ref_gcg_solve_foreign.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double),
                                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    if a.slot_timing:
+        hip.g.gcge_hip_slot_timing(1)
     ev = np.zeros(a.nevmax or 2 * a.nev)
     conv, it, sec = C.c_int(), C.c_int(), C.c_double()
     rc = ref.ref_gcg_solve_foreign(ops, mA, mB, a.nev, a.nevmax, a.block, 0, 1e-1, 1e-8, 500, a.flag,
                                    ev.ctypes.data_as(C.POINTER(C.c_double)), C.byref(conv), C.byref(it), C.byref(sec))
     assert rc == 0
+    if a.slot_timing:
+        buf = C.create_string_buffer(16384)
+        hip.g.gcge_hip_slot_timing_report(buf, 16384)
+        sys.stderr.write(buf.value.decode())
+        hip.g.gcge_hip_slot_timing(0)
     out = {"stack": "reference GCG + ModifiedGramSchmidt + %s over OPS_HIP_Set slots" % ("HIP fused CG (flag 1)" if a.flag else "reference BlockPCG (flag 0)"),
            "kind": a.kind, "size": a.size, "n": int(A.nrows), "nev": a.nev, "block": a.block, "nevMax": a.nevmax,
            "nev_converged": conv.value, "gcg_iterations": it.value, "seconds": sec.value,
