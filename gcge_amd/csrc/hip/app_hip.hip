@@ -40,6 +40,9 @@ int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, double* d_y,
 int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2, const double* d_x, long ldx,
                           double* d_y, long ldy, int ncols, double* d_dots, double* d_dots_yy, void* stream);
 int gcge_hip_colscale(int nrows, double* d_y, long ldy, int m, const double* d_s, void* stream);
+int gcge_hip_panel_dot1(int nrows, const double* d_x, long ldx, int k, const double* d_y, long ldy, double* d_out, void* stream);
+int gcge_hip_rank1_update(int nrows, const double* d_x, long ldx, const double* d_c, const double* d_beta, double* d_y, long ldy, int m, void* stream);
+int gcge_hip_colscale1(int nrows, double* d_y, long ldy, double s, void* stream);
 int gcge_hip_fill_uniform(int nrows, long row_begin, long nglobal, double* d_y, long ldy, int c0, int m,
                           unsigned long long seed, void* stream);
 int gcge_hip_colmajor_to_rowmajor(int nrows, int m, const double* d_src, long lds, double* d_dst, long ldd, void* stream);
@@ -676,6 +679,10 @@ static void HIP_MultiVecAxpby(double alpha, void** x, double beta, void** y, int
     GCGE_REQUIRE(vx->nrows == vy->nrows, "MultiVecAxpby: equal row counts");
     GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols, "MultiVecAxpby: x column range");
   }
+  if (vx == nullptr && m == 1 && beta != 0.0) {   // one column scaled in place (q_k = x_k / r_kk of a column-wise Gram-Schmidt)
+    gcge_hip_colscale1(vy->nrows, vy->d + start[1], vy->ld, beta, g_stream);
+    return;
+  }
   gcge_hip_axpby(vy->nrows, alpha, vx ? vx->d + start[0] : nullptr, vx ? vx->ld : 0, beta, vy->d + start[1],
                  vy->ld, m, g_stream);
 }
@@ -701,6 +708,18 @@ static void HIP_MultiVecLinearComb(void** x, void** y, int is_vec, int* start, i
     double* db = stage_d(m);
     GCGE_HIP_CHECK(hipMemcpyAsync(db, hb, m * sizeof(double), hipMemcpyHostToDevice, g_stream));
     gcge_hip_colscale(vy->nrows, vy->d + start[1], vy->ld, m, db, g_stream);
+    return;
+  }
+  if (k == 1) {   // rank-1 update y_j = x c_j + beta_j y_j: one sweep over the m contiguous columns of every row
+    const size_t len = 2 * (size_t)m;
+    GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));   // staging buffers are reused
+    double* hc = stage_h(len);
+    for (int j = 0; j < m; ++j) { hc[j] = coef[(size_t)j * ldc]; hc[m + j] = beta == nullptr ? 0.0 : (incb == 0 ? *beta : beta[(size_t)j * incb]); }
+    double* dc = stage_d(len);
+    GCGE_HIP_CHECK(hipMemcpyAsync(dc, hc, len * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    const bool unit_beta = beta != nullptr && incb == 0 && *beta == 1.0;
+    int rc = gcge_hip_rank1_update(vy->nrows, vx->d + start[0], vx->ld, dc, unit_beta ? nullptr : dc + m, vy->d + start[1], vy->ld, m, g_stream);
+    GCGE_REQUIRE(rc == 0, "MultiVecLinearComb: kernel launch");
     return;
   }
   // panels of <= 128 output columns; coefficient panel uploaded row-major (k x mp) [+ beta]
@@ -741,7 +760,8 @@ static void HIP_MultiVecLocalInnerProd(char nsd, void** x, void** y, int is_vec,
     return;
   }
   double* dg = stage_d((size_t)k * m);
-  gcge_hip_gram(vx->nrows, vx->d + start[0], vx->ld, k, vy->d + start[1], vy->ld, m, dg, g_stream);
+  if (m == 1) gcge_hip_panel_dot1(vx->nrows, vx->d + start[0], vx->ld, k, vy->d + start[1], vy->ld, dg, g_stream);   // panel . column
+  else gcge_hip_gram(vx->nrows, vx->d + start[0], vx->ld, k, vy->d + start[1], vy->ld, m, dg, g_stream);
   double* hg = stage_h((size_t)k * m);
   GCGE_HIP_CHECK(hipMemcpyAsync(hg, dg, (size_t)k * m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));

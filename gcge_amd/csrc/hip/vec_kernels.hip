@@ -268,6 +268,115 @@ extern "C" double* gcge_hip_partial_ws(size_t len) {
   return g_partial;
 }
 
+// ---- the three single-column operations of a column-wise Gram-Schmidt (reference OrthSelf, src/ops_orth.c:45-118) ----------
+// On a row-major block a "column" is a strided walk, but the k columns it is combined with sit in the SAME rows right next
+// to it: every kernel here walks row segments of k contiguous doubles (one lane per column, `tpc` lanes per row, several
+// rows per wave instruction) and takes the single column's element from the same row.
+// (a) partial[b*k + i] = sum over the block's rows of X[r, i] * y[r]      (panel . column: the k x 1 Gram of MGS step k)
+template <int UNR>
+__global__ __launch_bounds__(256) void panel_dot1_partial(long nrows, const double* __restrict__ x, long ldx,
+    const double* __restrict__ y, long ldy, int k, double* __restrict__ partial, long rows_per_block, int tpc) {
+  __shared__ double red[256];
+  const int tx = threadIdx.x % tpc, ty = threadIdx.x / tpc, rpi = 256 / tpc;   // rpi rows per block iteration
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
+  for (int c0 = 0; c0 < k; c0 += tpc) {
+    const int j = c0 + tx;
+    const int jj = j < k ? j : 0;
+    double s[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) s[u] = 0.0;
+    long r = r0 + ty;
+    for (; r + (long)(UNR - 1) * rpi < r1; r += (long)UNR * rpi) {
+      double xv[UNR], yv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) { xv[u] = x[(r + (long)u * rpi) * ldx + jj]; yv[u] = y[(r + (long)u * rpi) * ldy]; }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) s[u] = fma(xv[u], yv[u], s[u]);
+    }
+    for (; r < r1; r += rpi) s[0] = fma(x[r * ldx + jj], y[r * ldy], s[0]);
+    double t = 0.0;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) t += s[u];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int h = rpi / 2; h > 0; h >>= 1) {
+      if (ty < h) red[threadIdx.x] += red[threadIdx.x + h * tpc];
+      __syncthreads();
+    }
+    if (ty == 0 && j < k) partial[(long)blockIdx.x * k + j] = red[tx];
+    __syncthreads();
+  }
+}
+// (b) Y[r, j] = x[r] * c[j] + beta[j] * Y[r, j]  for j < m  (rank-1 update; beta == NULL: 1)
+template <int UNR>
+__global__ __launch_bounds__(256) void rank1_update_kernel(long nrows, const double* __restrict__ x, long ldx,
+    const double* __restrict__ c, const double* __restrict__ beta, double* __restrict__ y, long ldy, int m, int tpc) {
+  const int tx = threadIdx.x % tpc, ty = threadIdx.x / tpc, rpi = 256 / tpc;
+  const long slab = (((nrows + gridDim.x - 1) / gridDim.x) + rpi - 1) / rpi * rpi;
+  const long r0 = (long)blockIdx.x * slab, r1 = min(nrows, r0 + slab);
+  for (int c0 = 0; c0 < m; c0 += tpc) {
+    const int j = c0 + tx;
+    if (j >= m) continue;
+    const double cj = c[j], bj = beta ? beta[j] : 1.0;
+    long r = r0 + ty;
+    for (; r + (long)(UNR - 1) * rpi < r1; r += (long)UNR * rpi) {
+      double xv[UNR], yv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) { xv[u] = x[(r + (long)u * rpi) * ldx]; yv[u] = y[(r + (long)u * rpi) * ldy + j]; }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) y[(r + (long)u * rpi) * ldy + j] = fma(xv[u], cj, bj == 0.0 ? 0.0 : bj * yv[u]);   // beta 0: Y may hold anything
+    }
+    for (; r < r1; r += rpi) y[r * ldy + j] = fma(x[r * ldx], cj, bj == 0.0 ? 0.0 : bj * y[r * ldy + j]);
+  }
+}
+// (c) y[r] *= s   (one column)
+__global__ __launch_bounds__(256) void colscale1_kernel(long nrows, double* __restrict__ y, long ldy, double s) {
+  const long stride = (long)gridDim.x * 256;
+  long r = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; r + 3 * stride < nrows; r += 4 * stride) {
+    const double a = y[r * ldy], b = y[(r + stride) * ldy], c = y[(r + 2 * stride) * ldy], d = y[(r + 3 * stride) * ldy];
+    y[r * ldy] = a * s; y[(r + stride) * ldy] = b * s; y[(r + 2 * stride) * ldy] = c * s; y[(r + 3 * stride) * ldy] = d * s;
+  }
+  for (; r < nrows; r += stride) y[r * ldy] *= s;
+}
+
+static int pow2_at_least(int v, int cap) { int t = 1; while (t < v && t < cap) t *= 2; return t; }
+// d_out[i] = sum_r X[r, i] y[r], i < k: X = d_x (leading dimension ldx), y = d_y with stride ldy
+extern "C" int gcge_hip_panel_dot1(int nrows, const double* d_x, long ldx, int k, const double* d_y, long ldy, double* d_out, void* stream) {
+  if (k <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (nrows <= 0) return (int)hipMemsetAsync(d_out, 0, k * sizeof(double), st);
+  const int tpc = pow2_at_least(k, 64), rpi = 256 / tpc;
+  long nb = ((long)nrows + 4L * rpi * 8 - 1) / (4L * rpi * 8);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  const long rpb = (((long)nrows + nb - 1) / nb + rpi - 1) / rpi * rpi;
+  nb = ((long)nrows + rpb - 1) / rpb;
+  double* part = gcge_hip_partial_ws((size_t)nb * k);
+  hipLaunchKernelGGL(panel_dot1_partial<4>, dim3((unsigned)nb), dim3(256), 0, st, (long)nrows, d_x, ldx, d_y, ldy, k, part, rpb, tpc);
+  hipLaunchKernelGGL(reduce_partials, dim3((k + 63) / 64), dim3(1024), 0, st, part, (int)nb, k, d_out);
+  return (int)hipGetLastError();
+}
+// Y[:, 0:m) = x c^T + Y diag(beta): d_c, d_beta device arrays of m (d_beta NULL: beta = 1)
+extern "C" int gcge_hip_rank1_update(int nrows, const double* d_x, long ldx, const double* d_c, const double* d_beta, double* d_y,
+                                     long ldy, int m, void* stream) {
+  if (nrows <= 0 || m <= 0) return 0;
+  const int tpc = pow2_at_least(m, 64), rpi = 256 / tpc;
+  long nb = ((long)nrows + 4L * rpi * 4 - 1) / (4L * rpi * 4);
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(rank1_update_kernel<4>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (long)nrows, d_x, ldx, d_c, d_beta,
+                     d_y, ldy, m, tpc);
+  return (int)hipGetLastError();
+}
+extern "C" int gcge_hip_colscale1(int nrows, double* d_y, long ldy, double s, void* stream) {
+  if (nrows <= 0) return 0;
+  long nb = ((long)nrows + 1023) / 1024;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(colscale1_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (long)nrows, d_y, ldy, s);
+  return (int)hipGetLastError();
+}
+
 extern "C" int gcge_hip_coldots(int nrows, const double* d_x, long ldx, const double* d_y, long ldy, int m,
                                 double* d_out, void* stream) {
   if (m <= 0) return 0;
