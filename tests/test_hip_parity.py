@@ -223,10 +223,17 @@ def test_gcg_on_hip_matches_reference_run(hip, key):
     args += c["extra"]
     hip.set_random_mode(0)     # the reference's rand() stream after srand(0)
     ev, res = gcg_on(hip, c["kind"], c["size"], args, K=6, R0=1.5, R1=2.0, seed=12345)
-    assert res.nevConv == c["nevConv"]
-    if "autoshift" not in key and "order2" not in key:   # see test_oracle_golden.py: the reference's own count is not reproducible there
-        assert abs(res.numIter - c["numIter"]) <= 2
     ref = np.array(c["eval"])
+    if "autoshift" not in key and "order2" not in key:
+        assert res.nevConv == c["nevConv"]
+        assert abs(res.numIter - c["numIter"]) <= 2
+    else:
+        # see test_oracle_golden.py: with these options the reference's own iteration count differs from process to process
+        # (its shift follows the rounding of the Ritz values), and pairs lock a block at a time, so a run that reaches the
+        # wanted count an iteration earlier or later exits with a different converged count (here: 15 or 17 of the wanted 12,
+        # depending on the summation order inside the dot kernels).  Pinned: the wanted count and every commonly converged value.
+        assert res.nevConv >= c["nev"]
+        ref = ref[:min(res.nevConv, len(ref))]
     rel = np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref))
     # 1e-10 is the bar of the north star.  The stock 1-D pair (B = h I, h = 1/808) is the exception: a pair is accepted at
     # ||A x - lambda B x||_2 <= 1e-8 lambda with x'Bx = 1, i.e. ||x||_2^2 = 808, which pins lambda_1 = 9.87 only to ~1e-10;
