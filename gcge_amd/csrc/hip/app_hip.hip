@@ -43,6 +43,7 @@ int gcge_hip_colscale(int nrows, double* d_y, long ldy, int m, const double* d_s
 int gcge_hip_panel_dot1(int nrows, const double* d_x, long ldx, int k, const double* d_y, long ldy, double* d_out, void* stream);
 int gcge_hip_rank1_update(int nrows, const double* d_x, long ldx, const double* d_c, const double* d_beta, double* d_y, long ldy, int m, void* stream);
 int gcge_hip_colscale1(int nrows, double* d_y, long ldy, double s, void* stream);
+int gcge_hip_mgs_step(int nrows, double* d_xk, long ld, double s, const double* d_c, int w, double* d_dots, void* stream);
 int gcge_hip_fill_uniform(int nrows, long row_begin, long nglobal, double* d_y, long ldy, int c0, int m,
                           unsigned long long seed, void* stream);
 int gcge_hip_colmajor_to_rowmajor(int nrows, int m, const double* d_src, long lds, double* d_dst, long ldd, void* stream);
@@ -144,6 +145,25 @@ extern "C" int gcge_hip_slot_timing_report(char* buf, int len) {
   if (buf != nullptr && len > 0) { strncpy(buf, out.c_str(), (size_t)len - 1); buf[len - 1] = 0; }
   return (int)out.size();
 }
+
+// ------------------------------------------------------------------ column-wise Gram-Schmidt over the slots, one sweep per column
+// The reference's OrthSelf (src/ops_orth.c:45-118) issues per column k: QtAP (k x 1 Gram of the remaining panel with x_k), a
+// scaling of x_k, a rank-1 update of the columns behind it — three strided sweeps over the panel.  The back-end fuses them
+// WITHOUT changing what is computed: the scaling is held back until the next call; if that call is the rank-1 update from
+// that very column, one kernel scales x_k, updates the panel and accumulates the Gram column of x_{k+1} that the next
+// QtAP will ask for (same operands, same products — only the order of the row sum differs).  Anything else flushes the
+// held-back scaling first.  The speculative Gram column is served only to the IMMEDIATELY following data call (epoch
+// check) on the same block and column range; every entry point that touches block data goes through enter().
+static unsigned long g_epoch = 0;
+static struct { GcgeHipMV* mv; int col; double fac; } g_pend = {nullptr, 0, 1.0};
+static struct { GcgeHipMV* mv; int c0, c1; unsigned long epoch; std::vector<double> dots; } g_spec = {nullptr, 0, 0, 0, {}};
+static int g_mgs_fuse = 1;
+extern "C" void gcge_hip_set_mgs_fusion(int on) { g_mgs_fuse = on; }
+static long g_mgs_fused_steps = 0, g_mgs_spec_hits = 0;
+extern "C" void gcge_hip_mgs_fusion_stats(long* fused_steps, long* served_grams) { if (fused_steps) *fused_steps = g_mgs_fused_steps; if (served_grams) *served_grams = g_mgs_spec_hits; }
+static void flush_pending();
+static inline void enter(bool keep_pending = false) { ++g_epoch; if (!keep_pending && g_pend.mv != nullptr) flush_pending(); }
+extern "C" void gcge_hip_flush_pending(void) { enter(); }   /* for other translation units that take device pointers of blocks */
 
 static double* stage_d(size_t len) {
   if (len > g_stage_d_len) {
@@ -584,17 +604,26 @@ static void HIP_MultiVecCreateByMultiVec(void*** mv, int num_vec, void** src, st
 }
 static void HIP_MultiVecDestroy(void*** mv, int num_vec, struct OPS_* ops) {
   GcgeHipMV* v = *(GcgeHipMV**)mv;
+  enter();
+  if (g_spec.mv == v) g_spec.mv = nullptr;
   if (v) { pool_free(v->d, v->bytes); free(v); }
   *mv = nullptr;
+}
+static void flush_pending() {
+  GcgeHipMV* v = g_pend.mv;
+  g_pend.mv = nullptr;
+  if (v != nullptr) gcge_hip_colscale1(v->nrows, v->d + g_pend.col, v->ld, g_pend.fac, g_stream);
 }
 extern "C" int gcge_hip_mv_nrows(void** mv) { return ((GcgeHipMV*)mv)->nrows; }
 extern "C" int gcge_hip_mv_ncols(void** mv) { return ((GcgeHipMV*)mv)->ncols; }
 extern "C" double* gcge_hip_mv_device_ptr(void** mv, long* ld) {
+  enter();
   GcgeHipMV* v = (GcgeHipMV*)mv; if (ld) *ld = v->ld; return v->d;
 }
 
 // host column-major  <->  device row-major, in panels so the staging stays bounded
 extern "C" void gcge_hip_mv_from_host(void** mv, int c0, int c1, const double* host, long ldh) {
+  enter();
   GcgeHipMV* v = (GcgeHipMV*)mv;
   const int n = v->nrows;
   GCGE_REQUIRE(c0 >= 0 && c1 <= v->ncols && ldh >= n, "gcge_hip_mv_from_host: ranges");
@@ -610,6 +639,7 @@ extern "C" void gcge_hip_mv_from_host(void** mv, int c0, int c1, const double* h
   }
 }
 extern "C" void gcge_hip_mv_to_host(void** mv, int c0, int c1, double* host, long ldh) {
+  enter();
   GcgeHipMV* v = (GcgeHipMV*)mv;
   const int n = v->nrows;
   GCGE_REQUIRE(c0 >= 0 && c1 <= v->ncols && ldh >= n, "gcge_hip_mv_to_host: ranges");
@@ -639,6 +669,7 @@ static void HIP_MultiVecView(void** x, int start, int end, struct OPS_* ops) {
 
 // app_lapack.c:322-333 — mode 0: the reference's rand() stream, column by column
 static void HIP_MultiVecSetRandomValue(void** x, int start, int end, struct OPS_* ops) {
+  enter();
   GcgeHipMV* v = (GcgeHipMV*)x;
   const int m = end - start;
   if (m <= 0) return;
@@ -671,6 +702,7 @@ static void HIP_MultiVecSetRandomValue(void** x, int start, int end, struct OPS_
 static void HIP_MultiVecAxpby(double alpha, void** x, double beta, void** y, int* start, int* end, struct OPS_* ops) {
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int m = end[1] - start[1];
+  enter();
   SlotTimer tm_(x ? "MultiVecAxpby" : "MultiVecAxpby (scale)", m);
   GCGE_REQUIRE(end[0] - start[0] == m, "MultiVecAxpby: equal column counts");
   if (m <= 0 || vy->nrows == 0) return;
@@ -680,6 +712,7 @@ static void HIP_MultiVecAxpby(double alpha, void** x, double beta, void** y, int
     GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols, "MultiVecAxpby: x column range");
   }
   if (vx == nullptr && m == 1 && beta != 0.0) {   // one column scaled in place (q_k = x_k / r_kk of a column-wise Gram-Schmidt)
+    if (g_mgs_fuse) { g_pend.mv = vy; g_pend.col = start[1]; g_pend.fac = beta; return; }   // held back: see enter()
     gcge_hip_colscale1(vy->nrows, vy->d + start[1], vy->ld, beta, g_stream);
     return;
   }
@@ -692,7 +725,33 @@ static void HIP_MultiVecLinearComb(void** x, void** y, int is_vec, int* start, i
                                    double* beta, int incb, struct OPS_* ops) {
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int k = end[0] - start[0], m = end[1] - start[1];
+  enter(true);   // a held-back scaling of x_k survives until it is known whether this is its rank-1 update
   SlotTimer tm_(k == 1 ? "MultiVecLinearComb (rank 1)" : "MultiVecLinearComb", m);
+  {
+    const bool step = g_mgs_fuse && k == 1 && vx == vy && vx != nullptr && coef != nullptr && start[1] == start[0] + 1 && m >= 1 && m <= 64 &&
+                      beta != nullptr && incb == 0 && *beta == 1.0 && start[0] >= 0 && end[1] <= vy->ncols && vy->nrows > 0;
+    double fac = 1.0;
+    if (g_pend.mv != nullptr) {
+      if (step && g_pend.mv == vx && g_pend.col == start[0]) { fac = g_pend.fac; g_pend.mv = nullptr; }
+      else flush_pending();
+    }
+    if (step) {
+      // x_k *= fac, columns (k, k + m] += x_k coef^T, and the Gram column of x_{k+1} with the updated panel in the same sweep
+      GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));   // staging buffers are reused
+      double* hc = stage_h(2 * (size_t)m);
+      for (int j = 0; j < m; ++j) hc[j] = coef[(size_t)j * ldc];
+      double* dc = stage_d(2 * (size_t)m);
+      GCGE_HIP_CHECK(hipMemcpyAsync(dc, hc, m * sizeof(double), hipMemcpyHostToDevice, g_stream));
+      const int rc = gcge_hip_mgs_step(vy->nrows, vy->d + start[0], vy->ld, fac, dc, m, dc + m, g_stream);
+      GCGE_REQUIRE(rc == 0, "MultiVecLinearComb: kernel launch");
+      GCGE_HIP_CHECK(hipMemcpyAsync(hc + m, dc + m, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+      GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+      g_spec.mv = vy; g_spec.c0 = start[1]; g_spec.c1 = end[1]; g_spec.epoch = g_epoch;
+      g_spec.dots.assign(hc + m, hc + 2 * m);
+      ++g_mgs_fused_steps;
+      return;
+    }
+  }
   if (k == 0 || m == 0 || vy->nrows == 0) return;
   GCGE_REQUIRE(start[1] >= 0 && end[1] <= vy->ncols && m > 0, "MultiVecLinearComb: y column range");
   if (vx != nullptr && coef != nullptr) {
@@ -744,8 +803,18 @@ static void HIP_MultiVecLocalInnerProd(char nsd, void** x, void** y, int is_vec,
                                        double* ip, int ldIP, struct OPS_* ops) {
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int k = end[0] - start[0], m = end[1] - start[1];
+  enter();
   SlotTimer tm_(m == 1 ? "MultiVecLocalInnerProd (k x 1)" : "MultiVecLocalInnerProd", m == 1 ? k : m);
   if (k <= 0 || m <= 0) return;
+  if (m == 1 && nsd != 'D' && g_spec.mv != nullptr && g_spec.mv == vx && vx == vy && g_spec.epoch + 1 == g_epoch &&
+      start[0] == g_spec.c0 && start[1] == g_spec.c0 && end[0] == g_spec.c1 && (int)g_spec.dots.size() == k && ldIP >= k) {
+    // the Gram column the previous call (the rank-1 update of a Gram-Schmidt step) accumulated on its way: nothing has
+    // touched the block since (epoch), same block, same column range
+    for (int i = 0; i < k; ++i) ip[i] = g_spec.dots[i];
+    g_spec.mv = nullptr; ++g_mgs_spec_hits;
+    return;
+  }
+  g_spec.mv = nullptr;
   GCGE_REQUIRE(vx->nrows == vy->nrows, "MultiVecInnerProd: equal row counts");
   GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols && start[1] >= 0 && end[1] <= vy->ncols, "MultiVecInnerProd: column ranges");
   GCGE_REQUIRE(nsd == 'D' ? ldIP >= 1 : ldIP >= k, "MultiVecInnerProd: ldIP");
@@ -892,6 +961,7 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int m = end[0] - start[0];
+  enter();
   SlotTimer tm_(mat ? "MatDotMultiVec" : "MatDotMultiVec (copy)", m);
   GCGE_REQUIRE(m == end[1] - start[1], "MatDotMultiVec: equal column counts");
   if (m <= 0) return;
@@ -937,6 +1007,7 @@ extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, 
 // host_yy != NULL: additionally yy[j] = sum_r y[r,j]^2 (local part) — free on the pattern path
 extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots,
                                       double* host_yy, struct OPS_* ops) {
+  enter();
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int m = end[0] - start[0];
@@ -1006,6 +1077,7 @@ extern "C" int gcge_hip_cg_recompute_pays(void* mat) {
 // d_out[0, m) = sum_r p[r,j] (A p)[r,j], d_out[m, 2m) = sum_r (A p)[r,j]^2 over the LOCAL rows, left on the DEVICE (d_out holds
 // >= 6 m doubles, the rest is scratch of the split product); fetches the halo rows of p; nothing is waited for
 extern "C" int gcge_hip_cg_pass1_dev(void* mat, void** p, int c0, int m, double* d_out) {
+  enter();
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat; GcgeHipMV* vp = (GcgeHipMV*)p;
   if (!gcge_hip_cg_fusable(mat, p, m) || (c0 & 1)) return -1;
   GCGE_REQUIRE(c0 >= 0 && c0 + m <= vp->ncols && A->nrows == vp->nrows && A->nrows + A->nghost <= vp->nrows_alloc, "cg_pass1: shapes");
@@ -1040,6 +1112,7 @@ extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* 
 // the DEVICE.  The halo rows of p must be the ones pass 1 fetched (p unchanged since).  d_alpha / d_beta / d_flag: device, m each.
 extern "C" int gcge_hip_cg_pass2_dev(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
                                      const double* d_beta, const int* d_flag, double* d_rho) {
+  enter();
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
   GcgeHipMV *vp = (GcgeHipMV*)p, *vr = (GcgeHipMV*)r, *vn = (GcgeHipMV*)pnew;
   if (!gcge_hip_cg_fusable(mat, p, m) || (c0 & 1) || (vr->ld & 1) || (vn->ld & 1) || ((uintptr_t)vr->d & 15) ||
@@ -1076,6 +1149,7 @@ extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, 
 // Reads p, pprev, writes pnew: 3 block streams instead of 4.
 extern "C" int gcge_hip_cg_pass2i_dev(void* mat, void** p, void** pprev, void** pnew, int c0, int m, const double* d_alpha,
                                       const double* d_beta, const int* d_flag, const double* d_betaprev, double* d_rho) {
+  enter();
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
   GcgeHipMV *vp = (GcgeHipMV*)p, *vq = (GcgeHipMV*)pprev, *vn = (GcgeHipMV*)pnew;
   if (!gcge_hip_cg_fusable(mat, p, m) || (c0 & 1) || (vq->ld & 1) || (vn->ld & 1) || ((uintptr_t)vq->d & 15) ||
@@ -1111,6 +1185,7 @@ extern "C" int gcge_hip_cg_pass2i_mv(void* mat, void** p, void** pprev, void** p
 // -1 without touching anything when matrix or operands do not qualify.
 extern "C" int gcge_hip_cg_start_mv(void* mat, void** x, int xc0, void** b, int bc0, void** r, void** p0, int rc0, int m,
                                     double* host_rho) {
+  enter();
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
   GcgeHipMV *vx = (GcgeHipMV*)x, *vb = (GcgeHipMV*)b, *vr = (GcgeHipMV*)r, *vp = (GcgeHipMV*)p0;
   if (A == nullptr || A->d_pid == nullptr || g_spmm_path != 0 || getenv("GCGE_CG_NO_RECOMPUTE") != nullptr) return -1;
@@ -1136,6 +1211,7 @@ extern "C" int gcge_hip_cg_start_mv(void* mat, void** x, int xc0, void** b, int 
 // A w = (lambda + sigma) x start from w = x, so b is never formed and never read (kernel MODE 6).  host_scale: m factors.
 extern "C" int gcge_hip_cg_start_scaled_mv(void* mat, void** x, int xc0, const double* host_scale, void** r, void** p0, int rc0,
                                            int m, double* host_rho) {
+  enter();
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
   GcgeHipMV *vx = (GcgeHipMV*)x, *vr = (GcgeHipMV*)r, *vp = (GcgeHipMV*)p0;
   if (A == nullptr || A->d_pid == nullptr || g_spmm_path != 0 || getenv("GCGE_CG_NO_RECOMPUTE") != nullptr) return -1;
@@ -1164,6 +1240,7 @@ extern "C" int gcge_hip_cg_start_scaled_mv(void* mat, void** x, int xc0, const d
 // matrices without pattern form, blocks that cannot be walked in 16-byte column pairs.  Odd column ranges are widened
 // to even ones (the extra columns are computed and dropped).
 static int HIP_ResidualSq(void* mat, void* matB, void** x, int start, int end, const double* lambda, double* res_sq) {
+  enter();
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat; GcgeHipMV* vx = (GcgeHipMV*)x;
   if (A == nullptr || matB != nullptr || end <= start) return 0;
   const int c0 = start & ~1, c1 = (end + 1) & ~1, m = c1 - c0;

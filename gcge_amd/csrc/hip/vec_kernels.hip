@@ -340,6 +340,52 @@ __global__ __launch_bounds__(256) void colscale1_kernel(long nrows, double* __re
   for (; r < nrows; r += stride) y[r * ldy] *= s;
 }
 
+// (d) one step of a column-wise Gram-Schmidt in ONE sweep (what OrthSelf of the reference does in three slot calls + the
+// first of the next step, src/ops_orth.c:58-93):  x_k *= s (written back);  y_j += x_k c_j for the w columns behind it;
+// partial[b*w + i] = sum over the block's rows of y_i(new) * y_0(new) — the k x 1 Gram the NEXT step asks for.
+// base points at column k of the block (element (r, k) at base[r*ld]); w <= 64 columns, tpc = power of two >= w.
+template <int UNR>
+__global__ __launch_bounds__(256) void mgs_step_kernel(long nrows, double* __restrict__ base, long ld, double s,
+    const double* __restrict__ c, int w, double* __restrict__ partial, long rows_per_block, int tpc) {
+  __shared__ double red[256];
+  const int tx = threadIdx.x % tpc, ty = threadIdx.x / tpc, rpi = 256 / tpc;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
+  const bool mine = tx < w;
+  const int j = mine ? tx : 0;
+  const double cj = c[j], c0 = c[0];
+  double acc = 0.0;
+  long r = r0 + ty;
+  for (; r + (long)(UNR - 1) * rpi < r1; r += (long)UNR * rpi) {
+    double xk[UNR], y0[UNR], yj[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const double* row = base + (r + (long)u * rpi) * ld;
+      xk[u] = row[0]; y0[u] = row[1]; yj[u] = row[1 + j];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      double* row = base + (r + (long)u * rpi) * ld;
+      const double q = xk[u] * s;
+      const double y0n = fma(q, c0, y0[u]), yjn = fma(q, cj, yj[u]);
+      if (tx == 0) row[0] = q;
+      if (mine) { row[1 + j] = yjn; acc = fma(yjn, y0n, acc); }
+    }
+  }
+  for (; r < r1; r += rpi) {
+    double* row = base + r * ld;
+    const double q = row[0] * s, y0n = fma(q, c0, row[1]), yjn = fma(q, cj, row[1 + j]);
+    if (tx == 0) row[0] = q;
+    if (mine) { row[1 + j] = yjn; acc = fma(yjn, y0n, acc); }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int h = rpi / 2; h > 0; h >>= 1) {
+    if (ty < h) red[threadIdx.x] += red[threadIdx.x + h * tpc];
+    __syncthreads();
+  }
+  if (ty == 0 && mine) partial[(long)blockIdx.x * w + tx] = red[tx];
+}
+
 static int pow2_at_least(int v, int cap) { int t = 1; while (t < v && t < cap) t *= 2; return t; }
 // d_out[i] = sum_r X[r, i] y[r], i < k: X = d_x (leading dimension ldx), y = d_y with stride ldy
 extern "C" int gcge_hip_panel_dot1(int nrows, const double* d_x, long ldx, int k, const double* d_y, long ldy, double* d_out, void* stream) {
@@ -367,6 +413,23 @@ extern "C" int gcge_hip_rank1_update(int nrows, const double* d_x, long ldx, con
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(rank1_update_kernel<4>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (long)nrows, d_x, ldx, d_c, d_beta,
                      d_y, ldy, m, tpc);
+  return (int)hipGetLastError();
+}
+// x_k *= s; Y[:, 0:w) += x_k c^T (Y = the w columns right behind x_k in the same block, leading dimension ld);
+// d_dots[i] = Y_i(new) . Y_0(new), i < w.  -1: w > 64 (the caller takes the separate kernels)
+extern "C" int gcge_hip_mgs_step(int nrows, double* d_xk, long ld, double s, const double* d_c, int w, double* d_dots, void* stream) {
+  if (w <= 0 || w > 64) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (nrows <= 0) return (int)hipMemsetAsync(d_dots, 0, w * sizeof(double), st);
+  const int tpc = pow2_at_least(w, 64), rpi = 256 / tpc;
+  long nb = ((long)nrows + 4L * rpi * 4 - 1) / (4L * rpi * 4);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  const long rpb = (((long)nrows + nb - 1) / nb + rpi - 1) / rpi * rpi;
+  nb = ((long)nrows + rpb - 1) / rpb;
+  double* part = gcge_hip_partial_ws((size_t)nb * w);
+  hipLaunchKernelGGL(mgs_step_kernel<4>, dim3((unsigned)nb), dim3(256), 0, st, (long)nrows, d_xk, ld, s, d_c, w, part, rpb, tpc);
+  hipLaunchKernelGGL(reduce_partials, dim3(1), dim3(1024), 0, st, part, (int)nb, w, d_dots);
   return (int)hipGetLastError();
 }
 extern "C" int gcge_hip_colscale1(int nrows, double* d_y, long ldy, double s, void* stream) {

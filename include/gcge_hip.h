@@ -174,6 +174,11 @@ long gcge_hip_dense_selfcheck (int nrows, int ncols_local, const int *rowptr, co
  *     only and the values are streamed per row (8 doubles per row), so such matrices keep the pattern kernels (tables of
  *     at most 8 slots); 0 switches that off (takes effect at the next gcge_hip_mat_create*)                             */
 void gcge_hip_set_offset_patterns (int on);
+/*     column-wise Gram-Schmidt over the slots (the reference's OrthSelf, src/ops_orth.c:45-118): the scaling of x_k is held
+ *     back and folded, with the k x 1 Gram of the NEXT column, into the rank-1 update that follows it — one sweep per column
+ *     instead of three, same operands and products (1 default, 0: every slot call launches its own kernel)               */
+void gcge_hip_set_mgs_fusion (int on);
+void gcge_hip_mgs_fusion_stats (long *fused_steps, long *served_grams);
 /*     host-only structural self-check of that upload (no device needed): expands the tiles back into (row, column,
  *     value) triples and compares with the CSR arrays bit for bit; returns the number of differences (0 = identical),
  *     the X rows staged per matrix row, the ELL entries per non-zero and the grid strides it detected (0: none)       */
