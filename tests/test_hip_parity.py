@@ -1418,3 +1418,74 @@ def test_gcg_auto_shift_with_the_fused_solver(hip, key):
     assert res.nevConv == c["nevConv"]
     ref = np.array(c["eval"])
     assert np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref)) < 1e-10
+
+
+def test_mgs_step_fusion_equals_separate_kernels(both):
+    """Column-wise Gram-Schmidt over the slots (the call pattern of the reference's OrthSelf, src/ops_orth.c:45-118: per
+    column a k x 1 QtAP, a scaling, a rank-1 update): the back-end holds the scaling back and folds it, with the NEXT
+    column's Gram, into the rank-1 update (app_hip.hip: enter / g_pend / g_spec).  Same numbers as with every call launching
+    its own kernel and as the CPU oracle; and the held-back state never leaks: a scaling followed by anything but its own
+    rank-1 update is applied first, a speculative Gram column is served only to the immediately following matching call."""
+    hip, ora = both
+    g = hip.g
+    g.gcge_hip_set_mgs_fusion.argtypes = [C.c_int]
+    g.gcge_hip_mgs_fusion_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    A, _ = make_problem("lap3d", 11)
+    n = A.nrows
+    V0 = uniform(41, (n, 40)) - 0.5
+    V0[:, 9] = V0[:, 8] * 2.0 + 1e-9 * V0[:, 10]          # a nearly dependent column
+
+    def mgs(be, mat, fuse):
+        """OrthSelf on columns [5, 29) of a 40-column block, call for call as the reference issues it."""
+        if be is hip:
+            g.gcge_hip_set_mgs_fusion(fuse)
+        v = be.mv_from_numpy(mat, V0)
+        ws = be.ops.mv_create(40, mat)
+        end = 29
+        for k in range(5, end):
+            r = be.ops.qtap("S", "N", v, None, v, (k, k), (end, k + 1), ws, ld=end - k)[:, 0]
+            nrm = np.sqrt(r[0])
+            be.ops.axpby(0.0, None, 1.0 / nrm, v, (k, k), (k + 1, k + 1))
+            if k < end - 1:
+                coef = np.ascontiguousarray(-r[1:] / nrm)
+                be.ops.lincomb(v, v, (k, k + 1), (k + 1, end), coef, 1, beta=np.ones(1), incb=0)
+        out = be.mv_to_numpy(v, n, 0, 40)
+        be.ops.mv_destroy(v, 40); be.ops.mv_destroy(ws, 40)
+        return out
+    mh, mo = hip.matrix(A), ora.matrix(A)
+    f0, s0 = C.c_long(), C.c_long(); g.gcge_hip_mgs_fusion_stats(C.byref(f0), C.byref(s0))
+    try:
+        fused = mgs(hip, mh, 1)
+        f1, s1 = C.c_long(), C.c_long(); g.gcge_hip_mgs_fusion_stats(C.byref(f1), C.byref(s1))
+        assert f1.value - f0.value == 23 and s1.value - s0.value == 23, (f1.value - f0.value, s1.value - s0.value)
+        plain = mgs(hip, mh, 0)
+        f2 = C.c_long(); g.gcge_hip_mgs_fusion_stats(C.byref(f2), None)
+        assert f2.value == f1.value
+        ref = mgs(ora, mo, 0)
+        _close(fused, plain, tol=1e-12, what="fused Gram-Schmidt steps vs separate kernels")
+        _close(fused, ref, tol=1e-10, what="fused Gram-Schmidt steps vs oracle")     # (a nearly dependent column amplifies rounding)
+        Q = fused[:, 5:29]
+        assert np.max(np.abs(Q.T @ Q - np.eye(24))) < 1e-6
+        assert np.array_equal(fused[:, :5], V0[:, :5]) and np.array_equal(fused[:, 29:], V0[:, 29:])
+        # the held-back scaling is applied before anything else sees the block ...
+        g.gcge_hip_set_mgs_fusion(1)
+        v = hip.mv_from_numpy(mh, V0)
+        hip.ops.axpby(0.0, None, 3.0, v, (4, 4), (5, 5))
+        assert np.allclose(hip.mv_to_numpy(v, n, 4, 5), 3.0 * V0[:, 4:5], rtol=1e-15, atol=0)
+        # ... also when the next call is a rank-1 update from ANOTHER column, or an update that is not the adjacent panel
+        hip.ops.axpby(0.0, None, 0.5, v, (7, 7), (8, 8))
+        hip.ops.lincomb(v, v, (6, 7), (7, 9), np.array([2.0, -1.0]), 1, beta=np.ones(1), incb=0)
+        W = V0.copy(); W[:, 4] *= 3.0; W[:, 7] *= 0.5
+        W[:, 7] += 2.0 * W[:, 6]; W[:, 8] += -1.0 * W[:, 6]
+        _close(hip.mv_to_numpy(v, n, 0, 40), W, tol=1e-14, what="scaling followed by a foreign rank-1 update")
+        # ... and a speculative Gram column is not served once something else has touched the block
+        hip.ops.lincomb(v, v, (10, 11), (11, 14), np.array([0.5, 0.25, 0.125]), 1, beta=np.ones(1), incb=0)   # leaves Gram of column 11
+        W[:, 11:14] += np.outer(W[:, 10], [0.5, 0.25, 0.125])
+        hip.ops.axpby(1.0, v, 0.0, v, (20, 12), (21, 13))                                                       # overwrites column 12
+        W[:, 12] = W[:, 20]
+        got = hip.ops.qtap("S", "N", v, None, v, (11, 11), (14, 12), hip.ops.mv_create(4, mh), ld=3)[:, 0]
+        np.testing.assert_allclose(got, W[:, 11:14].T @ W[:, 11], rtol=1e-12)
+        hip.ops.mv_destroy(v, 40)
+    finally:
+        g.gcge_hip_set_mgs_fusion(1)
+    hip.free_matrix(mh)
