@@ -29,7 +29,7 @@
 extern "C" int gcge_hip_pad8_spmm(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval, const double* d_x,
                                   long ldx, double* d_y, long ldy, int ncols, void* stream);
 extern "C" void gcge_hip_spmm_pad8_auto(double avg_octets_per_row);
-extern "C" void* gcge_hip_tile_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val);
+extern "C" void* gcge_hip_tile_build_for(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, int remainder);
 extern "C" void gcge_hip_tile_free(void* tm);
 extern "C" int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
 extern "C" int gcge_hip_spmm_tile_mode_get(void);
@@ -321,7 +321,7 @@ extern "C" void* gcge_hip_dense_build(int nrows, int ncols_local, const int* row
   }
   D->noct = (long)noct;
   D->d_orp = to_device(orp); D->d_pcol = to_device(pc); D->d_pval = to_device(pv);
-  D->rem_tile = gcge_hip_spmm_tile_mode_get() >= 1 ? gcge_hip_tile_build(nrows, ncols_local, H.rem_rowptr.data(), H.rem_col.data(), H.rem_val.data()) : nullptr;
+  D->rem_tile = gcge_hip_tile_build_for(nrows, ncols_local, H.rem_rowptr.data(), H.rem_col.data(), H.rem_val.data(), 1);   // NULL: pad-8
   return D;
 }
 

@@ -259,7 +259,7 @@ static void build_range(int t0, int t1, const std::vector<int>& trow_off, const 
 
 using namespace gcge;
 
-static int g_tile_mode = 0;   // 0 off, 1 every matrix without a pattern form, 2 every matrix (tests: next to a pattern form), -1 never
+static int g_tile_mode = 0;   // 0 automatic (remainders of the block form that qualify), 1 every matrix without a pattern form, 2 every matrix (tests: next to a pattern form), -1 never
 extern "C" void gcge_hip_spmm_tile_mode(int mode) { g_tile_mode = mode; }
 extern "C" int gcge_hip_spmm_tile_mode_get(void) { return g_tile_mode; }
 
@@ -403,11 +403,20 @@ static T* tile_to_device(const std::vector<T>& v) {
   return d;
 }
 
-// NULL: the matrix keeps the generic kernels (path switched off, a row longer than the LDS tile, more than 2^31 ELL steps)
-extern "C" void* gcge_hip_tile_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val) {
-  if (g_tile_mode <= 0 || nrows <= 0) return nullptr;   // measured slower than the pad-8 kernel so far (profiles/r03_spmm_generic): only on request
+// NULL: the matrix keeps the generic kernels (path not applicable, a row longer than the LDS tile, more than 2^31 ELL steps).
+// Automatic rule (mode 0; profiles/r03_spmm_generic): the tile form pays on matrices of SHORT rows on a detected grid whose
+// bricks stage few X rows per matrix row — the remainder of the SiO2-like matrix once its long rows sit in dense blocks:
+// 5.0 against 6.7 ms for the pad-8 kernel — and not on matrices with long rows (the matrix stream then outweighs the
+// gathers saved) or without grid structure (runs of rows share too little).  `remainder`: the caller is spmm_dense.hip.
+extern "C" void* gcge_hip_tile_build_for(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, int remainder) {
+  if (g_tile_mode < 0 || nrows <= 0) return nullptr;
+  if (g_tile_mode == 0 && (!remainder || nrows < 4096 || rowptr[nrows] > 64L * nrows)) return nullptr;
   TileHost H;
   if (!tile_build_host(nrows, ncols_local, rowptr, colidx, val, &H)) return nullptr;
+  if (g_tile_mode == 0) {
+    const double xrows = (double)H.ucols.size() / nrows, ov = (double)H.ov_col.size() / (double)std::max<long>(1, rowptr[nrows]);
+    if (H.sy == 0 || xrows > 10.0 || ov > 0.05) return nullptr;
+  }
   TileMat* T = new TileMat();
   T->ntiles = (int)H.th.size(); T->nsteps = (long)(H.steps.size() / STEP_DOUBLES) - 1; T->nnz = rowptr[nrows];
   T->nucols = (long)H.ucols.size(); T->nrows = nrows;
@@ -418,6 +427,10 @@ extern "C" void* gcge_hip_tile_build(int nrows, int ncols_local, const int* rowp
   T->d_ov_rows = tile_to_device(H.ov_rows); T->d_ov_ptr = tile_to_device(H.ov_ptr);
   T->d_ov_col = tile_to_device(H.ov_col); T->d_ov_val = tile_to_device(H.ov_val);
   return T;
+}
+extern "C" void* gcge_hip_tile_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val) {
+  if (g_tile_mode <= 0) return nullptr;   // whole matrices: on request only (tests, measurements)
+  return gcge_hip_tile_build_for(nrows, ncols_local, rowptr, colidx, val, 0);
 }
 
 // what the upload found: tiles, X rows staged per matrix row (the request factor), ELL entries per non-zero (padding),

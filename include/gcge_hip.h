@@ -159,9 +159,10 @@ void gcge_hip_pool_enable (int on);
 size_t gcge_hip_pool_cached_bytes (void);
 void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > X tiles > pad-8 > CSR), 1 SELL-8 passes, 2 no pattern kernels, 3 pad-8 / CSR only */
 /*     tile path (csrc/hip/spmm_tile.hip): matrices without a pattern form whose rows are long enough (>= 12 entries on
- *     average) are additionally kept as row tiles (bricks of a detected grid, or runs of rows) with 16-bit positions into
- *     the tile's list of X rows, which the kernel stages in LDS once per 16-column pass.  mode: 0 automatic, 1 every
- *     matrix without a pattern form, 2 every matrix, -1 never (takes effect at the next gcge_hip_mat_create*)          */
+ *     average; automatic rule: see mode) are additionally kept as row tiles (bricks of a detected grid, or runs of rows) with 16-bit positions into
+ *     the tile's list of X rows, which the kernel stages in LDS once per 8-column pass.  mode: 0 automatic (the remainder
+ *     of a matrix whose long rows went into dense blocks, when it has short rows on a detected grid), 1 every matrix
+ *     without a pattern form, 2 every matrix, -1 never (takes effect at the next gcge_hip_mat_create*)                  */
 void gcge_hip_spmm_tile_mode (int mode);
 /*     supernode path (csrc/hip/spmm_dense.hip): row sets that share a column set (the dense blocks real-space DFT
  *     Hamiltonians keep per atom) are found at upload and multiplied as dense blocks on FP64 MFMA, the rest of the
