@@ -25,8 +25,6 @@
 extern "C" {
 int gcge_hip_pad8_spmm_dot(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval, const double* d_x,
                            long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream);
-int gcge_hip_sell8_spmm(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval, const double* d_x, long ldx,
-                        double* d_y, long ldy, int ncols, void* stream);
 void gcge_hip_spmm_pad8_auto(double avg_octets_per_row);
 int gcge_hip_pattern_width(int max_row_len);
 void* gcge_hip_tile_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val);
@@ -106,7 +104,7 @@ static hipStream_t g_stream = nullptr;
 static int g_inited = 0;
 static double* g_stage_d = nullptr; static size_t g_stage_d_len = 0;   // device staging (doubles)
 static double* g_stage_h = nullptr; static size_t g_stage_h_len = 0;   // pinned host staging
-static int g_spmm_path = 0;   // 0: automatic (pattern > X tiles > pad-8 > CSR), 1: SELL-8 passes, 2: no pattern path, 3: pad-8 / CSR only, 4: no block form (tile form if present)
+static int g_spmm_path = 0;   // 0: automatic (pattern > dense blocks + remainder > X tiles > pad-8 > CSR), 2: no pattern path, 3: pad-8 / CSR only, 4: no block form (tile form if present)
 extern "C" void gcge_hip_set_spmm_path(int path) { g_spmm_path = path; }
 static int g_offset_patterns = 1;   // 1: stencils with row-dependent coefficients take the pattern kernels with streamed values
 extern "C" void gcge_hip_set_offset_patterns(int on) { g_offset_patterns = on; }
@@ -327,7 +325,7 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const in
   // so what a lane loads through a slot depends on its position only, never on its pattern.
   do {
     const long S = A->pat_span;
-    if (getenv("GCGE_NO_CHAIN") != nullptr || lt < 4 || S <= 0 || S % 32 != 0) break;
+    if (lt < 4 || S <= 0 || S % 32 != 0) break;
     // canonical slots: the offsets of the interior stencil, chain first
     std::vector<long> offs;
     { bool m = false, c = false, q = false;
@@ -543,7 +541,7 @@ extern "C" const char* gcge_hip_mat_spmm_form(const GCGE_HIP_MAT* A) {
   }
   if (A->dense != nullptr && g_spmm_path != 1 && g_spmm_path != 3 && g_spmm_path != 4) return gcge_hip_dense_remainder_is_tiled(A->dense) ? "spmm_dense+spmm_tile" : "spmm_dense+spmm_pad8";
   if (A->tile != nullptr && g_spmm_path != 1 && g_spmm_path != 3) return "spmm_tile";
-  return g_spmm_path == 1 ? "spmm_sell8" : "spmm_pad8";
+  return "spmm_pad8";
 }
 
 // ------------------------------------------------------------------ device buffer pool
@@ -908,8 +906,7 @@ static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long 
     if (rc == 0 && d_yy) rc = gcge_hip_coldots(nr, y, ldy, y, ldy, m, d_yy, g_stream);
     return rc;
   }
-  if (m >= 16 && g_spmm_path == 1) rc = gcge_hip_sell8_spmm(nr, A->d_orp + r0, A->d_pcol, A->d_pval, dx, ldx, y, ldy, m, g_stream);
-  else if (m >= 16) {
+  if (m >= 16) {
     gcge_hip_spmm_pad8_auto(A->nrows > 0 ? (double)A->noct / A->nrows : 1.0);
     rc = gcge_hip_pad8_spmm(nr, A->d_orp + r0, A->d_pcol, A->d_pval, dx, ldx, y, ldy, m, g_stream);
   }
@@ -927,7 +924,7 @@ static int spmm_halo(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, double* dy, l
                      const CgPass* cg = nullptr) {
   const double* dx = vx->d + c_begin;
   const bool split = g_halo_overlap && A->nghost > 0 && A->exchange_begin != nullptr && A->exchange_end != nullptr &&
-                     m <= A->buf_cols && A->ov_hi - A->ov_lo >= A->nrows / 2 && getenv("GCGE_NO_HALO_OVERLAP") == nullptr &&
+                     m <= A->buf_cols && A->ov_hi - A->ov_lo >= A->nrows / 2 &&
                      A->tile == nullptr && A->dense == nullptr;   // (the block and tile forms multiply whole matrices, not row strips)
   if (!split) {
     halo_fetch(A, vx, c_begin, m);
@@ -1067,11 +1064,9 @@ extern "C" int gcge_hip_cg_fusable(void* mat, void** p, int ncols) {
 // Does forming the product twice pay?  Only where the product kernel is bound by HBM: the chain kernel with line exchange
 // (about 3 loads per row).  The plain pattern kernel issues 7+ cache-served loads per row and is bound by those, so a
 // second product costs more than the two block streams it saves (FE pair n = 10^6: 2.3 against 1.9 ms per iteration).
-// GCGE_CG_RECOMPUTE=1 forces the recompute form wherever it is possible.
 extern "C" int gcge_hip_cg_recompute_pays(void* mat) {
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
   if (A == nullptr || A->d_pid == nullptr) return 0;
-  if (getenv("GCGE_CG_RECOMPUTE") != nullptr) return 1;
   return gcge_hip_mat_pattern_chain(A) == 2;
 }
 // d_out[0, m) = sum_r p[r,j] (A p)[r,j], d_out[m, 2m) = sum_r (A p)[r,j]^2 over the LOCAL rows, left on the DEVICE (d_out holds
@@ -1334,8 +1329,7 @@ extern "C" void OPS_HIP_Set(struct OPS_* ops) {
   // writes, and writes them after its last read): one panel of <= 128 output columns may be updated in place
   GCGE_SetInplaceLinearComb((void*)HIP_MultiVecLinearComb, 128);
   {   // K7 on the device for the projected matrices where the host solver dominates an outer iteration (eig_device.hip)
-    const char* mn = getenv("GCGE_EIG_DEVICE_MIN_N");
-    GCGE_SetSymEigHook(gcge_hip_symeig, mn ? atoi(mn) : 192, (void*)HIP_MultiVecLinearComb);
+    GCGE_SetSymEigHook(gcge_hip_symeig, 192, (void*)HIP_MultiVecLinearComb);
   }
   ops->MatTransDotMultiVec      = HIP_MatTransDotMultiVec;
   ops->MultiVecQtAP             = HIP_MultiVecQtAP;

@@ -18,8 +18,8 @@
 //     pass 2: w rebuilt in the SpMM kernel's registers, r -= alpha_j w ; p' = r + beta_j p ; rho_j
 //             (reads p, r; writes r, p' into the next ring slot)    (MODE 3, gcge_hip_cg_pass2_mv)
 // 1 + 4 + 1.1 = 6.1 block streams per iteration in total; the start r = b - A x, p0 = r, rho is one sweep too (MODE 5).
-// The older two-sweep form (GCGE_CG_TWO_PASS=1, also
-// the fallback when a block cannot be walked with 16-byte lanes) needs no prediction:
+// The two-sweep form — the fallback when a block cannot be walked with 16-byte lanes (odd widths, odd column
+// origins) — needs no prediction:
 //     x += alpha'_j p ; p = r + beta_j p       (cg_update_xp: the x update of the PREVIOUS step is
 //                                               deferred into this pass: 3 reads + 2 writes)
 //     w = A p ; pTw_j = p_j . w_j
@@ -120,117 +120,6 @@ __global__ __launch_bounds__(256) void cg_update_r(long nrows, const double* __r
 }
 
 typedef double v2d __attribute__((ext_vector_type(2)));
-
-// ---- 16-byte-lane versions (all column origins 16-byte aligned, even leading dimensions, even m) ----
-// A thread owns ONE column pair for the whole launch (coefficients and flags live in registers) and walks
-// rows; TPR threads cover a row, 256/TPR rows per block step, UNR block steps in flight.  No load sits
-// under a per-element branch: a retired pair leaves the loop before it starts, and "p = r" on the first
-// step masks the (uninitialised) old p with an integer AND instead of a select.
-// WX / WP: some column of the window has a pending x update / a p update (host-known, so x or r are not even
-// read when nothing in the window needs them)
-template <int UNR, bool WX, bool WP>
-__global__ __launch_bounds__(256) void cg_update_xp_v2(long nrows, const double* __restrict__ r, long ldr,
-    double* __restrict__ p, long ldp, double* __restrict__ x, long ldx, int m, const double* __restrict__ beta,
-    const double* __restrict__ aprev, const int* __restrict__ flag, int tpr) {
-  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr, rpb = 256 / tpr;
-  const int j = 2 * tx;
-  if (j >= m) return;
-  const int f0 = flag[j], f1 = flag[j + 1];
-  if ((f0 | f1) == 0) return;
-  // per column: x += ax * p ; p = r * cr + (p & pm) * cb     (cr = 0, cb = 1, pm = ~0: p untouched)
-  const double ax0 = (f0 & 4) ? aprev[j] : 0.0, ax1 = (f1 & 4) ? aprev[j + 1] : 0.0;
-  const int m0 = f0 & 3, m1 = f1 & 3;
-  const double cr0 = m0 ? 1.0 : 0.0, cr1 = m1 ? 1.0 : 0.0;
-  const double cb0 = m0 == 1 ? beta[j] : (m0 == 2 ? 0.0 : 1.0), cb1 = m1 == 1 ? beta[j + 1] : (m1 == 2 ? 0.0 : 1.0);
-  const long long pm0 = m0 == 2 ? 0ll : -1ll, pm1 = m1 == 2 ? 0ll : -1ll;
-  // a block owns a contiguous slab of rows (10 % faster than grid-striding when the buffers happen to be mapped
-  // unfavourably, never slower: profiles/r01_stream/06_slab_vs_rows.log)
-  const long step = rpb, group = (long)rpb * UNR;
-  const long slab = (((nrows + gridDim.x - 1) / gridDim.x) + group - 1) / group * group;
-  const long rend = min(nrows, ((long)blockIdx.x + 1) * slab);
-  auto one = [&](long rr, v2d pvv, v2d rvv, v2d xvv) {
-    // x first: it uses the OLD p; on a first step (pm = 0) ax is 0 and the masked p is +0.0
-    const double q0 = __longlong_as_double(__double_as_longlong(pvv.x) & pm0);
-    const double q1 = __longlong_as_double(__double_as_longlong(pvv.y) & pm1);
-    if (WX) {
-      v2d xo = {fma(ax0, q0, xvv.x), fma(ax1, q1, xvv.y)};
-      __builtin_nontemporal_store(xo, reinterpret_cast<v2d*>(x + rr * ldx + j));
-    }
-    if (WP) {
-      v2d po = {fma(cb0, q0, cr0 * rvv.x), fma(cb1, q1, cr1 * rvv.y)};
-      __builtin_nontemporal_store(po, reinterpret_cast<v2d*>(p + rr * ldp + j));
-    }
-  };
-  long row = (long)blockIdx.x * slab + ty;
-  // full groups of UNR rows: straight-line code (a `break` between the stores makes hipcc sink every load next to
-  // its use and wait for each one), then the tail row by row
-  for (; row + (UNR - 1) * step < rend; row += step * UNR) {
-    v2d pv[UNR], rv[UNR], xv[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const long rr = row + u * step;
-      pv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p + rr * ldp + j));
-      if (WP) rv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(r + rr * ldr + j));
-      if (WX) xv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(x + rr * ldx + j));
-    }
-    __builtin_amdgcn_sched_barrier(0);   // all 3 UNR loads in flight before the first use (hipcc otherwise recycles registers)
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) one(row + u * step, pv[u], rv[u], xv[u]);
-  }
-  for (; row < rend; row += step) {
-    v2d pvv = *reinterpret_cast<const v2d*>(p + row * ldp + j), rvv = {0.0, 0.0}, xvv = {0.0, 0.0};
-    if (WP) rvv = *reinterpret_cast<const v2d*>(r + row * ldr + j);
-    if (WX) xvv = *reinterpret_cast<const v2d*>(x + row * ldx + j);
-    one(row, pvv, rvv, xvv);
-  }
-}
-
-// r_j -= alpha_j w_j ; partial[b*m + j] = sum over the block's rows of r_j^2   (alpha = 0 for retired columns)
-template <int UNR>
-__global__ __launch_bounds__(256) void cg_update_r_v2(long nrows, const double* __restrict__ w, long ldw,
-    double* __restrict__ r, long ldr, int m, const double* __restrict__ alpha, const int* __restrict__ flag,
-    double* __restrict__ partial, int tpr) {
-  __shared__ double red[256][2];
-  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr, rpb = 256 / tpr;
-  const int j = 2 * tx;
-  double s0 = 0.0, s1 = 0.0;
-  const bool mine = j < m;
-  const int f0 = mine ? flag[j] : 0, f1 = mine ? flag[j + 1] : 0;
-  if (mine && (f0 | f1)) {
-    const double a0 = f0 ? alpha[j] : 0.0, a1 = f1 ? alpha[j + 1] : 0.0;
-    const double k0 = f0 ? 1.0 : 0.0, k1 = f1 ? 1.0 : 0.0;   // retired columns contribute no partial (as before)
-    const long step = rpb, group = (long)rpb * UNR;
-    const long slab = (((nrows + gridDim.x - 1) / gridDim.x) + group - 1) / group * group;
-    const long rend = min(nrows, ((long)blockIdx.x + 1) * slab);
-    auto one = [&](long rr, v2d wvv, v2d rvv) {
-      v2d ro = {fma(-a0, wvv.x, rvv.x), fma(-a1, wvv.y, rvv.y)};
-      __builtin_nontemporal_store(ro, reinterpret_cast<v2d*>(r + rr * ldr + j));
-      s0 = fma(k0 * ro.x, ro.x, s0); s1 = fma(k1 * ro.y, ro.y, s1);
-    };
-    long row = (long)blockIdx.x * slab + ty;
-    for (; row + (UNR - 1) * step < rend; row += step * UNR) {
-      v2d wv[UNR], rv[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const long rr = row + u * step;
-        wv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(w + rr * ldw + j));
-        rv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(r + rr * ldr + j));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) one(row + u * step, wv[u], rv[u]);
-    }
-    for (; row < rend; row += step)
-      one(row, *reinterpret_cast<const v2d*>(w + row * ldw + j), *reinterpret_cast<const v2d*>(r + row * ldr + j));
-  }
-  red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1;
-  __syncthreads();
-  if (ty == 0 && mine) {   // fixed order over the block's row slots
-    for (int q = 1; q < rpb; ++q) { s0 += red[q * tpr + tx][0]; s1 += red[q * tpr + tx][1]; }
-    partial[(long)blockIdx.x * m + j] = s0;
-    partial[(long)blockIdx.x * m + j + 1] = s1;
-  }
-}
 
 // ---- one-pass step -------------------------------------------------------------------------------------------
 // r -= alpha w ; x += alpha p ; p = r_new + beta p ; partial[b*m + j] = sum over the block's rows of r_new^2
@@ -424,20 +313,9 @@ static bool cg_vec_ok(int m, std::initializer_list<const double*> ptrs, std::ini
 static int cg_tpr(int m) { int t = 1; while (t < m / 2) t *= 2; return t; }   // threads per row (m <= 512)
 
 static void launch_update_xp(long n, const double* r, long ldr, double* p, long ldp, double* x, long ldx, int mw,
-                             const double* beta, const double* aprev, const int* flag, bool any_x, bool any_p,
-                             hipStream_t st) {
-  if (mw <= 512 && cg_vec_ok(mw, {r, p, x}, {ldr, ldp, ldx})) {
-    const int tpr = cg_tpr(mw), rpb = 256 / tpr;
-    long g = (n + (long)rpb * 4 - 1) / ((long)rpb * 4); if (g > 4096) g = 4096; if (g < 1) g = 1;
-#define GCGE_XP(WX, WP) hipLaunchKernelGGL((cg_update_xp_v2<4, WX, WP>), dim3((unsigned)g), dim3(256), 0, st, n, r, ldr, p, \
-                                           ldp, x, ldx, mw, beta, aprev, flag, tpr)
-    if (any_x && any_p) GCGE_XP(true, true); else if (any_x) GCGE_XP(true, false); else if (any_p) GCGE_XP(false, true);
-#undef GCGE_XP
-  } else {
-    long total = n * mw, g = (total + 255) / 256; if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(cg_update_xp, dim3((unsigned)g), dim3(256), 0, st, n, r, ldr, p, ldp, x, ldx, mw, beta, aprev,
-                       flag);
-  }
+                             const double* beta, const double* aprev, const int* flag, hipStream_t st) {
+  long total = n * mw, g = (total + 255) / 256; if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(cg_update_xp, dim3((unsigned)g), dim3(256), 0, st, n, r, ldr, p, ldp, x, ldx, mw, beta, aprev, flag);
 }
 
 struct HipBpcg {
@@ -590,9 +468,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
     active[i] = init_res[i] > s->tol * norm_b[i];
     nact += active[i];
   }
-  static const long nb_cap = getenv("GCGE_CG_GRID") ? atol(getenv("GCGE_CG_GRID")) : 2048;   // tuning hook
-  static const int r_unr = getenv("GCGE_CG_RUNR") ? atoi(getenv("GCGE_CG_RUNR")) : 4;
-  long nb = ((long)n + 255) / 256; if (nb > nb_cap) nb = nb_cap;
+  long nb = ((long)n + 255) / 256; if (nb > 2048) nb = 2048;
   const long rpb = (((long)n + nb - 1) / nb + 3) / 4 * 4;
   nb = ((long)n + rpb - 1) / rpb;
 
@@ -610,8 +486,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
   };
   int niter = 0;
   // ---- one-pass scheme (default whenever all four blocks can be walked with 16-byte lanes) ----
-  static const bool two_pass = getenv("GCGE_CG_TWO_PASS") != nullptr;
-  if (!two_pass && nrhs <= 512 && cg_vec_ok(nrhs, {dw, dr, dp, dx}, {ldw, ldr, ldp, ldx})) {
+  if (nrhs <= 512 && cg_vec_ok(nrhs, {dw, dr, dp, dx}, {ldw, ldr, ldp, ldx})) {
     std::vector<double> wTw(nrhs), bet(nrhs);
     // p-ring (see cg_update_rp): as many slots as memory allows, at most 16; fewer than 4 pending terms do not pay
     const int ring_max = getenv("GCGE_CG_RING") ? atoi(getenv("GCGE_CG_RING")) : 16;   // (read when a ring is created)
@@ -625,11 +500,10 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       if (want > ring_max - 1) want = ring_max - 1;
       // smallest ring worth having: with the product recomputed (1 + 4 streams per iteration) even two extra slots pay —
       // x then costs (2 + 2) / 2 = 2 streams per iteration, 7 in all against 8.1 of the stored-w form; that is the case of
-      // BASELINE config 4's shape, where 244 of 288 GB are taken by the solver's own blocks (GCGE_CG_MIN_RING overrides)
+      // BASELINE config 4's shape, where 244 of 288 GB are taken by the solver's own blocks
       // (with the product stored — generic matrices, shifts — a ring only pays from 4 extra slots on: 2 + 5 + (J + 2) / J
       // streams against the 9 of the ring-less sweep)
-      static const int min_ring_env = getenv("GCGE_CG_MIN_RING") ? atoi(getenv("GCGE_CG_MIN_RING")) : 0;
-      const int min_ring = min_ring_env > 0 ? min_ring_env : ((sigma == 0.0 && gcge_hip_cg_recompute_pays(mat)) ? 2 : 4);
+      const int min_ring = (sigma == 0.0 && gcge_hip_cg_recompute_pays(mat)) ? 2 : 4;
       if (want < min_ring) want = 0;
       if (want > s->max_iter) want = s->max_iter;
       // Row-partitioned runs: the ring length decides the column window [alo, ahi) and with it the LENGTH of the two
@@ -852,11 +726,8 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
         for (int j = 0; j < nrhs; ++j) ahist[(size_t)npend * nrhs + j] = (j >= alo && j < ahi && active[j]) ? coef[j] : 0.0;
         ++npend; cur = (cur + 1) % R;
       } else {
-        static const int a_unr = getenv("GCGE_CG_AUNR") ? atoi(getenv("GCGE_CG_AUNR")) : 4;   // tuning hook
-#define GCGE_UA(U) hipLaunchKernelGGL(cg_update_all<U>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr, \
-                                      dp + alo, ldp, dx + alo, ldx, aw, s->d_coef + s->cap, s->d_coef, s->d_flag, part, cg_tpr(aw))
-        if (a_unr == 2) GCGE_UA(2); else if (a_unr == 3) GCGE_UA(3); else if (a_unr == 6) GCGE_UA(6); else GCGE_UA(4);
-#undef GCGE_UA
+        hipLaunchKernelGGL(cg_update_all<4>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr,
+                           dp + alo, ldp, dx + alo, ldx, aw, s->d_coef + s->cap, s->d_coef, s->d_flag, part, cg_tpr(aw));
       }
       gcge_hip_reduce_partials(part, (int)nb, aw, part + (size_t)nb * aw, st);
       GCGE_HIP_CHECK(hipMemcpyAsync(s->h_pin, part + (size_t)nb * aw, aw * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -892,12 +763,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       coef[j] = (active[j] && niter > 0) ? rho2[j] / rho1[j] : 0.0;
     }
     upload(lo, mw, coef.data(), aprev.data(), flag.data());
-    {
-      bool any_x = false, any_p = false;
-      for (int j = lo; j < hi; ++j) { any_x |= (flag[j] & 4) != 0; any_p |= (flag[j] & 3) != 0; }
-      launch_update_xp((long)n, dr + lo, ldr, dp + lo, ldp, dx + lo, ldx, mw, s->d_coef, s->d_coef + s->cap, s->d_flag,
-                       any_x, any_p, st);
-    }
+    launch_update_xp((long)n, dr + lo, ldr, dp + lo, ldp, dx + lo, ldx, mw, s->d_coef, s->d_coef + s->cap, s->d_flag, st);
     for (int j = lo; j < hi; ++j) pend[j] = 0;
     // w = A p and pTw on the window of ACTIVE columns
     int alo = lo, ahi = hi;
@@ -914,21 +780,8 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
     }
     upload(alo, aw, coef.data(), coef.data(), flag.data());
     double* part = gcge_hip_partial_ws((size_t)nb * aw + aw);
-    if (aw <= 512 && cg_vec_ok(aw, {dw + alo, dr + alo}, {ldw, ldr}))
-    {
-      if (r_unr == 8)
-        hipLaunchKernelGGL(cg_update_r_v2<8>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr,
-                           aw, s->d_coef, s->d_flag, part, cg_tpr(aw));
-      else if (r_unr == 2)
-        hipLaunchKernelGGL(cg_update_r_v2<2>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr,
-                           aw, s->d_coef, s->d_flag, part, cg_tpr(aw));
-      else
-        hipLaunchKernelGGL(cg_update_r_v2<4>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr,
-                           aw, s->d_coef, s->d_flag, part, cg_tpr(aw));
-    }
-    else
-      hipLaunchKernelGGL(cg_update_r, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr, aw,
-                         s->d_coef, s->d_flag, part, rpb);
+    hipLaunchKernelGGL(cg_update_r, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr, aw,
+                       s->d_coef, s->d_flag, part, rpb);
     gcge_hip_reduce_partials(part, (int)nb, aw, part + (size_t)nb * aw, st);
     GCGE_HIP_CHECK(hipMemcpyAsync(s->h_pin, part + (size_t)nb * aw, aw * sizeof(double), hipMemcpyDeviceToHost, st));
     GCGE_HIP_CHECK(hipStreamSynchronize(st));
@@ -952,8 +805,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       const int mw = hi - lo;
       for (int j = lo; j < hi; ++j) { flag[j] = pend[j] ? 4 : 0; coef[j] = 0.0; }
       upload(lo, mw, coef.data(), aprev.data(), flag.data());
-      launch_update_xp((long)n, dr + lo, ldr, dp + lo, ldp, dx + lo, ldx, mw, s->d_coef, s->d_coef + s->cap, s->d_flag,
-                       true, false, st);
+      launch_update_xp((long)n, dr + lo, ldr, dp + lo, ldp, dx + lo, ldx, mw, s->d_coef, s->d_coef + s->cap, s->d_flag, st);
     }
   }
   s->niter = niter;

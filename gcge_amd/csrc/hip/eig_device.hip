@@ -135,42 +135,6 @@ __global__ __launch_bounds__(256) void eig_apply_q(int n, int k, const double* _
   for (int i = lane; i < len; i += 64) col[i] -= t * v[i];
 }
 
-// Replay of the recorded QL sweeps against the columns of Q (column-major, ld n): sweep s = rotations in columns
-// (i, i+1) for i = first .. last (descending), cs[2 (off + first - i)] = c, +1 = s.  One lane per row of Q.
-struct EigSweep { int first, last; long off; };
-__global__ __launch_bounds__(64) void eig_replay(int n, double* __restrict__ q, const EigSweep* __restrict__ sw, int nsweep,
-    const double* __restrict__ cs) {
-  const int r = blockIdx.x * 64 + threadIdx.x;
-  const int rr = r < n ? r : n - 1;                 // surplus lanes shadow the last row (no predicate near the loads)
-  double* qr = q + rr;
-  for (int s = 0; s < nsweep; ++s) {
-    const int first = sw[s].first, last = sw[s].last;
-    const double* c = cs + 2 * sw[s].off;
-    double hi = qr[(size_t)(first + 1) * n];
-    int i = first;
-    for (; i - 7 >= last; i -= 8) {                 // eight loads in flight, then the dependent chain of rotations
-      double lo[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) lo[u] = qr[(size_t)(i - u) * n];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const double cc = c[2 * (first - i + u)], ss = c[2 * (first - i + u) + 1];
-        const double out = fma(ss, lo[u], cc * hi);
-        hi = fma(cc, lo[u], -ss * hi);
-        if (r < n) qr[(size_t)(i - u + 1) * n] = out;
-      }
-    }
-    for (; i >= last; --i) {
-      const double cc = c[2 * (first - i)], ss = c[2 * (first - i) + 1];
-      const double lo = qr[(size_t)i * n];
-      const double out = fma(ss, lo, cc * hi);
-      hi = fma(cc, lo, -ss * hi);
-      if (r < n) qr[(size_t)(i + 1) * n] = out;
-    }
-    if (r < n) qr[(size_t)last * n] = hi;
-  }
-}
-
 
 // ---- fused replay: EIG_K consecutive sweeps in one pass over the columns ---------------------------------------------
 // The plain replay above is latency-bound (one L2 round trip per eight rotations: 62 ms for the 4.3e5 rotations of
@@ -242,6 +206,8 @@ __global__ __launch_bounds__(64) void eig_replay_fused(int n, double* __restrict
 
 using namespace gcge;
 
+// a recorded QL sweep: rotations in columns (i, i+1) for i = first .. last (descending), cs[2 (off + first - i)] = c, +1 = s
+struct EigSweep { int first, last; long off; };
 // implicit QL on the tridiagonal (d, e), e[k] couples k and k+1 — the iteration of csrc/host/eig_sym.c with the
 // rotations recorded (descending column index inside a sweep) instead of applied.  0, or l+1 if eigenvalue l failed.
 // sqrt(f^2 + g^2); the libm hypot (over/underflow-proof, ~50 ns) only outside the range where the squares are safe
@@ -363,9 +329,8 @@ extern "C" int gcge_hip_symeig(char uplo, int n, const double* a, int lda, doubl
   if (info != 0) { GCGE_HIP_CHECK(hipStreamSynchronize(st)); return info; }
   const double w1 = wall();
   // 4. replay on the device: groups of EIG_K consecutive sweeps, padded to a common column range, coefficients time-major
-  static const bool plain_replay = getenv("GCGE_EIG_PLAIN_REPLAY") != nullptr;
   size_t n_rot = cs.size() / 2;
-  if (!sweeps.empty() && !plain_replay) {
+  if (!sweeps.empty()) {
     std::vector<EigGroup> groups;
     size_t total = 0;
     for (size_t a = 0; a < sweeps.size(); a += EIG_K) {
@@ -406,14 +371,6 @@ extern "C" int gcge_hip_symeig(char uplo, int n, const double* a, int lda, doubl
     hipLaunchKernelGGL(eig_replay_fused, dim3((n + 63) / 64), dim3(64), 0, st, n, g.q, (const EigGroup*)g.sw, (int)groups.size(), g.cs);
     if (timing) GCGE_HIP_CHECK(hipEventRecord(tev[4], st));
     GCGE_HIP_CHECK(hipStreamSynchronize(st));          // `groups` is pageable and leaves scope here
-  } else if (!sweeps.empty()) {
-    if (cs.size() > g.cap_cs) { if (g.cs) { GCGE_HIP_CHECK(hipStreamSynchronize(st)); hipFree(g.cs); } g.cap_cs = cs.size() * 2; GCGE_HIP_CHECK(hipMalloc(&g.cs, g.cap_cs * sizeof(double))); }
-    if (sweeps.size() > g.cap_sw) { if (g.sw) { GCGE_HIP_CHECK(hipStreamSynchronize(st)); hipFree(g.sw); } g.cap_sw = sweeps.size() * 2; GCGE_HIP_CHECK(hipMalloc(&g.sw, g.cap_sw * sizeof(EigSweep))); }
-    GCGE_HIP_CHECK(hipMemcpyAsync(g.cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    GCGE_HIP_CHECK(hipMemcpyAsync(g.sw, sweeps.data(), sweeps.size() * sizeof(EigSweep), hipMemcpyHostToDevice, st));
-    if (timing) GCGE_HIP_CHECK(hipEventRecord(tev[3], st));
-    hipLaunchKernelGGL(eig_replay, dim3((n + 63) / 64), dim3(64), 0, st, n, g.q, g.sw, (int)sweeps.size(), g.cs);
-    if (timing) GCGE_HIP_CHECK(hipEventRecord(tev[4], st));
   }
   // 5. back to the host, ascending
   GCGE_HIP_CHECK(hipMemcpyAsync(g.h_pin, g.q, nn * sizeof(double), hipMemcpyDeviceToHost, st));

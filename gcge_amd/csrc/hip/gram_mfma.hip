@@ -212,7 +212,7 @@ extern "C" int gcge_hip_gram(int nrows, const double* d_q, long ldq, int k, cons
   const int tib = ti % 4 == 0 ? 4 : (ti % 2 == 0 ? 2 : 1);
   const int gy = (ti + tib - 1) / tib;
   // enough blocks to fill 256 CUs a few times over, chunks a multiple of 16 rows
-  static const long chunk_target = getenv("GCGE_GRAM_CHUNKS") ? atol(getenv("GCGE_GRAM_CHUNKS")) : 512;   // blocks per launch aimed at: two resident blocks per CU, one round (2048: 10.83 ms at k = 256, m = 64, 512: 10.08 ms; k = 64: 3.68 -> 2.90 ms — the fixed-order reduction of the slab walks fewer chunks)
+  static const long chunk_target = 512;   // blocks per launch aimed at: two resident blocks per CU, one round (2048: 10.83 ms at k = 256, m = 64, 512: 10.08 ms; k = 64: 3.68 -> 2.90 ms — the fixed-order reduction of the slab walks fewer chunks)
   long nchunks = chunk_target / ((long)gy * tj);
   if (nchunks < 64) nchunks = 64;
   long rpc = (((long)nrows + nchunks - 1) / nchunks + 63) / 64 * 64;

@@ -327,7 +327,7 @@ using namespace gcge;
 
 static double* g_cpad = nullptr;
 static size_t g_cpad_len = 0;
-static int g_lc_rf = getenv("GCGE_LINCOMB_RF") ? atoi(getenv("GCGE_LINCOMB_RF")) : 0;   // 0 automatic (the direct form for panels of >= 33 columns where the operand allows 16-byte loads);
+static int g_lc_rf = 0;   // 0 automatic (the direct form for panels of >= 33 columns where the operand allows 16-byte loads);
                           // 1 / 2: the LDS-staged kernel with that many row fragments per wave; >= 3: the direct form forced, see lc_launch
 extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 0 && row_fragments <= 14) g_lc_rf = row_fragments; }
 

@@ -228,9 +228,7 @@ extern "C" int gcge_hip_spmm_dense_mode_get(void) { return g_dense_mode; }
 extern "C" long gcge_hip_dense_selfcheck(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val,
                                          int min_len, long* nblocks, double* share, double* fill) {
   DenseHost H;
-  const clock_t t0 = clock();
   if (!dense_build_host(nrows, ncols_local, rowptr, colidx, val, min_len, &H)) return -1;
-  if (getenv("GCGE_DENSE_TIMING")) fprintf(stderr, "dense_build_host: %.2f s\n", (double)(clock() - t0) / CLOCKS_PER_SEC);
   long bad = 0, entries = 0;
   std::vector<std::vector<std::pair<int, double>>> got((size_t)nrows);
   std::vector<int> owner((size_t)nrows, -1);
@@ -265,11 +263,6 @@ extern "C" long gcge_hip_dense_selfcheck(int nrows, int ncols_local, const int* 
       else if (w.second != 0.0) ++bad;
     }
     if (g != got[r].size()) ++bad;
-  }
-  if (getenv("GCGE_DENSE_TIMING")) {
-    long mx = 0, over64 = 0, over48 = 0, nnz_over = 0;
-    for (int r = 0; r < nrows; ++r) { const long l = H.rem_rowptr[r + 1] - H.rem_rowptr[r]; mx = std::max(mx, l); over64 += l > 64; over48 += l > 48; if (l > 64) nnz_over += l; }
-    fprintf(stderr, "remainder: nnz %d, longest row %ld, rows > 48: %ld, > 64: %ld (holding %ld entries)\n", H.rem_rowptr[nrows], mx, over48, over64, nnz_over);
   }
   if (nblocks) *nblocks = (long)H.sn.size();
   if (share) *share = (double)H.dense_nnz / (double)rowptr[nrows];

@@ -334,7 +334,7 @@ static int g_ring_depth = 3;   // planes requested ahead (2 or 3)
 // Y = A X through the ring: off by default — measured 3.44 ms against 3.43-3.46 ms of the chain2 kernel at 256^3 x 64 (the
 // product is bound by its read + write traffic, 18.2 GB at 5.3 TB/s, not by rows in flight); kept, and tested, because it
 // shows the counted waits with stores in the queue (what a ring form of the second CG pass would need)
-static int g_ring_product = getenv("GCGE_RING_PRODUCT") ? atoi(getenv("GCGE_RING_PRODUCT")) : 0;
+static int g_ring_product = 0;
 extern "C" void gcge_hip_spmm_ring_product(int on) { g_ring_product = on; }
 static int g_ring_wide = 0;    // 1: always 64-bit lane addresses (tests)
 extern "C" void gcge_hip_spmm_ring_wide(int on) { g_ring_wide = on; }

@@ -148,16 +148,12 @@ int gcge_hip_pad8_spmm (int nrows, const int *d_orp, const int *d_pcol, const do
 /* K2  G(k x m, row-major on device, ld m) = Q[:,0:k)^T P[:,0:m)  over nrows rows (MFMA f64) */
 int gcge_hip_gram (int nrows, const double *d_q, long ldq, int k, const double *d_p, long ldp, int m,
 		double *d_g, void *stream);
-/*     experimental narrow-pass variant (16 columns per pass, 8 rows per wave instruction: keeps a grid plane of X
- *     in L2; csrc/hip/spmm_sell8.hip); gcge_hip_set_spmm_path(1) routes MatDotMultiVec through it              */
-int gcge_hip_sell8_spmm (int nrows, const int *d_orp, const int *d_pcol, const double *d_pval,
-		const double *d_x, long ldx, double *d_y, long ldy, int ncols, void *stream);
 /*     blocks of vectors freed through MultiVecDestroy are kept by size and reused (hipMalloc/hipFree of multi-GB
  *     blocks cost ~0.3 s each); release returns them to the driver, enable(0) switches the cache off            */
 void gcge_hip_pool_release (void);
 void gcge_hip_pool_enable (int on);
 size_t gcge_hip_pool_cached_bytes (void);
-void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > X tiles > pad-8 > CSR), 1 SELL-8 passes, 2 no pattern kernels, 3 pad-8 / CSR only */
+void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > dense blocks + remainder > pad-8 > CSR), 2 no pattern kernels, 3 pad-8 / CSR only, 4 no dense blocks */
 /*     tile path (csrc/hip/spmm_tile.hip): matrices without a pattern form whose rows are long enough (>= 12 entries on
  *     average; automatic rule: see mode) are additionally kept as row tiles (bricks of a detected grid, or runs of rows) with 16-bit positions into
  *     the tile's list of X rows, which the kernel stages in LDS once per 8-column pass.  mode: 0 automatic (the remainder
@@ -219,7 +215,7 @@ long gcge_hip_spmm_ring_launches (void);   /* 16-column launches the ring sweep 
 /*     the same on operator-table objects (halo rows of p fetched by pass 1 and reused by pass 2; sums are the LOCAL
  *     parts, on the host); gcge_hip_cg_fusable: 1 if (mat, p, ncols) qualify                                        */
 int gcge_hip_cg_fusable (void *mat, void **p, int ncols);
-int gcge_hip_cg_recompute_pays (void *mat);   /* 1: chain + line-exchange layout (HBM-bound product); GCGE_CG_RECOMPUTE=1 forces */
+int gcge_hip_cg_recompute_pays (void *mat);   /* 1: chain + line-exchange layout (HBM-bound product) */
 /*     the GCGE_RESIDUAL_FN (include/gcge_ops.h) OPS_HIP_Set registers: squared residual norms of Ritz pairs of a
  *     standard problem in one read of x (kernel MODE 4); returned as void* for test harnesses                    */
 void *gcge_hip_residual_hook (void);

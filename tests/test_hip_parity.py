@@ -58,26 +58,6 @@ def test_spmm_vs_oracle(both, kind, size, kw):
     _close(hip.mv_to_numpy(yh, n, 0, 64), S @ X[:, 4:68], tol=1e-13, what="spmm vs scipy")
 
 
-@pytest.mark.parametrize("kind,size,kw", [("lap3d", 13, {}), ("sio2", 10, {"K": 8, "R0": 2.0, "R1": 3.0})])
-def test_spmm_sell8_path_vs_oracle(both, kind, size, kw):
-    """The narrow-pass SpMM variant (16 columns per pass) through the same slot."""
-    hip, ora = both
-    A, mh, mo = _pair_mats(both, kind, size, **kw)
-    n = A.nrows
-    X = uniform(9, (n, 80)) - 0.5
-    xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
-    hip.g.gcge_hip_set_spmm_path(1)
-    try:
-        for m, s0, s1 in [(16, 0, 0), (18, 2, 4), (32, 0, 16), (64, 0, 0), (70, 8, 2)]:
-            Y0 = uniform(10, (n, 80))
-            yh, yo = hip.mv_from_numpy(mh, Y0), ora.mv_from_numpy(mo, Y0)
-            hip.ops.spmm(mh, xh, yh, (s0, s1), (s0 + m, s1 + m))
-            ora.ops.spmm(mo, xo, yo, (s0, s1), (s0 + m, s1 + m))
-            _close(hip.mv_to_numpy(yh, n, 0, 80), ora.mv_to_numpy(yo, n, 0, 80), tol=1e-13, what="sell8 spmm m=%d" % m)
-    finally:
-        hip.g.gcge_hip_set_spmm_path(0)
-
-
 @pytest.mark.parametrize("kind,size,expect,chain", [("lap3d", 13, True, False), ("fe3d", 11, True, False),
                                                     ("fe1d", 500, True, False), ("sio2", 10, False, False),
                                                     ("lap3d", 16, True, True), ("fe3d", 24, True, True)])

@@ -19,8 +19,6 @@ extern "C" int gcge_hip_pad8_spmm(int nrows, const int*, const int*, const doubl
                                   long, double*, long, int, void*);
 extern "C" void gcge_hip_spmm_pad8_tune(int rows_per_wave, int batch, int store_policy, int col_pass);
 extern "C" void gcge_hip_spmm_pad8_gridcap(int cap);
-extern "C" int gcge_hip_sell8_spmm(int, const int*, const int*, const double*, const double*, long, double*, long, int, void*);
-extern "C" void gcge_hip_spmm_sell8_tune(int);
 extern "C" void gcge_hip_spmm_pad8_schedule(const int* d_sched, int len, int rows_per_wave, int grid);
 
 __global__ void fill_kernel(double* x, size_t n, unsigned seed) {
@@ -265,20 +263,6 @@ int main(int argc, char** argv) {
       hipEventRecord(e0); for (int r = 0; r < reps; ++r) run(); hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
       printf("pattern probe spw=%d  %8.3f ms  (%.1f%% of 8 TB/s on the CSR-equivalent bytes)\n", spw, ms, alg_bytes * 1e-6 / ms / 80.0);
-    }
-  }
-  if (getenv("SELL8")) {
-    for (int spw : {1, 2, 4, 7}) {
-      gcge_hip_spmm_sell8_tune(spw);
-      GCGE_HIP_CHECK(hipMemset(d_y, 0xff, n * (size_t)m * sizeof(double)));
-      int rc = gcge_hip_sell8_spmm((int)n, d_orp, d_pc, d_pv, d_x + x0, ldx, d_y, m, m, 0);
-      if (rc) { printf("sell8 rc=%d\n", rc); return 2; }
-      GCGE_HIP_CHECK(hipDeviceSynchronize());
-      hipEventRecord(e0);
-      for (int r = 0; r < reps; ++r) gcge_hip_sell8_spmm((int)n, d_orp, d_pc, d_pv, d_x + x0, ldx, d_y, m, m, 0);
-      hipEventRecord(e1); hipEventSynchronize(e1);
-      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
-      printf("sell8 spw=%d  %8.3f ms  %8.1f GB/s alg  (%.1f%% of 8 TB/s)\n", spw, ms, alg_bytes * 1e-6 / ms, alg_bytes * 1e-6 / ms / 80.0);
     }
   }
   // verification on sampled rows against a host recomputation
