@@ -1413,7 +1413,7 @@ def test_mgs_step_fusion_equals_separate_kernels(both):
     A, _ = make_problem("lap3d", 11)
     n = A.nrows
     V0 = uniform(41, (n, 40)) - 0.5
-    V0[:, 9] = V0[:, 8] * 2.0 + 1e-9 * V0[:, 10]          # a nearly dependent column
+    V0[:, 9] = V0[:, 8] * 2.0 + 1e-3 * V0[:, 10]          # a column that loses three digits in the projection
 
     def mgs(be, mat, fuse):
         """OrthSelf on columns [5, 29) of a 40-column block, call for call as the reference issues it."""
@@ -1442,10 +1442,12 @@ def test_mgs_step_fusion_equals_separate_kernels(both):
         f2 = C.c_long(); g.gcge_hip_mgs_fusion_stats(C.byref(f2), None)
         assert f2.value == f1.value
         ref = mgs(ora, mo, 0)
-        _close(fused, plain, tol=1e-12, what="fused Gram-Schmidt steps vs separate kernels")
-        _close(fused, ref, tol=1e-10, what="fused Gram-Schmidt steps vs oracle")     # (a nearly dependent column amplifies rounding)
+        # (the three digits lost in column 9 amplify the rounding of the dot products — whose row sums run in different
+        #  orders in the three implementations — by 1e3)
+        _close(fused, plain, tol=1e-10, what="fused Gram-Schmidt steps vs separate kernels")
+        _close(fused, ref, tol=1e-10, what="fused Gram-Schmidt steps vs oracle")
         Q = fused[:, 5:29]
-        assert np.max(np.abs(Q.T @ Q - np.eye(24))) < 1e-6
+        assert np.max(np.abs(Q.T @ Q - np.eye(24))) < 1e-9
         assert np.array_equal(fused[:, :5], V0[:, :5]) and np.array_equal(fused[:, 29:], V0[:, 29:])
         # the held-back scaling is applied before anything else sees the block ...
         g.gcge_hip_set_mgs_fusion(1)
