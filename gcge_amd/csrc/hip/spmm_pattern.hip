@@ -479,26 +479,11 @@ __device__ __forceinline__ void chain2_body(
   }
 }
 
-// gridDim.y = the 16-column passes of one block operation, in ONE launch: pass ps works on columns [16 ps, 16 ps + 16) of
-// every operand (mtot columns in all) and on its own slab of the partial-sum workspace; the blocks of pass ps + 1 start on
-// the CUs the tail of pass ps leaves idle (four separate launches cost four tails: ~0.1 ms each at 256^3).
 template <int LT, int MODE, int NW, bool VALS = false>
 __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
-    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int mtot, long ntiles, long line,
+    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
     double* __restrict__ dot_partial, long yy_offset, int xcd_runs, CgArgs cg) {
-  {
-    const int c0 = 16 * (int)blockIdx.y;
-    x += c0; if (y != nullptr) y += c0;
-    if (dot_partial != nullptr) dot_partial += (size_t)blockIdx.y * gridDim.x * 16;
-    if (cg.r != nullptr) cg.r += c0;
-    if (cg.pnew != nullptr) cg.pnew += c0;
-    if (cg.alpha != nullptr) cg.alpha += c0;
-    if (cg.beta != nullptr) cg.beta += c0;
-    if (cg.flag != nullptr) cg.flag += c0;
-    if (cg.b != nullptr) cg.b += c0;
-  }
-  const int m = min(16, mtot - 16 * (int)blockIdx.y);
   constexpr int DOT = MODE != 0;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
@@ -605,10 +590,10 @@ static long pat_launch(long nrows, const unsigned short* pid, const void* tab, i
                        double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st,
                        long cline, int nw, const CgArgs& cg) {
   const int ntab = npat * LT;
-  if (cline > 0) {   // chain + line exchange: nw waves per block, lines of `cline` rows; m = ALL columns, one launch for the passes
+  if (cline > 0) {   // chain + line exchange: nw waves per block, lines of `cline` rows
     if (LT < 5) return -1;
     const long nlines = (nrows + cline - 1) / cline, ntl = (nlines + nw - 1) / nw * (cline / 8);
-#define GCGE_C2(NWV) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), MODE, NWV, VALS>), dim3((unsigned)nb, (unsigned)((m + 15) / 16)), dim3(64 * NWV), \
+#define GCGE_C2(NWV) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), MODE, NWV, VALS>), dim3((unsigned)nb), dim3(64 * NWV), \
                        (size_t)ntab * sizeof(PatEntry), st, nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, ntl, cline, partial, yy_off, g_chain2_xcd, cg)
     if (nw == 16) GCGE_C2(16); else if (nw == 8) GCGE_C2(8); else GCGE_C2(4);
 #undef GCGE_C2
@@ -705,11 +690,17 @@ extern "C" int gcge_hip_pattern_spmm_vals(int nrows, const unsigned short* d_pid
     hipStream_t stc = (hipStream_t)stream;
     double* partc = d_dots ? gcge_hip_partial_ws((size_t)nbc * 16 * npassc * 2) : nullptr;
     const long yyc = (long)nbc * 16 * npassc;
-    const bool ring = near > 0 && lt == 7 && d_x != d_y && d_rowval == nullptr;
-    // all 16-column passes in one launch (grid.y); the LDS-ring sweep where it applies, else the chain2 kernel
-    if (!(ring && gcge_hip_ring_pass(d_dots ? 1 : 0, nrows, d_pid, d_tab, npat, L, nw, nbc, d_x, ldx, ncols, partc, yyc, nullptr, stc, near, d_y, ldy) == 0)) {
-      const long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, partc, yyc, nbc, 8, stc, L, nw, cgv)
-                              : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, nullptr, 0, nbc, 8, stc, L, nw, cgv);
+    bool ring = near > 0 && lt == 7 && d_x != d_y && d_rowval == nullptr;
+    for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
+      const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
+      double* pp = partc ? partc + (size_t)ps * nbc * 16 : nullptr;
+      if (ring) {
+        if (gcge_hip_ring_pass(d_dots ? 1 : 0, nrows, d_pid, d_tab, npat, L, nw, nbc, d_x + c0, ldx, m, pp, yyc, nullptr, stc, near,
+                               d_y + c0, ldy) == 0) continue;
+        ring = false;   // declined (first pass): the chain2 kernel below
+      }
+      long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyc, nbc, 8, stc, L, nw, cgv)
+                        : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nbc, 8, stc, L, nw, cgv);
       if (rcl < 0) return -1;
     }
     if (d_dots) gcge_hip_reduce_partials16(partc, (int)nbc, nbc * 16, ncols, d_dots, stc);
@@ -806,16 +797,15 @@ extern "C" int gcge_hip_pattern_cg_vals(int mode, int nrows, const unsigned shor
   double* part = gcge_hip_partial_ws((size_t)nb * 16 * npass * 2);
   const long yyo = (long)nb * 16 * npass;
   // read-only passes on a [-S, 0, +S, -L, +L, -1, +1] table: the LDS-ring sweep (spmm_ring.hip), same geometry and workspace
-  const bool ring = near && lt == 7 && nw >= 4 && (mode == 2 || mode == 4) && d_rowval == nullptr;
-  // chain + line-exchange tables: all 16-column passes in ONE launch (grid.y = passes; the LDS-ring sweep for the read-only
-  // modes where it applies); other tables: one launch of the plain kernel per pass
-  const int step = nw > 0 ? ncols : 16;
-  for (int c0 = 0, ps = 0; c0 < ncols; c0 += step, ++ps) {
-    const int m = (ncols - c0 < step) ? ncols - c0 : step;
+  bool ring = near && lt == 7 && nw >= 4 && (mode == 2 || mode == 4) && d_rowval == nullptr;
+  for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
+    const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
     double* pp = part + (size_t)ps * nb * 16;
     long rc;
-    if (ring && nw > 0 &&
-        gcge_hip_ring_pass(mode, nrows, d_pid, d_tab, npat, L, nw, nb, d_x + c0, ldx, m, pp, yyo, mode == 4 ? d_alpha + c0 : nullptr, st, near, nullptr, 0) == 0) continue;
+    if (ring) {
+      if (gcge_hip_ring_pass(mode, nrows, d_pid, d_tab, npat, L, nw, nb, d_x + c0, ldx, m, pp, yyo, mode == 4 ? d_alpha + c0 : nullptr, st, near, nullptr, 0) == 0) continue;
+      ring = false;   // declined (first pass): the chain2 kernel below
+    }
     if (mode == 2) { CgArgs cg = CgArgs{}; cg.rowval = d_rowval; rc = pat_dispatch<2>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg); }
     else if (mode == 4) {
       const CgArgs cg = {nullptr, 0, nullptr, 0, d_alpha + c0, nullptr, nullptr, nullptr, 0, d_rowval};

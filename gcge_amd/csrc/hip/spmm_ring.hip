@@ -270,15 +270,9 @@ __device__ __forceinline__ void ring_body(
 template <int MODE, int NW, int DP, bool WIDE>
 __global__ __launch_bounds__(64 * NW) void spmm_ring_kernel(
     long nrows, const unsigned short* __restrict__ pid, const PatEntry* __restrict__ tab, int ntab,
-    const double* __restrict__ x, size_t ldx, int mtot, int ntiles, long line, long step_rows, int xcd_runs,
+    const double* __restrict__ x, size_t ldx, int m, int ntiles, long line, long step_rows, int xcd_runs,
     double* __restrict__ dot_partial, long yy_offset, const double* __restrict__ lambda, double* __restrict__ y, size_t ldy) {
   static_assert(MODE == 0 || MODE == 1 || MODE == 2 || MODE == 4, "product (with sums) and the passes that store nothing");
-  // gridDim.y = the 16-column passes of one block operation in ONE launch (as spmm_pattern_chain2_kernel)
-  x += 16 * blockIdx.y;
-  if (y != nullptr) y += 16 * blockIdx.y;
-  if (lambda != nullptr) lambda += 16 * blockIdx.y;
-  if (dot_partial != nullptr) dot_partial += (size_t)blockIdx.y * gridDim.x * 16;
-  const int m = min(16, mtot - 16 * (int)blockIdx.y);
   constexpr int R = DP + 3;
   constexpr unsigned PB = Plane<NW>::PB;
   extern __shared__ __align__(16) unsigned char smem_raw[];   // ONE LDS object: ring | table | coefficients | reduction
@@ -365,7 +359,7 @@ static int ring_launch(long nb, hipStream_t st, long nrows, const unsigned short
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return -1; }
     granted = lds;
   }
-  hipLaunchKernelGGL((spmm_ring_kernel<MODE, NW, DP, WIDE>), dim3((unsigned)nb, (unsigned)((m + 15) / 16)), dim3(64 * NW), lds, st, nrows, pid,
+  hipLaunchKernelGGL((spmm_ring_kernel<MODE, NW, DP, WIDE>), dim3((unsigned)nb), dim3(64 * NW), lds, st, nrows, pid,
                      (const PatEntry*)tab, ntab, x, ldx, m, (int)ntl, line, step_rows, g_ring_xcd, part, yyo, lambda, y, ldy);
   return 0;
 }
@@ -394,7 +388,7 @@ static int ring_pass_nw(int mode, long nb, hipStream_t st, long nrows, const uns
   return -1;
 }
 
-// The 16-column passes of an m-column operation (ONE launch, grid.y = passes) of the ring sweep on a [-S, 0, +S, -L, +L, -1, +1] table; same geometry (nb blocks of nw waves,
+// One 16-column launch of the ring sweep on a [-S, 0, +S, -L, +L, -1, +1] table; same geometry (nb blocks of nw waves,
 // lines of L rows) and the same partial-sum workspace as the chain2 kernel.  mode 2 / 4: the passes that store nothing
 // (gcge_hip_pattern_cg); mode 0 / 1: Y = A X (with the column sums) — only when every slice of the sweep lies inside the
 // matrix (the counted waits rely on one store per wave and iteration).  -1: not applicable, the caller goes on.
@@ -419,6 +413,6 @@ extern "C" int gcge_hip_ring_pass(int mode, int nrows, const unsigned short* d_p
   else if (nw == 8) rc = GCGE_RING_NW(8);
   else if (nw == 4) rc = GCGE_RING_NW(4);
 #undef GCGE_RING_NW
-  if (rc == 0) g_ring_launches += (m + 15) / 16;   // (counted in 16-column passes)
+  if (rc == 0) ++g_ring_launches;
   return rc;
 }
