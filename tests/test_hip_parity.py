@@ -1413,7 +1413,7 @@ def test_mgs_step_fusion_equals_separate_kernels(both):
     A, _ = make_problem("lap3d", 11)
     n = A.nrows
     V0 = uniform(41, (n, 40)) - 0.5
-    V0[:, 9] = V0[:, 8] * 2.0 + 1e-3 * V0[:, 10]          # a column that loses three digits in the projection
+    V0[:, 9] = V0[:, 8] * 2.0 + 1e-3 * (uniform(43, (n,)) - 0.5)   # a column that loses three digits in the projection
 
     def mgs(be, mat, fuse):
         """OrthSelf on columns [5, 29) of a 40-column block, call for call as the reference issues it."""
