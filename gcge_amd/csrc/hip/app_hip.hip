@@ -149,8 +149,10 @@ extern "C" int gcge_hip_slot_timing_report(char* buf, int len) {
 // scaling of x_k, a rank-1 update of the columns behind it — three strided sweeps over the panel.  The back-end fuses them
 // WITHOUT changing what is computed: the scaling is held back until the next call; if that call is the rank-1 update from
 // that very column, one kernel scales x_k, updates the panel and accumulates the Gram column of x_{k+1} that the next
-// QtAP will ask for (same operands, same products — only the order of the row sum differs).  Anything else flushes the
-// held-back scaling first.  The speculative Gram column is served only to the IMMEDIATELY following data call (epoch
+// QtAP will ask for — same operands, same products, and the SAME order of the row sums as the separate kernel
+// (vec_kernels.hip: mgs_step_kernel mirrors panel_dot1_partial), so the fused path is bit-identical to the unfused one; a
+// Gram column that differs in the last bit is enough to change which noise-level columns a degenerate block drops.
+// Anything else flushes the held-back scaling first.  The speculative Gram column is served only to the IMMEDIATELY following data call (epoch
 // check) on the same block and column range; every entry point that touches block data goes through enter().
 static unsigned long g_epoch = 0;
 static struct { GcgeHipMV* mv; int col; double fac; } g_pend = {nullptr, 0, 1.0};

@@ -347,13 +347,17 @@ __global__ __launch_bounds__(256) void colscale1_kernel(long nrows, double* __re
 template <int UNR>
 __global__ __launch_bounds__(256) void mgs_step_kernel(long nrows, double* __restrict__ base, long ld, double s,
     const double* __restrict__ c, int w, double* __restrict__ partial, long rows_per_block, int tpc) {
+  // same decomposition, same UNR accumulators and the same reduction tree as panel_dot1_partial: the Gram column this kernel
+  // leaves is BIT-IDENTICAL to the one the separate kernel would compute from the updated panel
   __shared__ double red[256];
   const int tx = threadIdx.x % tpc, ty = threadIdx.x / tpc, rpi = 256 / tpc;
   const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
   const bool mine = tx < w;
   const int j = mine ? tx : 0;
   const double cj = c[j], c0 = c[0];
-  double acc = 0.0;
+  double acc[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) acc[u] = 0.0;
   long r = r0 + ty;
   for (; r + (long)(UNR - 1) * rpi < r1; r += (long)UNR * rpi) {
     double xk[UNR], y0[UNR], yj[UNR];
@@ -368,16 +372,21 @@ __global__ __launch_bounds__(256) void mgs_step_kernel(long nrows, double* __res
       const double q = xk[u] * s;
       const double y0n = fma(q, c0, y0[u]), yjn = fma(q, cj, yj[u]);
       if (tx == 0) row[0] = q;
-      if (mine) { row[1 + j] = yjn; acc = fma(yjn, y0n, acc); }
+      if (mine) row[1 + j] = yjn;
+      acc[u] = fma(yjn, y0n, acc[u]);
     }
   }
   for (; r < r1; r += rpi) {
     double* row = base + r * ld;
     const double q = row[0] * s, y0n = fma(q, c0, row[1]), yjn = fma(q, cj, row[1 + j]);
     if (tx == 0) row[0] = q;
-    if (mine) { row[1 + j] = yjn; acc = fma(yjn, y0n, acc); }
+    if (mine) row[1 + j] = yjn;
+    acc[0] = fma(yjn, y0n, acc[0]);
   }
-  red[threadIdx.x] = acc;
+  double t = 0.0;
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) t += acc[u];
+  red[threadIdx.x] = t;
   __syncthreads();
   for (int h = rpi / 2; h > 0; h >>= 1) {
     if (ty < h) red[threadIdx.x] += red[threadIdx.x + h * tpc];
@@ -387,17 +396,22 @@ __global__ __launch_bounds__(256) void mgs_step_kernel(long nrows, double* __res
 }
 
 static int pow2_at_least(int v, int cap) { int t = 1; while (t < v && t < cap) t *= 2; return t; }
+// row slabs of the panel kernels: blocks of `rpb` rows (a multiple of the rpi rows a block walks per step), at most 2048 blocks
+static void panel_geometry(int nrows, int rpi, long* nb_out, long* rpb_out) {
+  long nb = ((long)nrows + 4L * rpi * 4 - 1) / (4L * rpi * 4);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  const long rpb = (((long)nrows + nb - 1) / nb + rpi - 1) / rpi * rpi;
+  *nb_out = ((long)nrows + rpb - 1) / rpb; *rpb_out = rpb;
+}
 // d_out[i] = sum_r X[r, i] y[r], i < k: X = d_x (leading dimension ldx), y = d_y with stride ldy
 extern "C" int gcge_hip_panel_dot1(int nrows, const double* d_x, long ldx, int k, const double* d_y, long ldy, double* d_out, void* stream) {
   if (k <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (nrows <= 0) return (int)hipMemsetAsync(d_out, 0, k * sizeof(double), st);
   const int tpc = pow2_at_least(k, 64), rpi = 256 / tpc;
-  long nb = ((long)nrows + 4L * rpi * 8 - 1) / (4L * rpi * 8);
-  if (nb > 2048) nb = 2048;
-  if (nb < 1) nb = 1;
-  const long rpb = (((long)nrows + nb - 1) / nb + rpi - 1) / rpi * rpi;
-  nb = ((long)nrows + rpb - 1) / rpb;
+  long nb, rpb;
+  panel_geometry(nrows, rpi, &nb, &rpb);
   double* part = gcge_hip_partial_ws((size_t)nb * k);
   hipLaunchKernelGGL(panel_dot1_partial<4>, dim3((unsigned)nb), dim3(256), 0, st, (long)nrows, d_x, ldx, d_y, ldy, k, part, rpb, tpc);
   hipLaunchKernelGGL(reduce_partials, dim3((k + 63) / 64), dim3(1024), 0, st, part, (int)nb, k, d_out);
@@ -422,11 +436,8 @@ extern "C" int gcge_hip_mgs_step(int nrows, double* d_xk, long ld, double s, con
   hipStream_t st = (hipStream_t)stream;
   if (nrows <= 0) return (int)hipMemsetAsync(d_dots, 0, w * sizeof(double), st);
   const int tpc = pow2_at_least(w, 64), rpi = 256 / tpc;
-  long nb = ((long)nrows + 4L * rpi * 4 - 1) / (4L * rpi * 4);
-  if (nb > 2048) nb = 2048;
-  if (nb < 1) nb = 1;
-  const long rpb = (((long)nrows + nb - 1) / nb + rpi - 1) / rpi * rpi;
-  nb = ((long)nrows + rpb - 1) / rpb;
+  long nb, rpb;
+  panel_geometry(nrows, rpi, &nb, &rpb);      // the SAME slabs as gcge_hip_panel_dot1 would take for these w columns
   double* part = gcge_hip_partial_ws((size_t)nb * w);
   hipLaunchKernelGGL(mgs_step_kernel<4>, dim3((unsigned)nb), dim3(256), 0, st, (long)nrows, d_xk, ld, s, d_c, w, part, rpb, tpc);
   hipLaunchKernelGGL(reduce_partials, dim3(1), dim3(1024), 0, st, part, (int)nb, w, d_dots);

@@ -1442,9 +1442,9 @@ def test_mgs_step_fusion_equals_separate_kernels(both):
         f2 = C.c_long(); g.gcge_hip_mgs_fusion_stats(C.byref(f2), None)
         assert f2.value == f1.value
         ref = mgs(ora, mo, 0)
-        # (the three digits lost in column 9 amplify the rounding of the dot products — whose row sums run in different
-        #  orders in the three implementations — by 1e3)
-        _close(fused, plain, tol=1e-10, what="fused Gram-Schmidt steps vs separate kernels")
+        # bit for bit: the fused sweep multiplies the same operands and sums the rows in the same order as the separate kernels
+        assert np.array_equal(fused, plain), "fused Gram-Schmidt steps differ from the separate kernels: %.3e" % np.max(np.abs(fused - plain))
+        # (the three digits lost in column 9 amplify the rounding of the dot products — summed in another order on the CPU — by 1e3)
         _close(fused, ref, tol=1e-10, what="fused Gram-Schmidt steps vs oracle")
         Q = fused[:, 5:29]
         assert np.max(np.abs(Q.T @ Q - np.eye(24))) < 1e-9
