@@ -9,9 +9,9 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
            "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/tile_probe.py $G $K $M > $OUT/log$i.txt 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/$PROBE $ARGS > $OUT/log$i.txt 2>&1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tools/tile_probe.py $G $K $M > $OUT/log_trace.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/$PROBE $ARGS > $OUT/log_trace.txt 2>&1
 python3 - "$OUT" <<'PY'
 import csv,glob,sys,collections
 out=sys.argv[1]; acc=collections.defaultdict(list)
@@ -21,11 +21,13 @@ for f in glob.glob(out+'/p*/**/*counter_collection.csv',recursive=True):
         if 'spmm_tile_kernel' in k: tag='tile'
         elif 'spmm_pad8' in k: tag='pad8'
         elif 'spmm_dense' in k: tag='dense'
+        elif 'spmm_pattern_chain2' in k: tag='chain2' + ('+values' if 'true>' in k.replace(' ', '') else '')
+        elif 'spmm_pattern' in k: tag='pattern'
         else: continue
         acc[(tag,r['Counter_Name'])].append(float(r['Counter_Value']))
 with open(out+'/summary.txt','w') as fo:
     for c,v in sorted(acc.items()):
-        line="%-5s %-34s per-launch mean=%.6g launches=%d"%(c[0],c[1],sum(v)/len(v),len(v))
+        line="%-14s %-34s per-launch mean=%.6g launches=%d"%(c[0],c[1],sum(v)/len(v),len(v))
         print(line); fo.write(line+"\n")
     for f in glob.glob(out+'/trace/**/*kernel_stats.csv',recursive=True):
         for r in csv.DictReader(open(f)):
