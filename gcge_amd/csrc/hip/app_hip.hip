@@ -33,6 +33,9 @@ int gcge_hip_spmm_tile_mode_get(void);
 void* gcge_hip_dense_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val);
 void gcge_hip_dense_free(void* dm);
 int gcge_hip_dense_remainder_is_tiled(const void* dm);
+const void* gcge_hip_dense_remainder_tile(const void* dm);
+void gcge_hip_dense_stats(const void* dm, long* nblocks, long* items, long* dense_nnz, long* dense_entries, long* rem_nnz);
+void gcge_hip_tile_stats(const void* tm, long* ntiles, long* ov_nnz, double* xrows_per_row, double* ell_per_nnz, int* brick, long* strides);
 int gcge_hip_dense_spmm(const void* dm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream, int which);
 int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
 int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2, const double* d_x, long ldx,
@@ -544,6 +547,23 @@ extern "C" const char* gcge_hip_mat_spmm_form(const GCGE_HIP_MAT* A) {
   if (A->dense != nullptr && g_spmm_path != 1 && g_spmm_path != 3 && g_spmm_path != 4) return gcge_hip_dense_remainder_is_tiled(A->dense) ? "spmm_dense+spmm_tile" : "spmm_dense+spmm_pad8";
   if (A->tile != nullptr && g_spmm_path != 1 && g_spmm_path != 3) return "spmm_tile";
   return "spmm_pad8";
+}
+
+// what the upload made of a matrix without a pattern form (measurement aid): out[0..4] = dense blocks, row blocks of 32, non-zeros
+// in blocks, stored block entries, remainder non-zeros; out[5..11] = tiles of the remainder (0: pad-8), X rows staged per matrix
+// row, ELL entries per non-zero, overflow entries, brick dimensions.  0: the matrix has no block form.
+extern "C" int gcge_hip_mat_form_stats(const GCGE_HIP_MAT* A, double* out) {
+  for (int i = 0; i < 12; ++i) out[i] = 0.0;
+  if (A->dense == nullptr) return 0;
+  long nb = 0, items = 0, dn = 0, de = 0, rn = 0;
+  gcge_hip_dense_stats(A->dense, &nb, &items, &dn, &de, &rn);
+  out[0] = (double)nb; out[1] = (double)items; out[2] = (double)dn; out[3] = (double)de; out[4] = (double)rn;
+  if (const void* T = gcge_hip_dense_remainder_tile(A->dense)) {
+    long nt = 0, ov = 0; double xr = 0, el = 0; int brick[3] = {0, 0, 0}; long strides[2];
+    gcge_hip_tile_stats(T, &nt, &ov, &xr, &el, brick, strides);
+    out[5] = (double)nt; out[6] = xr; out[7] = el; out[8] = (double)ov; out[9] = brick[0]; out[10] = brick[1]; out[11] = brick[2];
+  }
+  return 1;
 }
 
 // ------------------------------------------------------------------ device buffer pool

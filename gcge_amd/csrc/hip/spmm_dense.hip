@@ -319,6 +319,7 @@ extern "C" void* gcge_hip_dense_build(int nrows, int ncols_local, const int* row
 }
 
 extern "C" int gcge_hip_dense_remainder_is_tiled(const void* dm) { return ((const DenseMat*)dm)->rem_tile != nullptr; }
+extern "C" const void* gcge_hip_dense_remainder_tile(const void* dm) { return ((const DenseMat*)dm)->rem_tile; }
 extern "C" void gcge_hip_dense_stats(const void* dm, long* nblocks, long* items, long* dense_nnz, long* dense_entries, long* rem_nnz) {
   const DenseMat* D = (const DenseMat*)dm;
   if (nblocks) *nblocks = D->nsn;

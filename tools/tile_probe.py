@@ -27,6 +27,14 @@ t1 = time.time()
 mA = hip.matrix(A)
 t2 = time.time()
 print("n", A.nrows, "nnz", A.nnz, "gen %.1f s upload %.1f s" % (t1 - t0, t2 - t1), "form", g.gcge_hip_mat_spmm_form(mA).decode(), flush=True)
+g.gcge_hip_mat_form_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+st = (C.c_double * 12)()
+if g.gcge_hip_mat_form_stats(mA, st):
+    print("dense blocks %d (%d row blocks of 32), non-zeros in blocks %d = %.1f %% of the matrix, stored entries %d (fill %.1f %%), remainder %d non-zeros;"
+          % (st[0], st[1], st[2], 100.0 * st[2] / A.nnz, st[3], 100.0 * st[2] / max(st[3], 1), st[4]), flush=True)
+    if st[5] > 0:
+        print("remainder tiles %d, X rows staged per matrix row %.2f, ELL entries per non-zero %.3f, overflow entries %d, brick %dx%dx%d"
+              % (st[5], st[6], st[7], st[8], st[9], st[10], st[11]), flush=True)
 hip.set_random_mode(1, 7)
 ops = hip.ops
 V = ops.mv_create(2 * m, mA); ops.set_random(V, 0, 2 * m)
