@@ -1282,7 +1282,18 @@ def test_device_eigensolver_serves_the_hip_table_only(both):
     assert g.gcge_hip_symeig_calls() == before, "the oracle's projected eigenproblems went to the device"
     hip.set_random_mode(0)
     ev_h, res_h = gcg_on(hip, c["kind"], c["size"], args)
-    assert g.gcge_hip_symeig_calls() > before
+    after = g.gcge_hip_symeig_calls()
+    assert after > before
+    import os
+    os.environ["GCGE_EIG_HOST"] = "1"              # the HIP table with the projected eigenproblem kept on the host
+    try:
+        hip.set_random_mode(0)
+        ev_h2, res_h2 = gcg_on(hip, c["kind"], c["size"], args)
+    finally:
+        os.environ.pop("GCGE_EIG_HOST", None)
+    assert g.gcge_hip_symeig_calls() == after
+    k2 = min(res_h.nevConv, res_h2.nevConv)
+    assert np.max(np.abs(ev_h[:k2] - ev_h2[:k2]) / np.abs(ev_h[:k2])) < 1e-10
     k = min(res_o.nevConv, res_h.nevConv)
     assert k >= c["nev"] and np.max(np.abs(ev_h[:k] - ev_o[:k]) / np.abs(ev_o[:k])) < 1e-10
 

@@ -23,3 +23,16 @@ def test_cholesky_qr_tracks_block_mgs(oracle, kind, size, nev, blk):
     assert ca >= nev and cb >= nev, (ca, cb)
     assert abs(ia - ib) <= max(3, ia // 5), (ia, ib)
     assert np.max(np.abs(ea - eb) / np.abs(ea)) < 1e-9
+
+
+def test_cholesky_qr_with_the_reference_absolute_reorth_test(oracle, monkeypatch):
+    """GCGE_ORTH_ABSOLUTE_TEST=1: the "chol" scheme decides about a further projection pass by the reference's absolute test
+    (|c| < reorth_tol, src/ops_orth.c:315-323) instead of relative to the columns: more passes, the same converged pairs."""
+    args = ["-nevConv", 12, "-gcge_initX_orth_method", "chol", "-gcge_compW_orth_method", "chol"]
+    ev_rel, res_rel = gcg_on(oracle, "lap3d", 12, args)
+    monkeypatch.setenv("GCGE_ORTH_ABSOLUTE_TEST", "1")
+    ev_abs, res_abs = gcg_on(oracle, "lap3d", 12, args)
+    assert res_rel.nevConv >= 12 and res_abs.nevConv >= 12
+    assert abs(res_rel.numIter - res_abs.numIter) <= 2
+    k = min(res_rel.nevConv, res_abs.nevConv)
+    assert np.max(np.abs(ev_rel[:k] - ev_abs[:k]) / np.abs(ev_abs[:k])) < 1e-10
