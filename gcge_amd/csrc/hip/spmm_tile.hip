@@ -43,8 +43,6 @@ struct TileMat {
   int ntiles; long nsteps, nnz, nucols; int nrows, bx, by, bz; long sy, sz;   // sy == 0: runs of consecutive rows
   TileHdr* d_th; int* d_rows; int* d_ucols; double* d_steps;
   int nov; long ov_nnz; int* d_ov_rows; int* d_ov_ptr; int* d_ov_col; double* d_ov_val;   // overflow: entries beyond TILE_MAXW per row
-  // teams: 32 neighbouring bricks (2 x 4 x 4) that one XCD's 32 CUs work on at the same time
-  int nteams; int* d_slot_first; int* d_slot_cnt; int* d_team_rounds; unsigned* d_bar;
 };
 
 // One workgroup (8 waves) per tile; wave w: slice w & 3, half w >> 2 of the slice's ELL steps.
@@ -56,13 +54,22 @@ struct TileMat {
 //   * LDS image: position p, column pair c (0..3) at p*4 + (c ^ ((p >> 2) & 1)) (16-byte units): the 16 lanes a
 //     ds_read_b128 serves together hold 8 rows x 2 halves and hit 16 different bank quads when the rows read
 //     neighbouring positions (stencil rows) or the same one.
-// One pass sequence over one tile (see the kernel below for the roles of the waves)
 template <int MAXH>
-__device__ __forceinline__ void tile_passes(const TileHdr* __restrict__ T, const int* __restrict__ rows, const int* __restrict__ ucols,
-    const double* __restrict__ steps, const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols,
-    v2d* xt, v2d* yt) {
+__global__ __launch_bounds__(512) void spmm_tile_kernel(
+    const TileHdr* __restrict__ th, const int* __restrict__ rows, const int* __restrict__ ucols,
+    const double* __restrict__ steps, const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy,
+    int ncols, int ntiles) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  v2d* xt = reinterpret_cast<v2d*>(smem_raw);        // 2 buffers x TILE_CAP positions x 4 column pairs
+  v2d* yt = xt + (size_t)2 * TILE_CAP * 4;           // TILE_ROWS rows x 4 column pairs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row32 = lane >> 1, h = lane & 1, slice = wave & 3, kh = wave >> 2;
+  // blocks are dealt round-robin to the 8 XCDs: every XCD walks one contiguous eighth of the tiles, so bricks that
+  // share halo rows run on the same L2 at about the same time
+  const int per = (ntiles + 7) >> 3;
+  const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (tile >= ntiles) return;
+  const TileHdr* __restrict__ T = th + tile;
   const int nu = T->nu, nr = T->nrows;
   // ---- my share of the slice's steps, into registers
   double sval[MAXH]; unsigned spos[MAXH];
@@ -143,53 +150,6 @@ __device__ __forceinline__ void tile_passes(const TileHdr* __restrict__ T, const
   }
 }
 
-// Persistent launch: 8 * TEAM workgroups (8 waves each, one per CU).  Workgroup b belongs to XCD b & 7 (blocks are dealt
-// round-robin to the XCDs) and holds slot b >> 3 of that XCD's team; a team walks the TEAMS of bricks assigned to its XCD —
-// 32 neighbouring bricks (2 x 4 x 4) — all slots starting a round together (a counter in global memory, polled by one
-// lane; nothing but TIMING depends on it, and the poll gives up after a while, so a missing team mate costs time, never
-// a hang): the bricks of a round share 60 % of the X rows they stage, and started together they find them in the XCD's L2
-// instead of fetching them over the fabric once per brick.
-//   wave w of a workgroup: slice w & 3, half w >> 2 of the slice's ELL steps;
-//   * the (value, position) steps of a wave — at most MAXH = TILE_MAXW / 2 — are loaded ONCE and stay in registers for
-//     all passes: the matrix is read once per product whatever the block width;
-//   * a pass covers 8 columns; the X rows of pass p + 1 are requested into registers before pass p is computed from one
-//     LDS buffer and written into the other buffer afterwards;
-//   * LDS image: position p, column pair c (0..3) at p*4 + (c ^ ((p >> 2) & 1)) (16-byte units): the 16 lanes a
-//     ds_read_b128 serves together hold 8 rows x 2 halves and hit 16 different bank quads when the rows read
-//     neighbouring positions (stencil rows) or the same one.
-template <int MAXH>
-__global__ __launch_bounds__(512) void spmm_tile_kernel(
-    const TileHdr* __restrict__ th, const int* __restrict__ rows, const int* __restrict__ ucols,
-    const double* __restrict__ steps, const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy,
-    int ncols, int nteams, const int* __restrict__ slot_first, const int* __restrict__ slot_cnt,
-    const int* __restrict__ team_rounds, unsigned* __restrict__ bar, int sync_rounds) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  v2d* xt = reinterpret_cast<v2d*>(smem_raw);        // 2 buffers x TILE_CAP positions x 4 column pairs
-  v2d* yt = xt + (size_t)2 * TILE_CAP * 4;           // TILE_ROWS rows x 4 column pairs
-  const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3), team_size = (int)(gridDim.x >> 3);
-  unsigned arrivals = 0;                              // rounds this XCD's team has started so far
-  for (int team = xcd; team < nteams; team += 8) {
-    const int rounds = team_rounds[team];
-    const int first = slot < 32 ? slot_first[team * 32 + slot] : 0, mine = slot < 32 ? slot_cnt[team * 32 + slot] : 0;
-    for (int rd = 0; rd < rounds; ++rd) {
-      if (sync_rounds) {
-        ++arrivals;
-        if (threadIdx.x == 0) {
-          unsigned* c = bar + 32 * xcd;               // one counter per XCD, each on a line of its own
-          __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned target = arrivals * (unsigned)team_size;
-          for (int spin = 0; spin < (1 << 16); ++spin) {
-            if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-            __builtin_amdgcn_s_sleep(8);
-          }
-        }
-        __syncthreads();
-      }
-      if (rd < mine) tile_passes<MAXH>(th + first + rd, rows, ucols, steps, x, ldx, y, ldy, ncols, xt, yt);
-    }
-  }
-}
-
 // Y[row] += (entries a row has beyond TILE_MAXW steps) X: one wave per such row, a lane per column
 __global__ __launch_bounds__(256) void spmm_tile_overflow_kernel(int nov, const int* __restrict__ ov_rows, const int* __restrict__ ov_ptr,
     const int* __restrict__ ov_col, const double* __restrict__ ov_val, const double* __restrict__ x, size_t ldx,
@@ -206,9 +166,8 @@ __global__ __launch_bounds__(256) void spmm_tile_overflow_kernel(int nov, const 
 }
 
 // ---------------------------------------------------------------------------------------------- upload-time builder
-struct TileOut {   // what one builder thread produced for its range of bricks
+struct TileOut {   // what one builder thread produced for its range of tiles
   std::vector<TileHdr> th; std::vector<int> rows, ucols; std::vector<double> steps;
-  std::vector<int> brick_tiles;   // tiles each brick of the range became (1 unless its union had to be split)
   std::vector<int> ov_rows, ov_ptr, ov_col; std::vector<double> ov_val;
 };
 
@@ -292,11 +251,8 @@ static void build_range(int t0, int t1, const std::vector<int>& trow_off, const 
   TileScratch S;
   S.stamp.assign((size_t)ncols_local, 0); S.lid.assign((size_t)ncols_local, 0);
   int stamp_id = 0;
-  for (int t = t0; t < t1; ++t) {
-    const size_t before = out->th.size();
+  for (int t = t0; t < t1; ++t)
     build_tile(trows.data() + trow_off[t], trow_off[t + 1] - trow_off[t], S, stamp_id, rowptr, colidx, val, out);
-    out->brick_tiles.push_back((int)(out->th.size() - before));
-  }
 }
 
 }  // namespace gcge
@@ -306,15 +262,12 @@ using namespace gcge;
 static int g_tile_mode = 0;   // 0 automatic (remainders of the block form that qualify), 1 every matrix without a pattern form, 2 every matrix (tests: next to a pattern form), -1 never
 extern "C" void gcge_hip_spmm_tile_mode(int mode) { g_tile_mode = mode; }
 extern "C" int gcge_hip_spmm_tile_mode_get(void) { return g_tile_mode; }
-static int g_tile_sync = 1;    // 1: the slots of a team start every round together (measurements: 0 lets them drift)
-extern "C" void gcge_hip_spmm_tile_sync(int on) { g_tile_sync = on; }
 
 extern "C" void gcge_hip_tile_free(void* tm) {
   TileMat* T = (TileMat*)tm;
   if (!T) return;
   hipFree(T->d_th); hipFree(T->d_rows); hipFree(T->d_ucols); hipFree(T->d_steps);
   hipFree(T->d_ov_rows); hipFree(T->d_ov_ptr); hipFree(T->d_ov_col); hipFree(T->d_ov_val);
-  hipFree(T->d_slot_first); hipFree(T->d_slot_cnt); hipFree(T->d_team_rounds); hipFree(T->d_bar);
   delete T;
 }
 
@@ -322,7 +275,6 @@ extern "C" void gcge_hip_tile_free(void* tm) {
 struct TileHost {
   std::vector<TileHdr> th; std::vector<int> rows, ucols; std::vector<double> steps;
   std::vector<int> ov_rows, ov_ptr, ov_col; std::vector<double> ov_val;
-  std::vector<int> slot_first, slot_cnt, team_rounds;   // teams of 32 slots: tile range of every slot, rounds of every team
   int bx = 0, by = 0, bz = 0; long sy = 0, sz = 0;
 };
 static bool tile_build_host(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, TileHost* H) {
@@ -333,16 +285,9 @@ static bool tile_build_host(int nrows, int ncols_local, const int* rowptr, const
   if (grid) { if (sz > 0) { bx = 8; by = 4; bz = 4; } else { bx = 16; by = 8; bz = 1; sz = (long)nrows + sy; } }
   // tiles: bricks in grid order (x fastest), rows of a brick in natural order
   std::vector<int> trow_off, trows;
-  std::vector<long> brick_team; std::vector<int> brick_slot;   // which team (2 x 4 x 4 bricks; runs of 32 without a grid) and slot
-  long nteams = 0;
   trows.reserve((size_t)nrows);
   if (!grid) {
-    for (int r0 = 0; r0 < nrows; r0 += TILE_ROWS) {
-      const long t = (long)trow_off.size();
-      brick_team.push_back(t / 32); brick_slot.push_back((int)(t % 32));
-      trow_off.push_back((int)trows.size()); for (int r = r0; r < std::min(nrows, r0 + TILE_ROWS); ++r) trows.push_back(r);
-    }
-    nteams = ((long)trow_off.size() + 31) / 32;
+    for (int r0 = 0; r0 < nrows; r0 += TILE_ROWS) { trow_off.push_back((int)trows.size()); for (int r = r0; r < std::min(nrows, r0 + TILE_ROWS); ++r) trows.push_back(r); }
   } else {
     const long nx = sy, ny = sz / sy, nz = ((long)nrows + sz - 1) / sz;
     // brick order: x fastest (y- or z-fastest orders measured the same: 5.86 / 5.83 / 5.75 ms on the SiO2-like matrix —
@@ -354,14 +299,8 @@ static bool tile_build_host(int nrows, int ncols_local, const int* rowptr, const
       const size_t before = trows.size();
       for (long z = z0; z < std::min(nz, z0 + bz); ++z) for (long yy = y0; yy < std::min(ny, y0 + by); ++yy)
         for (long xx = x0; xx < std::min(nx, x0 + bx); ++xx) { const long r = xx + sy * yy + sz * z; if (r < nrows) trows.push_back((int)r); }
-      if (trows.size() > before) {
-        trow_off.push_back((int)before);
-        const long tx = (nbx + 1) / 2, ty = (nby + 3) / 4;
-        brick_team.push_back((ix / 2) + tx * ((iy / 4) + ty * (iz / 4)));
-        brick_slot.push_back((int)((ix % 2) + 2 * ((iy % 4) + 4 * (iz % 4))));
-      }
+      if (trows.size() > before) trow_off.push_back((int)before);
     }
-    nteams = ((nbx + 1) / 2) * ((nby + 3) / 4) * ((nbz + 3) / 4);
   }
   const int nbricks = (int)trow_off.size();
   trow_off.push_back((int)trows.size());
@@ -383,18 +322,6 @@ static bool tile_build_host(int nrows, int ncols_local, const int* rowptr, const
   size_t nst = 0, nuc = 0, nov = 0;
   for (auto& o : outs) { nst += o.steps.size(); nuc += o.ucols.size(); nov += o.ov_col.size(); }
   if (nst / STEP_DOUBLES + 1 > 2147483647UL || nuc > 2147483647UL || nov > 2147483647UL) return false;
-  // tiles of every brick (in brick order) -> slots of the teams
-  if (nteams > (1L << 26)) return false;
-  H->slot_first.assign((size_t)nteams * 32, 0); H->slot_cnt.assign((size_t)nteams * 32, 0); H->team_rounds.assign((size_t)nteams, 0);
-  {
-    size_t b = 0; int tile = 0;
-    for (auto& o : outs) for (int nt : o.brick_tiles) {
-      const size_t sl = (size_t)brick_team[b] * 32 + brick_slot[b];
-      H->slot_first[sl] = tile; H->slot_cnt[sl] = nt;
-      H->team_rounds[brick_team[b]] = std::max(H->team_rounds[brick_team[b]], nt);
-      tile += nt; ++b;
-    }
-  }
   for (auto& o : outs) {
     const int o_rows = (int)H->rows.size(), o_uc = (int)H->ucols.size(), o_st = (int)(H->steps.size() / STEP_DOUBLES), o_ov = (int)H->ov_col.size();
     for (auto& t : o.th) { t.row_off += o_rows; t.ucol_off += o_uc; for (int s = 0; s < 4; ++s) t.step_off[s] += o_st; H->th.push_back(t); }
@@ -461,14 +388,6 @@ extern "C" long gcge_hip_tile_selfcheck(int nrows, int ncols_local, const int* r
     }
   }
   for (int r = 0; r < nrows; ++r) if (seen[r] != 1) ++bad;
-  {   // every tile lies in exactly one slot of one team, and no slot holds more tiles than its team has rounds
-    std::vector<int> owner(H.th.size(), 0);
-    for (size_t sl = 0; sl < H.slot_first.size(); ++sl) {
-      if (H.slot_cnt[sl] > H.team_rounds[sl / 32]) ++bad;
-      for (int q = 0; q < H.slot_cnt[sl]; ++q) { const int t = H.slot_first[sl] + q; if (t < 0 || t >= (int)H.th.size()) ++bad; else ++owner[t]; }
-    }
-    for (int o : owner) if (o != 1) ++bad;
-  }
   return bad;
 }
 
@@ -503,9 +422,6 @@ extern "C" void* gcge_hip_tile_build_for(int nrows, int ncols_local, const int* 
   T->nov = (int)H.ov_rows.size(); T->ov_nnz = (long)H.ov_col.size();
   T->d_ov_rows = tile_to_device(H.ov_rows); T->d_ov_ptr = tile_to_device(H.ov_ptr);
   T->d_ov_col = tile_to_device(H.ov_col); T->d_ov_val = tile_to_device(H.ov_val);
-  T->nteams = (int)H.team_rounds.size();
-  T->d_slot_first = tile_to_device(H.slot_first); T->d_slot_cnt = tile_to_device(H.slot_cnt); T->d_team_rounds = tile_to_device(H.team_rounds);
-  GCGE_HIP_CHECK(hipMalloc(&T->d_bar, 8 * 32 * sizeof(unsigned)));
   return T;
 }
 extern "C" void* gcge_hip_tile_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val) {
@@ -537,14 +453,9 @@ extern "C" int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, d
     GCGE_HIP_CHECK(hipFuncSetAttribute((const void*)spmm_tile_kernel<TILE_MAXW / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  // persistent launch: 8 teams of 32 workgroups, one workgroup per CU (its LDS fills the CU), all resident at once
-  static int cus = 0;
-  if (cus == 0) { int dev = 0; hipDeviceProp_t pr; GCGE_HIP_CHECK(hipGetDevice(&dev)); GCGE_HIP_CHECK(hipGetDeviceProperties(&pr, dev)); cus = pr.multiProcessorCount; }
-  const int sync_rounds = (cus >= 256 && g_tile_sync) ? 1 : 0;   // fewer CUs than workgroups: no waiting for team mates that cannot be resident
-  if (sync_rounds) GCGE_HIP_CHECK(hipMemsetAsync(T->d_bar, 0, 8 * 32 * sizeof(unsigned), (hipStream_t)stream));
-  hipLaunchKernelGGL((spmm_tile_kernel<TILE_MAXW / 2>), dim3(256), dim3(512), lds, (hipStream_t)stream, T->d_th, T->d_rows,
-                     T->d_ucols, T->d_steps, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, T->nteams, T->d_slot_first, T->d_slot_cnt,
-                     T->d_team_rounds, T->d_bar, sync_rounds);
+  const int per = (T->ntiles + 7) / 8;
+  hipLaunchKernelGGL((spmm_tile_kernel<TILE_MAXW / 2>), dim3((unsigned)(8 * per)), dim3(512), lds, (hipStream_t)stream, T->d_th, T->d_rows,
+                     T->d_ucols, T->d_steps, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, T->ntiles);
   if (T->nov > 0)
     hipLaunchKernelGGL(spmm_tile_overflow_kernel, dim3((unsigned)((T->nov + 3) / 4)), dim3(256), 0, (hipStream_t)stream, T->nov, T->d_ov_rows,
                        T->d_ov_ptr, T->d_ov_col, T->d_ov_val, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols);

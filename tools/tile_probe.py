@@ -14,8 +14,6 @@ g.gcge_hip_spmm_tile_mode.argtypes = [C.c_int]
 g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
 if os.environ.get("TILE_MODE"):
     g.gcge_hip_spmm_tile_mode(int(os.environ["TILE_MODE"]))      # 1: also keep the tile form (of the remainder when blocks exist)
-if os.environ.get("TILE_SYNC"):
-    g.gcge_hip_spmm_tile_sync(int(os.environ["TILE_SYNC"]))      # 0: the slots of a team do not wait for each other at the start of a round
 if os.environ.get("DENSE_MODE"):
     g.gcge_hip_spmm_dense_mode(int(os.environ["DENSE_MODE"]))    # -1: no supernode blocks
 g.gcge_hip_profile_enable.argtypes = [C.c_int]
