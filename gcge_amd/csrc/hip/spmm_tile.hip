@@ -48,9 +48,9 @@ struct TileMat {
 // One workgroup (8 waves) per tile; wave w: slice w & 3, half w >> 2 of the slice's ELL steps.
 //   * the (value, position) steps of a wave — at most MAXH = TILE_MAXW / 2 — are loaded ONCE and stay in registers for
 //     all passes: the matrix is read once per product whatever the block width;
-//   * a pass covers 8 columns; the X rows of the next TWO passes are in flight in two register sets while a pass is
-//     computed from one LDS buffer (the set that arrived is written into the other buffer afterwards): 144 KB of requests
-//     per CU hide the fabric latency with ONE workgroup per CU (the two X buffers and the Y tile fill the LDS);
+//   * a pass covers 8 columns; the X rows of pass p + 1 are requested into registers before pass p is computed from one
+//     LDS buffer and written into the other buffer afterwards: the staging latency is hidden behind the arithmetic
+//     with ONE workgroup per CU (the two X buffers and the Y tile fill the LDS);
 //   * LDS image: position p, column pair c (0..3) at p*4 + (c ^ ((p >> 2) & 1)) (16-byte units): the 16 lanes a
 //     ds_read_b128 serves together hold 8 rows x 2 halves and hit 16 different bank quads when the rows read
 //     neighbouring positions (stencil rows) or the same one.
@@ -90,20 +90,19 @@ __global__ __launch_bounds__(512) void spmm_tile_kernel(
   // ---- staging: position su + 128 q, 16-byte part si
   const int su = tid >> 2, si = tid & 3;
   constexpr int NQ = (TILE_CAP + 127) / 128;
-  int col[NQ]; v2d svA[NQ], svB[NQ];      // two register sets: the X rows of the next TWO passes are in flight
+  int col[NQ]; v2d sv[NQ];
   {
     const int* __restrict__ uc = ucols + T->ucol_off;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) col[q] = uc[min(su + 128 * q, nu - 1)];
   }
-  const int npass = (ncols + 7) >> 3;
-  auto load_x = [&](v2d (&sv)[NQ], int pass) {     // no branch near the loads: passes beyond the last one re-read the last one
-    const int c = 8 * min(pass, npass - 1) + 2 * si;
+  auto load_x = [&](int pass) {
+    const int c = 8 * pass + 2 * si;
     const double* __restrict__ xs = x + (c < ncols ? c : 0);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) sv[q] = *reinterpret_cast<const v2d*>(xs + (size_t)col[q] * ldx);
   };
-  auto store_x = [&](const v2d (&sv)[NQ], int buf) {
+  auto store_x = [&](int buf) {
     v2d* dst = xt + (size_t)buf * TILE_CAP * 4;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -111,14 +110,16 @@ __global__ __launch_bounds__(512) void spmm_tile_kernel(
       if (u < nu) dst[u * 4 + (si ^ ((u >> 2) & 1))] = sv[q];
     }
   };
+  load_x(0);
+  store_x(0);
+  __syncthreads();
+  const int npass = (ncols + 7) >> 3;
   const int r = slice * 32 + row32;
   v2d* yr = yt + (size_t)r * 4 + 2 * h;
-  const int myrow = rows[T->row_off + min(su, nr - 1)];   // the matrix row whose Y segment this thread stores (loaded once: a load
-                                                         // inside the pass loop would be waited for WITH the staging loads in front of it)
-  // one pass from LDS buffer `buf`: products, the two halves of a slice meet in the Y tile (second half stored, first half
-  // added), then the tile's rows leave as 64-byte segments
-  auto compute = [&](int pass, int buf) {
-    const v2d* __restrict__ xb = xt + (size_t)buf * TILE_CAP * 4;
+  for (int pass = 0; pass < npass; ++pass) {
+    const bool more = pass + 1 < npass;
+    if (more) load_x(pass + 1);
+    const v2d* __restrict__ xb = xt + (size_t)(pass & 1) * TILE_CAP * 4;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
     for (int i0 = 0; i0 < MAXH; i0 += 4) {
@@ -133,6 +134,9 @@ __global__ __launch_bounds__(512) void spmm_tile_kernel(
         }
       }
     }
+    if (more) store_x((pass + 1) & 1);    // that buffer was last read in pass - 1, which every wave has left
+    // the two halves of a slice meet in the Y tile (second half stored, first half added), then the tile's rows leave as
+    // 64-byte segments
     if (kh == 1) { yr[0] = v2d{a0, a1}; yr[1] = v2d{a2, a3}; }
     __syncthreads();
     if (kh == 0) { const v2d p0 = yr[0], p1 = yr[1]; yr[0] = v2d{a0 + p0.x, a1 + p0.y}; yr[1] = v2d{a2 + p1.x, a3 + p1.y}; }
@@ -140,25 +144,9 @@ __global__ __launch_bounds__(512) void spmm_tile_kernel(
     {
       const int c = 8 * pass + 2 * si;
       if (su < nr && c < ncols)
-        __builtin_nontemporal_store(yt[su * 4 + si], reinterpret_cast<v2d*>(y + (size_t)myrow * ldy + c));
+        __builtin_nontemporal_store(yt[su * 4 + si], reinterpret_cast<v2d*>(y + (size_t)rows[T->row_off + su] * ldy + c));
     }
-  };
-  load_x(svA, 0);
-  store_x(svA, 0);
-  load_x(svA, 1);                          // in flight across the barrier
-  __syncthreads();
-  for (int pass = 0; pass < npass; pass += 2) {
-    // even pass from buffer 0; in flight: set A (pass + 1), now also set B (pass + 2)
-    load_x(svB, pass + 2);
-    compute(pass, 0);
-    store_x(svA, 1);                       // buffer 1 was last read in pass - 1, which every wave has left
     __syncthreads();
-    if (pass + 1 < npass) {                // block-uniform
-      load_x(svA, pass + 3);
-      compute(pass + 1, 1);
-      store_x(svB, 0);
-      __syncthreads();
-    }
   }
 }
 
