@@ -1,7 +1,8 @@
 #!/bin/bash
 # SQ / cache counters of the K1 kernels for matrices without a pattern form (spmm_tile.hip, spmm_dense.hip, spmm_pad8.hip)
 # on the SiO2-like matrix.    tools/prof_tile.sh <outdir> [G K m]        (run on the GPU box; TILE_MODE / DENSE_MODE as tools/tile_probe.py)
-OUT=$GRAFT_REPO_ROOT/$1; G=${2:-96}; K=${3:-354}; M=${4:-64}
+#   PROBE=tools/offset_probe.py tools/prof_tile.sh <outdir> 256 64     (any probe script: its arguments follow the directory)
+OUT=$GRAFT_REPO_ROOT/$1; shift; PROBE=${PROBE:-tools/tile_probe.py}; ARGS="${@:-96 354 64}"
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" \
