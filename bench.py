@@ -424,11 +424,11 @@ def main():
             if c_ == 0:
                 return None
             ach = (by_ / c_) / (ms_ / c_ * 1e-3) / 1e9
-            kname = "%s<7,%d,16>" % (kbase, kind) if npat > 0 else kbase
+            kname = "%s<7,%d,16,false>" % (kbase, kind) if npat > 0 else kbase
             if kind == 2 and ring_launches > 0:   # the read-only pass ran the LDS-ring sweep (spmm_ring.hip), 3 planes ahead
                 kname = "spmm_ring<2,16,3,false>"
             if kind == 3 and implicit_r > 0:      # second pass without a stored residual (kernel MODE 7): 3 block streams
-                kname = "%s<7,7,16>" % kbase
+                kname = "%s<7,7,16,false>" % kbase
                 streams = 3
             traffic, note = pmc_traffic(kname, N, args.block) if (npat > 0 and world == 1 and not c5) else (None, "no PMC profile for this shape")
             req = (8.0 * streams * args.block + 2.0 * npass) * A.nrows if npat > 0 else by_ / c_
