@@ -344,6 +344,56 @@ static void reduce_over_ranks(double* v, int n) {
   if (c != nullptr && n > 0) c->allreduce_sum(v, n, c->ctx);
 }
 
+// r, p, w (and the shift's scratch block on demand) for this problem shape; a change of shape drops the ring
+static void bpcg_shape(HipBpcg* s, int n, int nrhs, void** mv_x, struct OPS_* ops) {
+  if (s->ws_cols >= nrhs && s->ws_rows == n) return;
+  for (int i = 1; i < s->ring_len; ++i) if (s->ring[i]) ops->MultiVecDestroy(&s->ring[i], s->ws_cols, ops);
+  s->ring_len = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (s->mv_ws[i]) ops->MultiVecDestroy(&s->mv_ws[i], s->ws_cols, ops);
+    if (i < 3) ops->MultiVecCreateByMultiVec(&s->mv_ws[i], nrhs, mv_x, ops);
+  }
+  s->ws_cols = nrhs; s->ws_rows = n;
+}
+static void bpcg_ring(HipBpcg* s, void* mat, void** mv_x, double sigma, struct OPS_* ops) {
+  long ldp = 0;
+  (void)gcge_hip_mv_device_ptr(s->mv_ws[1], &ldp);
+  // p-ring (see cg_update_rp): as many slots as memory allows, at most 16; fewer than 4 pending terms do not pay
+  const int ring_max = getenv("GCGE_CG_RING") ? atoi(getenv("GCGE_CG_RING")) : 16;   // (read when a ring is created)
+  if (s->ring_len == 0 && s->max_iter >= 8) {   // (every rank gets here in the same call: the vote below is collective)
+    size_t fr = 0, tot = 0;
+    GCGE_HIP_CHECK(hipMemGetInfo(&fr, &tot));
+    fr += gcge_hip_pool_cached_bytes();   // blocks parked in the back-end's pool are available to MultiVecCreate*
+    const size_t slot = (size_t)gcge_hip_mv_nrows(s->mv_ws[1]) * (size_t)ldp * sizeof(double) + ((size_t)64 << 20);
+    const size_t keep = (size_t)12 << 30;   // leave room for staging, partial sums and the caller
+    long want = fr > keep ? (long)((fr - keep) / slot) : 0;
+    if (want > ring_max - 1) want = ring_max - 1;
+    // smallest ring worth having: with the product recomputed (1 + 4 streams per iteration) even two extra slots pay —
+    // x then costs (2 + 2) / 2 = 2 streams per iteration, 7 in all against 8.1 of the stored-w form; that is the case of
+    // BASELINE config 4's shape, where 244 of 288 GB are taken by the solver's own blocks
+    // (with the product stored — generic matrices, shifts — a ring only pays from 4 extra slots on: 2 + 5 + (J + 2) / J
+    // streams against the 9 of the ring-less sweep)
+    const int min_ring = (sigma == 0.0 && gcge_hip_cg_recompute_pays(mat)) ? 2 : 4;
+    if (want < min_ring) want = 0;
+    if (want > s->max_iter) want = s->max_iter;
+    // Row-partitioned runs: the ring length decides the column window [alo, ahi) and with it the LENGTH of the two
+    // all-reduces of an iteration, so every rank must use the same one — the minimum over the ranks (free memory
+    // differs between slabs cut by non-zeros and between ranks sharing a device).  GCGE_COMM only sums: rank r's
+    // "can hold at least q+1 extra slots" indicators are summed, the agreed length is the count of unanimous entries.
+    if (GCGE_COMM* c = GCGE_GetComm()) {
+      double vote[16];
+      for (int q = 0; q < 16; ++q) vote[q] = q < want ? 1.0 : 0.0;
+      c->allreduce_sum(vote, 16, c->ctx);
+      long agreed = 0;
+      while (agreed < 16 && vote[agreed] > (double)c->size - 0.5) ++agreed;
+      want = agreed;
+    }
+    s->ring[0] = s->mv_ws[1]; s->ring_len = 1;
+    if (want >= 1)
+      for (long i = 0; i < want; ++i) { ops->MultiVecCreateByMultiVec(&s->ring[s->ring_len], s->ws_cols, mv_x, ops); ++s->ring_len; }
+  }
+}
+
 static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx, int* end_bx, struct OPS_* ops);
 static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int* end_bx, struct OPS_* ops) {
   HipBpcg* s = (HipBpcg*)ops->multi_linear_solver_workspace;
@@ -351,6 +401,10 @@ static void HIP_BlockPCG(void* mat, void** mv_b, void** mv_x, int* start_bx, int
   HIP_BlockPCG_run(mat, mv_b, mv_x, start_bx, end_bx, ops);
   s->total_iters += s->niter;
   if (ops->GetWtime) s->total_seconds += ops->GetWtime() - t0;
+  static const bool trace = getenv("GCGE_CG_TRACE") != nullptr;   // one line per call on stderr (tuning aid)
+  if (trace && ops->GetWtime)
+    fprintf(stderr, "HIP_BlockPCG: %d columns (b at %d, x at %d), %d iterations, ring of %d, %.1f ms\n", end_bx[0] - start_bx[0], start_bx[0],
+            start_bx[1], s->niter, s->ring_len, 1e3 * (ops->GetWtime() - t0));
 }
 static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx, int* end_bx, struct OPS_* ops) {
   HipBpcg* s = (HipBpcg*)ops->multi_linear_solver_workspace;
@@ -360,15 +414,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
   if (nrhs <= 0) { s->niter = 0; return; }
   const int n = gcge_hip_mv_nrows(mv_x);
   if (gcge_hip_mv_nrows(mv_b) != n) { fprintf(stderr, "HIP_BlockPCG: b and x have different row counts\n"); abort(); }
-  if (s->ws_cols < nrhs || s->ws_rows != n) {   // (re)create r, p, w for this problem shape
-    for (int i = 1; i < s->ring_len; ++i) if (s->ring[i]) ops->MultiVecDestroy(&s->ring[i], s->ws_cols, ops);
-    s->ring_len = 0;
-    for (int i = 0; i < 4; ++i) {
-      if (s->mv_ws[i]) ops->MultiVecDestroy(&s->mv_ws[i], s->ws_cols, ops);
-      if (i < 3) ops->MultiVecCreateByMultiVec(&s->mv_ws[i], nrhs, mv_x, ops);
-    }
-    s->ws_cols = nrhs; s->ws_rows = n;
-  }
+  bpcg_shape(s, n, nrhs, mv_x, ops);
   // operator: A, or A + sigma B when the caller published a shift (GCGE_SetLinearSolverShift)
   double sigma = 0.0; void* matB = nullptr;
   GCGE_GetLinearSolverShift(&sigma, &matB);
@@ -488,40 +534,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
   // ---- one-pass scheme (default whenever all four blocks can be walked with 16-byte lanes) ----
   if (nrhs <= 512 && cg_vec_ok(nrhs, {dw, dr, dp, dx}, {ldw, ldr, ldp, ldx})) {
     std::vector<double> wTw(nrhs), bet(nrhs);
-    // p-ring (see cg_update_rp): as many slots as memory allows, at most 16; fewer than 4 pending terms do not pay
-    const int ring_max = getenv("GCGE_CG_RING") ? atoi(getenv("GCGE_CG_RING")) : 16;   // (read when a ring is created)
-    if (s->ring_len == 0 && s->max_iter >= 8) {   // (every rank gets here in the same call: the vote below is collective)
-      size_t fr = 0, tot = 0;
-      GCGE_HIP_CHECK(hipMemGetInfo(&fr, &tot));
-      fr += gcge_hip_pool_cached_bytes();   // blocks parked in the back-end's pool are available to MultiVecCreate*
-      const size_t slot = (size_t)gcge_hip_mv_nrows(s->mv_ws[1]) * (size_t)ldp * sizeof(double) + ((size_t)64 << 20);
-      const size_t keep = (size_t)12 << 30;   // leave room for staging, partial sums and the caller
-      long want = fr > keep ? (long)((fr - keep) / slot) : 0;
-      if (want > ring_max - 1) want = ring_max - 1;
-      // smallest ring worth having: with the product recomputed (1 + 4 streams per iteration) even two extra slots pay —
-      // x then costs (2 + 2) / 2 = 2 streams per iteration, 7 in all against 8.1 of the stored-w form; that is the case of
-      // BASELINE config 4's shape, where 244 of 288 GB are taken by the solver's own blocks
-      // (with the product stored — generic matrices, shifts — a ring only pays from 4 extra slots on: 2 + 5 + (J + 2) / J
-      // streams against the 9 of the ring-less sweep)
-      const int min_ring = (sigma == 0.0 && gcge_hip_cg_recompute_pays(mat)) ? 2 : 4;
-      if (want < min_ring) want = 0;
-      if (want > s->max_iter) want = s->max_iter;
-      // Row-partitioned runs: the ring length decides the column window [alo, ahi) and with it the LENGTH of the two
-      // all-reduces of an iteration, so every rank must use the same one — the minimum over the ranks (free memory
-      // differs between slabs cut by non-zeros and between ranks sharing a device).  GCGE_COMM only sums: rank r's
-      // "can hold at least q+1 extra slots" indicators are summed, the agreed length is the count of unanimous entries.
-      if (GCGE_COMM* c = GCGE_GetComm()) {
-        double vote[16];
-        for (int q = 0; q < 16; ++q) vote[q] = q < want ? 1.0 : 0.0;
-        c->allreduce_sum(vote, 16, c->ctx);
-        long agreed = 0;
-        while (agreed < 16 && vote[agreed] > (double)c->size - 0.5) ++agreed;
-        want = agreed;
-      }
-      s->ring[0] = s->mv_ws[1]; s->ring_len = 1;
-      if (want >= 1)
-        for (long i = 0; i < want; ++i) { ops->MultiVecCreateByMultiVec(&s->ring[s->ring_len], s->ws_cols, mv_x, ops); ++s->ring_len; }
-    }
+    bpcg_ring(s, mat, mv_x, sigma, ops);
     // Pattern matrices (stencils) with a ring: the product is formed twice and never stored — pass 1 reads p for
     // p.w and w.w, pass 2 reads p again and applies the r / p update with w rebuilt in registers (app_hip.hip:
     // gcge_hip_cg_pass1_mv / pass2_mv): 1 + 4 block streams per iteration instead of 2 + 5.  Same recurrences,
@@ -825,6 +838,21 @@ extern "C" void gcge_hip_bpcg_setup(struct OPS_* ops, int max_iter, double rate,
   ops->multi_linear_solver_workspace = (void*)&g_bpcg;
   ops->MultiLinearSolver = HIP_BlockPCG;
   GCGE_SetRhsScaleCapability((void*)HIP_BlockPCG);   // b = x diag(scale) need not be formed (see HIP_BlockPCG_run)
+}
+// Optional: create the solver's blocks (r, p, w and the ring of direction slots) NOW, for systems with the rows of `mv_like` and up
+// to `ncols` right-hand sides, instead of inside the first solve.  The counterpart of the reference's EigenSolverCreateWorkspace /
+// MultiLinearSolverSetup_BlockPCG (src/ops_lin_sol.c:439-465), which take the CG's blocks from the caller before any timer
+// starts: a ring of 15 slots at BASELINE config 2's shape is 129 GB of fresh device memory, which the driver clears on first
+// use (4 s in a new process — otherwise spent inside the first call).  Collective when a communicator exists.
+extern "C" int gcge_hip_bpcg_prepare(struct OPS_* ops, void* mat, void** mv_like, int ncols) {
+  if (ops == nullptr || ops->MultiLinearSolver != HIP_BlockPCG || mv_like == nullptr || ncols <= 0) return -1;
+  HipBpcg* s = (HipBpcg*)ops->multi_linear_solver_workspace;
+  double sigma = 0.0; void* matB = nullptr;
+  GCGE_GetLinearSolverShift(&sigma, &matB);
+  bpcg_shape(s, gcge_hip_mv_nrows(mv_like), ncols, mv_like, ops);
+  bpcg_ring(s, mat, mv_like, sigma, ops);
+  GCGE_HIP_CHECK(hipStreamSynchronize((hipStream_t)gcge_hip_stream()));
+  return s->ring_len;
 }
 extern "C" void gcge_hip_bpcg_stats(long* spmm_calls, long* spmm_cols, int* last_niter) {
   if (spmm_calls) *spmm_calls = g_bpcg.spmm_calls;

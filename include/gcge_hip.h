@@ -108,6 +108,11 @@ void gcge_hip_set_random_mode (int mode, unsigned long long seed);
  * call this once, then run the harness with flag = 1.                                  */
 void gcge_hip_bpcg_setup (struct OPS_ *ops, int max_iter, double rate, double tol, const char *tol_type);
 void gcge_hip_bpcg_stats (long *spmm_calls, long *spmm_cols, int *last_niter);
+/* optional, after gcge_hip_bpcg_setup: create the solver's own blocks (r, p, w and the ring of direction slots) for systems with the
+ * rows of mv_like and up to ncols right-hand sides now rather than inside the first solve — the reference hands BlockPCG its blocks
+ * from EigenSolverCreateWorkspace_GCG, before the harness starts its timer (test/test_eig_sol_gcg.c:89-143).  Returns the ring
+ * length (>= 1), -1 when ops->MultiLinearSolver is not this solver.  Collective when a communicator exists.                    */
+int  gcge_hip_bpcg_prepare (struct OPS_ *ops, void *mat, void **mv_like, int ncols);
 /*     tol_type: "abs", "rel" or "user" (src/ops_lin_sol.c:175-197; "user": scales from GCGE_GetLinearSolverUserScale).
  *     Residual of the recompute form: 0 automatic (not stored where rate >= 1e-4 and max_iter <= 100), 1 never stored
  *     (r_k = p_k - beta_{k-1} p_{k-1} rebuilt from the ring), 2 always stored                                         */

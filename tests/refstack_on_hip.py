@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--flag", type=int, default=1)
     ap.add_argument("--rng", type=int, default=1)
     ap.add_argument("--slot-timing", action="store_true", help="synchronise after every slot call and report wall time per slot and width class (stderr)")
+    ap.add_argument("--prepare", action="store_true", help="gcge_hip_bpcg_prepare before the solve: the fused CG's blocks are created outside the timed region, "
+                    "as the reference creates BlockPCG's (EigenSolverCreateWorkspace_GCG)")
+    ap.add_argument("--verbose", action="store_true", help="let the reference print its own log and phase-time table (stdout, before the JSON line)")
     a = ap.parse_args()
     import numpy as np
     import torch  # noqa: F401
@@ -48,8 +51,18 @@ def main():
     ref.ref_gcg_solve_foreign.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double),
                                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    if a.prepare and a.flag == 1:
+        like = hip.ops.mv_create(a.block, mA)
+        hip.g.gcge_hip_bpcg_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        ring = hip.g.gcge_hip_bpcg_prepare(ops, mA, like, a.block)
+        assert ring >= 1, ring
+        hip.ops.mv_destroy(like, a.block)
     if a.slot_timing:
         hip.g.gcge_hip_slot_timing(1)
+    hip.g.gcge_hip_bpcg_time_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_double), C.c_int]
+    hip.g.gcge_hip_bpcg_time_stats(None, None, 1)
+    if a.verbose:
+        ref.ref_set_verbose(1)
     ev = np.zeros(a.nevmax or 2 * a.nev)
     conv, it, sec = C.c_int(), C.c_int(), C.c_double()
     rc = ref.ref_gcg_solve_foreign(ops, mA, mB, a.nev, a.nevmax, a.block, 0, 1e-1, 1e-8, 500, a.flag,
@@ -62,8 +75,17 @@ def main():
         hip.g.gcge_hip_slot_timing(0)
     out = {"stack": "reference GCG + ModifiedGramSchmidt + %s over OPS_HIP_Set slots" % ("HIP fused CG (flag 1)" if a.flag else "reference BlockPCG (flag 0)"),
            "kind": a.kind, "size": a.size, "n": int(A.nrows), "nev": a.nev, "block": a.block, "nevMax": a.nevmax,
-           "nev_converged": conv.value, "gcg_iterations": it.value, "seconds": sec.value,
+           "cg_blocks_prepared": bool(a.prepare and a.flag == 1), "nev_converged": conv.value, "gcg_iterations": it.value, "seconds": sec.value,
            "eigenpairs_per_s": conv.value / sec.value}
+    if a.flag == 1:   # how the fused CG ran underneath the reference's ComputeW (form, iterations, time inside the solver slot)
+        its, cs_ = C.c_long(), C.c_double()
+        hip.g.gcge_hip_bpcg_time_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_double), C.c_int]
+        hip.g.gcge_hip_bpcg_time_stats(C.byref(its), C.byref(cs_), 0)
+        for nm in ("recompute_iters", "device_scalar_iters", "implicit_r_iters", "surplus_iters"):
+            getattr(hip.g, "gcge_hip_bpcg_" + nm).restype = C.c_long
+        out["cg"] = {"iterations": its.value, "seconds": cs_.value, "recompute_iters": hip.g.gcge_hip_bpcg_recompute_iters(),
+                     "device_scalar_iters": hip.g.gcge_hip_bpcg_device_scalar_iters(),
+                     "implicit_r_iters": hip.g.gcge_hip_bpcg_implicit_r_iters(), "surplus_iters": hip.g.gcge_hip_bpcg_surplus_iters()}
     if a.kind == "lap3d":
         exact = lap3d_exact(a.size, conv.value) if a.size <= 64 else None
         if exact is None:
