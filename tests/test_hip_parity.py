@@ -1482,3 +1482,44 @@ def test_mgs_step_fusion_equals_separate_kernels(both):
     finally:
         g.gcge_hip_set_mgs_fusion(1)
     hip.free_matrix(mh)
+
+
+def test_fused_cg_prepare_creates_the_blocks_before_the_solve(hip):
+    """gcge_hip_bpcg_prepare (include/gcge_hip.h): the solver's r, p, w and its ring of direction slots exist after the call
+    (ring length returned, >= 1), the solve that follows neither creates a block nor changes its answer — bitwise the same
+    solution as a solve that created its blocks itself — and a table whose MultiLinearSolver is not the fused CG is refused."""
+    import torch
+    g = hip.g
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    g.gcge_hip_bpcg_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    g.gcge_hip_bpcg_release.argtypes = [C.c_void_p]
+    g.gcge_hip_pool_cached_bytes.restype = C.c_size_t
+    A, _ = make_problem("lap3d", 64)                                     # 33.5 MB per 16-column block: allocations show
+    n = A.nrows; nrhs = 16
+    mat = hip.matrix(A)
+    Bm = uniform(5, (n, nrhs)) - 0.5
+    sols = []
+    try:
+        for prepared in (False, True):
+            g.gcge_hip_bpcg_release(hip.ops_handle)                      # drop the blocks of earlier tests: a first call again
+            g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+            b = hip.mv_from_numpy(mat, Bm); x = hip.mv_from_numpy(mat, np.zeros((n, nrhs)))
+            if prepared:
+                ring = g.gcge_hip_bpcg_prepare(hip.ops_handle, mat, x, nrhs)
+                assert ring >= 1, ring
+                free_before = torch.cuda.mem_get_info()[0] + g.gcge_hip_pool_cached_bytes()
+            hip.ops.multi_linear_solver(mat, b, x, (0, 0), (nrhs, nrhs))
+            if prepared:
+                assert torch.cuda.mem_get_info()[0] + g.gcge_hip_pool_cached_bytes() >= free_before - (16 << 20), "the prepared solve allocated blocks"
+            sols.append(hip.mv_to_numpy(x, n, 0, nrhs))
+            hip.ops.mv_destroy(b, nrhs); hip.ops.mv_destroy(x, nrhs)
+        assert np.array_equal(sols[0], sols[1])
+        # a table without the fused solver
+        other = C.c_void_p(); hip.h.OPS_Create(C.byref(other)); g.OPS_HIP_Set(other)
+        x = hip.mv_from_numpy(mat, np.zeros((n, nrhs)))
+        assert g.gcge_hip_bpcg_prepare(other, mat, x, nrhs) == -1
+        hip.ops.mv_destroy(x, nrhs)
+        hip.h.OPS_Destroy(C.byref(other))
+    finally:
+        g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    hip.free_matrix(mat)
