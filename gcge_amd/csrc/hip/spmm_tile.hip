@@ -58,16 +58,17 @@ template <int MAXH>
 __global__ __launch_bounds__(512) void spmm_tile_kernel(
     const TileHdr* __restrict__ th, const int* __restrict__ rows, const int* __restrict__ ucols,
     const double* __restrict__ steps, const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy,
-    int ncols, int ntiles, int map) {
+    int ncols, int ntiles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   v2d* xt = reinterpret_cast<v2d*>(smem_raw);        // 2 buffers x TILE_CAP positions x 4 column pairs
   v2d* yt = xt + (size_t)2 * TILE_CAP * 4;           // TILE_ROWS rows x 4 column pairs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row32 = lane >> 1, h = lane & 1, slice = wave & 3, kh = wave >> 2;
   // blocks are dealt round-robin to the 8 XCDs: every XCD walks one contiguous eighth of the tiles, so bricks that
-  // share halo rows run on the same L2 at about the same time
+  // share halo rows run on the same L2 at about the same time (tile = blockIdx, all XCDs in one z-region for the
+  // Infinity Cache: 5.88 against 5.80 ms, profiles/r03_spmm_generic/34_...)
   const int per = (ntiles + 7) >> 3;
-  const int tile = map ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (tile >= ntiles) return;
   const TileHdr* __restrict__ T = th + tile;
   const int nu = T->nu, nr = T->nrows;
@@ -454,9 +455,8 @@ extern "C" int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, d
     attr_set = true;
   }
   const int per = (T->ntiles + 7) / 8;
-  static const int map = getenv("GCGE_TILE_MAP") ? atoi(getenv("GCGE_TILE_MAP")) : 0;
   hipLaunchKernelGGL((spmm_tile_kernel<TILE_MAXW / 2>), dim3((unsigned)(8 * per)), dim3(512), lds, (hipStream_t)stream, T->d_th, T->d_rows,
-                     T->d_ucols, T->d_steps, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, T->ntiles, map);
+                     T->d_ucols, T->d_steps, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, T->ntiles);
   if (T->nov > 0)
     hipLaunchKernelGGL(spmm_tile_overflow_kernel, dim3((unsigned)((T->nov + 3) / 4)), dim3(256), 0, (hipStream_t)stream, T->nov, T->d_ov_rows,
                        T->d_ov_ptr, T->d_ov_col, T->d_ov_val, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols);
