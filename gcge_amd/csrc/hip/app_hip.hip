@@ -1040,6 +1040,16 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
   const bool fast = aligned && (use_pat || (m >= 16 && m <= 128 && !long_rows)) && (A->nghost == 0 || m <= A->buf_cols);
   if (!fast) {
     HIP_MatDotMultiVec(mat, x, y, start, end, ops);
+    if (host_yy && vx->nrows == vy->nrows) {   // x.y and y.y in one sweep over the two blocks
+      double* dd = stage_d(2 * (size_t)m);
+      GCGE_REQUIRE(gcge_hip_coldots2(vx->nrows, vx->d + start[0], vx->ld, vy->d + start[1], vy->ld, m, dd, g_stream) == 0, "spmm_dot: column sums");
+      double* hd = stage_h(2 * (size_t)m);
+      GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, 2 * (size_t)m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+      GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+      memcpy(host_dots, hd, m * sizeof(double));
+      memcpy(host_yy, hd + m, m * sizeof(double));
+      return;
+    }
     ops->MultiVecLocalInnerProd('D', x, y, 0, start, end, host_dots, 1, ops);
     if (host_yy) {
       int s2[2] = {start[1], start[1]}, e2[2] = {end[1], end[1]};

@@ -138,6 +138,35 @@ __global__ __launch_bounds__(256) void coldots_partial(long nrows, const double*
     __syncthreads();
   }
 }
+// the same sweep with two results: partial[b*2m + j] = sum x[r,j]*y[r,j], partial[b*2m + m + j] = sum y[r,j]^2 — the pair the
+// fused CG asks for after a product it could not fuse the sums into (p.w and w.w: one read of p and w instead of p, w, w)
+__global__ __launch_bounds__(256) void coldots2_partial(long nrows, const double* __restrict__ x, long ldx,
+    const double* __restrict__ y, long ldy, int m, double* __restrict__ partial, long rows_per_block) {
+  __shared__ double red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(nrows, r0 + rows_per_block);
+  for (int c0 = 0; c0 < m; c0 += 64) {
+    const int j = c0 + tx;
+    double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
+    if (j < m) {
+      long r = r0 + ty;
+      for (; r + 4 < r1; r += 8) {
+        const double ya = y[r * ldy + j], yb = y[(r + 4) * ldy + j];
+        s0 = fma(x[r * ldx + j], ya, s0); q0 = fma(ya, ya, q0);
+        s1 = fma(x[(r + 4) * ldx + j], yb, s1); q1 = fma(yb, yb, q1);
+      }
+      for (; r < r1; r += 4) { const double ya = y[r * ldy + j]; s0 = fma(x[r * ldx + j], ya, s0); q0 = fma(ya, ya, q0); }
+    }
+    red[0][ty][tx] = s0 + s1; red[1][ty][tx] = q0 + q1;
+    __syncthreads();
+    if (ty == 0 && j < m) {
+      partial[(long)blockIdx.x * 2 * m + j] = (red[0][0][tx] + red[0][1][tx]) + (red[0][2][tx] + red[0][3][tx]);
+      partial[(long)blockIdx.x * 2 * m + m + j] = (red[1][0][tx] + red[1][1][tx]) + (red[1][2][tx] + red[1][3][tx]);
+    }
+    __syncthreads();
+  }
+}
 // out[j] = sum_b partial[b*len + j]; 16 row groups x 64 columns per block, fixed summation
 // tree => bitwise reproducible, and no thread walks more than nblocks/16 entries
 __global__ __launch_bounds__(1024) void reduce_partials(const double* __restrict__ partial, int nblocks, int len,
@@ -464,6 +493,22 @@ extern "C" int gcge_hip_coldots(int nrows, const double* d_x, long ldx, const do
   hipLaunchKernelGGL(coldots_partial, dim3((unsigned)nb), dim3(256), 0, st, (long)nrows, d_x, ldx, d_y, ldy, m,
                      part, rpb);
   hipLaunchKernelGGL(reduce_partials, dim3((m + 63) / 64), dim3(1024), 0, st, part, (int)nb, m, d_out);
+  return (int)hipGetLastError();
+}
+
+// d_out[0:m) = column dots x.y, d_out[m:2m) = y.y: the same slabs and the same summation order as two gcge_hip_coldots calls
+extern "C" int gcge_hip_coldots2(int nrows, const double* d_x, long ldx, const double* d_y, long ldy, int m,
+                                 double* d_out, void* stream) {
+  if (m <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (nrows <= 0) return (int)hipMemsetAsync(d_out, 0, 2 * (size_t)m * sizeof(double), st);
+  long nb = ((long)nrows + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  const long rpb = (((long)nrows + nb - 1) / nb + 3) / 4 * 4;
+  nb = ((long)nrows + rpb - 1) / rpb;
+  double* part = gcge_hip_partial_ws((size_t)nb * 2 * m);
+  hipLaunchKernelGGL(coldots2_partial, dim3((unsigned)nb), dim3(256), 0, st, (long)nrows, d_x, ldx, d_y, ldy, m, part, rpb);
+  hipLaunchKernelGGL(reduce_partials, dim3((2 * m + 63) / 64), dim3(1024), 0, st, part, (int)nb, 2 * m, d_out);
   return (int)hipGetLastError();
 }
 

@@ -248,6 +248,9 @@ int gcge_hip_mat_pattern_chain (const GCGE_HIP_MAT *A);   /* 0 none, 1 chain lay
 /*     d_out[j] = sum_r x[r,j] y[r,j] */
 int gcge_hip_coldots (int nrows, const double *d_x, long ldx, const double *d_y, long ldy, int m,
 		double *d_out, void *stream);
+/*     d_out[j] = x_j . y_j, d_out[m + j] = y_j . y_j in one sweep (bitwise what two gcge_hip_coldots calls return) */
+int gcge_hip_coldots2 (int nrows, const double *d_x, long ldx, const double *d_y, long ldy, int m,
+		double *d_out, void *stream);
 /* K3  Y[:,0:m) = X[:,0:k) C + Y diag(beta);  d_c row-major k x m; d_beta NULL => overwrite */
 int gcge_hip_lincomb (int nrows, const double *d_x, long ldx, int k, const double *d_c, int m,
 		const double *d_beta, double *d_y, long ldy, void *stream);

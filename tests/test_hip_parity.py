@@ -1523,3 +1523,27 @@ def test_fused_cg_prepare_creates_the_blocks_before_the_solve(hip):
     finally:
         g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
     hip.free_matrix(mat)
+
+
+@pytest.mark.parametrize("n,m,ldx,ldy", [(1, 1, 1, 1), (1000, 7, 9, 7), (70001, 64, 128, 64), (262147, 33, 40, 36)])
+def test_coldots2_equals_two_column_dot_sweeps(hip, n, m, ldx, ldy):
+    """gcge_hip_coldots2 (x.y and y.y of every column in one sweep — the pair the fused CG asks for after a product of a
+    matrix without a pattern form) returns, bit for bit, what two gcge_hip_coldots sweeps return, and both agree with numpy."""
+    import torch
+    g = hip.g
+    g.gcge_hip_coldots.argtypes = [C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
+    g.gcge_hip_coldots2.argtypes = g.gcge_hip_coldots.argtypes
+    g.gcge_hip_stream.restype = C.c_void_p
+    st = g.gcge_hip_stream()
+    gen = torch.Generator(device="cpu"); gen.manual_seed(n + m)
+    X = (torch.rand((n, ldx), dtype=torch.float64, generator=gen) - 0.5).cuda()
+    Y = (torch.rand((n, ldy), dtype=torch.float64, generator=gen) - 0.5).cuda()
+    one = torch.zeros(2 * m, dtype=torch.float64, device="cuda"); two = torch.zeros(2 * m, dtype=torch.float64, device="cuda")
+    assert g.gcge_hip_coldots2(n, X.data_ptr(), ldx, Y.data_ptr(), ldy, m, one.data_ptr(), st) == 0
+    assert g.gcge_hip_coldots(n, X.data_ptr(), ldx, Y.data_ptr(), ldy, m, two.data_ptr(), st) == 0
+    assert g.gcge_hip_coldots(n, Y.data_ptr(), ldy, Y.data_ptr(), ldy, m, two.data_ptr() + 8 * m, st) == 0
+    hip.sync()
+    assert torch.equal(one, two)
+    Xh, Yh = X[:, :m].cpu().numpy(), Y[:, :m].cpu().numpy()
+    ref = np.concatenate([(Xh * Yh).sum(0), (Yh * Yh).sum(0)])
+    assert np.allclose(one.cpu().numpy(), ref, rtol=1e-12, atol=1e-12 * n)
