@@ -240,6 +240,11 @@ def main():
     transport = "none (single rank)"
     comm = None
     if world > 1:
+        # a rank that hangs in the communicator set-up or the first exchange (a peer that died, a transport that never
+        # connects) must end the job rather than sit in a C call for ever: SIGALRM with its default action terminates this
+        # rank, torch.distributed.run then stops the others.  Cancelled once the exchange check has passed.
+        import signal
+        signal.alarm(1200)
         # data path: RCCL inside the back-end (NativeComm); the rehearsal on one shared GPU cannot use RCCL (it refuses
         # two ranks on one device) and takes the torch.distributed callbacks staged through the host
         comm = gdist.install(hip, dist, rank, world, stage_through_host=True) if rehearse else gdist.NativeComm(hip, dist, rank, world)
@@ -309,6 +314,8 @@ def main():
         exchange = {"ok": ok, "got": float(got[0]), "want": want, "what": "sum over ranks of 1 . A 1 (halo rows + all-reduce) vs the sum of all matrix entries"}
         if not ok:
             raise SystemExit("bench.py rank %d: exchange check FAILED over transport '%s': %.12g != %.12g" % (rank, transport, got[0], want))
+    if world > 1:
+        signal.alarm(0)
     # memory set-up, like the matrix upload: hipMalloc of the 17-34 GB work blocks costs 0.2-0.3 s each on a fresh
     # process, so the blocks one solve needs (V, eigenvectors, 3 work blocks, 3 CG blocks) are allocated once here and
     # handed back to the back-end's size-keyed pool, from which the solver's MultiVecCreateByMat calls take them

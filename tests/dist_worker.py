@@ -1,6 +1,7 @@
 """Worker of the 2-rank tests (launched by tests/test_dist.py with RANK/WORLD_SIZE/MASTER_* set).
 mode 'oracle': CPU oracle back-end, gloo.   mode 'hip': HIP back-end on cuda:0 for every rank, gloo
-transport staged through the host (what differs from production is only the torch.distributed backend)."""
+transport staged through the host (what differs from production is only the torch.distributed backend).
+mode 'hip_native': one device per rank, RCCL from C inside the back-end (needs as many GPUs as ranks)."""
 import ctypes as C
 import os
 import sys
@@ -78,6 +79,15 @@ def main():
         po.oracle_lib().oracle_set_partition.argtypes = [C.c_long, C.c_long]
         po.oracle_lib().oracle_set_partition(part[rank], n_global)
         mat = be.matrix(A)             # ORACLE_CCS view: nrows = n_loc, ncols = n_loc + nghost
+    elif mode == "hip_native":
+        # every rank on its OWN device, RCCL called from C inside the back-end (csrc/hip/rccl_comm.hip): the production path of
+        # bench.py --gpus N.  gloo only hands rank 0's communicator id round.
+        from gcge_amd import HipBackend
+        torch.cuda.set_device(rank)
+        be = HipBackend(device=rank)
+        comm = gdist.NativeComm(be, dist, rank, world)
+        mat = comm.slab_matrix(A, part, cap_cols=8)
+        be.set_random_mode(1, 777)
     else:
         from gcge_amd import HipBackend
         be = HipBackend(device=0)
@@ -98,10 +108,10 @@ def main():
     ip = be.ops.inner_prod("N", x, x, (0, 1), (3, 5))
     assert np.max(np.abs(ip - X[:, 0:3].T @ X[:, 1:5])) < 1e-12
     # 3. whole eigensolve, SPMD
-    if mode == "hip":
+    if mode in ("hip", "hip_native"):
         be.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
         be.g.gcge_hip_bpcg_setup(be.ops_handle, 30, 1e-2, 1e-14, b"abs")
-    ev, res = run_gcg(be.ops_handle, mat, None, ["-nevConv", 8, "-gcge_compW_orth_method", os.environ.get("GCGE_TEST_ORTH", "chol")], flag=1 if mode == "hip" else 0)
+    ev, res = run_gcg(be.ops_handle, mat, None, ["-nevConv", 8, "-gcge_compW_orth_method", os.environ.get("GCGE_TEST_ORTH", "chol")], flag=1 if mode in ("hip", "hip_native") else 0)
     if sio2:
         import scipy.sparse.linalg as sla
         exact = np.sort(sla.eigsh(S.tocsc(), k=res.nevConv, sigma=0.0, which="LM", return_eigenvectors=False))
@@ -110,7 +120,7 @@ def main():
     rel = np.max(np.abs(ev[:res.nevConv] - exact) / exact)
     assert res.nevConv >= 8 and rel < 1e-10, (res.nevConv, res.numIter, rel, list(ev[:10]))
     note = ""
-    if mode == "hip" and not sio2:
+    if mode in ("hip", "hip_native") and not sio2:
         # 4. the REFERENCE's compiled GCG / orthonormalisation (oracle/_ref, its own OPS_Setup, flag 1 = the back-end's
         # solver) over a table only OPS_HIP_Set has touched, on the same slab matrices: OPS_HIP_Set installs
         # MultiVecInnerProd / MultiVecQtAP with the all-reduce, so no line of the reference's src/ is edited (its own

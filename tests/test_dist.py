@@ -105,6 +105,26 @@ def test_rccl_loopback_one_gpu(dims):
 
 
 @pytest.mark.gpu
+def test_native_worker_as_one_rank():
+    """The worker of the two-GPU test below, as a world of one rank on the one GPU (communicator created, slab built by
+    gcge_hip_mat_create_slab, whole solves): keeps that script running on the one-GPU box."""
+    _run("hip_native", world=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", [None, "sio2:16"])
+def test_two_ranks_two_gpus_rccl_native(spec):
+    """the world > 1 branches of gcge_hip_mat_create_slab (all-gather of the per-slab counts, grouped send/recv of the
+    index lists), the split halo exchange next to the all-reduces on one communicator and the device-scalar CG — two ranks on
+    two devices, SpMM / Gram / whole solves (ours and the reference's stack) against the global matrix.  Needs two GPUs: skipped
+    on the one-GPU test box, where this path runs as a one-rank loop-back only (test_rccl_native_loopback_one_gpu)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (%d visible)" % torch.cuda.device_count())
+    _run("hip_native", spec=spec)
+
+
+@pytest.mark.gpu
 def test_two_ranks_on_one_gpu_hip_sio2_rows_split_by_nnz():
     _run("hip", spec="sio2:16")
 
