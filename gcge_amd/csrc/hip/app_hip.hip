@@ -38,6 +38,12 @@ void gcge_hip_dense_stats(const void* dm, long* nblocks, long* items, long* dens
 void gcge_hip_tile_stats(const void* tm, long* ntiles, long* ov_nnz, double* xrows_per_row, double* ell_per_nnz, int* brick, long* strides);
 int gcge_hip_dense_spmm(const void* dm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream, int which);
 int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
+void* gcge_hip_star_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val,
+                          const int** rem_rowptr, const int** rem_col, const double** rem_val);
+void gcge_hip_star_release_remainder(void);
+void gcge_hip_star_free(void* sm);
+void gcge_hip_star_stats(const void* sm, long* out);
+int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
 int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2, const double* d_x, long ldx,
                           double* d_y, long ldy, int ncols, double* d_dots, double* d_dots_yy, void* stream);
 int gcge_hip_colscale(int nrows, double* d_y, long ldy, int m, const double* d_s, void* stream);
@@ -469,10 +475,21 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, i
   GCGE_HIP_CHECK(hipMemcpy(A->d_pval, pv.data(), noct * 8 * sizeof(double), hipMemcpyHostToDevice));
   build_patterns(A, nrows, ncols_local, rowptr, colidx, val);
   if (A->d_pid == nullptr && g_offset_patterns) build_patterns(A, nrows, ncols_local, rowptr, colidx, val, true);   // same stencil, other coefficients in every row
+  // matrices without a pattern form whose rows are mostly ONE star stencil on a grid (free diagonal): those rows leave the CSR
+  // arrays for the plane sweep of spmm_star.hip, the others (rows inside dense blocks, ...) keep every entry and take the block form
+  A->star = nullptr; A->star_rem = nullptr;
+  if (A->d_pid == nullptr) {
+    const int *rr = nullptr, *rc = nullptr; const double* rv = nullptr;
+    if (void* S = gcge_hip_star_build(nrows, ncols_local, rowptr, colidx, val, &rr, &rc, &rv)) {
+      void* D = gcge_hip_dense_build(nrows, ncols_local, rr, rc, rv);
+      if (D != nullptr) { A->star = S; A->star_rem = D; } else gcge_hip_star_free(S);   // (no blocks among the other rows: the forms below)
+      gcge_hip_star_release_remainder();
+    }
+  }
   // matrices without a pattern form: dense row blocks (supernodes) on MFMA + remainder CSR, where such blocks exist
-  A->dense = A->d_pid == nullptr ? gcge_hip_dense_build(nrows, ncols_local, rowptr, colidx, val) : nullptr;
+  A->dense = (A->d_pid == nullptr && A->star == nullptr) ? gcge_hip_dense_build(nrows, ncols_local, rowptr, colidx, val) : nullptr;
   // ... and, where switched on, row tiles with LDS-staged X rows
-  A->tile = (A->d_pid == nullptr || gcge_hip_spmm_tile_mode_get() == 2) ? gcge_hip_tile_build(nrows, ncols_local, rowptr, colidx, val) : nullptr;
+  A->tile = ((A->d_pid == nullptr && A->star == nullptr) || gcge_hip_spmm_tile_mode_get() == 2) ? gcge_hip_tile_build(nrows, ncols_local, rowptr, colidx, val) : nullptr;
   // interior rows: none of them references a halo column (slabs: everything but the first and the last plane)
   A->ov_lo = 0; A->ov_hi = nrows;
   if (A->nghost > 0) {
@@ -523,6 +540,8 @@ extern "C" void gcge_hip_mat_destroy(GCGE_HIP_MAT* A) {
   if (A->d_send_rows) hipFree(A->d_send_rows);
   if (A->tile != nullptr) gcge_hip_tile_free(A->tile);
   if (A->dense != nullptr) gcge_hip_dense_free(A->dense);
+  if (A->star_rem != nullptr) gcge_hip_dense_free(A->star_rem);
+  if (A->star != nullptr) gcge_hip_star_free(A->star);
   if (A->native_halo != nullptr) gcge_hip_halo_native_free(A);   // RCCL plan + the exchange buffers it owns (rccl_comm.hip)
   free(A);
 }
@@ -544,6 +563,7 @@ extern "C" const char* gcge_hip_mat_spmm_form(const GCGE_HIP_MAT* A) {
     if (A->d_rowval != nullptr) return ch == 2 ? "spmm_pattern_chain2+values" : "spmm_pattern+values";   // offsets-only table, values per row
     return ch == 2 ? "spmm_pattern_chain2" : ch == 1 ? "spmm_pattern_chain" : "spmm_pattern";
   }
+  if (A->star != nullptr && g_spmm_path == 0) return gcge_hip_dense_remainder_is_tiled(A->star_rem) ? "spmm_star+spmm_dense+spmm_tile" : "spmm_star+spmm_dense+spmm_pad8";
   if (A->dense != nullptr && g_spmm_path != 1 && g_spmm_path != 3 && g_spmm_path != 4) return gcge_hip_dense_remainder_is_tiled(A->dense) ? "spmm_dense+spmm_tile" : "spmm_dense+spmm_pad8";
   if (A->tile != nullptr && g_spmm_path != 1 && g_spmm_path != 3) return "spmm_tile";
   return "spmm_pad8";
@@ -554,15 +574,22 @@ extern "C" const char* gcge_hip_mat_spmm_form(const GCGE_HIP_MAT* A) {
 // row, ELL entries per non-zero, overflow entries, brick dimensions.  0: the matrix has no block form.
 extern "C" int gcge_hip_mat_form_stats(const GCGE_HIP_MAT* A, double* out) {
   for (int i = 0; i < 12; ++i) out[i] = 0.0;
-  if (A->dense == nullptr) return 0;
+  const void* DM = A->star != nullptr ? A->star_rem : A->dense;       // (with a grid form: the block form of the rows it leaves)
+  if (DM == nullptr) return 0;
   long nb = 0, items = 0, dn = 0, de = 0, rn = 0;
-  gcge_hip_dense_stats(A->dense, &nb, &items, &dn, &de, &rn);
+  gcge_hip_dense_stats(DM, &nb, &items, &dn, &de, &rn);
   out[0] = (double)nb; out[1] = (double)items; out[2] = (double)dn; out[3] = (double)de; out[4] = (double)rn;
-  if (const void* T = gcge_hip_dense_remainder_tile(A->dense)) {
+  if (const void* T = gcge_hip_dense_remainder_tile(DM)) {
     long nt = 0, ov = 0; double xr = 0, el = 0; int brick[3] = {0, 0, 0}; long strides[2];
     gcge_hip_tile_stats(T, &nt, &ov, &xr, &el, brick, strides);
     out[5] = (double)nt; out[6] = xr; out[7] = el; out[8] = (double)ov; out[9] = brick[0]; out[10] = brick[1]; out[11] = brick[2];
   }
+  return 1;
+}
+// the grid form (spmm_star.hip): out[0..5] = nx, ny, nz, arm length of the star, rows it multiplies, rows of the matrix.  0: none.
+extern "C" int gcge_hip_mat_star_stats(const GCGE_HIP_MAT* A, long* out) {
+  if (A->star == nullptr) return 0;
+  gcge_hip_star_stats(A->star, out);
   return 1;
 }
 
@@ -917,6 +944,11 @@ static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long 
                                     y, ldy, m, d_dots, d_yy, g_stream, A->pat_near, A->d_rowval ? A->d_rowval + 8 * r0 : nullptr);
   if (rc != -1) return rc;
   // whole-matrix products only from here: neither the rows of a block nor those of a tile are a row range
+  if (A->star != nullptr && d_dots == nullptr && r0 == 0 && r1 == A->nrows && g_spmm_path == 0) {
+    rc = gcge_hip_dense_spmm(A->star_rem, dx, ldx, dy, ldy, m, g_stream, 0);     // the rows outside the grid form; writes every row
+    if (rc == 0) rc = gcge_hip_star_spmm(A->star, dx, ldx, dy, ldy, m, g_stream);   // ... then the star rows are overwritten
+  }
+  if (rc != -1) return rc;
   if (A->dense != nullptr && d_dots == nullptr && r0 == 0 && r1 == A->nrows && g_spmm_path != 1 && g_spmm_path != 3 && g_spmm_path != 4)
     rc = gcge_hip_dense_spmm(A->dense, dx, ldx, dy, ldy, m, g_stream, 0);
   if (rc != -1) return rc;

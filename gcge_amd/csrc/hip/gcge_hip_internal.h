@@ -39,6 +39,8 @@ struct GCGE_HIP_MAT_ {
   gcge_halo_exchange_fn exchange_begin; void (*exchange_end)(void*); int ov_lo, ov_hi;
   void* dense;         // supernode form (spmm_dense.hip): dense row blocks on MFMA + remainder CSR; NULL: no blocks found
   void* tile;          // LDS-staged X-tile form (spmm_tile.hip) of a matrix without a pattern form; NULL: generic kernels
+  void* star;          // grid form (spmm_star.hip): rows that are exactly a star stencil, swept plane by plane; NULL: none
+  void* star_rem;      // block form (spmm_dense.hip) of the rows the grid form leaves (multiplied first, writes every row)
   void* native_halo;   // RCCL plan of gcge_hip_mat_set_halo_rccl (rccl_comm.hip); it then owns sendbuf / recvbuf
 };
 extern "C" void gcge_hip_halo_native_free(struct GCGE_HIP_MAT_* A);

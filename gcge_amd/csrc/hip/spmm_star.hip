@@ -1,0 +1,363 @@
+// K1 (grid path) — rows that carry exactly a star stencil on a lexicographic 3-D grid, swept plane by plane.
+//
+// Same contract as the other K1 kernels (Y[:, 0:m) = A X[:, 0:m), reference app/app_ccs.c:50-139).  The matrices behind
+// BASELINE config 5 (real-space DFT Hamiltonians, test_eig_sol_SiO2_MAT.c of the reference) are a high-order finite-difference
+// Laplacian — a star of 6 R + 1 points, R = 6: 37 entries with the SAME 3 R coefficients in every row, a diagonal of its own per
+// row (the local potential), Dirichlet truncation at the faces — plus dense blocks where the atoms sit.  The tile form
+// (spmm_tile.hip) stages 8.3 X rows per row for such a star and streams 10 B per entry; here the rows whose off-diagonal
+// entries ARE that star, bit for bit, are taken out of the CSR arrays altogether ("clean" rows: a per-row diagonal and a flag
+// are all that is stored) and multiplied by a 2.5-D sweep:
+//   * a workgroup owns a 16 x 16 patch of one z-range and 8 columns; it walks z, one plane per step;
+//   * the 13 z-neighbours of a point live in REGISTERS of the lanes that own the point (a queue of 13 planes, rotated by
+//     unrolling 13 steps: every index is a compile-time constant);
+//   * the x / y arms of the current plane come from LDS: the patch's own values are written there from the queue, the 2 x 6
+//     halo strips on each side are loaded from global memory one step ahead (64-byte segments, 4 lanes per row);
+//   * per step and patch 640 X rows are fetched for 256 results (2.5 x; the patch core of plane z + 6 and the arms of plane z),
+//     no matrix entry is read at all.
+// What is not clean — rows inside atom blocks, rows with any other entry — stays a CSR matrix (the remainder, every entry of
+// those rows) and takes the block / tile / pad-8 forms; the remainder is multiplied first and writes every row, this kernel then
+// overwrites the clean ones.  One result per row either way: bit-reproducible.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <unordered_map>
+#include <vector>
+#include "gcge_hip_internal.h"
+
+namespace gcge {
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int STAR_R = 6;                       // arm length the kernel is built for (shorter stars: zero coefficients)
+constexpr int STAR_T = 16;                      // patch edge
+constexpr int STAR_PW = STAR_T + 2 * STAR_R;    // 28: patch with halo
+constexpr int STAR_NP = STAR_PW * STAR_PW;      // slots of the plane image (corners unused)
+constexpr int STAR_Q = 2 * STAR_R + 1;          // 13 planes in the register queue
+
+struct StarCoef { double cx[STAR_R + 1], cy[STAR_R + 1], cz[STAR_R + 1]; };   // [k]: coefficient of the neighbours k steps away ([0] unused)
+struct StarMat {
+  int nx, ny, nz, R; long nclean, nrows; StarCoef c; double* d_diag;   // d_diag[row]: the row's diagonal entry, NaN: not a clean row
+};
+
+// staging plan of a thread: unit u = tid + 1024 q, point u >> 2, 16-byte part u & 3
+struct StarUnit { int src; int dst; };   // src: in-plane row offset (x + nx y) or -1 (outside the grid: zero); dst: LDS index (v2d units), -1: no unit
+
+__device__ __forceinline__ v2d star_ld(const double* __restrict__ x, size_t ldx, long row, int col) {
+  return *reinterpret_cast<const v2d*>(x + (size_t)row * ldx + col);
+}
+
+// One plane step with queue phase U (compile-time): see the file header.  `z` is the output plane.
+#define STAR_SLOT(U, k) (((U) + 6 + (k) + 2 * STAR_Q) % STAR_Q)
+
+__global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz, StarCoef cf, const double* __restrict__ diag,
+    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols, int zlen, int ntx) {
+  __shared__ v2d plane[4 * STAR_NP];            // part-major: plane[part * NP + slot]
+  __shared__ v2d corein[4 * 256];
+  __shared__ v2d outt[4 * 256];
+  const int tid = threadIdx.x;
+  const int p = tid & 255, cp = tid >> 8, px = p & 15, py = p >> 4;
+  const int tile_x = blockIdx.x % ntx, tile_y = blockIdx.x / ntx;
+  const int x0 = tile_x * STAR_T, y0 = tile_y * STAR_T;
+  const int z0 = blockIdx.y * zlen, z1 = min(nz, z0 + zlen);
+  const int c0 = 8 * blockIdx.z;
+  const long plane_rows = (long)nx * ny;
+  // ---- compute lane: point (x0 + px, y0 + py), columns c0 + 2 cp, + 1
+  const int gx = x0 + px, gy = y0 + py;
+  const bool inside = gx < nx && gy < ny;
+  const long own = inside ? (long)gx + (long)nx * gy : 0;
+  const int ccol = c0 + 2 * cp;
+  const bool cvalid = ccol < ncols;
+  const int slot = (py + STAR_R) * STAR_PW + (px + STAR_R);
+  // ---- staging units
+  StarUnit su[3];
+  const int si = tid & 3;
+  const int scol = c0 + 2 * si;
+  const bool svalid = scol < ncols;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int pt = (tid + 1024 * q) >> 2;
+    int xx, yy, dst;
+    if (pt < 256) { xx = pt & 15; yy = pt >> 4; dst = -2 - (si * 256 + pt); }                  // core of plane z + 6 -> corein (encoded below)
+    else if (pt < 448) { const int j = pt - 256, ry = j / 12, a = j % 12; yy = ry; xx = a < 6 ? a - 6 : 10 + a;
+                         dst = si * STAR_NP + (yy + STAR_R) * STAR_PW + (xx + STAR_R); }
+    else if (pt < 640) { const int j = pt - 448, d = j >> 4; xx = j & 15; yy = d < 6 ? d - 6 : 10 + d;
+                         dst = si * STAR_NP + (yy + STAR_R) * STAR_PW + (xx + STAR_R); }
+    else { xx = 0; yy = 0; dst = -1; }
+    const int ax = x0 + xx, ay = y0 + yy;
+    su[q].dst = dst;
+    su[q].src = (dst != -1 && ax >= 0 && ax < nx && ay >= 0 && ay < ny && svalid) ? ax + nx * ay : -1;
+  }
+  // out-tile flush: point tid >> 2, part si
+  const int opt = tid >> 2, ox = x0 + (opt & 15), oy = y0 + (opt >> 4);
+  const bool oinside = ox < nx && oy < ny && svalid;
+  const long orow = oinside ? (long)ox + (long)nx * oy : 0;
+
+  // ---- queue: planes z0 - 6 .. z0 + 5 into slots 0 .. 11
+  v2d qv[STAR_Q];
+#pragma unroll
+  for (int t = 0; t < STAR_Q - 1; ++t) {
+    const int zz = z0 - STAR_R + t;
+    qv[t] = (inside && cvalid && zz >= 0 && zz < nz) ? star_ld(x, ldx, own + plane_rows * zz, ccol) : v2d{0.0, 0.0};
+  }
+  qv[STAR_Q - 1] = v2d{0.0, 0.0};
+  // staged loads of the first step: core of plane z0 + 6, arms of plane z0
+  v2d st[3];
+  auto stage_load = [&](int z) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int zz = su[q].dst < -1 ? z + STAR_R : z;          // core units fetch plane z + 6, arm units plane z
+      st[q] = (su[q].src >= 0 && zz >= 0 && zz < nz) ? star_ld(x, ldx, (long)su[q].src + plane_rows * zz, scol) : v2d{0.0, 0.0};
+    }
+  };
+  stage_load(z0);
+  double dg = (inside && z0 < z1) ? diag[own + plane_rows * z0] : NAN;     // diagonal of my point in the output plane (NaN: not mine to write)
+  double dgo = NAN;                                                       // the same for the point whose result I flush
+  long flush_plane = -1;
+
+  for (int zb = z0; zb < z1; zb += STAR_Q) {
+#define STAR_STEP(U)                                                                                                        \
+    {                                                                                                                       \
+      const int z = zb + (U);                                                                                               \
+      if (z >= z1) break;                                                                                                   \
+      __syncthreads();                                   /* A: last step's LDS reads are done, its results are in outt */    \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                                       \
+        if (su[q].dst >= 0) plane[su[q].dst] = st[q];                                                                       \
+        else if (su[q].dst < -1) corein[-2 - su[q].dst] = st[q];                                                            \
+      }                                                                                                                     \
+      plane[cp * STAR_NP + slot] = qv[STAR_SLOT(U, 0)];                                                                        \
+      if (flush_plane >= 0 && oinside && dgo == dgo)                                                                        \
+        __builtin_nontemporal_store(outt[si * 256 + opt], reinterpret_cast<v2d*>(y + (size_t)(orow + plane_rows * flush_plane) * ldy + scol)); \
+      __syncthreads();                                   /* B */                                                            \
+      qv[STAR_SLOT(U, STAR_R)] = corein[cp * 256 + p];      /* plane z + 6 */                                                   \
+      dgo = oinside ? diag[orow + plane_rows * z] : NAN;                                                                    \
+      flush_plane = z;                                                                                                      \
+      stage_load(z + 1);                                 /* in flight during the arithmetic below */                          \
+      const double dnext = (inside && z + 1 < z1) ? diag[own + plane_rows * (z + 1)] : NAN;                                  \
+      const double d0 = dg == dg ? dg : 0.0;                                                                                \
+      v2d acc = qv[STAR_SLOT(U, 0)] * d0;                                                                                      \
+      _Pragma("unroll") for (int k = 1; k <= STAR_R; ++k) {                                                                 \
+        const v2d zs = qv[STAR_SLOT(U, -k)] + qv[STAR_SLOT(U, k)];                                                                 \
+        acc.x = fma(cf.cz[k], zs.x, acc.x); acc.y = fma(cf.cz[k], zs.y, acc.y);                                              \
+      }                                                                                                                     \
+      const v2d* pl = plane + cp * STAR_NP + slot;                                                                          \
+      _Pragma("unroll") for (int k = 1; k <= STAR_R; ++k) {                                                                 \
+        const v2d xs = pl[-k] + pl[k];                                                                                      \
+        acc.x = fma(cf.cx[k], xs.x, acc.x); acc.y = fma(cf.cx[k], xs.y, acc.y);                                              \
+        const v2d ys = pl[-k * STAR_PW] + pl[k * STAR_PW];                                                                   \
+        acc.x = fma(cf.cy[k], ys.x, acc.x); acc.y = fma(cf.cy[k], ys.y, acc.y);                                              \
+      }                                                                                                                     \
+      outt[cp * 256 + p] = acc;                                                                                             \
+      dg = dnext;                                                                                                           \
+    }
+    STAR_STEP(0) STAR_STEP(1) STAR_STEP(2) STAR_STEP(3) STAR_STEP(4) STAR_STEP(5) STAR_STEP(6)
+    STAR_STEP(7) STAR_STEP(8) STAR_STEP(9) STAR_STEP(10) STAR_STEP(11) STAR_STEP(12)
+#undef STAR_STEP
+  }
+  __syncthreads();
+  if (flush_plane >= 0 && oinside && dgo == dgo)
+    __builtin_nontemporal_store(outt[si * 256 + opt], reinterpret_cast<v2d*>(y + (size_t)(orow + plane_rows * flush_plane) * ldy + scol));
+}
+#undef STAR_SLOT
+
+// ---------------------------------------------------------------------------------------------- upload-time analysis
+struct StarHost {
+  int nx = 0, ny = 0, nz = 0, R = 0; StarCoef c; long nclean = 0;
+  std::vector<double> diag;                                           // NaN: row stays in the remainder
+  std::vector<int> rem_rowptr, rem_col; std::vector<double> rem_val;  // every entry of the rows that are not clean
+};
+
+static inline uint64_t star_bits(double v) { uint64_t b; memcpy(&b, &v, 8); return b; }
+
+// grid strides and the star's coefficients from the offsets (column - row) most rows share; false: no star on a grid here
+static bool star_detect(int nrows, const int* rowptr, const int* colidx, const double* val, StarHost* H) {
+  if (nrows < 4096) return false;
+  const int nsamp = std::min(nrows, 8192);
+  std::unordered_map<long, int> hist;
+  for (int t = 0; t < nsamp; ++t) {
+    const int r = (int)((long)t * nrows / nsamp);
+    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) { const long o = (long)colidx[q] - r; if (o > 0) ++hist[o]; }
+  }
+  std::vector<long> offs;
+  for (auto& kv : hist) if (kv.second * 2 >= nsamp) offs.push_back(kv.first);
+  std::sort(offs.begin(), offs.end());
+  if (offs.empty() || offs[0] != 1) return false;
+  // runs: 1 .. Rx, then sy, 2 sy, .. Ry sy, then sz, 2 sz, .. Rz sz
+  size_t i = 0; int Rx = 0, Ry = 0, Rz = 0; long sy = 0, sz = 0;
+  while (i < offs.size() && offs[i] == Rx + 1) { ++Rx; ++i; }
+  if (i >= offs.size()) return false;
+  sy = offs[i];
+  while (i < offs.size() && offs[i] == (long)(Ry + 1) * sy) { ++Ry; ++i; }
+  if (i >= offs.size()) return false;
+  sz = offs[i];
+  while (i < offs.size() && offs[i] == (long)(Rz + 1) * sz) { ++Rz; ++i; }
+  if (i != offs.size()) return false;                                  // a frequent offset that is not part of a star
+  const int R = std::max(Rx, std::max(Ry, Rz));
+  if (R > STAR_R || sy <= 2L * STAR_R || sz % sy != 0 || sz / sy <= 2L * STAR_R || (long)nrows % sz != 0 || (long)nrows / sz < 2) return false;
+  H->nx = (int)sy; H->ny = (int)(sz / sy); H->nz = (int)((long)nrows / sz); H->R = R;
+  // coefficients: the most frequent value of every offset among the sampled rows; the star must be symmetric
+  memset(&H->c, 0, sizeof(H->c));
+  for (int axis = 0; axis < 3; ++axis) {
+    const int Ra = axis == 0 ? Rx : axis == 1 ? Ry : Rz;
+    const long stride = axis == 0 ? 1 : axis == 1 ? sy : sz;
+    double* dst = axis == 0 ? H->c.cx : axis == 1 ? H->c.cy : H->c.cz;
+    for (int k = 1; k <= Ra; ++k) {
+      std::unordered_map<uint64_t, int> vals[2];
+      for (int t = 0; t < nsamp; ++t) {
+        const int r = (int)((long)t * nrows / nsamp);
+        for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
+          const long o = (long)colidx[q] - r;
+          if (o == k * stride) ++vals[0][star_bits(val[q])];
+          else if (o == -k * stride) ++vals[1][star_bits(val[q])];
+        }
+      }
+      uint64_t best[2] = {0, 0};
+      for (int sgn = 0; sgn < 2; ++sgn) { int bc = -1; for (auto& kv : vals[sgn]) if (kv.second > bc) { bc = kv.second; best[sgn] = kv.first; } if (bc < 0) return false; }
+      if (best[0] != best[1]) return false;
+      memcpy(&dst[k], &best[0], 8);
+    }
+  }
+  return true;
+}
+
+// rows whose off-diagonal entries are exactly the star (truncated at the faces) -> diag[]; everything else -> remainder CSR
+static bool star_build_host(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, StarHost* H) {
+  if (ncols_local != nrows) return false;                             // slabs with halo columns keep the other forms
+  if (!star_detect(nrows, rowptr, colidx, val, H)) return false;
+  const int nx = H->nx, ny = H->ny, nz = H->nz;
+  const long sy = nx, sz = (long)nx * ny;
+  H->diag.assign((size_t)nrows, NAN);
+  H->rem_rowptr.assign((size_t)nrows + 1, 0);
+  uint64_t cb[3][STAR_R + 1];
+  for (int k = 0; k <= STAR_R; ++k) { cb[0][k] = star_bits(H->c.cx[k]); cb[1][k] = star_bits(H->c.cy[k]); cb[2][k] = star_bits(H->c.cz[k]); }
+  long nclean = 0;
+  std::vector<char> clean((size_t)nrows, 0);
+  for (int r = 0; r < nrows; ++r) {
+    const int gz = (int)(r / sz), gy = (int)((r - (long)gz * sz) / sy), gx = (int)(r - (long)gz * sz - (long)gy * sy);
+    const int g[3] = {gx, gy, gz}, dim[3] = {nx, ny, nz};
+    int expect = 0;
+    for (int a = 0; a < 3; ++a)
+      for (int k = 1; k <= STAR_R; ++k) {
+        if (cb[a][k] == 0) continue;                                  // (+0.0: no such neighbour in the star)
+        expect += (g[a] - k >= 0) + (g[a] + k < dim[a]);
+      }
+    int matched = 0; bool ok = true, have_diag = false; double dv = 0.0;
+    for (int q = rowptr[r]; q < rowptr[r + 1] && ok; ++q) {
+      const long o = (long)colidx[q] - r;
+      if (o == 0) { if (have_diag) ok = false; have_diag = true; dv = val[q]; continue; }
+      const long ao = o < 0 ? -o : o; const int sgn = o < 0 ? -1 : 1;
+      int a, k;
+      if (ao <= STAR_R) { a = 0; k = (int)ao; }
+      else if (ao % sz == 0 && ao / sz <= STAR_R) { a = 2; k = (int)(ao / sz); }
+      else if (ao % sy == 0 && ao / sy <= STAR_R) { a = 1; k = (int)(ao / sy); }
+      else { ok = false; break; }
+      const int nb = g[a] + sgn * k;
+      if (nb < 0 || nb >= dim[a] || cb[a][k] == 0 || star_bits(val[q]) != cb[a][k]) { ok = false; break; }
+      ++matched;
+    }
+    if (ok && matched == expect && !(dv != dv)) { clean[r] = 1; H->diag[r] = dv; ++nclean; }
+  }
+  H->nclean = nclean;
+  if (2 * nclean < nrows) return false;
+  for (int r = 0; r < nrows; ++r) H->rem_rowptr[r + 1] = H->rem_rowptr[r] + (clean[r] ? 0 : rowptr[r + 1] - rowptr[r]);
+  H->rem_col.resize((size_t)H->rem_rowptr[nrows]); H->rem_val.resize((size_t)H->rem_rowptr[nrows]);
+  for (int r = 0; r < nrows; ++r)
+    if (!clean[r]) {
+      memcpy(H->rem_col.data() + H->rem_rowptr[r], colidx + rowptr[r], (size_t)(rowptr[r + 1] - rowptr[r]) * sizeof(int));
+      memcpy(H->rem_val.data() + H->rem_rowptr[r], val + rowptr[r], (size_t)(rowptr[r + 1] - rowptr[r]) * sizeof(double));
+    }
+  return true;
+}
+
+}  // namespace gcge
+
+using namespace gcge;
+
+static int g_star_mode = 0;   // 0 automatic, -1 never
+extern "C" void gcge_hip_spmm_star_mode(int mode) { g_star_mode = mode; }
+extern "C" int gcge_hip_spmm_star_mode_get(void) { return g_star_mode; }
+
+// Structural self-check of the split (host only; tests): every clean row is rebuilt from the star, its diagonal and the grid and
+// compared with the CSR row, bit for bit; every other row must sit in the remainder unchanged.  0: identical; > 0: differences;
+// -1: the matrix does not take this form.  out[0..4] = nx, ny, nz, arm length, clean rows.
+extern "C" long gcge_hip_star_selfcheck(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, long* out) {
+  StarHost H;
+  if (!star_build_host(nrows, ncols_local, rowptr, colidx, val, &H)) return -1;
+  if (out) { out[0] = H.nx; out[1] = H.ny; out[2] = H.nz; out[3] = H.R; out[4] = H.nclean; }
+  long bad = 0;
+  const long sy = H.nx, sz = (long)H.nx * H.ny;
+  std::vector<std::pair<int, uint64_t>> want, got;
+  for (int r = 0; r < nrows; ++r) {
+    want.clear(); got.clear();
+    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) want.emplace_back(colidx[q], star_bits(val[q]));
+    if (H.diag[r] == H.diag[r]) {
+      if (H.rem_rowptr[r + 1] != H.rem_rowptr[r]) ++bad;
+      const int gz = (int)(r / sz), gy = (int)((r - (long)gz * sz) / sy), gx = (int)(r - (long)gz * sz - (long)gy * sy);
+      bool stored_diag = false;
+      for (auto& w : want) stored_diag |= w.first == r;
+      if (stored_diag || H.diag[r] != 0.0) got.emplace_back(r, star_bits(H.diag[r]));
+      for (int k = 1; k <= STAR_R; ++k) {
+        if (star_bits(H.c.cx[k])) { if (gx - k >= 0) got.emplace_back(r - k, star_bits(H.c.cx[k])); if (gx + k < H.nx) got.emplace_back(r + k, star_bits(H.c.cx[k])); }
+        if (star_bits(H.c.cy[k])) { if (gy - k >= 0) got.emplace_back((int)(r - k * sy), star_bits(H.c.cy[k])); if (gy + k < H.ny) got.emplace_back((int)(r + k * sy), star_bits(H.c.cy[k])); }
+        if (star_bits(H.c.cz[k])) { if (gz - k >= 0) got.emplace_back((int)(r - k * sz), star_bits(H.c.cz[k])); if (gz + k < H.nz) got.emplace_back((int)(r + k * sz), star_bits(H.c.cz[k])); }
+      }
+    } else {
+      for (int q = H.rem_rowptr[r]; q < H.rem_rowptr[r + 1]; ++q) got.emplace_back(H.rem_col[q], star_bits(H.rem_val[q]));
+    }
+    std::sort(want.begin(), want.end()); std::sort(got.begin(), got.end());
+    if (want != got) ++bad;
+  }
+  return bad;
+}
+
+struct StarBuilt { StarMat* S; StarHost* H; };
+
+extern "C" void gcge_hip_star_free(void* sm) {
+  StarMat* S = (StarMat*)sm;
+  if (!S) return;
+  hipFree(S->d_diag);
+  delete S;
+}
+
+// NULL: the matrix keeps the other forms.  Otherwise the device object, and through rem_* the CSR arrays of the remainder (rows
+// that are not clean keep all their entries, clean rows are empty), owned by the object until gcge_hip_star_release_remainder.
+static StarHost* g_star_last = nullptr;
+extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val,
+                                     const int** rem_rowptr, const int** rem_col, const double** rem_val) {
+  if (g_star_mode < 0 || nrows <= 0) return nullptr;
+  StarHost* H = new StarHost();
+  if (!star_build_host(nrows, ncols_local, rowptr, colidx, val, H)) { delete H; return nullptr; }
+  StarMat* S = new StarMat();
+  S->nx = H->nx; S->ny = H->ny; S->nz = H->nz; S->R = H->R; S->nclean = H->nclean; S->nrows = nrows; S->c = H->c;
+  GCGE_HIP_CHECK(hipMalloc(&S->d_diag, (size_t)nrows * sizeof(double)));
+  GCGE_HIP_CHECK(hipMemcpy(S->d_diag, H->diag.data(), (size_t)nrows * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<double>().swap(H->diag);
+  *rem_rowptr = H->rem_rowptr.data(); *rem_col = H->rem_col.data(); *rem_val = H->rem_val.data();
+  if (g_star_last) delete g_star_last;
+  g_star_last = H;
+  return S;
+}
+extern "C" void gcge_hip_star_release_remainder(void) { if (g_star_last) { delete g_star_last; g_star_last = nullptr; } }
+
+extern "C" void gcge_hip_star_stats(const void* sm, long* out) {   // nx, ny, nz, arm length, clean rows, rows
+  const StarMat* S = (const StarMat*)sm;
+  out[0] = S->nx; out[1] = S->ny; out[2] = S->nz; out[3] = S->R; out[4] = S->nclean; out[5] = S->nrows;
+}
+
+// Y[clean rows, 0:ncols) = (star + diagonal) X; the other rows of Y are left as they are.  -1: operands this kernel does not take.
+extern "C" int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream) {
+  const StarMat* S = (const StarMat*)sm;
+  if (ncols <= 0) return 0;
+  if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15) || d_x == d_y) return -1;
+  const int ntx = (S->nx + STAR_T - 1) / STAR_T, nty = (S->ny + STAR_T - 1) / STAR_T, npass = (ncols + 7) / 8;
+  // z ranges: enough workgroups for a few rounds over the CUs, at least 24 planes each (12 of warm-up per range)
+  int zchunks = (int)std::max(1L, std::min((long)S->nz / 24, (4L * 256 + (long)ntx * nty * npass - 1) / ((long)ntx * nty * npass)));
+  const int zlen = (S->nz + zchunks - 1) / zchunks;
+  zchunks = (S->nz + zlen - 1) / zlen;
+  hipLaunchKernelGGL(spmm_star_kernel, dim3((unsigned)(ntx * nty), (unsigned)zchunks, (unsigned)npass), dim3(1024), 0, (hipStream_t)stream,
+                     S->nx, S->ny, S->nz, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, zlen, ntx);
+  return (int)hipGetLastError();
+}

@@ -158,7 +158,7 @@ int gcge_hip_gram (int nrows, const double *d_q, long ldq, int k, const double *
 void gcge_hip_pool_release (void);
 void gcge_hip_pool_enable (int on);
 size_t gcge_hip_pool_cached_bytes (void);
-void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > dense blocks + remainder > pad-8 > CSR), 2 no pattern kernels, 3 pad-8 / CSR only, 4 no dense blocks */
+void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > star rows + block form of the rest > dense blocks + remainder > pad-8 > CSR), 2 no pattern kernels (nor the star sweep), 3 pad-8 / CSR only, 4 no dense blocks */
 /*     tile path (csrc/hip/spmm_tile.hip): matrices without a pattern form whose rows are long enough (>= 12 entries on
  *     average; automatic rule: see mode) are additionally kept as row tiles (bricks of a detected grid, or runs of rows) with 16-bit positions into
  *     the tile's list of X rows, which the kernel stages in LDS once per 8-column pass.  mode: 0 automatic (the remainder
@@ -172,6 +172,15 @@ void gcge_hip_spmm_tile_mode (int mode);
 void gcge_hip_spmm_dense_mode (int mode);
 long gcge_hip_dense_selfcheck (int nrows, int ncols_local, const int *rowptr, const int *colidx, const double *val,
 		int min_len, long *nblocks, double *share, double *fill);   /* host-only: blocks + remainder == CSR, bit for bit */
+/*     grid path (csrc/hip/spmm_star.hip): matrices without a pattern form on a lexicographic 3-D grid whose rows are mostly
+ *     ONE star stencil of arm length <= 6 with a diagonal of their own (the finite-difference Laplacian + local potential of
+ *     real-space DFT Hamiltonians): those rows leave the CSR arrays and are multiplied by a plane sweep (z-neighbours in
+ *     registers, x / y arms from LDS, 2.5 X rows fetched per row, no matrix stream), the other rows keep all their entries
+ *     and take the block form.  Needs blocks among the other rows and no halo columns.  mode: 0 automatic, -1 never      */
+void gcge_hip_spmm_star_mode (int mode);
+long gcge_hip_star_selfcheck (int nrows, int ncols_local, const int *rowptr, const int *colidx, const double *val,
+		long *out /* nx, ny, nz, arm length, star rows */);   /* host-only: star rows + remainder == CSR, bit for bit; -1: no such form */
+int  gcge_hip_mat_star_stats (const GCGE_HIP_MAT *A, long *out /* nx, ny, nz, arm length, star rows, rows */);   /* 0: the matrix has no grid form */
 /*     stencils whose coefficients differ from row to row: the pattern table is then built from the rows' column OFFSETS
  *     only and the values are streamed per row (8 doubles per row), so such matrices keep the pattern kernels (tables of
  *     at most 8 slots); 0 switches that off (takes effect at the next gcge_hip_mat_create*)                             */

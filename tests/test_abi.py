@@ -129,3 +129,28 @@ def test_supernode_split_reproduces_the_csr_arrays():
     assert check(A, 96) == 0 and nb.value >= 5 and sh.value > 0.2 and fl.value > 0.6, (nb.value, sh.value, fl.value)
     A, _ = make_problem("lap3d", 12)
     assert check(A, 24) == -1                                        # no long rows: no blocks
+
+
+def test_star_split_reproduces_the_csr_arrays():
+    """Host half of the grid path (csrc/hip/spmm_star.hip; no device call): the rows taken as "one star stencil with a
+    diagonal of their own", rebuilt from the detected grid, the star's coefficients and the stored diagonal, and the other
+    rows' remainder equal the CSR arrays bit for bit; grid and arm length are what the generator used; a slab with halo
+    columns and a 7-point Laplacian small enough to be refused do not take the form."""
+    import ctypes as C
+    from gcge_amd.lib import hip_lib, make_problem
+    g = hip_lib()
+    g.gcge_hip_star_selfcheck.restype = C.c_long
+    out = (C.c_long * 5)()
+
+    def check(M):
+        return g.gcge_hip_star_selfcheck(M.nrows, M.ncols, M.rowptr, M.colidx, M.val, out)
+    A, _ = make_problem("sio2", 24, K=8, R0=1.5, R1=3.0)
+    assert check(A) == 0 and list(out[:4]) == [24, 24, 24, 6] and 0.9 * A.nrows < out[4] < A.nrows, list(out)
+    A, _ = make_problem("sio2", 32, K=30, R0=2.0, R1=5.0)          # overlapping atoms of up to 7 cells
+    assert check(A) == 0 and list(out[:4]) == [32, 32, 32, 6] and 0.5 * A.nrows < out[4] < 0.97 * A.nrows, list(out)
+    A, _ = make_problem("sio2", 20, K=6, R0=2.0, R1=3.0, row_begin=1000, row_end=6000)   # a slab: halo columns
+    assert check(A) == -1
+    A, _ = make_problem("lap3d", 12)                                # 1728 rows: below the size where the form is considered
+    assert check(A) == -1
+    A, _ = make_problem("lap3d", 20)                                # a star of arm length 1 on 20^3: every row is clean
+    assert check(A) == 0 and list(out[:5]) == [20, 20, 20, 1, 8000], list(out)

@@ -1028,6 +1028,8 @@ def test_tile_spmm_vs_oracle(both, case):
     g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
     g.gcge_hip_spmm_tile_mode(2 if case.endswith("_forced") else 1)   # 1: every matrix without a pattern form, whatever its size; 2: every matrix
     g.gcge_hip_spmm_dense_mode(1 if case.endswith("_remainder") else -1)
+    g.gcge_hip_spmm_star_mode.argtypes = [C.c_int]
+    g.gcge_hip_spmm_star_mode(-1)          # (the star rows stay in the CSR arrays: this test is about the tile form)
     want_form = "spmm_dense+spmm_tile" if case.endswith("_remainder") else "spmm_tile"
     try:
         if case == "sio2_24":
@@ -1071,6 +1073,7 @@ def test_tile_spmm_vs_oracle(both, case):
         g.gcge_hip_set_spmm_path(0)
         g.gcge_hip_spmm_tile_mode(0)
         g.gcge_hip_spmm_dense_mode(0)
+        g.gcge_hip_spmm_star_mode(0)
 
 
 def _blocky_symmetric_csr(n, nblocks, seed):
@@ -1101,6 +1104,8 @@ def test_dense_block_spmm_vs_oracle(both, case):
     g.gcge_hip_mat_spmm_form.restype = C.c_char_p
     g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
     g.gcge_hip_spmm_dense_mode(1)         # rows of >= 24 entries may seed a block, however small the share of the blocks
+    g.gcge_hip_spmm_star_mode.argtypes = [C.c_int]
+    g.gcge_hip_spmm_star_mode(-1)         # (the star rows stay in the CSR arrays: this test is about the block form of a whole matrix)
     keep = None
     try:
         if case == "sio2_24":
@@ -1133,6 +1138,93 @@ def test_dense_block_spmm_vs_oracle(both, case):
         assert g.gcge_hip_mat_spmm_form(mh).decode() == "spmm_pad8"
         hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
         _close(a, hip.mv_to_numpy(yh, n, 0, 64), tol=1e-12, what="blocks + remainder vs pad-8 on the whole matrix")
+        hip.free_matrix(mh)
+    finally:
+        g.gcge_hip_set_spmm_path(0)
+        g.gcge_hip_spmm_dense_mode(0)
+        g.gcge_hip_spmm_star_mode(0)
+
+
+def _star_grid_csr(nx, ny, nz, R, seed, natoms, radius):
+    """A symmetric matrix on an nx x ny x nz grid (x fastest): a star of arm length R with different coefficients per axis,
+    truncated at the faces, a random diagonal, plus `natoms` dense blocks u u^T on the grid points within `radius` of random
+    centres (the shape of a real-space DFT Hamiltonian: stencil + local potential + non-local projectors)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+
+    def axis(nn, coef):
+        offs = [k + 1 for k in range(len(coef))]
+        return sp.diags([c * np.ones(nn - o) for c, o in zip(coef, offs)] + [c * np.ones(nn - o) for c, o in zip(coef, offs)],
+                        offs + [-o for o in offs], shape=(nn, nn), format="csr")
+    cx, cy, cz = -rng.random(R) - 0.1, -rng.random(R) - 0.1, -rng.random(R) - 0.1
+    Ix, Iy, Iz = sp.identity(nx), sp.identity(ny), sp.identity(nz)
+    S = sp.kron(Iz, sp.kron(Iy, axis(nx, cx))) + sp.kron(Iz, sp.kron(axis(ny, cy), Ix)) + sp.kron(axis(nz, cz), sp.kron(Iy, Ix))
+    n = nx * ny * nz
+    S = S + sp.diags(20.0 + rng.random(n))
+    zz, yy, xx = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    pts = np.stack([xx.ravel(), yy.ravel(), zz.ravel()], 1)
+    for _ in range(natoms):
+        c = rng.random(3) * np.array([nx, ny, nz])
+        d2 = ((pts - c) ** 2).sum(1)
+        idx = np.nonzero(d2 <= radius * radius)[0]
+        u = np.exp(-d2[idx] / radius ** 2) * (0.5 + rng.random())
+        S = S + sp.csr_matrix((np.outer(u, u).ravel(), (np.repeat(idx, idx.size), np.tile(idx, idx.size))), shape=(n, n))
+    S = S.tocsr(); S.sum_duplicates(); S.sort_indices()
+    return S
+
+
+@pytest.mark.parametrize("case", ["sio2_24", "sio2_20_big_atoms", "box_40x19x15_R3", "box_17x33x14_R6"])
+def test_star_sweep_spmm_vs_oracle(both, case):
+    """K1, grid path (spmm_star.hip: rows that are exactly a star stencil leave the CSR arrays and are multiplied by a plane
+    sweep — z-neighbours in registers, x / y arms from LDS; the other rows keep every entry and take the block form) against
+    the CPU oracle, scipy and the pad-8 kernel on the whole matrix: grids that are no multiple of the 16 x 16 patch, arm
+    lengths 3 and 6 with different coefficients per axis, a diagonal of its own in every row, z ranges split over
+    workgroups, widths from 2 to 130 columns (more than one 8-column pass, a last pass of 2), column offsets."""
+    from helpers import csr_from_scipy
+    hip, ora = both
+    g = hip.g
+    g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
+    g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+    g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+    g.gcge_hip_mat_star_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+    g.gcge_hip_spmm_dense_mode(1)         # small atoms: rows of >= 24 entries may seed a block
+    keep = None
+    try:
+        if case == "sio2_24":
+            A, _ = make_problem("sio2", 24, K=8, R0=1.5, R1=3.0); dims = (24, 24, 24, 6)
+        elif case == "sio2_20_big_atoms":
+            A, _ = make_problem("sio2", 20, K=20, R0=2.0, R1=5.0); dims = (20, 20, 20, 6)
+        elif case == "box_40x19x15_R3":
+            A, keep = csr_from_scipy(_star_grid_csr(40, 19, 15, 3, 5, 6, 2.6)); dims = (40, 19, 15, 3)
+        else:
+            A, keep = csr_from_scipy(_star_grid_csr(17, 33, 14, 6, 6, 5, 3.1)); dims = (17, 33, 14, 6)
+        mh, mo = hip.matrix(A), ora.matrix(A)
+        form = g.gcge_hip_mat_spmm_form(mh).decode()
+        assert form in ("spmm_star+spmm_dense+spmm_pad8", "spmm_star+spmm_dense+spmm_tile"), form
+        st = (C.c_long * 6)()
+        assert g.gcge_hip_mat_star_stats(mh, st) == 1 and tuple(st[:4]) == dims and st[5] == A.nrows and 2 * st[4] >= A.nrows, list(st)
+        n = A.nrows
+        S = csr_to_scipy(A)
+        X = uniform(12, (n, 136)) - 0.5
+        xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
+        for m, s0, s1 in [(64, 0, 0), (16, 2, 4), (2, 0, 0), (30, 4, 2), (66, 6, 0), (130, 0, 2), (17, 1, 0), (48, 8, 16)]:
+            Y0 = uniform(8, (n, 136))
+            yh, yo = hip.mv_from_numpy(mh, Y0), ora.mv_from_numpy(mo, Y0)
+            hip.ops.spmm(mh, xh, yh, (s0, s1), (s0 + m, s1 + m))
+            ora.ops.spmm(mo, xo, yo, (s0, s1), (s0 + m, s1 + m))
+            got = hip.mv_to_numpy(yh, n, 0, 136)
+            _close(got, ora.mv_to_numpy(yo, n, 0, 136), tol=1e-12, what="star sweep m=%d" % m)
+            _close(got[:, s1:s1 + m], S @ X[:, s0:s0 + m], tol=1e-12, what="star sweep vs scipy m=%d" % m)
+            hip.ops.mv_destroy(yh); ora.ops.mv_destroy(yo)
+        yh = hip.mv_from_numpy(mh, np.zeros((n, 64)))
+        hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
+        a = hip.mv_to_numpy(yh, n, 0, 64)
+        hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
+        assert np.array_equal(a, hip.mv_to_numpy(yh, n, 0, 64)), "the star sweep is not reproducible from run to run"
+        g.gcge_hip_set_spmm_path(3)
+        assert g.gcge_hip_mat_spmm_form(mh).decode() == "spmm_pad8"
+        hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
+        _close(a, hip.mv_to_numpy(yh, n, 0, 64), tol=1e-12, what="star rows + blocks vs pad-8 on the whole matrix")
         hip.free_matrix(mh)
     finally:
         g.gcge_hip_set_spmm_path(0)

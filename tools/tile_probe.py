@@ -14,6 +14,9 @@ g.gcge_hip_spmm_tile_mode.argtypes = [C.c_int]
 g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
 if os.environ.get("TILE_MODE"):
     g.gcge_hip_spmm_tile_mode(int(os.environ["TILE_MODE"]))      # 1: also keep the tile form (of the remainder when blocks exist)
+g.gcge_hip_spmm_star_mode.argtypes = [C.c_int]
+if os.environ.get("STAR_MODE"):
+    g.gcge_hip_spmm_star_mode(int(os.environ["STAR_MODE"]))      # -1: no grid form (spmm_star.hip)
 if os.environ.get("DENSE_MODE"):
     g.gcge_hip_spmm_dense_mode(int(os.environ["DENSE_MODE"]))    # -1: no supernode blocks
 g.gcge_hip_profile_enable.argtypes = [C.c_int]
@@ -35,6 +38,11 @@ if g.gcge_hip_mat_form_stats(mA, st):
     if st[5] > 0:
         print("remainder tiles %d, X rows staged per matrix row %.2f, ELL entries per non-zero %.3f, overflow entries %d, brick %dx%dx%d"
               % (st[5], st[6], st[7], st[8], st[9], st[10], st[11]), flush=True)
+g.gcge_hip_mat_star_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+ss = (C.c_long * 6)()
+if g.gcge_hip_mat_star_stats(mA, ss):
+    print("star rows %d of %d (%.1f %%) on a %dx%dx%d grid, arm length %d; the block / tile figures above are those of the other rows"
+          % (ss[4], ss[5], 100.0 * ss[4] / ss[5], ss[0], ss[1], ss[2], ss[3]), flush=True)
 hip.set_random_mode(1, 7)
 ops = hip.ops
 V = ops.mv_create(2 * m, mA); ops.set_random(V, 0, 2 * m)
