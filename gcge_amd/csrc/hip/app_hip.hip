@@ -44,6 +44,8 @@ void gcge_hip_star_release_remainder(void);
 void gcge_hip_star_free(void* sm);
 void gcge_hip_star_stats(const void* sm, long* out);
 int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
+const double* gcge_hip_star_row_mask(const void* sm);
+void gcge_hip_spmm_pad8_skip_rows(const double* d_mask);
 int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2, const double* d_x, long ldx,
                           double* d_y, long ldy, int ncols, double* d_dots, double* d_dots_yy, void* stream);
 int gcge_hip_colscale(int nrows, double* d_y, long ldy, int m, const double* d_s, void* stream);
@@ -945,7 +947,9 @@ static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long 
   if (rc != -1) return rc;
   // whole-matrix products only from here: neither the rows of a block nor those of a tile are a row range
   if (A->star != nullptr && d_dots == nullptr && r0 == 0 && r1 == A->nrows && g_spmm_path == 0) {
-    rc = gcge_hip_dense_spmm(A->star_rem, dx, ldx, dy, ldy, m, g_stream, 0);     // the rows outside the grid form; writes every row
+    gcge_hip_spmm_pad8_skip_rows(gcge_hip_star_row_mask(A->star));               // (the pad-8 kernel leaves the star rows unwritten)
+    rc = gcge_hip_dense_spmm(A->star_rem, dx, ldx, dy, ldy, m, g_stream, 0);     // the rows outside the grid form
+    gcge_hip_spmm_pad8_skip_rows(nullptr);
     if (rc == 0) rc = gcge_hip_star_spmm(A->star, dx, ldx, dy, ldy, m, g_stream);   // ... then the star rows are overwritten
   }
   if (rc != -1) return rc;

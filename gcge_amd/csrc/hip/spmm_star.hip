@@ -15,8 +15,8 @@
 //   * per step and patch 640 X rows are fetched for 256 results (2.5 x; the patch core of plane z + 6 and the arms of plane z),
 //     no matrix entry is read at all.
 // What is not clean — rows inside atom blocks, rows with any other entry — stays a CSR matrix (the remainder, every entry of
-// those rows) and takes the block / tile / pad-8 forms; the remainder is multiplied first and writes every row, this kernel then
-// overwrites the clean ones.  One result per row either way: bit-reproducible.
+// those rows) and takes the block / tile / pad-8 forms; the remainder is multiplied first (its pad-8 kernel leaves the clean rows
+// unwritten, gcge_hip_spmm_pad8_skip_rows), this kernel then writes the clean ones.  One result per row either way: bit-reproducible.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -342,6 +342,7 @@ extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, const int* rowp
 }
 extern "C" void gcge_hip_star_release_remainder(void) { if (g_star_last) { delete g_star_last; g_star_last = nullptr; } }
 
+extern "C" const double* gcge_hip_star_row_mask(const void* sm) { return ((const StarMat*)sm)->d_diag; }   // != NaN: a star row
 extern "C" void gcge_hip_star_stats(const void* sm, long* out) {   // nx, ny, nz, arm length, clean rows, rows
   const StarMat* S = (const StarMat*)sm;
   out[0] = S->nx; out[1] = S->ny; out[2] = S->nz; out[3] = S->R; out[4] = S->nclean; out[5] = S->nrows;
@@ -353,8 +354,12 @@ extern "C" int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, d
   if (ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15) || d_x == d_y) return -1;
   const int ntx = (S->nx + STAR_T - 1) / STAR_T, nty = (S->ny + STAR_T - 1) / STAR_T, npass = (ncols + 7) / 8;
-  // z ranges: enough workgroups for a few rounds over the CUs, at least 24 planes each (12 of warm-up per range)
-  int zchunks = (int)std::max(1L, std::min((long)S->nz / 24, (4L * 256 + (long)ntx * nty * npass - 1) / ((long)ntx * nty * npass)));
+  // z ranges: ONE where the patches x passes already give every CU two workgroups' worth of work (each range re-reads 12 planes
+  // of warm-up: 171^3, 64 columns: 1 / 2 / 3 / 4 ranges = 3.93 / 4.26 / 4.35 / 4.47 ms for the whole product), otherwise enough
+  // ranges of at least 24 planes to get there
+  int zchunks = (int)std::max(1L, std::min((long)S->nz / 24, (2L * 256 + (long)ntx * nty * npass - 1) / ((long)ntx * nty * npass)));
+  static const int zc_env = getenv("GCGE_STAR_ZCHUNKS") ? atoi(getenv("GCGE_STAR_ZCHUNKS")) : 0;   // (tuning aid)
+  if (zc_env > 0) zchunks = std::min(zc_env, std::max(1, S->nz / 13));
   const int zlen = (S->nz + zchunks - 1) / zchunks;
   zchunks = (S->nz + zlen - 1) / zlen;
   hipLaunchKernelGGL(spmm_star_kernel, dim3((unsigned)(ntx * nty), (unsigned)zchunks, (unsigned)npass), dim3(1024), 0, (hipStream_t)stream,
