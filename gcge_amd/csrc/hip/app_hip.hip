@@ -44,8 +44,8 @@ void gcge_hip_star_release_remainder(void);
 void gcge_hip_star_free(void* sm);
 void gcge_hip_star_stats(const void* sm, long* out);
 int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
-const double* gcge_hip_star_row_mask(const void* sm);
-void gcge_hip_spmm_pad8_skip_rows(const double* d_mask);
+const unsigned char* gcge_hip_star_host_mask(void);
+void* gcge_hip_dense_build_rows(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, const unsigned char* not_listed);
 int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2, const double* d_x, long ldx,
                           double* d_y, long ldy, int ncols, double* d_dots, double* d_dots_yy, void* stream);
 int gcge_hip_colscale(int nrows, double* d_y, long ldy, int m, const double* d_s, void* stream);
@@ -483,7 +483,7 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, i
   if (A->d_pid == nullptr) {
     const int *rr = nullptr, *rc = nullptr; const double* rv = nullptr;
     if (void* S = gcge_hip_star_build(nrows, ncols_local, rowptr, colidx, val, &rr, &rc, &rv)) {
-      void* D = gcge_hip_dense_build(nrows, ncols_local, rr, rc, rv);
+      void* D = gcge_hip_dense_build_rows(nrows, ncols_local, rr, rc, rv, gcge_hip_star_host_mask());   // (its pad-8 part lists the other rows only)
       if (D != nullptr) { A->star = S; A->star_rem = D; } else gcge_hip_star_free(S);   // (no blocks among the other rows: the forms below)
       gcge_hip_star_release_remainder();
     }
@@ -947,9 +947,7 @@ static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long 
   if (rc != -1) return rc;
   // whole-matrix products only from here: neither the rows of a block nor those of a tile are a row range
   if (A->star != nullptr && d_dots == nullptr && r0 == 0 && r1 == A->nrows && g_spmm_path == 0) {
-    gcge_hip_spmm_pad8_skip_rows(gcge_hip_star_row_mask(A->star));               // (the pad-8 kernel leaves the star rows unwritten)
-    rc = gcge_hip_dense_spmm(A->star_rem, dx, ldx, dy, ldy, m, g_stream, 0);     // the rows outside the grid form
-    gcge_hip_spmm_pad8_skip_rows(nullptr);
+    rc = gcge_hip_dense_spmm(A->star_rem, dx, ldx, dy, ldy, m, g_stream, 0);     // the rows outside the grid form (and only those)
     if (rc == 0) rc = gcge_hip_star_spmm(A->star, dx, ldx, dy, ldy, m, g_stream);   // ... then the star rows are overwritten
   }
   if (rc != -1) return rc;

@@ -29,6 +29,7 @@
 extern "C" int gcge_hip_pad8_spmm(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval, const double* d_x,
                                   long ldx, double* d_y, long ldy, int ncols, void* stream);
 extern "C" void gcge_hip_spmm_pad8_auto(double avg_octets_per_row);
+extern "C" void gcge_hip_spmm_pad8_row_map(const int* d_map);
 extern "C" void* gcge_hip_tile_build_for(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, int remainder);
 extern "C" void gcge_hip_tile_free(void* tm);
 extern "C" int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
@@ -45,6 +46,7 @@ struct DenseMat {
   int nsn, nitems, nrows; long dense_entries, dense_nnz, rem_nnz;
   DenseSn* d_sn; DenseItem* d_items; int* d_rows; int* d_cols; double* d_vals;
   int* d_orp; int* d_pcol; double* d_pval; long noct;   // remainder, pad-8 form
+  int* d_rowmap; int nlisted;                            // remainder given as a list of rows (gcge_hip_dense_build_rows); NULL: all rows
   void* rem_tile;                                        // remainder in tile form (spmm_tile.hip) when that path is switched on
 };
 
@@ -275,6 +277,7 @@ extern "C" void gcge_hip_dense_free(void* dm) {
   if (!D) return;
   hipFree(D->d_sn); hipFree(D->d_items); hipFree(D->d_rows); hipFree(D->d_cols); hipFree(D->d_vals);
   hipFree(D->d_orp); hipFree(D->d_pcol); hipFree(D->d_pval);
+  if (D->d_rowmap) hipFree(D->d_rowmap);
   if (D->rem_tile) gcge_hip_tile_free(D->rem_tile);
   delete D;
 }
@@ -288,7 +291,13 @@ static T* to_device(const std::vector<T>& v) {
 }
 
 // NULL: no block worth forming (the matrix keeps the generic kernels alone)
+extern "C" void* gcge_hip_dense_build_rows(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, const unsigned char* not_listed);
 extern "C" void* gcge_hip_dense_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val) {
+  return gcge_hip_dense_build_rows(nrows, ncols_local, rowptr, colidx, val, nullptr);
+}
+// not_listed != NULL: rows with not_listed[r] != 0 are EMPTY in these arrays and belong to another kernel (spmm_star.hip): the
+// pad-8 part of the remainder then walks a list of the other rows only and leaves those rows of Y alone
+extern "C" void* gcge_hip_dense_build_rows(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, const unsigned char* not_listed) {
   if (g_dense_mode < 0 || nrows <= 0) return nullptr;
   const int min_len = g_dense_mode == 1 ? 24 : g_dense_min_len;
   DenseHost H;
@@ -302,19 +311,26 @@ extern "C" void* gcge_hip_dense_build(int nrows, int ncols_local, const int* row
   D->d_vals = to_device(H.vals);
   std::vector<double>().swap(H.vals);
   // remainder in pad-8 form: every row padded to a multiple of 8 entries with (own column, 0.0)
-  std::vector<int> orp((size_t)nrows + 1);
+  std::vector<int> list;
+  for (int r = 0; r < nrows; ++r) if (not_listed == nullptr || !not_listed[r]) list.push_back(r);
+  const int nl = (int)list.size();
+  std::vector<int> orp((size_t)nl + 1);
   size_t noct = 0;
-  for (int r = 0; r < nrows; ++r) { orp[r] = (int)noct; noct += ((size_t)(H.rem_rowptr[r + 1] - H.rem_rowptr[r]) + 7) / 8; }
-  orp[nrows] = (int)noct;
+  for (int i = 0; i < nl; ++i) { const int r = list[i]; orp[i] = (int)noct; noct += ((size_t)(H.rem_rowptr[r + 1] - H.rem_rowptr[r]) + 7) / 8; }
+  orp[nl] = (int)noct;
   std::vector<int> pc(noct * 8); std::vector<double> pv(noct * 8);
-  for (int r = 0; r < nrows; ++r) {
-    size_t o = (size_t)orp[r] * 8;
+  for (int i = 0; i < nl; ++i) {
+    const int r = list[i];
+    size_t o = (size_t)orp[i] * 8;
     for (int k = H.rem_rowptr[r]; k < H.rem_rowptr[r + 1]; ++k, ++o) { pc[o] = H.rem_col[k]; pv[o] = H.rem_val[k]; }
-    for (; o < (size_t)orp[r + 1] * 8; ++o) { pc[o] = r; pv[o] = 0.0; }
+    for (; o < (size_t)orp[i + 1] * 8; ++o) { pc[o] = r; pv[o] = 0.0; }
   }
   D->noct = (long)noct;
   D->d_orp = to_device(orp); D->d_pcol = to_device(pc); D->d_pval = to_device(pv);
-  D->rem_tile = gcge_hip_tile_build_for(nrows, ncols_local, H.rem_rowptr.data(), H.rem_col.data(), H.rem_val.data(), 1);   // NULL: pad-8
+  D->nlisted = nl;
+  D->d_rowmap = not_listed != nullptr ? to_device(list) : nullptr;
+  // (a listed remainder stays with the pad-8 kernel: a tile writes all of its rows)
+  D->rem_tile = not_listed != nullptr ? nullptr : gcge_hip_tile_build_for(nrows, ncols_local, H.rem_rowptr.data(), H.rem_col.data(), H.rem_val.data(), 1);   // NULL: pad-8
   return D;
 }
 
@@ -338,9 +354,11 @@ extern "C" int gcge_hip_dense_spmm(const void* dm, const double* d_x, long ldx, 
   if (which != 2 && D->rem_tile != nullptr) {
     const int rc = gcge_hip_tile_spmm(D->rem_tile, d_x, ldx, d_y, ldy, ncols, stream);
     if (rc != 0) return rc;
-  } else if (which != 2) {
-    gcge_hip_spmm_pad8_auto(D->nrows > 0 ? (double)D->noct / D->nrows : 1.0);
-    const int rc = gcge_hip_pad8_spmm(D->nrows, D->d_orp, D->d_pcol, D->d_pval, d_x, ldx, d_y, ldy, ncols, stream);
+  } else if (which != 2 && D->nlisted > 0) {
+    gcge_hip_spmm_pad8_auto((double)D->noct / D->nlisted);
+    gcge_hip_spmm_pad8_row_map(D->d_rowmap);
+    const int rc = gcge_hip_pad8_spmm(D->nlisted, D->d_orp, D->d_pcol, D->d_pval, d_x, ldx, d_y, ldy, ncols, stream);
+    gcge_hip_spmm_pad8_row_map(nullptr);
     if (rc != 0) return rc;
   }
   if (which != 1 && D->nitems > 0)

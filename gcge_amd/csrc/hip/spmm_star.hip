@@ -15,8 +15,8 @@
 //   * per step and patch 640 X rows are fetched for 256 results (2.5 x; the patch core of plane z + 6 and the arms of plane z),
 //     no matrix entry is read at all.
 // What is not clean — rows inside atom blocks, rows with any other entry — stays a CSR matrix (the remainder, every entry of
-// those rows) and takes the block / tile / pad-8 forms; the remainder is multiplied first (its pad-8 kernel leaves the clean rows
-// unwritten, gcge_hip_spmm_pad8_skip_rows), this kernel then writes the clean ones.  One result per row either way: bit-reproducible.
+// those rows) and takes the block / tile / pad-8 forms; the remainder is multiplied first (its pad-8 part is a LIST of the other rows,
+// gcge_hip_dense_build_rows: the clean rows are neither read nor written there), this kernel then writes the clean ones.  One result per row either way: bit-reproducible.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz,
 struct StarHost {
   int nx = 0, ny = 0, nz = 0, R = 0; StarCoef c; long nclean = 0;
   std::vector<double> diag;                                           // NaN: row stays in the remainder
+  std::vector<char> clean;                                            // 1: star row
   std::vector<int> rem_rowptr, rem_col; std::vector<double> rem_val;  // every entry of the rows that are not clean
 };
 
@@ -234,7 +235,8 @@ static bool star_build_host(int nrows, int ncols_local, const int* rowptr, const
   uint64_t cb[3][STAR_R + 1];
   for (int k = 0; k <= STAR_R; ++k) { cb[0][k] = star_bits(H->c.cx[k]); cb[1][k] = star_bits(H->c.cy[k]); cb[2][k] = star_bits(H->c.cz[k]); }
   long nclean = 0;
-  std::vector<char> clean((size_t)nrows, 0);
+  std::vector<char>& clean = H->clean;
+  clean.assign((size_t)nrows, 0);
   for (int r = 0; r < nrows; ++r) {
     const int gz = (int)(r / sz), gy = (int)((r - (long)gz * sz) / sy), gx = (int)(r - (long)gz * sz - (long)gy * sy);
     const int g[3] = {gx, gy, gz}, dim[3] = {nx, ny, nz};
@@ -342,7 +344,9 @@ extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, const int* rowp
 }
 extern "C" void gcge_hip_star_release_remainder(void) { if (g_star_last) { delete g_star_last; g_star_last = nullptr; } }
 
-extern "C" const double* gcge_hip_star_row_mask(const void* sm) { return ((const StarMat*)sm)->d_diag; }   // != NaN: a star row
+extern "C" const unsigned char* gcge_hip_star_host_mask(void) {   // 1: a star row (valid until gcge_hip_star_release_remainder)
+  return g_star_last ? (const unsigned char*)g_star_last->clean.data() : nullptr;
+}
 extern "C" void gcge_hip_star_stats(const void* sm, long* out) {   // nx, ny, nz, arm length, clean rows, rows
   const StarMat* S = (const StarMat*)sm;
   out[0] = S->nx; out[1] = S->ny; out[2] = S->nz; out[3] = S->R; out[4] = S->nclean; out[5] = S->nrows;

@@ -19,7 +19,8 @@ out=sys.argv[1]; acc=collections.defaultdict(list)
 for f in glob.glob(out+'/p*/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(f)):
         k=r.get('Kernel_Name','')
-        if 'spmm_tile_kernel' in k: tag='tile'
+        if 'spmm_star_kernel' in k: tag='star'
+        elif 'spmm_tile_kernel' in k: tag='tile'
         elif 'spmm_pad8' in k: tag='pad8'
         elif 'spmm_dense' in k: tag='dense'
         elif 'spmm_pattern_chain2' in k: tag='chain2' + ('+values' if 'true>' in k.replace(' ', '') else '')
