@@ -105,12 +105,12 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz,
   }
   qv[STAR_Q - 1] = v2d{0.0, 0.0};
   // staged loads of the first step: core of plane z0 + 6, arms of plane z0
-  v2d st[3];
+  v2d st[3], stn[3];                                          // this step's staged rows / the next step's, in flight for a whole step
   auto stage_load = [&](int z) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const int zz = su[q].dst < -1 ? z + STAR_R : z;          // core units fetch plane z + 6, arm units plane z
-      st[q] = (su[q].src >= 0 && zz >= 0 && zz < nz) ? star_ld(x, ldx, (long)su[q].src + plane_rows * zz, scol) : v2d{0.0, 0.0};
+      stn[q] = (su[q].src >= 0 && zz >= 0 && zz < nz) ? star_ld(x, ldx, (long)su[q].src + plane_rows * zz, scol) : v2d{0.0, 0.0};
     }
   };
   stage_load(z0);
@@ -123,6 +123,8 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz,
     {                                                                                                                       \
       const int z = zb + (U);                                                                                               \
       if (z >= z1) break;                                                                                                   \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) st[q] = stn[q];                                                          \
+      stage_load(z + 1);                                 /* requested a whole step before they are written to LDS */         \
       __syncthreads();                                   /* A: last step's LDS reads are done, its results are in outt */    \
       _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                                       \
         if (su[q].dst >= 0) plane[su[q].dst] = st[q];                                                                       \
@@ -135,7 +137,6 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz,
       qv[STAR_SLOT(U, STAR_R)] = corein[cp * 256 + p];      /* plane z + 6 */                                                   \
       dgo = oinside ? diag[orow + plane_rows * z] : NAN;                                                                    \
       flush_plane = z;                                                                                                      \
-      stage_load(z + 1);                                 /* in flight during the arithmetic below */                          \
       const double dnext = (inside && z + 1 < z1) ? diag[own + plane_rows * (z + 1)] : NAN;                                  \
       const double d0 = dg == dg ? dg : 0.0;                                                                                \
       v2d acc = qv[STAR_SLOT(U, 0)] * d0;                                                                                      \
