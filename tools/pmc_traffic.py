@@ -26,10 +26,10 @@ def source_hash():
     """sha256 over the HIP sources of libgcge_hip.so (sorted by name): what `traffic` is valid for."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "gcge_amd", "csrc", "hip")
-    # the sources that define the profiled kernels (SpMM / CG passes) and the headers they share — an edit to the
-    # eigensolver or the CG's host loop does not change what a launch of these kernels moves
+    # the sources that define the profiled kernels (SpMM / CG passes): an edit to the eigensolver, to another matrix form or
+    # to the CG's host loop does not change what a launch of these kernels moves
     for f in sorted(os.listdir(d)):
-        if f in ("spmm_pattern.hip", "spmm_ring.hip") or f.endswith((".h", ".inc")):
+        if f in ("spmm_pattern.hip", "spmm_ring.hip"):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
