@@ -363,8 +363,6 @@ extern "C" int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, d
   // of warm-up: 171^3, 64 columns: 1 / 2 / 3 / 4 ranges = 3.93 / 4.26 / 4.35 / 4.47 ms for the whole product), otherwise enough
   // ranges of at least 24 planes to get there
   int zchunks = (int)std::max(1L, std::min((long)S->nz / 24, (2L * 256 + (long)ntx * nty * npass - 1) / ((long)ntx * nty * npass)));
-  static const int zc_env = getenv("GCGE_STAR_ZCHUNKS") ? atoi(getenv("GCGE_STAR_ZCHUNKS")) : 0;   // (tuning aid)
-  if (zc_env > 0) zchunks = std::min(zc_env, std::max(1, S->nz / 13));
   const int zlen = (S->nz + zchunks - 1) / zchunks;
   zchunks = (S->nz + zlen - 1) / zlen;
   hipLaunchKernelGGL(spmm_star_kernel, dim3((unsigned)(ntx * nty), (unsigned)zchunks, (unsigned)npass), dim3(1024), 0, (hipStream_t)stream,
