@@ -45,6 +45,9 @@ void gcge_hip_star_free(void* sm);
 void gcge_hip_star_stats(const void* sm, long* out);
 int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
 const unsigned char* gcge_hip_star_host_mask(void);
+int gcge_hip_star_spmm_dots(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream);
+int gcge_hip_star_coldots2_rows(int nlist, const int* d_list, const double* d_x, long ldx, const double* d_y, long ldy, int m, double* d_out, void* stream);
+const int* gcge_hip_dense_row_list(const void* dm, int* nlisted);
 void* gcge_hip_dense_build_rows(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, const unsigned char* not_listed);
 int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt, long span, long span2, const double* d_x, long ldx,
                           double* d_y, long ldy, int ncols, double* d_dots, double* d_dots_yy, void* stream);
@@ -1072,6 +1075,34 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
   // plus separate column dots beats the fused kernel (SiO2-like, 36 nnz/row: 6.8 + 1.5 ms against 11 ms)
   const bool long_rows = A != nullptr && A->nrows > 0 && (double)A->noct / A->nrows >= 2.5;
   const bool fast = aligned && (use_pat || (m >= 16 && m <= 128 && !long_rows)) && (A->nghost == 0 || m <= A->buf_cols);
+  if (!fast && host_yy != nullptr && A != nullptr && A->star != nullptr && g_spmm_path == 0 && A->nghost == 0 && vx != vy &&
+      vx->nrows == vy->nrows && A->nrows == vy->nrows) {
+    // grid form: the sweep over the star rows sums x.y and y.y of its rows on the way (registers), a short sweep over the LIST of
+    // the other rows adds theirs — no pass over the two blocks afterwards
+    const double* dx = vx->d + start[0]; double* dy = vy->d + start[1];
+    SpmmEvent ev;
+    if (g_prof_on) {
+      GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
+      ev.m = m; ev.kind = 0;
+      ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
+      GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
+    }
+    int rc = gcge_hip_dense_spmm(A->star_rem, dx, vx->ld, dy, vy->ld, m, g_stream, 0);
+    if (rc == 0) {
+      double* dd = stage_d(4 * (size_t)m);
+      rc = gcge_hip_star_spmm_dots(A->star, dx, vx->ld, dy, vy->ld, m, dd, g_stream);
+      if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
+      GCGE_REQUIRE(rc == 0, "spmm_dot: star sweep");
+      int nlist = 0; const int* list = gcge_hip_dense_row_list(A->star_rem, &nlist);
+      GCGE_REQUIRE(gcge_hip_star_coldots2_rows(nlist, list, dx, vx->ld, dy, vy->ld, m, dd + 2 * (size_t)m, g_stream) == 0, "spmm_dot: listed rows");
+      double* hd = stage_h(4 * (size_t)m);
+      GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, 4 * (size_t)m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+      GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+      for (int j = 0; j < m; ++j) { host_dots[j] = hd[j] + hd[2 * m + j]; host_yy[j] = hd[m + j] + hd[3 * m + j]; }
+      return;
+    }
+    if (g_prof_on) { hipEventDestroy(ev.e0); hipEventDestroy(ev.e1); }   // (operands the block form does not take: the generic route below)
+  }
   if (!fast) {
     HIP_MatDotMultiVec(mat, x, y, start, end, ops);
     if (host_yy && vx->nrows == vy->nrows) {   // x.y and y.y in one sweep over the two blocks

@@ -334,6 +334,11 @@ extern "C" void* gcge_hip_dense_build_rows(int nrows, int ncols_local, const int
   return D;
 }
 
+extern "C" const int* gcge_hip_dense_row_list(const void* dm, int* nlisted) {   // the rows its pad-8 part walks (NULL: all rows)
+  const DenseMat* D = (const DenseMat*)dm;
+  if (nlisted) *nlisted = D->d_rowmap != nullptr ? D->nlisted : 0;
+  return D->d_rowmap;
+}
 extern "C" int gcge_hip_dense_remainder_is_tiled(const void* dm) { return ((const DenseMat*)dm)->rem_tile != nullptr; }
 extern "C" const void* gcge_hip_dense_remainder_tile(const void* dm) { return ((const DenseMat*)dm)->rem_tile; }
 extern "C" void gcge_hip_dense_stats(const void* dm, long* nblocks, long* items, long* dense_nnz, long* dense_entries, long* rem_nnz) {

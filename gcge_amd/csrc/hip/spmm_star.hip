@@ -53,8 +53,12 @@ __device__ __forceinline__ v2d star_ld(const double* __restrict__ x, size_t ldx,
 // One plane step with queue phase U (compile-time): see the file header.  `z` is the output plane.
 #define STAR_SLOT(U, k) (((U) + 6 + (k) + 2 * STAR_Q) % STAR_Q)
 
+// DOT: additionally partial[(workgroup of this patch and z range) * 2 ncols + j] = sum over the star rows the workgroup wrote of
+// x[r, j] y[r, j], and at + ncols the same of y[r, j]^2 (columns of this pass only) — the p.w and w.w of a CG step, for free.
+template <bool DOT>
 __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz, StarCoef cf, const double* __restrict__ diag,
-    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols, int zlen, int ntx) {
+    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols, int zlen, int ntx,
+    double* __restrict__ partial) {
   __shared__ v2d plane[4 * STAR_NP];            // part-major: plane[part * NP + slot]
   __shared__ v2d corein[4 * 256];
   __shared__ v2d outt[4 * 256];
@@ -117,6 +121,7 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz,
   double dg = (inside && z0 < z1) ? diag[own + plane_rows * z0] : NAN;     // diagonal of my point in the output plane (NaN: not mine to write)
   double dgo = NAN;                                                       // the same for the point whose result I flush
   long flush_plane = -1;
+  v2d spw = v2d{0.0, 0.0}, sww = v2d{0.0, 0.0};                           // DOT: sums over my point's star rows
 
   for (int zb = z0; zb < z1; zb += STAR_Q) {
 #define STAR_STEP(U)                                                                                                        \
@@ -152,6 +157,11 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz,
         acc.x = fma(cf.cy[k], ys.x, acc.x); acc.y = fma(cf.cy[k], ys.y, acc.y);                                              \
       }                                                                                                                     \
       outt[cp * 256 + p] = acc;                                                                                             \
+      if (DOT && dg == dg) {                                                                                                \
+        const v2d xc = qv[STAR_SLOT(U, 0)];                                                                                 \
+        spw.x = fma(xc.x, acc.x, spw.x); spw.y = fma(xc.y, acc.y, spw.y);                                                    \
+        sww.x = fma(acc.x, acc.x, sww.x); sww.y = fma(acc.y, acc.y, sww.y);                                                  \
+      }                                                                                                                     \
       dg = dnext;                                                                                                           \
     }
     STAR_STEP(0) STAR_STEP(1) STAR_STEP(2) STAR_STEP(3) STAR_STEP(4) STAR_STEP(5) STAR_STEP(6)
@@ -161,8 +171,52 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz,
   __syncthreads();
   if (flush_plane >= 0 && oinside && dgo == dgo)
     __builtin_nontemporal_store(outt[si * 256 + opt], reinterpret_cast<v2d*>(y + (size_t)(orow + plane_rows * flush_plane) * ldy + scol));
+  if (DOT) {
+    // fixed-order reduction over the 256 points of every column pair: through the plane image (4 x 784 >= 2 x 1024 v2d)
+    __syncthreads();
+    plane[tid] = spw; plane[1024 + tid] = sww;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+      if (p < h) {
+        const v2d a = plane[tid + h], b = plane[1024 + tid + h];
+        plane[tid].x += a.x; plane[tid].y += a.y; plane[1024 + tid].x += b.x; plane[1024 + tid].y += b.y;
+      }
+      __syncthreads();
+    }
+    if (p == 0 && cvalid) {
+      double* out = partial + ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 2 * ncols;
+      out[ccol] = plane[tid].x; out[ccol + 1] = plane[tid].y;
+      out[ncols + ccol] = plane[1024 + tid].x; out[ncols + ccol + 1] = plane[1024 + tid].y;
+    }
+  }
 }
 #undef STAR_SLOT
+
+// partial[b * 2 m + j] = sum over the block's listed rows of x[r, j] y[r, j]; at + m: of y[r, j]^2 (rows = list[i]); 256 threads =
+// 4 row lanes x 64 columns, as coldots2_partial of vec_kernels.hip
+__global__ __launch_bounds__(256) void star_coldots2_rows(int nlist, const int* __restrict__ list, const double* __restrict__ x, size_t ldx,
+    const double* __restrict__ y, size_t ldy, int m, double* __restrict__ partial, int per_block) {
+  __shared__ double red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * per_block, i1 = min(nlist, i0 + per_block);
+  for (int c0 = 0; c0 < m; c0 += 64) {
+    const int j = c0 + tx;
+    double s = 0.0, q = 0.0;
+    if (j < m)
+      for (int i = i0 + ty; i < i1; i += 4) {
+        const size_t r = (size_t)list[i];
+        const double yv = y[r * ldy + j];
+        s = fma(x[r * ldx + j], yv, s); q = fma(yv, yv, q);
+      }
+    red[0][ty][tx] = s; red[1][ty][tx] = q;
+    __syncthreads();
+    if (ty == 0 && j < m) {
+      partial[(size_t)blockIdx.x * 2 * m + j] = (red[0][0][tx] + red[0][1][tx]) + (red[0][2][tx] + red[0][3][tx]);
+      partial[(size_t)blockIdx.x * 2 * m + m + j] = (red[1][0][tx] + red[1][1][tx]) + (red[1][2][tx] + red[1][3][tx]);
+    }
+    __syncthreads();
+  }
+}
 
 // ---------------------------------------------------------------------------------------------- upload-time analysis
 struct StarHost {
@@ -354,7 +408,11 @@ extern "C" void gcge_hip_star_stats(const void* sm, long* out) {   // nx, ny, nz
 }
 
 // Y[clean rows, 0:ncols) = (star + diagonal) X; the other rows of Y are left as they are.  -1: operands this kernel does not take.
-extern "C" int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream) {
+extern "C" int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
+extern "C" double* gcge_hip_partial_ws(size_t len);
+extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, int len, double* d_out, void* stream);
+// d_dots != NULL: d_dots[0:ncols) = sum over the star rows of x y, d_dots[ncols:2 ncols) = of y^2 (device, 2 ncols doubles)
+extern "C" int gcge_hip_star_spmm_dots(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream) {
   const StarMat* S = (const StarMat*)sm;
   if (ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15) || d_x == d_y) return -1;
@@ -365,7 +423,32 @@ extern "C" int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, d
   int zchunks = (int)std::max(1L, std::min((long)S->nz / 24, (2L * 256 + (long)ntx * nty * npass - 1) / ((long)ntx * nty * npass)));
   const int zlen = (S->nz + zchunks - 1) / zchunks;
   zchunks = (S->nz + zlen - 1) / zlen;
-  hipLaunchKernelGGL(spmm_star_kernel, dim3((unsigned)(ntx * nty), (unsigned)zchunks, (unsigned)npass), dim3(1024), 0, (hipStream_t)stream,
-                     S->nx, S->ny, S->nz, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, zlen, ntx);
+  if (d_dots == nullptr) {
+    hipLaunchKernelGGL(spmm_star_kernel<false>, dim3((unsigned)(ntx * nty), (unsigned)zchunks, (unsigned)npass), dim3(1024), 0, (hipStream_t)stream,
+                       S->nx, S->ny, S->nz, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, zlen, ntx, (double*)nullptr);
+    return (int)hipGetLastError();
+  }
+  // with the column sums of the star rows: one partial row per (patch, z range), summed in fixed order
+  const int nb = ntx * nty * zchunks;
+  double* part = gcge_hip_partial_ws((size_t)nb * 2 * ncols);
+  hipLaunchKernelGGL(spmm_star_kernel<true>, dim3((unsigned)(ntx * nty), (unsigned)zchunks, (unsigned)npass), dim3(1024), 0, (hipStream_t)stream,
+                     S->nx, S->ny, S->nz, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, zlen, ntx, part);
+  gcge_hip_reduce_partials(part, nb, 2 * ncols, d_dots, stream);
+  return (int)hipGetLastError();
+}
+extern "C" int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream) {
+  return gcge_hip_star_spmm_dots(sm, d_x, ldx, d_y, ldy, ncols, nullptr, stream);
+}
+// d_out[0:m) = sum over the LISTED rows of x[r, j] y[r, j], d_out[m:2m) = of y[r, j]^2 (the rows the sweep does not multiply)
+extern "C" int gcge_hip_star_coldots2_rows(int nlist, const int* d_list, const double* d_x, long ldx, const double* d_y, long ldy, int m,
+                                           double* d_out, void* stream) {
+  if (m <= 0) return 0;
+  if (nlist <= 0) return (int)hipMemsetAsync(d_out, 0, 2 * (size_t)m * sizeof(double), (hipStream_t)stream);
+  int nb = (nlist + 511) / 512; if (nb > 2048) nb = 2048;
+  const int per = ((nlist + nb - 1) / nb + 3) / 4 * 4;
+  nb = (nlist + per - 1) / per;
+  double* part = gcge_hip_partial_ws((size_t)nb * 2 * m);
+  hipLaunchKernelGGL(star_coldots2_rows, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, nlist, d_list, d_x, (size_t)ldx, d_y, (size_t)ldy, m, part, per);
+  gcge_hip_reduce_partials(part, nb, 2 * m, d_out, stream);
   return (int)hipGetLastError();
 }

@@ -1221,6 +1221,19 @@ def test_star_sweep_spmm_vs_oracle(both, case):
         a = hip.mv_to_numpy(yh, n, 0, 64)
         hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
         assert np.array_equal(a, hip.mv_to_numpy(yh, n, 0, 64)), "the star sweep is not reproducible from run to run"
+        # the product with its column sums, as the fused CG asks for it (x.y and y.y: summed by the sweep over its rows + a short
+        # sweep over the list of the other rows)
+        g.gcge_hip_spmm_dot2_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        for m, s0, s1 in [(64, 0, 0), (30, 4, 2), (2, 8, 0)]:
+            y2 = hip.mv_from_numpy(mh, uniform(9, (n, 64)))
+            dots, yy = np.zeros(m), np.zeros(m)
+            st2, en2 = (C.c_int * 2)(s0, s1), (C.c_int * 2)(s0 + m, s1 + m)
+            g.gcge_hip_spmm_dot2_mv(mh, xh, y2, st2, en2, dots.ctypes.data, yy.ctypes.data, hip.ops_handle)
+            Yw = S @ X[:, s0:s0 + m]
+            _close(hip.mv_to_numpy(y2, n, 0, 64)[:, s1:s1 + m], Yw, tol=1e-12, what="star product with column sums m=%d" % m)
+            assert np.allclose(dots, (X[:, s0:s0 + m] * Yw).sum(0), rtol=1e-11, atol=1e-9) and np.allclose(yy, (Yw * Yw).sum(0), rtol=1e-11), m
+            hip.ops.mv_destroy(y2)
         g.gcge_hip_set_spmm_path(3)
         assert g.gcge_hip_mat_spmm_form(mh).decode() == "spmm_pad8"
         hip.ops.spmm(mh, xh, yh, (0, 0), (64, 64))
