@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--atoms", default="2000,2.0,5.0", help="c5: K,R0,R1 of the SiO2-like generator (SURVEY 8d)")
     ap.add_argument("--cpu-size", type=int, default=50, help="grid size of the CPU baseline (50 = BASELINE config 1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dense-shapes", action="store_true", help="after the timed steps, print the in-solve rate of the Gram / panel-update kernels per shape (k, m) on stderr")
     ap.add_argument("--orth", default="chol", help="block orthonormalisation scheme for X and W: chol | mgs | bgs")
     a = ap.parse_args()
     if a.config == "c4":
@@ -346,6 +347,9 @@ def main():
     for _ in range(args.warmup):
         run_gcg(hip.ops_handle, mat, None, solver_args, flag=1)
     g.gcge_hip_profile_enable(1)
+    if args.dense_shapes:
+        g.gcge_hip_dense_profile.argtypes = [C.c_int]
+        g.gcge_hip_dense_profile(1)
     g.gcge_hip_bpcg_time_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_double), C.c_int]
     g.gcge_hip_bpcg_time_stats(None, None, 1)
     barrier()
@@ -386,6 +390,12 @@ def main():
     stats = {k: prof(k, args.block) for k in (0, 2, 3)}
     spmm_ms_all = sum(prof(k, 0)[1] for k in (0, 2, 3))
     g.gcge_hip_profile_enable(0)
+    if args.dense_shapes and rank == 0:
+        buf = C.create_string_buffer(1 << 16)
+        g.gcge_hip_dense_profile_report.argtypes = [C.c_char_p, C.c_int]
+        g.gcge_hip_dense_profile_report(buf, 1 << 16)
+        sys.stderr.write("in-solve rate of the dense kernels over the %d timed steps (n = %d rows per rank):\n%s" % (args.steps, A.nrows, buf.value.decode()))
+        g.gcge_hip_dense_profile(0)
 
     # parity guard inside the bench (all ranks take part: the slots are collective)
     ev, res = last[0], last[1]

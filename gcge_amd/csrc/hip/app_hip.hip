@@ -130,6 +130,7 @@ static int g_rand_mode = 0; static unsigned long long g_rand_seed = 0x5DEECE66Du
 // a solver stack that was NOT written for this layout spends its time (tests/refstack_on_hip.py).
 #include <chrono>
 #include <map>
+#include <tuple>
 #include <string>
 static int g_slot_timing = 0;
 static std::map<std::string, std::pair<long, double>> g_slot_time;
@@ -152,6 +153,50 @@ extern "C" int gcge_hip_slot_timing_report(char* buf, int len) {
     char line[256];
     snprintf(line, sizeof line, "%-44s calls %8ld  %9.3f s  %8.3f ms/call\n", kv.first.c_str(), kv.second.first, kv.second.second,
              1e3 * kv.second.second / (double)kv.second.first);
+    out += line;
+  }
+  if (buf != nullptr && len > 0) { strncpy(buf, out.c_str(), (size_t)len - 1); buf[len - 1] = 0; }
+  return (int)out.size();
+}
+
+// ------------------------------------------------------------------ in-solve rate of the dense kernels per shape (measurement aid)
+// gcge_hip_dense_profile(1): every Gram (K2) and panel update (K3) launched by the slots is bracketed by two HIP events on the
+// back-end's stream (no synchronisation); gcge_hip_dense_profile_report sums them per (kernel, k, m): calls, average time and
+// 2 n k m flop / time — the TF a solve actually sees for each shape, not a stand-alone benchmark's.
+struct DenseEvent { hipEvent_t e0, e1; int kind, k, m; long n; };   // kind 0: Gram, 1: panel update
+static std::vector<DenseEvent> g_dense_prof;
+static int g_dense_prof_on = 0;
+extern "C" void gcge_hip_dense_profile(int on) {
+  for (auto& e : g_dense_prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
+  g_dense_prof.clear();
+  g_dense_prof_on = on;
+}
+struct DenseProfScope {
+  DenseEvent ev; bool on;
+  DenseProfScope(int kind, long n, int k, int m) : on(g_dense_prof_on != 0) {
+    if (!on) return;
+    ev.kind = kind; ev.k = k; ev.m = m; ev.n = n;
+    GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
+    GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
+  }
+  ~DenseProfScope() { if (on) { hipEventRecord(ev.e1, g_stream); g_dense_prof.push_back(ev); } }
+};
+extern "C" int gcge_hip_dense_profile_report(char* buf, int len) {
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+  std::map<std::tuple<int, int, int>, std::tuple<long, double, double>> acc;   // (kind, k, m) -> calls, ms, flop
+  for (auto& e : g_dense_prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.e0, e.e1) != hipSuccess) continue;
+    auto& a = acc[std::make_tuple(e.kind, e.k, e.m)];
+    std::get<0>(a) += 1; std::get<1>(a) += ms; std::get<2>(a) += 2.0 * (double)e.n * e.k * e.m;
+  }
+  std::string out;
+  for (auto& kv : acc) {
+    char line[256];
+    const long calls = std::get<0>(kv.second); const double ms = std::get<1>(kv.second), fl = std::get<2>(kv.second);
+    snprintf(line, sizeof line, "%-13s k = %4d  m = %4d  calls %6ld  %9.3f ms per call  %6.1f TF  (%.1f ms in all)\n",
+             std::get<0>(kv.first) == 0 ? "Gram" : "panel update", std::get<1>(kv.first), std::get<2>(kv.first), calls, ms / calls,
+             ms > 0 ? fl / (ms * 1e-3) * 1e-12 : 0.0, ms);
     out += line;
   }
   if (buf != nullptr && len > 0) { strncpy(buf, out.c_str(), (size_t)len - 1); buf[len - 1] = 0; }
@@ -844,6 +889,7 @@ static void HIP_MultiVecLinearComb(void** x, void** y, int is_vec, int* start, i
     if (beta != nullptr) for (int j = 0; j < mp; ++j) hc[(size_t)k * mp + j] = (incb == 0) ? *beta : beta[(size_t)(j0 + j) * incb];
     double* dc = stage_d(len);
     GCGE_HIP_CHECK(hipMemcpyAsync(dc, hc, len * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    DenseProfScope prof_(1, vy->nrows, k, mp);
     int rc = gcge_hip_lincomb(vy->nrows, vx->d + start[0], vx->ld, k, dc, mp, beta ? dc + (size_t)k * mp : nullptr,
                               vy->d + start[1] + j0, vy->ld, g_stream);
     GCGE_REQUIRE(rc == 0, "MultiVecLinearComb: kernel launch");
@@ -882,7 +928,7 @@ static void HIP_MultiVecLocalInnerProd(char nsd, void** x, void** y, int is_vec,
   }
   double* dg = stage_d((size_t)k * m);
   if (m == 1) gcge_hip_panel_dot1(vx->nrows, vx->d + start[0], vx->ld, k, vy->d + start[1], vy->ld, dg, g_stream);   // panel . column
-  else gcge_hip_gram(vx->nrows, vx->d + start[0], vx->ld, k, vy->d + start[1], vy->ld, m, dg, g_stream);
+  else { DenseProfScope prof_(0, vx->nrows, k, m); gcge_hip_gram(vx->nrows, vx->d + start[0], vx->ld, k, vy->d + start[1], vy->ld, m, dg, g_stream); }
   double* hg = stage_h((size_t)k * m);
   GCGE_HIP_CHECK(hipMemcpyAsync(hg, dg, (size_t)k * m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));

@@ -260,6 +260,10 @@ int gcge_hip_coldots (int nrows, const double *d_x, long ldx, const double *d_y,
 /*     d_out[j] = x_j . y_j, d_out[m + j] = y_j . y_j in one sweep (bitwise what two gcge_hip_coldots calls return) */
 int gcge_hip_coldots2 (int nrows, const double *d_x, long ldx, const double *d_y, long ldy, int m,
 		double *d_out, void *stream);
+/*     in-solve rate of K2 / K3 per shape: bracket every Gram and panel update the slots launch with HIP events (no
+ *     synchronisation added); the report lists, per (kernel, k, m), calls, average time and 2 n k m flop / time            */
+void gcge_hip_dense_profile (int on);
+int  gcge_hip_dense_profile_report (char *buf, int len);
 /* K3  Y[:,0:m) = X[:,0:k) C + Y diag(beta);  d_c row-major k x m; d_beta NULL => overwrite */
 int gcge_hip_lincomb (int nrows, const double *d_x, long ldx, int k, const double *d_c, int m,
 		const double *d_beta, double *d_y, long ldy, void *stream);
