@@ -208,7 +208,8 @@ extern "C" int gcge_hip_gram(int nrows, const double* d_q, long ldq, int k, cons
   if (nrows <= 0) return (int)hipMemsetAsync(d_g, 0, (size_t)k * m * sizeof(double), st);
   const int ti = (k + 63) / 64, tj = (m + 63) / 64;
   // waves of a block side by side on Q tiles when the tile count divides (P rows shared through L1); an idle wave
-  // (3 tiles on 4 waves) costs more than it saves: 10.6 vs 8.5 ms at k = 192
+  // (3 tiles on 4 waves) costs more than it saves: 10.6 vs 8.5 ms at k = 192 — and so do blocks of three waves, one tile
+  // each (round 3, tools/gram_probe.py: 9.9 vs 8.4 ms)
   const int tib = ti % 4 == 0 ? 4 : (ti % 2 == 0 ? 2 : 1);
   const int gy = (ti + tib - 1) / tib;
   // enough blocks to fill 256 CUs a few times over, chunks a multiple of 16 rows
