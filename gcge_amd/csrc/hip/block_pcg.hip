@@ -240,6 +240,62 @@ __global__ __launch_bounds__(256) void cg_update_rp(long nrows, const double* __
   }
 }
 
+// The same step without a stored residual (ring of >= 3 slots): r_k = p_k - beta_{k-1} p_{k-1} is rebuilt from the two directions
+// the ring holds, so the sweep reads w, p_k, p_{k-1} and writes p_{k+1} — 4 streams instead of 5.  bprev = 0 in the first
+// iteration and after a restart (p_k = r_k); retired columns are copied to the next slot.  The rebuilt residual carries an error
+// of eps |p| instead of eps |r|: only where the stopping rule is loose (HIP_BlockPCG_run: rate >= 1e-4, <= 100 iterations).
+template <int UNR>
+__global__ __launch_bounds__(256) void cg_update_p_implicit(long nrows, const double* __restrict__ w, long ldw,
+    const double* __restrict__ pprev, const double* __restrict__ pold, double* __restrict__ pnew, long ldp, int m,
+    const double* __restrict__ alpha, const double* __restrict__ beta, const double* __restrict__ bprev, const int* __restrict__ flag,
+    double* __restrict__ partial, int tpr) {
+  __shared__ double red[256][2];
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr, rpb = 256 / tpr;
+  const int j = 2 * tx;
+  double s0 = 0.0, s1 = 0.0;
+  const bool mine = j < m;
+  const int f0 = mine ? flag[j] : 0, f1 = mine ? flag[j + 1] : 0;
+  if (mine) {
+    const double a0 = f0 ? alpha[j] : 0.0, a1 = f1 ? alpha[j + 1] : 0.0;
+    const double cr0 = f0 ? 1.0 : 0.0, cr1 = f1 ? 1.0 : 0.0;
+    const double cb0 = f0 ? beta[j] : 1.0, cb1 = f1 ? beta[j + 1] : 1.0;
+    const double bp0 = f0 ? bprev[j] : 0.0, bp1 = f1 ? bprev[j + 1] : 0.0;
+    const long step = rpb, group = (long)rpb * UNR;
+    const long slab = (((nrows + gridDim.x - 1) / gridDim.x) + group - 1) / group * group;
+    const long rend = min(nrows, ((long)blockIdx.x + 1) * slab);
+    auto one = [&](long rr, v2d wv, v2d qv, v2d pv) {
+      v2d rn = {fma(-a0, wv.x, fma(-bp0, qv.x, pv.x)), fma(-a1, wv.y, fma(-bp1, qv.y, pv.y))};
+      v2d pn = {fma(cb0, pv.x, cr0 * rn.x), fma(cb1, pv.y, cr1 * rn.y)};
+      __builtin_nontemporal_store(pn, reinterpret_cast<v2d*>(pnew + rr * ldp + j));
+      s0 = fma(cr0 * rn.x, rn.x, s0); s1 = fma(cr1 * rn.y, rn.y, s1);
+    };
+    long row = (long)blockIdx.x * slab + ty;
+    for (; row + (UNR - 1) * step < rend; row += step * UNR) {
+      v2d wv[UNR], qv[UNR], pv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long rr = row + u * step;
+        wv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(w + rr * ldw + j));
+        qv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(pprev + rr * ldp + j));
+        pv[u] = *reinterpret_cast<const v2d*>(pold + rr * ldp + j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) one(row + u * step, wv[u], qv[u], pv[u]);
+    }
+    for (; row < rend; row += step)
+      one(row, *reinterpret_cast<const v2d*>(w + row * ldw + j), *reinterpret_cast<const v2d*>(pprev + row * ldp + j),
+          *reinterpret_cast<const v2d*>(pold + row * ldp + j));
+  }
+  red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1;
+  __syncthreads();
+  if (ty == 0 && mine) {
+    for (int q = 1; q < rpb; ++q) { s0 += red[q * tpr + tx][0]; s1 += red[q * tpr + tx][1]; }
+    partial[(long)blockIdx.x * m + j] = s0;
+    partial[(long)blockIdx.x * m + j + 1] = s1;
+  }
+}
+
 struct RingPtrs { const double* p[16]; };
 // x[:, j] += sum_{q < cnt} coef[q * m + j] * ring[q][:, j]      (cnt <= 16)
 __global__ __launch_bounds__(256) void cg_accum_x(long nrows, RingPtrs ring, int cnt, long ldp, double* __restrict__ x,
@@ -689,6 +745,9 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       s->residual = s->h_pin[0];
       return;
     }
+    // stored-product form without a stored residual: same rule as the device-scalar loop above
+    const bool host_implicit_r = !recompute && R >= 3 && (g_residual_form == 1 || (g_residual_form == 0 && s->rate >= 1e-4 && s->max_iter <= 100));
+    std::vector<double> bprev_host(nrhs, 0.0);
     while (niter < s->max_iter && nact > 0) {
       s->col_iters += nrhs; s->active_col_iters += nact;
       int alo = 0, ahi = nrhs;
@@ -734,6 +793,18 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
         long ldq;
         const double* pold = gcge_hip_mv_device_ptr(slots[cur], &ldq);
         double* pnew = gcge_hip_mv_device_ptr(slots[(cur + 1) % R], &ldq);
+        if (host_implicit_r) {   // r is not stored: rebuilt from p_k and p_{k-1} (beta_{k-1} of the previous step, 0 at the start)
+          const double* pprev = gcge_hip_mv_device_ptr(slots[(cur + R - 1) % R], &ldq);
+          double* d_bprev = part + (size_t)nb * aw + aw;   // (behind the partial sums and their total; J * nrhs doubles are reserved there)
+          GCGE_HIP_CHECK(hipStreamSynchronize(st));        // the pinned staging below may still feed the upload() above
+          memcpy(s->h_pin, bprev_host.data() + alo, aw * sizeof(double));
+          GCGE_HIP_CHECK(hipMemcpyAsync(d_bprev, s->h_pin, aw * sizeof(double), hipMemcpyHostToDevice, st));
+          hipLaunchKernelGGL(cg_update_p_implicit<4>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw,
+                             (niter == 0 ? pold : pprev) + alo, pold + alo, pnew + alo, ldp, aw, s->d_coef + s->cap, s->d_coef,
+                             (const double*)d_bprev, s->d_flag, part, cg_tpr(aw));
+          for (int j = alo; j < ahi; ++j) bprev_host[j] = active[j] ? bet[j] : 0.0;
+          ++s->implicit_r_iters;
+        } else
         hipLaunchKernelGGL(cg_update_rp<4>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, dw + alo, ldw, dr + alo, ldr,
                            pold + alo, pnew + alo, ldp, aw, s->d_coef + s->cap, s->d_coef, s->d_flag, part, cg_tpr(aw));
         for (int j = 0; j < nrhs; ++j) ahist[(size_t)npend * nrhs + j] = (j >= alo && j < ahi && active[j]) ? coef[j] : 0.0;

@@ -1652,3 +1652,49 @@ def test_coldots2_equals_two_column_dot_sweeps(hip, n, m, ldx, ldy):
     Xh, Yh = X[:, :m].cpu().numpy(), Y[:, :m].cpu().numpy()
     ref = np.concatenate([(Xh * Yh).sum(0), (Yh * Yh).sum(0)])
     assert np.allclose(one.cpu().numpy(), ref, rtol=1e-12, atol=1e-12 * n)
+
+
+@pytest.mark.parametrize("kind,size,kw", [("sio2", 12, {"K": 10, "R0": 2.0, "R1": 3.0}), ("fe3d", 12, {})])
+def test_fused_cg_stored_product_without_stored_residual(hip, kind, size, kw):
+    """The stored-product form of the fused CG (matrices whose product is not worth forming twice: no pattern form, or a pattern
+    without the line exchange) with the residual NOT stored — r_k = p_k - beta_{k-1} p_{k-1} rebuilt from the ring, 4 block
+    streams per sweep instead of 5 (block_pcg.hip: cg_update_p_implicit) — against the stored-residual form and a direct solve:
+    same iteration counts, true residuals |b - A x| / |b| within the requested reduction, for the loose rate the GCG harness
+    uses (automatic rule: not stored) and, forced, for 1e-6."""
+    import scipy.sparse.linalg as sla
+    g = hip.g
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    g.gcge_hip_bpcg_residual_form.argtypes = [C.c_int]
+    g.gcge_hip_bpcg_implicit_r_iters.restype = C.c_long
+    g.gcge_hip_bpcg_recompute_iters.restype = C.c_long
+    A, _ = make_problem(kind, size, **kw)
+    S = csr_to_scipy(A); n = A.nrows
+    mat = hip.matrix(A)
+    nrhs = 8
+    Bm = uniform(83, (n, nrhs)) - 0.5
+    nb = np.linalg.norm(Bm, axis=0)
+    res = {}
+    try:
+        for rate, forms in ((1e-2, (0, 2)), (1e-6, (1, 2))):
+            for form in forms:
+                g.gcge_hip_bpcg_residual_form(form)
+                g.gcge_hip_bpcg_setup(hip.ops_handle, 60, rate, 1e-300, b"abs")
+                b = hip.mv_from_numpy(mat, Bm); x = hip.mv_from_numpy(mat, np.zeros((n, nrhs)))
+                bi, br = g.gcge_hip_bpcg_implicit_r_iters(), g.gcge_hip_bpcg_recompute_iters()
+                hip.ops.multi_linear_solver(mat, b, x, (0, 0), (nrhs, nrhs))
+                it = C.c_int(); g.gcge_hip_bpcg_stats(None, None, C.byref(it))
+                X = hip.mv_to_numpy(x, n, 0, nrhs)
+                res[(rate, form)] = (it.value, (np.linalg.norm(Bm - S @ X, axis=0) / nb).max(), g.gcge_hip_bpcg_implicit_r_iters() - bi,
+                                     g.gcge_hip_bpcg_recompute_iters() - br)
+                hip.ops.mv_destroy(b, nrhs); hip.ops.mv_destroy(x, nrhs)
+    finally:
+        g.gcge_hip_bpcg_residual_form(0)
+        g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    for rate, fi in ((1e-2, 0), (1e-6, 1)):
+        it_i, tr_i, ni_i, rc_i = res[(rate, fi)]; it_s, tr_s, ni_s, rc_s = res[(rate, 2)]
+        assert rc_i == 0 and rc_s == 0, "this matrix was expected to take the stored-product form"
+        assert ni_i == it_i and ni_s == 0, (ni_i, it_i, ni_s)
+        assert abs(it_i - it_s) <= 1, (rate, it_i, it_s)
+        assert tr_i <= 10.0 * rate and tr_s <= 10.0 * rate, (rate, tr_i, tr_s)
+        assert tr_i <= max(3.0 * tr_s, 1e-12), (rate, tr_i, tr_s)
+    hip.free_matrix(mat)

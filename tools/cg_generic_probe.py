@@ -21,6 +21,10 @@ ops = hip.ops
 b = ops.mv_create(m, mA); x = ops.mv_create(m, mA)
 ops.set_random(b, 0, m)
 g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-30, 1e-300, b"abs")     # 30 iterations whatever the residual
+g.gcge_hip_bpcg_residual_form.argtypes = [C.c_int]
+form = int(os.environ.get("RESIDUAL_FORM", "1"))                      # 1: r rebuilt from the ring (what the GCG harness's rate 1e-2 selects), 2: stored
+g.gcge_hip_bpcg_residual_form(form)
+print("residual form", form, flush=True)
 for rep in range(3):
     ops.axpby(0.0, None, 0.0, x, (0, 0), (m, m))
     hip.sync(); t0 = time.perf_counter()
