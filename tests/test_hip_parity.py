@@ -1698,3 +1698,25 @@ def test_fused_cg_stored_product_without_stored_residual(hip, kind, size, kw):
         assert tr_i <= 10.0 * rate and tr_s <= 10.0 * rate, (rate, tr_i, tr_s)
         assert tr_i <= max(3.0 * tr_s, 1e-12), (rate, tr_i, tr_s)
     hip.free_matrix(mat)
+
+
+def test_dense_profile_reports_the_shapes_a_solve_used(hip):
+    """gcge_hip_dense_profile / gcge_hip_dense_profile_report (bench.py --dense-shapes): every Gram and panel update a solve
+    launches shows up under its (k, m) with a call count, a time and a rate; switching the profile off empties it."""
+    g = hip.g
+    g.gcge_hip_dense_profile.argtypes = [C.c_int]
+    g.gcge_hip_dense_profile_report.argtypes = [C.c_char_p, C.c_int]
+    g.gcge_hip_dense_profile(1)
+    try:
+        ev, res = gcg_on(hip, "lap3d", 16, ["-nevConv", 6, "-blockSize", 4, "-nevMax", 12])
+        buf = C.create_string_buffer(1 << 16)
+        assert g.gcge_hip_dense_profile_report(buf, 1 << 16) > 0
+        lines = [ln for ln in buf.value.decode().splitlines() if ln.strip()]
+        assert any(ln.startswith("Gram") for ln in lines) and any(ln.startswith("panel update") for ln in lines), lines
+        for ln in lines:
+            assert " k = " in ln and " m = " in ln and " calls " in ln and " TF" in ln, ln
+    finally:
+        g.gcge_hip_dense_profile(0)
+    buf = C.create_string_buffer(256)
+    assert g.gcge_hip_dense_profile_report(buf, 256) == 0
+    assert res.nevConv >= 6
