@@ -46,11 +46,11 @@ if g.gcge_hip_mat_star_stats(mA, ss):
 hip.set_random_mode(1, 7)
 ops = hip.ops
 V = ops.mv_create(2 * m, mA); ops.set_random(V, 0, 2 * m)
-W1 = ops.mv_create(m, mA); W2 = ops.mv_create(m, mA)
+W1 = ops.mv_create(m, mA); W2 = ops.mv_create(m, mA); W4 = ops.mv_create(m, mA)
 res = {}
 for path in (0, 4, 3):
     g.gcge_hip_set_spmm_path(path)
-    Wv = W1 if path != 3 else W2
+    Wv = {0: W1, 4: W4, 3: W2}[path]
     ops.spmm(mA, V, Wv, (m, 0), (2 * m, m)); hip.sync()
     g.gcge_hip_profile_enable(1)
     for _ in range(5):
@@ -63,4 +63,4 @@ for path in (0, 4, 3):
     print("path %d (%s) m=%d: %.3f ms  %.1f GB/s on CSR bytes (%.1f%% of 8 TB/s)" % (path, g.gcge_hip_mat_spmm_form(mA).decode(), m, t, by.value / cnt / t * 1e-6, by.value / cnt / t * 1e-6 / 80), flush=True)
 g.gcge_hip_set_spmm_path(0)
 a = hip.mv_to_numpy(W1, A.nrows, 0, 4); b = hip.mv_to_numpy(W2, A.nrows, 0, 4)
-print("max |tile - pad8| / max|pad8| =", float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
+print("max |automatic form - pad8| / max|pad8| =", float(np.max(np.abs(a - b)) / np.max(np.abs(b))))
