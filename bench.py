@@ -271,7 +271,8 @@ def main():
         else:
             part0 = gdist.row_partition(n_global, world)
             A0, _ = make_problem("sio2", N, row_begin=part0[rank], row_end=part0[rank + 1], **kw)
-            part = gdist.partition_by_nnz(dist, A0, part0) if world > 1 else part0
+            # cuts on plane boundaries (a plane of N^2 rows is 1 / N of the matrix): every slab keeps the plane sweep of spmm_star.hip
+            part = gdist.partition_by_nnz(dist, A0, part0, align=N * N) if world > 1 else part0
             A, _ = make_problem("sio2", N, row_begin=part[rank], row_end=part[rank + 1], **kw)
             mat = comm.slab_matrix(A, part) if isinstance(comm, gdist.NativeComm) else gdist.hip_slab_matrix(hip, comm, A, n_global, part)
         workload = ("SiO2-like matrix on a %d^3 grid (12th-order 37-point stencil + %s atom blocks, R = %s + %s u1 u2; n=%d global), "

@@ -38,7 +38,7 @@ void gcge_hip_dense_stats(const void* dm, long* nblocks, long* items, long* dens
 void gcge_hip_tile_stats(const void* tm, long* ntiles, long* ov_nnz, double* xrows_per_row, double* ell_per_nnz, int* brick, long* strides);
 int gcge_hip_dense_spmm(const void* dm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream, int which);
 int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
-void* gcge_hip_star_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val,
+void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin, long nglobal, const int* ghost, const int* rowptr, const int* colidx, const double* val,
                           const int** rem_rowptr, const int** rem_col, const double** rem_val);
 void gcge_hip_star_release_remainder(void);
 void gcge_hip_star_free(void* sm);
@@ -46,6 +46,8 @@ void gcge_hip_star_stats(const void* sm, long* out);
 int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
 const unsigned char* gcge_hip_star_host_mask(void);
 int gcge_hip_star_spmm_dots(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream);
+int gcge_hip_star_spmm_part(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream, int part);
+int gcge_hip_star_interior(const void* sm, int* ilo, int* ihi);
 int gcge_hip_star_coldots2_rows(int nlist, const int* d_list, const double* d_x, long ldx, const double* d_y, long ldy, int m, double* d_out, void* stream);
 const int* gcge_hip_dense_row_list(const void* dm, int* nlisted);
 void* gcge_hip_dense_build_rows(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, const unsigned char* not_listed);
@@ -487,9 +489,11 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const in
   GCGE_HIP_CHECK(hipMemcpy(A->d_tab, tab.data(), tab.size() * sizeof(PatEntryH), hipMemcpyHostToDevice));
 }
 
-// rows of one slab with LOCAL column indices in [0, ncols_local); columns >= nrows are halo rows
-extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, int nglobal, int row_begin,
-                                                   const int* rowptr, const int* colidx, const double* val) {
+// rows of one slab with LOCAL column indices in [0, ncols_local); columns >= nrows are halo rows.  ghost_global (may be NULL): the
+// global rows behind the halo columns, ascending — with it (and nglobal) a slab of a grid matrix cut on plane boundaries keeps the
+// plane sweep of spmm_star.hip: the planes below and above the slab are then found among the halo rows.
+extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local_ghosts(int nrows, int ncols_local, int nglobal, int row_begin,
+                                                          const int* rowptr, const int* colidx, const double* val, const int* ghost_global) {
   if (gcge_hip_init(-1) != 0) return nullptr;
   GCGE_HIP_MAT* A = (GCGE_HIP_MAT*)calloc(1, sizeof(GCGE_HIP_MAT));
   A->nrows = nrows; A->nglobal = nglobal; A->row_begin = row_begin; A->nnz = rowptr[nrows];
@@ -530,7 +534,11 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, i
   A->star = nullptr; A->star_rem = nullptr;
   if (A->d_pid == nullptr) {
     const int *rr = nullptr, *rc = nullptr; const double* rv = nullptr;
-    if (void* S = gcge_hip_star_build(nrows, ncols_local, rowptr, colidx, val, &rr, &rc, &rv)) {
+    // (the sweep needs to know where the slab sits in the grid: a whole matrix, or a slab with its global size and halo rows named)
+    const bool whole = row_begin == 0 && ncols_local == nrows && (nglobal <= 0 || nglobal == nrows);
+    const bool slab = !whole && nglobal > 0 && (ncols_local == nrows || ghost_global != nullptr);
+    void* S = (whole || slab) ? gcge_hip_star_build(nrows, ncols_local, row_begin, whole ? nrows : nglobal, ghost_global, rowptr, colidx, val, &rr, &rc, &rv) : nullptr;
+    if (S != nullptr) {
       void* D = gcge_hip_dense_build_rows(nrows, ncols_local, rr, rc, rv, gcge_hip_star_host_mask());   // (its pad-8 part lists the other rows only)
       if (D != nullptr) { A->star = S; A->star_rem = D; } else gcge_hip_star_free(S);   // (no blocks among the other rows: the forms below)
       gcge_hip_star_release_remainder();
@@ -551,6 +559,10 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, i
     }
   }
   return A;
+}
+extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, int nglobal, int row_begin,
+                                                   const int* rowptr, const int* colidx, const double* val) {
+  return gcge_hip_mat_create_local_ghosts(nrows, ncols_local, nglobal, row_begin, rowptr, colidx, val, nullptr);
 }
 extern "C" GCGE_HIP_MAT* gcge_hip_mat_create(int nrows, int nglobal, int row_begin, const int* rowptr,
                                              const int* colidx, const double* val) {
@@ -1022,12 +1034,58 @@ static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long 
 static int g_halo_overlap = 1;
 extern "C" void gcge_hip_set_halo_overlap(int on) { g_halo_overlap = on; }
 
+// Y[:, 0:m) = A X[:, c_begin : c_begin + m) for a matrix in grid form (spmm_star.hip), whole or a row slab cut on plane
+// boundaries.  On a slab with a split exchange the planes that need no halo row are swept while the halo is in flight (the
+// reference's distributed product does the same with its diagonal block: app/app_phg.c:307-357), the first and last STAR_R
+// planes and the rows outside the grid form (blocks + listed rows, which may reference any halo row) follow its arrival.
+// dd != NULL (4 m doubles, device): the column sums x.y and y.y over the star rows (dd[0:2m)) and over the other rows (dd[2m:4m)).
+// -1 before anything was launched or sent: operands the sweep does not take.
+static long g_star_products = 0, g_star_split_products = 0;
+extern "C" void gcge_hip_star_product_stats(long* products, long* split) { if (products) *products = g_star_products; if (split) *split = g_star_split_products; }
+static int star_product(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, double* dy, long ldy, int m, double* dd) {
+  const double* dx = vx->d + c_begin;
+  const long ldx = vx->ld;
+  if ((m & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)dx & 15) || ((uintptr_t)dy & 15) || dx == dy) return -1;
+  const bool split = A->nghost > 0 && g_halo_overlap && A->exchange_begin != nullptr && A->exchange_end != nullptr && m <= A->buf_cols &&
+                     gcge_hip_star_interior(A->star, nullptr, nullptr);
+  int rc;
+  ++g_star_products;
+  if (split) {
+    ++g_star_split_products;
+    if (A->nsend > 0) {
+      long tot = (long)A->nsend * m, g = (tot + 255) / 256; if (g > 4096) g = 4096;
+      hipLaunchKernelGGL(halo_pack, dim3((unsigned)g), dim3(256), 0, g_stream, A->nsend, A->d_send_rows, dx, ldx, m, A->sendbuf);
+    }
+    A->exchange_begin(A->sendbuf, A->recvbuf, m, A->exchange_ctx);
+    rc = gcge_hip_star_spmm_part(A->star, dx, ldx, dy, ldy, m, dd, g_stream, 1);        // overlaps the transfers
+    A->exchange_end(A->exchange_ctx);
+    long tot = (long)A->nghost * m, g = (tot + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(halo_unpack, dim3((unsigned)g), dim3(256), 0, g_stream, A->nghost, A->recvbuf, m, vx->d + (long)A->nrows * ldx + c_begin, ldx);
+    if (rc == 0) rc = gcge_hip_star_spmm_part(A->star, dx, ldx, dy, ldy, m, dd, g_stream, 2);
+  } else {
+    halo_fetch(A, vx, c_begin, m);
+    rc = gcge_hip_star_spmm_part(A->star, dx, ldx, dy, ldy, m, dd, g_stream, 0);
+  }
+  GCGE_REQUIRE(rc == 0, "star product: sweep");
+  rc = gcge_hip_dense_spmm(A->star_rem, dx, ldx, dy, ldy, m, g_stream, 0);               // the rows outside the grid form (and only those)
+  GCGE_REQUIRE(rc == 0, "star product: blocks and listed rows");
+  if (dd != nullptr) {
+    int nlist = 0; const int* list = gcge_hip_dense_row_list(A->star_rem, &nlist);
+    GCGE_REQUIRE(gcge_hip_star_coldots2_rows(nlist, list, dx, ldx, dy, ldy, m, dd + 2 * (size_t)m, g_stream) == 0, "star product: sums over the listed rows");
+  }
+  return 0;
+}
+
 // Y[:, 0:m) = A X[:, c_begin : c_begin+m) on a row slab, halo included; d_dots / d_yy as in spmm_rows (3 m doubles of
 // scratch behind each when the product is split).  With a split exchange the interior rows are multiplied while the
 // halo rows travel, the two boundary strips follow.
 static int spmm_halo(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, double* dy, long ldy, int m, double* d_dots, double* d_yy,
                      const CgPass* cg = nullptr) {
   const double* dx = vx->d + c_begin;
+  if (A->star != nullptr && g_spmm_path == 0 && cg == nullptr && d_dots == nullptr && d_yy == nullptr) {
+    const int rc = star_product(A, vx, c_begin, dy, ldy, m, nullptr);
+    if (rc != -1) return rc;
+  }
   const bool split = g_halo_overlap && A->nghost > 0 && A->exchange_begin != nullptr && A->exchange_end != nullptr &&
                      m <= A->buf_cols && A->ov_hi - A->ov_lo >= A->nrows / 2 &&
                      A->tile == nullptr && A->dense == nullptr;   // (the block and tile forms multiply whole matrices, not row strips)
@@ -1090,12 +1148,13 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
   // config 5's matrix.  The whole-matrix forms multiply the enclosing even range of X into a scratch block instead (columns of
   // the padding are allocated and zero), the requested columns are copied out.
   const int xs = start[0] & ~1, xe = (end[0] + 1) & ~1;
-  if (A->nghost == 0 && A->d_pid == nullptr && (A->star != nullptr || A->dense != nullptr || A->tile != nullptr) && g_spmm_path == 0 &&
+  if (A->d_pid == nullptr && (A->star != nullptr || A->dense != nullptr || A->tile != nullptr) && g_spmm_path == 0 &&
       m >= 8 && ((start[0] | start[1] | m) & 1) && xe <= vx->ld) {
     const int mw = xe - xs;
     const long ldt = ((long)mw + 7) / 8 * 8;
     const size_t bytes = (size_t)A->nrows * ldt * sizeof(double);
     double* t = (double*)pool_alloc(bytes);
+    halo_fetch(A, vx, xs, mw);                                             // (row slabs: the halo rows of the widened range)
     rc = spmm_rows(A, 0, A->nrows, vx->d + xs, vx->ld, t, ldt, mw, nullptr, nullptr);
     if (rc == 0) rc = gcge_hip_axpby(vy->nrows, 1.0, t + (start[0] - xs), ldt, 0.0, dy, vy->ld, m, g_stream);
     pool_free(t, bytes);   // (one stream: whoever takes the block next is ordered behind the copy)
@@ -1136,11 +1195,10 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
   // plus separate column dots beats the fused kernel (SiO2-like, 36 nnz/row: 6.8 + 1.5 ms against 11 ms)
   const bool long_rows = A != nullptr && A->nrows > 0 && (double)A->noct / A->nrows >= 2.5;
   const bool fast = aligned && (use_pat || (m >= 16 && m <= 128 && !long_rows)) && (A->nghost == 0 || m <= A->buf_cols);
-  if (!fast && host_yy != nullptr && A != nullptr && A->star != nullptr && g_spmm_path == 0 && A->nghost == 0 && vx != vy &&
-      vx->nrows == vy->nrows && A->nrows == vy->nrows) {
+  if (!fast && host_yy != nullptr && A != nullptr && A->star != nullptr && g_spmm_path == 0 && vx != vy &&
+      vx->nrows == vy->nrows && A->nrows == vy->nrows && A->nrows + A->nghost <= vx->nrows_alloc) {
     // grid form: the sweep over the star rows sums x.y and y.y of its rows on the way (registers), a short sweep over the LIST of
     // the other rows adds theirs — no pass over the two blocks afterwards
-    const double* dx = vx->d + start[0]; double* dy = vy->d + start[1];
     SpmmEvent ev;
     if (g_prof_on) {
       GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
@@ -1148,21 +1206,17 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
       ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
       GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
     }
-    int rc = gcge_hip_dense_spmm(A->star_rem, dx, vx->ld, dy, vy->ld, m, g_stream, 0);
+    double* dd = stage_d(4 * (size_t)m);
+    const int rc = star_product(A, vx, start[0], vy->d + start[1], vy->ld, m, dd);
     if (rc == 0) {
-      double* dd = stage_d(4 * (size_t)m);
-      rc = gcge_hip_star_spmm_dots(A->star, dx, vx->ld, dy, vy->ld, m, dd, g_stream);
       if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
-      GCGE_REQUIRE(rc == 0, "spmm_dot: star sweep");
-      int nlist = 0; const int* list = gcge_hip_dense_row_list(A->star_rem, &nlist);
-      GCGE_REQUIRE(gcge_hip_star_coldots2_rows(nlist, list, dx, vx->ld, dy, vy->ld, m, dd + 2 * (size_t)m, g_stream) == 0, "spmm_dot: listed rows");
       double* hd = stage_h(4 * (size_t)m);
       GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, 4 * (size_t)m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
       GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
       for (int j = 0; j < m; ++j) { host_dots[j] = hd[j] + hd[2 * m + j]; host_yy[j] = hd[m + j] + hd[3 * m + j]; }
       return;
     }
-    if (g_prof_on) { hipEventDestroy(ev.e0); hipEventDestroy(ev.e1); }   // (operands the block form does not take: the generic route below)
+    if (g_prof_on) { hipEventDestroy(ev.e0); hipEventDestroy(ev.e1); }   // (operands the sweep does not take: the generic route below)
   }
   if (!fast) {
     HIP_MatDotMultiVec(mat, x, y, start, end, ops);

@@ -261,8 +261,9 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_slab(const long* part, const int* r
     return nullptr;
   }
   if (gcge_dist_localize(&S, ghosts, ng) != 0) { gcge_free_ints(ghosts); return nullptr; }
+  // (the halo rows' global ids travel with the arrays: a slab of a grid matrix cut on plane boundaries keeps the plane sweep)
+  GCGE_HIP_MAT* A = gcge_hip_mat_create_local_ghosts(nrows, nrows + ng, (int)n_global, (int)part[rank], rowptr, cols.data(), val, ghosts);
   gcge_free_ints(ghosts);
-  GCGE_HIP_MAT* A = gcge_hip_mat_create_local(nrows, nrows + ng, (int)n_global, (int)part[rank], rowptr, cols.data(), val);
   if (A == nullptr) return nullptr;
   if (world > 1) {
     const int rc = gcge_hip_mat_set_halo_rccl(A, (int)n_global, world, peer.data(), send_cnt.data(), recv_cnt.data(),

@@ -39,8 +39,14 @@ constexpr int STAR_NP = STAR_PW * STAR_PW;      // slots of the plane image (cor
 constexpr int STAR_Q = 2 * STAR_R + 1;          // 13 planes in the register queue
 
 struct StarCoef { double cx[STAR_R + 1], cy[STAR_R + 1], cz[STAR_R + 1]; };   // [k]: coefficient of the neighbours k steps away ([0] unused)
+// Where the planes of the grid live in a block of vectors.  One rank: the slab is the grid.  A row slab of a partitioned matrix
+// (planes [zs, ze) of nz; cuts on plane boundaries) finds the planes below and above among its halo rows: the halo rows are
+// ascending by global index, so the up to R whole planes on either side are two contiguous runs of them — row of grid point
+// (in-plane offset i, plane zz) = off + plane_rows * zz + i with off = mid_off inside the slab, lo_off below, hi_off above;
+// planes outside [zmin, zmax) are outside the grid (Dirichlet: zero) or beyond the star's arms (coefficient zero): never loaded.
+struct StarGeom { int nx, ny, nz, zs, ze, zmin, zmax; long lo_off, mid_off, hi_off; };
 struct StarMat {
-  int nx, ny, nz, R; long nclean, nrows; StarCoef c; double* d_diag;   // d_diag[row]: the row's diagonal entry, NaN: not a clean row
+  StarGeom g; int R; long nclean, nrows; StarCoef c; double* d_diag;   // d_diag[local row]: the row's diagonal entry, NaN: not a clean row
 };
 
 // staging plan of a thread: unit u = tid + 1024 q, point u >> 2, 16-byte part u & 3
@@ -56,9 +62,10 @@ __device__ __forceinline__ v2d star_ld(const double* __restrict__ x, size_t ldx,
 // DOT: additionally partial[(workgroup of this patch and z range) * 2 ncols + j] = sum over the star rows the workgroup wrote of
 // x[r, j] y[r, j], and at + ncols the same of y[r, j]^2 (columns of this pass only) — the p.w and w.w of a CG step, for free.
 template <bool DOT>
-__global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz, StarCoef cf, const double* __restrict__ diag,
-    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols, int zlen, int ntx,
+__global__ __launch_bounds__(1024) void spmm_star_kernel(StarGeom g, StarCoef cf, const double* __restrict__ diag,
+    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols, int zlo, int zhi, int zlen, int ntx,
     double* __restrict__ partial) {
+  const int nx = g.nx, ny = g.ny;
   __shared__ v2d plane[4 * STAR_NP];            // part-major: plane[part * NP + slot]
   __shared__ v2d corein[4 * 256];
   __shared__ v2d outt[4 * 256];
@@ -66,9 +73,11 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz,
   const int p = tid & 255, cp = tid >> 8, px = p & 15, py = p >> 4;
   const int tile_x = blockIdx.x % ntx, tile_y = blockIdx.x / ntx;
   const int x0 = tile_x * STAR_T, y0 = tile_y * STAR_T;
-  const int z0 = blockIdx.y * zlen, z1 = min(nz, z0 + zlen);
+  const int z0 = zlo + blockIdx.y * zlen, z1 = min(zhi, z0 + zlen);     // output planes of this workgroup (global plane numbers)
   const int c0 = 8 * blockIdx.z;
   const long plane_rows = (long)nx * ny;
+  auto plane_row0 = [&](int zz) -> long { return (zz < g.zs ? g.lo_off : zz >= g.ze ? g.hi_off : g.mid_off) + plane_rows * zz; };   // row of X of its point 0
+  const long loc = -plane_rows * g.zs;                                   // local row of diag / Y = loc + plane_rows z + in-plane offset
   // ---- compute lane: point (x0 + px, y0 + py), columns c0 + 2 cp, + 1
   const int gx = x0 + px, gy = y0 + py;
   const bool inside = gx < nx && gy < ny;
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz,
 #pragma unroll
   for (int t = 0; t < STAR_Q - 1; ++t) {
     const int zz = z0 - STAR_R + t;
-    qv[t] = (inside && cvalid && zz >= 0 && zz < nz) ? star_ld(x, ldx, own + plane_rows * zz, ccol) : v2d{0.0, 0.0};
+    qv[t] = (inside && cvalid && zz >= g.zmin && zz < g.zmax) ? star_ld(x, ldx, own + plane_row0(zz), ccol) : v2d{0.0, 0.0};
   }
   qv[STAR_Q - 1] = v2d{0.0, 0.0};
   // staged loads of the first step: core of plane z0 + 6, arms of plane z0
@@ -114,11 +123,11 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz,
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const int zz = su[q].dst < -1 ? z + STAR_R : z;          // core units fetch plane z + 6, arm units plane z
-      stn[q] = (su[q].src >= 0 && zz >= 0 && zz < nz) ? star_ld(x, ldx, (long)su[q].src + plane_rows * zz, scol) : v2d{0.0, 0.0};
+      stn[q] = (su[q].src >= 0 && zz >= g.zmin && zz < g.zmax) ? star_ld(x, ldx, (long)su[q].src + plane_row0(zz), scol) : v2d{0.0, 0.0};
     }
   };
   stage_load(z0);
-  double dg = (inside && z0 < z1) ? diag[own + plane_rows * z0] : NAN;     // diagonal of my point in the output plane (NaN: not mine to write)
+  double dg = (inside && z0 < z1) ? diag[own + loc + plane_rows * z0] : NAN;     // diagonal of my point in the output plane (NaN: not mine to write)
   double dgo = NAN;                                                       // the same for the point whose result I flush
   long flush_plane = -1;
   v2d spw = v2d{0.0, 0.0}, sww = v2d{0.0, 0.0};                           // DOT: sums over my point's star rows
@@ -137,12 +146,12 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz,
       }                                                                                                                     \
       plane[cp * STAR_NP + slot] = qv[STAR_SLOT(U, 0)];                                                                        \
       if (flush_plane >= 0 && oinside && dgo == dgo)                                                                        \
-        __builtin_nontemporal_store(outt[si * 256 + opt], reinterpret_cast<v2d*>(y + (size_t)(orow + plane_rows * flush_plane) * ldy + scol)); \
+        __builtin_nontemporal_store(outt[si * 256 + opt], reinterpret_cast<v2d*>(y + (size_t)(orow + loc + plane_rows * flush_plane) * ldy + scol)); \
       __syncthreads();                                   /* B */                                                            \
       qv[STAR_SLOT(U, STAR_R)] = corein[cp * 256 + p];      /* plane z + 6 */                                                   \
-      dgo = oinside ? diag[orow + plane_rows * z] : NAN;                                                                    \
+      dgo = oinside ? diag[orow + loc + plane_rows * z] : NAN;                                                              \
       flush_plane = z;                                                                                                      \
-      const double dnext = (inside && z + 1 < z1) ? diag[own + plane_rows * (z + 1)] : NAN;                                  \
+      const double dnext = (inside && z + 1 < z1) ? diag[own + loc + plane_rows * (z + 1)] : NAN;                            \
       const double d0 = dg == dg ? dg : 0.0;                                                                                \
       v2d acc = qv[STAR_SLOT(U, 0)] * d0;                                                                                      \
       _Pragma("unroll") for (int k = 1; k <= STAR_R; ++k) {                                                                 \
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int nz,
   }
   __syncthreads();
   if (flush_plane >= 0 && oinside && dgo == dgo)
-    __builtin_nontemporal_store(outt[si * 256 + opt], reinterpret_cast<v2d*>(y + (size_t)(orow + plane_rows * flush_plane) * ldy + scol));
+    __builtin_nontemporal_store(outt[si * 256 + opt], reinterpret_cast<v2d*>(y + (size_t)(orow + loc + plane_rows * flush_plane) * ldy + scol));
   if (DOT) {
     // fixed-order reduction over the 256 points of every column pair: through the plane image (4 x 784 >= 2 x 1024 v2d)
     __syncthreads();
@@ -220,22 +229,38 @@ __global__ __launch_bounds__(256) void star_coldots2_rows(int nlist, const int* 
 
 // ---------------------------------------------------------------------------------------------- upload-time analysis
 struct StarHost {
-  int nx = 0, ny = 0, nz = 0, R = 0; StarCoef c; long nclean = 0;
+  StarGeom g; int R = 0; StarCoef c; long nclean = 0;
   std::vector<double> diag;                                           // NaN: row stays in the remainder
   std::vector<char> clean;                                            // 1: star row
-  std::vector<int> rem_rowptr, rem_col; std::vector<double> rem_val;  // every entry of the rows that are not clean
+  std::vector<int> rem_rowptr, rem_col; std::vector<double> rem_val;  // every entry of the rows that are not clean (local columns)
 };
 
 static inline uint64_t star_bits(double v) { uint64_t b; memcpy(&b, &v, 8); return b; }
 
-// grid strides and the star's coefficients from the offsets (column - row) most rows share; false: no star on a grid here
-static bool star_detect(int nrows, const int* rowptr, const int* colidx, const double* val, StarHost* H) {
-  if (nrows < 4096) return false;
+// The rows of one slab: local rows [0, nrows) are global rows row_begin + r; local column c < nrows is global column row_begin + c,
+// c >= nrows is halo row c - nrows = global column ghost[c - nrows] (ascending).  One rank: row_begin = 0, no halo columns.
+struct StarRows {
+  int nrows, ncols_local; long row_begin, nglobal; const int* ghost; const int *rowptr, *colidx; const double* val;
+  bool global_cols = false;                                           // colidx holds global columns already (partitioners)
+  long gcol(int c) const { return global_cols ? (long)c : c < nrows ? row_begin + c : (long)ghost[c - nrows]; }
+};
+
+// The offsets (global column - global row) of a star on a lexicographic grid: |o| in {1..Rx} u {sy, 2 sy, .., Ry sy} u {sz, .., Rz sz},
+// each carried (as + o or - o: rows next to a face of the grid, or of a slab at the end of the grid, have only one of the two)
+// by at least half of the sampled rows.  false: the frequent offsets are not such a set.
+static bool star_offsets(const StarRows& M, int* Rx_, int* Ry_, int* Rz_, long* sy_, long* sz_) {
+  const int nrows = M.nrows;
+  if (nrows < 2048) return false;
   const int nsamp = std::min(nrows, 8192);
   std::unordered_map<long, int> hist;
+  std::vector<long> seen;
   for (int t = 0; t < nsamp; ++t) {
     const int r = (int)((long)t * nrows / nsamp);
-    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) { const long o = (long)colidx[q] - r; if (o > 0) ++hist[o]; }
+    seen.clear();
+    for (int q = M.rowptr[r]; q < M.rowptr[r + 1]; ++q) { const long o = M.gcol(M.colidx[q]) - (M.row_begin + r); if (o != 0) seen.push_back(o < 0 ? -o : o); }
+    std::sort(seen.begin(), seen.end());
+    seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+    for (long o : seen) ++hist[o];
   }
   std::vector<long> offs;
   for (auto& kv : hist) if (kv.second * 2 >= nsamp) offs.push_back(kv.first);
@@ -251,9 +276,41 @@ static bool star_detect(int nrows, const int* rowptr, const int* colidx, const d
   sz = offs[i];
   while (i < offs.size() && offs[i] == (long)(Rz + 1) * sz) { ++Rz; ++i; }
   if (i != offs.size()) return false;                                  // a frequent offset that is not part of a star
+  if (sz % sy != 0 || M.nglobal % sz != 0) return false;
+  *Rx_ = Rx; *Ry_ = Ry; *Rz_ = Rz; *sy_ = sy; *sz_ = sz;
+  return true;
+}
+
+// grid strides and the star's coefficients from the offsets (global column - global row) most rows share; false: no star on a grid here
+static bool star_detect(const StarRows& M, StarHost* H) {
+  const int nrows = M.nrows; const int* rowptr = M.rowptr; const int* colidx = M.colidx; const double* val = M.val;
+  int Rx = 0, Ry = 0, Rz = 0; long sy = 0, sz = 0;
+  if (!star_offsets(M, &Rx, &Ry, &Rz, &sy, &sz)) return false;
+  const int nsamp = std::min(nrows, 8192);
   const int R = std::max(Rx, std::max(Ry, Rz));
-  if (R > STAR_R || sy <= 2L * STAR_R || sz % sy != 0 || sz / sy <= 2L * STAR_R || (long)nrows % sz != 0 || (long)nrows / sz < 2) return false;
-  H->nx = (int)sy; H->ny = (int)(sz / sy); H->nz = (int)((long)nrows / sz); H->R = R;
+  if (R > STAR_R || sy <= 2L * STAR_R || sz % sy != 0 || sz / sy <= 2L * STAR_R || M.nglobal % sz != 0 || M.nglobal / sz < 2) return false;
+  // the slab must be whole planes (a partition cut inside a plane keeps the other forms: gcge_amd.dist.partition_by_nnz(align=))
+  if (M.row_begin % sz != 0 || (long)nrows % sz != 0) return false;
+  StarGeom& g = H->g;
+  g.nx = (int)sy; g.ny = (int)(sz / sy); g.nz = (int)(M.nglobal / sz); H->R = R;
+  g.zs = (int)(M.row_begin / sz); g.ze = g.zs + (int)((long)nrows / sz);
+  if (g.ze > g.nz) return false;
+  g.zmin = std::max(0, g.zs - R); g.zmax = std::min(g.nz, g.ze + R);
+  g.mid_off = -sz * g.zs; g.lo_off = g.hi_off = 0;
+  // the planes below and above among the halo rows: whole and contiguous (every point of them is some row's neighbour)
+  const int ng = M.ncols_local - nrows;
+  auto run = [&](long first, long count, long* off) -> bool {       // halo rows first .. first + count - 1 -> *off + global = row of X
+    if (count == 0) return true;
+    if (M.ghost == nullptr) return false;
+    const int* lo = std::lower_bound(M.ghost, M.ghost + ng, (int)first);
+    const long idx = lo - M.ghost;
+    if (idx + count > ng) return false;
+    if (M.ghost[idx] != first || M.ghost[idx + count - 1] != first + count - 1) return false;   // (ascending and unique: the run is gap-free)
+    *off = (long)nrows + idx - first;
+    return true;
+  };
+  if (!run((long)g.zmin * sz, (long)(g.zs - g.zmin) * sz, &g.lo_off)) return false;
+  if (!run((long)g.ze * sz, (long)(g.zmax - g.ze) * sz, &g.hi_off)) return false;
   // coefficients: the most frequent value of every offset among the sampled rows; the star must be symmetric
   memset(&H->c, 0, sizeof(H->c));
   for (int axis = 0; axis < 3; ++axis) {
@@ -265,25 +322,27 @@ static bool star_detect(int nrows, const int* rowptr, const int* colidx, const d
       for (int t = 0; t < nsamp; ++t) {
         const int r = (int)((long)t * nrows / nsamp);
         for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
-          const long o = (long)colidx[q] - r;
+          const long o = M.gcol(colidx[q]) - (M.row_begin + r);
           if (o == k * stride) ++vals[0][star_bits(val[q])];
           else if (o == -k * stride) ++vals[1][star_bits(val[q])];
         }
       }
-      uint64_t best[2] = {0, 0};
-      for (int sgn = 0; sgn < 2; ++sgn) { int bc = -1; for (auto& kv : vals[sgn]) if (kv.second > bc) { bc = kv.second; best[sgn] = kv.first; } if (bc < 0) return false; }
-      if (best[0] != best[1]) return false;
-      memcpy(&dst[k], &best[0], 8);
+      uint64_t best[2] = {0, 0}; int bcnt[2] = {-1, -1};
+      for (int sgn = 0; sgn < 2; ++sgn) for (auto& kv : vals[sgn]) if (kv.second > bcnt[sgn]) { bcnt[sgn] = kv.second; best[sgn] = kv.first; }
+      if (bcnt[0] < 0 && bcnt[1] < 0) return false;
+      if (bcnt[0] >= 0 && bcnt[1] >= 0 && best[0] != best[1]) return false;   // (a slab at the end of the grid may see one direction only)
+      memcpy(&dst[k], &best[bcnt[0] >= 0 ? 0 : 1], 8);
     }
   }
   return true;
 }
 
 // rows whose off-diagonal entries are exactly the star (truncated at the faces) -> diag[]; everything else -> remainder CSR
-static bool star_build_host(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, StarHost* H) {
-  if (ncols_local != nrows) return false;                             // slabs with halo columns keep the other forms
-  if (!star_detect(nrows, rowptr, colidx, val, H)) return false;
-  const int nx = H->nx, ny = H->ny, nz = H->nz;
+static bool star_build_host(const StarRows& M, StarHost* H) {
+  const int nrows = M.nrows; const int* rowptr = M.rowptr; const int* colidx = M.colidx; const double* val = M.val;
+  if (M.ncols_local != nrows && M.ghost == nullptr) return false;     // halo columns of unknown origin: the other forms
+  if (!star_detect(M, H)) return false;
+  const int nx = H->g.nx, ny = H->g.ny, nz = H->g.nz;
   const long sy = nx, sz = (long)nx * ny;
   H->diag.assign((size_t)nrows, NAN);
   H->rem_rowptr.assign((size_t)nrows + 1, 0);
@@ -293,7 +352,8 @@ static bool star_build_host(int nrows, int ncols_local, const int* rowptr, const
   std::vector<char>& clean = H->clean;
   clean.assign((size_t)nrows, 0);
   for (int r = 0; r < nrows; ++r) {
-    const int gz = (int)(r / sz), gy = (int)((r - (long)gz * sz) / sy), gx = (int)(r - (long)gz * sz - (long)gy * sy);
+    const long gr = M.row_begin + r;
+    const int gz = (int)(gr / sz), gy = (int)((gr - (long)gz * sz) / sy), gx = (int)(gr - (long)gz * sz - (long)gy * sy);
     const int g[3] = {gx, gy, gz}, dim[3] = {nx, ny, nz};
     int expect = 0;
     for (int a = 0; a < 3; ++a)
@@ -303,7 +363,7 @@ static bool star_build_host(int nrows, int ncols_local, const int* rowptr, const
       }
     int matched = 0; bool ok = true, have_diag = false; double dv = 0.0;
     for (int q = rowptr[r]; q < rowptr[r + 1] && ok; ++q) {
-      const long o = (long)colidx[q] - r;
+      const long o = M.gcol(colidx[q]) - gr;
       if (o == 0) { if (have_diag) ok = false; have_diag = true; dv = val[q]; continue; }
       const long ao = o < 0 ? -o : o; const int sgn = o < 0 ? -1 : 1;
       int a, k;
@@ -337,40 +397,71 @@ static int g_star_mode = 0;   // 0 automatic, -1 never
 extern "C" void gcge_hip_spmm_star_mode(int mode) { g_star_mode = mode; }
 extern "C" int gcge_hip_spmm_star_mode_get(void) { return g_star_mode; }
 
+// Grid of a matrix whose rows are (mostly) star stencils, from a slab of its rows with GLOBAL column indices (host only; what a
+// partitioner needs to put its cuts on plane boundaries: gcge_amd.dist.partition_by_nnz(align = nx * ny)).  out[0..3] = nx, ny,
+// nz, arm length.  1: found, 0: no such grid.
+extern "C" int gcge_hip_star_grid(int nrows, long row_begin, long nglobal, const int* rowptr, const int* colidx_global, const double* val, long* out) {
+  StarRows M = {nrows, nrows, row_begin, nglobal, nullptr, rowptr, colidx_global, val};
+  M.global_cols = true;
+  int Rx = 0, Ry = 0, Rz = 0; long sy = 0, sz = 0;
+  if (!star_offsets(M, &Rx, &Ry, &Rz, &sy, &sz)) return 0;
+  if (out) { out[0] = sy; out[1] = sz / sy; out[2] = nglobal / sz; out[3] = std::max(Rx, std::max(Ry, Rz)); }
+  return 1;
+}
+
 // Structural self-check of the split (host only; tests): every clean row is rebuilt from the star, its diagonal and the grid and
 // compared with the CSR row, bit for bit; every other row must sit in the remainder unchanged.  0: identical; > 0: differences;
-// -1: the matrix does not take this form.  out[0..4] = nx, ny, nz, arm length, clean rows.
-extern "C" long gcge_hip_star_selfcheck(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, long* out) {
+// -1: the matrix does not take this form.  out[0..4] = nx, ny, nz, arm length, clean rows; out[5..10] (slabs) = first / last + 1
+// plane of the slab, first / last + 1 plane the sweep may load, rows of X where the planes below / above begin (-1: none).
+extern "C" long gcge_hip_star_selfcheck_slab(int nrows, int ncols_local, long row_begin, long nglobal, const int* ghost, const int* rowptr,
+                                             const int* colidx, const double* val, long* out) {
   StarHost H;
-  if (!star_build_host(nrows, ncols_local, rowptr, colidx, val, &H)) return -1;
-  if (out) { out[0] = H.nx; out[1] = H.ny; out[2] = H.nz; out[3] = H.R; out[4] = H.nclean; }
+  const StarRows M = {nrows, ncols_local, row_begin, nglobal, ghost, rowptr, colidx, val};
+  if (!star_build_host(M, &H)) return -1;
+  const StarGeom& g = H.g;
+  const long sy = g.nx, sz = (long)g.nx * g.ny;
+  if (out) {
+    out[0] = g.nx; out[1] = g.ny; out[2] = g.nz; out[3] = H.R; out[4] = H.nclean;
+    out[5] = g.zs; out[6] = g.ze; out[7] = g.zmin; out[8] = g.zmax;
+    out[9] = g.zmin < g.zs ? g.lo_off + sz * g.zmin : -1; out[10] = g.ze < g.zmax ? g.hi_off + sz * g.ze : -1;
+  }
   long bad = 0;
-  const long sy = H.nx, sz = (long)H.nx * H.ny;
-  std::vector<std::pair<int, uint64_t>> want, got;
+  // where the sweep finds grid point (global row gq): the row of X, as the kernel computes it
+  auto xrow = [&](long gq) -> long { const int zz = (int)(gq / sz); return (zz < g.zs ? g.lo_off : zz >= g.ze ? g.hi_off : g.mid_off) + gq; };
+  std::vector<std::pair<long, uint64_t>> want, got;
   for (int r = 0; r < nrows; ++r) {
     want.clear(); got.clear();
-    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) want.emplace_back(colidx[q], star_bits(val[q]));
+    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) want.emplace_back((long)colidx[q], star_bits(val[q]));   // local columns = rows of X
     if (H.diag[r] == H.diag[r]) {
       if (H.rem_rowptr[r + 1] != H.rem_rowptr[r]) ++bad;
-      const int gz = (int)(r / sz), gy = (int)((r - (long)gz * sz) / sy), gx = (int)(r - (long)gz * sz - (long)gy * sy);
+      const long gr = row_begin + r;
+      const int gz = (int)(gr / sz), gy = (int)((gr - (long)gz * sz) / sy), gx = (int)(gr - (long)gz * sz - (long)gy * sy);
       bool stored_diag = false;
       for (auto& w : want) stored_diag |= w.first == r;
-      if (stored_diag || H.diag[r] != 0.0) got.emplace_back(r, star_bits(H.diag[r]));
+      if (stored_diag || H.diag[r] != 0.0) got.emplace_back((long)r, star_bits(H.diag[r]));
       for (int k = 1; k <= STAR_R; ++k) {
-        if (star_bits(H.c.cx[k])) { if (gx - k >= 0) got.emplace_back(r - k, star_bits(H.c.cx[k])); if (gx + k < H.nx) got.emplace_back(r + k, star_bits(H.c.cx[k])); }
-        if (star_bits(H.c.cy[k])) { if (gy - k >= 0) got.emplace_back((int)(r - k * sy), star_bits(H.c.cy[k])); if (gy + k < H.ny) got.emplace_back((int)(r + k * sy), star_bits(H.c.cy[k])); }
-        if (star_bits(H.c.cz[k])) { if (gz - k >= 0) got.emplace_back((int)(r - k * sz), star_bits(H.c.cz[k])); if (gz + k < H.nz) got.emplace_back((int)(r + k * sz), star_bits(H.c.cz[k])); }
+        if (star_bits(H.c.cx[k])) { if (gx - k >= 0) got.emplace_back(xrow(gr - k), star_bits(H.c.cx[k])); if (gx + k < g.nx) got.emplace_back(xrow(gr + k), star_bits(H.c.cx[k])); }
+        if (star_bits(H.c.cy[k])) { if (gy - k >= 0) got.emplace_back(xrow(gr - k * sy), star_bits(H.c.cy[k])); if (gy + k < g.ny) got.emplace_back(xrow(gr + k * sy), star_bits(H.c.cy[k])); }
+        if (star_bits(H.c.cz[k])) {
+          if (gz - k >= 0) { if (gz - k < g.zmin) ++bad; got.emplace_back(xrow(gr - k * sz), star_bits(H.c.cz[k])); }
+          if (gz + k < g.nz) { if (gz + k >= g.zmax) ++bad; got.emplace_back(xrow(gr + k * sz), star_bits(H.c.cz[k])); }
+        }
       }
     } else {
-      for (int q = H.rem_rowptr[r]; q < H.rem_rowptr[r + 1]; ++q) got.emplace_back(H.rem_col[q], star_bits(H.rem_val[q]));
+      for (int q = H.rem_rowptr[r]; q < H.rem_rowptr[r + 1]; ++q) got.emplace_back((long)H.rem_col[q], star_bits(H.rem_val[q]));
     }
     std::sort(want.begin(), want.end()); std::sort(got.begin(), got.end());
     if (want != got) ++bad;
   }
   return bad;
 }
-
-struct StarBuilt { StarMat* S; StarHost* H; };
+extern "C" long gcge_hip_star_selfcheck(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, long* out) {
+  if (ncols_local != nrows) return -1;
+  long o[11];
+  const long bad = gcge_hip_star_selfcheck_slab(nrows, ncols_local, 0, nrows, nullptr, rowptr, colidx, val, o);
+  if (out && bad >= 0) for (int i = 0; i < 5; ++i) out[i] = o[i];
+  return bad;
+}
 
 extern "C" void gcge_hip_star_free(void* sm) {
   StarMat* S = (StarMat*)sm;
@@ -381,14 +472,16 @@ extern "C" void gcge_hip_star_free(void* sm) {
 
 // NULL: the matrix keeps the other forms.  Otherwise the device object, and through rem_* the CSR arrays of the remainder (rows
 // that are not clean keep all their entries, clean rows are empty), owned by the object until gcge_hip_star_release_remainder.
+// ghost: the global rows behind the halo columns nrows .. ncols_local - 1 (ascending; NULL on one rank).
 static StarHost* g_star_last = nullptr;
-extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val,
-                                     const int** rem_rowptr, const int** rem_col, const double** rem_val) {
+extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin, long nglobal, const int* ghost, const int* rowptr,
+                                     const int* colidx, const double* val, const int** rem_rowptr, const int** rem_col, const double** rem_val) {
   if (g_star_mode < 0 || nrows <= 0) return nullptr;
   StarHost* H = new StarHost();
-  if (!star_build_host(nrows, ncols_local, rowptr, colidx, val, H)) { delete H; return nullptr; }
+  const StarRows M = {nrows, ncols_local, row_begin, nglobal, ghost, rowptr, colidx, val};
+  if (!star_build_host(M, H)) { delete H; return nullptr; }
   StarMat* S = new StarMat();
-  S->nx = H->nx; S->ny = H->ny; S->nz = H->nz; S->R = H->R; S->nclean = H->nclean; S->nrows = nrows; S->c = H->c;
+  S->g = H->g; S->R = H->R; S->nclean = H->nclean; S->nrows = nrows; S->c = H->c;
   GCGE_HIP_CHECK(hipMalloc(&S->d_diag, (size_t)nrows * sizeof(double)));
   GCGE_HIP_CHECK(hipMemcpy(S->d_diag, H->diag.data(), (size_t)nrows * sizeof(double), hipMemcpyHostToDevice));
   std::vector<double>().swap(H->diag);
@@ -402,42 +495,89 @@ extern "C" void gcge_hip_star_release_remainder(void) { if (g_star_last) { delet
 extern "C" const unsigned char* gcge_hip_star_host_mask(void) {   // 1: a star row (valid until gcge_hip_star_release_remainder)
   return g_star_last ? (const unsigned char*)g_star_last->clean.data() : nullptr;
 }
-extern "C" void gcge_hip_star_stats(const void* sm, long* out) {   // nx, ny, nz, arm length, clean rows, rows
+extern "C" void gcge_hip_star_stats(const void* sm, long* out) {   // nx, ny, nz, arm length, clean rows, rows, first / last + 1 plane of the slab
   const StarMat* S = (const StarMat*)sm;
-  out[0] = S->nx; out[1] = S->ny; out[2] = S->nz; out[3] = S->R; out[4] = S->nclean; out[5] = S->nrows;
+  out[0] = S->g.nx; out[1] = S->g.ny; out[2] = S->g.nz; out[3] = S->R; out[4] = S->nclean; out[5] = S->nrows; out[6] = S->g.zs; out[7] = S->g.ze;
 }
 
-// Y[clean rows, 0:ncols) = (star + diagonal) X; the other rows of Y are left as they are.  -1: operands this kernel does not take.
-extern "C" int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
+// The output planes that need no halo row — [*ilo, *ihi) — so that they can be swept while the halo is in flight (the sweep loads
+// STAR_R planes on either side of an output plane whatever the arm length).  Returns 0 when the slab has no halo or no such plane.
+extern "C" int gcge_hip_star_interior(const void* sm, int* ilo, int* ihi) {
+  const StarGeom& g = ((const StarMat*)sm)->g;
+  const int lo = g.zmin < g.zs ? g.zs + STAR_R : g.zs, hi = g.ze < g.zmax ? g.ze - STAR_R : g.ze;
+  if (ilo) *ilo = lo;
+  if (ihi) *ihi = hi;
+  return (g.zmin < g.zs || g.ze < g.zmax) && hi > lo;
+}
+
 extern "C" double* gcge_hip_partial_ws(size_t len);
 extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, int len, double* d_out, void* stream);
-// d_dots != NULL: d_dots[0:ncols) = sum over the star rows of x y, d_dots[ncols:2 ncols) = of y^2 (device, 2 ncols doubles)
-extern "C" int gcge_hip_star_spmm_dots(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream) {
-  const StarMat* S = (const StarMat*)sm;
-  if (ncols <= 0) return 0;
-  if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15) || d_x == d_y) return -1;
-  const int ntx = (S->nx + STAR_T - 1) / STAR_T, nty = (S->ny + STAR_T - 1) / STAR_T, npass = (ncols + 7) / 8;
+
+// one launch over the output planes [zlo, zhi); returns the number of partial rows it writes behind `part` (DOT) or 0
+static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_y, long ldy, int ncols, int zlo, int zhi, double* part, bool count_only,
+                       hipStream_t stream) {
+  const int nzl = zhi - zlo;
+  if (nzl <= 0) return 0;
+  const int ntx = (S->g.nx + STAR_T - 1) / STAR_T, nty = (S->g.ny + STAR_T - 1) / STAR_T, npass = (ncols + 7) / 8;
   // z ranges: ONE where the patches x passes already give every CU two workgroups' worth of work (each range re-reads 12 planes
   // of warm-up: 171^3, 64 columns: 1 / 2 / 3 / 4 ranges = 3.93 / 4.26 / 4.35 / 4.47 ms for the whole product), otherwise enough
   // ranges of at least 24 planes to get there
-  int zchunks = (int)std::max(1L, std::min((long)S->nz / 24, (2L * 256 + (long)ntx * nty * npass - 1) / ((long)ntx * nty * npass)));
-  const int zlen = (S->nz + zchunks - 1) / zchunks;
-  zchunks = (S->nz + zlen - 1) / zlen;
+  int zchunks = (int)std::max(1L, std::min((long)nzl / 24, (2L * 256 + (long)ntx * nty * npass - 1) / ((long)ntx * nty * npass)));
+  const int zlen = (nzl + zchunks - 1) / zchunks;
+  zchunks = (nzl + zlen - 1) / zlen;
+  const int nb = ntx * nty * zchunks;
+  if (count_only) return nb;
+  const dim3 grid((unsigned)(ntx * nty), (unsigned)zchunks, (unsigned)npass);
+  if (part == nullptr)
+    hipLaunchKernelGGL(spmm_star_kernel<false>, grid, dim3(1024), 0, stream, S->g, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy,
+                       ncols, zlo, zhi, zlen, ntx, (double*)nullptr);
+  else
+    hipLaunchKernelGGL(spmm_star_kernel<true>, grid, dim3(1024), 0, stream, S->g, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy,
+                       ncols, zlo, zhi, zlen, ntx, part);
+  return nb;
+}
+
+// Y[clean rows, 0:ncols) = (star + diagonal) X; the other rows of Y are left as they are.  -1: operands this kernel does not take.
+// d_dots != NULL: d_dots[0:ncols) = sum over the star rows of x y, d_dots[ncols:2 ncols) = of y^2 (device, 2 ncols doubles).
+// part: 0 = every plane of the slab in one go; 1 = the planes that need no halo row (gcge_hip_star_interior); 2 = the others, after
+// part 1 on the same stream — with d_dots the sums of part 1 stay in the partial workspace and part 2 reduces both (fixed order).
+static int g_star_part1_rows = 0;
+extern "C" int gcge_hip_star_spmm_part(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream, int part) {
+  const StarMat* S = (const StarMat*)sm;
+  if (ncols <= 0) return 0;
+  if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15) || d_x == d_y) return -1;
+  const StarGeom& g = S->g;
+  int ilo = g.zs, ihi = g.ze;
+  if (part != 0 && !gcge_hip_star_interior(sm, &ilo, &ihi)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  int zr[3][2]; int nr = 0;
+  if (part == 0) { zr[0][0] = g.zs; zr[0][1] = g.ze; nr = 1; }
+  else if (part == 1) { zr[0][0] = ilo; zr[0][1] = ihi; nr = 1; }
+  else { zr[0][0] = g.zs; zr[0][1] = ilo; zr[1][0] = ihi; zr[1][1] = g.ze; nr = 2; }
   if (d_dots == nullptr) {
-    hipLaunchKernelGGL(spmm_star_kernel<false>, dim3((unsigned)(ntx * nty), (unsigned)zchunks, (unsigned)npass), dim3(1024), 0, (hipStream_t)stream,
-                       S->nx, S->ny, S->nz, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, zlen, ntx, (double*)nullptr);
+    for (int i = 0; i < nr; ++i) star_launch(S, d_x, ldx, d_y, ldy, ncols, zr[i][0], zr[i][1], nullptr, false, st);
     return (int)hipGetLastError();
   }
-  // with the column sums of the star rows: one partial row per (patch, z range), summed in fixed order
-  const int nb = ntx * nty * zchunks;
-  double* part = gcge_hip_partial_ws((size_t)nb * 2 * ncols);
-  hipLaunchKernelGGL(spmm_star_kernel<true>, dim3((unsigned)(ntx * nty), (unsigned)zchunks, (unsigned)npass), dim3(1024), 0, (hipStream_t)stream,
-                     S->nx, S->ny, S->nz, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols, zlen, ntx, part);
-  gcge_hip_reduce_partials(part, nb, 2 * ncols, d_dots, stream);
+  // with the column sums of the star rows: one partial row per (patch, z range), summed in fixed order; the workspace is laid
+  // out for the whole product (interior first, then the two strips) so that part 1 and part 2 share it
+  const int n_int = part == 0 ? 0 : star_launch(S, d_x, ldx, d_y, ldy, ncols, ilo, ihi, nullptr, true, st);
+  int n_all = n_int;
+  if (part == 0) n_all = star_launch(S, d_x, ldx, d_y, ldy, ncols, g.zs, g.ze, nullptr, true, st);
+  else n_all += star_launch(S, d_x, ldx, d_y, ldy, ncols, g.zs, ilo, nullptr, true, st) + star_launch(S, d_x, ldx, d_y, ldy, ncols, ihi, g.ze, nullptr, true, st);
+  double* ws = gcge_hip_partial_ws((size_t)n_all * 2 * ncols);
+  if (part == 1) { star_launch(S, d_x, ldx, d_y, ldy, ncols, ilo, ihi, ws, false, st); g_star_part1_rows = n_int; return (int)hipGetLastError(); }
+  int off = part == 2 ? n_int : 0;
+  if (part == 2 && g_star_part1_rows != n_int) return -2;            // (part 1 of the same product must have run just before)
+  for (int i = 0; i < nr; ++i) off += star_launch(S, d_x, ldx, d_y, ldy, ncols, zr[i][0], zr[i][1], ws + (size_t)off * 2 * ncols, false, st);
+  g_star_part1_rows = 0;
+  gcge_hip_reduce_partials(ws, n_all, 2 * ncols, d_dots, stream);
   return (int)hipGetLastError();
 }
+extern "C" int gcge_hip_star_spmm_dots(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream) {
+  return gcge_hip_star_spmm_part(sm, d_x, ldx, d_y, ldy, ncols, d_dots, stream, 0);
+}
 extern "C" int gcge_hip_star_spmm(const void* sm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream) {
-  return gcge_hip_star_spmm_dots(sm, d_x, ldx, d_y, ldy, ncols, nullptr, stream);
+  return gcge_hip_star_spmm_part(sm, d_x, ldx, d_y, ldy, ncols, nullptr, stream, 0);
 }
 // d_out[0:m) = sum over the LISTED rows of x[r, j] y[r, j], d_out[m:2m) = of y[r, j]^2 (the rows the sweep does not multiply)
 extern "C" int gcge_hip_star_coldots2_rows(int nlist, const int* d_list, const double* d_x, long ldx, const double* d_y, long ldy, int m,

@@ -40,14 +40,34 @@ def row_partition(n_global, world):
     return part
 
 
-def partition_by_nnz(dist, A, part, bucket=None):
+def grid_of(A):
+    """(nx, ny, nz, arm) of the lexicographic grid behind a matrix whose rows are mostly one star stencil (the real-space
+    DFT Hamiltonians of BASELINE config 5), read off a CSR slab with GLOBAL columns; None: no such grid.  Host only."""
+    from .lib import hip_lib
+    g = hip_lib()
+    g.gcge_hip_star_grid.argtypes = [C.c_int, C.c_long, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    out = (C.c_long * 4)()
+    if not g.gcge_hip_star_grid(A.nrows, A.row_begin, A.ncols, A.rowptr, A.colidx, A.val, out):
+        return None
+    return tuple(int(v) for v in out)
+
+
+def partition_by_nnz(dist, A, part, bucket=None, align=None):
     """Contiguous row partition with (nearly) equal numbers of non-zeros per rank — what SURVEY §8e asks for on the
     load-imbalanced matrices (rows of very different length).  A: this rank's CSR slab under the current partition
     `part` (any contiguous one, e.g. row_partition).  Every rank sums its row lengths over buckets of `bucket` global
-    rows, the sums are gathered, and the cuts are put at the bucket boundaries nearest to k/world of the total."""
+    rows, the sums are gathered, and the cuts are put at the bucket boundaries nearest to k/world of the total.
+    align: cuts only at multiples of `align` rows — the plane size nx * ny of a grid matrix (grid_of), so that every slab is
+    whole planes and keeps the plane sweep of spmm_star.hip; a plane of 171^2 rows is 0.6 % of BASELINE config 5's matrix."""
     world = len(part) - 1
     n_global = part[-1]
     rank = dist.get_rank()
+    if align is not None:
+        if n_global % align != 0 or n_global // align < world:
+            align = None                                  # fewer planes than ranks: free cuts
+        else:
+            bucket = align
     if bucket is None:
         bucket = max(1, n_global // (1024 * world))      # cuts resolved to ~0.1 % of a rank's share
     rp = np.ctypeslib.as_array(A.rowptr, shape=(A.nrows + 1,)).astype(np.int64)
@@ -56,13 +76,21 @@ def partition_by_nnz(dist, A, part, bucket=None):
     mine = np.bincount(rows // bucket, weights=np.diff(rp).astype(np.float64), minlength=nb)
     allb = [None] * world
     dist.all_gather_object(allb, mine)
-    cum = np.concatenate([[0.0], np.cumsum(np.sum(allb, axis=0))])
+    return cuts_by_weight(np.sum(allb, axis=0), world, bucket, n_global)
+
+
+def cuts_by_weight(weight, world, bucket, n_global):
+    """weight[b]: non-zeros of global rows [b * bucket, (b + 1) * bucket).  Cuts at the bucket boundaries nearest to k / world of
+    the total; every rank keeps at least one bucket (so at least one row)."""
+    cum = np.concatenate([[0.0], np.cumsum(weight)])
+    nb = len(weight)
     new = [0]
     for k in range(1, world):
         cut = int(np.searchsorted(cum, cum[-1] * k / world))
         if cut > 0 and abs(cum[cut - 1] - cum[-1] * k / world) < abs(cum[cut] - cum[-1] * k / world):
             cut -= 1
-        new.append(min(n_global, max(new[-1] + 1, cut * bucket)))
+        cut = min(cut, nb - (world - k))                   # leave a bucket for every rank that follows
+        new.append(min(n_global, max(new[-1] + bucket, cut * bucket)))
     new.append(n_global)
     return new
 
@@ -298,7 +326,16 @@ def hip_slab_matrix(hip, comm, A, n_global, part, cap_cols=128):
     g = hip.g
     ghosts = localize_slab(A)
     send_rows, send_cnt, recv_cnt = comm.plan_halo(ghosts, part)
-    mat = hip.matrix(A)
+    # (the halo rows' global ids go with the arrays: a slab of a grid matrix cut on plane boundaries keeps the plane sweep)
+    g.gcge_hip_mat_create_local_ghosts.restype = C.c_void_p
+    g.gcge_hip_mat_create_local_ghosts.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                                   C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    gh = np.ascontiguousarray(ghosts, dtype=np.int32)
+    m = g.gcge_hip_mat_create_local_ghosts(A.nrows, A.ncols, n_global, A.row_begin, A.rowptr, A.colidx, A.val,
+                                           gh.ctypes.data_as(C.POINTER(C.c_int)))
+    if not m:
+        raise RuntimeError("gcge_hip_mat_create_local_ghosts failed")
+    mat = C.c_void_p(m)
     cb, sp, rp = comm.make_exchange(send_cnt, recv_cnt, cap_cols)
     g.gcge_hip_mat_set_halo.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                         C.POINTER(C.c_double), C.c_int, C.c_void_p, C.c_void_p]

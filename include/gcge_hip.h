@@ -47,6 +47,11 @@ GCGE_HIP_MAT *gcge_hip_mat_create_csr (const GCGE_CSR *A);
 typedef void (*gcge_halo_exchange_fn) (double *sendbuf, double *recvbuf, int ncols, void *ctx);
 GCGE_HIP_MAT *gcge_hip_mat_create_local (int nrows, int ncols_local, int nglobal, int row_begin,
 		const int *rowptr, const int *colidx, const double *val);
+/*     the same with the global rows behind the halo columns (ascending, as gcge_dist_ghosts lists them) and the global size:
+ *     a slab of a grid matrix cut on plane boundaries then keeps the plane sweep of spmm_star.hip — the planes below and
+ *     above the slab are found among its halo rows (gcge_hip_mat_create_slab passes them by itself)                      */
+GCGE_HIP_MAT *gcge_hip_mat_create_local_ghosts (int nrows, int ncols_local, int nglobal, int row_begin,
+		const int *rowptr, const int *colidx, const double *val, const int *ghost_global);
 void gcge_hip_mat_set_halo (GCGE_HIP_MAT *A, int nglobal, int nsend, const int *send_rows,
 		double *sendbuf, double *recvbuf, int buf_cols, gcge_halo_exchange_fn fn, void *ctx);
 /*     optional split form of the exchange: begin posts the transfers of the packed rows and returns, end returns
@@ -176,11 +181,23 @@ long gcge_hip_dense_selfcheck (int nrows, int ncols_local, const int *rowptr, co
  *     ONE star stencil of arm length <= 6 with a diagonal of their own (the finite-difference Laplacian + local potential of
  *     real-space DFT Hamiltonians): those rows leave the CSR arrays and are multiplied by a plane sweep (z-neighbours in
  *     registers, x / y arms from LDS, 2.5 X rows fetched per row, no matrix stream), the other rows keep all their entries
- *     and take the block form.  Needs blocks among the other rows and no halo columns.  mode: 0 automatic, -1 never      */
+ *     and take the block form.  Needs blocks among the other rows.  Row slabs (one process per GPU) keep the form when
+ *     they are whole grid planes: the planes below / above come from the halo rows, and with a split exchange the planes that
+ *     need none are swept while the halo is in flight (reference: app/app_phg.c:307-357).  mode: 0 automatic, -1 never   */
 void gcge_hip_spmm_star_mode (int mode);
 long gcge_hip_star_selfcheck (int nrows, int ncols_local, const int *rowptr, const int *colidx, const double *val,
 		long *out /* nx, ny, nz, arm length, star rows */);   /* host-only: star rows + remainder == CSR, bit for bit; -1: no such form */
-int  gcge_hip_mat_star_stats (const GCGE_HIP_MAT *A, long *out /* nx, ny, nz, arm length, star rows, rows */);   /* 0: the matrix has no grid form */
+/*     the same for a row slab with LOCAL columns (halo column nrows + i = global row ghost[i]): additionally checks that the
+ *     sweep's own addressing of the planes below / above lands on the halo rows the CSR arrays name.  out[5..10] = first /
+ *     last + 1 plane of the slab, of the planes the sweep may load, first halo row of the planes below / above (-1: none) */
+long gcge_hip_star_selfcheck_slab (int nrows, int ncols_local, long row_begin, long nglobal, const int *ghost,
+		const int *rowptr, const int *colidx, const double *val, long *out);
+/*     grid of a matrix whose rows are mostly one star stencil, from a slab of its rows with GLOBAL columns (host only;
+ *     what a partitioner needs to cut on plane boundaries).  out[0..3] = nx, ny, nz, arm length; 1 found, 0 none         */
+int  gcge_hip_star_grid (int nrows, long row_begin, long nglobal, const int *rowptr, const int *colidx_global,
+		const double *val, long *out);
+int  gcge_hip_mat_star_stats (const GCGE_HIP_MAT *A, long *out /* nx, ny, nz, arm length, star rows, rows, first / last + 1 plane of the slab */);   /* 0: the matrix has no grid form */
+void gcge_hip_star_product_stats (long *products, long *split);   /* products through the grid form so far, and how many swept their interior planes while the halo travelled */
 /*     stencils whose coefficients differ from row to row: the pattern table is then built from the rows' column OFFSETS
  *     only and the values are streamed per row (8 doubles per row), so such matrices keep the pattern kernels (tables of
  *     at most 8 slots); 0 switches that off (takes effect at the next gcge_hip_mat_create*)                             */

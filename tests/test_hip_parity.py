@@ -1201,7 +1201,7 @@ def test_star_sweep_spmm_vs_oracle(both, case):
         mh, mo = hip.matrix(A), ora.matrix(A)
         form = g.gcge_hip_mat_spmm_form(mh).decode()
         assert form in ("spmm_star+spmm_dense+spmm_pad8", "spmm_star+spmm_dense+spmm_tile"), form
-        st = (C.c_long * 6)()
+        st = (C.c_long * 8)()
         assert g.gcge_hip_mat_star_stats(mh, st) == 1 and tuple(st[:4]) == dims and st[5] == A.nrows and 2 * st[4] >= A.nrows, list(st)
         n = A.nrows
         S = csr_to_scipy(A)

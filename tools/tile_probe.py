@@ -39,7 +39,7 @@ if g.gcge_hip_mat_form_stats(mA, st):
         print("remainder tiles %d, X rows staged per matrix row %.2f, ELL entries per non-zero %.3f, overflow entries %d, brick %dx%dx%d"
               % (st[5], st[6], st[7], st[8], st[9], st[10], st[11]), flush=True)
 g.gcge_hip_mat_star_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
-ss = (C.c_long * 6)()
+ss = (C.c_long * 8)()
 if g.gcge_hip_mat_star_stats(mA, ss):
     print("star rows %d of %d (%.1f %%) on a %dx%dx%d grid, arm length %d; the block / tile figures above are those of the other rows"
           % (ss[4], ss[5], 100.0 * ss[4] / ss[5], ss[0], ss[1], ss[2], ss[3]), flush=True)
