@@ -46,7 +46,7 @@ struct StarCoef { double cx[STAR_R + 1], cy[STAR_R + 1], cz[STAR_R + 1]; };   //
 // planes outside [zmin, zmax) are outside the grid (Dirichlet: zero) or beyond the star's arms (coefficient zero): never loaded.
 struct StarGeom { int nx, ny, nz, zs, ze, zmin, zmax; long lo_off, mid_off, hi_off; };
 struct StarMat {
-  StarGeom g; int R; long nclean, nrows; StarCoef c; double* d_diag;   // d_diag[local row]: the row's diagonal entry, NaN: not a clean row
+  StarGeom g; int R; bool iso; long nclean, nrows; StarCoef c; double* d_diag;   // d_diag[local row]: the row's diagonal entry, NaN: not a clean row
 };
 
 // staging plan of a thread: unit u = tid + 1024 q, point u >> 2, 16-byte part u & 3
@@ -61,11 +61,16 @@ __device__ __forceinline__ v2d star_ld(const double* __restrict__ x, size_t ldx,
 
 // DOT: additionally partial[(workgroup of this patch and z range) * 2 ncols + j] = sum over the star rows the workgroup wrote of
 // x[r, j] y[r, j], and at + ncols the same of y[r, j]^2 (columns of this pass only) — the p.w and w.w of a CG step, for free.
-template <bool DOT>
-__global__ __launch_bounds__(1024) void spmm_star_kernel(StarGeom g, StarCoef cf, const double* __restrict__ diag,
-    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols, int zlo, int zhi, int zlen, int ntx,
-    double* __restrict__ partial) {
-  const int nx = g.nx, ny = g.ny;
+// ISO: the three axes share one set of coefficients, bit for bit (a uniform grid spacing — the usual case): 12 scalar registers
+// of coefficients instead of 36.  SLAB: a row slab with halo planes (dlo / dhi != 0); without it the selects below are compiled out.
+// The scalar registers are what this loop is short of: with everything a slab needs on top of three coefficient sets the compiler
+// re-fetched kernel arguments inside the loop (s_load + lgkmcnt(0) per step: 2.42 -> 2.74 ms on the 171^3 matrix).  Hence also:
+// diagv / xv / yv are the operands shifted by the host to GLOBAL plane numbering (row of grid point (i, zz) = plane_rows zz + i
+// for the planes of the slab), so no "minus first plane" is left in here; dlo / dhi = what to add for the planes below / above.
+template <bool DOT, bool ISO, bool SLAB>
+__global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int zs, int ze, int zmin, int zmax, long dlo, long dhi, StarCoef cf,
+    const double* __restrict__ diag, const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols,
+    int zlo, int zhi, int zlen, int ntx, double* __restrict__ partial) {
   __shared__ v2d plane[4 * STAR_NP];            // part-major: plane[part * NP + slot]
   __shared__ v2d corein[4 * 256];
   __shared__ v2d outt[4 * 256];
@@ -76,8 +81,8 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(StarGeom g, StarCoef cf
   const int z0 = zlo + blockIdx.y * zlen, z1 = min(zhi, z0 + zlen);     // output planes of this workgroup (global plane numbers)
   const int c0 = 8 * blockIdx.z;
   const long plane_rows = (long)nx * ny;
-  auto plane_row0 = [&](int zz) -> long { return (zz < g.zs ? g.lo_off : zz >= g.ze ? g.hi_off : g.mid_off) + plane_rows * zz; };   // row of X of its point 0
-  const long loc = -plane_rows * g.zs;                                   // local row of diag / Y = loc + plane_rows z + in-plane offset
+  auto plane_row0 = [&](int zz) -> long { return plane_rows * zz + (SLAB ? (zz < zs ? dlo : zz >= ze ? dhi : 0L) : 0L); };   // row of X of its point 0
+  constexpr long loc = 0;
   // ---- compute lane: point (x0 + px, y0 + py), columns c0 + 2 cp, + 1
   const int gx = x0 + px, gy = y0 + py;
   const bool inside = gx < nx && gy < ny;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(StarGeom g, StarCoef cf
 #pragma unroll
   for (int t = 0; t < STAR_Q - 1; ++t) {
     const int zz = z0 - STAR_R + t;
-    qv[t] = (inside && cvalid && zz >= g.zmin && zz < g.zmax) ? star_ld(x, ldx, own + plane_row0(zz), ccol) : v2d{0.0, 0.0};
+    qv[t] = (inside && cvalid && zz >= zmin && zz < zmax) ? star_ld(x, ldx, own + plane_row0(zz), ccol) : v2d{0.0, 0.0};
   }
   qv[STAR_Q - 1] = v2d{0.0, 0.0};
   // staged loads of the first step: core of plane z0 + 6, arms of plane z0
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(StarGeom g, StarCoef cf
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const int zz = su[q].dst < -1 ? z + STAR_R : z;          // core units fetch plane z + 6, arm units plane z
-      stn[q] = (su[q].src >= 0 && zz >= g.zmin && zz < g.zmax) ? star_ld(x, ldx, (long)su[q].src + plane_row0(zz), scol) : v2d{0.0, 0.0};
+      stn[q] = (su[q].src >= 0 && zz >= zmin && zz < zmax) ? star_ld(x, ldx, (long)su[q].src + plane_row0(zz), scol) : v2d{0.0, 0.0};
     }
   };
   stage_load(z0);
@@ -161,9 +166,9 @@ __global__ __launch_bounds__(1024) void spmm_star_kernel(StarGeom g, StarCoef cf
       const v2d* pl = plane + cp * STAR_NP + slot;                                                                          \
       _Pragma("unroll") for (int k = 1; k <= STAR_R; ++k) {                                                                 \
         const v2d xs = pl[-k] + pl[k];                                                                                      \
-        acc.x = fma(cf.cx[k], xs.x, acc.x); acc.y = fma(cf.cx[k], xs.y, acc.y);                                              \
+        acc.x = fma(ISO ? cf.cz[k] : cf.cx[k], xs.x, acc.x); acc.y = fma(ISO ? cf.cz[k] : cf.cx[k], xs.y, acc.y);            \
         const v2d ys = pl[-k * STAR_PW] + pl[k * STAR_PW];                                                                   \
-        acc.x = fma(cf.cy[k], ys.x, acc.x); acc.y = fma(cf.cy[k], ys.y, acc.y);                                              \
+        acc.x = fma(ISO ? cf.cz[k] : cf.cy[k], ys.x, acc.x); acc.y = fma(ISO ? cf.cz[k] : cf.cy[k], ys.y, acc.y);            \
       }                                                                                                                     \
       outt[cp * 256 + p] = acc;                                                                                             \
       if (DOT && dg == dg) {                                                                                                \
@@ -482,6 +487,7 @@ extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin,
   if (!star_build_host(M, H)) { delete H; return nullptr; }
   StarMat* S = new StarMat();
   S->g = H->g; S->R = H->R; S->nclean = H->nclean; S->nrows = nrows; S->c = H->c;
+  S->iso = memcmp(H->c.cx, H->c.cy, sizeof(H->c.cx)) == 0 && memcmp(H->c.cx, H->c.cz, sizeof(H->c.cx)) == 0;
   GCGE_HIP_CHECK(hipMalloc(&S->d_diag, (size_t)nrows * sizeof(double)));
   GCGE_HIP_CHECK(hipMemcpy(S->d_diag, H->diag.data(), (size_t)nrows * sizeof(double), hipMemcpyHostToDevice));
   std::vector<double>().swap(H->diag);
@@ -528,12 +534,25 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
   const int nb = ntx * nty * zchunks;
   if (count_only) return nb;
   const dim3 grid((unsigned)(ntx * nty), (unsigned)zchunks, (unsigned)npass);
-  if (part == nullptr)
-    hipLaunchKernelGGL(spmm_star_kernel<false>, grid, dim3(1024), 0, stream, S->g, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy,
-                       ncols, zlo, zhi, zlen, ntx, (double*)nullptr);
-  else
-    hipLaunchKernelGGL(spmm_star_kernel<true>, grid, dim3(1024), 0, stream, S->g, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy,
-                       ncols, zlo, zhi, zlen, ntx, part);
+  // operands in global plane numbering (see the kernel): the slab's first plane is plane zs of the grid
+  const StarGeom& g = S->g;
+  const long shift = g.mid_off;                                       // = - plane_rows * zs
+  const double* xv = (const double*)((uintptr_t)d_x + (uintptr_t)(shift * ldx * (long)sizeof(double)));
+  double* yv = (double*)((uintptr_t)d_y + (uintptr_t)(shift * ldy * (long)sizeof(double)));
+  const double* dv = (const double*)((uintptr_t)S->d_diag + (uintptr_t)(shift * (long)sizeof(double)));
+  const long dlo = g.lo_off - g.mid_off, dhi = g.hi_off - g.mid_off;
+  const bool slab = g.zmin < g.zs || g.ze < g.zmax, iso = S->iso;
+#define STAR_LAUNCH(DOT, ISO, SLAB)                                                                                                     \
+  hipLaunchKernelGGL((spmm_star_kernel<DOT, ISO, SLAB>), grid, dim3(1024), 0, stream, g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax, dlo, dhi, S->c, dv, xv, \
+                     (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part)
+  if (part == nullptr) {
+    if (iso) { if (slab) STAR_LAUNCH(false, true, true); else STAR_LAUNCH(false, true, false); }
+    else     { if (slab) STAR_LAUNCH(false, false, true); else STAR_LAUNCH(false, false, false); }
+  } else {
+    if (iso) { if (slab) STAR_LAUNCH(true, true, true); else STAR_LAUNCH(true, true, false); }
+    else     { if (slab) STAR_LAUNCH(true, false, true); else STAR_LAUNCH(true, false, false); }
+  }
+#undef STAR_LAUNCH
   return nb;
 }
 
