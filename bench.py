@@ -238,6 +238,7 @@ def main():
 
     N = args.size
     c5 = args.config == "c5"
+    t_upload0 = None                           # set right before the matrix goes to the device
     transport = "none (single rank)"
     comm = None
     if world > 1:
@@ -266,6 +267,7 @@ def main():
         dims = (N, N, N)
         if comm is None:
             A, _ = make_problem("sio2", N, **kw)
+            t_upload0 = time.perf_counter()
             mat = hip.matrix(A)
             part = [0, n_global]
         else:
@@ -274,6 +276,7 @@ def main():
             # cuts on plane boundaries (a plane of N^2 rows is 1 / N of the matrix): every slab keeps the plane sweep of spmm_star.hip
             part = gdist.partition_by_nnz(dist, A0, part0, align=N * N) if world > 1 else part0
             A, _ = make_problem("sio2", N, row_begin=part[rank], row_end=part[rank + 1], **kw)
+            t_upload0 = time.perf_counter()
             mat = comm.slab_matrix(A, part) if isinstance(comm, gdist.NativeComm) else gdist.hip_slab_matrix(hip, comm, A, n_global, part)
         workload = ("SiO2-like matrix on a %d^3 grid (12th-order 37-point stencil + %s atom blocks, R = %s + %s u1 u2; n=%d global), "
                     "rows split by non-zeros" % (N, K, R0, R1, n_global))
@@ -283,11 +286,15 @@ def main():
         dims = gdist.weak_scaling_box(N, world)
         n_global = dims[0] * dims[1] * dims[2]
         if comm is not None:
+            t_upload0 = time.perf_counter()     # (the slab generator runs inside: a few tenths of a second of it are not upload)
             A, mat = gdist.lap3d_slab(hip, dims, rank, world, comm)
         else:
             A, _ = make_problem("lap3d", N)
+            t_upload0 = time.perf_counter()
             mat = hip.matrix(A)
         workload = "Lap3D %d^3 rows per GPU, grid %dx%dx%d (7-pt, CSR, n=%d global)" % (N, dims[0], dims[1], dims[2], n_global)
+    hip.sync()
+    upload_seconds = time.perf_counter() - t_upload0      # host arrays -> device matrix in all its forms (analysis included)
     nnz_local = int(A.nnz)
 
     exchange = None
@@ -345,12 +352,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_w0 = time.perf_counter()
     for _ in range(args.warmup):
         run_gcg(hip.ops_handle, mat, None, solver_args, flag=1)
+    hip.sync()
+    warm_solve = (time.perf_counter() - t_w0) / args.warmup if args.warmup > 0 else None
+    # A collective that hangs inside the timed region (a peer that died) must end THIS process with a non-zero code well
+    # before the driver's limit: SIGALRM (default action: terminate) stays armed over the timed solves with a generous
+    # budget — three times what the warm-up solve took per step, an hour when there was no warm-up solve to go by.
+    import signal
+    alarm_budget = int(3.0 * warm_solve * args.steps) + 300 if warm_solve is not None else 3600 + 600 * args.steps
+    signal.alarm(alarm_budget)
     g.gcge_hip_profile_enable(1)
-    if args.dense_shapes:
-        g.gcge_hip_dense_profile.argtypes = [C.c_int]
-        g.gcge_hip_dense_profile(1)
+    g.gcge_hip_dense_profile.argtypes = [C.c_int]
+    g.gcge_hip_dense_profile(1)                 # HIP events round every Gram (K2) / panel update (K3) launch: no synchronisation added
     g.gcge_hip_bpcg_time_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_double), C.c_int]
     g.gcge_hip_bpcg_time_stats(None, None, 1)
     barrier()
@@ -367,6 +382,7 @@ def main():
         iters += last[1].numIter
     barrier()
     elapsed = time.perf_counter() - t0
+    signal.alarm(0)
     if world > 1:
         t = torch.tensor([elapsed], device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -391,12 +407,18 @@ def main():
     stats = {k: prof(k, args.block) for k in (0, 2, 3)}
     spmm_ms_all = sum(prof(k, 0)[1] for k in (0, 2, 3))
     g.gcge_hip_profile_enable(0)
+    # in-solve rate of the dense kernels per shape (north_star: "MFMA utilisation for the TSQR/Gram kernels reported against
+    # gfx950 peak"): 2 n k m flop of a launch / its HIP-event duration, summed per (kernel, k, m) over the timed steps
+    g.gcge_hip_dense_profile_shapes.argtypes = [C.POINTER(C.c_double), C.c_int]
+    dbuf = (C.c_double * (6 * 64))()
+    nshape = min(64, g.gcge_hip_dense_profile_shapes(dbuf, 64))
+    dense_rows = [tuple(dbuf[6 * i + j] for j in range(6)) for i in range(nshape)]
     if args.dense_shapes and rank == 0:
         buf = C.create_string_buffer(1 << 16)
         g.gcge_hip_dense_profile_report.argtypes = [C.c_char_p, C.c_int]
         g.gcge_hip_dense_profile_report(buf, 1 << 16)
         sys.stderr.write("in-solve rate of the dense kernels over the %d timed steps (n = %d rows per rank):\n%s" % (args.steps, A.nrows, buf.value.decode()))
-        g.gcge_hip_dense_profile(0)
+    g.gcge_hip_dense_profile(0)
 
     # parity guard inside the bench (all ranks take part: the slots are collective)
     ev, res = last[0], last[1]
@@ -463,6 +485,27 @@ def main():
         r_p1 = roof(2, "CG pass 1, p.Ap and |Ap|^2 without storing Ap", 1)
         r_p2 = roof(3, "CG pass 2, Ap recomputed + r = p - beta_prev p_prev - alpha Ap (no stored residual), p' = r + beta p" if implicit_r > 0
                     else "CG pass 2, Ap recomputed + r -= alpha Ap, p' = r + beta p", 4)
+        FP64_MFMA_PEAK_TF = 78.6               # MI355X_MICROARCH.md: dense FP64 matrix peak
+
+        def dense_roof(kind, kernel, what):
+            rows_ = [r for r in dense_rows if int(r[0]) == kind and r[3] > 0 and r[4] > 0]
+            if not rows_:
+                return None, []
+            def entry(r):
+                _, k_, m_, calls_, ms_, fl_ = r
+                tf = fl_ / (ms_ * 1e-3) * 1e-12
+                # bytes a launch must move: both operands read once (+ the panel written / read-modified: panel update)
+                by = 8.0 * A.nrows * (k_ + m_) * calls_ if kind == 0 else 8.0 * A.nrows * (k_ + 2.0 * m_) * calls_
+                return {"shape": {"k": int(k_), "m": int(m_), "n": int(A.nrows)}, "calls": int(calls_), "avg_launch_ms": ms_ / calls_,
+                        "achieved": tf, "frac": tf / FP64_MFMA_PEAK_TF, "hbm_GBs": by / (ms_ * 1e-3) / 1e9,
+                        "share_of_step": ms_ * 1e-3 / elapsed if elapsed > 0 else None}
+            top = entry(rows_[0])                # rows come sorted by total time: the shape with the largest share of the step
+            top.update({"bound": "mfma", "kernel": kernel, "what": what, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                        "share_of_step_all_shapes": sum(r[4] for r in rows_) * 1e-3 / elapsed if elapsed > 0 else None})
+            return top, [entry(r) for r in rows_[1:4]]
+
+        r_gram, gram_more = dense_roof(0, "gram_mfma (v_mfma_f64_16x16x4_f64)", "K2 Gram G = Q^T P (k x m) of MultiVecInnerProd / QtAP")
+        r_upd, upd_more = dense_roof(1, "lincomb_mfma (v_mfma_f64_16x16x4_f64)", "K3 panel update Y = X C + Y diag(beta) (k x m coefficients) of MultiVecLinearComb")
         cands = [r for r in (r_k1, r_p1, r_p2) if r is not None]
         dominant = max(cands, key=lambda r: r["share_of_step"]) if cands else None
         cfg = {"workload": "%s, nev=%d, block=%d, nevMax=%d, B=NULL, tol abs 1e-1 rel 1e-8, fused device block-CG (30 its, rate 1e-2), "
@@ -478,12 +521,19 @@ def main():
             "metric": ("converged eigenpairs/sec (GCG, SiO2-like irregular CSR n=%d, block=%d)" if c5 else
                        "converged eigenpairs/sec (GCG, 3D Laplacian n=%d, block=%d)") % (n_global, args.block),
             "value": conv_total / elapsed, "unit": "eigenpairs/s", "n_gpus": world, "steps": args.steps,
+            # `value` counts every pair a solve converged (a whole block locks at once: 56 for 50 wanted at config 2);
+            # the pairs that were ASKED for, per second:
+            "pairs_wanted_per_s": args.nev * args.steps / elapsed,
+            "upload_seconds": upload_seconds, "warmup_solve_seconds": warm_solve, "alarm_budget_seconds": alarm_budget,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong" if c5 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": cfg,
             # the dominant kernel of the step; the K1 product alone (the north-star figure) and the other CG pass follow
             "roofline": dominant,
             "roofline_k1_spmm": r_k1, "roofline_cg_pass1": r_p1, "roofline_cg_pass2": r_p2,
+            # MFMA utilisation of the dense kernels in the solve: the shape with the largest share of the step, then the next three
+            "roofline_gram": r_gram, "roofline_panel_update": r_upd,
+            "dense_other_shapes": {"gram": gram_more, "panel_update": upd_more},
             "spmm_share_of_step": spmm_ms_all * 1e-3 / elapsed if elapsed > 0 else None,
         }
         if not args.no_cpu and world == 1:

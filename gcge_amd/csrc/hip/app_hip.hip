@@ -167,10 +167,27 @@ extern "C" int gcge_hip_slot_timing_report(char* buf, int len) {
 // 2 n k m flop / time — the TF a solve actually sees for each shape, not a stand-alone benchmark's.
 struct DenseEvent { hipEvent_t e0, e1; int kind, k, m; long n; };   // kind 0: Gram, 1: panel update
 static std::vector<DenseEvent> g_dense_prof;
+static std::map<std::tuple<int, int, int>, std::tuple<long, double, double>> g_dense_acc;   // (kind, k, m) -> calls, ms, flop: events already folded
 static int g_dense_prof_on = 0;
+// fold the recorded intervals into the per-shape sums (all of them: the caller has synchronised; otherwise the completed front)
+static void dense_prof_fold(bool all) {
+  size_t i = 0;
+  for (; i < g_dense_prof.size(); ++i) {
+    DenseEvent& e = g_dense_prof[i];
+    if (!all && hipEventQuery(e.e1) != hipSuccess) break;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) {
+      auto& a = g_dense_acc[std::make_tuple(e.kind, e.k, e.m)];
+      std::get<0>(a) += 1; std::get<1>(a) += ms; std::get<2>(a) += 2.0 * (double)e.n * e.k * e.m;
+    }
+    hipEventDestroy(e.e0); hipEventDestroy(e.e1);
+  }
+  g_dense_prof.erase(g_dense_prof.begin(), g_dense_prof.begin() + (long)i);
+}
 extern "C" void gcge_hip_dense_profile(int on) {
   for (auto& e : g_dense_prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
   g_dense_prof.clear();
+  g_dense_acc.clear();
   g_dense_prof_on = on;
 }
 struct DenseProfScope {
@@ -181,19 +198,35 @@ struct DenseProfScope {
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
-  ~DenseProfScope() { if (on) { hipEventRecord(ev.e1, g_stream); g_dense_prof.push_back(ev); } }
+  ~DenseProfScope() {
+    if (!on) return;
+    hipEventRecord(ev.e1, g_stream); g_dense_prof.push_back(ev);
+    if (g_dense_prof.size() >= 4096) dense_prof_fold(false);          // (a bench of 20 solves brackets ~1e5 launches)
+  }
 };
+// the same sums as numbers: rows of 6 doubles (kind 0 Gram / 1 panel update, k, m, calls, milliseconds in all, flop in all), at
+// most max_rows of them, largest total time first; returns the number of shapes seen
+extern "C" int gcge_hip_dense_profile_shapes(double* out, int max_rows) {
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+  dense_prof_fold(true);
+  std::vector<std::pair<double, std::tuple<int, int, int>>> order;
+  for (auto& kv : g_dense_acc) order.emplace_back(-std::get<1>(kv.second), kv.first);
+  std::sort(order.begin(), order.end());
+  int r = 0;
+  for (auto& o : order) {
+    if (r >= max_rows) break;
+    const auto& a = g_dense_acc[o.second];
+    double* q = out + 6 * (size_t)r++;
+    q[0] = std::get<0>(o.second); q[1] = std::get<1>(o.second); q[2] = std::get<2>(o.second);
+    q[3] = (double)std::get<0>(a); q[4] = std::get<1>(a); q[5] = std::get<2>(a);
+  }
+  return (int)order.size();
+}
 extern "C" int gcge_hip_dense_profile_report(char* buf, int len) {
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
-  std::map<std::tuple<int, int, int>, std::tuple<long, double, double>> acc;   // (kind, k, m) -> calls, ms, flop
-  for (auto& e : g_dense_prof) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e.e0, e.e1) != hipSuccess) continue;
-    auto& a = acc[std::make_tuple(e.kind, e.k, e.m)];
-    std::get<0>(a) += 1; std::get<1>(a) += ms; std::get<2>(a) += 2.0 * (double)e.n * e.k * e.m;
-  }
+  dense_prof_fold(true);
   std::string out;
-  for (auto& kv : acc) {
+  for (auto& kv : g_dense_acc) {
     char line[256];
     const long calls = std::get<0>(kv.second); const double ms = std::get<1>(kv.second), fl = std::get<2>(kv.second);
     snprintf(line, sizeof line, "%-13s k = %4d  m = %4d  calls %6ld  %9.3f ms per call  %6.1f TF  (%.1f ms in all)\n",
