@@ -942,7 +942,18 @@ static void HIP_MultiVecLinearComb(void** x, void** y, int is_vec, int* start, i
 }
 
 // app_lapack.c:299-313 -> DenseMatQtAP(matA == NULL) :64-183.  Result to HOST, column-major ldIP.
-static void HIP_MultiVecLocalInnerProd(char nsd, void** x, void** y, int is_vec, int* start, int* end,
+static void reduce_inner_prod(char nsd, int nr, int nc, double* ip, int ldIP);
+static void local_inner_prod(char nsd, void** x, void** y, int is_vec, int* start, int* end, double* ip, int ldIP, struct OPS_* ops);
+// the slot: the local rows' part — or, where the caller opted in (GCGE_SetLocalInnerProdReduces: stacks that sum through MPI only,
+// the reference's BlockPCG src/ops_lin_sol.c:306-321), the sum over the ranks
+static void HIP_MultiVecLocalInnerProd(char nsd, void** x, void** y, int is_vec, int* start, int* end, double* ip, int ldIP, struct OPS_* ops) {
+  local_inner_prod(nsd, x, y, is_vec, start, end, ip, ldIP, ops);
+  if (GCGE_GetLocalInnerProdReduces()) reduce_inner_prod(nsd, end[0] - start[0], end[1] - start[1], ip, ldIP);
+}
+extern "C" void gcge_hip_local_inner_prod(char nsd, void** x, void** y, int* start, int* end, double* ip, int ldIP, struct OPS_* ops) {
+  local_inner_prod(nsd, x, y, 0, start, end, ip, ldIP, ops);           // for block_pcg.hip: the local rows' part, never reduced
+}
+static void local_inner_prod(char nsd, void** x, void** y, int is_vec, int* start, int* end,
                                        double* ip, int ldIP, struct OPS_* ops) {
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int k = end[0] - start[0], m = end[1] - start[1];
@@ -1263,10 +1274,10 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
       memcpy(host_yy, hd + m, m * sizeof(double));
       return;
     }
-    ops->MultiVecLocalInnerProd('D', x, y, 0, start, end, host_dots, 1, ops);
+    local_inner_prod('D', x, y, 0, start, end, host_dots, 1, ops);       // (LOCAL parts whatever GCGE_SetLocalInnerProdReduces says: the caller reduces)
     if (host_yy) {
       int s2[2] = {start[1], start[1]}, e2[2] = {end[1], end[1]};
-      ops->MultiVecLocalInnerProd('D', y, y, 0, s2, e2, host_yy, 1, ops);
+      local_inner_prod('D', y, y, 0, s2, e2, host_yy, 1, ops);
     }
     return;
   }
@@ -1513,9 +1524,10 @@ static void HIP_MatTransDotMultiVec(void* mat, void** x, void** y, int* start, i
 // default of the same name only reduces under OPS_USE_MPI, src/ops_multi_vec.c:202-230 — finds these slots filled.
 static void HIP_MultiVecInnerProd(char nsd, void** x, void** y, int is_vec, int* start, int* end, double* ip, int ldIP,
                                   struct OPS_* ops) {
-  int nr = end[0] - start[0];
-  const int nc = end[1] - start[1];
-  HIP_MultiVecLocalInnerProd(nsd, x, y, is_vec, start, end, ip, ldIP, ops);
+  local_inner_prod(nsd, x, y, is_vec, start, end, ip, ldIP, ops);
+  reduce_inner_prod(nsd, end[0] - start[0], end[1] - start[1], ip, ldIP);
+}
+static void reduce_inner_prod(char nsd, int nr, int nc, double* ip, int ldIP) {
   GCGE_COMM* comm = GCGE_GetComm();
   if (comm == nullptr || nr <= 0 || nc <= 0) return;
   if (nsd == 'D') nr = 1;   // one value per column, stride ldIP

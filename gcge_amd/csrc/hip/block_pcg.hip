@@ -53,6 +53,7 @@ extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, i
 extern "C" void gcge_hip_spmm_dot_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots, struct OPS_* ops);
 extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start, int* end, double* host_dots, double* host_yy,
                                       struct OPS_* ops);
+extern "C" void gcge_hip_local_inner_prod(char nsd, void** x, void** y, int* start, int* end, double* ip, int ldIP, struct OPS_* ops);
 extern "C" int gcge_hip_cg_fusable(void* mat, void** p, int ncols);
 extern "C" int gcge_hip_cg_recompute_pays(void* mat);
 extern "C" int gcge_hip_cg_pass2i_dev(void* mat, void** p, void** pprev, void** pnew, int c0, int m, const double* d_alpha,
@@ -492,8 +493,8 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
     } else {
       ops->MultiVecAxpby(sigma, xin, 1.0, yout, a2, b2, ops);
     }
-    if (dots) ops->MultiVecLocalInnerProd('D', xin, yout, 0, a2, b2, dots, 1, ops);
-    if (yy) { int a5[2] = {ys, ys}, b5[2] = {ys + k, ys + k}; ops->MultiVecLocalInnerProd('D', yout, yout, 0, a5, b5, yy, 1, ops); }
+    if (dots) gcge_hip_local_inner_prod('D', xin, yout, a2, b2, dots, 1, ops);
+    if (yy) { int a5[2] = {ys, ys}, b5[2] = {ys + k, ys + k}; gcge_hip_local_inner_prod('D', yout, yout, a5, b5, yy, 1, ops); }
   };
   if (s->cap < nrhs) {
     if (s->d_coef) { hipFree(s->d_coef); hipFree(s->d_flag); hipHostFree(s->h_pin); }

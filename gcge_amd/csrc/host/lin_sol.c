@@ -19,6 +19,7 @@
 static void reduce_over_ranks(double *v, int n)
 {
 	GCGE_COMM *c = GCGE_GetComm();
+	if (GCGE_GetLocalInnerProdReduces()) return;      /* the back-end's MultiVecLocalInnerProd summed over the ranks already */
 	if (c != NULL && n > 0) c->allreduce_sum(v, n, c->ctx);
 }
 

@@ -34,6 +34,13 @@ void GCGE_SetComm(const GCGE_COMM *comm)
 	g_comm_storage = *comm; g_comm = &g_comm_storage;
 }
 GCGE_COMM *GCGE_GetComm(void) { return g_comm; }
+/* Opt-in for solver stacks that sum their "local" inner products through MPI only (the reference's BlockPCG:
+ * MultiVecLocalInnerProd + MPI_Allreduce under OPS_USE_MPI, src/ops_lin_sol.c:306-321,355-369): a back-end that honours the
+ * switch (OPS_HIP_Set's MultiVecLocalInnerProd) then returns the sum over the ranks from its LOCAL slot as well, so a non-MPI
+ * build of such a stack spans the ranks with flag 0.  Our own BlockPCG (lin_sol.c) asks before it reduces a second time. */
+static int g_local_ip_reduces = 0;
+void GCGE_SetLocalInnerProdReduces(int on) { g_local_ip_reduces = on != 0; }
+int  GCGE_GetLocalInnerProdReduces(void) { return g_local_ip_reduces && g_comm != NULL; }
 
 static GCGE_RESIDUAL_FN g_res_hook = NULL; static void *g_res_owner = NULL;
 void GCGE_SetResidualHook(GCGE_RESIDUAL_FN fn, void *owner) { g_res_hook = fn; g_res_owner = owner; }

@@ -395,3 +395,80 @@ int gcge_csr_from_ccs(int nrows, int ncols, const int *j_col, const int *i_row, 
 	free(fill);
 	return 0;
 }
+
+/* ---- Matrix Market coordinate files (the form the SuiteSparse collection ships the PARSEC matrices of the reference's
+ * test/submit.sh:9-15 in: "%%MatrixMarket matrix coordinate real symmetric", 1-based, lower triangle).  general / symmetric /
+ * skew-symmetric, real / integer / pattern (pattern: every entry 1.0); entries in any order, duplicates summed; the result is
+ * the full matrix in CSR with ascending columns.  0 ok, -1 cannot open / short file, -2 not such a file (or complex / array
+ * format, more than 2^31 - 1 entries), -3 out of memory. */
+typedef struct { int r, c; double v; } mm_entry;
+static int mm_cmp(const void *a, const void *b)
+{
+	const mm_entry *x = (const mm_entry*)a, *y = (const mm_entry*)b;
+	if (x->r != y->r) return x->r < y->r ? -1 : 1;
+	return x->c < y->c ? -1 : x->c > y->c;
+}
+int gcge_load_matrix_market(const char *path, GCGE_CSR *A)
+{
+	FILE *f = fopen(path, "r");
+	char line[1024], obj[64], fmt[64], field[64], sym[64];
+	long rows, cols, nz, k, m = 0, out;
+	int symmetric = 0, skew = 0, pattern = 0;
+	mm_entry *e;
+	if (f == NULL) return -1;
+	if (fgets(line, sizeof line, f) == NULL) { fclose(f); return -1; }
+	if (sscanf(line, "%%%%MatrixMarket %63s %63s %63s %63s", obj, fmt, field, sym) != 4) { fclose(f); return -2; }
+	for (k = 0; obj[k]; ++k) if (obj[k] >= 'A' && obj[k] <= 'Z') obj[k] += 32;
+	for (k = 0; fmt[k]; ++k) if (fmt[k] >= 'A' && fmt[k] <= 'Z') fmt[k] += 32;
+	for (k = 0; field[k]; ++k) if (field[k] >= 'A' && field[k] <= 'Z') field[k] += 32;
+	for (k = 0; sym[k]; ++k) if (sym[k] >= 'A' && sym[k] <= 'Z') sym[k] += 32;
+	if (strcmp(obj, "matrix") != 0 || strcmp(fmt, "coordinate") != 0) { fclose(f); return -2; }
+	if (strcmp(field, "pattern") == 0) pattern = 1;
+	else if (strcmp(field, "real") != 0 && strcmp(field, "integer") != 0 && strcmp(field, "double") != 0) { fclose(f); return -2; }
+	if (strcmp(sym, "symmetric") == 0) symmetric = 1;
+	else if (strcmp(sym, "skew-symmetric") == 0) { symmetric = 1; skew = 1; }
+	else if (strcmp(sym, "general") != 0) { fclose(f); return -2; }
+	do { if (fgets(line, sizeof line, f) == NULL) { fclose(f); return -1; } } while (line[0] == '%' || line[0] == '\n' || line[0] == '\r');
+	if (sscanf(line, "%ld %ld %ld", &rows, &cols, &nz) != 3 || rows < 0 || cols < 0 || nz < 0 || rows > 2147483647L || cols > 2147483647L) { fclose(f); return -2; }
+	e = (mm_entry*)malloc((size_t)(nz > 0 ? (symmetric ? 2 * nz : nz) : 1) * sizeof(mm_entry));
+	if (e == NULL) { fclose(f); return -3; }
+	for (k = 0; k < nz; ++k) {
+		long r, c; double v = 1.0; int got;
+		if (fgets(line, sizeof line, f) == NULL) { free(e); fclose(f); return -1; }
+		if (line[0] == '%' || line[0] == '\n' || line[0] == '\r') { --k; continue; }
+		got = pattern ? sscanf(line, "%ld %ld", &r, &c) : sscanf(line, "%ld %ld %lf", &r, &c, &v);
+		if (got != (pattern ? 2 : 3) || r < 1 || r > rows || c < 1 || c > cols) { free(e); fclose(f); return -2; }
+		e[m].r = (int)(r - 1); e[m].c = (int)(c - 1); e[m].v = v; ++m;
+		if (symmetric && r != c) { e[m].r = (int)(c - 1); e[m].c = (int)(r - 1); e[m].v = skew ? -v : v; ++m; }
+	}
+	fclose(f);
+	qsort(e, (size_t)m, sizeof(mm_entry), mm_cmp);
+	for (k = 0, out = 0; k < m; ++k) {                  /* duplicates: summed (the format allows them in an assembled file) */
+		if (out > 0 && e[out - 1].r == e[k].r && e[out - 1].c == e[k].c) e[out - 1].v += e[k].v;
+		else e[out++] = e[k];
+	}
+	if (out > 2147483647L || csr_alloc(A, rows, (int)cols, 0, out)) { free(e); return out > 2147483647L ? -2 : -3; }
+	A->nnz = out;
+	memset(A->rowptr, 0, ((size_t)rows + 1) * sizeof(int));
+	for (k = 0; k < out; ++k) { ++A->rowptr[e[k].r + 1]; A->colidx[k] = e[k].c; A->val[k] = e[k].v; }
+	for (k = 0; k < rows; ++k) A->rowptr[k + 1] += A->rowptr[k];
+	free(e);
+	return 0;
+}
+
+/* writer of the same format (tests, data exchange): symmetric != 0 writes the lower triangle only ("real symmetric") */
+int gcge_save_matrix_market(const char *path, const GCGE_CSR *A, int symmetric)
+{
+	FILE *f = fopen(path, "w");
+	int64_t cnt = 0; int r, k;
+	if (f == NULL) return -1;
+	for (r = 0; r < A->nrows; ++r)
+		for (k = A->rowptr[r]; k < A->rowptr[r + 1]; ++k) if (!symmetric || A->colidx[k] <= r + A->row_begin) ++cnt;
+	fprintf(f, "%%%%MatrixMarket matrix coordinate real %s\n%% written by gcge_save_matrix_market\n%d %d %lld\n",
+			symmetric ? "symmetric" : "general", A->nrows, A->ncols, (long long)cnt);
+	for (r = 0; r < A->nrows; ++r)
+		for (k = A->rowptr[r]; k < A->rowptr[r + 1]; ++k)
+			if (!symmetric || A->colidx[k] <= r + A->row_begin)
+				fprintf(f, "%d %d %.17g\n", r + A->row_begin + 1, A->colidx[k] + 1, A->val[k]);
+	return fclose(f) ? -1 : 0;
+}

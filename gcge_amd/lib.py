@@ -82,6 +82,18 @@ def load_petsc_binary(path, row_begin=0, row_end=-1):
     return A
 
 
+def load_matrix_market(path):
+    """Matrix Market coordinate file (the form SuiteSparse ships the reference's SiO2 / Ga41As41H72 ... in) -> host CSR, full
+    matrix (symmetric files are expanded), ascending columns."""
+    h = host_lib()
+    h.gcge_load_matrix_market.argtypes = [C.c_char_p, C.POINTER(CSR)]
+    A = CSR()
+    rc = h.gcge_load_matrix_market(os.fsencode(path), C.byref(A))
+    if rc != 0:
+        raise RuntimeError("gcge_load_matrix_market(%r) failed: %d" % (path, rc))
+    return A
+
+
 def make_problem(kind, size, row_begin=0, row_end=-1, **kw):
     """Returns (A, B) CSR structs (B is None for standard problems)."""
     h = host_lib()

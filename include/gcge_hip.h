@@ -32,6 +32,11 @@ void *gcge_hip_stream (void);                 /* hipStream_t all kernels are lau
 /* ---- back-end registration (replaces OPS_CCS_Set, app/app_ccs.c:213-249) ------ */
 void OPS_HIP_Set (struct OPS_ *ops);
 
+/* ---- the driver a maintainer calls from test/main.c:40-49 (counterpart of TestAppCCS, test/test_app_ccs.c:86-140):
+ * table + OPS_HIP_Set + OPS_Setup, matrices from a generator or a file, TestEigenSolverGCG(A, B, flag, argc, argv, ops).
+ * Options: csrc/host/test_app_hip.c (-hip_problem, -hip_size, -hip_petsc_A/B, -hip_mtx_A/B, -hip_flag, -hip_device).  */
+int TestAppHIP (int argc, char *argv[]);
+
 /* ---- sparse matrix handle (replaces CCSMAT, app/app_ccs.h:20-24) -------------- */
 typedef struct GCGE_HIP_MAT_ GCGE_HIP_MAT;
 /* rows [row_begin,row_begin+nrows) of a symmetric matrix, GLOBAL column indices, host CSR

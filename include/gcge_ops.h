@@ -140,6 +140,12 @@ typedef struct GCGE_COMM_ {
 } GCGE_COMM;
 void       GCGE_SetComm (const GCGE_COMM *comm);   /* NULL: single rank */
 GCGE_COMM *GCGE_GetComm (void);
+/* Opt-in: the back-end's MultiVecLocalInnerProd slot returns the sum over the ranks too.  For solver stacks that reduce their
+ * "local" products through MPI only — the reference's BlockPCG (src/ops_lin_sol.c:306-321,355-369: MultiVecLocalInnerProd, then
+ * MPI_Allreduce under OPS_USE_MPI) — so that a NON-MPI build of the reference spans the ranks with flag 0 as well.  Honoured by
+ * OPS_HIP_Set's slot; libgcge_host.so's own BlockPCG skips its reduction while it is on.  Get: 1 only while a communicator exists. */
+void       GCGE_SetLocalInnerProdReduces (int on);
+int        GCGE_GetLocalInnerProdReduces (void);
 /* Shift of the W systems for a user-defined MultiLinearSolver (flag 1): the reference calls such a solver with A
  * only (ops_eig_sol_gcg.c:584-618) and leaves sigma to it; our GCG publishes (sigma, B) here before every call so
  * that a shift-aware solver (the fused block CG of the HIP back-end) can apply A + sigma B.  An application that

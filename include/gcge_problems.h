@@ -61,6 +61,13 @@ int gcge_problem_sio2_like(int G, int K, double R0, double R1, uint64_t seed,
 int gcge_load_petsc_binary(const char *path, int64_t row_begin, int64_t row_end, GCGE_CSR *A);
 /* writer of the same format (tests, data exchange with a PETSc build) */
 int gcge_save_petsc_binary(const char *path, const GCGE_CSR *A);
+/* Matrix Market coordinate file (what the SuiteSparse collection ships SiO2, Ga41As41H72, ... of test/submit.sh:9-15 in; the
+ * reference's users convert them to PETSc binary for test_app_slepc.c:416-445): general / symmetric / skew-symmetric,
+ * real / integer / pattern, any entry order, duplicates summed -> the full matrix in CSR, ascending columns.
+ * Returns 0, -1 cannot open / short file, -2 not a real coordinate file, -3 out of memory. */
+int gcge_load_matrix_market(const char *path, GCGE_CSR *A);
+/* writer (tests, data exchange): symmetric != 0 writes the lower triangle as "real symmetric" */
+int gcge_save_matrix_market(const char *path, const GCGE_CSR *A, int symmetric);
 /* Compressed-column triple (app/app_ccs.h:20-24 CCSMAT; MATLAB's jc/ir/pr of app/app_matlab.c:80-98) of a
  * general square or rectangular matrix -> CSR (transposition by counting; a symmetric matrix comes out
  * identical).  one_based != 0: MATLAB-style 1-based indices. */

@@ -172,6 +172,52 @@ int ref_gcg_solve_foreign(void *foreign_ops, void *matA, void *matB,
 	return gcg_solve_core(ops, 0, matA, matB, 0, nevConv, nevMax, block_size, nevInit, abs_tol, rel_tol, max_iter,
 			flag, 0, NULL, eval_out, NULL, nevConv_out, numIter_out, seconds_out, 0, NULL);
 }
+/* The reference's OWN harness function — TestEigenSolverGCG of test/test_eig_sol_gcg.c:28-169, compiled into this library by
+ * oracle/Makefile — over a table another back-end's OPS_xxx_Set filled (OPS_HIP_Set), with that back-end's matrix handles:
+ * north_star's "TestEigenSolverGCG() is a drop-in", literally.  The harness reports through ops->Printf only ("numIter = %d,
+ * nevConv = %d", then "%d: %6.14e" per converged pair, :139-165), so Printf is pointed at a buffer the caller parses. */
+extern int TestEigenSolverGCG(void *A, void *B, int flag, int argc, char *argv[], struct OPS_ *ops);
+static char *g_log = NULL; static size_t g_log_len = 0, g_log_cap = 0;
+#include <stdarg.h>
+static void capture_printf(const char *fmt, ...)
+{
+	char line[1024];
+	va_list ap; va_start(ap, fmt);
+	int k = vsnprintf(line, sizeof line, fmt, ap);
+	va_end(ap);
+	if (k < 0) return;
+	if (k >= (int)sizeof line) k = (int)sizeof line - 1;
+	if (g_log_len + (size_t)k + 1 > g_log_cap) {
+		g_log_cap = 2 * (g_log_len + (size_t)k + 1) + 4096;
+		g_log = realloc(g_log, g_log_cap);
+	}
+	memcpy(g_log + g_log_len, line, (size_t)k); g_log_len += (size_t)k; g_log[g_log_len] = 0;
+}
+/* returns the harness's return value; *log_out points at its whole output (valid until the next call) */
+int ref_test_eigen_solver_gcg(void *foreign_ops, void *matA, void *matB, int flag, int argc, char **argv, const char **log_out)
+{
+	OPS *ops = (OPS*)foreign_ops;
+	void (*lin_sol)(void*, void**, void**, int*, int*, struct OPS_*) = ops->MultiLinearSolver;
+	void *lin_ws = ops->multi_linear_solver_workspace;
+	OPS_Setup(ops);                      /* the reference's defaulting, as test/main.c does after OPS_xxx_Set */
+	ops->MultiLinearSolver = lin_sol; ops->multi_linear_solver_workspace = lin_ws;
+	ops->Printf = capture_printf; ops->lapack_ops->Printf = capture_printf;
+	ops->GetWtime = wall_now;
+	g_log_len = 0; if (g_log) g_log[0] = 0;
+	int rc = TestEigenSolverGCG(matA, matB, flag, argc, argv, ops);
+	if (log_out) *log_out = g_log ? g_log : "";
+	return rc;
+}
+/* address of a function of THIS library by name: lets a test see that the reference's tables hold the reference's own
+ * functions (the library is linked -Bsymbolic: its calls to its exported functions must not be interposed) */
+void *ref_address_of(const char *name)
+{
+	if (0 == strcmp(name, "OPS_Setup")) return (void*)OPS_Setup;
+	if (0 == strcmp(name, "EigenSolverSetup_GCG")) return (void*)EigenSolverSetup_GCG;
+	if (0 == strcmp(name, "TestEigenSolverGCG")) return (void*)TestEigenSolverGCG;
+	if (0 == strcmp(name, "DefaultMultiVecQtAP")) return (void*)DefaultMultiVecQtAP;
+	return NULL;
+}
 int ref_gcg_solve(int n, int *a_rowptr, int *a_colidx, double *a_val,
 		int *b_rowptr, int *b_colidx, double *b_val,
 		int nevConv, int nevMax, int block_size, int nevInit,

@@ -200,6 +200,31 @@ def main():
             rel2 = np.max(np.abs(ev2[:conv2.value] - box_exact(dims, conv2.value)) / box_exact(dims, conv2.value))
             assert rel2 < 1e-10, ("reference stack over the HIP slots, %d ranks" % world, rel2, list(ev2[:conv2.value]))
             note = " refstack: nevConv=%d numIter=%d rel=%.2e" % (conv2.value, it2.value, rel2)
+            # 5. flag 0 — the reference's OWN BlockPCG over the slots — across ranks with a NON-MPI build of the reference: its
+            # dots go through MultiVecLocalInnerProd and are summed by MPI_Allreduce under OPS_USE_MPI only
+            # (src/ops_lin_sol.c:306-321,355-369); GCGE_SetLocalInnerProdReduces(1) makes the back-end's local slot return the
+            # sum over the ranks.  And our own BlockPCG with the switch on: it must not reduce a second time.
+            be.h.GCGE_SetLocalInnerProdReduces(1)
+            assert be.h.GCGE_GetLocalInnerProdReduces() == 1
+            try:
+                ops3 = C.c_void_p()
+                be.h.OPS_Create(C.byref(ops3))
+                be.g.OPS_HIP_Set(ops3)
+                be.set_random_mode(1, 779)
+                a0 = comm.n_allreduce
+                rc = ref.ref_gcg_solve_foreign(ops3, mat, None, 8, 16, 0, 0, 1e-1, 1e-8, 500, 0, ev2.ctypes.data_as(C.POINTER(C.c_double)),
+                                               C.byref(conv2), C.byref(it2), C.byref(sec2))
+                assert rc == 0 and conv2.value >= 8, (rc, conv2.value)
+                ex3 = box_exact(dims, conv2.value)
+                rel3 = np.max(np.abs(ev2[:conv2.value] - ex3) / ex3)
+                assert rel3 < 1e-10, ("reference stack with ITS BlockPCG (flag 0) over the HIP slots, %d ranks" % world, rel3)
+                assert comm.n_allreduce - a0 > 60 * it2.value, "the reference's BlockPCG did not reduce through the local slot"
+                ev4, res4 = run_gcg(be.ops_handle, mat, None, ["-nevConv", 8], flag=0)      # our MGS + our BlockPCG, switch on
+                ex4 = box_exact(dims, res4.nevConv)
+                assert res4.nevConv >= 8 and np.max(np.abs(ev4[:res4.nevConv] - ex4) / ex4) < 1e-10
+                note += " flag0: nevConv=%d numIter=%d rel=%.2e (ours: %d its)" % (conv2.value, it2.value, rel3, res4.numIter)
+            finally:
+                be.h.GCGE_SetLocalInnerProdReduces(0)
     allc = [None] * world
     dist.all_gather_object(allc, (res.nevConv, res.numIter, float(ev[0])))
     assert all(a[:2] == allc[0][:2] for a in allc), "ranks disagree: %r" % (allc,)

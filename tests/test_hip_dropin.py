@@ -64,6 +64,87 @@ def test_reference_stack_drives_hip_slots(hip, key, flag):
     assert np.max(np.abs(ev[:len(refv)] - refv) / np.abs(refv)) < 1e-10
 
 
+@pytest.mark.skipif(po.ref_lib() is None, reason="oracle/_ref not present on this box")
+@pytest.mark.parametrize("flag", [0, 1])
+@pytest.mark.parametrize("key", ["lap3d_12_nev10", "fe3d_12_nev10"])
+def test_reference_harness_function_over_the_hip_table(hip, key, flag):
+    """north_star, literally: "TestEigenSolverGCG() is a drop-in".  The reference's OWN harness function
+    (test/test_eig_sol_gcg.c:28-169, compiled from /root/reference into oracle/_ref/libgcge_ref.so, linked -Bsymbolic so that
+    every call inside it stays inside the reference) runs over a table only OPS_HIP_Set has touched, with the back-end's matrix
+    handles and the command line test/main.c would pass; what it prints through ops->Printf — "numIter = .., nevConv = .."
+    and one line per eigenvalue (:139-165) — is parsed and compared with the reference-only run in tests/golden/gcg.json."""
+    import re
+    c = GCG[key]
+    ref = po.ref_lib()
+    ops = _fresh_hip_table(hip)
+    if flag == 1:
+        hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+        hip.g.gcge_hip_bpcg_setup(ops, 30, 1e-2, 1e-14, b"abs")
+    hip.set_random_mode(0)
+    A, B = make_problem(c["kind"], c["size"], **c.get("kw", {}))
+    mA = hip.matrix(A)
+    mB = hip.matrix(B) if B is not None else None
+    words = ["test_app_hip", "-nevConv", str(c["nev"]), "-gcge_print_usage", "0"]
+    argv = (C.c_char_p * len(words))(*[w.encode() for w in words])
+    log = C.c_char_p()
+    ref.ref_test_eigen_solver_gcg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
+    rc = ref.ref_test_eigen_solver_gcg(ops, mA, mB, flag, len(words), argv, C.byref(log))
+    text = log.value.decode()
+    hip.free_matrix(mA)
+    if mB is not None:
+        hip.free_matrix(mB)
+    assert rc == 0 and "GCG Eigen Solver" in text, text[-600:]
+    m = re.search(r"numIter = (\d+), nevConv = (\d+)", text)
+    assert m, text[-600:]
+    it, conv = int(m.group(1)), int(m.group(2))
+    vals = [float(v) for v in re.findall(r"^\d+: ([-+0-9.eE]+)$", text.split("eigenvalues")[-1], flags=re.M)]
+    assert len(vals) == conv and conv == c["nevConv"] and abs(it - c["numIter"]) <= 2, (conv, it, c["nevConv"], c["numIter"])
+    refv = np.array(c["eval"][:conv])
+    assert np.max(np.abs(np.array(vals) - refv) / np.abs(refv)) < 1e-10
+
+
+def test_c_main_calls_the_compiled_TestAppHIP(tmp_path):
+    """the back-end exports `TestAppHIP(int argc, char **argv)` — the counterpart of TestAppCCS
+    (test/test_app_ccs.c:86-140) — and a plain-C main (tools/test_app_hip_main.c = test/main.c with that one call) runs it:
+    the reference's stock 1-D pair (n = 807: 38 iterations, lambda_1 = 9.8696 — the values SURVEY 8c lists), the same through the
+    back-end's fused CG, and a matrix read from a Matrix Market file (the SuiteSparse form of the reference's SiO2 & co.)."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "gcge_amd", "lib")
+    exe = str(tmp_path / "test_app_hip")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "test_app_hip_main.c"), "-o", exe,
+                    "-L" + lib, "-lgcge_hip", "-lgcge_host", "-Wl,-rpath," + lib, "-lm"], check=True)
+
+    def run(*args):
+        p = subprocess.run([exe] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:]
+        m = re.search(r"numIter = (\d+), nevConv = (\d+)", p.stdout)
+        assert m, p.stdout[-2000:]
+        vals = [float(v) for v in re.findall(r"^\d+: ([-+0-9.eE]+)$", p.stdout.split("eigenvalues")[-1], flags=re.M)]
+        return int(m.group(1)), int(m.group(2)), np.array(vals)
+
+    c = GCG.get("fe1d_807_nev30")
+    it, conv, ev = run()                                            # no arguments: the stock pair, harness defaults (nevConv 30)
+    assert conv >= 30 and abs(ev[0] - 9.86959196776013) < 1e-9 * 9.87, (it, conv, ev[:3])
+    if c is not None:
+        assert abs(it - c["numIter"]) <= 2 and np.max(np.abs(ev[:len(c["eval"])] - np.array(c["eval"])) / np.array(c["eval"])) < 1e-10
+    else:
+        assert abs(it - 38) <= 2, it                                # SURVEY 8c: 38 iterations
+    it1, conv1, ev1 = run("-hip_flag", 1)
+    assert conv1 >= 30 and np.max(np.abs(ev1[:30] - ev[:30]) / ev[:30]) < 1e-9
+    # a Matrix Market file -> TestAppHIP -> the same Ritz values as the generator's matrix
+    h = host_lib()
+    h.gcge_save_matrix_market.argtypes = [C.c_char_p, C.POINTER(CSR), C.c_int]
+    A, _ = make_problem("lap3d", 12)
+    mtx = str(tmp_path / "lap12.mtx")
+    assert h.gcge_save_matrix_market(mtx.encode(), C.byref(A), 1) == 0
+    g = GCG["lap3d_12_nev10"]
+    it2, conv2, ev2 = run("-hip_mtx_A", mtx, "-nevConv", g["nev"])
+    refv = np.array(g["eval"])
+    assert conv2 == g["nevConv"] and abs(it2 - g["numIter"]) <= 2 and np.max(np.abs(ev2[:len(refv)] - refv) / refv) < 1e-10
+
+
 def _check_shape_run(c, ev, conv, it):
     """With block = 64 / 128 a whole block of pairs locks per iteration, so a run that reaches nev one iteration
     earlier or later than the reference's ends with a different converged count (the reference itself: 60 of the

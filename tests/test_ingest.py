@@ -93,3 +93,52 @@ def test_csr_from_ccs_general_matrix(one_based):
     assert (got != S.tocsr()).nnz == 0
     assert all(np.all(np.diff(ci[ip[r]:ip[r + 1]]) > 0) for r in range(23)), "column indices ascending inside rows"
     h.gcge_csr_free(C.byref(A))
+
+
+def test_matrix_market_reader(tmp_path):
+    """Matrix Market coordinate files (the form SuiteSparse ships SiO2 / Ga41As41H72 ... of the reference's test/submit.sh:9-15
+    in): a file written by scipy (symmetric, lower triangle) and hand-written ones (general with comment lines, entries out of
+    order, a duplicate; pattern; integer) against scipy; our own writer round-trips a generator matrix bit for bit; bad files."""
+    import scipy.io as sio
+    h = host_lib()
+    h.gcge_load_matrix_market.argtypes = [C.c_char_p, C.POINTER(CSR)]
+    h.gcge_save_matrix_market.argtypes = [C.c_char_p, C.POINTER(CSR), C.c_int]
+    rng = np.random.default_rng(4)
+    S = sp.random(61, 61, density=0.1, random_state=rng, format="csr")
+    S = (S + S.T + sp.eye(61) * 2.25).tocsr()
+    path = str(tmp_path / "s.mtx")
+    sio.mmwrite(path, S, symmetry="symmetric", precision=17)
+    A = CSR()
+    assert h.gcge_load_matrix_market(path.encode(), C.byref(A)) == 0 and (A.nrows, A.ncols) == (61, 61)
+    got = csr_to_scipy(A)
+    assert got.has_sorted_indices and abs(got - S).max() == 0.0 and got.nnz == S.nnz
+    h.gcge_csr_free(C.byref(A))
+    gen = str(tmp_path / "g.mtx")
+    with open(gen, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n% a comment\n\n3 4 5\n3 1 -1.5\n1 2 2.0\n% another\n1 1 1.0\n1 2 0.25\n2 4 7e-1\n")
+    assert h.gcge_load_matrix_market(gen.encode(), C.byref(A)) == 0 and (A.nrows, A.ncols, A.nnz) == (3, 4, 4)
+    assert np.array_equal(csr_to_scipy(A).toarray(), np.array([[1.0, 2.25, 0, 0], [0, 0, 0, 0.7], [-1.5, 0, 0, 0]]))
+    h.gcge_csr_free(C.byref(A))
+    pat = str(tmp_path / "p.mtx")
+    with open(pat, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate pattern symmetric\n3 3 3\n2 1\n3 3\n3 1\n")
+    assert h.gcge_load_matrix_market(pat.encode(), C.byref(A)) == 0
+    assert np.array_equal(csr_to_scipy(A).toarray(), np.array([[0, 1.0, 1.0], [1.0, 0, 0], [1.0, 0, 1.0]]))
+    h.gcge_csr_free(C.byref(A))
+    # our writer -> our reader: bit for bit (both triangles from the lower one)
+    G, _ = make_problem("sio2", 7, K=3, R0=1.5, R1=2.0, seed=9)
+    out = str(tmp_path / "w.mtx")
+    for symmetric in (1, 0):
+        assert h.gcge_save_matrix_market(out.encode(), C.byref(G), symmetric) == 0
+        assert h.gcge_load_matrix_market(out.encode(), C.byref(A)) == 0
+        a, b = csr_to_scipy(A), csr_to_scipy(G)
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data)
+        assert abs(sio.mmread(out).tocsr() - b).max() == 0.0
+        h.gcge_csr_free(C.byref(A))
+    bad = str(tmp_path / "bad.mtx")
+    for text, rc in (("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n", -2), ("%%MatrixMarket matrix coordinate complex general\n1 1 1\n1 1 1 0\n", -2),
+                     ("%%MatrixMarket matrix coordinate real general\n2 2 3\n1 1 1.0\n", -1), ("%%MatrixMarket matrix coordinate real general\n2 2 1\n3 1 1.0\n", -2)):
+        with open(bad, "w") as f:
+            f.write(text)
+        assert h.gcge_load_matrix_market(bad.encode(), C.byref(A)) == rc, text
+    assert h.gcge_load_matrix_market(str(tmp_path / "missing.mtx").encode(), C.byref(A)) == -1

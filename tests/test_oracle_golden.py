@@ -14,6 +14,37 @@ def test_oracle_slots_match_reference_vectors(oracle):
     run_bpcg_case(oracle, P, bpcg_setup(oracle.ops_handle))
 
 
+def test_reference_library_binds_to_itself():
+    """oracle/_ref/libgcge_ref.so and our libgcge_host.so export the SAME names (ours mirrors the reference's API) and the tests
+    load ours RTLD_GLOBAL: unless the reference library is linked -Bsymbolic the dynamic linker resolves its internal calls
+    (OPS_Setup, EigenSolverSetup_GCG, MultiVecOrthSetup_*, DefaultMultiVec*) to OUR functions, and a "reference run" is our solver
+    over the reference's back-end.  Checked three ways: the ELF flag, the addresses inside a table the reference built, and
+    that the library's own TestEigenSolverGCG is not ours."""
+    import ctypes as C
+    import os
+    import subprocess
+    import pyoracle as po
+    from gcge_amd.lib import host_lib
+    from gcge_amd.ops_struct import OPS
+    ref = po.ref_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref not present on this box")
+    h = host_lib()
+    for name in ("libgcge_ref.so", "libgcge_ref_omp.so"):
+        path = os.path.join(os.path.dirname(po.__file__), "_ref", name)
+        if os.path.exists(path):
+            dyn = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+            assert "SYMBOLIC" in dyn, "%s is not linked -Bsymbolic" % name
+    ref.ref_address_of.restype = C.c_void_p
+    ref.ref_address_of.argtypes = [C.c_char_p]
+    ref.ref_make_ccs_ops.restype = C.c_void_p
+    ops = C.cast(C.c_void_p(ref.ref_make_ccs_ops()), C.POINTER(OPS)).contents      # OPS_Create + OPS_CCS_Set + OPS_Setup, all inside the library
+    assert ops.MultiVecQtAP == ref.ref_address_of(b"DefaultMultiVecQtAP")
+    assert ops.MultiVecQtAP != C.cast(h.DefaultMultiVecQtAP, C.c_void_p).value
+    for nm in ("OPS_Setup", "EigenSolverSetup_GCG", "TestEigenSolverGCG"):
+        assert ref.ref_address_of(nm.encode()) != C.cast(getattr(h, nm), C.c_void_p).value, nm
+
+
 GCG = load_golden("gcg.json")
 
 

@@ -35,6 +35,8 @@ def main(argv=None, post=None):
     ap.add_argument("--R1", type=float, default=2.0)
     ap.add_argument("--petsc", nargs="+", default=None, metavar="FILE",
                     help="PETSc binary Mat file(s): A [B] (the reference's -filename_matA / -filename_matB) instead of a generator")
+    ap.add_argument("--mtx", nargs="+", default=None, metavar="FILE",
+                    help="Matrix Market coordinate file(s): A [B] (the form SuiteSparse ships the reference's SiO2 / Ga41As41H72 ... in)")
     ap.add_argument("--box", default=None, metavar="NX,NY,NZ",
                     help="7-point Laplacian on an NX x NY x NZ grid instead of --kind/--size (e.g. 512,512,64: the slab one of 8 ranks owns at BASELINE config 4)")
     ap.add_argument("--extra", nargs="*", default=[])
@@ -42,7 +44,7 @@ def main(argv=None, post=None):
 
     import numpy as np
     import torch  # noqa: F401  (one libamdhip64 for torch and the extension)
-    from gcge_amd import HipBackend, load_petsc_binary, make_problem, run_gcg
+    from gcge_amd import HipBackend, load_matrix_market, load_petsc_binary, make_problem, run_gcg
     t0 = time.perf_counter()
     if a.box:
         from gcge_amd.lib import CSR, host_lib
@@ -51,6 +53,10 @@ def main(argv=None, post=None):
         if host_lib().gcge_problem_lap3d_box(C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int64(0), C.c_int64(-1), C.byref(A)) != 0:
             raise RuntimeError("gcge_problem_lap3d_box failed")
         a.kind, a.size = "lap3d_box:" + a.box, A.nrows
+    elif a.mtx:
+        A = load_matrix_market(a.mtx[0])
+        B = load_matrix_market(a.mtx[1]) if len(a.mtx) > 1 else None
+        a.kind, a.size = "mtx:" + os.path.basename(a.mtx[0]), A.nrows
     elif a.petsc:
         A = load_petsc_binary(a.petsc[0])
         B = load_petsc_binary(a.petsc[1]) if len(a.petsc) > 1 else None
