@@ -1052,8 +1052,8 @@ static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long 
   if (rc != -1) return rc;
   // whole-matrix products only from here: neither the rows of a block nor those of a tile are a row range
   if (A->star != nullptr && d_dots == nullptr && r0 == 0 && r1 == A->nrows && g_spmm_path == 0) {
-    rc = gcge_hip_dense_spmm(A->star_rem, dx, ldx, dy, ldy, m, g_stream, 0);     // the rows outside the grid form (and only those)
-    if (rc == 0) rc = gcge_hip_star_spmm(A->star, dx, ldx, dy, ldy, m, g_stream);   // ... then the star rows are overwritten
+    rc = gcge_hip_star_spmm(A->star, dx, ldx, dy, ldy, m, g_stream);              // star + diagonal of EVERY row ...
+    if (rc == 0) rc = gcge_hip_dense_spmm(A->star_rem, dx, ldx, dy, ldy, m, g_stream, 4);   // ... + what the other rows hold beyond it
   }
   if (rc != -1) return rc;
   if (A->dense != nullptr && d_dots == nullptr && r0 == 0 && r1 == A->nrows && g_spmm_path != 1 && g_spmm_path != 3 && g_spmm_path != 4)
@@ -1111,7 +1111,7 @@ static int star_product(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, double* dy
     rc = gcge_hip_star_spmm_part(A->star, dx, ldx, dy, ldy, m, dd, g_stream, 0);
   }
   GCGE_REQUIRE(rc == 0, "star product: sweep");
-  rc = gcge_hip_dense_spmm(A->star_rem, dx, ldx, dy, ldy, m, g_stream, 0);               // the rows outside the grid form (and only those)
+  rc = gcge_hip_dense_spmm(A->star_rem, dx, ldx, dy, ldy, m, g_stream, 4);               // += what the rows with more than the star hold beyond it
   GCGE_REQUIRE(rc == 0, "star product: blocks and listed rows");
   if (dd != nullptr) {
     int nlist = 0; const int* list = gcge_hip_dense_row_list(A->star_rem, &nlist);

@@ -30,6 +30,7 @@ extern "C" int gcge_hip_pad8_spmm(int nrows, const int* d_orp, const int* d_pcol
                                   long ldx, double* d_y, long ldy, int ncols, void* stream);
 extern "C" void gcge_hip_spmm_pad8_auto(double avg_octets_per_row);
 extern "C" void gcge_hip_spmm_pad8_row_map(const int* d_map);
+extern "C" void gcge_hip_spmm_pad8_row_map_add(const int* d_map);
 extern "C" void* gcge_hip_tile_build_for(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, int remainder);
 extern "C" void gcge_hip_tile_free(void* tm);
 extern "C" int gcge_hip_tile_spmm(const void* tm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream);
@@ -352,17 +353,20 @@ extern "C" void gcge_hip_dense_stats(const void* dm, long* nblocks, long* items,
 }
 
 // Y[:, 0:ncols) = A X[:, 0:ncols): remainder through the pad-8 kernel, then the blocks.  -1: alignment contract of the
-// pad-8 kernel not met (the caller keeps the CSR kernel on the full matrix).  which: 0 both, 1 remainder only, 2 blocks only (measurements)
+// pad-8 kernel not met (the caller keeps the CSR kernel on the full matrix).  which: 0 both, 1 remainder only, 2 blocks only (measurements);
+// + 4: a LISTED remainder is ADDED to the rows of Y (the sweep of spmm_star.hip wrote star + diagonal there before)
 extern "C" int gcge_hip_dense_spmm(const void* dm, const double* d_x, long ldx, double* d_y, long ldy, int ncols, void* stream, int which) {
   const DenseMat* D = (const DenseMat*)dm;
   if (ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15) || d_x == d_y) return -1;
+  const bool add = (which & 4) != 0 && D->d_rowmap != nullptr;
+  which &= 3;
   if (which != 2 && D->rem_tile != nullptr) {
     const int rc = gcge_hip_tile_spmm(D->rem_tile, d_x, ldx, d_y, ldy, ncols, stream);
     if (rc != 0) return rc;
   } else if (which != 2 && D->nlisted > 0) {
     gcge_hip_spmm_pad8_auto((double)D->noct / D->nlisted);
-    gcge_hip_spmm_pad8_row_map(D->d_rowmap);
+    if (add) gcge_hip_spmm_pad8_row_map_add(D->d_rowmap); else gcge_hip_spmm_pad8_row_map(D->d_rowmap);
     const int rc = gcge_hip_pad8_spmm(D->nlisted, D->d_orp, D->d_pcol, D->d_pval, d_x, ldx, d_y, ldy, ncols, stream);
     gcge_hip_spmm_pad8_row_map(nullptr);
     if (rc != 0) return rc;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void spmm_pad8_kernel(
     int nrows, const int* __restrict__ orp, const int* __restrict__ pcol,
     const double* __restrict__ pval, const double* __restrict__ x, size_t ldx,
     double* __restrict__ y, size_t ldy, int m, int rpw, long nchunks, double* __restrict__ dot_partial,
-    const int* __restrict__ sched, int sched_len, const int* __restrict__ rowmap) {
+    const int* __restrict__ sched, int sched_len, const int* __restrict__ rowmap, int accumulate) {
   constexpr int G = 64 / LPR;  // non-zeros per wave instruction
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -116,8 +116,11 @@ __global__ __launch_bounds__(256) void spmm_pad8_kernel(
     if (G >= 2) { acc0 += shfl_xor_f64(acc0, 32); acc1 += shfl_xor_f64(acc1, 32); }    \
     if (G >= 4) { acc0 += shfl_xor_f64(acc0, 16); acc1 += shfl_xor_f64(acc1, 16); }    \
     if (G >= 8) { acc0 += shfl_xor_f64(acc0, 8); acc1 += shfl_xor_f64(acc1, 8); }      \
-    if (act && g == 0)                                                                 \
-      store_row16<ST>(rowmap != nullptr ? y + (size_t)rowmap[row0 + r] * ldy + c0 : yl + (size_t)r * ldy, acc0, acc1); \
+    if (act && g == 0) {                                                               \
+      double* yq = rowmap != nullptr ? y + (size_t)rowmap[row0 + r] * ldy + c0 : yl + (size_t)r * ldy; \
+      if (accumulate) { const double2 yo = *reinterpret_cast<const double2*>(yq); acc0 += yo.x; acc1 += yo.y; }   /* Y += (a listed remainder on top of what another kernel wrote) */ \
+      store_row16<ST>(yq, acc0, acc1);                                                 \
+    }                                                                                  \
     if (DOT) {                                                                         \
       const double o0 = r == 0 ? xo0[0] : (r == 1 ? xo0[1] : (r == 2 ? xo0[2] : xo0[3])); \
       const double o1 = r == 0 ? xo1[0] : (r == 1 ? xo1[1] : (r == 2 ? xo1[2] : xo1[3])); \
@@ -192,7 +195,9 @@ static int g_p8_rpw = 8, g_p8_batch = 8, g_p8_store = 1, g_p8_pass = 0, g_p8_use
 // not listed are left alone): the remainder of a split whose other rows a different kernel writes (spmm_dense.hip under
 // spmm_star.hip).  Holds for the gcge_hip_pad8_spmm calls until it is reset with NULL (one stream, one caller).
 static const int* g_p8_rowmap = nullptr;
-extern "C" void gcge_hip_spmm_pad8_row_map(const int* d_map) { g_p8_rowmap = d_map; }
+static int g_p8_accumulate = 0;      // 1: Y[listed rows] += instead of =
+extern "C" void gcge_hip_spmm_pad8_row_map(const int* d_map) { g_p8_rowmap = d_map; g_p8_accumulate = 0; }
+extern "C" void gcge_hip_spmm_pad8_row_map_add(const int* d_map) { g_p8_rowmap = d_map; g_p8_accumulate = d_map != nullptr; }
 // rows per wave from the average row length (in octets of 8 padded non-zeros), unless a caller has tuned by hand.
 // Measured on the SiO2-like matrix (36 nnz/row, n = 5e6, 64 columns; profiles/r01_spmm_explore/26, 27):
 // rows per wave 8 / 4 / 2 / 1 = 9.87 / 8.33 / 6.95 / 6.81 ms — long rows keep a wave busy on their own, and fewer
@@ -227,7 +232,7 @@ static void p8_launch(int nrows, const int* orp, const int* pcol, const double* 
   const int* sched = nullptr; int slen = 0;
   if (g_p8_sched != nullptr && g_p8_sched_rpw == g_p8_rpw) { sched = g_p8_sched; slen = g_p8_sched_len; grid = g_p8_sched_grid; }
   hipLaunchKernelGGL((spmm_pad8_kernel<LPR, BATCH, ST, 0>), dim3((unsigned)grid), dim3(256), 0, st, nrows, orp,
-                     pcol, pval, x, ldx, y, ldy, m, g_p8_rpw, nchunks, (double*)nullptr, sched, slen, g_p8_rowmap);
+                     pcol, pval, x, ldx, y, ldy, m, g_p8_rpw, nchunks, (double*)nullptr, sched, slen, g_p8_rowmap, g_p8_accumulate);
 }
 // fused SpMM + column dots: rows_per_wave fixed at 4, at most `grid` partial rows
 template <int LPR>
@@ -236,7 +241,7 @@ static void p8_launch_dot(int nrows, const int* orp, const int* pcol, const doub
   const int rpw = 4;   // the kernel keeps the wave's own X rows in 4 register pairs; fewer rows per wave do not pay here
   const long nchunks = ((long)nrows + 4 * rpw - 1) / (4 * rpw);
   hipLaunchKernelGGL((spmm_pad8_kernel<LPR, 4, 1, 1>), dim3((unsigned)grid), dim3(256), 0, st, nrows, orp, pcol,
-                     pval, x, ldx, y, ldy, m, rpw, nchunks, partial, (const int*)nullptr, 0, (const int*)nullptr);
+                     pval, x, ldx, y, ldy, m, rpw, nchunks, partial, (const int*)nullptr, 0, (const int*)nullptr, 0);
 }
 template <int LPR, int BATCH>
 static void p8_store(int nrows, const int* orp, const int* pcol, const double* pval,

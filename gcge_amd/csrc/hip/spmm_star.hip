@@ -46,7 +46,7 @@ struct StarCoef { double cx[STAR_R + 1], cy[STAR_R + 1], cz[STAR_R + 1]; };   //
 // planes outside [zmin, zmax) are outside the grid (Dirichlet: zero) or beyond the star's arms (coefficient zero): never loaded.
 struct StarGeom { int nx, ny, nz, zs, ze, zmin, zmax; long lo_off, mid_off, hi_off; };
 struct StarMat {
-  StarGeom g; int R; bool iso; long nclean, nrows; StarCoef c; double* d_diag;   // d_diag[local row]: the row's diagonal entry, NaN: not a clean row
+  StarGeom g; int R; bool iso; long nclean, nrows; StarCoef c; double* d_diag; unsigned char* d_clean;   // d_clean[local row]: 1 = nothing but the star and a diagonal   // d_diag[local row]: the row's diagonal entry, NaN: not a clean row
 };
 
 // staging plan of a thread: unit u = tid + 1024 q, point u >> 2, 16-byte part u & 3
@@ -56,155 +56,192 @@ __device__ __forceinline__ v2d star_ld(const double* __restrict__ x, size_t ldx,
   return *reinterpret_cast<const v2d*>(x + (size_t)row * ldx + col);
 }
 
-// One plane step with queue phase U (compile-time): see the file header.  `z` is the output plane.
-#define STAR_SLOT(U, k) (((U) + 6 + (k) + 2 * STAR_Q) % STAR_Q)
 
-// DOT: additionally partial[(workgroup of this patch and z range) * 2 ncols + j] = sum over the star rows the workgroup wrote of
-// x[r, j] y[r, j], and at + ncols the same of y[r, j]^2 (columns of this pass only) — the p.w and w.w of a CG step, for free.
-// ISO: the three axes share one set of coefficients, bit for bit (a uniform grid spacing — the usual case): 12 scalar registers
-// of coefficients instead of 36.  SLAB: a row slab with halo planes (dlo / dhi != 0); without it the selects below are compiled out.
-// The scalar registers are what this loop is short of: with everything a slab needs on top of three coefficient sets the compiler
-// re-fetched kernel arguments inside the loop (s_load + lgkmcnt(0) per step: 2.42 -> 2.74 ms on the 171^3 matrix).  Hence also:
-// diagv / xv / yv are the operands shifted by the host to GLOBAL plane numbering (row of grid point (i, zz) = plane_rows zz + i
-// for the planes of the slab), so no "minus first plane" is left in here; dlo / dhi = what to add for the planes below / above.
-template <bool DOT, bool ISO, bool SLAB>
-__global__ __launch_bounds__(1024) void spmm_star_kernel(int nx, int ny, int zs, int ze, int zmin, int zmax, long dlo, long dhi, StarCoef cf,
+// ---------------------------------------------------------------------------------------------- the sweep, second form
+// Same patch (16 x 16 points, 8 columns, one z range), same register queue along z — another assignment of lanes and one
+// barrier per plane instead of two:
+//   * the 4 lanes that hold the 4 column pairs of a point are NEIGHBOURS in a wave, a wave is one grid line of the patch (16
+//     points): a lane's own 16 bytes of plane z + 7 come straight from global memory into its queue register and its result goes
+//     straight back (64-byte segments per point either way) — no "core in" / "result out" tiles in LDS;
+//   * the plane image is point-major (64 B per point): what a wave reads for an x or y neighbour is ONE contiguous kilobyte —
+//     the part-major image of the first form lost half of its LDS cycles to bank conflicts (4 line segments 448 B apart);
+//   * two plane images: step z reads image z, writes image z + 1 (own values from the queue, halo strips loaded TWO steps earlier
+//     into registers), one barrier separates the steps; 14 queue slots (13 planes live + the one in flight), unrolled 14 steps so
+//     that every slot index and the image in use are compile-time constants;
+//   * one coefficient set for all axes (ISO): the six neighbours at distance k are summed first, one multiply-add per k
+//     (72 instead of 144 double-precision operations per step).
+__device__ __forceinline__ v2d star2_and(v2d v, unsigned long long m) {   // m: all ones or zero
+  typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+  u2 b = __builtin_bit_cast(u2, v);
+  b.x &= m; b.y &= m;
+  return __builtin_bit_cast(v2d, b);
+}
+constexpr int STAR2_Q = 14;
+#define S2SLOT(U, k) (((U) + (k) + STAR_R + 2 * STAR2_Q) % STAR2_Q)
+// LPP: lanes (of 16 bytes) per grid point = columns per pass / 2.  4: a 16 x 16 patch, 8 columns — 64-byte pieces of the rows;
+// 8: a 16 x 8 patch, 16 columns — 128-byte pieces, i.e. whole cache lines.  tools/seg_bench.hip: on this chip 64-byte pieces of
+// 512-byte rows come in at 3.1-3.9 TB/s (2.8 with the write-back) whatever is done, 128-byte pieces at 6.2 (5.4) TB/s, and the
+// sweep's time is proportional to its traffic (tools/star_dbg_probe.py: LDS reads and barriers cost nothing, every X row fetched
+// costs its share): the smaller patch stages 3.25 rows per row instead of 2.5 but moves them at the full rate.
+template <int LPP> struct Star2Geom {
+  static constexpr int TY = 64 / LPP;                    // lines of the patch (16 points each)
+  static constexpr int ROWS = TY + 2 * STAR_R;           // image rows
+  static constexpr int IMG = ROWS * STAR_PW * LPP;       // v2d entries of one plane image
+  static constexpr int HPTS = 2 * STAR_R * TY + 2 * STAR_R * STAR_T;   // halo points per plane: side strips, then top / bottom strips
+  static constexpr int HQ = (HPTS * LPP + 1023) / 1024;  // halo units per thread
+};
+template <bool DOT, bool ISO, bool SLAB, int LPP, int dbg = 0>
+__global__ __launch_bounds__(1024) void spmm_star2_kernel(int nx, int ny, int zs, int ze, int zmin, int zmax, long dlo, long dhi, StarCoef cf,
     const double* __restrict__ diag, const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols,
-    int zlo, int zhi, int zlen, int ntx, double* __restrict__ partial) {
-  __shared__ v2d plane[4 * STAR_NP];            // part-major: plane[part * NP + slot]
-  __shared__ v2d corein[4 * 256];
-  __shared__ v2d outt[4 * 256];
+    int zlo, int zhi, int zlen, int ntx, double* __restrict__ partial, const unsigned char* __restrict__ cleanf) {
+  typedef Star2Geom<LPP> GEO;
+  constexpr int TY = GEO::TY, IMG = GEO::IMG, HQ = GEO::HQ, SIDE = 2 * STAR_R * TY;
+  __shared__ v2d img[2 * IMG];                  // img[b][(row * 28 + col) * LPP + part]
   const int tid = threadIdx.x;
-  const int p = tid & 255, cp = tid >> 8, px = p & 15, py = p >> 4;
+  const int part = tid % LPP, px = (tid / LPP) & 15, py = tid / (16 * LPP);
   const int tile_x = blockIdx.x % ntx, tile_y = blockIdx.x / ntx;
-  const int x0 = tile_x * STAR_T, y0 = tile_y * STAR_T;
-  const int z0 = zlo + blockIdx.y * zlen, z1 = min(zhi, z0 + zlen);     // output planes of this workgroup (global plane numbers)
-  const int c0 = 8 * blockIdx.z;
+  const int x0 = tile_x * STAR_T, y0 = tile_y * TY;
+  const int z0 = zlo + blockIdx.y * zlen, z1 = min(zhi, z0 + zlen);
+  const int c0 = 2 * LPP * blockIdx.z;
   const long plane_rows = (long)nx * ny;
-  auto plane_row0 = [&](int zz) -> long { return plane_rows * zz + (SLAB ? (zz < zs ? dlo : zz >= ze ? dhi : 0L) : 0L); };   // row of X of its point 0
-  constexpr long loc = 0;
-  // ---- compute lane: point (x0 + px, y0 + py), columns c0 + 2 cp, + 1
+  auto plane_row0 = [&](int zz) -> long { return plane_rows * zz + (SLAB ? (zz < zs ? dlo : zz >= ze ? dhi : 0L) : 0L); };
   const int gx = x0 + px, gy = y0 + py;
-  const bool inside = gx < nx && gy < ny;
-  const long own = inside ? (long)gx + (long)nx * gy : 0;
-  const int ccol = c0 + 2 * cp;
-  const bool cvalid = ccol < ncols;
-  const int slot = (py + STAR_R) * STAR_PW + (px + STAR_R);
-  // ---- staging units
-  StarUnit su[3];
-  const int si = tid & 3;
-  const int scol = c0 + 2 * si;
-  const bool svalid = scol < ncols;
+  const bool cvalid = c0 + 2 * part < ncols;
+  const int col = cvalid ? c0 + 2 * part : c0;                           // (a valid address whatever the lane: see star2_and)
+  const bool inside = gx < nx && gy < ny && cvalid;
+  const int own_i = inside ? gx + nx * gy : -1;                          // my point's offset inside a plane (< 0: none)
+  const int slot = ((py + STAR_R) * STAR_PW + (px + STAR_R)) * LPP + part;
+  // Every load below is UNCONDITIONAL at a clamped, valid address; what must read as zero (points outside the grid, planes
+  // outside [zmin, zmax), columns past the block) is masked to zero bit-wise afterwards.  A predicate next to a load makes
+  // hipcc branch round it and wait vmcnt(0) behind it ("no predicate anywhere near a load"): the requests of the
+  // NEXT steps would be drained at every step.
+#define own ((long)max(own_i, 0))
+#define own_m (~(unsigned long long)(long)(own_i >> 31))
+  // halo units of this thread: unit u = tid + 1024 q, point u / LPP, part u % LPP
+  int hsrc[HQ], hdst[HQ];                        // hsrc < 0: reads as zero (outside the grid / the block's columns)
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int pt = (tid + 1024 * q) >> 2;
-    int xx, yy, dst;
-    if (pt < 256) { xx = pt & 15; yy = pt >> 4; dst = -2 - (si * 256 + pt); }                  // core of plane z + 6 -> corein (encoded below)
-    else if (pt < 448) { const int j = pt - 256, ry = j / 12, a = j % 12; yy = ry; xx = a < 6 ? a - 6 : 10 + a;
-                         dst = si * STAR_NP + (yy + STAR_R) * STAR_PW + (xx + STAR_R); }
-    else if (pt < 640) { const int j = pt - 448, d = j >> 4; xx = j & 15; yy = d < 6 ? d - 6 : 10 + d;
-                         dst = si * STAR_NP + (yy + STAR_R) * STAR_PW + (xx + STAR_R); }
-    else { xx = 0; yy = 0; dst = -1; }
+  for (int q = 0; q < HQ; ++q) {
+    const int pt = (tid + 1024 * q) / LPP;
+    int xx, yy;
+    if (pt < SIDE) { const int ry = pt / 12, a = pt % 12; yy = ry; xx = a < 6 ? a - 6 : 10 + a; }
+    else if (pt < GEO::HPTS) { const int j = pt - SIDE, d = j >> 4; xx = j & 15; yy = d < 6 ? d - 6 : TY - 6 + d; }
+    else { xx = 0; yy = 0; }
     const int ax = x0 + xx, ay = y0 + yy;
-    su[q].dst = dst;
-    su[q].src = (dst != -1 && ax >= 0 && ax < nx && ay >= 0 && ay < ny && svalid) ? ax + nx * ay : -1;
+    const bool ok = pt < GEO::HPTS && ax >= 0 && ax < nx && ay >= 0 && ay < ny && cvalid;
+    hdst[q] = pt < GEO::HPTS ? ((yy + STAR_R) * STAR_PW + (xx + STAR_R)) * LPP + part : -1;
+    hsrc[q] = ok ? ax + nx * ay : -1;
   }
-  // out-tile flush: point tid >> 2, part si
-  const int opt = tid >> 2, ox = x0 + (opt & 15), oy = y0 + (opt >> 4);
-  const bool oinside = ox < nx && oy < ny && svalid;
-  const long orow = oinside ? (long)ox + (long)nx * oy : 0;
-
-  // ---- queue: planes z0 - 6 .. z0 + 5 into slots 0 .. 11
-  v2d qv[STAR_Q];
-#pragma unroll
-  for (int t = 0; t < STAR_Q - 1; ++t) {
-    const int zz = z0 - STAR_R + t;
-    qv[t] = (inside && cvalid && zz >= zmin && zz < zmax) ? star_ld(x, ldx, own + plane_row0(zz), ccol) : v2d{0.0, 0.0};
-  }
-  qv[STAR_Q - 1] = v2d{0.0, 0.0};
-  // staged loads of the first step: core of plane z0 + 6, arms of plane z0
-  v2d st[3], stn[3];                                          // this step's staged rows / the next step's, in flight for a whole step
-  auto stage_load = [&](int z) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int zz = su[q].dst < -1 ? z + STAR_R : z;          // core units fetch plane z + 6, arm units plane z
-      stn[q] = (su[q].src >= 0 && zz >= zmin && zz < zmax) ? star_ld(x, ldx, (long)su[q].src + plane_row0(zz), scol) : v2d{0.0, 0.0};
-    }
+  auto ld_own = [&](int zz) -> v2d {
+    const int zc = min(max(zz, zmin), zmax - 1);
+    const unsigned long long zm = (zz >= zmin && zz < zmax) ? ~0ull : 0ull;
+    return star2_and(star_ld(x, ldx, own + plane_row0(zc), col), own_m & zm);
   };
-  stage_load(z0);
-  double dg = (inside && z0 < z1) ? diag[own + loc + plane_rows * z0] : NAN;     // diagonal of my point in the output plane (NaN: not mine to write)
-  double dgo = NAN;                                                       // the same for the point whose result I flush
-  long flush_plane = -1;
-  v2d spw = v2d{0.0, 0.0}, sww = v2d{0.0, 0.0};                           // DOT: sums over my point's star rows
+  auto ld_halo = [&](int q, int zz) -> v2d {
+    const int zc = min(max(zz, zmin), zmax - 1);
+    const unsigned long long zm = (zz >= zmin && zz < zmax) ? ~0ull : 0ull;
+    const unsigned long long hmask = ~(unsigned long long)(long)(hsrc[q] >> 31);          // all ones unless hsrc < 0
+    return star2_and(star_ld(x, ldx, (long)max(hsrc[q], 0) + plane_row0(zc), col), hmask & zm);
+  };
+  // the diagonal of my point in plane zz (NaN: not a star row / not my plane), same rule
+  auto ld_diag = [&](int zz) -> double {
+    const int zc = min(max(zz, z0), max(z1 - 1, z0));
+    const unsigned long long m = (zz < z1 ? ~0ull : 0ull) & own_m;
+    unsigned long long b = __builtin_bit_cast(unsigned long long, diag[own + plane_rows * zc]);
+    b = (b & m) | (0x7ff8000000000000ull & ~m);
+    return __builtin_bit_cast(double, b);
+  };
+  // ---- prologue: planes z0 - 6 .. z0 + 6 into slots 0 .. 12; image 0 = plane z0; halo strips of plane z0 + 1 in flight
+  v2d qv[STAR2_Q];
+#pragma unroll
+  for (int t = 0; t < STAR2_Q - 1; ++t) qv[t] = ld_own(z0 - STAR_R + t);
+  qv[STAR2_Q - 1] = v2d{0.0, 0.0};
+  v2d st[HQ];                                    // halo strips in flight: requested at the end of a step, written to LDS at the end of the next
+  {
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) st[q] = ld_halo(q, z0);
+    img[slot] = qv[STAR_R];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) if (hdst[q] >= 0) img[hdst[q]] = st[q];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) st[q] = ld_halo(q, z0 + 1);
+  }
+  double dg = ld_diag(z0);                       // diagonal of my point in the output plane (NaN: no point of mine there)
+  // DOT: the sums run over the rows that are COMPLETE after the sweep (nothing but the star and a diagonal); the other rows get
+  // the rest of their product from the kernels that follow, and their share of the sums from star_coldots2_rows
+  auto ld_clean = [&](int zz) -> int { return DOT ? (int)cleanf[own + plane_rows * min(max(zz, z0), max(z1 - 1, z0))] : 1; };
+  int cl = ld_clean(z0);
+  v2d spw = v2d{0.0, 0.0}, sww = v2d{0.0, 0.0};
+  __syncthreads();
 
-  for (int zb = z0; zb < z1; zb += STAR_Q) {
-#define STAR_STEP(U)                                                                                                        \
+  for (int zb = z0; zb < z1; zb += STAR2_Q) {
+#define STAR2_STEP(U)                                                                                                       \
     {                                                                                                                       \
       const int z = zb + (U);                                                                                               \
       if (z >= z1) break;                                                                                                   \
-      _Pragma("unroll") for (int q = 0; q < 3; ++q) st[q] = stn[q];                                                          \
-      stage_load(z + 1);                                 /* requested a whole step before they are written to LDS */         \
-      __syncthreads();                                   /* A: last step's LDS reads are done, its results are in outt */    \
-      _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                                       \
-        if (su[q].dst >= 0) plane[su[q].dst] = st[q];                                                                       \
-        else if (su[q].dst < -1) corein[-2 - su[q].dst] = st[q];                                                            \
-      }                                                                                                                     \
-      plane[cp * STAR_NP + slot] = qv[STAR_SLOT(U, 0)];                                                                        \
-      if (flush_plane >= 0 && oinside && dgo == dgo)                                                                        \
-        __builtin_nontemporal_store(outt[si * 256 + opt], reinterpret_cast<v2d*>(y + (size_t)(orow + loc + plane_rows * flush_plane) * ldy + scol)); \
-      __syncthreads();                                   /* B */                                                            \
-      qv[STAR_SLOT(U, STAR_R)] = corein[cp * 256 + p];      /* plane z + 6 */                                                   \
-      dgo = oinside ? diag[orow + loc + plane_rows * z] : NAN;                                                              \
-      flush_plane = z;                                                                                                      \
-      const double dnext = (inside && z + 1 < z1) ? diag[own + loc + plane_rows * (z + 1)] : NAN;                            \
+      constexpr int CUR = ((U) & 1) * IMG, NXT = (((U) + 1) & 1) * IMG;                                                     \
+      /* request: my point in plane z + 7 (first used at step z + 1) */                                                     \
+      if (!(dbg & 8)) qv[S2SLOT(U, STAR_R + 1)] = ld_own(z + STAR_R + 1);                                                   \
+      const double dnext = ld_diag(z + 1);                                                                                  \
+      const int cnext = ld_clean(z + 1);                                                                                    \
       const double d0 = dg == dg ? dg : 0.0;                                                                                \
-      v2d acc = qv[STAR_SLOT(U, 0)] * d0;                                                                                      \
+      v2d acc = qv[S2SLOT(U, 0)] * d0;                                                                                      \
+      const v2d* pl = img + CUR + slot;                                                                                     \
       _Pragma("unroll") for (int k = 1; k <= STAR_R; ++k) {                                                                 \
-        const v2d zs = qv[STAR_SLOT(U, -k)] + qv[STAR_SLOT(U, k)];                                                                 \
-        acc.x = fma(cf.cz[k], zs.x, acc.x); acc.y = fma(cf.cz[k], zs.y, acc.y);                                              \
+        const v2d zsum = qv[S2SLOT(U, -k)] + qv[S2SLOT(U, k)];                                                              \
+        v2d xsum = v2d{0.0, 0.0}, ysum = v2d{0.0, 0.0};                                                                     \
+        if (!(dbg & 2)) { xsum = pl[-LPP * k] + pl[LPP * k]; ysum = pl[-LPP * k * STAR_PW] + pl[LPP * k * STAR_PW]; }        \
+        if (ISO) {                                                                                                          \
+          const v2d s6 = (zsum + xsum) + ysum;                                                                              \
+          acc.x = fma(cf.cz[k], s6.x, acc.x); acc.y = fma(cf.cz[k], s6.y, acc.y);                                            \
+        } else {                                                                                                            \
+          acc.x = fma(cf.cz[k], zsum.x, acc.x); acc.y = fma(cf.cz[k], zsum.y, acc.y);                                        \
+          acc.x = fma(cf.cx[k], xsum.x, acc.x); acc.y = fma(cf.cx[k], xsum.y, acc.y);                                        \
+          acc.x = fma(cf.cy[k], ysum.x, acc.x); acc.y = fma(cf.cy[k], ysum.y, acc.y);                                        \
+        }                                                                                                                   \
       }                                                                                                                     \
-      const v2d* pl = plane + cp * STAR_NP + slot;                                                                          \
-      _Pragma("unroll") for (int k = 1; k <= STAR_R; ++k) {                                                                 \
-        const v2d xs = pl[-k] + pl[k];                                                                                      \
-        acc.x = fma(ISO ? cf.cz[k] : cf.cx[k], xs.x, acc.x); acc.y = fma(ISO ? cf.cz[k] : cf.cx[k], xs.y, acc.y);            \
-        const v2d ys = pl[-k * STAR_PW] + pl[k * STAR_PW];                                                                   \
-        acc.x = fma(ISO ? cf.cz[k] : cf.cy[k], ys.x, acc.x); acc.y = fma(ISO ? cf.cz[k] : cf.cy[k], ys.y, acc.y);            \
+      if (dg == dg && (!(dbg & 4) || acc.x == 12345.678)) {                                                                 \
+        __builtin_nontemporal_store(acc, reinterpret_cast<v2d*>(y + (size_t)(own + plane_rows * z) * ldy + col));           \
+        if (DOT && cl != 0) {                                                                                               \
+          const v2d xc = qv[S2SLOT(U, 0)];                                                                                  \
+          spw.x = fma(xc.x, acc.x, spw.x); spw.y = fma(xc.y, acc.y, spw.y);                                                  \
+          sww.x = fma(acc.x, acc.x, sww.x); sww.y = fma(acc.y, acc.y, sww.y);                                                \
+        }                                                                                                                   \
       }                                                                                                                     \
-      outt[cp * 256 + p] = acc;                                                                                             \
-      if (DOT && dg == dg) {                                                                                                \
-        const v2d xc = qv[STAR_SLOT(U, 0)];                                                                                 \
-        spw.x = fma(xc.x, acc.x, spw.x); spw.y = fma(xc.y, acc.y, spw.y);                                                    \
-        sww.x = fma(acc.x, acc.x, sww.x); sww.y = fma(acc.y, acc.y, sww.y);                                                  \
-      }                                                                                                                     \
-      dg = dnext;                                                                                                           \
+      /* image of plane z + 1: my value from the queue, the strips requested a step ago; then the request for plane z + 2's */ \
+      img[NXT + slot] = qv[S2SLOT(U, 1)];                                                                                   \
+      _Pragma("unroll") for (int q = 0; q < HQ; ++q) if (hdst[q] >= 0) img[NXT + hdst[q]] = st[q];                           \
+      if (!(dbg & 1)) { _Pragma("unroll") for (int q = 0; q < HQ; ++q) st[q] = ld_halo(q, z + 2); }                          \
+      dg = dnext; cl = cnext;                                                                                               \
+      if (!(dbg & 16)) __syncthreads();                                                                                     \
     }
-    STAR_STEP(0) STAR_STEP(1) STAR_STEP(2) STAR_STEP(3) STAR_STEP(4) STAR_STEP(5) STAR_STEP(6)
-    STAR_STEP(7) STAR_STEP(8) STAR_STEP(9) STAR_STEP(10) STAR_STEP(11) STAR_STEP(12)
-#undef STAR_STEP
+    STAR2_STEP(0) STAR2_STEP(1) STAR2_STEP(2) STAR2_STEP(3) STAR2_STEP(4) STAR2_STEP(5) STAR2_STEP(6)
+    STAR2_STEP(7) STAR2_STEP(8) STAR2_STEP(9) STAR2_STEP(10) STAR2_STEP(11) STAR2_STEP(12) STAR2_STEP(13)
+#undef STAR2_STEP
   }
-  __syncthreads();
-  if (flush_plane >= 0 && oinside && dgo == dgo)
-    __builtin_nontemporal_store(outt[si * 256 + opt], reinterpret_cast<v2d*>(y + (size_t)(orow + loc + plane_rows * flush_plane) * ldy + scol));
   if (DOT) {
-    // fixed-order reduction over the 256 points of every column pair: through the plane image (4 x 784 >= 2 x 1024 v2d)
+    // fixed-order reduction over the points of every column pair: through the plane images (2 IMG >= 2 x 1024 v2d);
+    // a lane's partner at distance h in POINT index is LPP h lanes away
     __syncthreads();
-    plane[tid] = spw; plane[1024 + tid] = sww;
+    img[tid] = spw; img[IMG + tid] = sww;
     __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
-      if (p < h) {
-        const v2d a = plane[tid + h], b = plane[1024 + tid + h];
-        plane[tid].x += a.x; plane[tid].y += a.y; plane[1024 + tid].x += b.x; plane[1024 + tid].y += b.y;
+    const int pidx = tid / LPP;
+    for (int h = 512 / LPP; h > 0; h >>= 1) {
+      if (pidx < h) {
+        const v2d a = img[tid + LPP * h], b = img[IMG + tid + LPP * h];
+        img[tid].x += a.x; img[tid].y += a.y; img[IMG + tid].x += b.x; img[IMG + tid].y += b.y;
       }
       __syncthreads();
     }
-    if (p == 0 && cvalid) {
+    if (pidx == 0 && cvalid) {
       double* out = partial + ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 2 * ncols;
-      out[ccol] = plane[tid].x; out[ccol + 1] = plane[tid].y;
-      out[ncols + ccol] = plane[1024 + tid].x; out[ncols + ccol + 1] = plane[1024 + tid].y;
+      out[col] = img[tid].x; out[col + 1] = img[tid].y;
+      out[ncols + col] = img[IMG + tid].x; out[ncols + col + 1] = img[IMG + tid].y;
     }
   }
 }
-#undef STAR_SLOT
+#undef S2SLOT
+#undef own
+#undef own_m
 
 // partial[b * 2 m + j] = sum over the block's listed rows of x[r, j] y[r, j]; at + m: of y[r, j]^2 (rows = list[i]); 256 threads =
 // 4 row lanes x 64 columns, as coldots2_partial of vec_kernels.hip
@@ -342,55 +379,84 @@ static bool star_detect(const StarRows& M, StarHost* H) {
   return true;
 }
 
-// rows whose off-diagonal entries are exactly the star (truncated at the faces) -> diag[]; everything else -> remainder CSR
+// Split A = S + D + R: S the star (the same coefficients in every row, truncated at the faces of the grid), D the diagonal, R the
+// remainder.  EVERY row takes S + D from the sweep; a row is "clean" when its R is empty (its off-diagonal entries are exactly the
+// star, bit for bit).  In the other rows — inside atom blocks, next to anything irregular — R holds: every entry that is not at a
+// star position as it is; at a star position the entry MINUS the star's coefficient (nothing when they are equal; minus the
+// coefficient where the row has no entry there), rounded once.  R is added to what the sweep wrote by the kernels that follow it
+// (dense blocks + listed rows, spmm_dense.hip).  So the sweep needs no per-row decision and the listed rows carry only what really
+// differs from the star: on the SiO2-like matrix two thirds of the non-zeros the listed rows held before were plain star entries.
 static bool star_build_host(const StarRows& M, StarHost* H) {
   const int nrows = M.nrows; const int* rowptr = M.rowptr; const int* colidx = M.colidx; const double* val = M.val;
   if (M.ncols_local != nrows && M.ghost == nullptr) return false;     // halo columns of unknown origin: the other forms
   if (!star_detect(M, H)) return false;
-  const int nx = H->g.nx, ny = H->g.ny, nz = H->g.nz;
+  const StarGeom& gm = H->g;
+  const int nx = gm.nx, ny = gm.ny, nz = gm.nz;
   const long sy = nx, sz = (long)nx * ny;
-  H->diag.assign((size_t)nrows, NAN);
+  H->diag.assign((size_t)nrows, 0.0);
   H->rem_rowptr.assign((size_t)nrows + 1, 0);
-  uint64_t cb[3][STAR_R + 1];
-  for (int k = 0; k <= STAR_R; ++k) { cb[0][k] = star_bits(H->c.cx[k]); cb[1][k] = star_bits(H->c.cy[k]); cb[2][k] = star_bits(H->c.cz[k]); }
+  uint64_t cb[3][STAR_R + 1]; double cv[3][STAR_R + 1];
+  for (int k = 0; k <= STAR_R; ++k) {
+    cv[0][k] = H->c.cx[k]; cv[1][k] = H->c.cy[k]; cv[2][k] = H->c.cz[k];
+    for (int a = 0; a < 3; ++a) cb[a][k] = star_bits(cv[a][k]);
+  }
+  const long stride[3] = {1, sy, sz};
+  // local column (= row of X) of global row gq: own rows, or the halo planes below / above as the sweep addresses them
+  auto xcol = [&](long gq) -> long {
+    const int zz = (int)(gq / sz);
+    return (zz < gm.zs ? gm.lo_off : zz >= gm.ze ? gm.hi_off : gm.mid_off) + gq;
+  };
   long nclean = 0;
   std::vector<char>& clean = H->clean;
   clean.assign((size_t)nrows, 0);
+  std::vector<std::pair<int, double>> rem;                             // remainder of the row being looked at
+  std::vector<int>& rc = H->rem_col; std::vector<double>& rv = H->rem_val;
+  rc.clear(); rv.clear();
   for (int r = 0; r < nrows; ++r) {
     const long gr = M.row_begin + r;
     const int gz = (int)(gr / sz), gy = (int)((gr - (long)gz * sz) / sy), gx = (int)(gr - (long)gz * sz - (long)gy * sy);
     const int g[3] = {gx, gy, gz}, dim[3] = {nx, ny, nz};
-    int expect = 0;
+    bool seen[3][2][STAR_R + 1] = {};
+    rem.clear();
+    bool have_diag = false; double dv = 0.0;
+    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
+      const long o = M.gcol(colidx[q]) - gr;
+      if (o == 0 && !have_diag) { have_diag = true; dv = val[q]; continue; }
+      const long ao = o < 0 ? -o : o; const int sgn = o < 0 ? 0 : 1;
+      int a = -1, k = 0;
+      if (ao >= 1 && ao <= STAR_R) { a = 0; k = (int)ao; }
+      else if (ao % sz == 0 && ao / sz >= 1 && ao / sz <= STAR_R) { a = 2; k = (int)(ao / sz); }
+      else if (ao % sy == 0 && ao / sy >= 1 && ao / sy <= STAR_R) { a = 1; k = (int)(ao / sy); }
+      // a star position: the neighbour k steps along axis a exists in the grid and the star reaches that far
+      const bool star_pos = a >= 0 && cb[a][k] != 0 && !seen[a][sgn][k] && (sgn ? g[a] + k < dim[a] : g[a] - k >= 0);
+      if (!star_pos) { rem.emplace_back(colidx[q], val[q]); continue; }
+      seen[a][sgn][k] = true;
+      if (star_bits(val[q]) != cb[a][k]) rem.emplace_back(colidx[q], val[q] - cv[a][k]);
+    }
     for (int a = 0; a < 3; ++a)
       for (int k = 1; k <= STAR_R; ++k) {
-        if (cb[a][k] == 0) continue;                                  // (+0.0: no such neighbour in the star)
-        expect += (g[a] - k >= 0) + (g[a] + k < dim[a]);
+        if (cb[a][k] == 0) continue;
+        for (int sgn = 0; sgn < 2; ++sgn) {
+          const bool exists = sgn ? g[a] + k < dim[a] : g[a] - k >= 0;
+          if (!exists || seen[a][sgn][k]) continue;
+          // the sweep adds coefficient x neighbour here, the row has no such entry: the remainder takes it back
+          const long gq = gr + (sgn ? 1 : -1) * k * stride[a];
+          const int zz = (int)(gq / sz);
+          if (zz < gm.zmin || zz >= gm.zmax) return false;             // (cannot happen: zmin / zmax cover the star's reach)
+          rem.emplace_back((int)xcol(gq), -cv[a][k]);
+        }
       }
-    int matched = 0; bool ok = true, have_diag = false; double dv = 0.0;
-    for (int q = rowptr[r]; q < rowptr[r + 1] && ok; ++q) {
-      const long o = M.gcol(colidx[q]) - gr;
-      if (o == 0) { if (have_diag) ok = false; have_diag = true; dv = val[q]; continue; }
-      const long ao = o < 0 ? -o : o; const int sgn = o < 0 ? -1 : 1;
-      int a, k;
-      if (ao <= STAR_R) { a = 0; k = (int)ao; }
-      else if (ao % sz == 0 && ao / sz <= STAR_R) { a = 2; k = (int)(ao / sz); }
-      else if (ao % sy == 0 && ao / sy <= STAR_R) { a = 1; k = (int)(ao / sy); }
-      else { ok = false; break; }
-      const int nb = g[a] + sgn * k;
-      if (nb < 0 || nb >= dim[a] || cb[a][k] == 0 || star_bits(val[q]) != cb[a][k]) { ok = false; break; }
-      ++matched;
+    if (dv != dv) return false;                                        // a NaN on the diagonal: not for this form
+    H->diag[r] = dv;
+    if (rem.empty()) { clean[r] = 1; ++nclean; }
+    else {
+      std::sort(rem.begin(), rem.end(), [](const std::pair<int, double>& p, const std::pair<int, double>& q) { return p.first < q.first; });
+      for (auto& e : rem) { rc.push_back(e.first); rv.push_back(e.second); }
     }
-    if (ok && matched == expect && !(dv != dv)) { clean[r] = 1; H->diag[r] = dv; ++nclean; }
+    H->rem_rowptr[r + 1] = (int)rc.size();
   }
   H->nclean = nclean;
   if (2 * nclean < nrows) return false;
-  for (int r = 0; r < nrows; ++r) H->rem_rowptr[r + 1] = H->rem_rowptr[r] + (clean[r] ? 0 : rowptr[r + 1] - rowptr[r]);
-  H->rem_col.resize((size_t)H->rem_rowptr[nrows]); H->rem_val.resize((size_t)H->rem_rowptr[nrows]);
-  for (int r = 0; r < nrows; ++r)
-    if (!clean[r]) {
-      memcpy(H->rem_col.data() + H->rem_rowptr[r], colidx + rowptr[r], (size_t)(rowptr[r + 1] - rowptr[r]) * sizeof(int));
-      memcpy(H->rem_val.data() + H->rem_rowptr[r], val + rowptr[r], (size_t)(rowptr[r + 1] - rowptr[r]) * sizeof(double));
-    }
   return true;
 }
 
@@ -399,6 +465,10 @@ static bool star_build_host(const StarRows& M, StarHost* H) {
 using namespace gcge;
 
 static int g_star_mode = 0;   // 0 automatic, -1 never
+static int g_star_lpp = 4;    // second form: 8 = 16-column passes on 16 x 8 patches (128-byte pieces of the rows), 4 = 8 columns on 16 x 16 (64-byte pieces)
+extern "C" void gcge_hip_spmm_star_lanes(int lpp) { g_star_lpp = lpp == 4 ? 4 : 8; }
+static int g_star_dbg = 0;    // measurement only: 1 no halo loads, 2 no LDS arm reads, 4 no stores, 8 no own-plane loads (results are wrong then)
+extern "C" void gcge_hip_spmm_star_dbg(int bits) { g_star_dbg = bits; }
 extern "C" void gcge_hip_spmm_star_mode(int mode) { g_star_mode = mode; }
 extern "C" int gcge_hip_spmm_star_mode_get(void) { return g_star_mode; }
 
@@ -430,39 +500,54 @@ extern "C" long gcge_hip_star_selfcheck_slab(int nrows, int ncols_local, long ro
     out[5] = g.zs; out[6] = g.ze; out[7] = g.zmin; out[8] = g.zmax;
     out[9] = g.zmin < g.zs ? g.lo_off + sz * g.zmin : -1; out[10] = g.ze < g.zmax ? g.hi_off + sz * g.ze : -1;
   }
+  if (out) out[11] = H.rem_rowptr[nrows];
   long bad = 0;
   // where the sweep finds grid point (global row gq): the row of X, as the kernel computes it
   auto xrow = [&](long gq) -> long { const int zz = (int)(gq / sz); return (zz < g.zs ? g.lo_off : zz >= g.ze ? g.hi_off : g.mid_off) + gq; };
-  std::vector<std::pair<long, uint64_t>> want, got;
+  // every row rebuilt as star + diagonal + remainder (per column, in the order the kernels add them) against the CSR row: clean
+  // rows bit for bit; the others to the one rounding of "entry minus coefficient" at the star positions; a position the row
+  // has no entry at must cancel exactly
+  std::vector<std::pair<long, double>> want, got;
   for (int r = 0; r < nrows; ++r) {
     want.clear(); got.clear();
-    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) want.emplace_back((long)colidx[q], star_bits(val[q]));   // local columns = rows of X
-    if (H.diag[r] == H.diag[r]) {
-      if (H.rem_rowptr[r + 1] != H.rem_rowptr[r]) ++bad;
-      const long gr = row_begin + r;
-      const int gz = (int)(gr / sz), gy = (int)((gr - (long)gz * sz) / sy), gx = (int)(gr - (long)gz * sz - (long)gy * sy);
-      bool stored_diag = false;
-      for (auto& w : want) stored_diag |= w.first == r;
-      if (stored_diag || H.diag[r] != 0.0) got.emplace_back((long)r, star_bits(H.diag[r]));
-      for (int k = 1; k <= STAR_R; ++k) {
-        if (star_bits(H.c.cx[k])) { if (gx - k >= 0) got.emplace_back(xrow(gr - k), star_bits(H.c.cx[k])); if (gx + k < g.nx) got.emplace_back(xrow(gr + k), star_bits(H.c.cx[k])); }
-        if (star_bits(H.c.cy[k])) { if (gy - k >= 0) got.emplace_back(xrow(gr - k * sy), star_bits(H.c.cy[k])); if (gy + k < g.ny) got.emplace_back(xrow(gr + k * sy), star_bits(H.c.cy[k])); }
-        if (star_bits(H.c.cz[k])) {
-          if (gz - k >= 0) { if (gz - k < g.zmin) ++bad; got.emplace_back(xrow(gr - k * sz), star_bits(H.c.cz[k])); }
-          if (gz + k < g.nz) { if (gz + k >= g.zmax) ++bad; got.emplace_back(xrow(gr + k * sz), star_bits(H.c.cz[k])); }
-        }
+    for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) want.emplace_back((long)colidx[q], val[q]);   // local columns = rows of X
+    const long gr = row_begin + r;
+    const int gz = (int)(gr / sz), gy = (int)((gr - (long)gz * sz) / sy), gx = (int)(gr - (long)gz * sz - (long)gy * sy);
+    const bool is_clean = H.clean[r] != 0;
+    if (is_clean != (H.rem_rowptr[r + 1] == H.rem_rowptr[r])) ++bad;
+    bool stored_diag = false;
+    for (auto& w : want) stored_diag |= w.first == r;
+    if (stored_diag || H.diag[r] != 0.0) got.emplace_back((long)r, H.diag[r]);
+    for (int k = 1; k <= STAR_R; ++k) {
+      if (star_bits(H.c.cx[k])) { if (gx - k >= 0) got.emplace_back(xrow(gr - k), H.c.cx[k]); if (gx + k < g.nx) got.emplace_back(xrow(gr + k), H.c.cx[k]); }
+      if (star_bits(H.c.cy[k])) { if (gy - k >= 0) got.emplace_back(xrow(gr - k * sy), H.c.cy[k]); if (gy + k < g.ny) got.emplace_back(xrow(gr + k * sy), H.c.cy[k]); }
+      if (star_bits(H.c.cz[k])) {
+        if (gz - k >= 0) { if (gz - k < g.zmin) ++bad; got.emplace_back(xrow(gr - k * sz), H.c.cz[k]); }
+        if (gz + k < g.nz) { if (gz + k >= g.zmax) ++bad; got.emplace_back(xrow(gr + k * sz), H.c.cz[k]); }
       }
-    } else {
-      for (int q = H.rem_rowptr[r]; q < H.rem_rowptr[r + 1]; ++q) got.emplace_back((long)H.rem_col[q], star_bits(H.rem_val[q]));
     }
-    std::sort(want.begin(), want.end()); std::sort(got.begin(), got.end());
-    if (want != got) ++bad;
+    const size_t nstar = got.size();
+    for (int q = H.rem_rowptr[r]; q < H.rem_rowptr[r + 1]; ++q) got.emplace_back((long)H.rem_col[q], H.rem_val[q]);
+    auto less = [](const std::pair<long, double>& p, const std::pair<long, double>& q) { return p.first < q.first; };
+    std::stable_sort(want.begin(), want.end(), less); std::stable_sort(got.begin(), got.end(), less);   // (stable: star part before remainder)
+    (void)nstar;
+    size_t i = 0, j = 0;
+    bool ok = true;
+    while (i < want.size() || j < got.size()) {
+      const long c = (j >= got.size() || (i < want.size() && want[i].first <= got[j].first)) ? want[i].first : got[j].first;
+      double wv = 0.0, gv = 0.0, mag = 0.0; int nw = 0, ng = 0;
+      while (i < want.size() && want[i].first == c) { wv += want[i].second; ++i; ++nw; }
+      while (j < got.size() && got[j].first == c) { gv += got[j].second; mag = std::max(mag, fabs(got[j].second)); ++j; ++ng; }
+      if (is_clean || nw == 0 || ng <= 1) { if (star_bits(wv + 0.0) != star_bits(gv + 0.0) && !(wv == 0.0 && gv == 0.0)) ok = false; }
+      else if (fabs(wv - gv) > 4.0 * 2.220446049250313e-16 * std::max(mag, fabs(wv))) ok = false;
+    }
+    if (!ok) ++bad;
   }
   return bad;
 }
 extern "C" long gcge_hip_star_selfcheck(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, long* out) {
   if (ncols_local != nrows) return -1;
-  long o[11];
+  long o[12];
   const long bad = gcge_hip_star_selfcheck_slab(nrows, ncols_local, 0, nrows, nullptr, rowptr, colidx, val, o);
   if (out && bad >= 0) for (int i = 0; i < 5; ++i) out[i] = o[i];
   return bad;
@@ -471,7 +556,7 @@ extern "C" long gcge_hip_star_selfcheck(int nrows, int ncols_local, const int* r
 extern "C" void gcge_hip_star_free(void* sm) {
   StarMat* S = (StarMat*)sm;
   if (!S) return;
-  hipFree(S->d_diag);
+  hipFree(S->d_diag); hipFree(S->d_clean);
   delete S;
 }
 
@@ -491,6 +576,8 @@ extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin,
   GCGE_HIP_CHECK(hipMalloc(&S->d_diag, (size_t)nrows * sizeof(double)));
   GCGE_HIP_CHECK(hipMemcpy(S->d_diag, H->diag.data(), (size_t)nrows * sizeof(double), hipMemcpyHostToDevice));
   std::vector<double>().swap(H->diag);
+  GCGE_HIP_CHECK(hipMalloc(&S->d_clean, (size_t)nrows));
+  GCGE_HIP_CHECK(hipMemcpy(S->d_clean, H->clean.data(), (size_t)nrows, hipMemcpyHostToDevice));
   *rem_rowptr = H->rem_rowptr.data(); *rem_col = H->rem_col.data(); *rem_val = H->rem_val.data();
   if (g_star_last) delete g_star_last;
   g_star_last = H;
@@ -524,7 +611,12 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
                        hipStream_t stream) {
   const int nzl = zhi - zlo;
   if (nzl <= 0) return 0;
-  const int ntx = (S->g.nx + STAR_T - 1) / STAR_T, nty = (S->g.ny + STAR_T - 1) / STAR_T, npass = (ncols + 7) / 8;
+  const StarGeom& g = S->g;
+  const bool slab = g.zmin < g.zs || g.ze < g.zmax, iso = S->iso;
+  // 8 lanes per point = 16-column passes on 16 x 8 patches, 4 = 8-column passes on 16 x 16 patches (see the kernel)
+  const int lpp = (!iso || g_star_lpp == 4) ? 4 : 8;       // (per-axis coefficients, rare: the 8-column form needs fewer registers)
+  const int ty = 64 / lpp;
+  const int ntx = (g.nx + STAR_T - 1) / STAR_T, nty = (g.ny + ty - 1) / ty, npass = (ncols + 2 * lpp - 1) / (2 * lpp);
   // z ranges: ONE where the patches x passes already give every CU two workgroups' worth of work (each range re-reads 12 planes
   // of warm-up: 171^3, 64 columns: 1 / 2 / 3 / 4 ranges = 3.93 / 4.26 / 4.35 / 4.47 ms for the whole product), otherwise enough
   // ranges of at least 24 planes to get there
@@ -535,24 +627,27 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
   if (count_only) return nb;
   const dim3 grid((unsigned)(ntx * nty), (unsigned)zchunks, (unsigned)npass);
   // operands in global plane numbering (see the kernel): the slab's first plane is plane zs of the grid
-  const StarGeom& g = S->g;
   const long shift = g.mid_off;                                       // = - plane_rows * zs
   const double* xv = (const double*)((uintptr_t)d_x + (uintptr_t)(shift * ldx * (long)sizeof(double)));
   double* yv = (double*)((uintptr_t)d_y + (uintptr_t)(shift * ldy * (long)sizeof(double)));
   const double* dv = (const double*)((uintptr_t)S->d_diag + (uintptr_t)(shift * (long)sizeof(double)));
+  const unsigned char* cv = (const unsigned char*)((uintptr_t)S->d_clean + (uintptr_t)shift);
   const long dlo = g.lo_off - g.mid_off, dhi = g.hi_off - g.mid_off;
-  const bool slab = g.zmin < g.zs || g.ze < g.zmax, iso = S->iso;
-#define STAR_LAUNCH(DOT, ISO, SLAB)                                                                                                     \
-  hipLaunchKernelGGL((spmm_star_kernel<DOT, ISO, SLAB>), grid, dim3(1024), 0, stream, g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax, dlo, dhi, S->c, dv, xv, \
-                     (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part)
-  if (part == nullptr) {
-    if (iso) { if (slab) STAR_LAUNCH(false, true, true); else STAR_LAUNCH(false, true, false); }
-    else     { if (slab) STAR_LAUNCH(false, false, true); else STAR_LAUNCH(false, false, false); }
-  } else {
-    if (iso) { if (slab) STAR_LAUNCH(true, true, true); else STAR_LAUNCH(true, true, false); }
-    else     { if (slab) STAR_LAUNCH(true, false, true); else STAR_LAUNCH(true, false, false); }
-  }
-#undef STAR_LAUNCH
+#define STAR_ARGS g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax, dlo, dhi, S->c, dv, xv, (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part, cv
+#define STAR_LAUNCH2(DOT, ISO, SLAB, LPP) hipLaunchKernelGGL((spmm_star2_kernel<DOT, ISO, SLAB, LPP>), grid, dim3(1024), 0, stream, STAR_ARGS)
+#define STAR_DBG(B) case B: hipLaunchKernelGGL((spmm_star2_kernel<false, true, false, 8, B>), grid, dim3(1024), 0, stream, STAR_ARGS); return nb;
+  if (g_star_dbg != 0 && part == nullptr && iso && lpp == 8 && !slab)
+    switch (g_star_dbg) { STAR_DBG(1) STAR_DBG(2) STAR_DBG(8) STAR_DBG(3) STAR_DBG(9) STAR_DBG(16) default: break; }
+  const bool dot = part != nullptr;
+#define STAR_PICK(ISO, LPP)                                                                                          \
+  do { if (dot) { if (slab) STAR_LAUNCH2(true, ISO, true, LPP); else STAR_LAUNCH2(true, ISO, false, LPP); }          \
+       else     { if (slab) STAR_LAUNCH2(false, ISO, true, LPP); else STAR_LAUNCH2(false, ISO, false, LPP); } } while (0)
+  if (iso) { if (lpp == 8) STAR_PICK(true, 8); else STAR_PICK(true, 4); }
+  else STAR_PICK(false, 4);
+#undef STAR_PICK
+#undef STAR_DBG
+#undef STAR_LAUNCH2
+#undef STAR_ARGS
   return nb;
 }
 

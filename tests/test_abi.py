@@ -170,7 +170,7 @@ def test_star_split_on_row_slabs_cut_on_plane_boundaries():
     g.gcge_hip_star_selfcheck_slab.restype = C.c_long
     g.gcge_hip_star_selfcheck_slab.argtypes = [C.c_int, C.c_int, C.c_long, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                                C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_long)]
-    out = (C.c_long * 11)()
+    out = (C.c_long * 12)()
     G, kw = 24, dict(K=8, R0=1.5, R1=3.0)
     plane, n = G * G, G ** 3
     Ag, _ = make_problem("sio2", G, **kw)
