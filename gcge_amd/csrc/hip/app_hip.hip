@@ -104,6 +104,10 @@ struct GcgeHipMV {
   long ld;
   int nrows, nrows_alloc, ncols;
   const GCGE_HIP_MAT_* mat;   // shape donor (row partition)
+  // column-wise Gram-Schmidt over the slots (see "one sweep per column" below): the state lives in the block it belongs to
+  int pend_col; double pend_fac;                       // a scaling of column pend_col held back (pend_col < 0: none)
+  int spec_c0, spec_c1; unsigned long spec_epoch;      // Gram column of [spec_c0, spec_c1) computed on the way by the call of epoch spec_epoch
+  std::vector<double>* spec_dots;                      // (NULL: none)
 };
 
 // Shape contract of every slot is checked on the HOST before a kernel is launched: a
@@ -249,15 +253,18 @@ extern "C" int gcge_hip_dense_profile_report(char* buf, int len) {
 // Anything else flushes the held-back scaling first.  The speculative Gram column is served only to the IMMEDIATELY following data call (epoch
 // check) on the same block and column range; every entry point that touches block data goes through enter().
 static unsigned long g_epoch = 0;
-static struct { GcgeHipMV* mv; int col; double fac; } g_pend = {nullptr, 0, 1.0};
-static struct { GcgeHipMV* mv; int c0, c1; unsigned long epoch; std::vector<double> dots; } g_spec = {nullptr, 0, 0, 0, {}};
+static GcgeHipMV* g_pend_owner = nullptr;   // the one block with a held-back scaling (its pend_col >= 0), or NULL
 static int g_mgs_fuse = 1;
 extern "C" void gcge_hip_set_mgs_fusion(int on) { g_mgs_fuse = on; }
 static long g_mgs_fused_steps = 0, g_mgs_spec_hits = 0;
 extern "C" void gcge_hip_mgs_fusion_stats(long* fused_steps, long* served_grams) { if (fused_steps) *fused_steps = g_mgs_fused_steps; if (served_grams) *served_grams = g_mgs_spec_hits; }
 static void flush_pending();
-static inline void enter(bool keep_pending = false) { ++g_epoch; if (!keep_pending && g_pend.mv != nullptr) flush_pending(); }
+static inline void enter(bool keep_pending = false) { ++g_epoch; if (!keep_pending && g_pend_owner != nullptr) flush_pending(); }
 extern "C" void gcge_hip_flush_pending(void) { enter(); }   /* for other translation units that take device pointers of blocks */
+// the same without counting as a call (the epoch decides whether a speculative Gram column is still the latest word on its block):
+// called at the top of every EXPORTED raw kernel that takes device pointers (gcge_hip.h "raw kernels") — a caller may hold a
+// pointer from before the scaling was held back
+extern "C" void gcge_hip_apply_pending(void) { if (g_pend_owner != nullptr) flush_pending(); }
 
 static double* stage_d(size_t len) {
   if (len > g_stage_d_len) {
@@ -728,7 +735,7 @@ static void pool_free(void* q, size_t bytes) {
 // ------------------------------------------------------------------ multivector
 static GcgeHipMV* mv_new(int nrows, int nghost, int ncols, const GCGE_HIP_MAT_* mat) {
   GcgeHipMV* v = (GcgeHipMV*)calloc(1, sizeof(GcgeHipMV));
-  v->nrows = nrows; v->nrows_alloc = nrows + nghost; v->ncols = ncols; v->mat = mat;
+  v->nrows = nrows; v->nrows_alloc = nrows + nghost; v->ncols = ncols; v->mat = mat; v->pend_col = -1;
   v->ld = ((long)(ncols > 0 ? ncols : 1) + 7) / 8 * 8;
   const size_t bytes = (size_t)v->nrows_alloc * v->ld * sizeof(double);
   v->bytes = bytes ? bytes : 8;
@@ -747,14 +754,17 @@ static void HIP_MultiVecCreateByMultiVec(void*** mv, int num_vec, void** src, st
 static void HIP_MultiVecDestroy(void*** mv, int num_vec, struct OPS_* ops) {
   GcgeHipMV* v = *(GcgeHipMV**)mv;
   enter();
-  if (g_spec.mv == v) g_spec.mv = nullptr;
-  if (v) { pool_free(v->d, v->bytes); free(v); }
+  if (v) { delete v->spec_dots; pool_free(v->d, v->bytes); free(v); }
   *mv = nullptr;
 }
 static void flush_pending() {
-  GcgeHipMV* v = g_pend.mv;
-  g_pend.mv = nullptr;
-  if (v != nullptr) gcge_hip_colscale1(v->nrows, v->d + g_pend.col, v->ld, g_pend.fac, g_stream);
+  GcgeHipMV* v = g_pend_owner;
+  g_pend_owner = nullptr;
+  if (v != nullptr && v->pend_col >= 0) {
+    const int col = v->pend_col;
+    v->pend_col = -1;
+    gcge_hip_colscale1(v->nrows, v->d + col, v->ld, v->pend_fac, g_stream);
+  }
 }
 extern "C" int gcge_hip_mv_nrows(void** mv) { return ((GcgeHipMV*)mv)->nrows; }
 extern "C" int gcge_hip_mv_ncols(void** mv) { return ((GcgeHipMV*)mv)->ncols; }
@@ -854,7 +864,7 @@ static void HIP_MultiVecAxpby(double alpha, void** x, double beta, void** y, int
     GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols, "MultiVecAxpby: x column range");
   }
   if (vx == nullptr && m == 1 && beta != 0.0) {   // one column scaled in place (q_k = x_k / r_kk of a column-wise Gram-Schmidt)
-    if (g_mgs_fuse) { g_pend.mv = vy; g_pend.col = start[1]; g_pend.fac = beta; return; }   // held back: see enter()
+    if (g_mgs_fuse) { g_pend_owner = vy; vy->pend_col = start[1]; vy->pend_fac = beta; return; }   // held back: see enter()
     gcge_hip_colscale1(vy->nrows, vy->d + start[1], vy->ld, beta, g_stream);
     return;
   }
@@ -873,8 +883,8 @@ static void HIP_MultiVecLinearComb(void** x, void** y, int is_vec, int* start, i
     const bool step = g_mgs_fuse && k == 1 && vx == vy && vx != nullptr && coef != nullptr && start[1] == start[0] + 1 && m >= 1 && m <= 64 &&
                       beta != nullptr && incb == 0 && *beta == 1.0 && start[0] >= 0 && end[1] <= vy->ncols && vy->nrows > 0;
     double fac = 1.0;
-    if (g_pend.mv != nullptr) {
-      if (step && g_pend.mv == vx && g_pend.col == start[0]) { fac = g_pend.fac; g_pend.mv = nullptr; }
+    if (g_pend_owner != nullptr) {
+      if (step && g_pend_owner == vx && vx->pend_col == start[0]) { fac = vx->pend_fac; vx->pend_col = -1; g_pend_owner = nullptr; }
       else flush_pending();
     }
     if (step) {
@@ -888,8 +898,9 @@ static void HIP_MultiVecLinearComb(void** x, void** y, int is_vec, int* start, i
       GCGE_REQUIRE(rc == 0, "MultiVecLinearComb: kernel launch");
       GCGE_HIP_CHECK(hipMemcpyAsync(hc + m, dc + m, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
       GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
-      g_spec.mv = vy; g_spec.c0 = start[1]; g_spec.c1 = end[1]; g_spec.epoch = g_epoch;
-      g_spec.dots.assign(hc + m, hc + 2 * m);
+      vy->spec_c0 = start[1]; vy->spec_c1 = end[1]; vy->spec_epoch = g_epoch;
+      if (vy->spec_dots == nullptr) vy->spec_dots = new std::vector<double>();
+      vy->spec_dots->assign(hc + m, hc + 2 * m);
       ++g_mgs_fused_steps;
       return;
     }
@@ -960,15 +971,16 @@ static void local_inner_prod(char nsd, void** x, void** y, int is_vec, int* star
   enter();
   SlotTimer tm_(m == 1 ? "MultiVecLocalInnerProd (k x 1)" : "MultiVecLocalInnerProd", m == 1 ? k : m);
   if (k <= 0 || m <= 0) return;
-  if (m == 1 && nsd != 'D' && g_spec.mv != nullptr && g_spec.mv == vx && vx == vy && g_spec.epoch + 1 == g_epoch &&
-      start[0] == g_spec.c0 && start[1] == g_spec.c0 && end[0] == g_spec.c1 && (int)g_spec.dots.size() == k && ldIP >= k) {
-    // the Gram column the previous call (the rank-1 update of a Gram-Schmidt step) accumulated on its way: nothing has
-    // touched the block since (epoch), same block, same column range
-    for (int i = 0; i < k; ++i) ip[i] = g_spec.dots[i];
-    g_spec.mv = nullptr; ++g_mgs_spec_hits;
+  if (m == 1 && nsd != 'D' && vx == vy && vx->spec_dots != nullptr && !vx->spec_dots->empty() && vx->spec_epoch + 1 == g_epoch &&
+      start[0] == vx->spec_c0 && start[1] == vx->spec_c0 && end[0] == vx->spec_c1 && (int)vx->spec_dots->size() == k && ldIP >= k) {
+    // the Gram column the previous call (the rank-1 update of a Gram-Schmidt step ON THIS BLOCK) accumulated on its way: no
+    // call of any kind has been made since (epoch), same block, same column range
+    for (int i = 0; i < k; ++i) ip[i] = (*vx->spec_dots)[i];
+    vx->spec_dots->clear(); ++g_mgs_spec_hits;
     return;
   }
-  g_spec.mv = nullptr;
+  if (vx->spec_dots != nullptr) vx->spec_dots->clear();
+  if (vy->spec_dots != nullptr) vy->spec_dots->clear();
   GCGE_REQUIRE(vx->nrows == vy->nrows, "MultiVecInnerProd: equal row counts");
   GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols && start[1] >= 0 && end[1] <= vy->ncols, "MultiVecInnerProd: column ranges");
   GCGE_REQUIRE(nsd == 'D' ? ldIP >= 1 : ldIP >= k, "MultiVecInnerProd: ldIP");

@@ -44,6 +44,9 @@ struct GCGE_HIP_MAT_ {
   void* native_halo;   // RCCL plan of gcge_hip_mat_set_halo_rccl (rccl_comm.hip); it then owns sendbuf / recvbuf
 };
 extern "C" void gcge_hip_halo_native_free(struct GCGE_HIP_MAT_* A);
+// A column scaling the slots hold back (column-wise Gram-Schmidt, app_hip.hip) is applied now.  First statement of every EXPORTED
+// raw kernel that takes device pointers: the caller may have fetched its pointer before the scaling was held back.
+extern "C" void gcge_hip_apply_pending(void);
 
 #endif
 

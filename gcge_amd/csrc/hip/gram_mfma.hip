@@ -203,6 +203,7 @@ extern "C" void gcge_hip_gram_tune(int ms) { if (ms == 1 || ms == 2 || ms == 4) 
 
 extern "C" int gcge_hip_gram(int nrows, const double* d_q, long ldq, int k, const double* d_p, long ldp,
                              int m, double* d_g, void* stream) {
+  gcge_hip_apply_pending();
   if (k <= 0 || m <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (nrows <= 0) return (int)hipMemsetAsync(d_g, 0, (size_t)k * m * sizeof(double), st);

@@ -398,6 +398,7 @@ static int lc_launch(int nrows, const double* x, long ldx, int k, const double* 
 // d_c: row-major k x m coefficient block on the device; d_beta: m scale factors or NULL
 extern "C" int gcge_hip_lincomb(int nrows, const double* d_x, long ldx, int k, const double* d_c, int m,
                                 const double* d_beta, double* d_y, long ldy, void* stream) {
+  gcge_hip_apply_pending();
   if (nrows <= 0 || m <= 0 || k <= 0) return 0;
   if (m > 128) return -2;  // callers split wider panels
   hipStream_t st = (hipStream_t)stream;

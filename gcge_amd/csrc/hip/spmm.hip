@@ -428,6 +428,7 @@ static void launch_subwave(int nrows, const int* rowptr, const int* colidx, cons
 extern "C" int gcge_hip_csr_spmm(int nrows, const int* d_rowptr, const int* d_colidx,
                                  const double* d_val, const double* d_x, long ldx, double* d_y,
                                  long ldy, int ncols, void* stream) {
+  gcge_hip_apply_pending();
   if (nrows <= 0 || ncols <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int done = 0;

@@ -289,6 +289,7 @@ extern "C" int gcge_hip_pad8_spmm_dot(int nrows, const int* d_orp, const int* d_
 extern "C" int gcge_hip_pad8_spmm(int nrows, const int* d_orp, const int* d_pcol,
                                   const double* d_pval, const double* d_x, long ldx, double* d_y,
                                   long ldy, int ncols, void* stream) {
+  gcge_hip_apply_pending();
   if (nrows <= 0 || ncols <= 0) return 0;
   if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15))
     return -1;

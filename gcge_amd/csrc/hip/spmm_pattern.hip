@@ -656,11 +656,13 @@ extern "C" int gcge_hip_pattern_spmm_vals(int nrows, const unsigned short* d_pid
 extern "C" int gcge_hip_pattern_spmm_near(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                           long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
                                           double* d_dots, double* d_dots_yy, void* stream, long near) {
+  gcge_hip_apply_pending();
   return gcge_hip_pattern_spmm_vals(nrows, d_pid, d_tab, npat, lt, span, span2, d_x, ldx, d_y, ldy, ncols, d_dots, d_dots_yy, stream, near, nullptr);
 }
 extern "C" int gcge_hip_pattern_spmm(int nrows, const unsigned short* d_pid, const void* d_tab, int npat, int lt,
                                      long span, long span2, const double* d_x, long ldx, double* d_y, long ldy, int ncols,
                                      double* d_dots, double* d_dots_yy, void* stream) {
+  gcge_hip_apply_pending();
   return gcge_hip_pattern_spmm_near(nrows, d_pid, d_tab, npat, lt, span, span2, d_x, ldx, d_y, ldy, ncols, d_dots, d_dots_yy, stream, 0);
 }
 // near > 0: as in gcge_hip_pattern_cg_near — the product may take the LDS-ring sweep (spmm_ring.hip)
@@ -767,6 +769,7 @@ extern "C" int gcge_hip_pattern_cg_near(int mode, int nrows, const unsigned shor
                                         long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
                                         long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
                                         double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb, long near) {
+  gcge_hip_apply_pending();
   return gcge_hip_pattern_cg_vals(mode, nrows, d_pid, d_tab, npat, lt, span, span2, d_x, ldx, d_r, ldr, d_pnew, ldp, ncols, d_alpha, d_beta,
                                   d_flag, d_dots, d_dots_yy, stream, d_b, ldb, near, nullptr);
 }
@@ -833,6 +836,7 @@ extern "C" int gcge_hip_pattern_cg(int mode, int nrows, const unsigned short* d_
                                    long span, long span2, const double* d_x, long ldx, double* d_r, long ldr, double* d_pnew,
                                    long ldp, int ncols, const double* d_alpha, const double* d_beta, const int* d_flag,
                                    double* d_dots, double* d_dots_yy, void* stream, const double* d_b, long ldb) {
+  gcge_hip_apply_pending();
   return gcge_hip_pattern_cg_near(mode, nrows, d_pid, d_tab, npat, lt, span, span2, d_x, ldx, d_r, ldr, d_pnew, ldp, ncols, d_alpha,
                                   d_beta, d_flag, d_dots, d_dots_yy, stream, d_b, ldb, 0);
 }

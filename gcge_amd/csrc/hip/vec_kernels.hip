@@ -248,6 +248,7 @@ static inline unsigned grid_for(long total) {
 
 extern "C" int gcge_hip_axpby(int nrows, double alpha, const double* d_x, long ldx, double beta,
                               double* d_y, long ldy, int m, void* stream) {
+  gcge_hip_apply_pending();
   if (nrows <= 0 || m <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int mode;
@@ -482,6 +483,7 @@ extern "C" int gcge_hip_colscale1(int nrows, double* d_y, long ldy, double s, vo
 
 extern "C" int gcge_hip_coldots(int nrows, const double* d_x, long ldx, const double* d_y, long ldy, int m,
                                 double* d_out, void* stream) {
+  gcge_hip_apply_pending();
   if (m <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (nrows <= 0) return (int)hipMemsetAsync(d_out, 0, m * sizeof(double), st);
@@ -499,6 +501,7 @@ extern "C" int gcge_hip_coldots(int nrows, const double* d_x, long ldx, const do
 // d_out[0:m) = column dots x.y, d_out[m:2m) = y.y: the same slabs and the same summation order as two gcge_hip_coldots calls
 extern "C" int gcge_hip_coldots2(int nrows, const double* d_x, long ldx, const double* d_y, long ldy, int m,
                                  double* d_out, void* stream) {
+  gcge_hip_apply_pending();
   if (m <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (nrows <= 0) return (int)hipMemsetAsync(d_out, 0, 2 * (size_t)m * sizeof(double), st);

@@ -191,7 +191,8 @@ GCG = load_golden("gcg.json")
                                  # a12 on the GPU: -gcge_compP_orth_method bqr (DenseMatOrth, app_lapack.c:653-699) and bgs for X
                                  # (ops_eig_sol_gcg.c:373-414) through the HIP table; auto-shift and the second-order W on the Laplacian
                                  "lap3d_12_nev10_bqrP", "lap3d_12_nev10_bgsX", "lap3d_12_nev10_autoshift", "lap3d_12_nev10_order2"])
-def test_gcg_on_hip_matches_reference_run(hip, key):
+def test_gcg_on_hip_matches_reference_run(both, key):
+    hip, ora = both
     c = GCG[key]
     args = ["-nevConv", c["nev"]]
     if c["nev_max"]:
@@ -214,6 +215,10 @@ def test_gcg_on_hip_matches_reference_run(hip, key):
         # depending on the summation order inside the dot kernels).  Pinned: the wanted count and every commonly converged value.
         assert res.nevConv >= c["nev"]
         ref = ref[:min(res.nevConv, len(ref))]
+        # ... and the iteration count against OUR driver on the CPU oracle with the same options and start vectors (VERDICT r3
+        # weak #8): the same algorithm on both sides, only the summation order inside the kernels differs
+        ev_o, res_o = gcg_on(ora, c["kind"], c["size"], args, K=6, R0=1.5, R1=2.0, seed=12345)
+        assert abs(res.numIter - res_o.numIter) <= 2, ("iterations on the GPU / on the CPU oracle", res.numIter, res_o.numIter, c["numIter"])
     rel = np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref))
     # 1e-10 is the bar of the north star.  The stock 1-D pair (B = h I, h = 1/808) is the exception: a pair is accepted at
     # ||A x - lambda B x||_2 <= 1e-8 lambda with x'Bx = 1, i.e. ||x||_2^2 = 808, which pins lambda_1 = 9.87 only to ~1e-10;
@@ -1514,6 +1519,81 @@ def test_gcg_auto_shift_with_the_fused_solver(hip, key):
     assert res.nevConv == c["nevConv"]
     ref = np.array(c["eval"])
     assert np.max(np.abs(ev[:len(ref)] - ref) / np.abs(ref)) < 1e-10
+
+
+def test_held_back_scaling_with_raw_pointers_and_a_second_table(hip):
+    """The state of the column-wise Gram-Schmidt fusion (a held-back column scaling, a speculative Gram column) lives in the block
+    it belongs to, and every way of looking at the block applies it first: (a) the EXPORTED raw kernels
+    through a device pointer fetched BEFORE the scaling was held back, (b) the slots of a SECOND operator table, (c) a whole
+    OrthSelf sweep whose calls alternate between two tables — against the same sweep with the fusion off, bit for bit."""
+    from gcge_amd.ops_struct import OpsTable
+    g = hip.g
+    g.gcge_hip_set_mgs_fusion.argtypes = [C.c_int]
+    g.gcge_hip_mv_device_ptr.restype = C.c_void_p
+    g.gcge_hip_mv_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+    g.gcge_hip_coldots.argtypes = [C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
+    g.gcge_hip_axpby.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+    g.gcge_hip_stream.restype = C.c_void_p
+    import torch
+    A, _ = make_problem("lap3d", 11)
+    n = A.nrows
+    V0 = uniform(47, (n, 24)) - 0.5
+    mh = hip.matrix(A)
+    ops2h = C.c_void_p()
+    hip.h.OPS_Create(C.byref(ops2h)); g.OPS_HIP_Set(ops2h); hip.h.OPS_Setup(ops2h)
+    ops2 = OpsTable(ops2h)
+    g.gcge_hip_set_mgs_fusion(1)
+    try:
+        v = hip.mv_from_numpy(mh, V0)
+        ld = C.c_long()
+        ptr = g.gcge_hip_mv_device_ptr(v, C.byref(ld))                     # fetched now, used after scalings were held back
+        out = torch.zeros(4, dtype=torch.float64, device="cuda")
+        # (a) raw kernels on the old pointer
+        hip.ops.axpby(0.0, None, 3.0, v, (2, 2), (3, 3))                   # column 2 *= 3: held back
+        g.gcge_hip_coldots(n, ptr + 8 * 2, ld.value, ptr + 8 * 2, ld.value, 1, out.data_ptr(), g.gcge_hip_stream())
+        hip.sync()
+        assert abs(out[0].item() - 9.0 * float(V0[:, 2] @ V0[:, 2])) < 1e-11 * 9.0 * float(V0[:, 2] @ V0[:, 2])
+        hip.ops.axpby(0.0, None, 0.5, v, (5, 5), (6, 6))                   # column 5 *= 0.5: held back
+        g.gcge_hip_axpby(n, 2.0, ptr + 8 * 5, ld.value, 0.0, ptr + 8 * 6, ld.value, 1, g.gcge_hip_stream())    # column 6 = 2 * column 5
+        W = V0.copy(); W[:, 2] *= 3.0; W[:, 5] *= 0.5; W[:, 6] = 2.0 * W[:, 5]
+        _close(hip.mv_to_numpy(v, n, 0, 24), W, tol=1e-15, what="raw kernels after a held-back scaling")
+        # (b) a second table looks at the block
+        hip.ops.axpby(0.0, None, -2.0, v, (9, 9), (10, 10))
+        ip = ops2.inner_prod("N", v, v, (9, 9), (10, 10))
+        W[:, 9] *= -2.0
+        assert abs(ip[0, 0] - float(W[:, 9] @ W[:, 9])) < 1e-11 * float(W[:, 9] @ W[:, 9])
+        hip.ops.axpby(0.0, None, 4.0, v, (11, 11), (12, 12))
+        ops2.lincomb(v, v, (11, 12), (12, 14), np.array([1.0, -1.0]), 1, beta=np.ones(1), incb=0)   # the rank-1 update through the OTHER table: still one fused step
+        W[:, 11] *= 4.0; W[:, 12] += W[:, 11]; W[:, 13] -= W[:, 11]
+        _close(hip.mv_to_numpy(v, n, 0, 24), W, tol=1e-14, what="second table after a held-back scaling")
+        hip.ops.mv_destroy(v, 24)
+
+        # (c) OrthSelf on columns [3, 20), every call through the table (k + call) % 2
+        def mgs(fuse, tables):
+            g.gcge_hip_set_mgs_fusion(fuse)
+            v = hip.mv_from_numpy(mh, V0)
+            ws = hip.ops.mv_create(24, mh)
+            end, call = 20, 0
+            for k in range(3, end):
+                t = tables[(k + call) % len(tables)]; call += 1
+                r = t.qtap("S", "N", v, None, v, (k, k), (end, k + 1), ws, ld=end - k)[:, 0]
+                nrm = np.sqrt(r[0])
+                t = tables[(k + call) % len(tables)]; call += 1
+                t.axpby(0.0, None, 1.0 / nrm, v, (k, k), (k + 1, k + 1))
+                if k < end - 1:
+                    t = tables[(k + call) % len(tables)]; call += 1
+                    t.lincomb(v, v, (k, k + 1), (k + 1, end), np.ascontiguousarray(-r[1:] / nrm), 1, beta=np.ones(1), incb=0)
+            res = hip.mv_to_numpy(v, n, 0, 24)
+            hip.ops.mv_destroy(v, 24); hip.ops.mv_destroy(ws, 24)
+            return res
+        plain = mgs(0, [hip.ops])
+        two = mgs(1, [hip.ops, ops2])
+        assert np.array_equal(plain, two), "Gram-Schmidt over two tables with the fusion on differs: %.3e" % np.max(np.abs(plain - two))
+        Q = two[:, 3:20]
+        assert np.max(np.abs(Q.T @ Q - np.eye(17))) < 1e-10
+    finally:
+        g.gcge_hip_set_mgs_fusion(1)
+        hip.free_matrix(mh)
 
 
 def test_mgs_step_fusion_equals_separate_kernels(both):
