@@ -255,6 +255,64 @@ int gcge_problem_sio2_like(int G, int K, double R0, double R1, uint64_t seed,
 	return 0;
 }
 
+/* The same operator on a BALL inside the G^3 box — the domain of the real-space DFT matrices behind BASELINE config 5 (PARSEC:
+ * grid points inside a sphere, numbered in scan order, x fastest; test/submit.sh:9-15 of the reference): the principal submatrix
+ * of gcge_problem_sio2_like over the grid points with (x - c)^2 + (y - c)^2 + (z - c)^2 <= (G / 2)^2, c = (G - 1) / 2, i.e. the
+ * stencil and the atom blocks truncated at the sphere (Dirichlet), still symmetric positive definite.  Rows are the points
+ * inside in scan order.  box_of_row (may be NULL): for every row of the slab its box index x + G (y + G z). */
+static int in_ball(int G, int x, int y, int z)
+{
+	/* doubled coordinates keep it in integers: (2x - (G-1))^2 + ... <= G^2 */
+	long a = 2L * x - (G - 1), b = 2L * y - (G - 1), c = 2L * z - (G - 1);
+	return a * a + b * b + c * c <= (long)G * G;
+}
+int64_t gcge_problem_sio2_ball_rows(int G)
+{
+	int64_t n = 0; int x, y, z;
+	for (z = 0; z < G; ++z) for (y = 0; y < G; ++y) for (x = 0; x < G; ++x) n += in_ball(G, x, y, z);
+	return n;
+}
+int gcge_problem_sio2_ball(int G, int K, double R0, double R1, uint64_t seed,
+		int64_t row_begin, int64_t row_end, GCGE_CSR *A, int **box_of_row)
+{
+	int64_t nbox = (int64_t)G * G * G, nball = 0, q, b0 = -1, b1 = -1, r, p = 0;
+	int *idx, x, y, z, rc;
+	GCGE_CSR Bx;
+	if (nbox > 2147483647LL) return -2;
+	idx = (int*)malloc((size_t)nbox * sizeof(int));
+	if (idx == NULL) return -1;
+	for (z = 0, q = 0; z < G; ++z) for (y = 0; y < G; ++y) for (x = 0; x < G; ++x, ++q)
+		idx[q] = in_ball(G, x, y, z) ? (int)nball++ : -1;
+	if (row_begin < 0) row_begin = 0;
+	if (row_end > nball || row_end < 0) row_end = nball;
+	/* the box rows that enclose the slab (scan order is kept by the numbering) */
+	for (q = 0; q < nbox; ++q) {
+		if (idx[q] == row_begin && b0 < 0) b0 = q;
+		if (idx[q] >= 0 && idx[q] < row_end) b1 = q;
+	}
+	if (row_end <= row_begin) { b0 = 0; b1 = -1; }
+	memset(&Bx, 0, sizeof Bx);
+	rc = gcge_problem_sio2_like(G, K, R0, R1, seed, b0, b1 + 1, &Bx);
+	if (rc != 0) { free(idx); return rc; }
+	if (csr_alloc(A, row_end - row_begin, (int)nball, row_begin, Bx.nnz > 0 ? Bx.nnz : 1)) { gcge_csr_free(&Bx); free(idx); return -1; }
+	if (box_of_row != NULL) *box_of_row = (int*)malloc((size_t)(row_end - row_begin > 0 ? row_end - row_begin : 1) * sizeof(int));
+	A->rowptr[0] = 0;
+	for (r = 0, q = b0; q <= b1; ++q) {
+		int k;
+		if (idx[q] < 0) continue;
+		for (k = Bx.rowptr[q - b0]; k < Bx.rowptr[q - b0 + 1]; ++k) {
+			const int c = idx[Bx.colidx[k]];
+			if (c < 0) continue;                      /* a neighbour outside the sphere: dropped (Dirichlet) */
+			A->colidx[p] = c; A->val[p] = Bx.val[k]; ++p;
+		}
+		if (box_of_row != NULL) (*box_of_row)[r] = (int)q;
+		A->rowptr[++r] = (int)p;
+	}
+	A->nnz = p;
+	gcge_csr_free(&Bx); free(idx);
+	return 0;
+}
+
 /* ---- row-partition helpers ---------------------------------------------------------- */
 static int cmp_int(const void *a, const void *b)
 {

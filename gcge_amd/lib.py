@@ -108,11 +108,31 @@ def make_problem(kind, size, row_begin=0, row_end=-1, **kw):
         rc = h.gcge_problem_sio2_like(C.c_int(size), C.c_int(kw.get("K", 8)), C.c_double(kw.get("R0", 1.5)),
                                       C.c_double(kw.get("R1", 3.0)), C.c_uint64(kw.get("seed", 12345)),
                                       C.c_int64(row_begin), C.c_int64(row_end), C.byref(A)); B = None
+    elif kind == "sio2ball":
+        rc = h.gcge_problem_sio2_ball(C.c_int(size), C.c_int(kw.get("K", 8)), C.c_double(kw.get("R0", 1.5)),
+                                      C.c_double(kw.get("R1", 3.0)), C.c_uint64(kw.get("seed", 12345)),
+                                      C.c_int64(row_begin), C.c_int64(row_end), C.byref(A), None); B = None
     else:
         raise ValueError(kind)
     if rc != 0:
         raise RuntimeError("problem generator failed rc=%d" % rc)
     return A, B
+
+
+def ball_geometry(size, row_begin=0, row_end=-1):
+    """box index x + G (y + G z) of every row of the ball matrix make_problem("sio2ball", size) (numpy int32 array)."""
+    import numpy as np
+    h = host_lib()
+    A = CSR()
+    bp = C.POINTER(C.c_int)()
+    rc = h.gcge_problem_sio2_ball(C.c_int(size), C.c_int(0), C.c_double(1.0), C.c_double(0.0), C.c_uint64(1),
+                                  C.c_int64(row_begin), C.c_int64(row_end), C.byref(A), C.byref(bp))
+    if rc != 0:
+        raise RuntimeError("gcge_problem_sio2_ball failed rc=%d" % rc)
+    out = np.ctypeslib.as_array(bp, shape=(A.nrows,)).astype(np.int32).copy()
+    h.gcge_free_ints(bp)
+    h.gcge_csr_free(C.byref(A))
+    return out
 
 
 def make_argv(args):

@@ -53,6 +53,14 @@ int gcge_problem_fe3d(int M, int64_t row_begin, int64_t row_end, GCGE_CSR *A, GC
 int gcge_problem_sio2_like(int G, int K, double R0, double R1, uint64_t seed,
 		int64_t row_begin, int64_t row_end, GCGE_CSR *A);
 
+/* The same operator on the BALL inscribed in the G^3 box, rows = the grid points inside in scan order (x fastest) — the domain
+ * and numbering of the PARSEC real-space matrices of the reference's test/submit.sh:9-15 (SiO2, Ga41As41H72, ...): the
+ * principal submatrix of the box matrix (stencil arms and atom blocks cut at the sphere).  box_of_row (may be NULL; free with
+ * gcge_free_ints): the box index x + G (y + G z) of every row of the slab — the geometry gcge_hip_mat_create_grid takes. */
+int64_t gcge_problem_sio2_ball_rows(int G);
+int gcge_problem_sio2_ball(int G, int K, double R0, double R1, uint64_t seed,
+		int64_t row_begin, int64_t row_end, GCGE_CSR *A, int **box_of_row);
+
 /* ---- matrix ingestion (the formats the reference's users hold) --------------------------
  * PETSc binary Mat file (what test/test_app_slepc.c:416-445 loads with MatLoad: SiO2, Ga41As41H72, ... of
  * submit.sh:9-15): big-endian int32 header {1211216, rows, cols, nnz}, int32 row lengths, int32 column

@@ -166,6 +166,8 @@ for key, kind, size, nev, extra, kw in (
         ("fe3d_20_nev20", "fe3d", 20, 20, (), {}),
         ("fe1d_807_nev30", "fe1d", 807, 30, (), {}),
         ("sio2_12_nev10", "sio2", 12, 10, (), {}),
+        # the same operator on the ball inscribed in the box, rows in scan order (the PARSEC layout behind BASELINE config 5)
+        ("sio2ball_16_nev10", "sio2ball", 16, 10, (), {}),
         ("lap3d_12_nev10_bgsX", "lap3d", 12, 10, ("-gcge_initX_orth_method", "bgs"), {}),
         ("lap3d_12_nev10_bqrP", "lap3d", 12, 10, ("-gcge_compP_orth_method", "bqr"), {}),
         # X grows from nevInit to nevMax as pairs lock (ops_eig_sol_gcg.c:1281,1395-1412)
