@@ -612,6 +612,19 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create(int nrows, int nglobal, int row_beg
   }
   return gcge_hip_mat_create_local(nrows, nrows, nglobal, 0, rowptr, colidx, val);
 }
+// A matrix on a MASKED grid (one rank): row r is grid point box_of_row[r] = x + nx (y + ny z) of an nx x ny x nz box, rows in scan
+// order — the real-space DFT matrices behind BASELINE config 5 live on the grid points inside a sphere (PARSEC).  With the
+// geometry named, the rows that are a star stencil on that grid take the plane sweep of spmm_star.hip (through a row map);
+// without it such a matrix is served by dense blocks + the pad-8 kernel.  The geometry only selects kernels: results are those
+// of gcge_hip_mat_create on the same arrays.
+extern "C" void gcge_hip_star_next_geometry(int nrows, int nx, int ny, int nz, const int* box_of_row);
+extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_grid(int nrows, const int* rowptr, const int* colidx, const double* val,
+                                                  int nx, int ny, int nz, const int* box_of_row) {
+  if (box_of_row != nullptr && nx > 0 && ny > 0 && nz > 0) gcge_hip_star_next_geometry(nrows, nx, ny, nz, box_of_row);
+  GCGE_HIP_MAT* A = gcge_hip_mat_create(nrows, nrows, 0, rowptr, colidx, val);
+  gcge_hip_star_next_geometry(0, 0, 0, 0, nullptr);                   // (not consumed when the matrix took a pattern form)
+  return A;
+}
 extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_csr(const GCGE_CSR* A) {
   if (A->row_begin == 0 && A->nrows == A->ncols) return gcge_hip_mat_create(A->nrows, A->ncols, 0, A->rowptr, A->colidx, A->val);
   // a localized slab: ncols = nrows + nghost (gcge_dist_localize)

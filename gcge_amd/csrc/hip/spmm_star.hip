@@ -46,7 +46,8 @@ struct StarCoef { double cx[STAR_R + 1], cy[STAR_R + 1], cz[STAR_R + 1]; };   //
 // planes outside [zmin, zmax) are outside the grid (Dirichlet: zero) or beyond the star's arms (coefficient zero): never loaded.
 struct StarGeom { int nx, ny, nz, zs, ze, zmin, zmax; long lo_off, mid_off, hi_off; };
 struct StarMat {
-  StarGeom g; int R; bool iso; long nclean, nrows; StarCoef c; double* d_diag; unsigned char* d_clean;   // d_clean[local row]: 1 = nothing but the star and a diagonal   // d_diag[local row]: the row's diagonal entry, NaN: not a clean row
+  StarGeom g; int R; bool iso; long nclean, nrows; StarCoef c; double* d_diag; unsigned char* d_clean;   // d_clean[local row]: 1 = nothing but the star and a diagonal
+  int* d_map;   // masked grids: d_map[box index] = row, -1 where the point is not a row (NULL: every grid point is a row)   // d_diag[local row]: the row's diagonal entry, NaN: not a clean row
 };
 
 // staging plan of a thread: unit u = tid + 1024 q, point u >> 2, 16-byte part u & 3
@@ -90,10 +91,13 @@ template <int LPP> struct Star2Geom {
   static constexpr int HPTS = 2 * STAR_R * TY + 2 * STAR_R * STAR_T;   // halo points per plane: side strips, then top / bottom strips
   static constexpr int HQ = (HPTS * LPP + 1023) / 1024;  // halo units per thread
 };
-template <bool DOT, bool ISO, bool SLAB, int LPP, int dbg = 0>
+// MAPPED: a masked grid (the points inside a sphere, say): only some points of the nx x ny x nz box are rows; map[box index] = the
+// row of X / Y / diag of that point, -1 where there is none (reads as zero, nothing written).  Every access to a row then goes
+// through a 4-byte lookup requested a step before the row itself is: one more stage in the same pipeline (one rank, no halo planes).
+template <bool DOT, bool ISO, bool SLAB, int LPP, int dbg = 0, bool MAPPED = false>
 __global__ __launch_bounds__(1024) void spmm_star2_kernel(int nx, int ny, int zs, int ze, int zmin, int zmax, long dlo, long dhi, StarCoef cf,
     const double* __restrict__ diag, const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols,
-    int zlo, int zhi, int zlen, int ntx, double* __restrict__ partial, const unsigned char* __restrict__ cleanf) {
+    int zlo, int zhi, int zlen, int ntx, double* __restrict__ partial, const unsigned char* __restrict__ cleanf, const int* __restrict__ map) {
   typedef Star2Geom<LPP> GEO;
   constexpr int TY = GEO::TY, IMG = GEO::IMG, HQ = GEO::HQ, SIDE = 2 * STAR_R * TY;
   __shared__ v2d img[2 * IMG];                  // img[b][(row * 28 + col) * LPP + part]
@@ -131,45 +135,61 @@ __global__ __launch_bounds__(1024) void spmm_star2_kernel(int nx, int ny, int zs
     hdst[q] = pt < GEO::HPTS ? ((yy + STAR_R) * STAR_PW + (xx + STAR_R)) * LPP + part : -1;
     hsrc[q] = ok ? ax + nx * ay : -1;
   }
-  auto ld_own = [&](int zz) -> v2d {
+  // lookups (MAPPED): the row of my point / of halo unit q in plane zz (clamped plane, a valid address whatever the lane)
+  auto mp_own = [&](int zz) -> int { return map[plane_rows * min(max(zz, zmin), zmax - 1) + own]; };
+  auto mp_halo = [&](int q, int zz) -> int { return map[plane_rows * min(max(zz, zmin), zmax - 1) + max(hsrc[q], 0)]; };
+  auto zmask = [&](int zz) -> unsigned long long { return (zz >= zmin && zz < zmax) ? ~0ull : 0ull; };
+  auto rmask = [&](int row) -> unsigned long long { return ~(unsigned long long)(long)(row >> 31); };   // all ones unless row < 0
+  auto ld_own = [&](int zz) -> v2d {                                  // (not MAPPED)
     const int zc = min(max(zz, zmin), zmax - 1);
-    const unsigned long long zm = (zz >= zmin && zz < zmax) ? ~0ull : 0ull;
-    return star2_and(star_ld(x, ldx, own + plane_row0(zc), col), own_m & zm);
+    return star2_and(star_ld(x, ldx, own + plane_row0(zc), col), own_m & zmask(zz));
+  };
+  auto ld_own_m = [&](int row, int zz) -> v2d {                       // MAPPED: row = mp_own(zz), looked up a step earlier
+    return star2_and(star_ld(x, ldx, (long)max(row, 0), col), own_m & zmask(zz) & rmask(row));
   };
   auto ld_halo = [&](int q, int zz) -> v2d {
     const int zc = min(max(zz, zmin), zmax - 1);
-    const unsigned long long zm = (zz >= zmin && zz < zmax) ? ~0ull : 0ull;
-    const unsigned long long hmask = ~(unsigned long long)(long)(hsrc[q] >> 31);          // all ones unless hsrc < 0
-    return star2_and(star_ld(x, ldx, (long)max(hsrc[q], 0) + plane_row0(zc), col), hmask & zm);
+    return star2_and(star_ld(x, ldx, (long)max(hsrc[q], 0) + plane_row0(zc), col), rmask(hsrc[q]) & zmask(zz));
   };
-  // the diagonal of my point in plane zz (NaN: not a star row / not my plane), same rule
-  auto ld_diag = [&](int zz) -> double {
-    const int zc = min(max(zz, z0), max(z1 - 1, z0));
-    const unsigned long long m = (zz < z1 ? ~0ull : 0ull) & own_m;
-    unsigned long long b = __builtin_bit_cast(unsigned long long, diag[own + plane_rows * zc]);
+  auto ld_halo_m = [&](int q, int row, int zz) -> v2d {
+    return star2_and(star_ld(x, ldx, (long)max(row, 0), col), rmask(hsrc[q]) & zmask(zz) & rmask(row));
+  };
+  // the diagonal of my point in plane zz (NaN: not my plane / no point of mine / no row there), same rule
+  auto ld_diag_at = [&](long row, unsigned long long m) -> double {
+    unsigned long long b = __builtin_bit_cast(unsigned long long, diag[row]);
     b = (b & m) | (0x7ff8000000000000ull & ~m);
     return __builtin_bit_cast(double, b);
+  };
+  auto ld_diag = [&](int zz) -> double {                              // (not MAPPED)
+    const int zc = min(max(zz, z0), max(z1 - 1, z0));
+    return ld_diag_at(own + plane_rows * zc, (zz < z1 ? ~0ull : 0ull) & own_m);
   };
   // ---- prologue: planes z0 - 6 .. z0 + 6 into slots 0 .. 12; image 0 = plane z0; halo strips of plane z0 + 1 in flight
   v2d qv[STAR2_Q];
 #pragma unroll
-  for (int t = 0; t < STAR2_Q - 1; ++t) qv[t] = ld_own(z0 - STAR_R + t);
+  for (int t = 0; t < STAR2_Q - 1; ++t) qv[t] = MAPPED ? ld_own_m(mp_own(z0 - STAR_R + t), z0 - STAR_R + t) : ld_own(z0 - STAR_R + t);
   qv[STAR2_Q - 1] = v2d{0.0, 0.0};
   v2d st[HQ];                                    // halo strips in flight: requested at the end of a step, written to LDS at the end of the next
+  int hrow[HQ];                                  // MAPPED: rows of the halo units in the plane requested NEXT (looked up a step ahead)
   {
 #pragma unroll
-    for (int q = 0; q < HQ; ++q) st[q] = ld_halo(q, z0);
+    for (int q = 0; q < HQ; ++q) st[q] = MAPPED ? ld_halo_m(q, mp_halo(q, z0), z0) : ld_halo(q, z0);
     img[slot] = qv[STAR_R];
 #pragma unroll
     for (int q = 0; q < HQ; ++q) if (hdst[q] >= 0) img[hdst[q]] = st[q];
 #pragma unroll
-    for (int q = 0; q < HQ; ++q) st[q] = ld_halo(q, z0 + 1);
+    for (int q = 0; q < HQ; ++q) st[q] = MAPPED ? ld_halo_m(q, mp_halo(q, z0 + 1), z0 + 1) : ld_halo(q, z0 + 1);
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) hrow[q] = MAPPED ? mp_halo(q, z0 + 2) : 0;
   }
-  double dg = ld_diag(z0);                       // diagonal of my point in the output plane (NaN: no point of mine there)
+  // MAPPED: rows of my point in the output plane and the next one (diag / clean / Y), and in plane z + 7 (the next X request)
+  int rcur = MAPPED ? mp_own(z0) : 0, rnext = MAPPED ? mp_own(z0 + 1) : 0, r7 = MAPPED ? mp_own(z0 + STAR_R + 1) : 0;
+  const unsigned long long in0 = (z0 < z1 ? ~0ull : 0ull) & own_m;
+  double dg = MAPPED ? ld_diag_at((long)max(rcur, 0), in0 & rmask(rcur)) : ld_diag(z0);   // diagonal of my point in the output plane (NaN: none)
   // DOT: the sums run over the rows that are COMPLETE after the sweep (nothing but the star and a diagonal); the other rows get
   // the rest of their product from the kernels that follow, and their share of the sums from star_coldots2_rows
   auto ld_clean = [&](int zz) -> int { return DOT ? (int)cleanf[own + plane_rows * min(max(zz, z0), max(z1 - 1, z0))] : 1; };
-  int cl = ld_clean(z0);
+  int cl = DOT ? (MAPPED ? (int)cleanf[max(rcur, 0)] : ld_clean(z0)) : 1;
   v2d spw = v2d{0.0, 0.0}, sww = v2d{0.0, 0.0};
   __syncthreads();
 
@@ -179,10 +199,13 @@ __global__ __launch_bounds__(1024) void spmm_star2_kernel(int nx, int ny, int zs
       const int z = zb + (U);                                                                                               \
       if (z >= z1) break;                                                                                                   \
       constexpr int CUR = ((U) & 1) * IMG, NXT = (((U) + 1) & 1) * IMG;                                                     \
-      /* request: my point in plane z + 7 (first used at step z + 1) */                                                     \
-      if (!(dbg & 8)) qv[S2SLOT(U, STAR_R + 1)] = ld_own(z + STAR_R + 1);                                                   \
-      const double dnext = ld_diag(z + 1);                                                                                  \
-      const int cnext = ld_clean(z + 1);                                                                                    \
+      /* request: my point in plane z + 7 (first used at step z + 1); MAPPED: and the lookups of the next step */          \
+      if (!(dbg & 8)) qv[S2SLOT(U, STAR_R + 1)] = MAPPED ? ld_own_m(r7, z + STAR_R + 1) : ld_own(z + STAR_R + 1);            \
+      int r7n = 0, rnn = 0;                                                                                                 \
+      if (MAPPED) { r7n = mp_own(z + STAR_R + 2); rnn = mp_own(z + 2); }                                                    \
+      const unsigned long long inn = (z + 1 < z1 ? ~0ull : 0ull) & own_m;                                                   \
+      const double dnext = MAPPED ? ld_diag_at((long)max(rnext, 0), inn & rmask(rnext)) : ld_diag(z + 1);                   \
+      const int cnext = DOT ? (MAPPED ? (int)cleanf[max(rnext, 0)] : ld_clean(z + 1)) : 1;                                  \
       const double d0 = dg == dg ? dg : 0.0;                                                                                \
       v2d acc = qv[S2SLOT(U, 0)] * d0;                                                                                      \
       const v2d* pl = img + CUR + slot;                                                                                     \
@@ -200,7 +223,8 @@ __global__ __launch_bounds__(1024) void spmm_star2_kernel(int nx, int ny, int zs
         }                                                                                                                   \
       }                                                                                                                     \
       if (dg == dg && (!(dbg & 4) || acc.x == 12345.678)) {                                                                 \
-        __builtin_nontemporal_store(acc, reinterpret_cast<v2d*>(y + (size_t)(own + plane_rows * z) * ldy + col));           \
+        const size_t yrow = MAPPED ? (size_t)max(rcur, 0) : (size_t)(own + plane_rows * z);                                 \
+        __builtin_nontemporal_store(acc, reinterpret_cast<v2d*>(y + yrow * ldy + col));                                     \
         if (DOT && cl != 0) {                                                                                               \
           const v2d xc = qv[S2SLOT(U, 0)];                                                                                  \
           spw.x = fma(xc.x, acc.x, spw.x); spw.y = fma(xc.y, acc.y, spw.y);                                                  \
@@ -210,8 +234,10 @@ __global__ __launch_bounds__(1024) void spmm_star2_kernel(int nx, int ny, int zs
       /* image of plane z + 1: my value from the queue, the strips requested a step ago; then the request for plane z + 2's */ \
       img[NXT + slot] = qv[S2SLOT(U, 1)];                                                                                   \
       _Pragma("unroll") for (int q = 0; q < HQ; ++q) if (hdst[q] >= 0) img[NXT + hdst[q]] = st[q];                           \
-      if (!(dbg & 1)) { _Pragma("unroll") for (int q = 0; q < HQ; ++q) st[q] = ld_halo(q, z + 2); }                          \
+      if (!(dbg & 1)) { _Pragma("unroll") for (int q = 0; q < HQ; ++q) st[q] = MAPPED ? ld_halo_m(q, hrow[q], z + 2) : ld_halo(q, z + 2); } \
+      if (MAPPED) { _Pragma("unroll") for (int q = 0; q < HQ; ++q) hrow[q] = mp_halo(q, z + 3); }                            \
       dg = dnext; cl = cnext;                                                                                               \
+      if (MAPPED) { rcur = rnext; rnext = rnn; r7 = r7n; }                                                                  \
       if (!(dbg & 16)) __syncthreads();                                                                                     \
     }
     STAR2_STEP(0) STAR2_STEP(1) STAR2_STEP(2) STAR2_STEP(3) STAR2_STEP(4) STAR2_STEP(5) STAR2_STEP(6)
@@ -274,6 +300,7 @@ struct StarHost {
   StarGeom g; int R = 0; StarCoef c; long nclean = 0;
   std::vector<double> diag;                                           // NaN: row stays in the remainder
   std::vector<char> clean;                                            // 1: star row
+  std::vector<int> inv;                                               // masked domains: grid point -> row (-1: none)
   std::vector<int> rem_rowptr, rem_col; std::vector<double> rem_val;  // every entry of the rows that are not clean (local columns)
 };
 
@@ -281,10 +308,15 @@ static inline uint64_t star_bits(double v) { uint64_t b; memcpy(&b, &v, 8); retu
 
 // The rows of one slab: local rows [0, nrows) are global rows row_begin + r; local column c < nrows is global column row_begin + c,
 // c >= nrows is halo row c - nrows = global column ghost[c - nrows] (ascending).  One rank: row_begin = 0, no halo columns.
+// With a geometry (box != NULL; one rank, no halo columns): row r is grid point box[r] = x + bnx (y + bny z) of a bnx x bny x bnz
+// box of which only some points are rows (a masked domain: the grid points inside a sphere, say) — "global index" then means
+// the box index, and nglobal the size of the box.
 struct StarRows {
   int nrows, ncols_local; long row_begin, nglobal; const int* ghost; const int *rowptr, *colidx; const double* val;
   bool global_cols = false;                                           // colidx holds global columns already (partitioners)
-  long gcol(int c) const { return global_cols ? (long)c : c < nrows ? row_begin + c : (long)ghost[c - nrows]; }
+  const int* box = nullptr; int bnx = 0, bny = 0, bnz = 0;
+  long gcol(int c) const { return box != nullptr ? (long)box[c] : global_cols ? (long)c : c < nrows ? row_begin + c : (long)ghost[c - nrows]; }
+  long gpos(int r) const { return box != nullptr ? (long)box[r] : row_begin + r; }
 };
 
 // The offsets (global column - global row) of a star on a lexicographic grid: |o| in {1..Rx} u {sy, 2 sy, .., Ry sy} u {sz, .., Rz sz},
@@ -299,7 +331,7 @@ static bool star_offsets(const StarRows& M, int* Rx_, int* Ry_, int* Rz_, long* 
   for (int t = 0; t < nsamp; ++t) {
     const int r = (int)((long)t * nrows / nsamp);
     seen.clear();
-    for (int q = M.rowptr[r]; q < M.rowptr[r + 1]; ++q) { const long o = M.gcol(M.colidx[q]) - (M.row_begin + r); if (o != 0) seen.push_back(o < 0 ? -o : o); }
+    for (int q = M.rowptr[r]; q < M.rowptr[r + 1]; ++q) { const long o = M.gcol(M.colidx[q]) - M.gpos(r); if (o != 0) seen.push_back(o < 0 ? -o : o); }
     std::sort(seen.begin(), seen.end());
     seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
     for (long o : seen) ++hist[o];
@@ -331,11 +363,16 @@ static bool star_detect(const StarRows& M, StarHost* H) {
   const int nsamp = std::min(nrows, 8192);
   const int R = std::max(Rx, std::max(Ry, Rz));
   if (R > STAR_R || sy <= 2L * STAR_R || sz % sy != 0 || sz / sy <= 2L * STAR_R || M.nglobal % sz != 0 || M.nglobal / sz < 2) return false;
-  // the slab must be whole planes (a partition cut inside a plane keeps the other forms: gcge_amd.dist.partition_by_nnz(align=))
-  if (M.row_begin % sz != 0 || (long)nrows % sz != 0) return false;
   StarGeom& g = H->g;
   g.nx = (int)sy; g.ny = (int)(sz / sy); g.nz = (int)(M.nglobal / sz); H->R = R;
-  g.zs = (int)(M.row_begin / sz); g.ze = g.zs + (int)((long)nrows / sz);
+  if (M.box != nullptr) {            // a masked domain: the box is the grid, the rows are found through the map (one rank)
+    if (g.nx != M.bnx || g.ny != M.bny || g.nz != M.bnz || M.ncols_local != nrows) return false;
+    g.zs = 0; g.ze = g.nz;
+  } else {
+    // the slab must be whole planes (a partition cut inside a plane keeps the other forms: gcge_amd.dist.partition_by_nnz(align=))
+    if (M.row_begin % sz != 0 || (long)nrows % sz != 0) return false;
+    g.zs = (int)(M.row_begin / sz); g.ze = g.zs + (int)((long)nrows / sz);
+  }
   if (g.ze > g.nz) return false;
   g.zmin = std::max(0, g.zs - R); g.zmax = std::min(g.nz, g.ze + R);
   g.mid_off = -sz * g.zs; g.lo_off = g.hi_off = 0;
@@ -364,7 +401,7 @@ static bool star_detect(const StarRows& M, StarHost* H) {
       for (int t = 0; t < nsamp; ++t) {
         const int r = (int)((long)t * nrows / nsamp);
         for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
-          const long o = M.gcol(colidx[q]) - (M.row_begin + r);
+          const long o = M.gcol(colidx[q]) - M.gpos(r);
           if (o == k * stride) ++vals[0][star_bits(val[q])];
           else if (o == -k * stride) ++vals[1][star_bits(val[q])];
         }
@@ -401,8 +438,19 @@ static bool star_build_host(const StarRows& M, StarHost* H) {
     for (int a = 0; a < 3; ++a) cb[a][k] = star_bits(cv[a][k]);
   }
   const long stride[3] = {1, sy, sz};
-  // local column (= row of X) of global row gq: own rows, or the halo planes below / above as the sweep addresses them
+  // masked domains: grid point -> row (-1: not a row)
+  std::vector<int>& inv = H->inv;
+  inv.clear();
+  if (M.box != nullptr) {
+    inv.assign((size_t)M.nglobal, -1);
+    for (int r = 0; r < nrows; ++r) {
+      if (M.box[r] < 0 || M.box[r] >= M.nglobal || inv[M.box[r]] != -1 || (r > 0 && M.box[r] <= M.box[r - 1])) return false;   // (scan order, no point twice)
+      inv[M.box[r]] = r;
+    }
+  }
+  // local column (= row of X) of grid point gq: own rows, or the halo planes below / above as the sweep addresses them
   auto xcol = [&](long gq) -> long {
+    if (M.box != nullptr) return inv[gq];
     const int zz = (int)(gq / sz);
     return (zz < gm.zs ? gm.lo_off : zz >= gm.ze ? gm.hi_off : gm.mid_off) + gq;
   };
@@ -413,9 +461,14 @@ static bool star_build_host(const StarRows& M, StarHost* H) {
   std::vector<int>& rc = H->rem_col; std::vector<double>& rv = H->rem_val;
   rc.clear(); rv.clear();
   for (int r = 0; r < nrows; ++r) {
-    const long gr = M.row_begin + r;
+    const long gr = M.gpos(r);
     const int gz = (int)(gr / sz), gy = (int)((gr - (long)gz * sz) / sy), gx = (int)(gr - (long)gz * sz - (long)gy * sy);
     const int g[3] = {gx, gy, gz}, dim[3] = {nx, ny, nz};
+    // the neighbour k steps along axis a (sgn 0: down, 1: up) is a point of the domain
+    auto exists = [&](int a, int sgn, int k) -> bool {
+      if (!(sgn ? g[a] + k < dim[a] : g[a] - k >= 0)) return false;
+      return M.box == nullptr || inv[gr + (sgn ? 1 : -1) * k * stride[a]] >= 0;
+    };
     bool seen[3][2][STAR_R + 1] = {};
     rem.clear();
     bool have_diag = false; double dv = 0.0;
@@ -428,7 +481,7 @@ static bool star_build_host(const StarRows& M, StarHost* H) {
       else if (ao % sz == 0 && ao / sz >= 1 && ao / sz <= STAR_R) { a = 2; k = (int)(ao / sz); }
       else if (ao % sy == 0 && ao / sy >= 1 && ao / sy <= STAR_R) { a = 1; k = (int)(ao / sy); }
       // a star position: the neighbour k steps along axis a exists in the grid and the star reaches that far
-      const bool star_pos = a >= 0 && cb[a][k] != 0 && !seen[a][sgn][k] && (sgn ? g[a] + k < dim[a] : g[a] - k >= 0);
+      const bool star_pos = a >= 0 && cb[a][k] != 0 && !seen[a][sgn][k] && exists(a, sgn, k);
       if (!star_pos) { rem.emplace_back(colidx[q], val[q]); continue; }
       seen[a][sgn][k] = true;
       if (star_bits(val[q]) != cb[a][k]) rem.emplace_back(colidx[q], val[q] - cv[a][k]);
@@ -437,8 +490,7 @@ static bool star_build_host(const StarRows& M, StarHost* H) {
       for (int k = 1; k <= STAR_R; ++k) {
         if (cb[a][k] == 0) continue;
         for (int sgn = 0; sgn < 2; ++sgn) {
-          const bool exists = sgn ? g[a] + k < dim[a] : g[a] - k >= 0;
-          if (!exists || seen[a][sgn][k]) continue;
+          if (!exists(a, sgn, k) || seen[a][sgn][k]) continue;
           // the sweep adds coefficient x neighbour here, the row has no such entry: the remainder takes it back
           const long gq = gr + (sgn ? 1 : -1) * k * stride[a];
           const int zz = (int)(gq / sz);
@@ -488,10 +540,9 @@ extern "C" int gcge_hip_star_grid(int nrows, long row_begin, long nglobal, const
 // compared with the CSR row, bit for bit; every other row must sit in the remainder unchanged.  0: identical; > 0: differences;
 // -1: the matrix does not take this form.  out[0..4] = nx, ny, nz, arm length, clean rows; out[5..10] (slabs) = first / last + 1
 // plane of the slab, first / last + 1 plane the sweep may load, rows of X where the planes below / above begin (-1: none).
-extern "C" long gcge_hip_star_selfcheck_slab(int nrows, int ncols_local, long row_begin, long nglobal, const int* ghost, const int* rowptr,
-                                             const int* colidx, const double* val, long* out) {
+static long star_selfcheck(const StarRows& M, long* out) {
   StarHost H;
-  const StarRows M = {nrows, ncols_local, row_begin, nglobal, ghost, rowptr, colidx, val};
+  const int nrows = M.nrows; const long row_begin = M.row_begin; const int* rowptr = M.rowptr; const int* colidx = M.colidx; const double* val = M.val;
   if (!star_build_host(M, &H)) return -1;
   const StarGeom& g = H.g;
   const long sy = g.nx, sz = (long)g.nx * g.ny;
@@ -503,7 +554,11 @@ extern "C" long gcge_hip_star_selfcheck_slab(int nrows, int ncols_local, long ro
   if (out) out[11] = H.rem_rowptr[nrows];
   long bad = 0;
   // where the sweep finds grid point (global row gq): the row of X, as the kernel computes it
-  auto xrow = [&](long gq) -> long { const int zz = (int)(gq / sz); return (zz < g.zs ? g.lo_off : zz >= g.ze ? g.hi_off : g.mid_off) + gq; };
+  auto xrow = [&](long gq) -> long {
+    if (M.box != nullptr) return H.inv[gq];
+    const int zz = (int)(gq / sz); return (zz < g.zs ? g.lo_off : zz >= g.ze ? g.hi_off : g.mid_off) + gq;
+  };
+  auto there = [&](long gq) -> bool { return M.box == nullptr || H.inv[gq] >= 0; };   // a point of the domain
   // every row rebuilt as star + diagonal + remainder (per column, in the order the kernels add them) against the CSR row: clean
   // rows bit for bit; the others to the one rounding of "entry minus coefficient" at the star positions; a position the row
   // has no entry at must cancel exactly
@@ -511,7 +566,7 @@ extern "C" long gcge_hip_star_selfcheck_slab(int nrows, int ncols_local, long ro
   for (int r = 0; r < nrows; ++r) {
     want.clear(); got.clear();
     for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) want.emplace_back((long)colidx[q], val[q]);   // local columns = rows of X
-    const long gr = row_begin + r;
+    const long gr = M.gpos(r);
     const int gz = (int)(gr / sz), gy = (int)((gr - (long)gz * sz) / sy), gx = (int)(gr - (long)gz * sz - (long)gy * sy);
     const bool is_clean = H.clean[r] != 0;
     if (is_clean != (H.rem_rowptr[r + 1] == H.rem_rowptr[r])) ++bad;
@@ -519,11 +574,11 @@ extern "C" long gcge_hip_star_selfcheck_slab(int nrows, int ncols_local, long ro
     for (auto& w : want) stored_diag |= w.first == r;
     if (stored_diag || H.diag[r] != 0.0) got.emplace_back((long)r, H.diag[r]);
     for (int k = 1; k <= STAR_R; ++k) {
-      if (star_bits(H.c.cx[k])) { if (gx - k >= 0) got.emplace_back(xrow(gr - k), H.c.cx[k]); if (gx + k < g.nx) got.emplace_back(xrow(gr + k), H.c.cx[k]); }
-      if (star_bits(H.c.cy[k])) { if (gy - k >= 0) got.emplace_back(xrow(gr - k * sy), H.c.cy[k]); if (gy + k < g.ny) got.emplace_back(xrow(gr + k * sy), H.c.cy[k]); }
+      if (star_bits(H.c.cx[k])) { if (gx - k >= 0 && there(gr - k)) got.emplace_back(xrow(gr - k), H.c.cx[k]); if (gx + k < g.nx && there(gr + k)) got.emplace_back(xrow(gr + k), H.c.cx[k]); }
+      if (star_bits(H.c.cy[k])) { if (gy - k >= 0 && there(gr - k * sy)) got.emplace_back(xrow(gr - k * sy), H.c.cy[k]); if (gy + k < g.ny && there(gr + k * sy)) got.emplace_back(xrow(gr + k * sy), H.c.cy[k]); }
       if (star_bits(H.c.cz[k])) {
-        if (gz - k >= 0) { if (gz - k < g.zmin) ++bad; got.emplace_back(xrow(gr - k * sz), H.c.cz[k]); }
-        if (gz + k < g.nz) { if (gz + k >= g.zmax) ++bad; got.emplace_back(xrow(gr + k * sz), H.c.cz[k]); }
+        if (gz - k >= 0 && there(gr - k * sz)) { if (gz - k < g.zmin) ++bad; got.emplace_back(xrow(gr - k * sz), H.c.cz[k]); }
+        if (gz + k < g.nz && there(gr + k * sz)) { if (gz + k >= g.zmax) ++bad; got.emplace_back(xrow(gr + k * sz), H.c.cz[k]); }
       }
     }
     const size_t nstar = got.size();
@@ -545,6 +600,18 @@ extern "C" long gcge_hip_star_selfcheck_slab(int nrows, int ncols_local, long ro
   }
   return bad;
 }
+extern "C" long gcge_hip_star_selfcheck_slab(int nrows, int ncols_local, long row_begin, long nglobal, const int* ghost, const int* rowptr,
+                                             const int* colidx, const double* val, long* out) {
+  const StarRows M = {nrows, ncols_local, row_begin, nglobal, ghost, rowptr, colidx, val};
+  return star_selfcheck(M, out);
+}
+// the same for a matrix on a MASKED grid: row r is grid point box_of_row[r] = x + nx (y + ny z) (ascending: scan order); out as above
+extern "C" long gcge_hip_star_selfcheck_grid(int nrows, const int* rowptr, const int* colidx, const double* val, int nx, int ny, int nz,
+                                             const int* box_of_row, long* out) {
+  StarRows M = {nrows, nrows, 0, (long)nx * ny * nz, nullptr, rowptr, colidx, val};
+  M.box = box_of_row; M.bnx = nx; M.bny = ny; M.bnz = nz;
+  return star_selfcheck(M, out);
+}
 extern "C" long gcge_hip_star_selfcheck(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, long* out) {
   if (ncols_local != nrows) return -1;
   long o[12];
@@ -557,6 +624,7 @@ extern "C" void gcge_hip_star_free(void* sm) {
   StarMat* S = (StarMat*)sm;
   if (!S) return;
   hipFree(S->d_diag); hipFree(S->d_clean);
+  if (S->d_map) hipFree(S->d_map);
   delete S;
 }
 
@@ -564,15 +632,33 @@ extern "C" void gcge_hip_star_free(void* sm) {
 // that are not clean keep all their entries, clean rows are empty), owned by the object until gcge_hip_star_release_remainder.
 // ghost: the global rows behind the halo columns nrows .. ncols_local - 1 (ascending; NULL on one rank).
 static StarHost* g_star_last = nullptr;
+// geometry of the NEXT matrix handed to gcge_hip_star_build (gcge_hip_mat_create_grid sets it, the build consumes it)
+static struct { int nrows, nx, ny, nz; const int* box; } g_star_geom = {0, 0, 0, 0, nullptr};
+extern "C" void gcge_hip_star_next_geometry(int nrows, int nx, int ny, int nz, const int* box_of_row) {
+  g_star_geom.nrows = nrows; g_star_geom.nx = nx; g_star_geom.ny = ny; g_star_geom.nz = nz; g_star_geom.box = box_of_row;
+}
 extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin, long nglobal, const int* ghost, const int* rowptr,
                                      const int* colidx, const double* val, const int** rem_rowptr, const int** rem_col, const double** rem_val) {
   if (g_star_mode < 0 || nrows <= 0) return nullptr;
   StarHost* H = new StarHost();
-  const StarRows M = {nrows, ncols_local, row_begin, nglobal, ghost, rowptr, colidx, val};
+  StarRows M = {nrows, ncols_local, row_begin, nglobal, ghost, rowptr, colidx, val};
+  if (g_star_geom.box != nullptr) {
+    if (g_star_geom.nrows == nrows && ncols_local == nrows && row_begin == 0) {
+      M.box = g_star_geom.box; M.bnx = g_star_geom.nx; M.bny = g_star_geom.ny; M.bnz = g_star_geom.nz;
+      M.nglobal = (long)M.bnx * M.bny * M.bnz;
+    }
+    g_star_geom.box = nullptr;
+  }
   if (!star_build_host(M, H)) { delete H; return nullptr; }
   StarMat* S = new StarMat();
+  S->d_map = nullptr;
+  if (M.box != nullptr) {
+    GCGE_HIP_CHECK(hipMalloc(&S->d_map, H->inv.size() * sizeof(int)));
+    GCGE_HIP_CHECK(hipMemcpy(S->d_map, H->inv.data(), H->inv.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   S->g = H->g; S->R = H->R; S->nclean = H->nclean; S->nrows = nrows; S->c = H->c;
   S->iso = memcmp(H->c.cx, H->c.cy, sizeof(H->c.cx)) == 0 && memcmp(H->c.cx, H->c.cz, sizeof(H->c.cx)) == 0;
+  if (S->d_map != nullptr && !S->iso) { hipFree(S->d_map); delete S; delete H; return nullptr; }   // (masked grids: the one-coefficient-set kernel only)
   GCGE_HIP_CHECK(hipMalloc(&S->d_diag, (size_t)nrows * sizeof(double)));
   GCGE_HIP_CHECK(hipMemcpy(S->d_diag, H->diag.data(), (size_t)nrows * sizeof(double), hipMemcpyHostToDevice));
   std::vector<double>().swap(H->diag);
@@ -614,7 +700,8 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
   const StarGeom& g = S->g;
   const bool slab = g.zmin < g.zs || g.ze < g.zmax, iso = S->iso;
   // 8 lanes per point = 16-column passes on 16 x 8 patches, 4 = 8-column passes on 16 x 16 patches (see the kernel)
-  const int lpp = (!iso || g_star_lpp == 4) ? 4 : 8;       // (per-axis coefficients, rare: the 8-column form needs fewer registers)
+  const bool mapped = S->d_map != nullptr;
+  const int lpp = (!iso || mapped || g_star_lpp == 4) ? 4 : 8;   // (per-axis coefficients / masked grids: the 8-column form, which needs fewer registers)
   const int ty = 64 / lpp;
   const int ntx = (g.nx + STAR_T - 1) / STAR_T, nty = (g.ny + ty - 1) / ty, npass = (ncols + 2 * lpp - 1) / (2 * lpp);
   // z ranges: ONE where the patches x passes already give every CU two workgroups' worth of work (each range re-reads 12 planes
@@ -633,12 +720,17 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
   const double* dv = (const double*)((uintptr_t)S->d_diag + (uintptr_t)(shift * (long)sizeof(double)));
   const unsigned char* cv = (const unsigned char*)((uintptr_t)S->d_clean + (uintptr_t)shift);
   const long dlo = g.lo_off - g.mid_off, dhi = g.hi_off - g.mid_off;
-#define STAR_ARGS g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax, dlo, dhi, S->c, dv, xv, (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part, cv
+#define STAR_ARGS g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax, dlo, dhi, S->c, dv, xv, (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part, cv, (const int*)S->d_map
 #define STAR_LAUNCH2(DOT, ISO, SLAB, LPP) hipLaunchKernelGGL((spmm_star2_kernel<DOT, ISO, SLAB, LPP>), grid, dim3(1024), 0, stream, STAR_ARGS)
 #define STAR_DBG(B) case B: hipLaunchKernelGGL((spmm_star2_kernel<false, true, false, 8, B>), grid, dim3(1024), 0, stream, STAR_ARGS); return nb;
   if (g_star_dbg != 0 && part == nullptr && iso && lpp == 8 && !slab)
     switch (g_star_dbg) { STAR_DBG(1) STAR_DBG(2) STAR_DBG(8) STAR_DBG(3) STAR_DBG(9) STAR_DBG(16) default: break; }
   const bool dot = part != nullptr;
+  if (mapped) {          // masked grid: one rank, one coefficient set (checked at upload)
+    if (dot) hipLaunchKernelGGL((spmm_star2_kernel<true, true, false, 4, 0, true>), grid, dim3(1024), 0, stream, STAR_ARGS);
+    else     hipLaunchKernelGGL((spmm_star2_kernel<false, true, false, 4, 0, true>), grid, dim3(1024), 0, stream, STAR_ARGS);
+    return nb;
+  }
 #define STAR_PICK(ISO, LPP)                                                                                          \
   do { if (dot) { if (slab) STAR_LAUNCH2(true, ISO, true, LPP); else STAR_LAUNCH2(true, ISO, false, LPP); }          \
        else     { if (slab) STAR_LAUNCH2(false, ISO, true, LPP); else STAR_LAUNCH2(false, ISO, false, LPP); } } while (0)

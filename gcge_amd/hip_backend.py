@@ -32,6 +32,19 @@ class HipBackendImpl:
             raise RuntimeError("gcge_hip_mat_create_csr failed")
         return C.c_void_p(m)
 
+    def matrix_grid(self, csr, dims, box_of_row):
+        """A matrix on a masked grid: box_of_row[r] = x + nx (y + ny z) (int32 array, ascending); see gcge_hip_mat_create_grid."""
+        g = self.g
+        g.gcge_hip_mat_create_grid.restype = C.c_void_p
+        g.gcge_hip_mat_create_grid.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                               C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        box = np.ascontiguousarray(box_of_row, dtype=np.int32)
+        m = g.gcge_hip_mat_create_grid(csr.nrows, csr.rowptr, csr.colidx, csr.val, int(dims[0]), int(dims[1]), int(dims[2]),
+                                       box.ctypes.data_as(C.POINTER(C.c_int)))
+        if not m:
+            raise RuntimeError("gcge_hip_mat_create_grid failed")
+        return C.c_void_p(m)
+
     def free_matrix(self, m):
         self.g.gcge_hip_mat_destroy(m)
 

@@ -209,3 +209,29 @@ def test_star_split_on_row_slabs_cut_on_plane_boundaries():
     assert gdist.cuts_by_weight(np.array([1.0, 1.0, 100.0, 1.0]), 3, 10, 40) == [0, 10, 20, 40] or True
     p4 = gdist.cuts_by_weight(np.array([100.0, 1.0, 1.0, 1.0]), 4, 10, 40)
     assert p4 == [0, 10, 20, 30, 40], p4
+
+
+def test_star_split_on_a_masked_grid():
+    """The grid path on a MASKED grid (csrc/hip/spmm_star.hip with a row map; host half): the SiO2-like operator on the ball inscribed
+    in the box, rows = the grid points inside in scan order (the PARSEC layout behind BASELINE config 5).  With the geometry
+    named, every row splits into star + diagonal + remainder exactly as on the full box (arms cut at the sphere like at a face),
+    and the sweep's own map finds every neighbour where the CSR row names it; a wrong geometry is refused."""
+    import ctypes as C
+    import numpy as np
+    from gcge_amd.lib import hip_lib, make_problem, ball_geometry
+    g = hip_lib()
+    g.gcge_hip_star_selfcheck_grid.restype = C.c_long
+    g.gcge_hip_star_selfcheck_grid.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,
+                                               C.POINTER(C.c_int), C.POINTER(C.c_long)]
+    out = (C.c_long * 12)()
+    ip_ = C.POINTER(C.c_int)
+    for G, kw in ((24, dict(K=8, R0=1.5, R1=3.0)), (32, dict(K=30, R0=2.0, R1=5.0))):
+        A, _ = make_problem("sio2ball", G, **kw)
+        box = ball_geometry(G)
+        assert box.size == A.nrows and np.all(np.diff(box) > 0)
+        assert g.gcge_hip_star_selfcheck_grid(A.nrows, A.rowptr, A.colidx, A.val, G, G, G, box.ctypes.data_as(ip_), out) == 0, list(out)
+        assert list(out[:4]) == [G, G, G, 6] and 0.5 * A.nrows < out[4] < A.nrows, list(out)
+    # without the geometry such a matrix has no constant offsets: no grid form; with a wrong one: refused
+    g.gcge_hip_star_selfcheck.restype = C.c_long
+    assert g.gcge_hip_star_selfcheck(A.nrows, A.ncols, A.rowptr, A.colidx, A.val, out) == -1
+    assert g.gcge_hip_star_selfcheck_grid(A.nrows, A.rowptr, A.colidx, A.val, G + 1, G, G, box.ctypes.data_as(ip_), out) == -1

@@ -1253,6 +1253,82 @@ def test_star_sweep_spmm_vs_oracle(both, case):
         g.gcge_hip_spmm_dense_mode(0)
 
 
+@pytest.mark.parametrize("G,kw", [(24, dict(K=8, R0=1.5, R1=3.0)), (28, dict(K=20, R0=2.0, R1=5.0))])
+def test_star_sweep_on_a_masked_grid_vs_oracle(both, G, kw):
+    """K1 on a MASKED grid: the SiO2-like operator on the ball inscribed in the box, rows = grid points inside in scan order (the
+    layout of the PARSEC matrices behind BASELINE config 5).  With the geometry named (gcge_hip_mat_create_grid) the star rows
+    take the plane sweep through a row map, the rest dense blocks + listed rows; against the CPU oracle, scipy and the same
+    matrix uploaded WITHOUT the geometry (dense blocks + pad-8): plain products, odd ranges, the product with column sums,
+    and a whole solve against the reference's run (tests/golden)."""
+    from gcge_amd.lib import ball_geometry
+    hip, ora = both
+    g = hip.g
+    g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
+    g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+    g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+    g.gcge_hip_spmm_dense_mode(1)
+    try:
+        A, _ = make_problem("sio2ball", G, **kw)
+        box = ball_geometry(G)
+        mh, mp, mo = hip.matrix_grid(A, (G, G, G), box), hip.matrix(A), ora.matrix(A)
+        assert g.gcge_hip_mat_spmm_form(mh).decode().startswith("spmm_star+spmm_dense"), g.gcge_hip_mat_spmm_form(mh).decode()
+        assert not g.gcge_hip_mat_spmm_form(mp).decode().startswith("spmm_star")
+        n = A.nrows
+        S = csr_to_scipy(A)
+        X = uniform(12, (n, 72)) - 0.5
+        xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
+        for m, s0, s1 in [(64, 0, 0), (16, 2, 4), (2, 0, 0), (30, 4, 2), (66, 6, 0), (17, 1, 0)]:
+            Y0 = uniform(8, (n, 72))
+            yh, yp, yo = hip.mv_from_numpy(mh, Y0), hip.mv_from_numpy(mp, Y0), ora.mv_from_numpy(mo, Y0)
+            hip.ops.spmm(mh, xh, yh, (s0, s1), (s0 + m, s1 + m))
+            hip.ops.spmm(mp, xh, yp, (s0, s1), (s0 + m, s1 + m))
+            ora.ops.spmm(mo, xo, yo, (s0, s1), (s0 + m, s1 + m))
+            got = hip.mv_to_numpy(yh, n, 0, 72)
+            _close(got, ora.mv_to_numpy(yo, n, 0, 72), tol=1e-12, what="sweep on a masked grid m=%d" % m)
+            _close(got, hip.mv_to_numpy(yp, n, 0, 72), tol=1e-12, what="with / without the geometry m=%d" % m)
+            _close(got[:, s1:s1 + m], S @ X[:, s0:s0 + m], tol=1e-12, what="sweep on a masked grid vs scipy m=%d" % m)
+            hip.ops.mv_destroy(yh); hip.ops.mv_destroy(yp); ora.ops.mv_destroy(yo)
+        g.gcge_hip_spmm_dot2_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        for m, s0, s1 in [(64, 0, 0), (30, 4, 2)]:
+            y2 = hip.mv_from_numpy(mh, uniform(9, (n, 64)))
+            dots, yy = np.zeros(m), np.zeros(m)
+            g.gcge_hip_spmm_dot2_mv(mh, xh, y2, (C.c_int * 2)(s0, s1), (C.c_int * 2)(s0 + m, s1 + m), dots.ctypes.data, yy.ctypes.data, hip.ops_handle)
+            Yw = S @ X[:, s0:s0 + m]
+            _close(hip.mv_to_numpy(y2, n, 0, 64)[:, s1:s1 + m], Yw, tol=1e-12, what="masked grid: product with column sums m=%d" % m)
+            assert np.allclose(dots, (X[:, s0:s0 + m] * Yw).sum(0), rtol=1e-11, atol=1e-9) and np.allclose(yy, (Yw * Yw).sum(0), rtol=1e-11), m
+            hip.ops.mv_destroy(y2)
+        hip.free_matrix(mh); hip.free_matrix(mp)
+    finally:
+        g.gcge_hip_spmm_dense_mode(0)
+
+
+def test_gcg_on_a_masked_grid_with_the_sweep_matches_reference_run(hip):
+    """The reference's run on the ball matrix (tests/golden: sio2ball_16_nev10) against our driver over the HIP table with the
+    geometry named, chol + fused CG (product with column sums through the mapped sweep)."""
+    from gcge_amd.lib import ball_geometry, run_gcg
+    c = GCG["sio2ball_16_nev10"]
+    g = hip.g
+    g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
+    g.gcge_hip_spmm_dense_mode(1)
+    try:
+        A, _ = make_problem("sio2ball", 16, K=6, R0=1.5, R1=2.0, seed=12345)
+        mA = hip.matrix_grid(A, (16, 16, 16), ball_geometry(16))
+        g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+        g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+        form = g.gcge_hip_mat_spmm_form(mA).decode()
+        g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+        g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+        hip.set_random_mode(0)
+        ev, res = run_gcg(hip.ops_handle, mA, None, ["-nevConv", c["nev"], "-gcge_initX_orth_method", "chol", "-gcge_compW_orth_method", "chol"], flag=1)
+        hip.free_matrix(mA)
+        refv = np.array(c["eval"])
+        assert res.nevConv >= c["nev"] and abs(res.numIter - c["numIter"]) <= 2, (res.nevConv, res.numIter, c["numIter"], form)
+        assert np.max(np.abs(ev[:len(refv)] - refv) / refv) < 1e-10
+    finally:
+        g.gcge_hip_spmm_dense_mode(0)
+
+
 @pytest.mark.parametrize("kind,size,form", [("lap3d", 16, "spmm_pattern_chain2+values"), ("lap3d", 32, "spmm_pattern_chain2+values"),
                                             ("lap3d", 13, "spmm_pattern+values")])
 def test_offset_pattern_spmm_vs_oracle(both, kind, size, form):
