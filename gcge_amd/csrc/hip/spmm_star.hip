@@ -47,7 +47,8 @@ struct StarCoef { double cx[STAR_R + 1], cy[STAR_R + 1], cz[STAR_R + 1]; };   //
 struct StarGeom { int nx, ny, nz, zs, ze, zmin, zmax; long lo_off, mid_off, hi_off; };
 struct StarMat {
   StarGeom g; int R; bool iso; long nclean, nrows; StarCoef c; double* d_diag; unsigned char* d_clean;   // d_clean[local row]: 1 = nothing but the star and a diagonal
-  int* d_map;   // masked grids: d_map[box index] = row, -1 where the point is not a row (NULL: every grid point is a row)   // d_diag[local row]: the row's diagonal entry, NaN: not a clean row
+  int* d_map;   // masked grids: d_map[box index] = row, -1 where the point is not a row (NULL: every grid point is a row)
+  int* d_prange;   // masked grids: for every 16 x 16 patch the first / last + 1 plane in which it has rows   // d_diag[local row]: the row's diagonal entry, NaN: not a clean row
 };
 
 // staging plan of a thread: unit u = tid + 1024 q, point u >> 2, 16-byte part u & 3
@@ -97,7 +98,8 @@ template <int LPP> struct Star2Geom {
 template <bool DOT, bool ISO, bool SLAB, int LPP, int dbg = 0, bool MAPPED = false>
 __global__ __launch_bounds__(1024) void spmm_star2_kernel(int nx, int ny, int zs, int ze, int zmin, int zmax, long dlo, long dhi, StarCoef cf,
     const double* __restrict__ diag, const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols,
-    int zlo, int zhi, int zlen, int ntx, double* __restrict__ partial, const unsigned char* __restrict__ cleanf, const int* __restrict__ map) {
+    int zlo, int zhi, int zlen, int ntx, double* __restrict__ partial, const unsigned char* __restrict__ cleanf, const int* __restrict__ map,
+    const int* __restrict__ prange) {
   typedef Star2Geom<LPP> GEO;
   constexpr int TY = GEO::TY, IMG = GEO::IMG, HQ = GEO::HQ, SIDE = 2 * STAR_R * TY;
   __shared__ v2d img[2 * IMG];                  // img[b][(row * 28 + col) * LPP + part]
@@ -105,12 +107,21 @@ __global__ __launch_bounds__(1024) void spmm_star2_kernel(int nx, int ny, int zs
   const int part = tid % LPP, px = (tid / LPP) & 15, py = tid / (16 * LPP);
   const int tile_x = blockIdx.x % ntx, tile_y = blockIdx.x / ntx;
   const int x0 = tile_x * STAR_T, y0 = tile_y * TY;
-  const int z0 = zlo + blockIdx.y * zlen, z1 = min(zhi, z0 + zlen);
+  // MAPPED: only the planes in which this patch has rows at all (a ball fills half of its box: the rest would be swept for nothing)
+  const int z0 = MAPPED ? max(zlo + (int)blockIdx.y * zlen, prange[2 * blockIdx.x]) : zlo + blockIdx.y * zlen;
+  const int z1 = MAPPED ? min(min(zhi, zlo + ((int)blockIdx.y + 1) * zlen), prange[2 * blockIdx.x + 1]) : min(zhi, z0 + zlen);
   const int c0 = 2 * LPP * blockIdx.z;
   const long plane_rows = (long)nx * ny;
   auto plane_row0 = [&](int zz) -> long { return plane_rows * zz + (SLAB ? (zz < zs ? dlo : zz >= ze ? dhi : 0L) : 0L); };
   const int gx = x0 + px, gy = y0 + py;
   const bool cvalid = c0 + 2 * part < ncols;
+  if (MAPPED && z0 >= z1) {          // (nothing of this patch in this z range: uniform over the workgroup, before any barrier)
+    if (DOT && tid < LPP && c0 + 2 * tid < ncols) {
+      double* out = partial + ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 2 * ncols;
+      out[c0 + 2 * tid] = 0.0; out[c0 + 2 * tid + 1] = 0.0; out[ncols + c0 + 2 * tid] = 0.0; out[ncols + c0 + 2 * tid + 1] = 0.0;
+    }
+    return;
+  }
   const int col = cvalid ? c0 + 2 * part : c0;                           // (a valid address whatever the lane: see star2_and)
   const bool inside = gx < nx && gy < ny && cvalid;
   const int own_i = inside ? gx + nx * gy : -1;                          // my point's offset inside a plane (< 0: none)
@@ -624,7 +635,7 @@ extern "C" void gcge_hip_star_free(void* sm) {
   StarMat* S = (StarMat*)sm;
   if (!S) return;
   hipFree(S->d_diag); hipFree(S->d_clean);
-  if (S->d_map) hipFree(S->d_map);
+  if (S->d_map) { hipFree(S->d_map); hipFree(S->d_prange); }
   delete S;
 }
 
@@ -651,14 +662,24 @@ extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin,
   }
   if (!star_build_host(M, H)) { delete H; return nullptr; }
   StarMat* S = new StarMat();
-  S->d_map = nullptr;
+  S->d_map = nullptr; S->d_prange = nullptr;
   if (M.box != nullptr) {
     GCGE_HIP_CHECK(hipMalloc(&S->d_map, H->inv.size() * sizeof(int)));
     GCGE_HIP_CHECK(hipMemcpy(S->d_map, H->inv.data(), H->inv.size() * sizeof(int), hipMemcpyHostToDevice));
+    const int nx = H->g.nx, ny = H->g.ny, nz = H->g.nz, ntx = (nx + STAR_T - 1) / STAR_T, nty = (ny + STAR_T - 1) / STAR_T;
+    std::vector<int> pr((size_t)2 * ntx * nty);
+    for (int p = 0; p < ntx * nty; ++p) { pr[2 * p] = nz; pr[2 * p + 1] = 0; }
+    for (int r = 0; r < nrows; ++r) {
+      const long b = M.box[r];
+      const int z = (int)(b / ((long)nx * ny)), y = (int)((b / nx) % ny), x = (int)(b % nx), p = (y / STAR_T) * ntx + x / STAR_T;
+      pr[2 * p] = std::min(pr[2 * p], z); pr[2 * p + 1] = std::max(pr[2 * p + 1], z + 1);
+    }
+    GCGE_HIP_CHECK(hipMalloc(&S->d_prange, pr.size() * sizeof(int)));
+    GCGE_HIP_CHECK(hipMemcpy(S->d_prange, pr.data(), pr.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   S->g = H->g; S->R = H->R; S->nclean = H->nclean; S->nrows = nrows; S->c = H->c;
   S->iso = memcmp(H->c.cx, H->c.cy, sizeof(H->c.cx)) == 0 && memcmp(H->c.cx, H->c.cz, sizeof(H->c.cx)) == 0;
-  if (S->d_map != nullptr && !S->iso) { hipFree(S->d_map); delete S; delete H; return nullptr; }   // (masked grids: the one-coefficient-set kernel only)
+  if (S->d_map != nullptr && !S->iso) { hipFree(S->d_map); hipFree(S->d_prange); delete S; delete H; return nullptr; }   // (masked grids: the one-coefficient-set kernel only)
   GCGE_HIP_CHECK(hipMalloc(&S->d_diag, (size_t)nrows * sizeof(double)));
   GCGE_HIP_CHECK(hipMemcpy(S->d_diag, H->diag.data(), (size_t)nrows * sizeof(double), hipMemcpyHostToDevice));
   std::vector<double>().swap(H->diag);
@@ -720,7 +741,7 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
   const double* dv = (const double*)((uintptr_t)S->d_diag + (uintptr_t)(shift * (long)sizeof(double)));
   const unsigned char* cv = (const unsigned char*)((uintptr_t)S->d_clean + (uintptr_t)shift);
   const long dlo = g.lo_off - g.mid_off, dhi = g.hi_off - g.mid_off;
-#define STAR_ARGS g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax, dlo, dhi, S->c, dv, xv, (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part, cv, (const int*)S->d_map
+#define STAR_ARGS g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax, dlo, dhi, S->c, dv, xv, (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part, cv, (const int*)S->d_map, (const int*)S->d_prange
 #define STAR_LAUNCH2(DOT, ISO, SLAB, LPP) hipLaunchKernelGGL((spmm_star2_kernel<DOT, ISO, SLAB, LPP>), grid, dim3(1024), 0, stream, STAR_ARGS)
 #define STAR_DBG(B) case B: hipLaunchKernelGGL((spmm_star2_kernel<false, true, false, 8, B>), grid, dim3(1024), 0, stream, STAR_ARGS); return nb;
   if (g_star_dbg != 0 && part == nullptr && iso && lpp == 8 && !slab)
