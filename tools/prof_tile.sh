@@ -19,7 +19,10 @@ out=sys.argv[1]; acc=collections.defaultdict(list)
 for f in glob.glob(out+'/p*/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(f)):
         k=r.get('Kernel_Name','')
-        if 'spmm_star_kernel' in k: tag='star'
+        if 'spmm_star2_kernel' in k:
+            kk=k.replace(' ','')
+            tag='star' + ('+sums' if 'kernel<true' in kk else '') + (' 16col' if ',8,0,' in kk else ' 8col') + (' masked' if kk.split('>')[0].endswith('true') else '')
+        elif 'spmm_star_kernel' in k: tag='star'
         elif 'spmm_tile_kernel' in k: tag='tile'
         elif 'spmm_pad8' in k: tag='pad8'
         elif 'spmm_dense' in k: tag='dense'
