@@ -136,6 +136,29 @@ def pmc_traffic(kernel, N, m):
     return k["fabric_bytes_per_block_operation"], "profiles/pmc_traffic.json (%s; sources %s)" % (t.get("bytes_rule", ""), t["source_sha256"][:12])
 
 
+def pmc_traffic_c5(G, atoms, m):
+    """Fabric bytes of the plane sweep per m-column product of BASELINE config 5's matrix (profiles/pmc_traffic.json, entry
+    "c5"), quoted only while spmm_star.hip hashes to what was profiled."""
+    import hashlib
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("c5")
+    except (OSError, ValueError):
+        return None, "no profiles/pmc_traffic.json"
+    if not t:
+        return None, "no entry for config 5 in profiles/pmc_traffic.json"
+    h = hashlib.sha256()
+    for f in sorted(t.get("source_files", [])):
+        h.update(f.encode())
+        h.update(open(os.path.join(ROOT, "gcge_amd", "csrc", "hip", f), "rb").read())
+    if h.hexdigest() != t.get("source_sha256"):
+        return None, "profiles/pmc_traffic.json (c5) was measured on other kernel sources (hash differs): not quoted"
+    sh = t.get("shape", {})
+    if sh.get("G") != G or sh.get("atoms") != atoms or sh.get("m") != m:
+        return None, "profiles/pmc_traffic.json (c5) holds G=%s atoms=%s m=%s" % (sh.get("G"), sh.get("atoms"), sh.get("m"))
+    k = next(iter(t["kernels"].values()))
+    return k["fabric_bytes_per_block_operation"], "plane sweep only (%s); %s" % (t.get("profile"), t.get("bytes_rule"))
+
+
 def cpu_baseline(args, hip):
     """The reference's CPU path on BASELINE config 1 (Lap3D 50^3, nev 20, block 20, nevMax 40), OpenMP build, all
     host cores; and the GPU on that same config."""
@@ -473,6 +496,8 @@ def main():
                 kname = "%s<7,7,16,false>" % kbase
                 streams = 3
             traffic, note = pmc_traffic(kname, N, args.block) if (npat > 0 and world == 1 and not c5) else (None, "no PMC profile for this shape")
+            if c5 and world == 1 and kind == 0 and form.startswith("spmm_star"):
+                traffic, note = pmc_traffic_c5(N, args.atoms, args.block)
             req = (8.0 * streams * args.block + 2.0 * npass) * A.nrows if npat > 0 else by_ / c_
             return {"bound": "hbm", "kernel": "%s x %d passes of 16 columns: %s (%d row patterns, m=%d)"
                                               % (kname, npass, what, npat, args.block) if npat > 0 else "%s: %s (m=%d)" % (kname, what, args.block),
