@@ -532,15 +532,23 @@ static void build_patterns(GCGE_HIP_MAT* A, int nrows, int ncols_local, const in
 // rows of one slab with LOCAL column indices in [0, ncols_local); columns >= nrows are halo rows.  ghost_global (may be NULL): the
 // global rows behind the halo columns, ascending — with it (and nglobal) a slab of a grid matrix cut on plane boundaries keeps the
 // plane sweep of spmm_star.hip: the planes below and above the slab are then found among the halo rows.
+static double upload_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local_ghosts(int nrows, int ncols_local, int nglobal, int row_begin,
                                                           const int* rowptr, const int* colidx, const double* val, const int* ghost_global) {
   if (gcge_hip_init(-1) != 0) return nullptr;
+  const bool timing = getenv("GCGE_UPLOAD_TIMING") != nullptr;   // phases of the host-side analysis on stderr
+  double t_phase = upload_now();
+  auto phase = [&](const char* what) { if (timing) { const double t = upload_now(); fprintf(stderr, "gcge_hip upload: %-28s %.3f s\n", what, t - t_phase); t_phase = t; } };
   GCGE_HIP_MAT* A = (GCGE_HIP_MAT*)calloc(1, sizeof(GCGE_HIP_MAT));
   A->nrows = nrows; A->nglobal = nglobal; A->row_begin = row_begin; A->nnz = rowptr[nrows];
   A->nghost = ncols_local - nrows;
   GCGE_REQUIRE(A->nghost >= 0, "gcge_hip_mat_create_local: ncols_local >= nrows");
-  for (long k = 0; k < A->nnz; ++k)
-    GCGE_REQUIRE(colidx[k] >= 0 && colidx[k] < ncols_local, "gcge_hip_mat_create_local: column index in range");
+  {
+    const int nt = gcge_upload_threads();
+    std::vector<int> bad((size_t)nt, 0);
+    gcge_parallel_chunks(A->nnz, nt, [&](int c, long k0, long k1) { int b = 0; for (long k = k0; k < k1; ++k) b |= (colidx[k] < 0) | (colidx[k] >= ncols_local); bad[c] = b; });
+    for (int c = 0; c < nt; ++c) GCGE_REQUIRE(bad[c] == 0, "gcge_hip_mat_create_local: column index in range");
+  }
   const size_t nnz = (size_t)A->nnz;
   GCGE_HIP_CHECK(hipMalloc(&A->d_rowptr, ((size_t)nrows + 1) * sizeof(int)));
   GCGE_HIP_CHECK(hipMalloc(&A->d_colidx, (nnz ? nnz : 1) * sizeof(int)));
@@ -555,11 +563,13 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local_ghosts(int nrows, int ncols_l
   orp[nrows] = (int)noct;
   std::vector<int> pc(noct * 8);
   std::vector<double> pv(noct * 8);
-  for (int r = 0; r < nrows; ++r) {
-    size_t o = (size_t)orp[r] * 8; int k;
-    for (k = rowptr[r]; k < rowptr[r + 1]; ++k, ++o) { pc[o] = colidx[k]; pv[o] = val[k]; }
-    for (; o < (size_t)orp[r + 1] * 8; ++o) { pc[o] = r; pv[o] = 0.0; }
-  }
+  gcge_parallel_chunks(nrows, gcge_upload_threads(), [&](int, long r0, long r1) {
+    for (long r = r0; r < r1; ++r) {
+      size_t o = (size_t)orp[r] * 8; int k;
+      for (k = rowptr[r]; k < rowptr[r + 1]; ++k, ++o) { pc[o] = colidx[k]; pv[o] = val[k]; }
+      for (; o < (size_t)orp[r + 1] * 8; ++o) { pc[o] = (int)r; pv[o] = 0.0; }
+    }
+  });
   A->noct = (long)noct;
   GCGE_HIP_CHECK(hipMalloc(&A->d_orp, ((size_t)nrows + 1) * sizeof(int)));
   GCGE_HIP_CHECK(hipMalloc(&A->d_pcol, (noct ? noct * 8 : 1) * sizeof(int)));
@@ -567,10 +577,12 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local_ghosts(int nrows, int ncols_l
   GCGE_HIP_CHECK(hipMemcpy(A->d_orp, orp.data(), ((size_t)nrows + 1) * sizeof(int), hipMemcpyHostToDevice));
   GCGE_HIP_CHECK(hipMemcpy(A->d_pcol, pc.data(), noct * 8 * sizeof(int), hipMemcpyHostToDevice));
   GCGE_HIP_CHECK(hipMemcpy(A->d_pval, pv.data(), noct * 8 * sizeof(double), hipMemcpyHostToDevice));
+  phase("CSR + pad-8 copies");
   build_patterns(A, nrows, ncols_local, rowptr, colidx, val);
   if (A->d_pid == nullptr && g_offset_patterns) build_patterns(A, nrows, ncols_local, rowptr, colidx, val, true);   // same stencil, other coefficients in every row
   // matrices without a pattern form whose rows are mostly ONE star stencil on a grid (free diagonal): those rows leave the CSR
   // arrays for the plane sweep of spmm_star.hip, the others (rows inside dense blocks, ...) keep every entry and take the block form
+  phase("pattern search");
   A->star = nullptr; A->star_rem = nullptr;
   if (A->d_pid == nullptr) {
     const int *rr = nullptr, *rc = nullptr; const double* rv = nullptr;
@@ -578,10 +590,12 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local_ghosts(int nrows, int ncols_l
     const bool whole = row_begin == 0 && ncols_local == nrows && (nglobal <= 0 || nglobal == nrows);
     const bool slab = !whole && nglobal > 0 && (ncols_local == nrows || ghost_global != nullptr);
     void* S = (whole || slab) ? gcge_hip_star_build(nrows, ncols_local, row_begin, whole ? nrows : nglobal, ghost_global, rowptr, colidx, val, &rr, &rc, &rv) : nullptr;
+    phase("star split");
     if (S != nullptr) {
       void* D = gcge_hip_dense_build_rows(nrows, ncols_local, rr, rc, rv, gcge_hip_star_host_mask());   // (its pad-8 part lists the other rows only)
       if (D != nullptr) { A->star = S; A->star_rem = D; } else gcge_hip_star_free(S);   // (no blocks among the other rows: the forms below)
       gcge_hip_star_release_remainder();
+      phase("blocks + listed rows");
     }
   }
   // matrices without a pattern form: dense row blocks (supernodes) on MFMA + remainder CSR, where such blocks exist

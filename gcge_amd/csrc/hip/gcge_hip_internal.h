@@ -16,7 +16,26 @@
   } while (0)
 
 #ifdef __cplusplus
+#include <thread>
+#include <vector>
 #include "gcge_hip.h"
+// host-side analysis of a matrix at upload: fn(chunk, first, last) over [0, n) cut into contiguous chunks, one thread each
+// (GCGE_UPLOAD_THREADS, default: the cores the process may use, at most 16)
+static inline int gcge_upload_threads() {
+  const char* e = getenv("GCGE_UPLOAD_THREADS");
+  int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+  if (t < 1) t = 1;
+  if (t > 16) t = 16;
+  return t;
+}
+template <class F>
+static inline void gcge_parallel_chunks(long n, int nchunks, F fn) {
+  if (nchunks <= 1 || n < 65536) { for (int c = 0; c < nchunks; ++c) fn(c, n * c / nchunks, n * (c + 1) / nchunks); return; }
+  std::vector<std::thread> th;
+  for (int c = 1; c < nchunks; ++c) th.emplace_back([=]() { fn(c, n * c / nchunks, n * (c + 1) / nchunks); });
+  fn(0, 0L, n / nchunks);
+  for (auto& t : th) t.join();
+}
 // sparse matrix handle (CCSMAT counterpart): shared by app_hip.hip (the slots) and rccl_comm.hip (the halo plan)
 struct GCGE_HIP_MAT_ {
   int nrows;      // local rows

@@ -465,13 +465,18 @@ static bool star_build_host(const StarRows& M, StarHost* H) {
     const int zz = (int)(gq / sz);
     return (zz < gm.zs ? gm.lo_off : zz >= gm.ze ? gm.hi_off : gm.mid_off) + gq;
   };
-  long nclean = 0;
   std::vector<char>& clean = H->clean;
   clean.assign((size_t)nrows, 0);
+  // rows are independent: contiguous chunks, one thread each, every chunk with its own remainder arrays (joined in order below)
+  const int nt = gcge_upload_threads();
+  std::vector<std::vector<int>> crc((size_t)nt); std::vector<std::vector<double>> crv((size_t)nt);
+  std::vector<long> cclean((size_t)nt, 0); std::vector<int> cfail((size_t)nt, 0);
+  std::vector<int>& rcnt = H->rem_rowptr;                             // [r + 1] = entries of row r for now, prefix-summed below
+  gcge_parallel_chunks(nrows, nt, [&](int chunk, long rb, long re) {
   std::vector<std::pair<int, double>> rem;                             // remainder of the row being looked at
-  std::vector<int>& rc = H->rem_col; std::vector<double>& rv = H->rem_val;
-  rc.clear(); rv.clear();
-  for (int r = 0; r < nrows; ++r) {
+  std::vector<int>& rc = crc[chunk]; std::vector<double>& rv = crv[chunk];
+  long nclean = 0;
+  for (int r = (int)rb; r < (int)re; ++r) {
     const long gr = M.gpos(r);
     const int gz = (int)(gr / sz), gy = (int)((gr - (long)gz * sz) / sy), gx = (int)(gr - (long)gz * sz - (long)gy * sy);
     const int g[3] = {gx, gy, gz}, dim[3] = {nx, ny, nz};
@@ -505,18 +510,34 @@ static bool star_build_host(const StarRows& M, StarHost* H) {
           // the sweep adds coefficient x neighbour here, the row has no such entry: the remainder takes it back
           const long gq = gr + (sgn ? 1 : -1) * k * stride[a];
           const int zz = (int)(gq / sz);
-          if (zz < gm.zmin || zz >= gm.zmax) return false;             // (cannot happen: zmin / zmax cover the star's reach)
+          if (zz < gm.zmin || zz >= gm.zmax) { cfail[chunk] = 1; return; }   // (cannot happen: zmin / zmax cover the star's reach)
           rem.emplace_back((int)xcol(gq), -cv[a][k]);
         }
       }
-    if (dv != dv) return false;                                        // a NaN on the diagonal: not for this form
+    if (dv != dv) { cfail[chunk] = 1; return; }                        // a NaN on the diagonal: not for this form
     H->diag[r] = dv;
     if (rem.empty()) { clean[r] = 1; ++nclean; }
     else {
       std::sort(rem.begin(), rem.end(), [](const std::pair<int, double>& p, const std::pair<int, double>& q) { return p.first < q.first; });
       for (auto& e : rem) { rc.push_back(e.first); rv.push_back(e.second); }
     }
-    H->rem_rowptr[r + 1] = (int)rc.size();
+    rcnt[r + 1] = (int)rem.size();
+  }
+  cclean[chunk] = nclean;
+  });
+  long nclean = 0;
+  for (int c = 0; c < nt; ++c) { if (cfail[c]) return false; nclean += cclean[c]; }
+  for (int r = 0; r < nrows; ++r) rcnt[r + 1] += rcnt[r];
+  std::vector<int>& rc = H->rem_col; std::vector<double>& rv = H->rem_val;
+  rc.resize((size_t)rcnt[nrows]); rv.resize((size_t)rcnt[nrows]);
+  {
+    size_t off = 0;
+    for (int c = 0; c < nt; ++c) {
+      if (!crc[c].empty()) { memcpy(rc.data() + off, crc[c].data(), crc[c].size() * sizeof(int)); memcpy(rv.data() + off, crv[c].data(), crv[c].size() * sizeof(double)); }
+      off += crc[c].size();
+      std::vector<int>().swap(crc[c]); std::vector<double>().swap(crv[c]);
+    }
+    if (off != rc.size()) return false;
   }
   H->nclean = nclean;
   if (2 * nclean < nrows) return false;
