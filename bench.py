@@ -28,6 +28,10 @@ torch.distributed only hands rank 0's RCCL id to the other ranks and synchronise
              pattern path (2 B per row for the matrix instead of 12 B per non-zero);
              traffic = fabric bytes per launch from rocprofv3 PMC passes (tools/pmc_traffic.py ->
              profiles/pmc_traffic.json), quoted only while the HIP sources hash to what was profiled.
+  roofline_gram / roofline_panel_update = the FP64-MFMA kernels (K2 / K3) in the solve: 2 n k m flop per launch / HIP-event
+             duration, summed per shape (k, m) over the timed steps; the shape with the largest share of the step, against the
+             78.6 TF dense FP64 matrix peak; dense_other_shapes = the next three.  pairs_wanted_per_s = nev x steps / elapsed
+             (value counts every pair a solve converged).  upload_seconds = host arrays -> device matrix in all its forms.
   cpu_baseline = the reference's own CPU path, OpenMP build (oracle/_ref/libgcge_ref_omp.so: app_ccs.c:117-131
              under OPS_USE_OMP), all host cores, on BASELINE config 1 (Lap3D 50^3, nev 20, block 20) — with the
              GPU's time on that SAME config beside it (gpu_same_config); kind "port" = our C restatement when the
