@@ -15,6 +15,16 @@
     }                                                                                 \
   } while (0)
 
+// Shape contract of every slot is checked on the HOST before a kernel is launched: a
+// mismatch must abort here, never turn into an out-of-bounds access on the device.
+#define GCGE_REQUIRE(cond, what)                                                        \
+  do {                                                                                  \
+    if (!(cond)) {                                                                      \
+      fprintf(stderr, "gcge_hip: %s violated (%s) at %s:%d\n", what, #cond, __FILE__, __LINE__); \
+      abort();                                                                          \
+    }                                                                                   \
+  } while (0)
+
 #ifdef __cplusplus
 #include <thread>
 #include <vector>
