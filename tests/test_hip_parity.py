@@ -344,6 +344,56 @@ def test_full_size_spmm_properties(hip):
     hip.free_matrix(mh)
 
 
+@pytest.mark.parametrize("domain", ["box", "ball"])
+def test_full_size_config5_spmm_properties(hip, domain):
+    """BASELINE config 5 at FULL size — the SiO2-like operator on the 171^3 grid (K = 2000 atoms; 5.0e6 rows, 3.5e8 non-zeros) and
+    on the ball inscribed in it (2.6e6 rows, the PARSEC layout) — through size-independent properties instead of a CPU product:
+    every ROW of A applied to the constant vector against the row sums of the host CSR arrays (any wrong address, halo or
+    map entry of the plane sweep / dense blocks / listed rows shows in some row), symmetry x^T (A y) = (A x)^T y per column, and
+    the grid form against the pad-8 kernel on the whole matrix."""
+    from gcge_amd.lib import ball_geometry
+    G, kw = 171, dict(K=2000, R0=2.0, R1=5.0, seed=12345)
+    g = hip.g
+    g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+    g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+    g.gcge_hip_set_spmm_path.argtypes = [C.c_int]
+    if domain == "box":
+        A, _ = make_problem("sio2", G, **kw)
+        mh = hip.matrix(A)
+    else:
+        A, _ = make_problem("sio2ball", G, **kw)
+        mh = hip.matrix_grid(A, (G, G, G), ball_geometry(G))
+    assert g.gcge_hip_mat_spmm_form(mh).decode().startswith("spmm_star+spmm_dense"), g.gcge_hip_mat_spmm_form(mh).decode()
+    n, nnz = A.nrows, int(A.nnz)
+    rp = np.ctypeslib.as_array(A.rowptr, shape=(n + 1,))
+    va = np.ctypeslib.as_array(A.val, shape=(nnz,))
+    rowsum = np.add.reduceat(va, rp[:-1].astype(np.int64))               # (no empty rows: every row has its diagonal)
+    absum = np.add.reduceat(np.abs(va), rp[:-1].astype(np.int64))
+    ops = hip.ops
+    ones = hip.mv_from_numpy(mh, np.ones((n, 2)))
+    y1 = ops.mv_create(2, mh)
+    ops.spmm(mh, ones, y1, (0, 0), (2, 2))
+    got = hip.mv_to_numpy(y1, n, 0, 2)
+    assert np.max(np.abs(got[:, 0] - rowsum) / absum) < 1e-13 and np.array_equal(got[:, 0], got[:, 1])      # (rows of up to ~1500 entries, summed in another order)
+    x = ops.mv_create(64, mh); y = ops.mv_create(64, mh); ax = ops.mv_create(64, mh); ay = ops.mv_create(64, mh)
+    hip.set_random_mode(1, 99)
+    ops.set_random(x, 0, 64); ops.set_random(y, 0, 64)
+    hip.set_random_mode(0)
+    ops.spmm(mh, x, ax, (0, 0), (64, 64)); ops.spmm(mh, y, ay, (0, 0), (64, 64))
+    d1 = ops.inner_prod("D", x, ay, (0, 0), (64, 64)); d2 = ops.inner_prod("D", ax, y, (0, 0), (64, 64))
+    assert np.max(np.abs(d1 - d2) / np.abs(d1)) < 1e-11
+    g.gcge_hip_set_spmm_path(3)
+    try:
+        ops.spmm(mh, x, ay, (0, 0), (64, 64))                           # the same product through the pad-8 kernel alone
+    finally:
+        g.gcge_hip_set_spmm_path(0)
+    a, b = hip.mv_to_numpy(ax, n, 0, 8), hip.mv_to_numpy(ay, n, 0, 8)
+    assert np.max(np.abs(a - b)) < 1e-12 * np.max(np.abs(b))
+    for hnd, c in ((x, 64), (y, 64), (ax, 64), (ay, 64), (ones, 2), (y1, 2)):
+        ops.mv_destroy(hnd, c)
+    hip.free_matrix(mh)
+
+
 @pytest.mark.parametrize("kind,size,which,m", [("lap3d", 16, "A", 22), ("lap3d", 16, "A", 64), ("lap3d", 12, "A", 6),
                                                ("fe3d", 12, "A", 10), ("fe3d", 12, "B", 16), ("lap3d", 20, "A", 2)])
 def test_cg_recompute_passes_match_numpy(hip, kind, size, which, m):
