@@ -100,9 +100,65 @@ def star_loopback(G):
     print("rccl loop-back ok: star sweep on a slab of %d planes of %d^2, %d halo rows, %d products with the interior swept while the halo travelled" % (G // 2, G, ng, nsplit[1]))
 
 
+def star_loopback_full_size(G, K):
+    """argv[2] == "native_star_full": BOTH slabs of a two-way plane-aligned cut of BASELINE config 5's matrix at full size, each
+    with its halo looped back onto this rank over RCCL from C — through a size-independent property: with X = 1 everywhere (halo
+    rows included, whoever serves them) every row of A X is the row sum of the slab's CSR row.  Any wrong halo-plane address of the
+    sweep, at any size of index, shows in some row."""
+    os.environ["GCGE_COMM_KEEP_SINGLE"] = "1"
+    import torch
+    torch.cuda.set_device(0)
+    from gcge_amd import HipBackend
+    from gcge_amd import dist as gdist
+    from gcge_amd.lib import make_problem
+    kw = dict(K=K, R0=2.0, R1=5.0, seed=12345)
+    plane, n = G * G, G ** 3
+    be = HipBackend(device=0)
+    g = be.g
+    comm = gdist.NativeComm(be, None, 0, 1)
+    ip_ = C.POINTER(C.c_int)
+    g.gcge_hip_mat_create_local_ghosts.restype = C.c_void_p
+    g.gcge_hip_mat_create_local_ghosts.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, ip_, ip_, C.POINTER(C.c_double), ip_]
+    g.gcge_hip_mat_set_halo_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, ip_, ip_, ip_, ip_, C.c_int]
+    g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+    g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+    g.gcge_hip_star_product_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    part = [0, (G // 2) * plane, n]
+    for r in range(2):
+        A, _ = make_problem("sio2", G, row_begin=part[r], row_end=part[r + 1], **kw)
+        nloc, nnz = A.nrows, int(A.nnz)
+        rp = np.ctypeslib.as_array(A.rowptr, shape=(nloc + 1,)).astype(np.int64)
+        va = np.ctypeslib.as_array(A.val, shape=(nnz,))
+        rowsum = np.add.reduceat(va, rp[:-1]); absum = np.add.reduceat(np.abs(va), rp[:-1])
+        ghosts = np.ascontiguousarray(gdist.localize_slab(A), dtype=np.int32)
+        ng = int(ghosts.size)
+        own = np.where(ghosts < part[r], ghosts - part[r] + nloc, ghosts - part[r + 1]).astype(np.int32)   # halo row -> an own row
+        assert own.min() >= 0 and own.max() < nloc
+        mat = C.c_void_p(g.gcge_hip_mat_create_local_ghosts(nloc, A.ncols, n, part[r], A.rowptr, A.colidx, A.val, ghosts.ctypes.data_as(ip_)))
+        peer, scnt, rcnt = (C.c_int * 2)(0, 0), (C.c_int * 2)(0, ng), (C.c_int * 2)(0, ng)
+        assert g.gcge_hip_mat_set_halo_rccl(mat, n, 2, peer, scnt, rcnt, np.ascontiguousarray(own).ctypes.data_as(ip_), 64) == 0
+        assert g.gcge_hip_mat_spmm_form(mat).decode().startswith("spmm_star+spmm_dense"), g.gcge_hip_mat_spmm_form(mat).decode()
+        x = be.mv_from_numpy(mat, np.ones((nloc, 16)))
+        y = be.ops.mv_create(16, mat)
+        p0, s0 = C.c_long(), C.c_long(); g.gcge_hip_star_product_stats(C.byref(p0), C.byref(s0))
+        be.ops.spmm(mat, x, y, (0, 0), (16, 16))
+        p1, s1 = C.c_long(), C.c_long(); g.gcge_hip_star_product_stats(C.byref(p1), C.byref(s1))
+        assert s1.value == s0.value + 1, "the product did not sweep its inner planes while the halo travelled"
+        got = be.mv_to_numpy(y, nloc, 0, 16)
+        err = float(np.max(np.abs(got[:, 0] - rowsum) / absum))
+        assert err < 1e-13 and np.array_equal(got[:, 0], got[:, 15]), (r, err)
+        be.ops.mv_destroy(x, 16); be.ops.mv_destroy(y, 16)
+        be.free_matrix(mat)
+        print("slab %d: %d rows, %d halo rows, row sums to %.1e" % (r, nloc, ng, err), flush=True)
+    comm.finalize()
+    print("rccl loop-back ok: full-size slabs of the %d^3 matrix, row sums of every row through the sweep with looped-back halo planes" % G)
+
+
 def main():
     if len(sys.argv) > 2 and sys.argv[2] == "native_star":
         return star_loopback(int(sys.argv[1]))
+    if len(sys.argv) > 2 and sys.argv[2] == "native_star_full":
+        return star_loopback_full_size(int(sys.argv[1]), int(sys.argv[3]) if len(sys.argv) > 3 else 2000)
     dims = tuple(int(t) for t in (sys.argv[1] if len(sys.argv) > 1 else "8,8,10").split(","))
     native = len(sys.argv) > 2 and sys.argv[2] == "native"
     os.environ["GCGE_COMM_KEEP_SINGLE"] = "1"      # a world of one rank: keep the all-reduces on the transport

@@ -110,6 +110,17 @@ def test_rccl_native_loopback_star_sweep_on_a_slab(G):
 
 
 @pytest.mark.gpu
+def test_rccl_native_loopback_star_sweep_full_size_row_sums():
+    """BASELINE config 5's matrix at full size (171^3, K = 2000), both slabs of a two-way plane-aligned cut, halo looped back over
+    RCCL from C, the interior swept while it travels: every row of A 1 against the row sums of the host arrays."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_loopback_worker.py"), "171", "native_star_full", "2000"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0 and "rccl loop-back ok" in p.stdout, p.stdout[-3000:]
+    print(p.stdout[-400:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dims", ["8,8,10", "32,32,40"])
 def test_rccl_loopback_one_gpu(dims):
     """The production transport (backend nccl == RCCL) on device buffers, one rank exchanging its halo with itself:
