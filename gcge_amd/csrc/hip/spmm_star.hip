@@ -280,6 +280,194 @@ __global__ __launch_bounds__(1024) void spmm_star2_kernel(int nx, int ny, int zs
 #undef own
 #undef own_m
 
+// ---------------------------------------------------------------------------------------------- the sweep, third form
+// 16-column passes (128-byte pieces of the rows: the full rate of the memory system, tools/seg_bench.hip) on a 16 x 8 patch, with
+// what the second form could not afford in registers: TWO planes of prefetch.  The halo strips of plane z + 2 come by LDS-DMA
+// (global_load_lds_dwordx4: no register is involved) into a ring of two strip buffers while plane z is computed; at the start of
+// step z every thread copies its three units of ring slot z & 1 into the plane image (masking what must read as zero) next to
+// its own value from the queue; the own point of plane z + 8 is requested at step z into a 15-slot register queue.  One plane
+// image, two barriers per plane (barriers and LDS traffic are free here: profiles/r04_star/06_...).
+// The DMA pieces and the compiler's own loads share the in-order vmcnt queue.  Hand-written waits count the MINIMUM number of
+// operations issued since (a result store may be skipped by a wave: the stricter count is the safe one); hipcc's waits for its
+// loads do not know the DMA pieces and so wait for MORE than they need — harmless as long as every load hipcc waits for was
+// issued at least two steps before its use (the queue, the diagonal two planes ahead): the newest operations it then still
+// allows in flight cover the pieces issued in the current step.  No spill may exist in this kernel (a scratch access is a
+// vector-memory operation hipcc waits for at once).
+constexpr int STAR3_Q = 15;
+constexpr int STAR3_TY = 8, STAR3_LPP = 8;
+constexpr int STAR3_ROWS = STAR3_TY + 2 * STAR_R;                           // 20 image rows
+constexpr int STAR3_IMG = STAR3_ROWS * STAR_PW * STAR3_LPP;                 // v2d entries of the plane image (71 680 B)
+constexpr int STAR3_HPTS = 2 * STAR_R * STAR3_TY + 2 * STAR_R * STAR_T;     // 288 halo points per plane
+constexpr int STAR3_RING = STAR3_HPTS * STAR3_LPP;                          // v2d entries of one strip buffer (36 864 B)
+constexpr int STAR3_PIECES = STAR3_RING / 64;                               // 36 pieces of 64 lanes x 16 B
+constexpr unsigned STAR3_LDS = (STAR3_IMG + 2 * STAR3_RING) * 16;           // 145 408 B
+#define S3SLOT(U, k) (((U) + (k) + STAR_R + 2 * STAR3_Q) % STAR3_Q)
+__device__ __forceinline__ void star3_dma(const char* base, unsigned voff, unsigned lds_dst) {   // one piece: lane l -> lds_dst + 16 l
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void star3_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+template <bool DOT, bool SLAB>
+__global__ __launch_bounds__(1024) void spmm_star3_kernel(int nx, int ny, int zs, int ze, int zmin, int zmax, long dlo, long dhi, StarCoef cf,
+    const double* __restrict__ diag, const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols,
+    int zlo, int zhi, int zlen, int ntx, double* __restrict__ partial, const unsigned char* __restrict__ cleanf) {
+  constexpr int LPP = STAR3_LPP, TY = STAR3_TY, SIDE = 2 * STAR_R * TY;
+  extern __shared__ __align__(16) unsigned char star3_smem[];
+  v2d* img = reinterpret_cast<v2d*>(star3_smem);                       // img[(row * 28 + col) * 8 + part]
+  v2d* ring = img + STAR3_IMG;                                          // ring[slot][piece][lane]
+  const unsigned ring0 = (unsigned)(uintptr_t)ring;                     // LDS byte address of the ring
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int part = tid % LPP, px = (tid / LPP) & 15, py = tid / (16 * LPP);
+  const int tile_x = blockIdx.x % ntx, tile_y = blockIdx.x / ntx;
+  const int x0 = tile_x * STAR_T, y0 = tile_y * TY;
+  const int z0 = zlo + blockIdx.y * zlen, z1 = min(zhi, z0 + zlen);
+  const int c0 = 2 * LPP * blockIdx.z;
+  const long plane_rows = (long)nx * ny;
+  auto plane_row0 = [&](int zz) -> long { return plane_rows * zz + (SLAB ? (zz < zs ? dlo : zz >= ze ? dhi : 0L) : 0L); };
+  const int gx = x0 + px, gy = y0 + py;
+  const bool cvalid = c0 + 2 * part < ncols;
+  const int col = cvalid ? c0 + 2 * part : c0;
+  const bool inside = gx < nx && gy < ny && cvalid;
+  const int own_i = inside ? gx + nx * gy : -1;
+#define own ((long)max(own_i, 0))
+#define own_m (~(unsigned long long)(long)(own_i >> 31))
+  const int slot = ((py + STAR_R) * STAR_PW + (px + STAR_R)) * LPP + part;
+  // my three halo units: piece wave + 16 j (the pieces past the 36th repeat earlier ones: every wave issues exactly three, so the
+  // hand-counted waits hold for all of them), lane = my lane: unit u = piece * 64 + lane, point u / 8, part u % 8
+  unsigned hoff[3], hlds[3]; int hdst[3]; unsigned hvalid = 0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    int piece = wave + 16 * j; if (piece >= STAR3_PIECES) piece -= STAR3_PIECES;
+    const int u = piece * 64 + lane, pt = u / LPP, hp = u % LPP;
+    int xx, yy;
+    if (pt < SIDE) { const int ry = pt / 12, a = pt % 12; yy = ry; xx = a < 6 ? a - 6 : 10 + a; }
+    else { const int jj = pt - SIDE, d = jj >> 4; xx = jj & 15; yy = d < 6 ? d - 6 : TY - 6 + d; }
+    const int ax = x0 + xx, ay = y0 + yy;
+    const bool hc = c0 + 2 * hp < ncols;
+    const bool ok = ax >= 0 && ax < nx && ay >= 0 && ay < ny && hc;
+    hdst[j] = ((yy + STAR_R) * STAR_PW + (xx + STAR_R)) * LPP + hp;
+    const long inplane = ok ? (long)ax + (long)nx * ay : 0;
+    hoff[j] = (unsigned)((inplane * (long)ldx + (hc ? c0 + 2 * hp : c0)) * 8);   // byte offset inside a plane of X (< 4 GB: checked on the host)
+    hlds[j] = (unsigned)(piece * 1024);                                            // piece base inside a strip buffer (wave-uniform)
+    if (ok) hvalid |= 1u << j;
+  }
+  auto zmask = [&](int zz) -> unsigned long long { return (zz >= zmin && zz < zmax) ? ~0ull : 0ull; };
+  auto ld_own = [&](int zz) -> v2d {
+    const int zc = min(max(zz, zmin), zmax - 1);
+    return star2_and(star_ld(x, ldx, own + plane_row0(zc), col), own_m & zmask(zz));
+  };
+  auto ld_diag = [&](int zz) -> double {
+    const int zc = min(max(zz, z0), max(z1 - 1, z0));
+    const unsigned long long m = (zz < z1 ? ~0ull : 0ull) & own_m;
+    unsigned long long b = __builtin_bit_cast(unsigned long long, diag[own + plane_rows * zc]);
+    b = (b & m) | (0x7ff8000000000000ull & ~m);
+    return __builtin_bit_cast(double, b);
+  };
+  auto ld_clean = [&](int zz) -> int { return DOT ? (int)cleanf[own + plane_rows * min(max(zz, z0), max(z1 - 1, z0))] : 1; };
+  // the three pieces of plane zz into strip buffer `sl` (clamped plane: what must be zero is masked at the copy)
+  auto dma_plane = [&](int zz, int sl) {
+    const int zc = min(max(zz, zmin), zmax - 1);
+    const char* base = reinterpret_cast<const char*>(x + (size_t)plane_row0(zc) * ldx);
+    const unsigned dst = ring0 + (unsigned)sl * (STAR3_RING * 16);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) star3_dma(base, hoff[j], dst + __builtin_amdgcn_readfirstlane(hlds[j]));
+  };
+  // strip buffer `sl` (plane zz) -> plane image
+  auto copy_strips = [&](int zz, int sl) {
+    const unsigned long long zm = zmask(zz);
+    const v2d* src = ring + sl * STAR3_RING;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const v2d v = src[(hlds[j] >> 4) + lane];
+      img[hdst[j]] = star2_and(v, zm & (((hvalid >> j) & 1u) ? ~0ull : 0ull));
+    }
+  };
+  // ---- prologue: planes z0 - 6 .. z0 + 7 into slots 0 .. 13 (z0 + 7 is first used at step 1); strips of z0, z0 + 1 by DMA
+  v2d qv[STAR3_Q];
+#pragma unroll
+  for (int t = 0; t < STAR3_Q - 1; ++t) qv[t] = ld_own(z0 - STAR_R + t);
+  qv[STAR3_Q - 1] = v2d{0.0, 0.0};
+  dma_plane(z0, 0);
+  dma_plane(z0 + 1, 1);
+  // the diagonal (NaN: none) and the clean flag of my point: three slots, plane z + k in slot (U + k) % 3 — renamed by the
+  // unrolling like the queue (a register MOVE of a value requested in this step would make hipcc wait for it in this step)
+  double dg3[3]; int cl3[3];
+  dg3[0] = ld_diag(z0); dg3[1] = ld_diag(z0 + 1); dg3[2] = 0.0;
+  cl3[0] = ld_clean(z0); cl3[1] = ld_clean(z0 + 1); cl3[2] = 0;
+  v2d spw = v2d{0.0, 0.0}, sww = v2d{0.0, 0.0};
+  star3_vmwait<0>();
+  __syncthreads();
+
+  for (int zb = z0; zb < z1; zb += STAR3_Q) {
+#define STAR3_STEP(U)                                                                                                       \
+    {                                                                                                                       \
+      const int z = zb + (U);                                                                                               \
+      if (z >= z1) break;                                                                                                   \
+      const int sl = (z - z0) & 1;                                                                                          \
+      /* the strips of plane z have landed: issued two steps ago; since then at least 2 + 3 + 2 operations (own request,      \
+         diagonal [, clean flag], the next plane's three pieces, and again) */                                              \
+      if ((U) == 0 && zb == z0) { /* (the prologue waited for everything) */ }                                              \
+      else star3_vmwait<DOT ? 9 : 7>();                                                                                     \
+      copy_strips(z, sl);                                                                                                   \
+      img[slot] = qv[S3SLOT(U, 0)];                                                                                         \
+      __syncthreads();                                   /* B: the image of plane z is complete, strip buffer sl is free */ \
+      dma_plane(z + 2, sl);                                                                                                 \
+      qv[S3SLOT(U, STAR_R + 2)] = ld_own(z + STAR_R + 2);      /* first used at step z + 2 */                               \
+      dg3[((U) + 2) % 3] = ld_diag(z + 2);                                                                                  \
+      cl3[((U) + 2) % 3] = ld_clean(z + 2);                                                                                 \
+      const double dg = dg3[(U) % 3];                                                                                       \
+      const int cl = cl3[(U) % 3];                                                                                          \
+      const double d0 = dg == dg ? dg : 0.0;                                                                                \
+      v2d acc = qv[S3SLOT(U, 0)] * d0;                                                                                      \
+      const v2d* pl = img + slot;                                                                                           \
+      _Pragma("unroll") for (int k = 1; k <= STAR_R; ++k) {                                                                 \
+        const v2d zsum = qv[S3SLOT(U, -k)] + qv[S3SLOT(U, k)];                                                              \
+        const v2d xsum = pl[-LPP * k] + pl[LPP * k];                                                                        \
+        const v2d ysum = pl[-LPP * k * STAR_PW] + pl[LPP * k * STAR_PW];                                                    \
+        const v2d s6 = (zsum + xsum) + ysum;                                                                                \
+        acc.x = fma(cf.cz[k], s6.x, acc.x); acc.y = fma(cf.cz[k], s6.y, acc.y);                                              \
+      }                                                                                                                     \
+      if (dg == dg) {                                                                                                       \
+        __builtin_nontemporal_store(acc, reinterpret_cast<v2d*>(y + (size_t)(own + plane_rows * z) * ldy + col));           \
+        if (DOT && cl != 0) {                                                                                               \
+          const v2d xc = qv[S3SLOT(U, 0)];                                                                                  \
+          spw.x = fma(xc.x, acc.x, spw.x); spw.y = fma(xc.y, acc.y, spw.y);                                                  \
+          sww.x = fma(acc.x, acc.x, sww.x); sww.y = fma(acc.y, acc.y, sww.y);                                                \
+        }                                                                                                                   \
+      }                                                                                                                     \
+      __syncthreads();                                   /* A: everybody has read the image of plane z */                   \
+    }
+    STAR3_STEP(0) STAR3_STEP(1) STAR3_STEP(2) STAR3_STEP(3) STAR3_STEP(4) STAR3_STEP(5) STAR3_STEP(6) STAR3_STEP(7)
+    STAR3_STEP(8) STAR3_STEP(9) STAR3_STEP(10) STAR3_STEP(11) STAR3_STEP(12) STAR3_STEP(13) STAR3_STEP(14)
+#undef STAR3_STEP
+  }
+  star3_vmwait<0>();                                     // no piece may land after the block has released its LDS
+  if (DOT) {
+    __syncthreads();
+    img[tid] = spw; img[1024 + tid] = sww;
+    __syncthreads();
+    const int pidx = tid / LPP;
+    for (int h = 512 / LPP; h > 0; h >>= 1) {
+      if (pidx < h) {
+        const v2d a = img[tid + LPP * h], b = img[1024 + tid + LPP * h];
+        img[tid].x += a.x; img[tid].y += a.y; img[1024 + tid].x += b.x; img[1024 + tid].y += b.y;
+      }
+      __syncthreads();
+    }
+    if (pidx == 0 && cvalid) {
+      double* out = partial + ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 2 * ncols;
+      out[col] = img[tid].x; out[col + 1] = img[tid].y;
+      out[ncols + col] = img[1024 + tid].x; out[ncols + col + 1] = img[1024 + tid].y;
+    }
+  }
+}
+#undef S3SLOT
+#undef own
+#undef own_m
+
 // partial[b * 2 m + j] = sum over the block's listed rows of x[r, j] y[r, j]; at + m: of y[r, j]^2 (rows = list[i]); 256 threads =
 // 4 row lanes x 64 columns, as coldots2_partial of vec_kernels.hip
 __global__ __launch_bounds__(256) void star_coldots2_rows(int nlist, const int* __restrict__ list, const double* __restrict__ x, size_t ldx,
@@ -549,6 +737,8 @@ static bool star_build_host(const StarRows& M, StarHost* H) {
 using namespace gcge;
 
 static int g_star_mode = 0;   // 0 automatic, -1 never
+static int g_star_form = 3;   // 2: second form of the sweep (registers stage the halo strips), 3: third form (LDS-DMA strips, 16-column passes)
+extern "C" void gcge_hip_spmm_star_form(int form) { g_star_form = form == 3 ? 3 : 2; }
 static int g_star_lpp = 4;    // second form: 8 = 16-column passes on 16 x 8 patches (128-byte pieces of the rows), 4 = 8 columns on 16 x 16 (64-byte pieces)
 extern "C" void gcge_hip_spmm_star_lanes(int lpp) { g_star_lpp = lpp == 4 ? 4 : 8; }
 static int g_star_dbg = 0;    // measurement only: 1 no halo loads, 2 no LDS arm reads, 4 no stores, 8 no own-plane loads (results are wrong then)
@@ -743,7 +933,9 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
   const bool slab = g.zmin < g.zs || g.ze < g.zmax, iso = S->iso;
   // 8 lanes per point = 16-column passes on 16 x 8 patches, 4 = 8-column passes on 16 x 16 patches (see the kernel)
   const bool mapped = S->d_map != nullptr;
-  const int lpp = (!iso || mapped || g_star_lpp == 4) ? 4 : 8;   // (per-axis coefficients / masked grids: the 8-column form, which needs fewer registers)
+  // third form (LDS-DMA strips, two planes of prefetch): one coefficient set, every grid point a row, lane offsets of a plane in 32 bits
+  const bool third = g_star_form == 3 && iso && !mapped && (double)g.nx * g.ny * (double)ldx * 8.0 < 4.0e9;
+  const int lpp = third ? 8 : (!iso || mapped || g_star_lpp == 4) ? 4 : 8;   // (per-axis coefficients / masked grids: the 8-column form, which needs fewer registers)
   const int ty = 64 / lpp;
   const int ntx = (g.nx + STAR_T - 1) / STAR_T, nty = (g.ny + ty - 1) / ty, npass = (ncols + 2 * lpp - 1) / (2 * lpp);
   // z ranges: ONE where the patches x passes already give every CU two workgroups' worth of work (each range re-reads 12 planes
@@ -768,6 +960,24 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
   if (g_star_dbg != 0 && part == nullptr && iso && lpp == 8 && !slab)
     switch (g_star_dbg) { STAR_DBG(1) STAR_DBG(2) STAR_DBG(8) STAR_DBG(3) STAR_DBG(9) STAR_DBG(16) default: break; }
   const bool dot = part != nullptr;
+  if (third) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      bool ok = true;
+      ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_star3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STAR3_LDS) == hipSuccess;
+      ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_star3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STAR3_LDS) == hipSuccess;
+      ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_star3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STAR3_LDS) == hipSuccess;
+      ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_star3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STAR3_LDS) == hipSuccess;
+      if (!ok) { (void)hipGetLastError(); fprintf(stderr, "gcge_hip: %u bytes of LDS refused for the third form of the sweep\n", STAR3_LDS); abort(); }
+      attr_set = true;
+    }
+#define STAR_LAUNCH3(DOT, SLAB) hipLaunchKernelGGL((spmm_star3_kernel<DOT, SLAB>), grid, dim3(1024), STAR3_LDS, stream, g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax, \
+                                                   dlo, dhi, S->c, dv, xv, (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part, cv)
+    if (dot) { if (slab) STAR_LAUNCH3(true, true); else STAR_LAUNCH3(true, false); }
+    else     { if (slab) STAR_LAUNCH3(false, true); else STAR_LAUNCH3(false, false); }
+#undef STAR_LAUNCH3
+    return nb;
+  }
   if (mapped) {          // masked grid: one rank, one coefficient set (checked at upload)
     if (dot) hipLaunchKernelGGL((spmm_star2_kernel<true, true, false, 4, 0, true>), grid, dim3(1024), 0, stream, STAR_ARGS);
     else     hipLaunchKernelGGL((spmm_star2_kernel<false, true, false, 4, 0, true>), grid, dim3(1024), 0, stream, STAR_ARGS);

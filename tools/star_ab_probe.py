@@ -10,6 +10,7 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 354
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 hip = HipBackend(); g = hip.g
 g.gcge_hip_spmm_star_lanes.argtypes = [C.c_int]
+g.gcge_hip_spmm_star_form.argtypes = [C.c_int]
 g.gcge_hip_profile_enable.argtypes = [C.c_int]
 g.gcge_hip_profile_spmm.restype = C.c_long
 g.gcge_hip_profile_spmm.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -26,9 +27,10 @@ if g.gcge_hip_mat_form_stats(mA, st):
 hip.set_random_mode(1, 7)
 ops = hip.ops
 V = ops.mv_create(m, mA); ops.set_random(V, 0, m)
-W = {2: ops.mv_create(m, mA), 3: ops.mv_create(m, mA)}
-for which in (2, 3, 2, 3):
+W = {2: ops.mv_create(m, mA), 3: ops.mv_create(m, mA), 4: ops.mv_create(m, mA)}
+for which in (2, 3, 4, 2, 3, 4):
     g.gcge_hip_spmm_star_lanes(4 if which == 2 else 8)           # 2: 8-column passes on 16 x 16 patches; 3: 16-column passes on 16 x 8 patches
+    g.gcge_hip_spmm_star_form(3 if which == 4 else 2)            # 4: third form (LDS-DMA strips)
     ops.spmm(mA, V, W[which], (0, 0), (m, m)); hip.sync()
     g.gcge_hip_profile_enable(1)
     for _ in range(6):
@@ -48,6 +50,9 @@ for which in (2, 3, 2, 3):
     print("form %d: product %.3f ms = %.1f %% of 8 TB/s on the CSR bytes; with column sums %.3f ms" % (which, t, by.value / cnt / t * 1e-6 / 80, ms2.value / cnt2), flush=True)
 a = hip.mv_to_numpy(W[2], A.nrows, 0, m); b = hip.mv_to_numpy(W[3], A.nrows, 0, m)
 print("max |16-column form - 8-column form| / max =", float(np.max(np.abs(a - b)) / np.max(np.abs(a))))
+b = hip.mv_to_numpy(W[4], A.nrows, 0, m)
+print("max |third form - 8-column form| / max =", float(np.max(np.abs(a - b)) / np.max(np.abs(a))))
+g.gcge_hip_spmm_star_form(2)
 g.gcge_hip_set_spmm_path.argtypes = [C.c_int]
 g.gcge_hip_set_spmm_path(3)
 ops.spmm(mA, V, W[3], (0, 0), (m, m))
