@@ -1,0 +1,56 @@
+"""CPU (needs hipcc, no GPU): the third form of the plane sweep (spmm_star.hip: spmm_star3_kernel) mixes LDS-DMA pieces issued from
+inline asm with loads and stores hipcc manages, all on ONE in-order vmcnt queue; its hand-written `s_waitcnt vmcnt(N)` before the
+strips of plane z are copied assumes a MINIMUM number of operations issued since those strips were requested two steps earlier
+(DESIGN.md §3): per step three DMA pieces, the request of the own point, the diagonal (and the clean flag with column sums), and at
+most one result store.  The disassembly is checked step by step, so that a compiler that reorders, duplicates or drops one of
+these — or spills a register to scratch, which is a vector-memory operation it would wait for at once — fails here and not as a
+wrong product on the GPU."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP = os.path.join(ROOT, "gcge_amd", "csrc", "hip")
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_hand_counted_waits_of_the_dma_sweep_match_the_disassembly(tmp_path):
+    out = str(tmp_path / "spmm_star.s")
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + HIP, "-S",
+                    "--cuda-device-only", os.path.join(HIP, "spmm_star.hip"), "-o", out], check=True, capture_output=True)
+    kernels, name = {}, None
+    for line in open(out):
+        m = re.match(r"^(_ZN4gcge17spmm_star3_kernelILb([01])ELb([01])E\w*):", line)
+        if m:
+            name = m.group(1); kernels[name] = {"dot": m.group(2) == "1", "code": []}
+            continue
+        if name and line.startswith(".Lfunc_end"):
+            name = None
+        elif name:
+            code = line.split(";")[0].strip()
+            if code and not code.startswith("."):
+                kernels[name]["code"].append(code)
+    assert len(kernels) == 4, list(kernels)
+    for name, k in kernels.items():
+        want = 9 if k["dot"] else 7
+        code = k["code"]
+        assert not any("scratch_" in c for c in code), name + ": a register was spilled to scratch"
+        # the steady-state steps: from one hand-written wait to the next
+        marks = [i for i, c in enumerate(code) if c == "s_waitcnt vmcnt(%d)" % want]
+        assert len(marks) >= 14, (name, len(marks))
+        for a, b in zip(marks, marks[1:]):
+            step = code[a:b]
+            dma = sum(c.startswith("global_load_lds_dwordx4") for c in step)
+            loads = sum(bool(re.match(r"global_load_(dwordx4|dwordx2|ubyte|dword)\b", c)) for c in step)
+            stores = sum(c.startswith("global_store") for c in step)
+            if dma == 0:        # (the stretch between the last step of the unrolled body and the loop head / epilogue)
+                continue
+            assert dma == 3, (name, "pieces per step", dma)
+            assert loads == (3 if k["dot"] else 2), (name, "compiler loads per step", loads, [c for c in step if c.startswith("global_load")])
+            assert stores <= 1, (name, "stores per step", stores)
+            # two steps' worth of operations behind the strips being waited for: 2 x (3 pieces + loads) - 3 = loads + 3 + loads
+            assert 2 * loads + 3 == want, (name, loads, want)
+        assert code.count("s_waitcnt vmcnt(0)") >= 2, name          # prologue and the drain before the block releases its LDS
