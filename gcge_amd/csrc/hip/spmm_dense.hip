@@ -86,34 +86,48 @@ __global__ __launch_bounds__(256) void spmm_dense_kernel(
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int cf = 0; cf < 4; ++cf) acc[f][cf] = v4d{0.0, 0.0, 0.0, 0.0};
-    double a0[2], b0[4], a1[2], b1[4];
-    auto load = [&](double (&a)[2], double (&b)[4], int g, int col) {
-      a[0] = vp[(size_t)g * 128]; a[1] = vp[(size_t)g * 128 + 64];
+    // FOUR register sets, the loads three column groups ahead of the MFMAs that use them: the block values stream from HBM
+    // (read once, 1.7 GB on the SiO2-like matrix) and only two waves fit a SIMD (64 accumulator registers), so with ONE group of
+    // lookahead every group waited most of a memory round trip behind 8 MFMAs (0.72 ms = 37 TF; the gathers of the X rows are not
+    // what it waits for: profiles/r04_star/README.md).  ng is even (padded at upload); groups past the end are clamped re-reads
+    // whose MFMAs are skipped.
+    double a[4][2], b[4][4];
+    auto load = [&](double (&av)[2], double (&bv)[4], int g, int col) {
+      av[0] = vp[(size_t)g * 128]; av[1] = vp[(size_t)g * 128 + 64];
 #pragma unroll
-      for (int cf = 0; cf < 4; ++cf) b[cf] = xc[cf][(size_t)col * ldx];
+      for (int cf = 0; cf < 4; ++cf) bv[cf] = xc[cf][(size_t)col * ldx];
     };
-    auto mfma = [&](const double (&a)[2], const double (&b)[4]) {
+    auto mfma = [&](const double (&av)[2], const double (&bv)[4]) {
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int cf = 0; cf < 4; ++cf) acc[f][cf] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[f], b[cf], acc[f][cf], 0, 0, 0);
+        for (int cf = 0; cf < 4; ++cf) acc[f][cf] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[f], bv[cf], acc[f][cf], 0, 0, 0);
     };
-    // two register sets, column indices two groups ahead; ng is even (padded at upload), loads beyond the end are
-    // clamped re-reads whose results are never used
-    int colA = cp[0], colB = cp[4 * min(1, ng - 1)];
-    load(a0, b0, 0, colA);
-    colA = cp[4 * min(2, ng - 1)];
-    for (int g = 0; g < ng; g += 2) {
-      load(a1, b1, g + 1, colB);
-      colB = cp[4 * min(g + 3, ng - 1)];
+    auto colof = [&](int g) { return cp[4 * min(g, ng - 1)]; };
+    // column indices a whole round (four groups) ahead of the gathers that use them
+    load(a[0], b[0], 0, cp[0]);
+    load(a[1], b[1], min(1, ng - 1), colof(1));
+    load(a[2], b[2], min(2, ng - 1), colof(2));
+    int cA = colof(3), cB = colof(4), cC = colof(5), cD = colof(6);
+    for (int g = 0; g < ng; g += 4) {
+      const int nA = colof(g + 7), nB = colof(g + 8), nC = colof(g + 9), nD = colof(g + 10);
+      load(a[3], b[3], min(g + 3, ng - 1), cA);
       __builtin_amdgcn_sched_barrier(0);
-      mfma(a0, b0);
+      mfma(a[0], b[0]);
       __builtin_amdgcn_sched_barrier(0);
-      load(a0, b0, min(g + 2, ng - 1), colA);
-      colA = cp[4 * min(g + 4, ng - 1)];
+      load(a[0], b[0], min(g + 4, ng - 1), cB);
       __builtin_amdgcn_sched_barrier(0);
-      mfma(a1, b1);
+      mfma(a[1], b[1]);
       __builtin_amdgcn_sched_barrier(0);
+      load(a[1], b[1], min(g + 5, ng - 1), cC);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 2 < ng) mfma(a[2], b[2]);
+      __builtin_amdgcn_sched_barrier(0);
+      load(a[2], b[2], min(g + 6, ng - 1), cD);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 2 < ng) mfma(a[3], b[3]);
+      __builtin_amdgcn_sched_barrier(0);
+      cA = nA; cB = nB; cC = nC; cD = nD;
     }
     // Y[R] += block: every row belongs to one block only and the remainder kernel has finished (stream order)
 #pragma unroll
