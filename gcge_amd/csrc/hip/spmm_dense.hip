@@ -62,7 +62,9 @@ struct DenseHost {
 //   A fragment (values): lane l holds D[row 16 f + (l & 15)][column 4 g + (l >> 4)]   — stored in exactly this order
 //   B fragment (X rows): lane l holds X[C[4 g + (l >> 4)]][c0 + 16 cf + (l & 15)]
 //   accumulators:        lane l, register t of tile (f, cf): row 16 f + 4 t + (l >> 4), column c0 + 16 cf + (l & 15)
-__global__ __launch_bounds__(256) void spmm_dense_kernel(
+//   FULL: m is a multiple of 64 — the four column fragments of a gather are one address plus immediate offsets.
+template <bool FULL>
+__global__ __launch_bounds__(256, FULL ? 3 : 2) void spmm_dense_kernel(
     const DenseItem* __restrict__ items, int nitems, const DenseSn* __restrict__ sns, const int* __restrict__ rows,
     const int* __restrict__ cols, const double* __restrict__ vals, const double* __restrict__ x, size_t ldx,
     double* __restrict__ y, size_t ldy, int m) {
@@ -78,9 +80,10 @@ __global__ __launch_bounds__(256) void spmm_dense_kernel(
   const int* __restrict__ cp = cols + S.col_off + kk;
   const int* __restrict__ rp = rows + S.row_off + 32 * it.block;
   for (int c0 = 0; c0 < m; c0 += 64) {
-    const double* xc[4];
+    const double* __restrict__ xb = x + c0 + li;
+    int xo[4];
 #pragma unroll
-    for (int cf = 0; cf < 4; ++cf) { const int c = c0 + 16 * cf + li; xc[cf] = x + (c < m ? c : 0); }
+    for (int cf = 0; cf < 4; ++cf) xo[cf] = FULL || c0 + 16 * cf + li < m ? 16 * cf : -(c0 + li);
     v4d acc[2][4];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
@@ -94,8 +97,9 @@ __global__ __launch_bounds__(256) void spmm_dense_kernel(
     double a[4][2], b[4][4];
     auto load = [&](double (&av)[2], double (&bv)[4], int g, int col) {
       av[0] = vp[(size_t)g * 128]; av[1] = vp[(size_t)g * 128 + 64];
+      const double* __restrict__ xr = xb + (size_t)col * ldx;
 #pragma unroll
-      for (int cf = 0; cf < 4; ++cf) bv[cf] = xc[cf][(size_t)col * ldx];
+      for (int cf = 0; cf < 4; ++cf) bv[cf] = FULL ? xr[16 * cf] : xr[xo[cf]];
     };
     auto mfma = [&](const double (&av)[2], const double (&bv)[4]) {
 #pragma unroll
@@ -386,7 +390,7 @@ extern "C" int gcge_hip_dense_spmm(const void* dm, const double* d_x, long ldx, 
     if (rc != 0) return rc;
   }
   if (which != 1 && D->nitems > 0)
-    hipLaunchKernelGGL(spmm_dense_kernel, dim3((unsigned)((D->nitems + 3) / 4)), dim3(256), 0, (hipStream_t)stream, D->d_items, D->nitems,
+    hipLaunchKernelGGL((ncols % 64 == 0 ? spmm_dense_kernel<true> : spmm_dense_kernel<false>), dim3((unsigned)((D->nitems + 3) / 4)), dim3(256), 0, (hipStream_t)stream, D->d_items, D->nitems,
                        D->d_sn, D->d_rows, D->d_cols, D->d_vals, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols);
   return (int)hipGetLastError();
 }
