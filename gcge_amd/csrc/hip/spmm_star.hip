@@ -500,6 +500,7 @@ struct StarHost {
   std::vector<double> diag;                                           // NaN: row stays in the remainder
   std::vector<char> clean;                                            // 1: star row
   std::vector<int> inv;                                               // masked domains: grid point -> row (-1: none)
+  std::vector<int> own_box;                                           // masked domains whose geometry was recovered here (star_infer_box)
   std::vector<int> rem_rowptr, rem_col; std::vector<double> rem_val;  // every entry of the rows that are not clean (local columns)
 };
 
@@ -732,11 +733,128 @@ static bool star_build_host(const StarRows& M, StarHost* H) {
   return true;
 }
 
+// Geometry of a MASKED grid recovered from the rows alone (one rank; a matrix that arrives as a file, e.g. Matrix Market, names
+// no grid): the rows are the points of a convex domain inside a box in scan order (x fastest), every row couples to its
+// neighbours along the three axes (a star of any arm length) and to anything else (atom blocks).  Then
+//   * rows r and r + 1 lie on one x LINE exactly when the entry (r, r + 1) is there;
+//   * consecutive lines l, l + 1 of one PLANE (y and y + 1) are coupled through the + y neighbours: every star row of l has ONE
+//     entry among the rows of l + 1, and all of them agree on the shift between where the two lines begin in x — the shift most
+//     rows vote for; lines without such a vote (the last line of a plane and the first of the next one share no neighbour) end a plane;
+//   * consecutive planes are coupled through the + z neighbours in the same way: a vote on the (x, y) shift between their frames.
+// Votes come from the rows that are no longer than the median row (the star rows), from all rows of a line only when none of
+// its rows is that short.  box[r] = x + nx (y + ny z) in the bounding box of what was found.  A wrong guess costs speed, never
+// the result: the split of star_build_host is exact for any one-to-one ascending map (the remainder takes every difference),
+// and the form is refused when fewer than half of the rows come out clean.  false: the rows do not look like this.
+static bool star_infer_box(int nrows, const int* rowptr, const int* colidx, std::vector<int>* box_, int* nx_, int* ny_, int* nz_) {
+  if (nrows < 2048) return false;
+  // lines
+  std::vector<int> lstart;                                             // first row of every line (+ nrows at the end)
+  std::vector<int> lineof((size_t)nrows);
+  long linked = 0;
+  lstart.push_back(0);
+  for (int r = 0; r < nrows; ++r) {
+    lineof[r] = (int)lstart.size() - 1;
+    if (r + 1 == nrows) break;
+    bool next = false;
+    for (int q = rowptr[r]; q < rowptr[r + 1] && !next; ++q) next = colidx[q] == r + 1;
+    if (next) ++linked; else lstart.push_back(r + 1);
+  }
+  const int nl = (int)lstart.size();
+  lstart.push_back(nrows);
+  if (2 * linked < nrows || nl < 16) return false;
+  // the median row length: rows up to it vote
+  int med;
+  {
+    std::vector<int> len((size_t)nrows);
+    for (int r = 0; r < nrows; ++r) len[r] = rowptr[r + 1] - rowptr[r];
+    std::nth_element(len.begin(), len.begin() + nrows / 2, len.end());
+    med = len[nrows / 2];
+  }
+  // planes: shift of line l + 1 against line l, or a break
+  std::vector<int> xoff((size_t)nl, 0), pstart;                        // x of a line's first row in its plane's frame; first line of every plane
+  std::vector<int> votes;
+  pstart.push_back(0);
+  for (int l = 0; l + 1 < nl; ++l) {
+    const int a0 = lstart[l], a1 = lstart[l + 1], b0 = a1, b1 = lstart[l + 2];
+    const int span = (a1 - a0) + (b1 - b0);
+    const int need = std::min(a1 - a0, b1 - b0);
+    int best = 0, bestn = 0;
+    // (the + y neighbour of a star row is its only entry in the next line: the vote of a true pair of lines is nearly unanimous;
+    //  pass 1 — every row of the line votes — where the short rows alone do not carry it)
+    for (int pass = 0; pass < 2 && 2 * bestn < need; ++pass) {
+      votes.assign((size_t)span + 1, 0);
+      for (int r = a0; r < a1; ++r) {
+        if (pass == 0 && rowptr[r + 1] - rowptr[r] > med) continue;
+        for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
+          const int c = colidx[q];
+          if (c >= b0 && c < b1) ++votes[(size_t)((r - a0) - (c - b0) + (b1 - b0))];
+        }
+      }
+      bestn = 0;
+      for (int k = 0; k <= span; ++k) if (votes[k] > bestn) { bestn = votes[k]; best = k - (b1 - b0); }
+    }
+    if (bestn > 0 && 2 * bestn >= need) xoff[l + 1] = xoff[l] + best;
+    else { pstart.push_back(l + 1); xoff[l + 1] = 0; }
+  }
+  const int np = (int)pstart.size();
+  pstart.push_back(nl);
+  if (getenv("GCGE_STAR_INFER_DEBUG")) fprintf(stderr, "star_infer_box: %d rows, %d lines, %d planes, median row %d\n", nrows, nl, np, med);
+  if (np < 2 * STAR_R + 2) return false;
+  // frames: (x, y) shift of plane p + 1 against plane p
+  std::vector<int> px((size_t)np, 0), py((size_t)np, 0);
+  std::unordered_map<long, int> pv;
+  for (int p = 0; p + 1 < np; ++p) {
+    const int r0 = lstart[pstart[p]], r1 = lstart[pstart[p + 1]], s1 = lstart[pstart[p + 2]];
+    const long need = std::min(r1 - r0, s1 - r1);
+    int bestn = 0; long bestk = 0;
+    for (int pass = 0; pass < 2 && 4L * bestn < need; ++pass) {
+      pv.clear();
+      for (int r = r0; r < r1; ++r) {
+        if (pass == 0 && rowptr[r + 1] - rowptr[r] > med) continue;
+        const int l = lineof[r], x = xoff[l] + (r - lstart[l]), y = l - pstart[p];
+        for (int q = rowptr[r]; q < rowptr[r + 1]; ++q) {
+          const int c = colidx[q];
+          if (c < r1 || c >= s1) continue;
+          const int lc = lineof[c], xc = xoff[lc] + (c - lstart[lc]), yc = lc - pstart[p + 1];
+          ++pv[(long)(x - xc + (1 << 20)) * (1L << 22) + (y - yc + (1 << 20))];
+        }
+      }
+      bestn = 0;
+      for (auto& kv : pv) if (kv.second > bestn) { bestn = kv.second; bestk = kv.first; }
+    }
+    if (getenv("GCGE_STAR_INFER_DEBUG")) fprintf(stderr, "plane %d rows %d..%d lines %d votes %d need %ld\n", p, r0, r1, pstart[p + 1] - pstart[p], bestn, need);
+    if (bestn == 0 || 4L * bestn < std::min(r1 - r0, s1 - r1)) return false;   // two planes that share no column of points: not such a domain
+    px[p + 1] = px[p] + (int)(bestk >> 22) - (1 << 20);
+    py[p + 1] = py[p] + (int)(bestk & ((1L << 22) - 1)) - (1 << 20);
+  }
+  // the bounding box
+  long xmin = 0, xmax = 0, ymin = 0, ymax = 0; bool first = true;
+  for (int p = 0; p < np; ++p)
+    for (int l = pstart[p]; l < pstart[p + 1]; ++l) {
+      const long x0 = (long)px[p] + xoff[l], x1 = x0 + (lstart[l + 1] - lstart[l]) - 1, y = (long)py[p] + (l - pstart[p]);
+      if (first) { xmin = x0; xmax = x1; ymin = ymax = y; first = false; }
+      xmin = std::min(xmin, x0); xmax = std::max(xmax, x1); ymin = std::min(ymin, y); ymax = std::max(ymax, y);
+    }
+  const long nx = xmax - xmin + 1, ny = ymax - ymin + 1, nz = np;
+  if (nx * ny * nz >= (1L << 31) || nx * ny * nz > 64L * nrows) return false;   // (a box far larger than the domain: the lines did not line up)
+  box_->resize((size_t)nrows);
+  for (int p = 0; p < np; ++p)
+    for (int l = pstart[p]; l < pstart[p + 1]; ++l) {
+      const long x0 = (long)px[p] + xoff[l] - xmin, y = (long)py[p] + (l - pstart[p]) - ymin;
+      for (int r = lstart[l]; r < lstart[l + 1]; ++r) (*box_)[r] = (int)(x0 + (r - lstart[l]) + nx * (y + ny * p));
+    }
+  for (int r = 1; r < nrows; ++r) if ((*box_)[r] <= (*box_)[r - 1]) return false;   // (scan order must have come out)
+  *nx_ = (int)nx; *ny_ = (int)ny; *nz_ = (int)nz;
+  return true;
+}
+
 }  // namespace gcge
 
 using namespace gcge;
 
 static int g_star_mode = 0;   // 0 automatic, -1 never
+static int g_star_infer = 1;  // 1: a matrix without a lexicographic grid is tried as a masked grid in scan order (star_infer_box)
+extern "C" void gcge_hip_spmm_star_infer(int on) { g_star_infer = on != 0; }
 static int g_star_form = 3;   // 2: second form of the sweep (registers stage the halo strips), 3: third form (LDS-DMA strips, 16-column passes)
 extern "C" void gcge_hip_spmm_star_form(int form) { g_star_form = form == 3 ? 3 : 2; }
 static int g_star_lpp = 4;    // second form: 8 = 16-column passes on 16 x 8 patches (128-byte pieces of the rows), 4 = 8 columns on 16 x 16 (64-byte pieces)
@@ -834,6 +952,15 @@ extern "C" long gcge_hip_star_selfcheck_grid(int nrows, const int* rowptr, const
   M.box = box_of_row; M.bnx = nx; M.bny = ny; M.bnz = nz;
   return star_selfcheck(M, out);
 }
+// The geometry star_infer_box recovers (host only; tests, tools): dims[0..2] = nx, ny, nz of the bounding box, box_of_row[r] = x + nx
+// (y + ny z).  1: found, 0: the rows are not the points of a masked grid in scan order.
+extern "C" int gcge_hip_star_infer_grid(int nrows, const int* rowptr, const int* colidx, int* dims, int* box_of_row) {
+  std::vector<int> box; int nx = 0, ny = 0, nz = 0;
+  if (!star_infer_box(nrows, rowptr, colidx, &box, &nx, &ny, &nz)) return 0;
+  dims[0] = nx; dims[1] = ny; dims[2] = nz;
+  memcpy(box_of_row, box.data(), (size_t)nrows * sizeof(int));
+  return 1;
+}
 extern "C" long gcge_hip_star_selfcheck(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, long* out) {
   if (ncols_local != nrows) return -1;
   long o[12];
@@ -871,7 +998,17 @@ extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin,
     }
     g_star_geom.box = nullptr;
   }
-  if (!star_build_host(M, H)) { delete H; return nullptr; }
+  bool ok = star_build_host(M, H);
+  if (!ok && M.box == nullptr && g_star_infer && ncols_local == nrows && row_begin == 0 && nglobal == nrows) {
+    // no lexicographic grid: the points of a masked one in scan order?  (the geometry recovered from the rows)
+    delete H; H = new StarHost();
+    int bx = 0, by = 0, bz = 0;
+    if (star_infer_box(nrows, rowptr, colidx, &H->own_box, &bx, &by, &bz)) {
+      M.box = H->own_box.data(); M.bnx = bx; M.bny = by; M.bnz = bz; M.nglobal = (long)bx * by * bz;
+      ok = star_build_host(M, H);
+    }
+  }
+  if (!ok) { delete H; return nullptr; }
   StarMat* S = new StarMat();
   S->d_map = nullptr; S->d_prange = nullptr;
   if (M.box != nullptr) {

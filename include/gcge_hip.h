@@ -50,6 +50,11 @@ GCGE_HIP_MAT *gcge_hip_mat_create_csr (const GCGE_CSR *A);
  * map); results are those of gcge_hip_mat_create on the same arrays.                                                          */
 GCGE_HIP_MAT *gcge_hip_mat_create_grid (int nrows, const int *rowptr, const int *colidx, const double *val,
 		int nx, int ny, int nz, const int *box_of_row);
+/* A matrix of that kind that names NO geometry (read from a file: gcge_load_matrix_market, gcge_load_petsc_binary) gets it
+ * recovered at upload by gcge_hip_mat_create itself: x lines from the (r, r + 1) couplings, planes and the shifts between
+ * lines / planes from the votes of the star rows' + y / + z neighbours.  A wrong guess costs speed, never the result (the
+ * remainder takes every difference); on = 0 switches the recovery off (measurements).                                         */
+void gcge_hip_spmm_star_infer (int on);
 /* Row-partitioned use (one process per GPU): localize the slab with gcge_dist_localize
  * (include/gcge_problems.h), create it with ncols_local = nrows + nghost, then install the halo
  * plan.  exchange(sendbuf, recvbuf, ncols, ctx) must deliver, for every peer, rows
@@ -206,6 +211,9 @@ long gcge_hip_star_selfcheck_slab (int nrows, int ncols_local, long row_begin, l
 /*     the same for a matrix on a masked grid (gcge_hip_mat_create_grid)                                                  */
 long gcge_hip_star_selfcheck_grid (int nrows, const int *rowptr, const int *colidx, const double *val, int nx, int ny, int nz,
 		const int *box_of_row, long *out);
+/*     the geometry gcge_hip_mat_create recovers for a matrix on a masked grid that names none (host only): dims[0..2] = nx, ny,
+ *     nz of the bounding box, box_of_row[r] = x + nx (y + ny z); 1 found, 0: the rows are no such domain in scan order    */
+int  gcge_hip_star_infer_grid (int nrows, const int *rowptr, const int *colidx, int *dims, int *box_of_row);
 /*     grid of a matrix whose rows are mostly one star stencil, from a slab of its rows with GLOBAL columns (host only;
  *     what a partitioner needs to cut on plane boundaries).  out[0..3] = nx, ny, nz, arm length; 1 found, 0 none         */
 int  gcge_hip_star_grid (int nrows, long row_begin, long nglobal, const int *rowptr, const int *colidx_global,

@@ -1308,8 +1308,9 @@ def test_star_sweep_on_a_masked_grid_vs_oracle(both, G, kw):
     """K1 on a MASKED grid: the SiO2-like operator on the ball inscribed in the box, rows = grid points inside in scan order (the
     layout of the PARSEC matrices behind BASELINE config 5).  With the geometry named (gcge_hip_mat_create_grid) the star rows
     take the plane sweep through a row map, the rest dense blocks + listed rows; against the CPU oracle, scipy and the same
-    matrix uploaded WITHOUT the geometry (dense blocks + pad-8): plain products, odd ranges, the product with column sums,
-    and a whole solve against the reference's run (tests/golden)."""
+    matrix uploaded WITHOUT the geometry — once with the recovery of the geometry from the rows switched off (dense blocks +
+    pad-8), once as any caller uploads it (gcge_hip_mat_create recovers lines, planes and their shifts from the couplings and
+    takes the sweep as well): plain products, odd ranges, the product with column sums."""
     from gcge_amd.lib import ball_geometry
     hip, ora = both
     g = hip.g
@@ -1320,24 +1321,35 @@ def test_star_sweep_on_a_masked_grid_vs_oracle(both, G, kw):
     try:
         A, _ = make_problem("sio2ball", G, **kw)
         box = ball_geometry(G)
-        mh, mp, mo = hip.matrix_grid(A, (G, G, G), box), hip.matrix(A), ora.matrix(A)
+        g.gcge_hip_spmm_star_infer.argtypes = [C.c_int]
+        g.gcge_hip_spmm_star_infer(0)
+        mp = hip.matrix(A)
+        g.gcge_hip_spmm_star_infer(1)
+        mh, mi, mo = hip.matrix_grid(A, (G, G, G), box), hip.matrix(A), ora.matrix(A)
         assert g.gcge_hip_mat_spmm_form(mh).decode().startswith("spmm_star+spmm_dense"), g.gcge_hip_mat_spmm_form(mh).decode()
+        assert g.gcge_hip_mat_spmm_form(mi).decode().startswith("spmm_star+spmm_dense"), g.gcge_hip_mat_spmm_form(mi).decode()
         assert not g.gcge_hip_mat_spmm_form(mp).decode().startswith("spmm_star")
+        st, si = (C.c_long * 8)(), (C.c_long * 8)()
+        g.gcge_hip_mat_star_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+        assert g.gcge_hip_mat_star_stats(mh, st) and g.gcge_hip_mat_star_stats(mi, si)
+        assert si[3] == st[3] == 6 and si[4] >= 0.98 * st[4], (list(st), list(si))   # (nearly) as many clean rows as with the true geometry
         n = A.nrows
         S = csr_to_scipy(A)
         X = uniform(12, (n, 72)) - 0.5
         xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
         for m, s0, s1 in [(64, 0, 0), (16, 2, 4), (2, 0, 0), (30, 4, 2), (66, 6, 0), (17, 1, 0)]:
             Y0 = uniform(8, (n, 72))
-            yh, yp, yo = hip.mv_from_numpy(mh, Y0), hip.mv_from_numpy(mp, Y0), ora.mv_from_numpy(mo, Y0)
+            yh, yp, yi, yo = hip.mv_from_numpy(mh, Y0), hip.mv_from_numpy(mp, Y0), hip.mv_from_numpy(mi, Y0), ora.mv_from_numpy(mo, Y0)
             hip.ops.spmm(mh, xh, yh, (s0, s1), (s0 + m, s1 + m))
             hip.ops.spmm(mp, xh, yp, (s0, s1), (s0 + m, s1 + m))
+            hip.ops.spmm(mi, xh, yi, (s0, s1), (s0 + m, s1 + m))
             ora.ops.spmm(mo, xo, yo, (s0, s1), (s0 + m, s1 + m))
             got = hip.mv_to_numpy(yh, n, 0, 72)
             _close(got, ora.mv_to_numpy(yo, n, 0, 72), tol=1e-12, what="sweep on a masked grid m=%d" % m)
             _close(got, hip.mv_to_numpy(yp, n, 0, 72), tol=1e-12, what="with / without the geometry m=%d" % m)
+            _close(got, hip.mv_to_numpy(yi, n, 0, 72), tol=1e-12, what="named / recovered geometry m=%d" % m)
             _close(got[:, s1:s1 + m], S @ X[:, s0:s0 + m], tol=1e-12, what="sweep on a masked grid vs scipy m=%d" % m)
-            hip.ops.mv_destroy(yh); hip.ops.mv_destroy(yp); ora.ops.mv_destroy(yo)
+            hip.ops.mv_destroy(yh); hip.ops.mv_destroy(yp); hip.ops.mv_destroy(yi); ora.ops.mv_destroy(yo)
         g.gcge_hip_spmm_dot2_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         for m, s0, s1 in [(64, 0, 0), (30, 4, 2)]:
@@ -1348,8 +1360,9 @@ def test_star_sweep_on_a_masked_grid_vs_oracle(both, G, kw):
             _close(hip.mv_to_numpy(y2, n, 0, 64)[:, s1:s1 + m], Yw, tol=1e-12, what="masked grid: product with column sums m=%d" % m)
             assert np.allclose(dots, (X[:, s0:s0 + m] * Yw).sum(0), rtol=1e-11, atol=1e-9) and np.allclose(yy, (Yw * Yw).sum(0), rtol=1e-11), m
             hip.ops.mv_destroy(y2)
-        hip.free_matrix(mh); hip.free_matrix(mp)
+        hip.free_matrix(mh); hip.free_matrix(mp); hip.free_matrix(mi)
     finally:
+        g.gcge_hip_spmm_star_infer(1)
         g.gcge_hip_spmm_dense_mode(0)
 
 

@@ -1,6 +1,7 @@
 """K1 on the SiO2-like operator restricted to the BALL inscribed in the grid (rows = grid points inside a sphere in scan order, the
 PARSEC layout of the matrices behind BASELINE config 5): with the geometry named (gcge_hip_mat_create_grid: the star rows take the
-plane sweep through a row map) and without it (dense blocks + pad-8), and the pad-8 kernel alone.  Measurement aid.
+plane sweep through a row map), with the geometry recovered from the rows (what gcge_hip_mat_create does by itself) and without
+it (dense blocks + pad-8), and the pad-8 kernel alone.  Measurement aid.
     python tools/ball_probe.py G K [m]"""
 import ctypes as C, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,8 +29,10 @@ ops = hip.ops
 rng = np.random.default_rng(7)
 X = np.asfortranarray(rng.random((A.nrows, m)) - 0.5)      # the SAME operand for every form
 res = {}
-for tag in ("with the geometry", "without"):
+g.gcge_hip_spmm_star_infer.argtypes = [C.c_int]
+for tag in ("with the geometry", "geometry recovered from the rows", "without"):
     t1 = time.time()
+    g.gcge_hip_spmm_star_infer(0 if tag == "without" else 1)
     mA = hip.matrix_grid(A, (G, G, G), box) if tag == "with the geometry" else hip.matrix(A)
     form = g.gcge_hip_mat_spmm_form(mA).decode()
     st = (C.c_double * 12)(); ss = (C.c_long * 8)()
