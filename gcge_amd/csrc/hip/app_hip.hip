@@ -747,6 +747,8 @@ extern "C" void gcge_hip_set_halo_overlap(int on) { g_halo_overlap = on; }
 // -1 before anything was launched or sent: operands the sweep does not take.
 static long g_star_products = 0, g_star_split_products = 0;
 extern "C" void gcge_hip_star_product_stats(long* products, long* split) { if (products) *products = g_star_products; if (split) *split = g_star_split_products; }
+static int g_star_race_probe = 0;   // MEASUREMENT ONLY (results are wrong): blocks + listed rows on a second stream beside the sweep, unordered
+extern "C" void gcge_hip_star_race_probe(int on) { g_star_race_probe = on; }
 static int star_product(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, double* dy, long ldy, int m, double* dd) {
   const double* dx = vx->d + c_begin;
   const long ldx = vx->ld;
@@ -769,6 +771,16 @@ static int star_product(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int c_begin, double* dy
     if (rc == 0) rc = gcge_hip_star_spmm_part(A->star, dx, ldx, dy, ldy, m, dd, g_stream, 2);
   } else {
     halo_fetch(A, vx, c_begin, m);
+    if (g_star_race_probe) {
+      static hipStream_t side = nullptr; static hipEvent_t e0, e1;
+      if (!side) { GCGE_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking)); GCGE_HIP_CHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming)); GCGE_HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming)); }
+      GCGE_HIP_CHECK(hipEventRecord(e0, g_stream)); GCGE_HIP_CHECK(hipStreamWaitEvent(side, e0, 0));
+      if (g_star_race_probe == 2) gcge_hip_dense_spmm(A->star_rem, dx, ldx, dy, ldy, m, side, 4);
+      rc = gcge_hip_star_spmm_part(A->star, dx, ldx, dy, ldy, m, dd, g_stream, 0);
+      if (g_star_race_probe == 1) gcge_hip_dense_spmm(A->star_rem, dx, ldx, dy, ldy, m, side, 4);
+      GCGE_HIP_CHECK(hipEventRecord(e1, side)); GCGE_HIP_CHECK(hipStreamWaitEvent(g_stream, e1, 0));
+      return rc;
+    }
     rc = gcge_hip_star_spmm_part(A->star, dx, ldx, dy, ldy, m, dd, g_stream, 0);
   }
   GCGE_REQUIRE(rc == 0, "star product: sweep");
