@@ -978,6 +978,55 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
   if (host_yy) memcpy(host_yy, hd + m, m * sizeof(double));
 }
 
+// The same with the sums LEFT ON THE DEVICE and nothing waited for (the device-scalar loop of block_pcg.hip on matrices whose
+// product is stored): y[:, cy : cy + m) = A x[:, cx : cx + m), d_out[0, m) = x.y, d_out[m, 2m) = y.y over the local rows (d_out: 2 m
+// doubles).  -1, nothing touched: operands the fused kernels do not take (odd widths or offsets, unaligned blocks).
+__global__ void dot2_sum_kernel(int m, const double* __restrict__ a0, const double* __restrict__ a1, const double* __restrict__ b0,
+                                const double* __restrict__ b1, double* __restrict__ out) {   // out = [a0 + b0 | a1 + b1] (b: NULL = none)
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) { out[j] = a0[j] + (b0 != nullptr ? b0[j] : 0.0); out[m + j] = a1[j] + (b1 != nullptr ? b1[j] : 0.0); }
+}
+extern "C" int gcge_hip_spmm_dot2_dev(void* mat, void** x, void** y, int cx, int cy, int m, double* d_out) {
+  enter();
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
+  GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
+  if (A == nullptr || m <= 0 || (m & 1) || (cx & 1) || (cy & 1) || (vx->ld & 1) || (vy->ld & 1) || vx == vy) return -1;
+  if (((uintptr_t)(vx->d + cx) & 15) || ((uintptr_t)(vy->d + cy) & 15)) return -1;
+  if (vx->nrows != vy->nrows || A->nrows != vy->nrows || A->nrows + A->nghost > vx->nrows_alloc) return -1;
+  if (A->nghost > 0 && m > A->buf_cols) return -1;
+  GCGE_REQUIRE(cx >= 0 && cx + m <= vx->ncols && cy >= 0 && cy + m <= vy->ncols, "spmm_dot2_dev: column ranges");
+  SpmmEvent ev;
+  if (g_prof_on) {
+    GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
+    ev.m = m; ev.kind = 0;
+    ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
+    GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
+  }
+  const bool use_pat = A->d_pid != nullptr && g_spmm_path == 0;
+  const bool long_rows = A->nrows > 0 && (double)A->noct / A->nrows >= 2.5;
+  const bool fast = use_pat || (m >= 16 && m <= 128 && !long_rows);
+  int rc = -1;
+  if (!fast && A->star != nullptr && g_spmm_path == 0) {
+    double* dd = stage_d(4 * (size_t)m);                               // sweep: x.y | y.y, listed rows: x.y | y.y
+    rc = star_product(A, vx, cx, vy->d + cy, vy->ld, m, dd);
+    if (rc == 0) hipLaunchKernelGGL(dot2_sum_kernel, dim3((m + 127) / 128), dim3(128), 0, g_stream, m, (const double*)dd, (const double*)(dd + m),
+                                    (const double*)(dd + 2 * (size_t)m), (const double*)(dd + 3 * (size_t)m), d_out);
+  }
+  if (rc != 0 && fast) {
+    double* dd = stage_d(6 * (size_t)m);                               // x.y (3 m: total + the strips of a split product), then y.y
+    rc = spmm_halo(A, vx, cx, vy->d + cy, vy->ld, m, dd, dd + 3 * (size_t)m);
+    GCGE_REQUIRE(rc == 0, "spmm_dot2_dev: kernel launch");
+    hipLaunchKernelGGL(dot2_sum_kernel, dim3((m + 127) / 128), dim3(128), 0, g_stream, m, (const double*)dd, (const double*)(dd + 3 * (size_t)m),
+                       (const double*)nullptr, (const double*)nullptr, d_out);
+  } else if (rc != 0) {
+    rc = spmm_halo(A, vx, cx, vy->d + cy, vy->ld, m, nullptr, nullptr);
+    GCGE_REQUIRE(rc == 0, "spmm_dot2_dev: kernel launch");
+    GCGE_REQUIRE(gcge_hip_coldots2(vx->nrows, vx->d + cx, vx->ld, vy->d + cy, vy->ld, m, d_out, g_stream) == 0, "spmm_dot2_dev: column sums");
+  }
+  if (g_prof_on) { GCGE_HIP_CHECK(hipEventRecord(ev.e1, g_stream)); g_prof.push_back(ev); }
+  return 0;
+}
+
 // ---- the two passes of a fused block-CG iteration (block_pcg.hip) on a pattern matrix -----------------------------
 // The product w = A p is formed twice and never stored: pass 1 reads p and returns p.w and w.w (that fixes alpha and
 // beta), pass 2 reads p again, rebuilds w in registers and applies  r -= alpha w ; p_new = r + beta p  on the spot.

