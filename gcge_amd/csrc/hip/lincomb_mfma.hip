@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, c
     const double* __restrict__ cpad, int m, const double* __restrict__ beta, double* y, long ldy, int cs) {
   extern __shared__ __align__(16) double lds[];       // [2][KTD][cs]
   constexpr int NJ = KTD / 8;                          // 16-byte loads per row fragment and k-tile
-  constexpr int CE = KTD * 16 * NT / 256;              // coefficient elements per thread and tile
+  constexpr int CE = (KTD * 16 * NT + 255) / 256;      // coefficient elements per thread and tile (NT odd at k-tiles of 8: the last round is half
+  constexpr bool CE_RAGGED = (KTD * 16 * NT) % 256 != 0;   //  used — its loads run into the next tile's rows, which the workspace holds; only the LDS stores are guarded)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int li = lane & 15, kk = lane >> 4;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256, MINB) void lincomb_direct_kernel(long nrows, c
 #pragma unroll
     for (int q = 0; q < CE; ++q) {
       const int e = threadIdx.x + 256 * q, row = e / (16 * NT), col = e % (16 * NT);
-      cst[row * cs + col] = cr[q];
+      if (!CE_RAGGED || e < KTD * 16 * NT) cst[row * cs + col] = cr[q];
     }
   };
   auto mfmas = [&](const v2d_lc (&a)[RF][NJ], int buf) {
@@ -329,6 +330,8 @@ static double* g_cpad = nullptr;
 static size_t g_cpad_len = 0;
 static int g_lc_rf = 0;   // 0 automatic (the direct form for panels of >= 33 columns where the operand allows 16-byte loads);
                           // 1 / 2: the LDS-staged kernel with that many row fragments per wave; >= 3: the direct form forced, see lc_launch
+static int g_lc_wide_only = 0;   // 1: panels of 65 .. 96 columns take the 128-column kernel as before round 4 (measurements)
+extern "C" void gcge_hip_lincomb_wide_only(int on) { g_lc_wide_only = on != 0; }
 extern "C" void gcge_hip_lincomb_tune(int row_fragments) { if (row_fragments >= 0 && row_fragments <= 14) g_lc_rf = row_fragments; }
 
 template <int NT>
@@ -341,9 +344,9 @@ static int lc_launch(int nrows, const double* x, long ldx, int k, const double* 
   int shift = 0;
   if ((((uintptr_t)x & 15) == 8) && (ldx % 2 == 0) && ((g_lc_rf == 0 && NT >= 4) || g_lc_rf >= 3)) { shift = 1; x -= 1; k += 1; }
   const int kp = (k + LC_KT - 1) / LC_KT * LC_KT, mp = 16 * NT;
-  if ((size_t)kp * mp > g_cpad_len) {   // grows rarely; freeing synchronises with kernels still reading the old one
+  if ((size_t)(kp + LC_KT) * mp > g_cpad_len) {   // grows rarely; freeing synchronises with kernels still reading the old one (one k-tile of slack: see CE_RAGGED)
     if (g_cpad) GCGE_HIP_CHECK(hipFree(g_cpad));
-    g_cpad_len = (size_t)kp * mp * 2;
+    g_cpad_len = (size_t)(kp + LC_KT) * mp * 2;
     GCGE_HIP_CHECK(hipMalloc(&g_cpad, g_cpad_len * sizeof(double)));
   }
   hipLaunchKernelGGL(lincomb_pad_c, dim3((kp * mp + 255) / 256), dim3(256), 0, st, c, k - shift, m, g_cpad, kp, mp, shift);
@@ -373,6 +376,10 @@ static int lc_launch(int nrows, const double* x, long ldx, int k, const double* 
       if (g_lc_rf == 7) GCGE_LCD(2, 2, 32, true); else if (g_lc_rf == 10) GCGE_LCD(2, 2, 16, true);
       else if (g_lc_rf == 14) GCGE_LCD(2, 3, 16, false);
       else GCGE_LCD(2, 3, 8, false);
+    } else if constexpr (NT >= 5) {   // panels of 65 .. 96 columns (round 4): 5 or 6 column fragments instead of 8 with up to 3/8 of the MFMAs on zero
+      // columns — k = 256: m = 72 35.1 -> 47.5 TF, 80 39.0 -> 51.8, 96 46.2 -> 56.1 (profiles/r04_bench); builtin MFMAs only (the named
+      // tiles were written for 8 and 16 of them).  Seven fragments (m <= 112) measured no faster than eight: those panels stay there.
+      if (g_lc_rf == 14) GCGE_LCD(2, 2, 16, false); else GCGE_LCD(2, 2, 8, false);
     } else {
       GCGE_LCD(2, 2, 16, false);
     }
@@ -405,6 +412,8 @@ extern "C" int gcge_hip_lincomb(int nrows, const double* d_x, long ldx, int k, c
   if (m <= 16) lc_launch<1>(nrows, d_x, ldx, k, d_c, m, d_beta, d_y, ldy, st);
   else if (m <= 32) lc_launch<2>(nrows, d_x, ldx, k, d_c, m, d_beta, d_y, ldy, st);
   else if (m <= 64) lc_launch<4>(nrows, d_x, ldx, k, d_c, m, d_beta, d_y, ldy, st);
+  else if (m <= 80 && g_lc_wide_only == 0) lc_launch<5>(nrows, d_x, ldx, k, d_c, m, d_beta, d_y, ldy, st);
+  else if (m <= 96 && g_lc_wide_only == 0) lc_launch<6>(nrows, d_x, ldx, k, d_c, m, d_beta, d_y, ldy, st);
   else lc_launch<8>(nrows, d_x, ldx, k, d_c, m, d_beta, d_y, ldy, st);
   return (int)hipGetLastError();
 }

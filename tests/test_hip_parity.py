@@ -669,7 +669,8 @@ def test_lincomb_row_fragment_variants_vs_oracle(both, rf):
     try:
         for k, m, s0, s1 in [(1, 65, 0, 0), (33, 100, 2, 1), (100, 128, 0, 3), (260, 65, 1, 0), (260, 128, 2, 2), (64, 17, 0, 5),
                              (130, 33, 3, 3), (192, 64, 0, 0), (256, 64, 2, 6), (255, 64, 0, 2), (64, 64, 4, 0), (256, 128, 0, 0),
-                             (24, 48, 0, 0), (8, 64, 0, 0)]:
+                             (24, 48, 0, 0), (8, 64, 0, 0),
+                             (208, 72, 0, 0), (255, 80, 2, 4), (131, 96, 0, 2), (64, 90, 6, 0), (9, 66, 1, 1)]:   # 5 / 6 column fragments (round 4)
             Y0 = uniform(48, (n, 140))
             xh, xo = hip.mv_from_numpy(mh, X), ora.mv_from_numpy(mo, X)
             coef = np.asfortranarray(uniform(49, (k + 1, m)) - 0.5)

@@ -1,5 +1,5 @@
 // Micro-benchmark of K2 (Gram) and K3 (panel update) at the C2 shapes.  Not part of the product.
-// hipcc -O3 --offload-arch=gfx950 -I gcge_amd/csrc/hip -I include tools/dense_bench.hip gcge_amd/csrc/hip/gram_mfma.hip gcge_amd/csrc/hip/lincomb_mfma.hip gcge_amd/csrc/hip/vec_kernels.hip -o /tmp/dense_bench
+// hipcc -O3 --offload-arch=gfx950 -I gcge_amd/csrc/hip -I include tools/dense_bench.hip gcge_amd/csrc/hip/gram_mfma.hip gcge_amd/csrc/hip/lincomb_mfma.hip gcge_amd/csrc/hip/vec_kernels.hip -o tools/_bin/dense_bench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -8,6 +8,8 @@
 extern "C" int gcge_hip_gram(int, const double*, long, int, const double*, long, int, double*, void*);
 extern "C" void gcge_hip_gram_tune(int);
 extern "C" void gcge_hip_lincomb_tune(int);
+extern "C" void gcge_hip_lincomb_wide_only(int);
+extern "C" void gcge_hip_apply_pending(void) {}   // (the back-end's held-back column scaling: nothing pending in a stand-alone bench)
 extern "C" int gcge_hip_lincomb(int, const double*, long, int, const double*, int, const double*, double*, long, void*);
 __global__ void fillk(double* x, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
@@ -71,6 +73,16 @@ int main(int argc, char** argv) {
     float ta; hipEventElapsedTime(&ta, a0, a1); hipEventElapsedTime(&tb, b0, b1);
     printf("mfma f64 16x16x4 register-only NEXT TO an HBM copy: %.2f ms -> %.1f TF  (copy: 24 reps in %.2f ms -> %.0f GB/s while both ran)\n",
            ta, 2048.0 * 16 * iters * blocks * 4 / ta * 1e-9, tb, 24 * 2.0 * n2 * 16 / tb * 1e-6);
+  }
+  if (getenv("DB_RAGGED")) {   // panels of 65 .. 127 columns: 5 / 6 / 7 column fragments (round 4) against the 128-column kernel
+    for (int k : {208, 256}) for (int m : {66, 72, 80, 84, 90, 96, 102, 108, 112, 120, 128}) for (int wide : {1, 0}) {
+      gcge_hip_lincomb_wide_only(wide);
+      gcge_hip_lincomb((int)n, V, ldv, k, C, m, nullptr, W, ldw, 0); hipDeviceSynchronize();
+      hipEventRecord(e0); for (int r = 0; r < reps; ++r) gcge_hip_lincomb((int)n, V, ldv, k, C, m, nullptr, W, ldw, 0);
+      hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+      printf("lincomb k=%3d m=%3d %s  %8.3f ms  %6.1f TF\n", k, m, wide ? "128-column kernel" : "fragments of m   ", ms, 2.0 * n * k * m / ms * 1e-9);
+    }
+    return 0;
   }
   int gk[] = {256, 192, 128, 64, 64, 256, 512, 512}, gm[] = {64, 64, 64, 64, 1, 128, 128, 64};
   for (int ms = 1; ms <= 4; ms *= 2)
