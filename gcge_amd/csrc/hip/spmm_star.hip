@@ -307,12 +307,32 @@ __device__ __forceinline__ void star3_dma(const char* base, unsigned voff, unsig
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
+// Workgroup -> (patch, z range, column pass) in an XCD-aware order (gcge_hip_spmm_star_xcd; OFF by default).  The dispatcher deals
+// linear workgroup ids round-robin to the 8 XCDs, each with its own L2, and a patch's halo strips are its neighbours' own points —
+// dealt in launch order, neighbouring patches sit on different XCDs and every strip comes over the fabric again (3.25 rows per
+// row).  Tried: XCD k = id % 8 takes the k-th contiguous eighth of the patch-fastest order (xcd = 1), or runs of G consecutive
+// patches dealt round-robin (xcd = G).  Measured at 171^3 x 64 (profiles/r04_star/16): launch order 2.84 ms, runs of 2 / 4 / 11 / 22
+// 2.83 / 2.83 / 2.82 / 2.78, contiguous eighths 2.95 — the strips of neighbours on other XCDs are served by the memory-side cache
+// at the rate the sweep consumes them; keeping them in one L2 buys nothing and contiguous eighths lose to channel imbalance.
+__device__ __forceinline__ void star_block_of(int xcd, unsigned& bx, unsigned& by, unsigned& bz) {
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+  if (!xcd) return;
+  const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+  const unsigned L = bx + gx * (by + gy * bz), k = L & 7u;
+  unsigned v = L;
+  if (xcd == 1) { const unsigned q = total >> 3, r = total & 7u; v = k * q + min(k, r) + (L >> 3); }
+  else {                                                              // runs of `xcd` consecutive patches per XCD, the runs dealt round-robin
+    const unsigned G = (unsigned)xcd, s = L >> 3, full = total / (8u * G) * (8u * G);
+    if (L < full) v = (s / G) * 8u * G + k * G + s % G;
+  }
+  bx = v % gx; by = (v / gx) % gy; bz = v / (gx * gy);
+}
 template <int N> __device__ __forceinline__ void star3_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
 template <bool DOT, bool SLAB>
 __global__ __launch_bounds__(1024) void spmm_star3_kernel(int nx, int ny, int zs, int ze, int zmin, int zmax, long dlo, long dhi, StarCoef cf,
     const double* __restrict__ diag, const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols,
-    int zlo, int zhi, int zlen, int ntx, double* __restrict__ partial, const unsigned char* __restrict__ cleanf) {
+    int zlo, int zhi, int zlen, int ntx, double* __restrict__ partial, const unsigned char* __restrict__ cleanf, int xcd) {
   constexpr int LPP = STAR3_LPP, TY = STAR3_TY, SIDE = 2 * STAR_R * TY;
   extern __shared__ __align__(16) unsigned char star3_smem[];
   v2d* img = reinterpret_cast<v2d*>(star3_smem);                       // img[(row * 28 + col) * 8 + part]
@@ -321,10 +341,12 @@ __global__ __launch_bounds__(1024) void spmm_star3_kernel(int nx, int ny, int zs
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int part = tid % LPP, px = (tid / LPP) & 15, py = tid / (16 * LPP);
-  const int tile_x = blockIdx.x % ntx, tile_y = blockIdx.x / ntx;
+  unsigned bx, by, bz;
+  star_block_of(xcd, bx, by, bz);
+  const int tile_x = bx % ntx, tile_y = bx / ntx;
   const int x0 = tile_x * STAR_T, y0 = tile_y * TY;
-  const int z0 = zlo + blockIdx.y * zlen, z1 = min(zhi, z0 + zlen);
-  const int c0 = 2 * LPP * blockIdx.z;
+  const int z0 = zlo + by * zlen, z1 = min(zhi, z0 + zlen);
+  const int c0 = 2 * LPP * bz;
   const long plane_rows = (long)nx * ny;
   auto plane_row0 = [&](int zz) -> long { return plane_rows * zz + (SLAB ? (zz < zs ? dlo : zz >= ze ? dhi : 0L) : 0L); };
   const int gx = x0 + px, gy = y0 + py;
@@ -458,7 +480,7 @@ __global__ __launch_bounds__(1024) void spmm_star3_kernel(int nx, int ny, int zs
       __syncthreads();
     }
     if (pidx == 0 && cvalid) {
-      double* out = partial + ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 2 * ncols;
+      double* out = partial + ((size_t)bx + (size_t)gridDim.x * by) * 2 * ncols;
       out[col] = img[tid].x; out[col + 1] = img[tid].y;
       out[ncols + col] = img[1024 + tid].x; out[ncols + col + 1] = img[1024 + tid].y;
     }
@@ -859,6 +881,8 @@ static int g_star_form = 3;   // 2: second form of the sweep (registers stage th
 extern "C" void gcge_hip_spmm_star_form(int form) { g_star_form = form == 3 ? 3 : 2; }
 static int g_star_lpp = 4;    // second form: 8 = 16-column passes on 16 x 8 patches (128-byte pieces of the rows), 4 = 8 columns on 16 x 16 (64-byte pieces)
 extern "C" void gcge_hip_spmm_star_lanes(int lpp) { g_star_lpp = lpp == 4 ? 4 : 8; }
+static int g_star_xcd = 0;    // 0: workgroups in launch order; 1 / G >= 2: XCD-aware orders (star_block_of) — measured, not faster
+extern "C" void gcge_hip_spmm_star_xcd(int on) { g_star_xcd = on < 0 ? 0 : on; }
 static int g_star_dbg = 0;    // measurement only: 1 no halo loads, 2 no LDS arm reads, 4 no stores, 8 no own-plane loads (results are wrong then)
 extern "C" void gcge_hip_spmm_star_dbg(int bits) { g_star_dbg = bits; }
 extern "C" void gcge_hip_spmm_star_mode(int mode) { g_star_mode = mode; }
@@ -1109,7 +1133,7 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
       attr_set = true;
     }
 #define STAR_LAUNCH3(DOT, SLAB) hipLaunchKernelGGL((spmm_star3_kernel<DOT, SLAB>), grid, dim3(1024), STAR3_LDS, stream, g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax, \
-                                                   dlo, dhi, S->c, dv, xv, (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part, cv)
+                                                   dlo, dhi, S->c, dv, xv, (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part, cv, g_star_xcd)
     if (dot) { if (slab) STAR_LAUNCH3(true, true); else STAR_LAUNCH3(true, false); }
     else     { if (slab) STAR_LAUNCH3(false, true); else STAR_LAUNCH3(false, false); }
 #undef STAR_LAUNCH3

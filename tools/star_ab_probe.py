@@ -9,6 +9,8 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 354
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 hip = HipBackend(); g = hip.g
+if os.environ.get("GCGE_STAR_XCD") is not None:      # 0: workgroups in launch order (before round 4's XCD-aware order)
+    g.gcge_hip_spmm_star_xcd.argtypes = [C.c_int]; g.gcge_hip_spmm_star_xcd(int(os.environ["GCGE_STAR_XCD"]))
 g.gcge_hip_spmm_star_lanes.argtypes = [C.c_int]
 g.gcge_hip_spmm_star_form.argtypes = [C.c_int]
 g.gcge_hip_profile_enable.argtypes = [C.c_int]
