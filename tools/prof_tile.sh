@@ -22,6 +22,7 @@ for f in glob.glob(out+'/p*/**/*counter_collection.csv',recursive=True):
         if 'spmm_star2_kernel' in k:
             kk=k.replace(' ','')
             tag='star' + ('+sums' if 'kernel<true' in kk else '') + (' 16col' if ',8,0,' in kk else ' 8col') + (' masked' if kk.split('>')[0].endswith('true') else '')
+        elif 'spmm_star3_kernel' in k: tag='star3' + ('+sums' if 'kernel<true' in k.replace(' ','') else '')
         elif 'spmm_star_kernel' in k: tag='star'
         elif 'spmm_tile_kernel' in k: tag='tile'
         elif 'spmm_pad8' in k: tag='pad8'
