@@ -1209,15 +1209,48 @@ extern "C" int gcge_hip_cg_start_scaled_mv(void* mat, void** x, int xc0, const d
 }
 
 // Residuals of Ritz pairs of a standard problem in one read of x (GCGE_RESIDUAL_FN, include/gcge_ops.h; kernel MODE 4 of
-// spmm_pattern.hip): res_sq[j] = sum over the local rows of ((A x_j) - lambda_j x_j)^2.  Declines (0) for B != NULL,
-// matrices without pattern form, blocks that cannot be walked in 16-byte column pairs.  Odd column ranges are widened
-// to even ones (the extra columns are computed and dropped).
+// spmm_pattern.hip): res_sq[j] = sum over the local rows of ((A x_j) - lambda_j x_j)^2.  Declines (0) for B != NULL and
+// blocks that cannot be walked in 16-byte column pairs; matrices without pattern form take resid_sq_stored above.  Odd
+// column ranges are widened to even ones (the extra columns are computed and dropped).
+// ... and for the matrices whose product cannot carry the sums (no pattern form: the plane sweep, dense blocks, pad-8): the product
+// into a scratch block, then ONE sweep over it and x — 2 block streams behind the product instead of the 9 of the five slot calls
+// (round 4; config 5: 13 -> 5 ms per outer iteration).  Chunks of <= 64 columns (the halo buffers' width on slabs).
+extern "C" int gcge_hip_resid_sq(int nrows, const double* d_w, long ldw, const double* d_x, long ldx, int m, const double* d_lambda,
+                                 double* d_out, void* stream);
+static int resid_sq_stored(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int start, int end, const double* lambda, double* res_sq) {
+  if (getenv("GCGE_NO_STORED_RESIDUAL_HOOK") != nullptr) return 0;
+  if ((vx->ld & 1) || ((uintptr_t)vx->d & 15) || A->nrows + A->nghost > vx->nrows_alloc) return 0;
+  const int c0 = start & ~1, c1 = (end + 1) & ~1;
+  if (c1 > vx->ld) return 0;
+  const int chunk = 64;
+  const size_t bytes = (size_t)A->nrows * chunk * sizeof(double);
+  double* t = (double*)pool_alloc(bytes);
+  int ok = 1;
+  for (int b0 = c0; b0 < c1 && ok; b0 += chunk) {
+    const int m = std::min(chunk, c1 - b0);
+    if (A->nghost > 0 && m > A->buf_cols) { ok = 0; break; }
+    double* dd = stage_d(2 * (size_t)m);
+    GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));   // the pinned staging may still feed an upload of the previous chunk / slot call
+    double* hl = stage_h(2 * (size_t)m);
+    for (int j = 0; j < m; ++j) hl[j] = (b0 + j >= start && b0 + j < end) ? lambda[b0 + j - start] : 0.0;
+    GCGE_HIP_CHECK(hipMemcpyAsync(dd + m, hl, m * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    const int rc = spmm_halo(A, vx, b0, t, (long)m, m, nullptr, nullptr);
+    GCGE_REQUIRE(rc == 0, "residual norms: product");
+    GCGE_REQUIRE(gcge_hip_resid_sq(A->nrows, t, (long)m, vx->d + b0, vx->ld, m, dd + m, dd, g_stream) == 0, "residual norms: sweep");
+    GCGE_HIP_CHECK(hipMemcpyAsync(hl + m, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+    for (int j = 0; j < m; ++j) if (b0 + j >= start && b0 + j < end) res_sq[b0 + j - start] = hl[m + j];
+  }
+  pool_free(t, bytes);
+  return ok;
+}
 static int HIP_ResidualSq(void* mat, void* matB, void** x, int start, int end, const double* lambda, double* res_sq) {
   enter();
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat; GcgeHipMV* vx = (GcgeHipMV*)x;
   if (A == nullptr || matB != nullptr || end <= start) return 0;
   const int c0 = start & ~1, c1 = (end + 1) & ~1, m = c1 - c0;
-  if (c1 > vx->ld || !gcge_hip_cg_fusable(mat, x, m) || A->nrows != vx->nrows) return 0;
+  if (c1 > vx->ld || A->nrows != vx->nrows) return 0;
+  if (!gcge_hip_cg_fusable(mat, x, m)) return resid_sq_stored(A, vx, start, end, lambda, res_sq);
   double* dd = stage_d(7 * (size_t)m);
   double* d_lam = dd + 6 * (size_t)m;
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));   // the pinned staging may still feed an upload of the previous slot call

@@ -167,6 +167,33 @@ __global__ __launch_bounds__(256) void coldots2_partial(long nrows, const double
     __syncthreads();
   }
 }
+// partial[b*m + j] = sum over the rows of block b of (w[r,j] - lambda_j x[r,j])^2 — the squared residual norms of Ritz pairs after a
+// product w = A x that could not carry them (ops_eig_sol_gcg.c:195-315 forms lambda B x, subtracts and takes norms: 9 block
+// streams for B = NULL; here 2)
+__global__ __launch_bounds__(256) void resid_sq_partial(long nrows, const double* __restrict__ w, long ldw,
+    const double* __restrict__ x, long ldx, int m, const double* __restrict__ lambda, double* __restrict__ partial, long rows_per_block) {
+  __shared__ double red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(nrows, r0 + rows_per_block);
+  for (int c0 = 0; c0 < m; c0 += 64) {
+    const int j = c0 + tx;
+    double s0 = 0.0, s1 = 0.0;
+    if (j < m) {
+      const double lam = lambda[j];
+      long r = r0 + ty;
+      for (; r + 4 < r1; r += 8) {
+        const double da = fma(-lam, x[r * ldx + j], w[r * ldw + j]), db = fma(-lam, x[(r + 4) * ldx + j], w[(r + 4) * ldw + j]);
+        s0 = fma(da, da, s0); s1 = fma(db, db, s1);
+      }
+      for (; r < r1; r += 4) { const double da = fma(-lam, x[r * ldx + j], w[r * ldw + j]); s0 = fma(da, da, s0); }
+    }
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && j < m) partial[(long)blockIdx.x * m + j] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    __syncthreads();
+  }
+}
 // out[j] = sum_b partial[b*len + j]; 16 row groups x 64 columns per block, fixed summation
 // tree => bitwise reproducible, and no thread walks more than nblocks/16 entries
 __global__ __launch_bounds__(1024) void reduce_partials(const double* __restrict__ partial, int nblocks, int len,
@@ -512,6 +539,21 @@ extern "C" int gcge_hip_coldots2(int nrows, const double* d_x, long ldx, const d
   double* part = gcge_hip_partial_ws((size_t)nb * 2 * m);
   hipLaunchKernelGGL(coldots2_partial, dim3((unsigned)nb), dim3(256), 0, st, (long)nrows, d_x, ldx, d_y, ldy, m, part, rpb);
   hipLaunchKernelGGL(reduce_partials, dim3((2 * m + 63) / 64), dim3(1024), 0, st, part, (int)nb, 2 * m, d_out);
+  return (int)hipGetLastError();
+}
+
+// d_out[j] = sum_r (w[r,j] - lambda_j x[r,j])^2, j < m (device, fixed summation order); d_lambda: m doubles on the device
+extern "C" int gcge_hip_resid_sq(int nrows, const double* d_w, long ldw, const double* d_x, long ldx, int m, const double* d_lambda,
+                                 double* d_out, void* stream) {
+  gcge_hip_apply_pending();
+  if (nrows <= 0 || m <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  long nb = ((long)nrows + 255) / 256; if (nb > 2048) nb = 2048;
+  const long rpb = (((long)nrows + nb - 1) / nb + 3) / 4 * 4;
+  nb = ((long)nrows + rpb - 1) / rpb;
+  double* part = gcge_hip_partial_ws((size_t)nb * m);
+  hipLaunchKernelGGL(resid_sq_partial, dim3((unsigned)nb), dim3(256), 0, st, (long)nrows, d_w, ldw, d_x, ldx, m, d_lambda, part, rpb);
+  hipLaunchKernelGGL(reduce_partials, dim3((m + 63) / 64), dim3(1024), 0, st, part, (int)nb, m, d_out);
   return (int)hipGetLastError();
 }
 

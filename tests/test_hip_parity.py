@@ -523,27 +523,40 @@ def test_cg_second_pass_without_stored_residual_matches_numpy(hip, kind, size, m
     hip.free_matrix(mat)
 
 
-@pytest.mark.parametrize("kind,size,start,end", [("lap3d", 16, 3, 14), ("lap3d", 16, 0, 16), ("lap3d", 12, 5, 6), ("lap3d", 20, 1, 24)])
-def test_residual_hook_matches_numpy(hip, kind, size, start, end):
-    """GCGE_RESIDUAL_FN of the HIP back-end (CheckConvergence in one read of x): odd and even column ranges."""
+@pytest.mark.parametrize("kind,size,start,end,kw", [("lap3d", 16, 3, 14, {}), ("lap3d", 16, 0, 16, {}), ("lap3d", 12, 5, 6, {}), ("lap3d", 20, 1, 24, {}),
+                                                    ("sio2", 14, 3, 14, {"K": 10, "R0": 2.0, "R1": 3.0}), ("sio2", 14, 0, 90, {"K": 10, "R0": 2.0, "R1": 3.0}),
+                                                    ("sio2", 16, 1, 70, {"K": 12, "R0": 2.0, "R1": 3.0}), ("fe3d", 12, 5, 6, {}), ("fe1d", 300, 2, 9, {})])
+def test_residual_hook_matches_numpy(hip, kind, size, start, end, kw):
+    """GCGE_RESIDUAL_FN of the HIP back-end (CheckConvergence): in one read of x on pattern matrices (kernel MODE 4), as product
+    + one sweep over the product and x on the others (round 4: the plane sweep / dense blocks / pad-8 forms; chunks of 64
+    columns) — odd and even column ranges, more columns than a chunk."""
     from helpers import csr_to_scipy, uniform
-    A, _ = make_problem(kind, size)
-    S = csr_to_scipy(A)
-    n = A.nrows
-    mat = hip.matrix(A)
-    X = uniform(21, (n, 26)) - 0.5
-    x = hip.mv_from_numpy(mat, X)
-    lam = uniform(22, (end - start,)) * 3.0
-    FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
-    hip.g.gcge_hip_residual_hook.restype = C.c_void_p
-    fn = FN(hip.g.gcge_hip_residual_hook())
-    out = np.zeros(end - start)
-    assert fn(mat, None, x, start, end, lam.ctypes.data, out.ctypes.data) == 1
-    R = S @ X[:, start:end] - X[:, start:end] * lam
-    np.testing.assert_allclose(out, np.sum(R * R, axis=0), rtol=1e-12)
-    assert fn(mat, mat, x, start, end, lam.ctypes.data, out.ctypes.data) == 0      # generalised problem: declined
-    hip.ops.mv_destroy(x, 26)
-    hip.free_matrix(mat)
+    g = hip.g
+    g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
+    if kind == "sio2":
+        g.gcge_hip_spmm_dense_mode(1)
+    try:
+        A, _ = make_problem(kind, size, **kw)
+        S = csr_to_scipy(A)
+        n = A.nrows
+        mat = hip.matrix(A)
+        ncol = max(26, end + 2 + (end & 1))
+        X = uniform(21, (n, ncol)) - 0.5
+        x = hip.mv_from_numpy(mat, X)
+        lam = uniform(22, (end - start,)) * 3.0
+        FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+        g.gcge_hip_residual_hook.restype = C.c_void_p
+        fn = FN(g.gcge_hip_residual_hook())
+        out = np.zeros(end - start)
+        assert fn(mat, None, x, start, end, lam.ctypes.data, out.ctypes.data) == 1
+        R = S @ X[:, start:end] - X[:, start:end] * lam
+        np.testing.assert_allclose(out, np.sum(R * R, axis=0), rtol=1e-12)
+        assert np.array_equal(hip.mv_to_numpy(x, n, 0, ncol), X)                       # x untouched
+        assert fn(mat, mat, x, start, end, lam.ctypes.data, out.ctypes.data) == 0      # generalised problem: declined
+        hip.ops.mv_destroy(x, ncol)
+        hip.free_matrix(mat)
+    finally:
+        g.gcge_hip_spmm_dense_mode(0)
 
 
 def test_gcg_residual_hook_equals_slot_path(hip):
@@ -558,6 +571,20 @@ def test_gcg_residual_hook_equals_slot_path(hip):
             hip.g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
             hip.set_random_mode(0)
             ev, res = gcg_on(hip, "lap3d", 16, ["-nevConv", 12, "-nevMax", 24, "-blockSize", 8], flag=1)
+            out[tag] = (ev[:res.nevConv].copy(), res.nevConv, res.numIter)
+        finally:
+            os.environ.pop("GCGE_NO_RESIDUAL_HOOK", None)
+    assert out["hook"][1:] == out["slots"][1:], (out["hook"][1:], out["slots"][1:])
+    assert np.max(np.abs(out["hook"][0] - out["slots"][0]) / np.abs(out["slots"][0])) < 1e-12
+    # a matrix without a pattern form (product + one sweep behind the hook): the same locking decisions as the five slots
+    out = {}
+    for tag in ("hook", "slots"):
+        if tag == "slots":
+            os.environ["GCGE_NO_RESIDUAL_HOOK"] = "1"
+        try:
+            hip.g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+            hip.set_random_mode(0)
+            ev, res = gcg_on(hip, "sio2", 12, ["-nevConv", 10, "-nevMax", 24, "-blockSize", 8], flag=1, K=6, R0=1.5, R1=2.0, seed=12345)
             out[tag] = (ev[:res.nevConv].copy(), res.nevConv, res.numIter)
         finally:
             os.environ.pop("GCGE_NO_RESIDUAL_HOOK", None)
