@@ -298,6 +298,55 @@ __global__ __launch_bounds__(256) void cg_update_p_implicit(long nrows, const do
   }
 }
 
+// Start of a solve whose right-hand sides are b = x diag(scale) (GCGE_SetLinearSolverRhsScale) on a matrix whose product is stored:
+// after w = A x, ONE sweep forms r = x diag(scale) - w, writes it as r and as p0 and sums r.r per column — instead of copying x to b,
+// scaling b, r = b - w, the column sums and the copy p0 = r (10 block streams; here 4).
+template <int UNR>
+__global__ __launch_bounds__(256) void cg_start_scaled_stored(long nrows, const double* __restrict__ x, long ldx, const double* __restrict__ w,
+    long ldw, double* __restrict__ r, long ldr, double* __restrict__ p0, long ldp, int m, const double* __restrict__ scale,
+    double* __restrict__ partial, int tpr) {
+  __shared__ double red[256][2];
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr, rpb = 256 / tpr;
+  const int j = 2 * tx;
+  double s0 = 0.0, s1 = 0.0;
+  const bool mine = j < m;
+  if (mine) {
+    const double c0 = scale[j], c1 = scale[j + 1];
+    const long step = rpb, group = (long)rpb * UNR;
+    const long slab = (((nrows + gridDim.x - 1) / gridDim.x) + group - 1) / group * group;
+    const long rend = min(nrows, ((long)blockIdx.x + 1) * slab);
+    auto one = [&](long rr, v2d xv, v2d wv) {
+#pragma clang fp contract(off)
+      v2d rn = {c0 * xv.x - wv.x, c1 * xv.y - wv.y};                   // rounded like the column scaling followed by the subtraction
+      __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(r + rr * ldr + j));
+      __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(p0 + rr * ldp + j));
+      s0 = fma(rn.x, rn.x, s0); s1 = fma(rn.y, rn.y, s1);
+    };
+    long row = (long)blockIdx.x * slab + ty;
+    for (; row + (UNR - 1) * step < rend; row += step * UNR) {
+      v2d xv[UNR], wv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long rr = row + u * step;
+        xv[u] = *reinterpret_cast<const v2d*>(x + rr * ldx + j);
+        wv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(w + rr * ldw + j));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) one(row + u * step, xv[u], wv[u]);
+    }
+    for (; row < rend; row += step)
+      one(row, *reinterpret_cast<const v2d*>(x + row * ldx + j), *reinterpret_cast<const v2d*>(w + row * ldw + j));
+  }
+  red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1;
+  __syncthreads();
+  if (ty == 0 && mine) {
+    for (int q = 1; q < rpb; ++q) { s0 += red[q * tpr + tx][0]; s1 += red[q * tpr + tx][1]; }
+    partial[(long)blockIdx.x * m + j] = s0;
+    partial[(long)blockIdx.x * m + j + 1] = s1;
+  }
+}
+
 struct RingPtrs { const double* p[16]; };
 // x[:, j] += sum_{q < cnt} coef[q * m + j] * ring[q][:, j]      (cnt <= 16)
 __global__ __launch_bounds__(256) void cg_accum_x(long nrows, RingPtrs ring, int cnt, long ldp, double* __restrict__ x,
@@ -391,6 +440,7 @@ struct HipBpcg {
   long dev_scalar_iters;
   long implicit_r_iters;    // iterations of the device-scalar loop that rebuilt r from two directions (no stored residual)
   long stored_dev_iters;    // iterations of the device-scalar loop with the product stored (matrices without a pattern form)
+  long fused_starts;        // solves started by product + one sweep (cg_start_scaled_stored)
   long surplus_iters;       // iterations enqueued after the last column had retired (no-ops on the data, but they stream)
 };
 static HipBpcg g_bpcg = {30, 1e-2, 1e-14, "abs", {nullptr, nullptr, nullptr, nullptr}, {nullptr}, 0, 0, 0, 0, -1.0, 0, 0, nullptr, nullptr, nullptr, 0};
@@ -526,6 +576,28 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
         gcge_hip_cg_start_scaled_mv(mat, mv_x, start_bx[1], rhs_scale, s->mv_ws[0], s->mv_ws[1], 0, nrhs, rho2.data()) == 0) {
       reduce_over_ranks(rho2.data(), nrhs);
       p0_done = true;
+    } else if (0 != strcmp(s->tol_type, "rel") && sigma == 0.0 && mat != nullptr && nrhs <= 512 && getenv("GCGE_CG_NO_FUSED_START") == nullptr &&
+               cg_vec_ok(nrhs, {dw, dr, dp, dx}, {ldw, ldr, ldp, ldx})) {
+      // matrices whose product is stored (no pattern form): w = A x, then one sweep for r = x diag(scale) - w, p0 = r, r.r
+      // (cg_start_scaled_stored: 4 block streams behind the product instead of 10)
+      apply(mv_x, start_bx[1], s->mv_ws[2], 0, nrhs, nullptr);
+      long nb0 = ((long)n + 255) / 256; if (nb0 > 2048) nb0 = 2048;
+      const long rpb0 = (((long)n + nb0 - 1) / nb0 + 3) / 4 * 4;
+      nb0 = ((long)n + rpb0 - 1) / rpb0;
+      hipStream_t st0 = (hipStream_t)gcge_hip_stream();
+      double* part = gcge_hip_partial_ws((size_t)nb0 * nrhs + nrhs);
+      GCGE_HIP_CHECK(hipStreamSynchronize(st0));          // the pinned staging may still feed an earlier upload
+      memcpy(s->h_pin, rhs_scale, nrhs * sizeof(double));
+      GCGE_HIP_CHECK(hipMemcpyAsync(s->d_coef, s->h_pin, nrhs * sizeof(double), hipMemcpyHostToDevice, st0));
+      hipLaunchKernelGGL(cg_start_scaled_stored<4>, dim3((unsigned)nb0), dim3(256), 0, st0, (long)n, (const double*)dx, ldx, (const double*)dw, ldw,
+                         dr, ldr, dp, ldp, nrhs, (const double*)s->d_coef, part, cg_tpr(nrhs));
+      gcge_hip_reduce_partials(part, (int)nb0, nrhs, part + (size_t)nb0 * nrhs, st0);
+      GCGE_HIP_CHECK(hipMemcpyAsync(s->h_pin, part + (size_t)nb0 * nrhs, nrhs * sizeof(double), hipMemcpyDeviceToHost, st0));
+      GCGE_HIP_CHECK(hipStreamSynchronize(st0));
+      memcpy(rho2.data(), s->h_pin, nrhs * sizeof(double));
+      reduce_over_ranks(rho2.data(), nrhs);
+      p0_done = true;
+      ++s->fused_starts;
     } else {
       st2[0] = start_bx[1]; en2[0] = end_bx[1]; st2[1] = start_bx[0]; en2[1] = end_bx[0];
       ops->MultiVecAxpby(1.0, mv_x, 0.0, mv_b, st2, en2, ops);
@@ -961,6 +1033,7 @@ extern "C" long gcge_hip_bpcg_recompute_iters(void) { return g_bpcg.recompute_it
 extern "C" long gcge_hip_bpcg_device_scalar_iters(void) { return g_bpcg.dev_scalar_iters; }
 extern "C" long gcge_hip_bpcg_implicit_r_iters(void) { return g_bpcg.implicit_r_iters; }
 extern "C" long gcge_hip_bpcg_stored_dev_iters(void) { return g_bpcg.stored_dev_iters; }
+extern "C" long gcge_hip_bpcg_fused_starts(void) { return g_bpcg.fused_starts; }
 extern "C" void gcge_hip_bpcg_time_stats(long* iters, double* seconds, int reset) {
   if (iters) *iters = g_bpcg.total_iters;
   if (seconds) *seconds = g_bpcg.total_seconds;

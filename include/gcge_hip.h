@@ -148,6 +148,9 @@ long gcge_hip_bpcg_device_scalar_iters (void);
 /* iterations of that device-scalar loop with the product STORED (matrices without a pattern form, no shift: product + column sums
  * left on the device by gcge_hip_spmm_dot2_dev, then one sweep over w and the directions); GCGE_CG_STORED_HOST=1: host scalars */
 long gcge_hip_bpcg_stored_dev_iters (void);
+/* solves with right-hand sides b = x diag(scale) (GCGE_SetLinearSolverRhsScale) on such a matrix that started as product + ONE sweep
+ * (r = x diag(scale) - A x, p0 = r, r.r) instead of forming b; GCGE_CG_NO_FUSED_START=1 switches it off */
+long gcge_hip_bpcg_fused_starts (void);
 /*     y[:, cy : cy + m) = A x[:, cx : cx + m) with d_out[0, m) = x.y and d_out[m, 2m) = y.y (local rows) left on the device, nothing
  *     waited for; -1 (nothing touched): odd widths / offsets or unaligned blocks                                                */
 int gcge_hip_spmm_dot2_dev (void *mat, void **x, void **y, int cx, int cy, int m, double *d_out);

