@@ -561,6 +561,8 @@ static long pat_ntiles(long nrows, long line) {
 // enough for the +-N rows to still be in the 32 KB L1.  Default: 4 consecutive slices (line = 8).
 // chain + line exchange: most waves per block to try (16, 8, 4; measured 3.20 / 3.37 / 3.67 ms at 256^3 x 64);
 // 0: use the plain chain kernel
+static int g_pass_streams = 0;   // > 1: the 16-column passes of a CG sweep on that many side streams (gcge_hip_pattern_cg_vals)
+extern "C" void gcge_hip_cg_pass_streams(int n) { g_pass_streams = n < 0 ? 0 : (n > 4 ? 4 : n); }
 static int g_chain2_nw = 16;
 static int g_chain2_xcd = 2;   // 2: runs of 4 neighbouring tiles per XCD (pass 2 6.50 -> 6.42 ms, fabric reads down); 1: one contiguous eighth of
                                // the tiles per XCD (slower: 3.43 vs 3.19 ms at 256^3); 0: tiles in block order
@@ -801,10 +803,28 @@ extern "C" int gcge_hip_pattern_cg_vals(int mode, int nrows, const unsigned shor
   const long yyo = (long)nb * 16 * npass;
   // read-only passes on a [-S, 0, +S, -L, +L, -1, +1] table: the LDS-ring sweep (spmm_ring.hip), same geometry and workspace
   bool ring = near && lt == 7 && nw >= 4 && (mode == 2 || mode == 4) && d_rowval == nullptr;
+  // The column passes are independent (their own columns, their own partial sums): g_pass_streams > 1 puts them on that many
+  // side streams between a fork and a join on `stream` (gcge_hip_cg_pass_streams; measured in profiles/r04_bench).
+  static hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+  static hipEvent_t ev_fork = nullptr, ev_join[4];
+  const hipStream_t st_main = st;
+  const int nside = (g_pass_streams > 1 && npass > 1) ? std::min(g_pass_streams, std::min(npass, 4)) : 0;
+  if (nside > 0) {
+    if (ev_fork == nullptr) {
+      GCGE_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+      for (int q = 0; q < 4; ++q) { GCGE_HIP_CHECK(hipStreamCreateWithFlags(&side[q], hipStreamNonBlocking)); GCGE_HIP_CHECK(hipEventCreateWithFlags(&ev_join[q], hipEventDisableTiming)); }
+    }
+    GCGE_HIP_CHECK(hipEventRecord(ev_fork, st_main));
+    for (int q = 0; q < nside; ++q) GCGE_HIP_CHECK(hipStreamWaitEvent(side[q], ev_fork, 0));
+  }
+  auto join = [&]() {
+    for (int q = 0; q < nside; ++q) { GCGE_HIP_CHECK(hipEventRecord(ev_join[q], side[q])); GCGE_HIP_CHECK(hipStreamWaitEvent(st_main, ev_join[q], 0)); }
+  };
   for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
     const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
     double* pp = part + (size_t)ps * nb * 16;
     long rc;
+    if (nside > 0) st = side[ps % nside];
     if (ring) {
       if (gcge_hip_ring_pass(mode, nrows, d_pid, d_tab, npat, L, nw, nb, d_x + c0, ldx, m, pp, yyo, mode == 4 ? d_alpha + c0 : nullptr, st, near, nullptr, 0) == 0) continue;
       ring = false;   // declined (first pass): the chain2 kernel below
@@ -826,8 +846,10 @@ extern "C" int gcge_hip_pattern_cg_vals(int mode, int nrows, const unsigned shor
       const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0, nullptr, 0, d_rowval};
       rc = pat_dispatch<3>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
     }
-    if (rc < 0) return -1;
+    if (rc < 0) { join(); return -1; }
   }
+  join();
+  st = st_main;
   gcge_hip_reduce_partials16(part, (int)nb, nb * 16, ncols, d_dots, st);
   if (mode == 2 && d_dots_yy) gcge_hip_reduce_partials16(part + yyo, (int)nb, nb * 16, ncols, d_dots_yy, st);
   return (int)hipGetLastError();

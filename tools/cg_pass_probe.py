@@ -30,6 +30,8 @@ if os.environ.get("RING_WIDE"):
     g.gcge_hip_spmm_ring_wide(int(os.environ["RING_WIDE"]))
 if os.environ.get("RING_XCD"):
     g.gcge_hip_spmm_ring_xcd(int(os.environ["RING_XCD"]))
+if os.environ.get("PASS_STREAMS"):   # the 16-column passes of a CG sweep on that many side streams (0 / 1: one after the other)
+    g.gcge_hip_cg_pass_streams(int(os.environ["PASS_STREAMS"]))
 if os.environ.get("CHAIN2_NW"):
     g.gcge_hip_spmm_chain2_tune(int(os.environ["CHAIN2_NW"]))
 vr = int(os.environ.get("R_COLS", vc))      # width of the block r sits in (p, p', w: V_COLS)
