@@ -256,3 +256,20 @@ def test_star_split_on_a_masked_grid():
     g.gcge_hip_star_selfcheck.restype = C.c_long
     assert g.gcge_hip_star_selfcheck(A.nrows, A.ncols, A.rowptr, A.colidx, A.val, out) == -1
     assert g.gcge_hip_star_selfcheck_grid(A.nrows, A.rowptr, A.colidx, A.val, G + 1, G, G, box.ctypes.data_as(ip_), out) == -1
+
+
+def test_pmc_traffic_file_matches_the_kernel_sources():
+    """profiles/pmc_traffic.json is keyed to a hash of the kernel sources it was measured on; bench.py quotes `roofline.traffic`
+    only while the hash matches (a stale file yields null).  This guard fails when a kernel source was edited after the last
+    measurement: re-run tools/pmc_traffic.py (CG passes) / tools/prof_tile.sh with PROBE=tools/star_ab_probe.py (the sweep) on the
+    GPU box and refresh the file."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_guard", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    t, note = b.pmc_traffic("spmm_pattern_chain2<7,7,16,false>", 256, 64)
+    assert t is not None and 0.9 * 25.9e9 < t < 1.3 * 25.9e9, (t, note)
+    t5, note5 = b.pmc_traffic_c5(171, "2000,2.0,5.0", 64)
+    assert t5 is not None and 8e9 < t5 < 14e9, (t5, note5)
