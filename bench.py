@@ -68,6 +68,11 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dense-shapes", action="store_true", help="after the timed steps, print the in-solve rate of the Gram / panel-update kernels per shape (k, m) on stderr")
     ap.add_argument("--orth", default="chol", help="block orthonormalisation scheme for X and W: chol | mgs | bgs")
+    ap.add_argument("--amg", type=int, default=0,
+                    help="levels (>= 2) of the multigrid hierarchy: the W systems are solved by BlockAMG (one V-cycle, fused block CG as the "
+                         "smoother; reference src/ops_lin_sol.c:466-715 set up as test/test_eig_sol_SiO2_MAT.c:96-128) instead of 30 block-CG "
+                         "iterations; 0 = plain block CG")
+    ap.add_argument("--amg-smooth", default="5,4", help="CG smoothing iterations before and after the coarse correction: finest level, coarser levels")
     a = ap.parse_args()
     if a.config == "c4":
         a.nev, a.block, a.nevmax = 200, 128, 400
@@ -352,6 +357,22 @@ def main():
             raise SystemExit("bench.py rank %d: exchange check FAILED over transport '%s': %.12g != %.12g" % (rank, transport, got[0], want))
     if world > 1:
         signal.alarm(0)
+    # the multigrid hierarchy behind BlockAMG (--amg L): set-up like the matrix upload (the reference's SiO2 driver builds it before
+    # EigenSolverSetup_GCG, test/test_eig_sol_SiO2_MAT.c:96-128); created BEFORE the blocks below so that the fused CG sizes its
+    # direction rings from what is left
+    amg, amg_setup_seconds, amg_levels = None, None, None
+    if args.amg >= 2:
+        if world > 1:
+            raise SystemExit("bench.py: --amg is one-rank only (the hierarchy of a row slab is not built yet)")
+        s0, s1 = (int(v) for v in args.amg_smooth.split(","))
+        hip.h.GCGE_AMGCreate.restype = C.c_void_p
+        hip.h.GCGE_AMGCreate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        hip.h.GCGE_AMGInstall.argtypes = [C.c_void_p, C.c_void_p]
+        t_a = time.perf_counter()
+        amg = C.c_void_p(hip.h.GCGE_AMGCreate(mat, None, args.amg, args.block, 1, s0, s1, 1e-2, hip.ops_handle))
+        hip.sync()
+        amg_setup_seconds = time.perf_counter() - t_a
+        amg_levels = C.cast(amg, C.POINTER(C.c_int * 8)).contents[6]     # GCGE_AMG: three pointers, then num_levels
     # memory set-up, like the matrix upload: hipMalloc of the 17-34 GB work blocks costs 0.2-0.3 s each on a fresh
     # process, so the blocks one solve needs (V, eigenvectors, 3 work blocks, 3 CG blocks) are allocated once here and
     # handed back to the back-end's size-keyed pool, from which the solver's MultiVecCreateByMat calls take them
@@ -370,6 +391,8 @@ def main():
     hip.sync()
     hip.set_random_mode(1, 20240601)          # device generator: 2e9 rand() calls would dominate at this n
     g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    if amg is not None:
+        hip.h.GCGE_AMGInstall(amg, hip.ops_handle)    # ops->MultiLinearSolver = BlockAMG (its smoother: the fused CG, per level)
     solver_args = ["-nevConv", args.nev, "-nevMax", args.nevmax, "-blockSize", args.block,
                    "-gcge_initX_orth_method", args.orth, "-gcge_compW_orth_method", args.orth]
 
@@ -537,8 +560,12 @@ def main():
         r_upd, upd_more = dense_roof(1, "lincomb_mfma (v_mfma_f64_16x16x4_f64)", "K3 panel update Y = X C + Y diag(beta) (k x m coefficients) of MultiVecLinearComb")
         cands = [r for r in (r_k1, r_p1, r_p2) if r is not None]
         dominant = max(cands, key=lambda r: r["share_of_step"]) if cands else None
-        cfg = {"workload": "%s, nev=%d, block=%d, nevMax=%d, B=NULL, tol abs 1e-1 rel 1e-8, fused device block-CG (30 its, rate 1e-2), "
-                           "X/W orthonormalisation '%s', device RNG start block" % (workload, args.nev, args.block, args.nevmax, args.orth),
+        wsolver = ("fused device block-CG (30 its, rate 1e-2)" if amg is None else
+                   "BlockAMG (%d levels of 2x2x2 aggregates, 1 V-cycle, %s fused-CG smoothing its before and after the coarse correction, rate 1e-2)"
+                   % (amg_levels, args.amg_smooth.replace(",", " / ")))
+        cfg = {"workload": "%s, nev=%d, block=%d, nevMax=%d, B=NULL, tol abs 1e-1 rel 1e-8, %s, "
+                           "X/W orthonormalisation '%s', device RNG start block" % (workload, args.nev, args.block, args.nevmax, wsolver, args.orth),
+               "amg_levels": amg_levels, "amg_setup_seconds": amg_setup_seconds,
                "gcg_iterations": iters, "nev_converged": conv_total,
                "cg_active_column_fraction": (ai.value / ci.value) if ci.value else None,
                "cg_iterations": cg_its.value, "ms_per_cg_iteration": 1e3 * cg_sec.value / cg_its.value if cg_its.value else None,

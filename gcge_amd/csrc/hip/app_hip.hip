@@ -394,6 +394,7 @@ static GcgeHipMV* mv_new(int nrows, int nghost, int ncols, const GCGE_HIP_MAT_* 
 }
 static void HIP_MultiVecCreateByMat(void*** mv, int num_vec, void* mat, struct OPS_* ops) {
   const GCGE_HIP_MAT_* A = (const GCGE_HIP_MAT_*)mat;
+  if (A->rect_ncols > 0) { *mv = (void**)mv_new(A->rect_ncols, 0, num_vec, nullptr); return; }   // app_ccs.c:43: rows = the matrix's COLUMNS
   *mv = (void**)mv_new(A->nrows, A->nghost, num_vec, A);
 }
 static void HIP_MultiVecCreateByMultiVec(void*** mv, int num_vec, void** src, struct OPS_* ops) {
@@ -844,6 +845,12 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
   if (m <= 0) return;
   GCGE_REQUIRE(vx != vy || end[0] <= start[1] || end[1] <= start[0], "MatDotMultiVec: x and y ranges must not overlap");
   GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols && start[1] >= 0 && end[1] <= vy->ncols, "MatDotMultiVec: column ranges");
+  if (A != nullptr && A->rect_ncols > 0) {   // a prolongation of the multigrid hierarchy (multigrid.hip): rows of level l x rows of level l + 1
+    GCGE_REQUIRE(vx->nrows == A->rect_ncols && vy->nrows == A->nrows, "MatDotMultiVec: shapes of a rectangular matrix");
+    GCGE_REQUIRE(gcge_hip_csr_spmm(A->nrows, A->d_rowptr, A->d_colidx, A->d_val, vx->d + start[0], vx->ld, vy->d + start[1], vy->ld, m, g_stream) == 0,
+                 "MatDotMultiVec: kernel launch (rectangular matrix)");
+    return;
+  }
   GCGE_REQUIRE(vx->nrows == vy->nrows, "MatDotMultiVec: equal row counts");
   if (A != nullptr) GCGE_REQUIRE(A->nrows == vy->nrows && A->nrows + A->nghost <= vx->nrows_alloc, "MatDotMultiVec: matrix/vector shapes");
   if (A == nullptr) {
@@ -986,14 +993,22 @@ __global__ void dot2_sum_kernel(int m, const double* __restrict__ a0, const doub
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < m) { out[j] = a0[j] + (b0 != nullptr ? b0[j] : 0.0); out[m + j] = a1[j] + (b1 != nullptr ? b1[j] : 0.0); }
 }
+// 1: gcge_hip_spmm_dot2_dev takes these operands (its contract, for callers that must decide BEFORE touching anything)
+extern "C" int gcge_hip_spmm_dot2_dev_ok(void* mat, void** x, void** y, int cx, int cy, int m) {
+  const GCGE_HIP_MAT_* A = (const GCGE_HIP_MAT_*)mat;
+  const GcgeHipMV *vx = (const GcgeHipMV*)x, *vy = (const GcgeHipMV*)y;
+  if (A == nullptr || A->rect_ncols > 0 || vx == nullptr || vy == nullptr) return 0;
+  if (m <= 0 || (m & 1) || (cx & 1) || (cy & 1) || (vx->ld & 1) || (vy->ld & 1) || vx == vy) return 0;
+  if (((uintptr_t)(vx->d + cx) & 15) || ((uintptr_t)(vy->d + cy) & 15)) return 0;
+  if (vx->nrows != vy->nrows || A->nrows != vy->nrows || A->nrows + A->nghost > vx->nrows_alloc) return 0;
+  if (A->nghost > 0 && m > A->buf_cols) return 0;
+  return 1;
+}
 extern "C" int gcge_hip_spmm_dot2_dev(void* mat, void** x, void** y, int cx, int cy, int m, double* d_out) {
   enter();
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
-  if (A == nullptr || m <= 0 || (m & 1) || (cx & 1) || (cy & 1) || (vx->ld & 1) || (vy->ld & 1) || vx == vy) return -1;
-  if (((uintptr_t)(vx->d + cx) & 15) || ((uintptr_t)(vy->d + cy) & 15)) return -1;
-  if (vx->nrows != vy->nrows || A->nrows != vy->nrows || A->nrows + A->nghost > vx->nrows_alloc) return -1;
-  if (A->nghost > 0 && m > A->buf_cols) return -1;
+  if (!gcge_hip_spmm_dot2_dev_ok(mat, x, y, cx, cy, m)) return -1;
   GCGE_REQUIRE(cx >= 0 && cx + m <= vx->ncols && cy >= 0 && cy + m <= vy->ncols, "spmm_dot2_dev: column ranges");
   SpmmEvent ev;
   if (g_prof_on) {
@@ -1268,9 +1283,21 @@ static int HIP_ResidualSq(void* mat, void* matB, void** x, int start, int end, c
 
 extern "C" void* gcge_hip_residual_hook(void) { return (void*)HIP_ResidualSq; }   /* for tests */
 
-// app_ccs.c:140-150 — symmetric matrices only
+// app_ccs.c:140-150 — symmetric matrices: the product itself; a rectangular matrix (a prolongation P_l, used transposed as the
+// restriction by DefaultMultiVecFromItoJ, src/ops_multi_grid.c:95-113) through the transposed CSR triple kept beside it
 static void HIP_MatTransDotMultiVec(void* mat, void** x, void** y, int* start, int* end, struct OPS_* ops) {
-  HIP_MatDotMultiVec(mat, x, y, start, end, ops);
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
+  if (A == nullptr || A->rect_ncols == 0) { HIP_MatDotMultiVec(mat, x, y, start, end, ops); return; }
+  GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
+  const int m = end[0] - start[0];
+  enter();
+  SlotTimer tm_("MatTransDotMultiVec", m);
+  GCGE_REQUIRE(m == end[1] - start[1], "MatTransDotMultiVec: equal column counts");
+  if (m <= 0) return;
+  GCGE_REQUIRE(start[0] >= 0 && end[0] <= vx->ncols && start[1] >= 0 && end[1] <= vy->ncols, "MatTransDotMultiVec: column ranges");
+  GCGE_REQUIRE(vx != vy && vx->nrows == A->nrows && vy->nrows == A->rect_ncols, "MatTransDotMultiVec: shapes of a rectangular matrix");
+  GCGE_REQUIRE(gcge_hip_csr_spmm(A->rect_ncols, A->d_t_rowptr, A->d_t_colidx, A->d_t_val, vx->d + start[0], vx->ld, vy->d + start[1], vy->ld, m, g_stream) == 0,
+               "MatTransDotMultiVec: kernel launch (rectangular matrix)");
 }
 
 // Local part + sum over the ranks of the communicator registered at call time (GCGE_GetComm(): RCCL inside the back-end,
@@ -1345,4 +1372,8 @@ extern "C" void OPS_HIP_Set(struct OPS_* ops) {
   }
   ops->MatTransDotMultiVec      = HIP_MatTransDotMultiVec;
   ops->MultiVecQtAP             = HIP_MultiVecQtAP;
+  // the hierarchy behind BlockAMG (src/ops.h:134-139; multigrid.hip) and the fused device CG as its smoother for THIS table
+  ops->MultiGridCreate          = gcge_hip_multigrid_create;
+  ops->MultiGridDestroy         = gcge_hip_multigrid_destroy;
+  GCGE_SetBlockAMGSmoother(gcge_hip_amg_smoother_setup, gcge_hip_amg_smoother_residual, (void*)HIP_MatDotMultiVec);
 }

@@ -65,6 +65,7 @@ extern "C" int gcge_hip_cg_start_mv(void* mat, void** x, int xc0, void** b, int 
 extern "C" int gcge_hip_cg_pass1_mv(void* mat, void** p, int c0, int m, double* host_pw, double* host_ww);
 extern "C" int gcge_hip_cg_pass1_dev(void* mat, void** p, int c0, int m, double* d_out);
 extern "C" int gcge_hip_spmm_dot2_dev(void* mat, void** x, void** y, int cx, int cy, int m, double* d_out);
+extern "C" int gcge_hip_spmm_dot2_dev_ok(void* mat, void** x, void** y, int cx, int cy, int m);
 extern "C" int gcge_hip_cg_pass2_dev(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
                                      const double* d_beta, const int* d_flag, double* d_rho);
 extern "C" int gcge_hip_cg_pass2_mv(void* mat, void** p, void** r, void** pnew, int c0, int m, const double* d_alpha,
@@ -453,9 +454,35 @@ static void reduce_over_ranks(double* v, int n) {
   if (c != nullptr && n > 0) c->allreduce_sum(v, n, c->ctx);
 }
 
-// r, p, w (and the shift's scratch block on demand) for this problem shape; a change of shape drops the ring
+// r, p, w (and the shift's scratch block on demand) for this problem shape.  A solver that alternates between systems of different
+// size — the levels of a multigrid cycle (BlockAMG smooths every level with this CG) — must not rebuild its blocks and ring on
+// every call: the set of the shape that is left is PARKED (up to 8 row counts) and taken out again when that shape comes back.
+// A change of the column count within a shape drops that shape's ring, as before.
+struct BpcgParked { void** mv_ws[4]; void** ring[17]; int ring_len, ws_cols, ws_rows; };
+static BpcgParked g_parked[8]; static int g_nparked = 0;
+static void bpcg_destroy_set(BpcgParked* q, struct OPS_* ops) {
+  for (int i = 1; i < q->ring_len; ++i) if (q->ring[i]) ops->MultiVecDestroy(&q->ring[i], q->ws_cols, ops);
+  for (int i = 0; i < 4; ++i) if (q->mv_ws[i]) ops->MultiVecDestroy(&q->mv_ws[i], q->ws_cols, ops);
+  memset(q, 0, sizeof *q);
+}
 static void bpcg_shape(HipBpcg* s, int n, int nrhs, void** mv_x, struct OPS_* ops) {
   if (s->ws_cols >= nrhs && s->ws_rows == n) return;
+  if (s->ws_rows != n) {
+    if (s->ws_rows > 0 && s->mv_ws[0] != nullptr) {          // park the current set
+      if (g_nparked == 8) { bpcg_destroy_set(&g_parked[0], ops); memmove(&g_parked[0], &g_parked[1], 7 * sizeof(BpcgParked)); --g_nparked; }
+      BpcgParked* q = &g_parked[g_nparked++];
+      memcpy(q->mv_ws, s->mv_ws, sizeof q->mv_ws); memcpy(q->ring, s->ring, sizeof q->ring);
+      q->ring_len = s->ring_len; q->ws_cols = s->ws_cols; q->ws_rows = s->ws_rows;
+      memset(s->mv_ws, 0, sizeof s->mv_ws); memset(s->ring, 0, sizeof s->ring); s->ring_len = 0; s->ws_cols = 0; s->ws_rows = 0;
+    }
+    for (int i = 0; i < g_nparked; ++i) if (g_parked[i].ws_rows == n) {     // a parked set of this row count comes back
+      memcpy(s->mv_ws, g_parked[i].mv_ws, sizeof s->mv_ws); memcpy(s->ring, g_parked[i].ring, sizeof s->ring);
+      s->ring_len = g_parked[i].ring_len; s->ws_cols = g_parked[i].ws_cols; s->ws_rows = n;
+      memmove(&g_parked[i], &g_parked[i + 1], (size_t)(g_nparked - 1 - i) * sizeof(BpcgParked)); --g_nparked;
+      break;
+    }
+    if (s->ws_cols >= nrhs && s->ws_rows == n) return;
+  }
   for (int i = 1; i < s->ring_len; ++i) if (s->ring[i]) ops->MultiVecDestroy(&s->ring[i], s->ws_cols, ops);
   s->ring_len = 0;
   for (int i = 0; i < 4; ++i) {
@@ -469,7 +496,10 @@ static void bpcg_ring(HipBpcg* s, void* mat, void** mv_x, double sigma, struct O
   (void)gcge_hip_mv_device_ptr(s->mv_ws[1], &ldp);
   // p-ring (see cg_update_rp): as many slots as memory allows, at most 16; fewer than 4 pending terms do not pay
   const int ring_max = getenv("GCGE_CG_RING") ? atoi(getenv("GCGE_CG_RING")) : 16;   // (read when a ring is created)
-  if (s->ring_len == 0 && s->max_iter >= 8) {   // (every rank gets here in the same call: the vote below is collective)
+  // (a ring that was created for a solver with fewer iterations — the smoothing runs of a multigrid cycle — grows when a later
+  //  set-up asks for more)
+  const int have = s->ring_len > 0 ? s->ring_len - 1 : 0;
+  if (s->max_iter >= 3 && have < 15 && have < s->max_iter) {   // (every rank gets here in the same call: the vote below is collective)
     size_t fr = 0, tot = 0;
     GCGE_HIP_CHECK(hipMemGetInfo(&fr, &tot));
     fr += gcge_hip_pool_cached_bytes();   // blocks parked in the back-end's pool are available to MultiVecCreate*
@@ -484,6 +514,8 @@ static void bpcg_ring(HipBpcg* s, void* mat, void** mv_x, double sigma, struct O
     // streams against the 9 of the ring-less sweep)
     const int min_ring = (sigma == 0.0 && gcge_hip_cg_recompute_pays(mat)) ? 2 : 4;
     if (want < min_ring) want = 0;
+    want += have;                                  // (slots this shape already holds are not "free memory" any more)
+    if (want > ring_max - 1) want = ring_max - 1;
     if (want > s->max_iter) want = s->max_iter;
     // Row-partitioned runs: the ring length decides the column window [alo, ahi) and with it the LENGTH of the two
     // all-reduces of an iteration, so every rank must use the same one — the minimum over the ranks (free memory
@@ -497,9 +529,8 @@ static void bpcg_ring(HipBpcg* s, void* mat, void** mv_x, double sigma, struct O
       while (agreed < 16 && vote[agreed] > (double)c->size - 0.5) ++agreed;
       want = agreed;
     }
-    s->ring[0] = s->mv_ws[1]; s->ring_len = 1;
-    if (want >= 1)
-      for (long i = 0; i < want; ++i) { ops->MultiVecCreateByMultiVec(&s->ring[s->ring_len], s->ws_cols, mv_x, ops); ++s->ring_len; }
+    if (s->ring_len == 0) { s->ring[0] = s->mv_ws[1]; s->ring_len = 1; }
+    for (long i = have; i < want; ++i) { ops->MultiVecCreateByMultiVec(&s->ring[s->ring_len], s->ws_cols, mv_x, ops); ++s->ring_len; }
   }
 }
 
@@ -725,7 +756,10 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
     // from round 4 on: product + sums left on the device (gcge_hip_spmm_dot2_dev), the direction update reading alpha / beta /
     // flags where cg_scalars_a put them.  Before, every iteration made two host round trips (sums down, coefficients up, new
     // rho down): 0.6 of 6.2 ms per iteration on the SiO2-like matrix.  GCGE_CG_HOST_SCALARS=1: the host loop below.
-    const bool stored_dev = !recompute && R >= 2 && sigma == 0.0 && mat != nullptr && getenv("GCGE_CG_STORED_HOST") == nullptr;
+    // (only where gcge_hip_spmm_dot2_dev will take these operands — a row slab whose halo buffers are narrower than the
+    //  block, or a slot without room for the halo rows, keeps the host-scalar loop, which chunks the columns)
+    const bool stored_dev = !recompute && R >= 2 && sigma == 0.0 && mat != nullptr && getenv("GCGE_CG_STORED_HOST") == nullptr &&
+                            gcge_hip_spmm_dot2_dev_ok(mat, slots[0], s->mv_ws[2], 0, 0, nrhs);
     if ((recompute || stored_dev) && !host_scalars && nact > 0 && s->max_iter <= 4000 && (comm_now == nullptr || gcge_hip_comm_is_native(comm_now))) {
       if (s->sc_cap < nrhs) {
         GCGE_HIP_CHECK(hipStreamSynchronize(st));
@@ -1044,7 +1078,15 @@ extern "C" void gcge_hip_bpcg_column_stats(long* col_iters, long* active_col_ite
   if (active_col_iters) *active_col_iters = g_bpcg.active_col_iters;
 }
 extern "C" long gcge_hip_bpcg_surplus_iters(void) { return g_bpcg.surplus_iters; }
+// the fused CG as the smoother of BlockAMG for the HIP table (GCGE_SetBlockAMGSmoother, registered by OPS_HIP_Set): same stopping
+// rules as MultiLinearSolverSetup_BlockPCG, its own blocks per level (parked sets above)
+extern "C" void gcge_hip_amg_smoother_setup(int max_iter, double rate, double tol, const char* tol_type, struct OPS_* ops) {
+  gcge_hip_bpcg_setup(ops, max_iter, rate, tol, tol_type);
+}
+extern "C" double gcge_hip_amg_smoother_residual(struct OPS_* ops) { (void)ops; return g_bpcg.residual; }
 extern "C" void gcge_hip_bpcg_release(struct OPS_* ops) {
+  for (int i = 0; i < g_nparked; ++i) bpcg_destroy_set(&g_parked[i], ops);
+  g_nparked = 0;
   for (int i = 1; i < g_bpcg.ring_len; ++i) if (g_bpcg.ring[i]) ops->MultiVecDestroy(&g_bpcg.ring[i], g_bpcg.ws_cols, ops);
   g_bpcg.ring_len = 0;
   for (int i = 0; i < 4; ++i)

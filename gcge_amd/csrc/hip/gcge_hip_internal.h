@@ -71,8 +71,16 @@ struct GCGE_HIP_MAT_ {
   void* star;          // grid form (spmm_star.hip): rows that are exactly a star stencil, swept plane by plane; NULL: none
   void* star_rem;      // block form (spmm_dense.hip) of the rows the grid form leaves (multiplied first, writes every row)
   void* native_halo;   // RCCL plan of gcge_hip_mat_set_halo_rccl (rccl_comm.hip); it then owns sendbuf / recvbuf
+  // rectangular matrices (the prolongations P_l of a multigrid hierarchy, multigrid.hip): nrows x rect_ncols in d_rowptr / d_colidx /
+  // d_val, the transpose as a second CSR triple; rect_ncols == 0: an ordinary (symmetric) matrix
+  int rect_ncols; int *d_t_rowptr, *d_t_colidx; double* d_t_val;
 };
 extern "C" void gcge_hip_halo_native_free(struct GCGE_HIP_MAT_* A);
+// multigrid.hip: the MultiGridCreate / MultiGridDestroy slots of OPS_HIP_Set and the block-CG smoother it registers for BlockAMG
+extern "C" void gcge_hip_multigrid_create(void*** A_array, void*** B_array, void*** P_array, int* num_levels, void* A, void* B, struct OPS_* ops);
+extern "C" void gcge_hip_multigrid_destroy(void*** A_array, void*** B_array, void*** P_array, int* num_levels, struct OPS_* ops);
+extern "C" void gcge_hip_amg_smoother_setup(int max_iter, double rate, double tol, const char* tol_type, struct OPS_* ops);
+extern "C" double gcge_hip_amg_smoother_residual(struct OPS_* ops);
 // A column scaling the slots hold back (column-wise Gram-Schmidt, app_hip.hip) is applied now.  First statement of every EXPORTED
 // raw kernel that takes device pointers: the caller may have fetched its pointer before the scaling was held back.
 extern "C" void gcge_hip_apply_pending(void);

@@ -352,6 +352,7 @@ extern "C" void gcge_hip_mat_set_halo_async(GCGE_HIP_MAT* A, gcge_halo_exchange_
 extern "C" void gcge_hip_mat_destroy(GCGE_HIP_MAT* A) {
   if (!A) return;
   hipFree(A->d_rowptr); hipFree(A->d_colidx); hipFree(A->d_val);
+  if (A->rect_ncols > 0) { hipFree(A->d_t_rowptr); hipFree(A->d_t_colidx); hipFree(A->d_t_val); free(A); return; }   // a prolongation (multigrid.hip)
   hipFree(A->d_orp); hipFree(A->d_pcol); hipFree(A->d_pval);
   if (A->d_pid) { hipFree(A->d_pid); hipFree(A->d_tab); }
   if (A->d_rowval) hipFree(A->d_rowval);

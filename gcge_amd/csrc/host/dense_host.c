@@ -321,6 +321,64 @@ static void D_MatTransDotVec(void *mat, void *x, void *y, struct OPS_ *ops)
 static void D_MatView(void *mat, struct OPS_ *ops)
 { DM *m = (DM*)mat; D_MultiVecView((void**)mat, 0, m->ncols, ops); }
 
+/* ------------------------------------------------------------ multigrid (dense toy)
+ * app_lapack.c:863-955: a fixed 1-D hierarchy for testing the multigrid machinery on dense matrices — level l + 1 has
+ * (rows - 1) / 2 rows, P_l is linear interpolation (1 at row 2c + 1, 1/2 at its two neighbours), A_{l+1} = P_l^T A_l P_l (B alike). */
+static DM *dm_new(int nrows, int ncols)
+{
+	DM *m = (DM*)malloc(sizeof(DM));
+	m->nrows = nrows; m->ncols = ncols; m->ldd = nrows;
+	m->data = (double*)calloc((size_t)nrows * (ncols > 0 ? ncols : 1), sizeof(double));
+	return m;
+}
+static void dm_ptap(const DM *P, const DM *A, DM *C)      /* C = P^T A P */
+{
+	const int nf = P->nrows, nc = P->ncols; int i, j, k;
+	double *t = (double*)calloc((size_t)nf * nc, sizeof(double));
+	for (j = 0; j < nc; ++j)
+		for (k = 0; k < nf; ++k) {
+			const double pkj = P->data[(size_t)P->ldd * j + k];
+			if (pkj != 0.0) axpyn(nf, pkj, A->data + (size_t)A->ldd * k, t + (size_t)nf * j);
+		}
+	for (j = 0; j < nc; ++j)
+		for (i = 0; i < nc; ++i) C->data[(size_t)C->ldd * j + i] = dotn(nf, P->data + (size_t)P->ldd * i, t + (size_t)nf * j);
+	free(t);
+}
+static void D_MultiGridCreate(void ***A_array, void ***B_array, void ***P_array, int *num_levels, void *A, void *B, struct OPS_ *ops)
+{
+	int level, nrows = ((DM*)A)->nrows, ncols = (nrows - 1) / 2, col;
+	ops->Printf("Just a test, P is fixed\n");
+	*A_array = (void**)calloc(*num_levels, sizeof(void*));
+	*P_array = (void**)calloc(*num_levels > 1 ? *num_levels - 1 : 1, sizeof(void*));
+	if (B != NULL) *B_array = (void**)calloc(*num_levels, sizeof(void*));
+	(*A_array)[0] = A;
+	if (B != NULL) (*B_array)[0] = B;
+	for (level = 1; level < *num_levels; ++level) {
+		DM *P = dm_new(nrows, ncols), *Ac = dm_new(ncols, ncols);
+		for (col = 0; col < ncols; ++col) {
+			P->data[(size_t)nrows * col + 2 * col + 1] = 1.0;
+			P->data[(size_t)nrows * col + 2 * col] = 0.5;
+			P->data[(size_t)nrows * col + 2 * col + 2] = 0.5;
+		}
+		dm_ptap(P, (DM*)(*A_array)[level - 1], Ac);
+		(*P_array)[level - 1] = P; (*A_array)[level] = Ac;
+		if (B != NULL) { DM *Bc = dm_new(ncols, ncols); dm_ptap(P, (DM*)(*B_array)[level - 1], Bc); (*B_array)[level] = Bc; }
+		nrows = ncols; ncols = (nrows - 1) / 2;
+	}
+}
+static void D_MultiGridDestroy(void ***A_array, void ***B_array, void ***P_array, int *num_levels, struct OPS_ *ops)
+{
+	int level;
+	for (level = 1; level < *num_levels; ++level) {
+		DM *a = (DM*)(*A_array)[level], *p = (DM*)(*P_array)[level - 1];
+		free(a->data); free(a); free(p->data); free(p);
+		if (B_array != NULL && *B_array != NULL) { DM *b = (DM*)(*B_array)[level]; free(b->data); free(b); }
+	}
+	free(*A_array); *A_array = NULL;
+	free(*P_array); *P_array = NULL;
+	if (B_array != NULL && *B_array != NULL) { free(*B_array); *B_array = NULL; }
+}
+
 void OPS_DENSE_Set(struct OPS_ *ops)
 {
 	ops->Printf                   = DefaultPrintf;
@@ -354,4 +412,6 @@ void OPS_DENSE_Set(struct OPS_ *ops)
 	ops->MultiVecQtAP             = D_MultiVecQtAP;
 	ops->DenseMatQtAP             = DenseMatQtAP;
 	ops->DenseMatOrth             = DenseMatOrth;
+	ops->MultiGridCreate          = D_MultiGridCreate;
+	ops->MultiGridDestroy         = D_MultiGridDestroy;
 }

@@ -130,3 +130,117 @@ void MultiLinearSolverSetup_BlockPCG(int max_iter, double rate, double tol, cons
 	ops->multi_linear_solver_workspace = (void*)&bpcg;
 	ops->MultiLinearSolver = BlockPCG;
 }
+
+/* ---- V-cycle multigrid with block CG as the smoother: the reference's BlockAlgebraicMultiGrid / BlockAMG
+ * (src/ops_lin_sol.c:466-715; set up as in test/test_eig_sol_SiO2_MAT.c:96-180, test/test_multi_grid.c:97-129).
+ * The hierarchy A_array / P_array comes from the back-end's MultiGridCreate slot.  One cycle on level l:
+ *   max_iter[2l + 1] CG iterations on A_l x = b from the current x (pre-smoothing; on the coarsest level that is all),
+ *   r = b - A_l x, restricted by P_l^T to the right-hand side of level l + 1, zero start there, the cycle on level l + 1,
+ *   x += P_l (coarse x), max_iter[2l + 2] CG iterations (post-smoothing).
+ * max_iter[0] cycles at most, stopping once the residual the last smoothing call reports is below tol[0].
+ * Workspace per level (mv_array_ws[i][level], as the reference): 0 coarse right-hand side, 1 coarse x, 2 / 3 / 4 the CG's
+ * r / p / w — 2 doubles as the residual / correction block, 4 as the scratch of MultiVecFromItoJ.
+ *
+ * The smoother is installed through a hook: by default MultiLinearSolverSetup_BlockPCG (the reference's choice,
+ * :482-486,:626-629); a back-end may register its own block CG for ITS table (owner = the table's MatDotMultiVec slot) —
+ * the HIP back-end's fused device CG — with the same stopping rules. */
+static GCGE_SMOOTHER_SETUP_FN g_smoother_fn = NULL; static GCGE_SMOOTHER_RESIDUAL_FN g_smoother_res = NULL;
+static void *g_smoother_owner = NULL;
+void GCGE_SetBlockAMGSmoother(GCGE_SMOOTHER_SETUP_FN setup, GCGE_SMOOTHER_RESIDUAL_FN residual, void *owner)
+{
+	g_smoother_fn = setup; g_smoother_res = residual; g_smoother_owner = owner;
+}
+static int own_smoother(struct OPS_ *ops)
+{
+	return g_smoother_fn != NULL && g_smoother_res != NULL && g_smoother_owner == (void*)ops->MatDotMultiVec &&
+	       getenv("GCGE_AMG_HOST_SMOOTHER") == NULL;
+}
+int GCGE_HasBlockAMGSmoother(struct OPS_ *ops) { return own_smoother(ops); }
+static void smoother_setup(int max_iter, double rate, double tol, const char *tol_type, void **mv_ws[3], double *dbl_ws,
+		int *int_ws, struct OPS_ *ops)
+{
+	if (own_smoother(ops)) g_smoother_fn(max_iter, rate, tol, tol_type, ops);
+	else MultiLinearSolverSetup_BlockPCG(max_iter, rate, tol, tol_type, mv_ws, dbl_ws, int_ws, NULL, NULL, ops);
+}
+/* residual of the smoothing call that ran last (src/ops_lin_sol.c:643: read from the BlockPCG struct behind the table) */
+static double smoother_residual(struct OPS_ *ops)
+{
+	if (own_smoother(ops)) return g_smoother_res(ops);
+	return ((BlockPCGSolver*)ops->multi_linear_solver_workspace)->residual;
+}
+
+static void BlockAlgebraicMultiGrid(int current_level, void **mv_b, void **mv_x, int *start_bx, int *end_bx, struct OPS_ *ops)
+{
+	BlockAMGSolver *bamg = (BlockAMGSolver*)ops->multi_linear_solver_workspace;
+	void (*multi_linear_sol)(void*, void**, void**, int*, int*, struct OPS_*) = ops->MultiLinearSolver;
+	const int coarsest_level = bamg->num_levels - 1, block_size = end_bx[1] - start_bx[1];
+	void *A = bamg->A_array[current_level];
+	void **mv_ws[3], **mv_r, **coarse_b, **coarse_x;
+	int start[2], end[2];
+	assert(end_bx[0] - start_bx[0] == end_bx[1] - start_bx[1]);
+	mv_ws[0] = bamg->mv_array_ws[2][current_level];
+	mv_ws[1] = bamg->mv_array_ws[3][current_level];
+	mv_ws[2] = bamg->mv_array_ws[4][current_level];
+	/* pre-smoothing (the coarsest level's "solve") */
+	smoother_setup(bamg->max_iter[current_level * 2 + 1], bamg->rate[current_level], bamg->tol[current_level],
+			bamg->tol_type, mv_ws, bamg->dbl_ws, bamg->int_ws, ops);
+	ops->MultiLinearSolver(A, mv_b, mv_x, start_bx, end_bx, ops);
+	if (current_level < coarsest_level) {
+		const int coarse_level = current_level + 1;
+		/* r = b - A x */
+		start[0] = start_bx[1]; end[0] = end_bx[1]; start[1] = 0; end[1] = block_size;
+		mv_r = bamg->mv_array_ws[2][current_level];
+		ops->MatDotMultiVec(A, mv_x, mv_r, start, end, ops);
+		start[0] = start_bx[0]; end[0] = end_bx[0]; start[1] = 0; end[1] = block_size;
+		ops->MultiVecAxpby(1.0, mv_b, -1.0, mv_r, start, end, ops);
+		/* restrict, zero start, recurse */
+		coarse_b = bamg->mv_array_ws[0][coarse_level];
+		coarse_x = bamg->mv_array_ws[1][coarse_level];
+		start[0] = 0; end[0] = block_size; start[1] = 0; end[1] = block_size;
+		ops->MultiVecFromItoJ(bamg->P_array, current_level, coarse_level, mv_r, coarse_b, start, end, bamg->mv_array_ws[4], ops);
+		ops->MultiVecAxpby(0.0, NULL, 0.0, coarse_x, start, end, ops);
+		ops->multi_linear_solver_workspace = (void*)bamg;
+		BlockAlgebraicMultiGrid(coarse_level, coarse_b, coarse_x, start, end, ops);
+		/* prolongate and correct */
+		ops->MultiVecFromItoJ(bamg->P_array, coarse_level, current_level, coarse_x, mv_r, start, end, bamg->mv_array_ws[4], ops);
+		start[0] = 0; end[0] = block_size; start[1] = start_bx[1]; end[1] = end_bx[1];
+		ops->MultiVecAxpby(1.0, mv_r, 1.0, mv_x, start, end, ops);
+		/* post-smoothing */
+		smoother_setup(bamg->max_iter[current_level * 2 + 2], bamg->rate[current_level], bamg->tol[current_level],
+				bamg->tol_type, mv_ws, bamg->dbl_ws, bamg->int_ws, ops);
+		ops->MultiLinearSolver(A, mv_b, mv_x, start_bx, end_bx, ops);
+	}
+	bamg->residual = smoother_residual(ops);
+	/* the table's solver is BlockAMG again */
+	ops->multi_linear_solver_workspace = (void*)bamg;
+	ops->MultiLinearSolver = multi_linear_sol;
+}
+
+static void BlockAMG(void *mat, void **mv_b, void **mv_x, int *start_bx, int *end_bx, struct OPS_ *ops)
+{
+	BlockAMGSolver *bamg = (BlockAMGSolver*)ops->multi_linear_solver_workspace;
+	int idx;
+	(void)mat;      /* level 0 of the hierarchy IS the matrix (src/ops_lin_sol.c:477) */
+	for (idx = 0; idx < bamg->max_iter[0]; ++idx) {
+		BlockAlgebraicMultiGrid(0, mv_b, mv_x, start_bx, end_bx, ops);
+		bamg->niter = idx + 1;
+		if (bamg->residual < bamg->tol[0]) break;
+	}
+}
+
+void MultiLinearSolverSetup_BlockAMG(int *max_iter, double *rate, double *tol, const char *tol_type,
+		void **A_array, void **P_array, int num_levels, void ***mv_array_ws[5], double *dbl_ws, int *int_ws,
+		void *pc, struct OPS_ *ops)
+{
+	static BlockAMGSolver bamg;
+	int i;
+	bamg.max_iter = max_iter; bamg.rate = rate; bamg.tol = tol;
+	strncpy(bamg.tol_type, tol_type, sizeof(bamg.tol_type) - 1);
+	bamg.tol_type[sizeof(bamg.tol_type) - 1] = '\0';
+	bamg.A_array = A_array; bamg.P_array = P_array; bamg.num_levels = num_levels;
+	for (i = 0; i < 5; ++i) bamg.mv_array_ws[i] = mv_array_ws[i];
+	bamg.dbl_ws = dbl_ws; bamg.int_ws = int_ws; bamg.pc = pc;
+	bamg.niter = 0; bamg.residual = -1.0;
+	ops->multi_linear_solver_workspace = (void*)&bamg;
+	ops->MultiLinearSolver = BlockAMG;
+}

@@ -165,6 +165,55 @@ void DefaultMultiVecQtAP(char ntsA, char ntsdQAP, void **mvQ, void *matA, void *
 	}
 }
 
+/* ---------------------------------------------------------------- multigrid transfers
+ * src/ops_multi_grid.c:20-117.  P_array[k] maps level k + 1 to level k.  From a coarse level i to a finer level j the vector is
+ * multiplied by P_{i-1}, ..., P_j in turn (MatDot*), from a fine level i to a coarser level j by P_i^T, ..., P_{j-1}^T
+ * (MatTransDot*); the levels in between are staged in the caller's per-level work vectors; i == j copies. */
+void DefaultVecFromItoJ(void **P_array, int level_i, int level_j, void *vec_i, void *vec_j, void **vec_ws, struct OPS_ *ops)
+{
+	void *from, *to; int k;
+	if (level_i > level_j) {
+		for (k = level_i; k > level_j; --k) {
+			from = (k == level_i) ? vec_i : vec_ws[k];
+			to = (k == level_j + 1) ? vec_j : vec_ws[k - 1];
+			ops->MatDotVec(P_array[k - 1], from, to, ops);
+		}
+	} else if (level_i < level_j) {
+		for (k = level_i; k < level_j; ++k) {
+			from = (k == level_i) ? vec_i : vec_ws[k];
+			to = (k == level_j - 1) ? vec_j : vec_ws[k + 1];
+			ops->MatTransDotVec(P_array[k], from, to, ops);
+		}
+	} else {
+		ops->VecAxpby(1.0, vec_i, 0.0, vec_j, ops);
+	}
+}
+void DefaultMultiVecFromItoJ(void **P_array, int level_i, int level_j, void **multi_vec_i, void **multi_vec_j,
+		int *startIJ, int *endIJ, void ***multi_vec_ws, struct OPS_ *ops)
+{
+	void **from, **to; int k, start[2], end[2];
+	const int m = endIJ[0] - startIJ[0];
+	if (level_i > level_j) {
+		for (k = level_i; k > level_j; --k) {
+			if (k == level_i) { from = multi_vec_i; start[0] = startIJ[0]; end[0] = endIJ[0]; }
+			else              { from = multi_vec_ws[k]; start[0] = 0; end[0] = m; }
+			if (k == level_j + 1) { to = multi_vec_j; start[1] = startIJ[1]; end[1] = endIJ[1]; }
+			else                  { to = multi_vec_ws[k - 1]; start[1] = 0; end[1] = m; }
+			ops->MatDotMultiVec(P_array[k - 1], from, to, start, end, ops);
+		}
+	} else if (level_i < level_j) {
+		for (k = level_i; k < level_j; ++k) {
+			if (k == level_i) { from = multi_vec_i; start[0] = startIJ[0]; end[0] = endIJ[0]; }
+			else              { from = multi_vec_ws[k]; start[0] = 0; end[0] = m; }
+			if (k == level_j - 1) { to = multi_vec_j; start[1] = startIJ[1]; end[1] = endIJ[1]; }
+			else                  { to = multi_vec_ws[k + 1]; start[1] = 0; end[1] = m; }
+			ops->MatTransDotMultiVec(P_array[k], from, to, start, end, ops);
+		}
+	} else {
+		ops->MultiVecAxpby(1.0, multi_vec_i, 0.0, multi_vec_j, startIJ, endIJ, ops);
+	}
+}
+
 /* ---------------------------------------------------------------- life cycle */
 void OPS_Create(OPS **ops)
 {
@@ -184,6 +233,8 @@ void OPS_Setup(OPS *ops)
 	if (ops->DenseMatOrth == NULL)      ops->DenseMatOrth = ops->lapack_ops->DenseMatOrth;
 	if (ops->MultiVecInnerProd == NULL) ops->MultiVecInnerProd = DefaultMultiVecInnerProd;
 	if (ops->MultiVecQtAP == NULL)      ops->MultiVecQtAP = DefaultMultiVecQtAP;
+	if (ops->VecFromItoJ == NULL)       ops->VecFromItoJ = DefaultVecFromItoJ;               /* src/ops.c:107-112 */
+	if (ops->MultiVecFromItoJ == NULL)  ops->MultiVecFromItoJ = DefaultMultiVecFromItoJ;
 }
 
 void OPS_Destroy(OPS **ops)

@@ -48,6 +48,19 @@ class HipBackendImpl:
     def free_matrix(self, m):
         self.g.gcge_hip_mat_destroy(m)
 
+    def matrix_rect(self, csr):
+        """A rectangular matrix (a prolongation of a multigrid hierarchy): MatDotMultiVec applies it, MatTransDotMultiVec its
+        transpose (gcge_hip_mat_create_rect_csr, csrc/hip/multigrid.hip)."""
+        self.g.gcge_hip_mat_create_rect_csr.restype = C.c_void_p
+        self.g.gcge_hip_mat_create_rect_csr.argtypes = [C.POINTER(CSR)]
+        m = self.g.gcge_hip_mat_create_rect_csr(C.byref(csr))
+        if not m:
+            raise RuntimeError("gcge_hip_mat_create_rect_csr failed")
+        return C.c_void_p(m)
+
+    def free_matrix_rect(self, m):
+        self.g.gcge_hip_mat_destroy(m)
+
     def mv_from_numpy(self, mat, arr):
         """arr: (n, ncols) array -> device multivector with the same columns."""
         a = np.asfortranarray(arr, dtype=np.float64)

@@ -75,6 +75,18 @@ void gcge_hip_mat_set_halo (GCGE_HIP_MAT *A, int nglobal, int nsend, const int *
 void gcge_hip_mat_set_halo_async (GCGE_HIP_MAT *A, gcge_halo_exchange_fn begin, void (*end) (void *ctx));
 void gcge_hip_set_halo_overlap (int on);
 void gcge_hip_mat_destroy (GCGE_HIP_MAT *A);
+/* ---- multigrid (csrc/hip/multigrid.hip): OPS_HIP_Set fills ops->MultiGridCreate / MultiGridDestroy (reference slots
+ * src/ops.h:134-139; what app/app_slepc.c:648-728 gets from PETSc GAMG): the CSR arrays come back from the device, the
+ * aggregation hierarchy of include/gcge_multigrid.h is built on the host (2 x 2 x 2 cells of a detected grid, greedy aggregates
+ * otherwise, A_{l+1} = scale P^T A_l P; gcge_mg_set_defaults), every level is uploaded like any other matrix, and the fused
+ * block CG is registered as the smoother of BlockAMG for this table (GCGE_SetBlockAMGSmoother, include/gcge_solver.h).
+ * One rank only.  A prolongation is a RECTANGULAR matrix handle: MatDotMultiVec applies P (rows of level l x rows of level
+ * l + 1), MatTransDotMultiVec its transpose (the restriction of src/ops_multi_grid.c:95-113); MultiVecCreateByMat of it gives
+ * blocks with its COLUMN count of rows (app_ccs.c:43).                                                                      */
+GCGE_HIP_MAT *gcge_hip_mat_create_rect (int nrows, int ncols, const int *rowptr, const int *colidx, const double *val,
+		const int *t_rowptr, const int *t_colidx, const double *t_val);      /* CSR of P and CSR of P^T */
+GCGE_HIP_MAT *gcge_hip_mat_create_rect_csr (const GCGE_CSR *P);              /* the transpose is formed here */
+double gcge_hip_multigrid_seconds (void);    /* host + upload time of the last MultiGridCreate */
 int  gcge_hip_mat_nrows (const GCGE_HIP_MAT *A);
 long gcge_hip_mat_nnz (const GCGE_HIP_MAT *A);
 
@@ -154,6 +166,7 @@ long gcge_hip_bpcg_fused_starts (void);
 /*     y[:, cy : cy + m) = A x[:, cx : cx + m) with d_out[0, m) = x.y and d_out[m, 2m) = y.y (local rows) left on the device, nothing
  *     waited for; -1 (nothing touched): odd widths / offsets or unaligned blocks                                                */
 int gcge_hip_spmm_dot2_dev (void *mat, void **x, void **y, int cx, int cy, int m, double *d_out);
+int gcge_hip_spmm_dot2_dev_ok (void *mat, void **x, void **y, int cx, int cy, int m);   /* 1: it takes these operands */
 /* columns the fused solver streamed, summed over its iterations, and how many of them were still active */
 void gcge_hip_bpcg_column_stats (long *col_iters, long *active_col_iters);
 /* CG iterations and host wall time spent inside the fused solver since the last reset (ms per CG iteration) */

@@ -87,7 +87,7 @@ typedef struct OPS_ {
 	/* ---- block orthonormalisation ------------------------------------------ */
 	void (*MultiVecOrth) (void **x, int start_x, int *end_x, void *B, struct OPS_ *ops);
 	void *orth_workspace;
-	/* ---- multigrid transfer (not on the GCG hot path; kept for layout) ------ */
+	/* ---- multigrid: hierarchy from the back-end, transfers through P_array (used by BlockAMG) ------ */
 	void (*MultiGridCreate)  (void ***A_array, void ***B_array, void ***P_array,
 			int *num_levels, void *A, void *B, struct OPS_ *ops);
 	void (*MultiGridDestroy) (void ***A_array, void ***B_array, void ***P_array,
@@ -120,6 +120,11 @@ void   DefaultMultiVecInnerProd (char nsdIP, void **x, void **y, int is_vec,
 void   DefaultMultiVecQtAP (char ntsA, char ntsdQAP, void **mvQ, void *matA, void **mvP,
 		int is_vec, int *startQP, int *endQP, double *qAp, int ldQAP,
 		void **mv_ws, struct OPS_ *ops);
+
+/* multigrid transfers through P_array (reference: src/ops_multi_grid.c:20-117; installed by OPS_Setup, src/ops.c:107-112) */
+void   DefaultVecFromItoJ (void **P_array, int level_i, int level_j, void *vec_i, void *vec_j, void **vec_ws, struct OPS_ *ops);
+void   DefaultMultiVecFromItoJ (void **P_array, int level_i, int level_j, void **multi_vec_i, void **multi_vec_j,
+		int *startIJ, int *endIJ, void ***multi_vec_ws, struct OPS_ *ops);
 
 /* Host dense back-end: column-major blocks in host memory.  Layout-compatible
  * with the reference's LAPACKVEC/LAPACKMAT (app/app_lapack.h:17-20).          */

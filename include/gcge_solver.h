@@ -69,6 +69,47 @@ void MultiLinearSolverSetup_BlockPCG (int max_iter, double rate, double tol,
 		void (*MatDotMultiVec) (void **x, void **y, int *start, int *end, void **z, int s, struct OPS_ *ops),
 		struct OPS_ *ops);
 
+/* ---- V-cycle multigrid with block CG smoothing (sets ops->MultiLinearSolver) ------
+ * The reference's BlockAMG (src/ops_lin_sol.h:47-60, src/ops_lin_sol.c:466-715): same struct, same argument order.
+ * max_iter[0] = V-cycles at most, max_iter[2l + 1] / [2l + 2] = pre- / post-smoothing CG iterations on level l (the
+ * coarsest level only pre-smooths: that is its solve); rate[l], tol[l] the CG's stopping parameters on level l, tol[0]
+ * also the stopping residual of the cycles.  A_array / P_array: num_levels matrices and num_levels - 1 prolongations of
+ * the back-end (ops->MultiGridCreate).  mv_array_ws[i][l]: 0 right-hand side and 1 solution of level l >= 1, 2 / 3 / 4 the
+ * CG's r / p / w on level l (2 also holds the residual and the prolongated correction).                                  */
+typedef struct BlockAMGSolver_ {
+	int    *max_iter; double *rate; double *tol; char tol_type[8];
+	void   **A_array; void **P_array; int num_levels;
+	void   ***mv_array_ws[5]; double *dbl_ws; int *int_ws;
+	void   *pc;
+	int    niter; double residual;
+} BlockAMGSolver;
+void MultiLinearSolverSetup_BlockAMG (int *max_iter, double *rate, double *tol, const char *tol_type,
+		void **A_array, void **P_array, int num_levels, void ***mv_array_ws[5], double *dbl_ws, int *int_ws,
+		void *pc, struct OPS_ *ops);
+/*     The smoother of BlockAMG.  Default: MultiLinearSolverSetup_BlockPCG on the level's r / p / w blocks, as the reference
+ *     (src/ops_lin_sol.c:482-486,626-629).  A back-end may register its own block CG for ITS table (owner = the table's
+ *     MatDotMultiVec slot): setup(max_iter, rate, tol, tol_type, ops) installs it in ops->MultiLinearSolver (it brings its own
+ *     work blocks), residual(ops) returns what BlockPCGSolver.residual would hold after the call.  The HIP back-end
+ *     registers its fused device CG in OPS_HIP_Set; GCGE_AMG_HOST_SMOOTHER=1 keeps the default.                          */
+typedef void   (*GCGE_SMOOTHER_SETUP_FN) (int max_iter, double rate, double tol, const char *tol_type, struct OPS_ *ops);
+typedef double (*GCGE_SMOOTHER_RESIDUAL_FN) (struct OPS_ *ops);
+void GCGE_SetBlockAMGSmoother (GCGE_SMOOTHER_SETUP_FN setup, GCGE_SMOOTHER_RESIDUAL_FN residual, void *owner);
+int  GCGE_HasBlockAMGSmoother (struct OPS_ *ops);      /* 1: a smoother is registered for THIS table and not switched off */
+/*     BlockAMG as the solver of GCG's W systems, the way the reference's SiO2 driver sets it up under OPS_USE_AMG
+ *     (test/test_eig_sol_SiO2_MAT.c:96-128,160-170): hierarchy from ops->MultiGridCreate (at most max_levels), work blocks of
+ *     block_size columns per level, max_iter = {cycles, smooth0, smooth0, smooth, smooth, ...} (reference: {1, 5, 5, 4, 4, ...}),
+ *     rate = {rate0, 1e-16, ...}, tol = {1e-14, 1e-16, ...}, "abs".  Create once (set-up, like the matrix upload), Install
+ *     puts BlockAMG into ops->MultiLinearSolver; run the harness with flag 1.  `-gcge_amg_levels L` makes the harness do all
+ *     of that itself.  NULL: the back-end has no MultiGridCreate.                                                           */
+typedef struct GCGE_AMG_ {
+	void **A_array, **B_array, **P_array; int num_levels, block_size, own_smoother;
+	void ***mv_ws[5]; int *max_iter; double *rate, *tol; double *dbl_ws; int *int_ws;
+} GCGE_AMG;
+GCGE_AMG *GCGE_AMGCreate (void *A, void *B, int max_levels, int block_size, int cycles, int smooth0, int smooth, double rate0,
+		struct OPS_ *ops);
+void GCGE_AMGInstall (GCGE_AMG *amg, struct OPS_ *ops);
+void GCGE_AMGDestroy (GCGE_AMG **amg, struct OPS_ *ops);
+
 /* ---- GCG eigensolver (sets ops->EigenSolver) -------------------------------- */
 typedef struct GCGSolver_ {
 	void   *A; void *B; double sigma;

@@ -12,7 +12,7 @@
  *   src/ops_multi_vec.c  DefaultMultiVecQtAP :351-411 (A P staged in mv_ws)
  * BLAS calls are written out as loops (deliberately naive: this is the checker).
  *
- * Parity pin: tests/test_oracle_vs_ref.py compares every slot and whole GCG runs
+ * Parity pin: tests/test_oracle_golden.py compares every slot and whole GCG runs
  * with the real reference compiled under oracle/_ref (here, where /root/reference
  * exists) and tests/golden/ holds the vectors produced by it for the GPU box.
  *
@@ -29,6 +29,7 @@
 #endif
 
 #include "gcge_ops.h"
+#include "gcge_multigrid.h"
 #include "oracle.h"
 
 typedef ORACLE_VEC VEC;
@@ -195,11 +196,73 @@ static void O_MatDotMultiVec(void *mat, void **x, void **y, int *start, int *end
 			for (i = A->j_col[j]; i < A->j_col[j + 1]; ++i) yd[A->i_row[i]] += A->data[i] * xs[j];
 	}
 }
-/* app_ccs.c:140-150 — symmetric only */
+/* app_ccs.c:140-150 — symmetric matrices: the product itself.  EXTENSION (the reference asserts a square matrix there, so its
+ * CCS back-end cannot restrict through P^T: only its dense and external back-ends run BlockAMG): a rectangular CCS matrix — a
+ * prolongation P of O_MultiGridCreate — is applied transposed in gather form, y[j] = sum over column j of a * x[i_row]. */
 static void O_MatTransDotMultiVec(void *mat, void **x, void **y, int *start, int *end, struct OPS_ *ops)
 {
-	if (mat != NULL) assert(((CCS*)mat)->nrows == ((CCS*)mat)->ncols);
-	O_MatDotMultiVec(mat, x, y, start, end, ops);
+	CCS *A = (CCS*)mat; VEC *vx = (VEC*)x, *vy = (VEC*)y; int c, m = end[0] - start[0];
+	if (A == NULL || A->nrows == A->ncols) { O_MatDotMultiVec(mat, x, y, start, end, ops); return; }
+	assert(m == end[1] - start[1] && vx->nrows == A->nrows && vy->nrows == A->ncols);
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+	for (c = 0; c < m; ++c) {
+		const double *xs = vx->data + (size_t)vx->ldd * (start[0] + c);
+		double *yd = vy->data + (size_t)vy->ldd * (start[1] + c); int j, i;
+		for (j = 0; j < A->ncols; ++j) {
+			double acc = 0.0;
+			for (i = A->j_col[j]; i < A->j_col[j + 1]; ++i) acc += A->data[i] * xs[A->i_row[i]];
+			yd[j] = acc;
+		}
+	}
+}
+/* ops.h:134-139 — the hierarchy behind BlockAMG.  The reference's CCS back-end has none (app_ccs.c:213-249 leaves the slot
+ * NULL); this one wraps the aggregation hierarchy of include/gcge_multigrid.h (the same one the HIP back-end uploads) into CCS
+ * matrices: A_l symmetric (CSR arrays == CCS arrays), P_l (rows of level l x rows of level l + 1) as the CCS triple whose
+ * column pointers are the row pointers of P_l^T. */
+typedef struct { void **A_array; GCGE_MG mg; CCS *mats; } O_MG_HOLD;
+static O_MG_HOLD g_mg_hold[8]; static int g_mg_nhold = 0;
+static void O_MultiGridCreate(void ***A_array, void ***B_array, void ***P_array, int *num_levels, void *A, void *B, struct OPS_ *ops)
+{
+	CCS *mA = (CCS*)A, *mB = (CCS*)B; GCGE_CSR cA, cB; O_MG_HOLD *h; int l, L;
+	assert(g_mg_nhold < 8 && mA->nrows == mA->ncols);
+	h = &g_mg_hold[g_mg_nhold++];
+	memset(&cA, 0, sizeof cA); memset(&cB, 0, sizeof cB);
+	cA.nrows = cA.ncols = mA->nrows; cA.rowptr = mA->j_col; cA.colidx = mA->i_row; cA.val = mA->data; cA.nnz = mA->j_col[mA->nrows];
+	if (mB != NULL) { cB.nrows = cB.ncols = mB->nrows; cB.rowptr = mB->j_col; cB.colidx = mB->i_row; cB.val = mB->data; cB.nnz = mB->j_col[mB->nrows]; }
+	if (gcge_mg_build(&cA, mB != NULL ? &cB : NULL, *num_levels, 0, 0.0, &h->mg) != 0) { fprintf(stderr, "O_MultiGridCreate: out of memory\n"); abort(); }
+	L = h->mg.num_levels;
+	h->mats = (CCS*)calloc(3 * (size_t)L, sizeof(CCS));
+	*A_array = (void**)calloc(L, sizeof(void*));
+	*P_array = (void**)calloc(L > 1 ? L - 1 : 1, sizeof(void*));
+	if (B_array != NULL) *B_array = (void**)calloc(L, sizeof(void*));
+	for (l = 0; l < L; ++l) {
+		CCS *a = &h->mats[3 * l], *b = &h->mats[3 * l + 1], *p = &h->mats[3 * l + 2];
+		if (l == 0) (*A_array)[0] = A;
+		else { a->nrows = a->ncols = h->mg.A[l].nrows; a->j_col = h->mg.A[l].rowptr; a->i_row = h->mg.A[l].colidx; a->data = h->mg.A[l].val; (*A_array)[l] = a; }
+		if (B_array != NULL) {
+			if (l == 0 || mB == NULL) (*B_array)[l] = l == 0 ? B : NULL;
+			else { b->nrows = b->ncols = h->mg.B[l].nrows; b->j_col = h->mg.B[l].rowptr; b->i_row = h->mg.B[l].colidx; b->data = h->mg.B[l].val; (*B_array)[l] = b; }
+		}
+		if (l + 1 < L) {
+			p->nrows = h->mg.P[l].nrows; p->ncols = h->mg.P[l].ncols;
+			p->j_col = h->mg.PT[l].rowptr; p->i_row = h->mg.PT[l].colidx; p->data = h->mg.PT[l].val;
+			(*P_array)[l] = p;
+		}
+	}
+	h->A_array = *A_array;
+	*num_levels = L;
+}
+static void O_MultiGridDestroy(void ***A_array, void ***B_array, void ***P_array, int *num_levels, struct OPS_ *ops)
+{
+	int i;
+	for (i = 0; i < g_mg_nhold; ++i) if (g_mg_hold[i].A_array == *A_array) {
+		gcge_mg_free(&g_mg_hold[i].mg); free(g_mg_hold[i].mats);
+		g_mg_hold[i] = g_mg_hold[--g_mg_nhold];
+		break;
+	}
+	free(*A_array); *A_array = NULL;
+	free(*P_array); *P_array = NULL;
+	if (B_array != NULL && *B_array != NULL) { free(*B_array); *B_array = NULL; }
 }
 /* ops_multi_vec.c:351-411 */
 static void O_MultiVecQtAP(char ntsA, char ntsd, void **mvQ, void *matA, void **mvP, int is_vec,
@@ -243,4 +306,6 @@ void OPS_ORACLE_Set(struct OPS_ *ops)
 	ops->MatDotMultiVec           = O_MatDotMultiVec;
 	ops->MatTransDotMultiVec      = O_MatTransDotMultiVec;
 	ops->MultiVecQtAP             = O_MultiVecQtAP;
+	ops->MultiGridCreate          = O_MultiGridCreate;
+	ops->MultiGridDestroy         = O_MultiGridDestroy;
 }

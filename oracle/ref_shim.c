@@ -345,3 +345,86 @@ int ref_dense_orth(double *mat, int nrows, int ldm, int start, int end, double z
 	OPS_Destroy(&ops);
 	return end;
 }
+
+/* ---- multigrid: the reference's dense back-end (app/app_lapack.c) is the only built-in one that can run BlockAMG — app_ccs.c:140-150
+ * refuses a rectangular P^T.  Blocks are column-major, ld == rows. */
+static OPS *make_dense_ops(void)
+{
+	OPS *ops = NULL;
+	OPS_Create(&ops);
+	OPS_LAPACK_Set(ops);
+	OPS_Setup(ops);
+	if (!g_verbose) { ops->Printf = quiet_printf; if (ops->lapack_ops) ops->lapack_ops->Printf = quiet_printf; }
+	ops->GetWtime = wall_now;
+	return ops;
+}
+/* the reference's own (toy) hierarchy of a dense matrix: MultiGridCreate, app_lapack.c:863-929.  n_out[l] = rows of level l;
+ * A_out / P_out: the level matrices one after the other (column-major); returns the number of levels */
+int ref_dense_multigrid(int n0, double *A0, int num_levels, int *n_out, double *A_out, double *P_out)
+{
+	OPS *ops = make_dense_ops(); LAPACKMAT A; void **A_array, **B_array = NULL, **P_array; int l; size_t oa = 0, op = 0;
+	A.data = A0; A.nrows = n0; A.ncols = n0; A.ldd = n0;
+	ops->MultiGridCreate(&A_array, &B_array, &P_array, &num_levels, &A, NULL, ops);
+	for (l = 0; l < num_levels; ++l) {
+		LAPACKMAT *a = (LAPACKMAT*)A_array[l];
+		n_out[l] = a->nrows;
+		memcpy(A_out + oa, a->data, (size_t)a->nrows * a->ncols * sizeof(double)); oa += (size_t)a->nrows * a->ncols;
+		if (l + 1 < num_levels) {
+			LAPACKMAT *p = (LAPACKMAT*)P_array[l];
+			memcpy(P_out + op, p->data, (size_t)p->nrows * p->ncols * sizeof(double)); op += (size_t)p->nrows * p->ncols;
+		}
+	}
+	ops->MultiGridDestroy(&A_array, NULL, &P_array, &num_levels, ops);
+	OPS_Destroy(&ops);
+	return num_levels;
+}
+/* BlockAMG (src/ops_lin_sol.c:466-715) over a given hierarchy: n[l] rows, A_flat / P_flat as above (P_l: n[l] x n[l+1]);
+ * b, x: n[0] x m; max_iter = {cycles, pre_0, post_0, pre_1, post_1, ...}, rate / tol per level */
+void ref_block_amg_dense(int num_levels, int *n, double *A_flat, double *P_flat, int m, double *b, double *x,
+		int *max_iter, double *rate, double *tol, const char *tol_type, int *niter_out, double *residual_out)
+{
+	OPS *ops = make_dense_ops();
+	LAPACKMAT *A = calloc(num_levels, sizeof(LAPACKMAT)), *P = calloc(num_levels, sizeof(LAPACKMAT));
+	void **A_array = calloc(num_levels, sizeof(void*)), **P_array = calloc(num_levels, sizeof(void*));
+	void ***ws[5]; LAPACKVEC *blk = calloc(5 * (size_t)num_levels, sizeof(LAPACKVEC)), vb, vx;
+	double *dbl = calloc(6 * m + 8, sizeof(double)); int *iw = calloc(2 * m + 8, sizeof(int));
+	int l, i, start[2] = {0, 0}, end[2] = {m, m}; size_t oa = 0, op = 0;
+	for (l = 0; l < num_levels; ++l) {
+		A[l].data = A_flat + oa; A[l].nrows = A[l].ncols = A[l].ldd = n[l]; oa += (size_t)n[l] * n[l]; A_array[l] = &A[l];
+		if (l + 1 < num_levels) { P[l].data = P_flat + op; P[l].nrows = P[l].ldd = n[l]; P[l].ncols = n[l + 1]; op += (size_t)n[l] * n[l + 1]; P_array[l] = &P[l]; }
+	}
+	for (i = 0; i < 5; ++i) {
+		ws[i] = calloc(num_levels, sizeof(void**));
+		for (l = 0; l < num_levels; ++l) {
+			LAPACKVEC *v = &blk[5 * l + i];
+			v->data = calloc((size_t)n[l] * m, sizeof(double)); v->nrows = v->ldd = n[l]; v->ncols = m;
+			ws[i][l] = (void**)v;
+		}
+	}
+	set_vec(&vb, b, n[0], m); set_vec(&vx, x, n[0], m);
+	MultiLinearSolverSetup_BlockAMG(max_iter, rate, tol, tol_type, A_array, P_array, num_levels, ws, dbl, iw, NULL, ops);
+	ops->MultiLinearSolver(A_array[0], (void**)&vb, (void**)&vx, start, end, ops);
+	{
+		BlockAMGSolver *s = (BlockAMGSolver*)ops->multi_linear_solver_workspace;
+		if (niter_out) *niter_out = s->niter;
+		if (residual_out) *residual_out = s->residual;
+	}
+	for (i = 0; i < 5; ++i) { for (l = 0; l < num_levels; ++l) free(blk[5 * l + i].data); free(ws[i]); }
+	free(blk); free(A); free(P); free(A_array); free(P_array); free(dbl); free(iw);
+	OPS_Destroy(&ops);
+}
+/* MultiVecFromItoJ (src/ops_multi_grid.c:69-117) through the dense back-end: from level i (n[i] x m in `from`) to level j */
+void ref_from_i_to_j_dense(int num_levels, int *n, double *P_flat, int level_i, int level_j, int m, double *from, double *to)
+{
+	OPS *ops = make_dense_ops();
+	LAPACKMAT *P = calloc(num_levels, sizeof(LAPACKMAT)); void **P_array = calloc(num_levels, sizeof(void*));
+	void ***ws = calloc(num_levels, sizeof(void**)); LAPACKVEC *blk = calloc(num_levels, sizeof(LAPACKVEC)), vf, vt;
+	int l, start[2] = {0, 0}, end[2] = {m, m}; size_t op = 0;
+	for (l = 0; l + 1 < num_levels; ++l) { P[l].data = P_flat + op; P[l].nrows = P[l].ldd = n[l]; P[l].ncols = n[l + 1]; op += (size_t)n[l] * n[l + 1]; P_array[l] = &P[l]; }
+	for (l = 0; l < num_levels; ++l) { blk[l].data = calloc((size_t)n[l] * m, sizeof(double)); blk[l].nrows = blk[l].ldd = n[l]; blk[l].ncols = m; ws[l] = (void**)&blk[l]; }
+	set_vec(&vf, from, n[level_i], m); set_vec(&vt, to, n[level_j], m);
+	ops->MultiVecFromItoJ(P_array, level_i, level_j, (void**)&vf, (void**)&vt, start, end, ws, ops);
+	for (l = 0; l < num_levels; ++l) free(blk[l].data);
+	free(blk); free(ws); free(P); free(P_array);
+	OPS_Destroy(&ops);
+}
