@@ -10,9 +10,10 @@ test/submit.sh:17-47, `mpirun -np k`).  Ranks started by a launcher (RANK set) r
 rank on cuda:0 over gloo (one-GPU boxes; the numbers then mean nothing).
 
 A "step" is ONE full eigensolve (GCG to convergence).  Default workload = BASELINE.json config 2: 3-D 7-point
-Laplacian 256^3 (n = 16 777 216, CSR), nev = 50, block = 64, nevMax = 128, standard problem, harness-default
-parameters (test/test_eig_sol_gcg.c:33-49,98-115 of the reference), fused device block-CG behind
-ops->MultiLinearSolver, matrix and all blocks of vectors resident in HBM before the timed region starts.  With
+Laplacian 256^3 (n = 16 777 216, CSR), nev = 50, block = 64, nevMax = 128, standard problem, tolerances and CG
+parameters of the reference's harness (test/test_eig_sol_gcg.c:33-49,98-115) but NOT its defaults elsewhere: block
+Cholesky-QR for X and W ("chol" instead of "mgs"), device RNG start block, the W systems behind ops->MultiLinearSolver
+(flag 1) — all named in config.workload — matrix and all blocks of vectors resident in HBM before the timed region starts.  With
 --gpus N every rank owns 256^3 rows of a box that stays as cube-like as N allows (weak scaling; N = 8: 512^3 =
 the grid of BASELINE config 4); --config c4 additionally switches the solver shape to config 4's (nev 200,
 block 128, nevMax 400); --config c5 is BASELINE config 5: the SiO2-like matrix (12th-order stencil + K = 2000
@@ -30,7 +31,7 @@ torch.distributed only hands rank 0's RCCL id to the other ranks and synchronise
              profiles/pmc_traffic.json), quoted only while the HIP sources hash to what was profiled.
   roofline_gram / roofline_panel_update = the FP64-MFMA kernels (K2 / K3) in the solve: 2 n k m flop per launch / HIP-event
              duration, summed per shape (k, m) over the timed steps; the shape with the largest share of the step, against the
-             78.6 TF dense FP64 matrix peak; dense_other_shapes = the next three.  pairs_wanted_per_s = nev x steps / elapsed
+             78.6 TF dense FP64 matrix peak (vendor spec); dense_other_shapes = the next three.  pairs_wanted_per_s = nev x steps / elapsed
              (value counts every pair a solve converged).  upload_seconds = host arrays -> device matrix in all its forms.
   cpu_baseline = the reference's own CPU path, OpenMP build (oracle/_ref/libgcge_ref_omp.so: app_ccs.c:117-131
              under OPS_USE_OMP), all host cores, on BASELINE config 1 (Lap3D 50^3, nev 20, block 20) — with the
@@ -68,11 +69,17 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dense-shapes", action="store_true", help="after the timed steps, print the in-solve rate of the Gram / panel-update kernels per shape (k, m) on stderr")
     ap.add_argument("--orth", default="chol", help="block orthonormalisation scheme for X and W: chol | mgs | bgs")
-    ap.add_argument("--amg", type=int, default=0,
+    ap.add_argument("--plain-steps", type=int, default=2,
+                    help="with --amg: additional solves with the plain fused block CG (30 iterations) after the timed region -> plain_block_cg "
+                         "(the configuration rounds 1-4 reported as value)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the legs after the timed region (plain_block_cg, roofline_k1_c5, dropin_reference_stack)")
+    ap.add_argument("--cpu-like-size", type=int, default=48, help="grid size of the like-for-like CPU sample (config 2's solver shape on the CPU reference)")
+    ap.add_argument("--amg", type=int, default=-1,
                     help="levels (>= 2) of the multigrid hierarchy: the W systems are solved by BlockAMG (one V-cycle, fused block CG as the "
                          "smoother; reference src/ops_lin_sol.c:466-715 set up as test/test_eig_sol_SiO2_MAT.c:96-128) instead of 30 block-CG "
-                         "iterations; 0 = plain block CG")
-    ap.add_argument("--amg-smooth", default="5,4", help="CG smoothing iterations before and after the coarse correction: finest level, coarser levels")
+                         "iterations; 0 = plain block CG; default: 6 for config c2 on one rank, 0 otherwise")
+    ap.add_argument("--amg-scale", type=float, default=0.0, help="coarse operators A_{l+1} = scale P^T A_l P (0: the back-end's default 0.5, include/gcge_multigrid.h)")
+    ap.add_argument("--amg-smooth", default="3,4", help="CG smoothing iterations before and after the coarse correction: finest level, coarser levels")
     a = ap.parse_args()
     if a.config == "c4":
         a.nev, a.block, a.nevmax = 200, 128, 400
@@ -80,6 +87,8 @@ def parse():
         a.nev, a.block, a.nevmax = 100, 64, 200
     if a.size <= 0:
         a.size = 171 if a.config == "c5" else 256
+    if a.amg < 0:
+        a.amg = 6 if (a.config == "c2" and a.gpus == 1) else 0
     if a.rehearse:
         os.environ["GCGE_BENCH_REHEARSE"] = "1"
     return a
@@ -226,6 +235,135 @@ def cpu_baseline(args, hip):
             "gpu_same_config": gpu}
 
 
+def k1_c5_leg(hip, args):
+    """roofline_k1_c5: the K1 product (MatDotMultiVec) of BASELINE config 5's matrix — SiO2-like, 171^3 grid, 3.5e8 non-zeros, rows of
+    very different length — on 64 columns, outside any solve: generate + upload + 3 untimed + 20 timed products, HIP events on the
+    launch stream (the back-end's own, gcge_hip_profile_kind).  Algorithmic bytes: SURVEY 8(d), 12 nnz + 4 (n + 1) + 16 n m."""
+    import numpy as np
+    from gcge_amd.lib import make_problem
+    g = hip.g
+    K, R0, R1 = "2000,2.0,5.0".split(",")
+    G, m = 171, 64
+    t0 = time.perf_counter()
+    A, _ = make_problem("sio2", G, K=int(K), R0=float(R0), R1=float(R1), seed=12345)
+    t1 = time.perf_counter()
+    mat = hip.matrix(A)
+    hip.sync()
+    t2 = time.perf_counter()
+    g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+    g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+    form = g.gcge_hip_mat_spmm_form(mat).decode()
+    x, y = hip.ops.mv_create(m, mat), hip.ops.mv_create(m, mat)
+    hip.set_random_mode(1, 77)
+    hip.ops.set_random(x, 0, m)
+    for _ in range(3):
+        hip.ops.spmm(mat, x, y, (0, 0), (m, m))
+    hip.sync()
+    g.gcge_hip_profile_enable(1)
+    nprod = 20
+    for _ in range(nprod):
+        hip.ops.spmm(mat, x, y, (0, 0), (m, m))
+    hip.sync()
+    ms_, by_ = C.c_double(), C.c_double()
+    cnt = g.gcge_hip_profile_kind(0, m, C.byref(ms_), C.byref(by_))
+    g.gcge_hip_profile_enable(0)
+    # parity inside the leg: 1 . (A x) = (A 1) . x needs every row and every entry once (A symmetric): column sums of y against
+    # the row sums of A applied to x, through the slots
+    ones = hip.ops.mv_create(2, mat)
+    a1 = hip.ops.mv_create(2, mat)
+    hip.g.gcge_hip_mv_from_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_long]
+    o = np.ones((A.nrows, 2), order="F")
+    hip.g.gcge_hip_mv_from_host(ones, 0, 2, o.ctypes.data_as(C.POINTER(C.c_double)), A.nrows)
+    hip.ops.spmm(mat, ones, a1, (0, 0), (2, 2))
+    lhs = hip.ops.inner_prod("N", ones, y, (0, 0), (1, 2))[0]          # 1 . y_j, j = 0, 1
+    rhs = hip.ops.inner_prod("N", a1, x, (0, 0), (1, 2))[0]            # (A 1) . x_j
+    sym = float(np.max(np.abs(lhs - rhs) / np.maximum(1e-300, np.abs(rhs))))
+    for v, c in ((x, m), (y, m), (ones, 2), (a1, 2)):
+        hip.ops.mv_destroy(v, c)
+    traffic, note = pmc_traffic_c5(G, "2000,2.0,5.0", m)
+    nnz, n = int(A.nnz), int(A.nrows)
+    hip.free_matrix(mat)
+    hip.h.gcge_csr_free(C.byref(A))
+    avg_ms = ms_.value / cnt
+    alg = by_.value / cnt
+    return {"bound": "hbm", "kernel": form + ": Y = A X, K1 (MatDotMultiVec), m=%d" % m,
+            "workload": "SiO2-like matrix of BASELINE config 5: %d^3 grid, 12th-order 37-point stencil + %s atom blocks (R = %s + %s u1 u2), n=%d, nnz=%d"
+                        % (G, K, R0, R1, n, nnz),
+            "achieved": alg / (avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / (avg_ms * 1e-3) / 1e9 / 8000.0,
+            "traffic": traffic, "traffic_note": note, "launches": int(cnt), "avg_launch_ms": avg_ms, "alg_bytes_per_launch": alg,
+            "generate_seconds": t1 - t0, "upload_seconds": t2 - t1, "symmetry_check_rel": sym}
+
+
+def dropin_leg(hip, mat, args):
+    """dropin_reference_stack: ONE solve of the REFERENCE's own compiled GCG + ModifiedGramSchmidt (oracle/_ref/libgcge_ref.so: its
+    OPS_Setup defaults, its LAPACK) over a second table only OPS_HIP_Set touched, fused block CG behind flag 1 — the literal
+    drop-in north_star names (TestEigenSolverGCG's parameter flow: oracle/ref_shim.c gcg_solve_core), on the matrix of the timed
+    region.  Test infrastructure: the reference library is the thing MEASURED here, beside the product, never part of it."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    ref = po.ref_lib()
+    if ref is None:
+        return {"error": "oracle/_ref/libgcge_ref.so not present"}
+    g = hip.g
+    ops = C.c_void_p()
+    hip.h.OPS_Create(C.byref(ops))
+    g.OPS_HIP_Set(ops)
+    g.gcge_hip_bpcg_setup(ops, 30, 1e-2, 1e-14, b"abs")
+    ref.ref_gcg_solve_foreign.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    like = hip.ops.mv_create(args.block, mat)
+    g.gcge_hip_bpcg_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    g.gcge_hip_bpcg_prepare(ops, mat, like, args.block)        # the CG's blocks before the timer, as EigenSolverCreateWorkspace_GCG does
+    hip.ops.mv_destroy(like, args.block)
+    ev = np.zeros(args.nevmax)
+    conv, it, sec = C.c_int(), C.c_int(), C.c_double()
+    rc = ref.ref_gcg_solve_foreign(ops, mat, None, args.nev, args.nevmax, args.block, 0, 1e-1, 1e-8, 500, 1,
+                                   ev.ctypes.data_as(C.POINTER(C.c_double)), C.byref(conv), C.byref(it), C.byref(sec))
+    if rc != 0 or conv.value <= 0:
+        return {"error": "ref_gcg_solve_foreign rc=%d converged %d" % (rc, conv.value)}
+    N = args.size
+    c = np.sort(2.0 * np.cos(np.arange(1, N + 1) * np.pi / (N + 1)))[::-1][:48]
+    exact = np.sort((6.0 - c[:, None, None] - c[None, :, None] - c[None, None, :]).ravel())[:conv.value]
+    return {"stack": "the reference's compiled GCG + ModifiedGramSchmidt + OPS_Setup defaults (oracle/_ref/libgcge_ref.so) over OPS_HIP_Set slots, "
+                     "fused device block CG behind flag 1 (30 its), device RNG start block",
+            "seconds": sec.value, "value": conv.value / sec.value, "unit": "eigenpairs/s", "nev_converged": conv.value,
+            "gcg_iterations": it.value, "max_rel_err_vs_closed_form": float(np.max(np.abs(ev[:conv.value] - exact) / exact))}
+
+
+def cpu_like_for_like(args, hip):
+    """Second CPU sample, like for like: the compiled reference (OpenMP build, all cores) at BASELINE config 2's SOLVER SHAPE
+    (nev 50, block 64, nevMax 128) on a smaller grid, and the GPU (this product: chol + fused CG, flag 1) on the same input."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    from gcge_amd.lib import make_problem, run_gcg
+    ref = po.ref_lib(omp=True)
+    if ref is None:
+        return None
+    N = args.cpu_like_size
+    A, _ = make_problem("lap3d", N)
+    cores = host_cores()
+    g = hip.g
+    mat = hip.matrix(A)
+    hip.set_random_mode(0)
+    g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    sargs = ["-nevConv", 50, "-nevMax", 128, "-blockSize", 64, "-gcge_initX_orth_method", args.orth, "-gcge_compW_orth_method", args.orth]
+    run_gcg(hip.ops_handle, mat, None, sargs, flag=1)
+    C.CDLL(None).srand(0)
+    ev_g, res_g = run_gcg(hip.ops_handle, mat, None, sargs, flag=1)
+    hip.free_matrix(mat)
+    ev, conv, it, sec = po.ref_gcg(A, None, 50, nev_max=128, block=64, omp=True)
+    k = min(conv, res_g.nevConv)
+    return {"value": conv / sec, "unit": "eigenpairs/s", "cores": cores, "kind": "reference",
+            "sample": "BASELINE config 2's solver shape (nev 50, block 64, nevMax 128, harness parameters) on Lap3D %d^3 (n=%d): OPS_USE_OMP build, "
+                      "%d threads; %d GCG its, %d pairs, %.1f s" % (N, A.nrows, cores, it, conv, sec),
+            "gpu_same_config": {"value": res_g.nevConv / res_g.seconds, "unit": "eigenpairs/s", "seconds": res_g.seconds,
+                                "gcg_iterations": res_g.numIter, "nev_converged": res_g.nevConv,
+                                "max_rel_diff_vs_cpu_reference": float(np.max(np.abs(ev_g[:k] - ev[:k]) / np.abs(ev[:k]))) if k > 0 else None}}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -368,6 +506,9 @@ def main():
         hip.h.GCGE_AMGCreate.restype = C.c_void_p
         hip.h.GCGE_AMGCreate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
         hip.h.GCGE_AMGInstall.argtypes = [C.c_void_p, C.c_void_p]
+        if args.amg_scale > 0.0:
+            hip.h.gcge_mg_set_defaults.argtypes = [C.c_double, C.c_int, C.c_double]
+            hip.h.gcge_mg_set_defaults(args.amg_scale, 0, -1.0)
         t_a = time.perf_counter()
         amg = C.c_void_p(hip.h.GCGE_AMGCreate(mat, None, args.amg, args.block, 1, s0, s1, 1e-2, hip.ops_handle))
         hip.sync()
@@ -460,9 +601,9 @@ def main():
     # in-solve rate of the dense kernels per shape (north_star: "MFMA utilisation for the TSQR/Gram kernels reported against
     # gfx950 peak"): 2 n k m flop of a launch / its HIP-event duration, summed per (kernel, k, m) over the timed steps
     g.gcge_hip_dense_profile_shapes.argtypes = [C.POINTER(C.c_double), C.c_int]
-    dbuf = (C.c_double * (6 * 64))()
+    dbuf = (C.c_double * (7 * 64))()
     nshape = min(64, g.gcge_hip_dense_profile_shapes(dbuf, 64))
-    dense_rows = [tuple(dbuf[6 * i + j] for j in range(6)) for i in range(nshape)]
+    dense_rows = [tuple(dbuf[7 * i + j] for j in range(7)) for i in range(nshape)]
     if args.dense_shapes and rank == 0:
         buf = C.create_string_buffer(1 << 16)
         g.gcge_hip_dense_profile_report.argtypes = [C.c_char_p, C.c_int]
@@ -537,17 +678,19 @@ def main():
         r_p1 = roof(2, "CG pass 1, p.Ap and |Ap|^2 without storing Ap", 1)
         r_p2 = roof(3, "CG pass 2, Ap recomputed + r = p - beta_prev p_prev - alpha Ap (no stored residual), p' = r + beta p" if implicit_r > 0
                     else "CG pass 2, Ap recomputed + r -= alpha Ap, p' = r + beta p", 4)
-        FP64_MFMA_PEAK_TF = 78.6               # MI355X_MICROARCH.md: dense FP64 matrix peak
+        # dense FP64 matrix peak: the VENDOR SPEC figure for MI355X (78.6 TF; /opt/skills/guides/MI355X_MICROARCH.md has no FP64 line).
+        # A register-only loop of v_mfma_f64_16x16x4_f64 measures 76.9 TF on this chip (tools/dense_bench.hip).
+        FP64_MFMA_PEAK_TF = 78.6
 
         def dense_roof(kind, kernel, what):
             rows_ = [r for r in dense_rows if int(r[0]) == kind and r[3] > 0 and r[4] > 0]
             if not rows_:
                 return None, []
             def entry(r):
-                _, k_, m_, calls_, ms_, fl_ = r
+                _, k_, m_, calls_, ms_, fl_, by = r
                 tf = fl_ / (ms_ * 1e-3) * 1e-12
-                # bytes a launch must move: both operands read once (+ the panel written / read-modified: panel update)
-                by = 8.0 * A.nrows * (k_ + m_) * calls_ if kind == 0 else 8.0 * A.nrows * (k_ + 2.0 * m_) * calls_
+                # `by`: bytes the launches had to move, summed by the back-end per call — operands once, the panel written, and
+                # read only where beta != 0 and the update is not in place
                 return {"shape": {"k": int(k_), "m": int(m_), "n": int(A.nrows)}, "calls": int(calls_), "avg_launch_ms": ms_ / calls_,
                         "achieved": tf, "frac": tf / FP64_MFMA_PEAK_TF, "hbm_GBs": by / (ms_ * 1e-3) / 1e9,
                         "share_of_step": ms_ * 1e-3 / elapsed if elapsed > 0 else None}
@@ -592,13 +735,63 @@ def main():
             "dense_other_shapes": {"gram": gram_more, "panel_update": upd_more},
             "spmm_share_of_step": spmm_ms_all * 1e-3 / elapsed if elapsed > 0 else None,
         }
-        if not args.no_cpu and world == 1:
-            try:                              # the finished measurement must reach the driver whatever the baseline leg does
-                out["cpu_baseline"] = cpu_baseline(args, hip)
+        import traceback
+
+        def leg(name, fn):                    # the finished measurement must reach the driver whatever a later leg does
+            t_l = time.perf_counter()
+            try:
+                r = fn()
             except Exception as exc:          # noqa: BLE001
-                import traceback
                 traceback.print_exc()
-                out["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                r = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            if isinstance(r, dict):
+                r["leg_seconds"] = time.perf_counter() - t_l
+            if r is not None:
+                out[name] = r
+
+        extra = world == 1 and not args.no_extra and args.config == "c2"
+        if extra and amg is not None and args.plain_steps > 0:
+            # the configuration rounds 1-4 reported as `value`: the same solves with the W systems through 30 iterations of the
+            # fused block CG (no multigrid), so that the round-over-round record stays comparable
+            def plain():
+                g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+                g.gcge_hip_bpcg_time_stats(None, None, 1)
+                run_gcg(hip.ops_handle, mat, None, solver_args, flag=1)       # (untimed: the ring of 15 direction blocks is created here)
+                hip.sync()
+                g.gcge_hip_bpcg_time_stats(None, None, 1)
+                t_p = time.perf_counter()
+                cv, itn = 0, 0
+                for _ in range(args.plain_steps):
+                    e_, r_ = run_gcg(hip.ops_handle, mat, None, solver_args, flag=1)
+                    cv += r_.nevConv
+                    itn += r_.numIter
+                hip.sync()
+                el = time.perf_counter() - t_p
+                ci_, cs_ = C.c_long(), C.c_double()
+                g.gcge_hip_bpcg_time_stats(C.byref(ci_), C.byref(cs_), 0)
+                return {"what": "the same solves with the W systems through 30 iterations of the fused block CG instead of BlockAMG "
+                                "(the configuration BENCH_r01-r04 report as value)",
+                        "value": cv / el, "unit": "eigenpairs/s", "steps": args.plain_steps, "ms_per_step": 1e3 * el / args.plain_steps,
+                        "gcg_iterations": itn, "nev_converged": cv, "cg_iterations": ci_.value,
+                        "ms_per_cg_iteration": 1e3 * cs_.value / ci_.value if ci_.value else None}
+            leg("plain_block_cg", plain)
+        if extra and not args.no_cpu:
+            leg("dropin_reference_stack", lambda: dropin_leg(hip, mat, args))
+        if extra:
+            def k1c5():
+                if amg is not None:
+                    hip.h.GCGE_AMGDestroy.argtypes = [C.c_void_p, C.c_void_p]
+                    hip.h.GCGE_AMGDestroy(C.byref(amg), hip.ops_handle)
+                g.gcge_hip_bpcg_release.argtypes = [C.c_void_p]
+                g.gcge_hip_bpcg_release(hip.ops_handle)
+                hip.free_matrix(mat)
+                g.gcge_hip_pool_release()
+                return k1_c5_leg(hip, args)
+            leg("roofline_k1_c5", k1c5)
+        if not args.no_cpu and world == 1:
+            leg("cpu_baseline", lambda: cpu_baseline(args, hip))
+            if extra:
+                leg("cpu_baseline_like_for_like", lambda: cpu_like_for_like(args, hip))
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

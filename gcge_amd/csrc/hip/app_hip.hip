@@ -159,10 +159,16 @@ extern "C" int gcge_hip_slot_timing_report(char* buf, int len) {
 // gcge_hip_dense_profile(1): every Gram (K2) and panel update (K3) launched by the slots is bracketed by two HIP events on the
 // back-end's stream (no synchronisation); gcge_hip_dense_profile_report sums them per (kernel, k, m): calls, average time and
 // 2 n k m flop / time — the TF a solve actually sees for each shape, not a stand-alone benchmark's.
-struct DenseEvent { hipEvent_t e0, e1; int kind, k, m; long n; };   // kind 0: Gram, 1: panel update
+struct DenseEvent { hipEvent_t e0, e1; int kind, k, m; long n; double bytes; };   // kind 0: Gram, 1: panel update; bytes the launch must move
 static std::vector<DenseEvent> g_dense_prof;
-static std::map<std::tuple<int, int, int>, std::tuple<long, double, double>> g_dense_acc;   // (kind, k, m) -> calls, ms, flop: events already folded
+static std::map<std::tuple<int, int, int>, std::tuple<long, double, double, double>> g_dense_acc;   // (kind, k, m) -> calls, ms, flop, bytes: events already folded
 static int g_dense_prof_on = 0;
+// events are recycled (~1e5 launches per bench must not create and destroy 2e5 events inside the timed region)
+static std::vector<hipEvent_t> g_dense_ev_pool;
+static hipEvent_t dense_ev_get() {
+  if (!g_dense_ev_pool.empty()) { hipEvent_t e = g_dense_ev_pool.back(); g_dense_ev_pool.pop_back(); return e; }
+  hipEvent_t e; GCGE_HIP_CHECK(hipEventCreate(&e)); return e;
+}
 // fold the recorded intervals into the per-shape sums (all of them: the caller has synchronised; otherwise the completed front)
 static void dense_prof_fold(bool all) {
   size_t i = 0;
@@ -172,24 +178,25 @@ static void dense_prof_fold(bool all) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) {
       auto& a = g_dense_acc[std::make_tuple(e.kind, e.k, e.m)];
-      std::get<0>(a) += 1; std::get<1>(a) += ms; std::get<2>(a) += 2.0 * (double)e.n * e.k * e.m;
+      std::get<0>(a) += 1; std::get<1>(a) += ms; std::get<2>(a) += 2.0 * (double)e.n * e.k * e.m; std::get<3>(a) += e.bytes;
     }
-    hipEventDestroy(e.e0); hipEventDestroy(e.e1);
+    g_dense_ev_pool.push_back(e.e0); g_dense_ev_pool.push_back(e.e1);
   }
   g_dense_prof.erase(g_dense_prof.begin(), g_dense_prof.begin() + (long)i);
 }
 extern "C" void gcge_hip_dense_profile(int on) {
-  for (auto& e : g_dense_prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
+  for (auto& e : g_dense_prof) { g_dense_ev_pool.push_back(e.e0); g_dense_ev_pool.push_back(e.e1); }
   g_dense_prof.clear();
   g_dense_acc.clear();
   g_dense_prof_on = on;
+  if (on) while (g_dense_ev_pool.size() < 8192) { hipEvent_t e; GCGE_HIP_CHECK(hipEventCreate(&e)); g_dense_ev_pool.push_back(e); }   // before anything is timed
 }
 struct DenseProfScope {
   DenseEvent ev; bool on;
-  DenseProfScope(int kind, long n, int k, int m) : on(g_dense_prof_on != 0) {
+  DenseProfScope(int kind, long n, int k, int m, double bytes) : on(g_dense_prof_on != 0) {
     if (!on) return;
-    ev.kind = kind; ev.k = k; ev.m = m; ev.n = n;
-    GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
+    ev.kind = kind; ev.k = k; ev.m = m; ev.n = n; ev.bytes = bytes;
+    ev.e0 = dense_ev_get(); ev.e1 = dense_ev_get();
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
   ~DenseProfScope() {
@@ -198,8 +205,9 @@ struct DenseProfScope {
     if (g_dense_prof.size() >= 4096) dense_prof_fold(false);          // (a bench of 20 solves brackets ~1e5 launches)
   }
 };
-// the same sums as numbers: rows of 6 doubles (kind 0 Gram / 1 panel update, k, m, calls, milliseconds in all, flop in all), at
-// most max_rows of them, largest total time first; returns the number of shapes seen
+// the same sums as numbers: rows of 7 doubles (kind 0 Gram / 1 panel update, k, m, calls, milliseconds in all, flop in all, bytes the
+// launches had to move in all: both operands once, + the panel read where beta != 0 and it is not updated in place), at most max_rows
+// of them, largest total time first; returns the number of shapes seen
 extern "C" int gcge_hip_dense_profile_shapes(double* out, int max_rows) {
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
   dense_prof_fold(true);
@@ -210,9 +218,9 @@ extern "C" int gcge_hip_dense_profile_shapes(double* out, int max_rows) {
   for (auto& o : order) {
     if (r >= max_rows) break;
     const auto& a = g_dense_acc[o.second];
-    double* q = out + 6 * (size_t)r++;
+    double* q = out + 7 * (size_t)r++;
     q[0] = std::get<0>(o.second); q[1] = std::get<1>(o.second); q[2] = std::get<2>(o.second);
-    q[3] = (double)std::get<0>(a); q[4] = std::get<1>(a); q[5] = std::get<2>(a);
+    q[3] = (double)std::get<0>(a); q[4] = std::get<1>(a); q[5] = std::get<2>(a); q[6] = std::get<3>(a);
   }
   return (int)order.size();
 }
@@ -595,7 +603,10 @@ static void HIP_MultiVecLinearComb(void** x, void** y, int is_vec, int* start, i
     if (beta != nullptr) for (int j = 0; j < mp; ++j) hc[(size_t)k * mp + j] = (incb == 0) ? *beta : beta[(size_t)(j0 + j) * incb];
     double* dc = stage_d(len);
     GCGE_HIP_CHECK(hipMemcpyAsync(dc, hc, len * sizeof(double), hipMemcpyHostToDevice, g_stream));
-    DenseProfScope prof_(1, vy->nrows, k, mp);
+    // bytes a launch moves: X read, the panel written; the panel is READ as well where beta != 0 — unless it is updated in place
+    // (y == x with the output columns inside the input range: the rows of X just read hold it)
+    const bool inplace_ = vx == vy && start[1] + j0 >= start[0] && start[1] + j0 + mp <= end[0];
+    DenseProfScope prof_(1, vy->nrows, k, mp, 8.0 * (double)vy->nrows * (k + mp + ((beta != nullptr && !inplace_) ? mp : 0)));
     int rc = gcge_hip_lincomb(vy->nrows, vx->d + start[0], vx->ld, k, dc, mp, beta ? dc + (size_t)k * mp : nullptr,
                               vy->d + start[1] + j0, vy->ld, g_stream);
     GCGE_REQUIRE(rc == 0, "MultiVecLinearComb: kernel launch");
@@ -646,7 +657,7 @@ static void local_inner_prod(char nsd, void** x, void** y, int is_vec, int* star
   }
   double* dg = stage_d((size_t)k * m);
   if (m == 1) gcge_hip_panel_dot1(vx->nrows, vx->d + start[0], vx->ld, k, vy->d + start[1], vy->ld, dg, g_stream);   // panel . column
-  else { DenseProfScope prof_(0, vx->nrows, k, m); gcge_hip_gram(vx->nrows, vx->d + start[0], vx->ld, k, vy->d + start[1], vy->ld, m, dg, g_stream); }
+  else { DenseProfScope prof_(0, vx->nrows, k, m, 8.0 * (double)vx->nrows * ((vx == vy && start[0] == start[1] && k == m) ? k : k + m)); gcge_hip_gram(vx->nrows, vx->d + start[0], vx->ld, k, vy->d + start[1], vy->ld, m, dg, g_stream); }
   double* hg = stage_h((size_t)k * m);
   GCGE_HIP_CHECK(hipMemcpyAsync(hg, dg, (size_t)k * m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));

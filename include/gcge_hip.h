@@ -325,8 +325,9 @@ int gcge_hip_coldots2 (int nrows, const double *d_x, long ldx, const double *d_y
  *     synchronisation added); the report lists, per (kernel, k, m), calls, average time and 2 n k m flop / time            */
 void gcge_hip_dense_profile (int on);
 int  gcge_hip_dense_profile_report (char *buf, int len);
-/*     the same as numbers: rows of 6 doubles (0 Gram / 1 panel update, k, m, calls, ms in all, flop in all), largest total time
- *     first, at most max_rows; returns the number of shapes seen (bench.py: roofline_gram / roofline_panel_update)              */
+/*     the same as numbers: rows of 7 doubles (0 Gram / 1 panel update, k, m, calls, ms in all, flop in all, bytes in all — what each
+ *     launch had to move: a panel with beta == NULL or updated in place is not read), largest total time first, at most max_rows;
+ *     returns the number of shapes seen (bench.py: roofline_gram / roofline_panel_update)                                       */
 int  gcge_hip_dense_profile_shapes (double *out, int max_rows);
 /* K3  Y[:,0:m) = X[:,0:k) C + Y diag(beta);  d_c row-major k x m; d_beta NULL => overwrite */
 int gcge_hip_lincomb (int nrows, const double *d_x, long ldx, int k, const double *d_c, int m,

@@ -447,14 +447,22 @@ def test_cg_recompute_passes_match_numpy(hip, kind, size, which, m):
     hip.free_matrix(mat)
 
 
-def test_gcg_recompute_cg_equals_stored_product_cg(hip):
+@pytest.mark.parametrize("nev", [11, 12])
+def test_gcg_recompute_cg_equals_stored_product_cg(hip, nev):
     """Whole eigensolves with the fused CG in its recompute form, with the product stored and the scalars on the device
     (GCGE_CG_NO_RECOMPUTE=1: what matrices without a pattern form get), and with the product stored and the scalars on the host
     (additionally GCGE_CG_STORED_HOST=1): same recurrences on the same operands — the same pairs converge, the same Ritz values to
-    rounding.  The outer iteration counts are 34 / 29 / 34 on this case (34 / 30 / 32 before the stored form got its one-sweep
-    start): the forms sum p.w, w.w and r.r in different orders and round r0 differently, and the convergence test of an outer
-    iteration is a threshold (the reference's own runs of one case differ by more between two builds: VERDICT r3 (c)), so the
-    counts are held within a fifth of each other; what must agree exactly is WHICH pairs converge and their values."""
+    rounding, the same number of outer iterations.
+
+    nev = 11 ends on a cluster boundary of the 16^3 spectrum (1 + 3 + 3 + 3 + 1 pairs, relative gap 0.14 to the next value): all
+    forms — also with the one-sweep start switched off or b formed explicitly — take exactly 22 outer iterations
+    (tools/iter_probe.py, gpurun_out/r5/02_iter_probe.log), pinned here within max(2, n // 8).
+    nev = 12 is the case round 4 widened the bound for (34 / 29 / 34): the 12th pair lies INSIDE the six-fold cluster (3, 2, 1)
+    (relative gap to the 13th: 5e-16), the locking rule never splits a cluster (src/ops_eig_sol_gcg.c:253-259), so the run ends when
+    all 17 pairs have converged — when the LAST member of a degenerate sextuplet crosses the threshold, which follows the rounding
+    of every sum: 34 / 29 / 30 / 34 / 32 / 33 over the six variants of the probe (formed b instead of the one-sweep start moves the
+    stored form from 29 to 30, the recompute form from 34 to 33: the start is not the cause).  For that case only the converged
+    count, the Ritz values and a loose band on the count are asserted."""
     import os
     g = hip.g
     g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
@@ -467,7 +475,7 @@ def test_gcg_recompute_cg_equals_stored_product_cg(hip):
             g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
             hip.set_random_mode(0)
             before, bdev = g.gcge_hip_bpcg_recompute_iters(), g.gcge_hip_bpcg_stored_dev_iters()
-            ev, res = gcg_on(hip, "lap3d", 16, ["-nevConv", 12, "-nevMax", 24, "-blockSize", 8], flag=1)
+            ev, res = gcg_on(hip, "lap3d", 16, ["-nevConv", nev, "-nevMax", 24, "-blockSize", 8], flag=1)
             out[tag] = (ev[:res.nevConv].copy(), res.nevConv, res.numIter, g.gcge_hip_bpcg_recompute_iters() - before, g.gcge_hip_bpcg_stored_dev_iters() - bdev)
         finally:
             for k in env:
@@ -475,7 +483,11 @@ def test_gcg_recompute_cg_equals_stored_product_cg(hip):
     assert out["recompute"][3] > 0 and out["stored"][3] == 0 and out["stored, host scalars"][3] == 0, [v[3] for v in out.values()]
     assert out["recompute"][4] == 0 and out["stored"][4] > 0 and out["stored, host scalars"][4] == 0, [v[4] for v in out.values()]
     its = [v[2] for v in out.values()]
-    assert len({v[1] for v in out.values()}) == 1 and max(its) - min(its) <= max(2, max(its) // 5), its
+    assert {v[1] for v in out.values()} == {11 if nev == 11 else 17}
+    if nev == 11:
+        assert max(its) - min(its) <= max(2, max(its) // 8), its
+    else:
+        assert max(its) - min(its) <= max(2, max(its) // 4), its
     k = out["stored"][1]
     for tag in ("recompute", "stored, host scalars"):
         assert np.max(np.abs(out[tag][0][:k] - out["stored"][0][:k]) / np.abs(out["stored"][0][:k])) < 1e-11, tag
