@@ -59,8 +59,10 @@ def parse():
     ap.add_argument("--nev", type=int, default=50)
     ap.add_argument("--block", type=int, default=64)
     ap.add_argument("--nevmax", type=int, default=128)
-    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
-                    help="c2 = Lap3D, nev 50 / block 64 / nevMax 128 (BASELINE config 2); c4 = Lap3D, nev 200 / block 128 / nevMax 400; "
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="c2 = Lap3D, nev 50 / block 64 / nevMax 128 (BASELINE config 2); c3 = FE stiffness / mass pair (P1 on the Kuhn "
+                         "triangulation, --size = interior nodes per direction, default 100: n = 10^6), generalised problem, nev 100 / block 128 / "
+                         "nevMax 256 (BASELINE config 3; one rank); c4 = Lap3D, nev 200 / block 128 / nevMax 400; "
                          "c5 = SiO2-like matrix (--size = grid points per direction, default 171), nev 100 / block 64 / nevMax 200, rows split by nnz")
     ap.add_argument("--rehearse", action="store_true",
                     help="every rank on cuda:0, gloo transport staged through the host (multi-rank code path on a one-GPU box)")
@@ -85,10 +87,12 @@ def parse():
         a.nev, a.block, a.nevmax = 200, 128, 400
     if a.config == "c5":
         a.nev, a.block, a.nevmax = 100, 64, 200
+    if a.config == "c3":
+        a.nev, a.block, a.nevmax = 100, 128, 256
     if a.size <= 0:
-        a.size = 171 if a.config == "c5" else 256
+        a.size = 171 if a.config == "c5" else 100 if a.config == "c3" else 256
     if a.amg < 0:
-        a.amg = 6 if (a.config == "c2" and a.gpus == 1) else 0
+        a.amg = 6 if (a.config in ("c2", "c3") and a.gpus == 1) else 0
     if a.rehearse:
         os.environ["GCGE_BENCH_REHEARSE"] = "1"
     return a
@@ -294,6 +298,33 @@ def k1_c5_leg(hip, args):
             "generate_seconds": t1 - t0, "upload_seconds": t2 - t1, "symmetry_check_rel": sym}
 
 
+def k1_plain_leg(hip, mat, A, m, what):
+    """K1 alone on a resident matrix: 3 untimed + 20 timed products Y = A X on m columns, HIP events on the launch stream; algorithmic
+    bytes per SURVEY 8(d): 12 nnz + 4 (n + 1) + 16 n m."""
+    g = hip.g
+    g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+    g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+    form = g.gcge_hip_mat_spmm_form(mat).decode()
+    x, y = hip.ops.mv_create(m, mat), hip.ops.mv_create(m, mat)
+    hip.ops.set_random(x, 0, m)
+    for _ in range(3):
+        hip.ops.spmm(mat, x, y, (0, 0), (m, m))
+    hip.sync()
+    g.gcge_hip_profile_enable(1)
+    for _ in range(20):
+        hip.ops.spmm(mat, x, y, (0, 0), (m, m))
+    hip.sync()
+    ms_, by_ = C.c_double(), C.c_double()
+    cnt = g.gcge_hip_profile_kind(0, m, C.byref(ms_), C.byref(by_))
+    g.gcge_hip_profile_enable(0)
+    hip.ops.mv_destroy(x, m)
+    hip.ops.mv_destroy(y, m)
+    avg_ms, alg = ms_.value / cnt, by_.value / cnt
+    return {"bound": "hbm", "kernel": "%s: Y = A X, K1 (MatDotMultiVec), m=%d" % (form, m), "what": what, "achieved": alg / (avg_ms * 1e-3) / 1e9,
+            "peak": 8000.0, "unit": "GB/s", "frac": alg / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "launches": int(cnt),
+            "avg_launch_ms": avg_ms, "alg_bytes_per_launch": alg, "n": int(A.nrows), "nnz": int(A.nnz)}
+
+
 def dropin_leg(hip, mat, args):
     """dropin_reference_stack: ONE solve of the REFERENCE's own compiled GCG + ModifiedGramSchmidt (oracle/_ref/libgcge_ref.so: its
     OPS_Setup defaults, its LAPACK) over a second table only OPS_HIP_Set touched, fused block CG behind flag 1 — the literal
@@ -408,6 +439,10 @@ def main():
 
     N = args.size
     c5 = args.config == "c5"
+    c3 = args.config == "c3"
+    matB = None
+    if c3 and world > 1:
+        raise SystemExit("bench.py: --config c3 is one-rank (BASELINE config 3: 1 x MI355X)")
     t_upload0 = None                           # set right before the matrix goes to the device
     transport = "none (single rank)"
     comm = None
@@ -428,7 +463,17 @@ def main():
         comm = gdist.NativeComm(hip, None, 0, 1)
         transport = "rccl-native (one-rank loop-back)"
 
-    if c5:
+    if c3:
+        # BASELINE config 3: generalised problem A x = lambda B x, P1 stiffness / consistent mass pair on the Kuhn triangulation of a
+        # cube (A 7-point x h, B 15-point x h^3), n = size^3 ~ 10^6
+        A, Bc = make_problem("fe3d", N)
+        n_global = N ** 3
+        dims = (N, N, N)
+        t_upload0 = time.perf_counter()
+        mat = hip.matrix(A)
+        matB = hip.matrix(Bc)
+        workload = "P1 FE stiffness / mass pair on a %d^3 grid of interior nodes (A 7-point, B 15-point, n=%d), generalised problem" % (N, n_global)
+    elif c5:
         # BASELINE config 5: ONE matrix whatever the rank count (strong scaling), rows cut so that every rank holds the
         # same number of non-zeros (gcge_amd.dist.partition_by_nnz)
         K, R0, R1 = args.atoms.split(",")
@@ -545,7 +590,7 @@ def main():
 
     t_w0 = time.perf_counter()
     for _ in range(args.warmup):
-        run_gcg(hip.ops_handle, mat, None, solver_args, flag=1)
+        run_gcg(hip.ops_handle, mat, matB, solver_args, flag=1)
     hip.sync()
     warm_solve = (time.perf_counter() - t_w0) / args.warmup if args.warmup > 0 else None
     # A collective that hangs inside the timed region (a peer that died) must end THIS process with a non-zero code well
@@ -563,12 +608,12 @@ def main():
     t0 = time.perf_counter()
     conv_total, iters, last = 0, 0, None
     for step in range(args.steps):
-        if c5 and step == args.steps - 1:      # keep the last solve's vectors: the parity guard recomputes their residuals
+        if (c5 or c3) and step == args.steps - 1:      # keep the last solve's vectors: the parity guard recomputes their residuals
             if last is not None and len(last) > 2:
                 hip.ops.mv_destroy(last[2], args.nevmax)
-            last = run_gcg(hip.ops_handle, mat, None, solver_args, flag=1, keep_evec=True)
+            last = run_gcg(hip.ops_handle, mat, matB, solver_args, flag=1, keep_evec=True)
         else:
-            last = run_gcg(hip.ops_handle, mat, None, solver_args, flag=1)
+            last = run_gcg(hip.ops_handle, mat, matB, solver_args, flag=1)
         conv_total += last[1].nevConv
         iters += last[1].numIter
     barrier()
@@ -613,20 +658,25 @@ def main():
 
     # parity guard inside the bench (all ranks take part: the slots are collective)
     ev, res = last[0], last[1]
-    if c5:
-        # no closed form: relative residuals ||A x - lambda x|| / (lambda ||x||) of the converged pairs, recomputed
+    if c5 or c3:
+        # no closed form: relative residuals ||A x - lambda B x|| / (lambda ||B x||) of the converged pairs, recomputed
         # through the slots from the eigenvectors the solver returned
         k = int(res.nevConv)
         evec = last[2]
         ax = hip.ops.mv_create(k, mat)
         hip.ops.spmm(mat, evec, ax, (0, 0), (k, k))
+        if matB is not None:
+            bx = hip.ops.mv_create(k, mat)
+            hip.ops.spmm(matB, evec, bx, (0, 0), (k, k))
+            hip.ops.mv_destroy(evec, args.nevmax)
+            evec = bx
         nx = np.sqrt(hip.ops.inner_prod("D", evec, evec, (0, 0), (k, k)))
         coef = np.zeros((k, k))
         coef[np.arange(k), np.arange(k)] = -ev[:k]
         hip.ops.lincomb(evec, ax, (0, 0), (k, k), np.asfortranarray(coef).ravel(order="F"), k, beta=np.ones(1), incb=0)
         nr = np.sqrt(hip.ops.inner_prod("D", ax, ax, (0, 0), (k, k)))
         hip.ops.mv_destroy(ax, k)
-        hip.ops.mv_destroy(evec, args.nevmax)
+        hip.ops.mv_destroy(evec, k if matB is not None else args.nevmax)
         parity = {"max_rel_residual_recomputed": float(np.max(nr / (np.abs(ev[:k]) * nx))) if k else None}
     else:
         cs = [np.sort(2.0 * np.cos(np.arange(1, d + 1) * np.pi / (d + 1)))[::-1][:48] for d in dims]
@@ -706,8 +756,8 @@ def main():
         wsolver = ("fused device block-CG (30 its, rate 1e-2)" if amg is None else
                    "BlockAMG (%d levels of 2x2x2 aggregates, 1 V-cycle, %s fused-CG smoothing its before and after the coarse correction, rate 1e-2)"
                    % (amg_levels, args.amg_smooth.replace(",", " / ")))
-        cfg = {"workload": "%s, nev=%d, block=%d, nevMax=%d, B=NULL, tol abs 1e-1 rel 1e-8, %s, "
-                           "X/W orthonormalisation '%s', device RNG start block" % (workload, args.nev, args.block, args.nevmax, wsolver, args.orth),
+        cfg = {"workload": "%s, nev=%d, block=%d, nevMax=%d, %s, tol abs 1e-1 rel 1e-8, %s, "
+                           "X/W orthonormalisation '%s', device RNG start block" % (workload, args.nev, args.block, args.nevmax, "B = mass matrix" if c3 else "B=NULL", wsolver, args.orth),
                "amg_levels": amg_levels, "amg_setup_seconds": amg_setup_seconds,
                "gcg_iterations": iters, "nev_converged": conv_total,
                "cg_active_column_fraction": (ai.value / ci.value) if ci.value else None,
@@ -718,6 +768,7 @@ def main():
         cfg.update(parity)
         out = {
             "metric": ("converged eigenpairs/sec (GCG, SiO2-like irregular CSR n=%d, block=%d)" if c5 else
+                       "converged eigenpairs/sec (GCG, FE stiffness/mass pair n=%d, block=%d, generalised)" if c3 else
                        "converged eigenpairs/sec (GCG, 3D Laplacian n=%d, block=%d)") % (n_global, args.block),
             "value": conv_total / elapsed, "unit": "eigenpairs/s", "n_gpus": world, "steps": args.steps,
             # `value` counts every pair a solve converged (a whole block locks at once: 56 for 50 wanted at config 2);
@@ -788,6 +839,9 @@ def main():
                 g.gcge_hip_pool_release()
                 return k1_c5_leg(hip, args)
             leg("roofline_k1_c5", k1c5)
+        if c3 and world == 1 and not args.no_extra:
+            leg("roofline_k1_spmm_A", lambda: k1_plain_leg(hip, mat, A, args.block, "stiffness matrix A (7-point stencil x h), config 3"))
+            leg("roofline_k1_spmm_B", lambda: k1_plain_leg(hip, matB, Bc, args.block, "consistent mass matrix B (15-point stencil x h^3), config 3"))
         if not args.no_cpu and world == 1:
             leg("cpu_baseline", lambda: cpu_baseline(args, hip))
             if extra:

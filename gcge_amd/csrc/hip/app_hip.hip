@@ -1243,18 +1243,24 @@ extern "C" int gcge_hip_cg_start_scaled_mv(void* mat, void** x, int xc0, const d
 // (round 4; config 5: 13 -> 5 ms per outer iteration).  Chunks of <= 64 columns (the halo buffers' width on slabs).
 extern "C" int gcge_hip_resid_sq(int nrows, const double* d_w, long ldw, const double* d_x, long ldx, int m, const double* d_lambda,
                                  double* d_out, void* stream);
-static int resid_sq_stored(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int start, int end, const double* lambda, double* res_sq) {
+// Round 5: the GENERALISED problem (B != NULL; reference src/ops_eig_sol_gcg.c:195-315: A x, B x, lambda B x, the difference, its
+// column norms = 11 block streams through five slots) takes the same route with two scratch blocks: A x and B x by the products
+// (whatever K1 form each matrix has), then ONE sweep sum_r ((A x)[r,j] - lambda_j (B x)[r,j])^2 over the two — 2 + 2 + 2 streams.
+static int resid_sq_stored(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int start, int end, const double* lambda, double* res_sq, GCGE_HIP_MAT_* Bm = nullptr) {
   if (getenv("GCGE_NO_STORED_RESIDUAL_HOOK") != nullptr) return 0;
   if ((vx->ld & 1) || ((uintptr_t)vx->d & 15) || A->nrows + A->nghost > vx->nrows_alloc) return 0;
+  if (Bm != nullptr && (Bm->nrows != A->nrows || Bm->rect_ncols > 0 || Bm->nrows + Bm->nghost > vx->nrows_alloc)) return 0;
   const int c0 = start & ~1, c1 = (end + 1) & ~1;
   if (c1 > vx->ld) return 0;
   const int chunk = 64;
   const size_t bytes = (size_t)A->nrows * chunk * sizeof(double);
   double* t = (double*)pool_alloc(bytes);
+  double* tb = Bm != nullptr ? (double*)pool_alloc(bytes) : nullptr;
   int ok = 1;
   for (int b0 = c0; b0 < c1 && ok; b0 += chunk) {
     const int m = std::min(chunk, c1 - b0);
     if (A->nghost > 0 && m > A->buf_cols) { ok = 0; break; }
+    if (Bm != nullptr && Bm->nghost > 0 && m > Bm->buf_cols) { ok = 0; break; }
     double* dd = stage_d(2 * (size_t)m);
     GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));   // the pinned staging may still feed an upload of the previous chunk / slot call
     double* hl = stage_h(2 * (size_t)m);
@@ -1262,20 +1268,23 @@ static int resid_sq_stored(GCGE_HIP_MAT_* A, GcgeHipMV* vx, int start, int end, 
     GCGE_HIP_CHECK(hipMemcpyAsync(dd + m, hl, m * sizeof(double), hipMemcpyHostToDevice, g_stream));
     const int rc = spmm_halo(A, vx, b0, t, (long)m, m, nullptr, nullptr);
     GCGE_REQUIRE(rc == 0, "residual norms: product");
-    GCGE_REQUIRE(gcge_hip_resid_sq(A->nrows, t, (long)m, vx->d + b0, vx->ld, m, dd + m, dd, g_stream) == 0, "residual norms: sweep");
+    if (Bm != nullptr) GCGE_REQUIRE(spmm_halo(Bm, vx, b0, tb, (long)m, m, nullptr, nullptr) == 0, "residual norms: product with B");
+    GCGE_REQUIRE(gcge_hip_resid_sq(A->nrows, t, (long)m, Bm != nullptr ? tb : vx->d + b0, Bm != nullptr ? (long)m : vx->ld, m, dd + m, dd, g_stream) == 0, "residual norms: sweep");
     GCGE_HIP_CHECK(hipMemcpyAsync(hl + m, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
     GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
     for (int j = 0; j < m; ++j) if (b0 + j >= start && b0 + j < end) res_sq[b0 + j - start] = hl[m + j];
   }
   pool_free(t, bytes);
+  if (tb != nullptr) pool_free(tb, bytes);
   return ok;
 }
 static int HIP_ResidualSq(void* mat, void* matB, void** x, int start, int end, const double* lambda, double* res_sq) {
   enter();
   GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat; GcgeHipMV* vx = (GcgeHipMV*)x;
-  if (A == nullptr || matB != nullptr || end <= start) return 0;
+  if (A == nullptr || end <= start) return 0;
   const int c0 = start & ~1, c1 = (end + 1) & ~1, m = c1 - c0;
   if (c1 > vx->ld || A->nrows != vx->nrows) return 0;
+  if (matB != nullptr) return getenv("GCGE_NO_GENERAL_RESIDUAL_HOOK") == nullptr ? resid_sq_stored(A, vx, start, end, lambda, res_sq, (GCGE_HIP_MAT_*)matB) : 0;
   if (!gcge_hip_cg_fusable(mat, x, m)) return resid_sq_stored(A, vx, start, end, lambda, res_sq);
   double* dd = stage_d(7 * (size_t)m);
   double* d_lam = dd + 6 * (size_t)m;

@@ -329,7 +329,9 @@ __device__ __forceinline__ void star_block_of(int xcd, unsigned& bx, unsigned& b
 }
 template <int N> __device__ __forceinline__ void star3_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
-template <bool DOT, bool SLAB>
+// PROBE (timing only, results wrong): the own points of plane z + 2 are requested at step z — at the lead of the halo strips — instead
+// of those of plane z + 8: what a sweep that needs a plane's own points and its halo in the SAME step would request (tools/star_lead_probe.py)
+template <bool DOT, bool SLAB, bool PROBE = false>
 __global__ __launch_bounds__(1024) void spmm_star3_kernel(int nx, int ny, int zs, int ze, int zmin, int zmax, long dlo, long dhi, StarCoef cf,
     const double* __restrict__ diag, const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols,
     int zlo, int zhi, int zlen, int ntx, double* __restrict__ partial, const unsigned char* __restrict__ cleanf, int xcd) {
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(1024) void spmm_star3_kernel(int nx, int ny, int zs
       img[slot] = qv[S3SLOT(U, 0)];                                                                                         \
       __syncthreads();                                   /* B: the image of plane z is complete, strip buffer sl is free */ \
       dma_plane(z + 2, sl);                                                                                                 \
-      qv[S3SLOT(U, STAR_R + 2)] = ld_own(z + STAR_R + 2);      /* first used at step z + 2 */                               \
+      qv[S3SLOT(U, STAR_R + 2)] = ld_own(z + (PROBE ? 2 : STAR_R + 2));      /* first used at step z + 2 */                 \
       dg3[((U) + 2) % 3] = ld_diag(z + 2);                                                                                  \
       cl3[((U) + 2) % 3] = ld_clean(z + 2);                                                                                 \
       const double dg = dg3[(U) % 3];                                                                                       \
@@ -881,7 +883,7 @@ static int g_star_form = 3;   // 2: second form of the sweep (registers stage th
 extern "C" void gcge_hip_spmm_star_form(int form) { g_star_form = form == 3 ? 3 : 2; }
 static int g_star_lpp = 4;    // second form: 8 = 16-column passes on 16 x 8 patches (128-byte pieces of the rows), 4 = 8 columns on 16 x 16 (64-byte pieces)
 extern "C" void gcge_hip_spmm_star_lanes(int lpp) { g_star_lpp = lpp == 4 ? 4 : 8; }
-static int g_star_xcd = 0;    // 0: workgroups in launch order; 1 / G >= 2: XCD-aware orders (star_block_of) — measured, not faster
+static int g_star_xcd = 22;   // 0: workgroups in launch order; 1 / G >= 2: XCD-aware orders (star_block_of): runs of 22 patches (two patch rows of the 171^2 plane) per XCD are 2 % faster than launch order (2.78 against 2.84 ms, profiles/r04_star/16, gpurun_out/r5/09)
 extern "C" void gcge_hip_spmm_star_xcd(int on) { g_star_xcd = on < 0 ? 0 : on; }
 static int g_star_dbg = 0;    // measurement only: 1 no halo loads, 2 no LDS arm reads, 4 no stores, 8 no own-plane loads (results are wrong then)
 extern "C" void gcge_hip_spmm_star_dbg(int bits) { g_star_dbg = bits; }
@@ -1134,6 +1136,13 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
     }
 #define STAR_LAUNCH3(DOT, SLAB) hipLaunchKernelGGL((spmm_star3_kernel<DOT, SLAB>), grid, dim3(1024), STAR3_LDS, stream, g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax, \
                                                    dlo, dhi, S->c, dv, xv, (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part, cv, g_star_xcd)
+    if (g_star_dbg == 32 && !dot && !slab) {
+      static bool probe_attr = false;
+      if (!probe_attr) { GCGE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_star3_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STAR3_LDS)); probe_attr = true; }
+      hipLaunchKernelGGL((spmm_star3_kernel<false, false, true>), grid, dim3(1024), STAR3_LDS, stream, g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax,
+                         dlo, dhi, S->c, dv, xv, (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part, cv, g_star_xcd);
+      return nb;
+    }
     if (dot) { if (slab) STAR_LAUNCH3(true, true); else STAR_LAUNCH3(true, false); }
     else     { if (slab) STAR_LAUNCH3(false, true); else STAR_LAUNCH3(false, false); }
 #undef STAR_LAUNCH3

@@ -605,6 +605,85 @@ def test_gcg_residual_hook_equals_slot_path(hip):
     assert np.max(np.abs(out["hook"][0] - out["slots"][0]) / np.abs(out["slots"][0])) < 1e-12
 
 
+def test_gcg_generalised_residual_hook_equals_slot_path(hip):
+    """B != NULL (BASELINE config 3's kind of problem): CheckConvergence through the hook — A x and B x into two scratch blocks, ONE
+    sweep for the column sums of (A x - lambda B x)^2 — and through the reference's five slots (src/ops_eig_sol_gcg.c:195-315):
+    same locking decisions, same iteration count, same Ritz values; and the hook's numbers against scipy on a ragged column range."""
+    import os
+    from helpers import csr_to_scipy, uniform
+    out = {}
+    for tag in ("hook", "slots"):
+        if tag == "slots":
+            os.environ["GCGE_NO_GENERAL_RESIDUAL_HOOK"] = "1"
+        try:
+            hip.set_random_mode(0)
+            ev, res = gcg_on(hip, "fe3d", 12, ["-nevConv", 10, "-nevMax", 24, "-blockSize", 8, "-gcge_initX_orth_method", "chol",
+                                               "-gcge_compW_orth_method", "chol"])
+            out[tag] = (ev[:res.nevConv].copy(), res.nevConv, res.numIter)
+        finally:
+            os.environ.pop("GCGE_NO_GENERAL_RESIDUAL_HOOK", None)
+    assert out["hook"][1:] == out["slots"][1:], (out["hook"][1:], out["slots"][1:])
+    assert np.max(np.abs(out["hook"][0] - out["slots"][0]) / np.abs(out["slots"][0])) < 1e-12
+    A, B = make_problem("fe3d", 11)
+    SA, SB = csr_to_scipy(A), csr_to_scipy(B)
+    mA, mB = hip.matrix(A), hip.matrix(B)
+    n = A.nrows
+    X = uniform(77, (n, 21)) - 0.5
+    lam = uniform(78, (21,)) * 50.0
+    vx = hip.mv_from_numpy(mA, X)
+    fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
+    hip.g.gcge_hip_residual_hook.restype = C.c_void_p
+    hook = fn(hip.g.gcge_hip_residual_hook())
+    for (s0, e0) in ((0, 21), (3, 20), (5, 6)):
+        got = np.zeros(e0 - s0)
+        la = np.ascontiguousarray(lam[s0:e0])
+        assert hook(mA, mB, vx, s0, e0, la.ctypes.data_as(C.POINTER(C.c_double)), got.ctypes.data_as(C.POINTER(C.c_double))) == 1
+        want = np.sum((SA @ X[:, s0:e0] - (SB @ X[:, s0:e0]) * la) ** 2, axis=0)
+        assert np.max(np.abs(got - want) / want) < 1e-12
+    hip.ops.mv_destroy(vx, 21)
+    hip.free_matrix(mA)
+    hip.free_matrix(mB)
+
+
+def test_full_size_config3_properties(hip):
+    """BASELINE config 3 at FULL size (P1 stiffness / mass pair on 100^3 interior nodes, n = 10^6, 128 columns): symmetry of both
+    products column-wise, the row sums of the mass matrix (sum of all entries = the volume covered by the interior hat functions:
+    1^T B 1 -> h^3 per interior node away from the boundary) and of the stiffness matrix (1^T A 1 = boundary couplings only)."""
+    import ctypes
+    M = 100
+    A, B = make_problem("fe3d", M)
+    mA, mB = hip.matrix(A), hip.matrix(B)
+    n = A.nrows
+    ops = hip.ops
+    m = 128
+    x = ops.mv_create(m, mA); y = ops.mv_create(m, mA); ax = ops.mv_create(m, mA); ay = ops.mv_create(m, mA)
+    hip.set_random_mode(1, 31)
+    ops.set_random(x, 0, m); ops.set_random(y, 0, m)
+    hip.set_random_mode(0)
+    for mat in (mA, mB):
+        ops.spmm(mat, x, ax, (0, 0), (m, m)); ops.spmm(mat, y, ay, (0, 0), (m, m))
+        d1 = ops.inner_prod("D", x, ay, (0, 0), (m, m)); d2 = ops.inner_prod("D", ax, y, (0, 0), (m, m))
+        assert np.max(np.abs(d1 - d2) / np.abs(d1)) < 1e-12
+    ones = ops.mv_create(2, mA)
+    hones = np.ones((n, 2), order="F")
+    hip.g.gcge_hip_mv_from_host(ones, 0, 2, hones.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n)
+    sums = {}
+    for tag, mat, csr in (("A", mA, A), ("B", mB, B)):
+        ops.spmm(mat, ones, x, (0, 0), (2, 2))
+        sums[tag] = ops.inner_prod("D", ones, x, (0, 0), (2, 2))[0]
+        want = float(np.sum(np.ctypeslib.as_array(csr.val, shape=(int(csr.nnz),))))
+        assert abs(sums[tag] - want) <= 1e-10 * abs(want), (tag, sums[tag], want)
+    h = 1.0 / (M + 1)
+    # interior rows of B sum to h^3 (0.4 + 6/20 + 2/20 + 6/30 = 1): the total is n h^3 minus what the faces cut off (a few per cent)
+    assert 0.9 * n * h ** 3 < sums["B"] < n * h ** 3
+    assert sums["A"] > 0 and sums["A"] < 6.0 * h * n                  # interior rows of A sum to zero: only boundary nodes contribute
+    for v in (x, y, ax, ay):
+        ops.mv_destroy(v, m)
+    ops.mv_destroy(ones, 2)
+    hip.free_matrix(mA)
+    hip.free_matrix(mB)
+
+
 @pytest.mark.parametrize("kind,size,m", [("lap3d", 16, 24), ("lap3d", 12, 6), ("fe3d", 12, 16)])
 def test_cg_start_sweep_matches_numpy(hip, kind, size, m):
     """r = b - A x, p0 = r, rho = diag(r^T r) in one sweep (gcge_hip_cg_start_mv, kernel MODE 5), both kernel routes."""
