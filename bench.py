@@ -177,6 +177,8 @@ def pmc_traffic_c5(G, atoms, m):
     sh = t.get("shape", {})
     if sh.get("G") != G or sh.get("atoms") != atoms or sh.get("m") != m:
         return None, "profiles/pmc_traffic.json (c5) holds G=%s atoms=%s m=%s" % (sh.get("G"), sh.get("atoms"), sh.get("m"))
+    if "product_fabric_bytes" in t:            # round 5: every kernel of the product (sweep + dense blocks + listed rows)
+        return t["product_fabric_bytes"], "all kernels of the product (%s); %s" % (t.get("profile"), t.get("bytes_rule"))
     k = next(iter(t["kernels"].values()))
     return k["fabric_bytes_per_block_operation"], "plane sweep only (%s); %s" % (t.get("profile"), t.get("bytes_rule"))
 
@@ -666,11 +668,15 @@ def main():
         ax = hip.ops.mv_create(k, mat)
         hip.ops.spmm(mat, evec, ax, (0, 0), (k, k))
         if matB is not None:
+            # generalised problem: the reference's own criterion (src/ops_eig_sol_gcg.c:240-259) — ||A x - lambda B x||_2 against
+            # lambda for B-normalised x — so the norm below is sqrt(x'Bx)
             bx = hip.ops.mv_create(k, mat)
             hip.ops.spmm(matB, evec, bx, (0, 0), (k, k))
+            nx = np.sqrt(hip.ops.inner_prod("D", evec, bx, (0, 0), (k, k)))
             hip.ops.mv_destroy(evec, args.nevmax)
             evec = bx
-        nx = np.sqrt(hip.ops.inner_prod("D", evec, evec, (0, 0), (k, k)))
+        else:
+            nx = np.sqrt(hip.ops.inner_prod("D", evec, evec, (0, 0), (k, k)))
         coef = np.zeros((k, k))
         coef[np.arange(k), np.arange(k)] = -ev[:k]
         hip.ops.lincomb(evec, ax, (0, 0), (k, k), np.asfortranarray(coef).ravel(order="F"), k, beta=np.ones(1), incb=0)

@@ -615,30 +615,39 @@ static void HIP_MultiVecLinearComb(void** x, void** y, int is_vec, int* start, i
 
 // app_lapack.c:299-313 -> DenseMatQtAP(matA == NULL) :64-183.  Result to HOST, column-major ldIP.
 static void reduce_inner_prod(char nsd, int nr, int nc, double* ip, int ldIP);
-static void local_inner_prod(char nsd, void** x, void** y, int is_vec, int* start, int* end, double* ip, int ldIP, struct OPS_* ops);
+// reduce != 0: the SUM OVER THE RANKS is returned; returns 1 if that sum was formed (on the device, before the one copy to the host:
+// RCCL inside the back-end), 0 if the caller still has to reduce the host result through GCGE_COMM (another transport; the served
+// Gram column of a fused Gram-Schmidt step)
+static int local_inner_prod(char nsd, void** x, void** y, int is_vec, int* start, int* end, double* ip, int ldIP, struct OPS_* ops, int reduce = 0);
 // the slot: the local rows' part — or, where the caller opted in (GCGE_SetLocalInnerProdReduces: stacks that sum through MPI only,
 // the reference's BlockPCG src/ops_lin_sol.c:306-321), the sum over the ranks
 static void HIP_MultiVecLocalInnerProd(char nsd, void** x, void** y, int is_vec, int* start, int* end, double* ip, int ldIP, struct OPS_* ops) {
-  local_inner_prod(nsd, x, y, is_vec, start, end, ip, ldIP, ops);
-  if (GCGE_GetLocalInnerProdReduces()) reduce_inner_prod(nsd, end[0] - start[0], end[1] - start[1], ip, ldIP);
+  const int want = GCGE_GetLocalInnerProdReduces();
+  if (!local_inner_prod(nsd, x, y, is_vec, start, end, ip, ldIP, ops, want) && want) reduce_inner_prod(nsd, end[0] - start[0], end[1] - start[1], ip, ldIP);
 }
 extern "C" void gcge_hip_local_inner_prod(char nsd, void** x, void** y, int* start, int* end, double* ip, int ldIP, struct OPS_* ops) {
   local_inner_prod(nsd, x, y, 0, start, end, ip, ldIP, ops);           // for block_pcg.hip: the local rows' part, never reduced
 }
-static void local_inner_prod(char nsd, void** x, void** y, int is_vec, int* start, int* end,
-                                       double* ip, int ldIP, struct OPS_* ops) {
+static int local_inner_prod(char nsd, void** x, void** y, int is_vec, int* start, int* end,
+                                       double* ip, int ldIP, struct OPS_* ops, int reduce) {
   GcgeHipMV *vx = (GcgeHipMV*)x, *vy = (GcgeHipMV*)y;
   const int k = end[0] - start[0], m = end[1] - start[1];
   enter();
   SlotTimer tm_(m == 1 ? "MultiVecLocalInnerProd (k x 1)" : "MultiVecLocalInnerProd", m == 1 ? k : m);
-  if (k <= 0 || m <= 0) return;
+  if (k <= 0 || m <= 0) return 0;
+  // Round 5: with RCCL inside the back-end the partial Gram is summed over the ranks WHERE IT IS — on the device,
+  // on the back-end's stream, in front of the one device-to-host copy — instead of host -> pinned -> device -> ncclAllReduce -> pinned
+  // -> host behind it: one stream synchronisation per inner product instead of two, no second staging.  ~1 700 inner products per
+  // solve are latency, not bytes.  Reference: MPI_Allreduce of the local result, src/ops_multi_vec.c:206-228.
+  GCGE_COMM* comm_ = reduce ? GCGE_GetComm() : nullptr;
+  const bool dev_reduce = comm_ != nullptr && gcge_hip_comm_is_native(comm_) && getenv("GCGE_GRAM_HOST_REDUCE") == nullptr;
   if (m == 1 && nsd != 'D' && vx == vy && vx->spec_dots != nullptr && !vx->spec_dots->empty() && vx->spec_epoch + 1 == g_epoch &&
       start[0] == vx->spec_c0 && start[1] == vx->spec_c0 && end[0] == vx->spec_c1 && (int)vx->spec_dots->size() == k && ldIP >= k) {
     // the Gram column the previous call (the rank-1 update of a Gram-Schmidt step ON THIS BLOCK) accumulated on its way: no
     // call of any kind has been made since (epoch), same block, same column range
     for (int i = 0; i < k; ++i) ip[i] = (*vx->spec_dots)[i];
     vx->spec_dots->clear(); ++g_mgs_spec_hits;
-    return;
+    return 0;
   }
   if (vx->spec_dots != nullptr) vx->spec_dots->clear();
   if (vy->spec_dots != nullptr) vy->spec_dots->clear();
@@ -649,15 +658,17 @@ static void local_inner_prod(char nsd, void** x, void** y, int is_vec, int* star
     GCGE_REQUIRE(k == m, "MultiVecInnerProd 'D': square");
     double* dd = stage_d(m);
     gcge_hip_coldots(vx->nrows, vx->d + start[0], vx->ld, vy->d + start[1], vy->ld, m, dd, g_stream);
+    if (dev_reduce) gcge_hip_comm_allreduce_device(dd, m);
     double* hd = stage_h(m);
     GCGE_HIP_CHECK(hipMemcpyAsync(hd, dd, m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
     GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
     for (int j = 0; j < m; ++j) ip[(size_t)ldIP * j] = hd[j];
-    return;
+    return dev_reduce ? 1 : 0;
   }
   double* dg = stage_d((size_t)k * m);
   if (m == 1) gcge_hip_panel_dot1(vx->nrows, vx->d + start[0], vx->ld, k, vy->d + start[1], vy->ld, dg, g_stream);   // panel . column
   else { DenseProfScope prof_(0, vx->nrows, k, m, 8.0 * (double)vx->nrows * ((vx == vy && start[0] == start[1] && k == m) ? k : k + m)); gcge_hip_gram(vx->nrows, vx->d + start[0], vx->ld, k, vy->d + start[1], vy->ld, m, dg, g_stream); }
+  if (dev_reduce) gcge_hip_comm_allreduce_device(dg, k * m);      // (the whole k x m block: contiguous on the device whatever ldIP is)
   double* hg = stage_h((size_t)k * m);
   GCGE_HIP_CHECK(hipMemcpyAsync(hg, dg, (size_t)k * m * sizeof(double), hipMemcpyDeviceToHost, g_stream));
   GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
@@ -669,6 +680,7 @@ static void local_inner_prod(char nsd, void** x, void** y, int is_vec, int* star
     for (int j = 0; j < m; ++j)
       for (int i = 0; i < k; ++i) ip[(size_t)ldIP * j + i] = hg[(size_t)i * m + j];
   }
+  return dev_reduce ? 1 : 0;
 }
 
 // row-partitioned matrices: fetch the halo rows of X[:, c_begin : c_begin + m) from their owners
@@ -1326,8 +1338,8 @@ static void HIP_MatTransDotMultiVec(void* mat, void** x, void** y, int* start, i
 // default of the same name only reduces under OPS_USE_MPI, src/ops_multi_vec.c:202-230 — finds these slots filled.
 static void HIP_MultiVecInnerProd(char nsd, void** x, void** y, int is_vec, int* start, int* end, double* ip, int ldIP,
                                   struct OPS_* ops) {
-  local_inner_prod(nsd, x, y, is_vec, start, end, ip, ldIP, ops);
-  reduce_inner_prod(nsd, end[0] - start[0], end[1] - start[1], ip, ldIP);
+  if (!local_inner_prod(nsd, x, y, is_vec, start, end, ip, ldIP, ops, 1))
+    reduce_inner_prod(nsd, end[0] - start[0], end[1] - start[1], ip, ldIP);
 }
 static void reduce_inner_prod(char nsd, int nr, int nc, double* ip, int ldIP) {
   GCGE_COMM* comm = GCGE_GetComm();

@@ -196,6 +196,41 @@ extern "C" int gcge_hip_mat_set_halo_rccl(GCGE_HIP_MAT* A, int nglobal, int npee
   return 0;
 }
 
+// the two int transports of the planner (GCGE_PLAN_TRANSPORT, include/gcge_problems.h) over RCCL: device staging, the back-end's stream
+static void rccl_allgather_int(const int* send, int n, int* recv_all, void* ctx) {
+  (void)ctx;
+  hipStream_t st = (hipStream_t)gcge_hip_stream();
+  int *d_s = nullptr, *d_r = nullptr;
+  GCGE_HIP_CHECK(hipMalloc(&d_s, std::max(1, n) * sizeof(int)));
+  GCGE_HIP_CHECK(hipMalloc(&d_r, (size_t)std::max(1, n) * g_world * sizeof(int)));
+  GCGE_HIP_CHECK(hipMemcpyAsync(d_s, send, n * sizeof(int), hipMemcpyHostToDevice, st));
+  GCGE_NCCL_CHECK(ncclAllGather(d_s, d_r, n, ncclInt32, g_nccl, st));
+  GCGE_HIP_CHECK(hipMemcpyAsync(recv_all, d_r, (size_t)n * g_world * sizeof(int), hipMemcpyDeviceToHost, st));
+  GCGE_HIP_CHECK(hipStreamSynchronize(st));
+  hipFree(d_s); hipFree(d_r);
+}
+static void rccl_exchange_int(const int* sendbuf, const int* send_cnt, int* recvbuf, const int* recv_cnt, void* ctx) {
+  (void)ctx;
+  hipStream_t st = (hipStream_t)gcge_hip_stream();
+  long ns = 0, nr = 0;
+  for (int q = 0; q < g_world; ++q) { ns += send_cnt[q]; nr += recv_cnt[q]; }
+  int *d_s = nullptr, *d_r = nullptr;
+  GCGE_HIP_CHECK(hipMalloc(&d_s, std::max<long>(1, ns) * sizeof(int)));
+  GCGE_HIP_CHECK(hipMalloc(&d_r, std::max<long>(1, nr) * sizeof(int)));
+  GCGE_HIP_CHECK(hipMemcpyAsync(d_s, sendbuf, ns * sizeof(int), hipMemcpyHostToDevice, st));
+  GCGE_NCCL_CHECK(ncclGroupStart());
+  long so = 0, ro = 0;
+  for (int q = 0; q < g_world; ++q) {
+    if (send_cnt[q] > 0) GCGE_NCCL_CHECK(ncclSend(d_s + so, send_cnt[q], ncclInt32, q, g_nccl, st));
+    if (recv_cnt[q] > 0) GCGE_NCCL_CHECK(ncclRecv(d_r + ro, recv_cnt[q], ncclInt32, q, g_nccl, st));
+    so += send_cnt[q]; ro += recv_cnt[q];
+  }
+  GCGE_NCCL_CHECK(ncclGroupEnd());
+  GCGE_HIP_CHECK(hipMemcpyAsync(recvbuf, d_r, nr * sizeof(int), hipMemcpyDeviceToHost, st));
+  GCGE_HIP_CHECK(hipStreamSynchronize(st));
+  hipFree(d_s); hipFree(d_r);
+}
+
 // Rows [part[rank], part[rank+1]) of a symmetric matrix with GLOBAL column indices (host CSR).  Everything a row-
 // partitioned product needs is set up here, collectively (every rank of the communicator calls it): ghost list and
 // local renumbering, who needs which of my rows (one all-gather of the per-slab counts, then the index lists by
@@ -218,48 +253,16 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_slab(const long* part, const int* r
   if (gcge_dist_ghosts(&S, &ghosts, &ng) != 0) return nullptr;
   std::vector<int> recv_cnt(world, 0), send_cnt(world, 0), peer(world);
   for (int q = 0; q < world; ++q) peer[q] = q;
-  for (int i = 0; i < ng; ++i) {
-    const int q = (int)(std::upper_bound(part, part + world + 1, (long)ghosts[i]) - part) - 1;
-    if (q < 0 || q >= world || q == rank) { fprintf(stderr, "gcge_hip_mat_create_slab: ghost %d outside the partition\n", ghosts[i]); abort(); }
-    ++recv_cnt[q];
-  }
-  std::vector<int> send_rows;
-  if (world > 1) {
-    if (g_nccl == nullptr) { fprintf(stderr, "gcge_hip_mat_create_slab: call gcge_hip_comm_init first\n"); return nullptr; }
-    hipStream_t st = (hipStream_t)gcge_hip_stream();
-    // 1. counts: need[p][q] = rows slab p needs from slab q
-    int *d_need = nullptr, *d_all = nullptr;
-    GCGE_HIP_CHECK(hipMalloc(&d_need, world * sizeof(int)));
-    GCGE_HIP_CHECK(hipMalloc(&d_all, (size_t)world * world * sizeof(int)));
-    GCGE_HIP_CHECK(hipMemcpyAsync(d_need, recv_cnt.data(), world * sizeof(int), hipMemcpyHostToDevice, st));
-    GCGE_NCCL_CHECK(ncclAllGather(d_need, d_all, world, ncclInt32, g_nccl, st));
-    std::vector<int> all((size_t)world * world);
-    GCGE_HIP_CHECK(hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, st));
-    GCGE_HIP_CHECK(hipStreamSynchronize(st));
-    long ns = 0;
-    for (int p = 0; p < world; ++p) { send_cnt[p] = all[(size_t)p * world + rank]; ns += send_cnt[p]; }
-    // 2. index lists: I tell every owner which of its rows (global ids, ascending) I need
-    int *d_gh = nullptr, *d_want = nullptr;
-    GCGE_HIP_CHECK(hipMalloc(&d_gh, std::max(1, ng) * sizeof(int)));
-    GCGE_HIP_CHECK(hipMalloc(&d_want, std::max<long>(1, ns) * sizeof(int)));
-    GCGE_HIP_CHECK(hipMemcpyAsync(d_gh, ghosts, ng * sizeof(int), hipMemcpyHostToDevice, st));
-    GCGE_NCCL_CHECK(ncclGroupStart());
-    long go = 0, wo = 0;
-    for (int q = 0; q < world; ++q) {
-      if (recv_cnt[q] > 0) GCGE_NCCL_CHECK(ncclSend(d_gh + go, recv_cnt[q], ncclInt32, q, g_nccl, st));
-      if (send_cnt[q] > 0) GCGE_NCCL_CHECK(ncclRecv(d_want + wo, send_cnt[q], ncclInt32, q, g_nccl, st));
-      go += recv_cnt[q]; wo += send_cnt[q];
-    }
-    GCGE_NCCL_CHECK(ncclGroupEnd());
-    send_rows.resize(ns);
-    GCGE_HIP_CHECK(hipMemcpyAsync(send_rows.data(), d_want, ns * sizeof(int), hipMemcpyDeviceToHost, st));
-    GCGE_HIP_CHECK(hipStreamSynchronize(st));
-    for (long i = 0; i < ns; ++i) send_rows[i] -= (int)part[rank];
-    hipFree(d_need); hipFree(d_all); hipFree(d_gh); hipFree(d_want);
-  } else if (ng != 0) {
-    fprintf(stderr, "gcge_hip_mat_create_slab: single rank but %d columns outside the row range\n", ng);
-    return nullptr;
-  }
+  if (world > 1 && g_nccl == nullptr) { fprintf(stderr, "gcge_hip_mat_create_slab: call gcge_hip_comm_init first\n"); return nullptr; }
+  // the plan comes from the ONE planner of the host library (gcge_dist_plan_halo, csrc/host/problems.c) — the function the gloo
+  // tests run with 2 / 3 / 8 ranks; only the two int transports below are RCCL's own
+  GCGE_PLAN_TRANSPORT tr;
+  tr.rank = rank; tr.size = world; tr.allgather_int = rccl_allgather_int; tr.exchange_int = rccl_exchange_int; tr.ctx = nullptr;
+  int* srows = nullptr; int nsend = 0;
+  const int prc = gcge_dist_plan_halo(part, ghosts, ng, &tr, recv_cnt.data(), send_cnt.data(), &srows, &nsend);
+  if (prc != 0) { fprintf(stderr, "gcge_hip_mat_create_slab: halo plan failed (%d)\n", prc); gcge_free_ints(ghosts); return nullptr; }
+  std::vector<int> send_rows(srows, srows + nsend);
+  gcge_free_ints(srows);
   if (gcge_dist_localize(&S, ghosts, ng) != 0) { gcge_free_ints(ghosts); return nullptr; }
   // (the halo rows' global ids travel with the arrays: a slab of a grid matrix cut on plane boundaries keeps the plane sweep)
   GCGE_HIP_MAT* A = gcge_hip_mat_create_local_ghosts(nrows, nrows + ng, (int)n_global, (int)part[rank], rowptr, cols.data(), val, ghosts);

@@ -356,6 +356,46 @@ int gcge_dist_localize(GCGE_CSR *A, const int *ghosts, int nghost)
 	return 0;
 }
 
+/* Halo plan of a row slab over ANY transport (one planner for every back-end and every transport: RCCL inside the HIP back-end,
+ * torch.distributed / gloo in the tests).  What the reference's distributed back-ends get from PETSc / hypre / PHG when a matrix
+ * is assembled (app/app_phg.c:292-359 uses the result: phgMapScatterBegin/End).  See include/gcge_problems.h. */
+int gcge_dist_plan_halo(const long *part, const int *ghosts, int nghost, const GCGE_PLAN_TRANSPORT *t,
+		int *recv_cnt, int *send_cnt, int **send_rows_out, int *nsend_out)
+{
+	const int world = t->size, rank = t->rank;
+	int q, i, *all = NULL, *want = NULL, *gsend = NULL; long ns = 0;
+	*send_rows_out = NULL; *nsend_out = 0;
+	for (q = 0; q < world; ++q) { recv_cnt[q] = 0; send_cnt[q] = 0; }
+	/* who owns each of my halo rows (ascending global ids: grouped by owner, owners ascending) */
+	for (i = 0, q = 0; i < nghost; ++i) {
+		if (i > 0 && ghosts[i] <= ghosts[i - 1]) return -2;                 /* not ascending / not unique */
+		while (q < world && (long)ghosts[i] >= part[q + 1]) ++q;
+		if (q >= world || (long)ghosts[i] < part[q] || q == rank) return -3;  /* outside the partition, or one of my own rows */
+		++recv_cnt[q];
+	}
+	if (world == 1) return nghost == 0 ? 0 : -3;
+	/* 1. counts: need[p][q] = rows slab p needs from slab q; I ship need[p][me] rows to p */
+	all = (int*)malloc((size_t)world * world * sizeof(int));
+	if (all == NULL) return -1;
+	t->allgather_int(recv_cnt, world, all, t->ctx);
+	for (q = 0; q < world; ++q) { send_cnt[q] = all[(size_t)q * world + rank]; ns += send_cnt[q]; }
+	free(all);
+	if (send_cnt[rank] != 0) return -4;
+	/* 2. index lists: every owner learns which of its rows (global ids, ascending) I need */
+	want = (int*)malloc((size_t)(ns > 0 ? ns : 1) * sizeof(int));
+	gsend = (int*)malloc((size_t)(nghost > 0 ? nghost : 1) * sizeof(int));
+	if (want == NULL || gsend == NULL) { free(want); free(gsend); return -1; }
+	memcpy(gsend, ghosts, (size_t)nghost * sizeof(int));
+	t->exchange_int(gsend, recv_cnt, want, send_cnt, t->ctx);            /* (I SEND recv_cnt[q] ids to q and RECEIVE send_cnt[q] from it) */
+	free(gsend);
+	for (i = 0; i < ns; ++i) {
+		if ((long)want[i] < part[rank] || (long)want[i] >= part[rank + 1]) { free(want); return -5; }   /* a peer asked for a row I do not own */
+		want[i] -= (int)part[rank];
+	}
+	*send_rows_out = want; *nsend_out = (int)ns;
+	return 0;
+}
+
 /* ---------------------------------------------------------------- ingestion */
 #include <stdio.h>
 

@@ -164,23 +164,58 @@ class Comm:
 
     # ---- halo planning ------------------------------------------------------------------------
     def plan_halo(self, ghosts, part):
-        """ghosts: ascending global row ids this rank needs.  Returns (send_rows, send_cnt, recv_cnt):
-        local rows to ship grouped by destination rank, and per-peer counts."""
-        mine = (part[self.rank], part[self.rank + 1])
-        all_ghosts = [None] * self.world
-        self.dist.all_gather_object(all_ghosts, np.asarray(ghosts, dtype=np.int64))
-        send_rows, send_cnt = [], [0] * self.world
-        for q in range(self.world):
-            if q == self.rank:
-                continue
-            g = all_ghosts[q]
-            sel = g[(g >= mine[0]) & (g < mine[1])] - mine[0]
-            send_cnt[q] = int(sel.size)
-            send_rows.append(sel.astype(np.int32))
-        gh = np.asarray(ghosts, dtype=np.int64)
-        recv_cnt = [int(((gh >= part[q]) & (gh < part[q + 1])).sum()) if q != self.rank else 0 for q in range(self.world)]
-        send_rows = np.concatenate(send_rows) if send_rows else np.zeros(0, dtype=np.int32)
-        return np.ascontiguousarray(send_rows, dtype=np.int32), send_cnt, recv_cnt
+        """ghosts: ascending global row ids this rank needs.  Returns (send_rows, send_cnt, recv_cnt): local rows to ship grouped by
+        destination rank, and per-peer counts — from gcge_dist_plan_halo (csrc/host/problems.c), the planner
+        gcge_hip_mat_create_slab runs over RCCL; here its two int transports are torch.distributed collectives."""
+        h = host_lib()
+        world, rank, dist = self.world, self.rank, self.dist
+
+        def allgather_int(send, n, recv_all, ctx):
+            mine = np.ctypeslib.as_array(send, shape=(max(1, n),))[:n].copy()
+            got = [None] * world
+            dist.all_gather_object(got, mine)
+            out = np.ctypeslib.as_array(recv_all, shape=(max(1, n * world),))
+            for r in range(world):
+                out[r * n:(r + 1) * n] = got[r]
+
+        def exchange_int(sendbuf, send_cnt, recvbuf, recv_cnt, ctx):
+            sc = np.ctypeslib.as_array(send_cnt, shape=(world,)).copy()
+            rc = np.ctypeslib.as_array(recv_cnt, shape=(world,)).copy()
+            ns, nr = int(sc.sum()), int(rc.sum())
+            sb = np.ctypeslib.as_array(sendbuf, shape=(max(1, ns),))[:ns].copy()
+            off = np.concatenate([[0], np.cumsum(sc)])
+            groups = [sb[off[q]:off[q + 1]] for q in range(world)]
+            got = [None] * world
+            dist.all_gather_object(got, groups)             # (set-up only: every rank sees every list and keeps its own)
+            out = np.ctypeslib.as_array(recvbuf, shape=(max(1, nr),))
+            o = 0
+            for q in range(world):
+                seg = got[q][rank]
+                assert len(seg) == rc[q], ("halo plan: rank %d sends %d ints, %d expected" % (q, len(seg), rc[q]))
+                out[o:o + rc[q]] = seg
+                o += rc[q]
+
+        AG = C.CFUNCTYPE(None, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_void_p)
+        EX = C.CFUNCTYPE(None, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p)
+
+        class Transport(C.Structure):
+            _fields_ = [("rank", C.c_int), ("size", C.c_int), ("allgather_int", AG), ("exchange_int", EX), ("ctx", C.c_void_p)]
+        tr = Transport(rank, world, AG(_loud(allgather_int)), EX(_loud(exchange_int)), None)
+        gh = np.ascontiguousarray(ghosts, dtype=np.int32)
+        parr = (C.c_long * (world + 1))(*[int(v) for v in part])
+        recv_cnt = (C.c_int * world)()
+        send_cnt = (C.c_int * world)()
+        rows = C.POINTER(C.c_int)()
+        ns = C.c_int()
+        h.gcge_dist_plan_halo.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_int), C.c_int, C.POINTER(Transport), C.POINTER(C.c_int),
+                                          C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.c_int)]
+        rc = h.gcge_dist_plan_halo(parr, gh.ctypes.data_as(C.POINTER(C.c_int)), int(gh.size), C.byref(tr), recv_cnt, send_cnt,
+                                   C.byref(rows), C.byref(ns))
+        if rc != 0:
+            raise RuntimeError("gcge_dist_plan_halo failed: %d" % rc)
+        send_rows = np.ctypeslib.as_array(rows, shape=(max(1, ns.value),))[:ns.value].astype(np.int32).copy()
+        h.gcge_free_ints(rows)
+        return np.ascontiguousarray(send_rows, dtype=np.int32), [int(v) for v in send_cnt], [int(v) for v in recv_cnt]
 
     def make_exchange(self, send_cnt, recv_cnt, cap_cols):
         """Allocates the exchange buffers and returns (callback, send_ptr, recv_ptr, keepalive)."""

@@ -91,6 +91,22 @@ int gcge_csr_from_ccs(int nrows, int ncols, const int *j_col, const int *i_row, 
 int gcge_dist_ghosts (const GCGE_CSR *A, int **ghosts_out, int *nghost_out);
 int gcge_dist_localize (GCGE_CSR *A, const int *ghosts, int nghost);
 void gcge_free_ints (int *p);
+/* gcge_dist_plan_halo: the halo plan of this rank's slab — collective over `t`.  part: size + 1 row offsets; ghosts: my halo rows
+ * (ascending global ids, gcge_dist_ghosts).  Out: recv_cnt[q] rows I receive from rank q (in ghost order), send_cnt[q] rows I ship
+ * to rank q, send_rows = MY local rows to ship, grouped by destination rank, ascending inside a group (free with gcge_free_ints).
+ * The transport moves ints once, at set-up: allgather_int(send, n, recv_all): every rank contributes n ints, recv_all[r * n + i] =
+ * rank r's i-th; exchange_int(sendbuf, send_cnt, recvbuf, recv_cnt): the ints for rank q are the q-th group of sendbuf (send_cnt[q]
+ * of them), those from rank q land in the q-th group of recvbuf (recv_cnt[q]).  Returns 0; < 0: inconsistent inputs / a peer
+ * asked for a row this rank does not own.  ONE planner for every transport: RCCL inside the HIP back-end
+ * (gcge_hip_mat_create_slab, csrc/hip/rccl_comm.hip) and torch.distributed in the tests (gcge_amd/dist.py) run this function. */
+typedef struct GCGE_PLAN_TRANSPORT_ {
+	int rank, size;
+	void (*allgather_int) (const int *send, int n, int *recv_all, void *ctx);
+	void (*exchange_int) (const int *sendbuf, const int *send_cnt, int *recvbuf, const int *recv_cnt, void *ctx);
+	void *ctx;
+} GCGE_PLAN_TRANSPORT;
+int gcge_dist_plan_halo (const long *part, const int *ghosts, int nghost, const GCGE_PLAN_TRANSPORT *t,
+		int *recv_cnt, int *send_cnt, int **send_rows_out, int *nsend_out);
 
 /* Reproducible U[0,1) stream shared by C and the python tests:
  * splitmix64(seed + index) >> 11 scaled by 2^-53.                           */

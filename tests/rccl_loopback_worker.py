@@ -95,6 +95,25 @@ def star_loopback(G):
         assert p1.value - p0.value >= 15
         nsplit.append(s1.value - s0.value)
     assert nsplit[0] == 0 and nsplit[1] >= 12, nsplit
+    # the fused CG with MORE right-hand sides than the halo buffers hold on a star matrix (stored-product form): 8-column
+    # buffers, 16 columns — the device-scalar loop must decline (gcge_hip_spmm_dot2_dev_ok) and the host-scalar loop chunk the
+    # columns; it used to abort.  The loop-back operator is not symmetric, so this is no solve: five iterations of the same
+    # recurrences against the same loop with 64-column buffers (one chunk), column for column.
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    g.gcge_hip_bpcg_release.argtypes = [C.c_void_p]
+    nr = 16
+    Bm = uniform(41, (n_loc, nr)) - 0.5
+    sols = []
+    for cap in (64, 8):
+        assert g.gcge_hip_mat_set_halo_rccl(mat, n_global, 2, peer, scnt, rcnt, send_rows.ctypes.data_as(ip_), cap) == 0
+        g.gcge_hip_bpcg_setup(be.ops_handle, 5, 1e-30, 1e-30, b"abs")
+        vb = be.mv_from_numpy(mat, Bm)
+        vx = be.mv_from_numpy(mat, np.zeros_like(Bm))
+        be.ops.multi_linear_solver(mat, vb, vx, (0, 0), (nr, nr))
+        sols.append(be.mv_to_numpy(vx, n_loc, 0, nr))
+        be.ops.mv_destroy(vb, nr); be.ops.mv_destroy(vx, nr)
+        g.gcge_hip_bpcg_release(be.ops_handle)
+    assert np.all(np.isfinite(sols[1])) and np.max(np.abs(sols[0] - sols[1])) <= 1e-9 * np.max(np.abs(sols[0])), np.max(np.abs(sols[0] - sols[1]))
     be.free_matrix(mat)
     comm.finalize()
     print("rccl loop-back ok: star sweep on a slab of %d planes of %d^2, %d halo rows, %d products with the interior swept while the halo travelled" % (G // 2, G, ng, nsplit[1]))
@@ -246,6 +265,36 @@ def main():
     rel = np.max(np.abs(ev[:res.nevConv] - exact) / exact)
     assert res.nevConv >= 8 and rel < 1e-10, (res.nevConv, res.numIter, rel, list(ev[:10]))
     note = ""
+    if native:
+        # 3b. ADVICE r4: a block WIDER than the halo buffers through the fused CG.  The plan is re-installed with 8-column buffers;
+        # 16 right-hand sides then cannot take the one-call product with sums (gcge_hip_spmm_dot2_dev refuses m > buf_cols) nor the
+        # recompute passes (gcge_hip_cg_fusable declines): the solver must fall back to the loop that chunks the columns — it used
+        # to abort ("refused operands the one-pass scheme had accepted").  Against a direct solve of the loop-back operator.
+        import scipy.sparse.linalg as sla
+        rc = be.g.gcge_hip_mat_set_halo_rccl(mat, n_global, 2, peer, scnt, rcnt, send_rows.ctypes.data_as(ip_), 8)
+        assert rc == 0, rc
+        nr = 16
+        Bm = uniform(31, (n_loc, nr)) - 0.5
+        Xs = sla.spsolve(S.tocsc(), Bm)
+        for env in ({}, {"GCGE_CG_NO_RECOMPUTE": "1"}):
+            os.environ.update(env)
+            try:
+                be.g.gcge_hip_bpcg_setup(be.ops_handle, 400, 1e-12, 1e-14, b"abs")
+                vb = be.mv_from_numpy(mat, Bm)
+                vx = be.mv_from_numpy(mat, np.zeros_like(Bm))
+                be.ops.multi_linear_solver(mat, vb, vx, (0, 0), (nr, nr))
+                got = be.mv_to_numpy(vx, n_loc, 0, nr)
+                errw = np.max(np.abs(got - Xs)) / np.max(np.abs(Xs))
+                assert errw < 1e-8, ("fused CG, 16 right-hand sides over 8-column halo buffers", env, errw)
+                be.ops.mv_destroy(vb, nr); be.ops.mv_destroy(vx, nr)
+            finally:
+                for k_ in env:
+                    os.environ.pop(k_, None)
+        be.g.gcge_hip_bpcg_release.argtypes = [C.c_void_p]
+        be.g.gcge_hip_bpcg_release(be.ops_handle)
+        rc = be.g.gcge_hip_mat_set_halo_rccl(mat, n_global, 2, peer, scnt, rcnt, send_rows.ctypes.data_as(ip_), 64)
+        assert rc == 0, rc
+        note += " wide-block CG over 8-column halo buffers ok"
     # 4. the REFERENCE's compiled stack (oracle/_ref: its GCG, its OPS_Setup, flag 1) over a table only OPS_HIP_Set has
     # touched, on the same loop-back matrix and communicator: the back-end's own MultiVecInnerProd / MultiVecQtAP reduce,
     # nothing of the reference's src/ is edited
