@@ -261,8 +261,8 @@ def test_star_split_on_a_masked_grid():
 def test_pmc_traffic_file_matches_the_kernel_sources():
     """profiles/pmc_traffic.json is keyed to a hash of the kernel sources it was measured on; bench.py quotes `roofline.traffic`
     only while the hash matches (a stale file yields null).  This guard fails when a kernel source was edited after the last
-    measurement: re-run tools/pmc_traffic.py (CG passes) / tools/prof_tile.sh with PROBE=tools/star_ab_probe.py (the sweep) on the
-    GPU box and refresh the file."""
+    measurement: re-run tools/pmc_traffic.py (CG passes) / tools/pmc_traffic_c5.py (the config-5 product) on the GPU box and
+    refresh the file."""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -272,4 +272,5 @@ def test_pmc_traffic_file_matches_the_kernel_sources():
     t, note = b.pmc_traffic("spmm_pattern_chain2<7,7,16,false>", 256, 64)
     assert t is not None and 0.9 * 25.9e9 < t < 1.3 * 25.9e9, (t, note)
     t5, note5 = b.pmc_traffic_c5(171, "2000,2.0,5.0", 64)
-    assert t5 is not None and 8e9 < t5 < 14e9, (t5, note5)
+    # round 5: every kernel of the product (sweep 10.2 GB + dense blocks 3.0 GB + listed rows 1.3 GB = 14.5 GB per 64 columns)
+    assert t5 is not None and 10e9 < t5 < 18e9, (t5, note5)

@@ -565,7 +565,10 @@ def test_residual_hook_matches_numpy(hip, kind, size, start, end, kw):
         R = S @ X[:, start:end] - X[:, start:end] * lam
         np.testing.assert_allclose(out, np.sum(R * R, axis=0), rtol=1e-12)
         assert np.array_equal(hip.mv_to_numpy(x, n, 0, ncol), X)                       # x untouched
-        assert fn(mat, mat, x, start, end, lam.ctypes.data, out.ctypes.data) == 0      # generalised problem: declined
+        # generalised problem (round 5: two products + one sweep): B := A here, so the residual is (1 - lambda) A x
+        assert fn(mat, mat, x, start, end, lam.ctypes.data, out.ctypes.data) == 1
+        Rg = (S @ X[:, start:end]) * (1.0 - lam)
+        np.testing.assert_allclose(out, np.sum(Rg * Rg, axis=0), rtol=1e-11)
         hip.ops.mv_destroy(x, ncol)
         hip.free_matrix(mat)
     finally:
