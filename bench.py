@@ -92,7 +92,7 @@ def parse():
     if a.size <= 0:
         a.size = 171 if a.config == "c5" else 100 if a.config == "c3" else 256
     if a.amg < 0:
-        a.amg = 6 if (a.config in ("c2", "c3") and a.gpus == 1) else 0
+        a.amg = 6 if (a.config in ("c2", "c3", "c4")) else 0      # (row slabs coarsen by themselves: csrc/hip/multigrid.hip)
     if a.rehearse:
         os.environ["GCGE_BENCH_REHEARSE"] = "1"
     return a
@@ -547,8 +547,8 @@ def main():
     # direction rings from what is left
     amg, amg_setup_seconds, amg_levels = None, None, None
     if args.amg >= 2:
-        if world > 1:
-            raise SystemExit("bench.py: --amg is one-rank only (the hierarchy of a row slab is not built yet)")
+        if world > 1 and rehearse:
+            gdist.install_slab_factory(hip, comm)         # coarse slabs through the rehearsal's transport (default: RCCL from C)
         s0, s1 = (int(v) for v in args.amg_smooth.split(","))
         hip.h.GCGE_AMGCreate.restype = C.c_void_p
         hip.h.GCGE_AMGCreate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]

@@ -232,6 +232,10 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local_ghosts(int nrows, int ncols_l
   A->nrows = nrows; A->nglobal = nglobal; A->row_begin = row_begin; A->nnz = rowptr[nrows];
   A->nghost = ncols_local - nrows;
   GCGE_REQUIRE(A->nghost >= 0, "gcge_hip_mat_create_local: ncols_local >= nrows");
+  if (ghost_global != nullptr && A->nghost > 0) {
+    A->h_ghost_global = (int*)malloc((size_t)A->nghost * sizeof(int));
+    memcpy(A->h_ghost_global, ghost_global, (size_t)A->nghost * sizeof(int));
+  }
   {
     const int nt = gcge_upload_threads();
     std::vector<int> bad((size_t)nt, 0);
@@ -362,7 +366,17 @@ extern "C" void gcge_hip_mat_destroy(GCGE_HIP_MAT* A) {
   if (A->star_rem != nullptr) gcge_hip_dense_free(A->star_rem);
   if (A->star != nullptr) gcge_hip_star_free(A->star);
   if (A->native_halo != nullptr) gcge_hip_halo_native_free(A);   // RCCL plan + the exchange buffers it owns (rccl_comm.hip)
+  free(A->h_ghost_global); free(A->h_part);
   free(A);
+}
+// the row partition of all ranks a slab belongs to (world + 1 offsets): recorded by gcge_hip_mat_create_slab, or by whoever built
+// the slab through gcge_hip_mat_create_local_ghosts + its own halo plan — MultiGridCreate coarsens a slab only when it knows it
+extern "C" void gcge_hip_mat_set_partition(GCGE_HIP_MAT* A, const long* part, int world) {
+  free(A->h_part); A->h_part = nullptr; A->part_world = 0;
+  if (part == nullptr || world < 1) return;
+  A->h_part = (long*)malloc((size_t)(world + 1) * sizeof(long));
+  memcpy(A->h_part, part, (size_t)(world + 1) * sizeof(long));
+  A->part_world = world;
 }
 extern "C" int gcge_hip_mat_nrows(const GCGE_HIP_MAT* A) { return A->nrows; }
 extern "C" long gcge_hip_mat_nnz(const GCGE_HIP_MAT* A) { return A->nnz; }

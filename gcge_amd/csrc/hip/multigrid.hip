@@ -8,7 +8,8 @@
 // real-space Hamiltonian its blocks, exactly like a matrix the caller uploads.  The prolongations are rectangular matrices
 // (GCGE_HIP_MAT_::rect_ncols): CSR of P for MatDotMultiVec, CSR of P^T for MatTransDotMultiVec, both through the generic CSR
 // kernel (spmm.hip) — one non-zero per fine row, every fine row of the block read or written exactly once.
-// One rank only: a row slab (halo columns) is refused.
+// Row slabs (one rank per GPU): a slab of whole planes cut on even plane numbers coarsens by itself — local prolongations, coarse slabs
+// through the slab constructor (gcge_hip_mat_create_slab over RCCL, or a registered factory: the tests' torch.distributed transport).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -70,13 +71,72 @@ static void download_csr(const GCGE_HIP_MAT_* A, GCGE_CSR* out, std::vector<int>
   out->rowptr = rp.data(); out->colidx = ci.data(); out->val = va.data();
 }
 
+static gcge_hip_slab_factory_fn g_slab_factory = nullptr; static void* g_slab_factory_ctx = nullptr;
+extern "C" void gcge_hip_set_slab_factory(gcge_hip_slab_factory_fn fn, void* ctx) { g_slab_factory = fn; g_slab_factory_ctx = ctx; }
+
+// a row slab (one rank per GPU): whole planes of a detected grid, cut on even plane numbers — every rank coarsens its own slab
+// (gcge_mg_build_slab), the coarse slabs go through the slab constructor (ghost list, halo plan: collective)
+static void multigrid_create_slab(void*** A_array, void*** B_array, void*** P_array, int* num_levels, const GCGE_HIP_MAT_* mA, void* A, void* B) {
+  GCGE_REQUIRE(mA->h_part != nullptr && mA->part_world >= 1, "MultiGridCreate on a row slab: the partition of all ranks (gcge_hip_mat_create_slab / gcge_hip_mat_set_partition)");
+  GCGE_REQUIRE(mA->nghost == 0 || mA->h_ghost_global != nullptr, "MultiGridCreate on a row slab: the global rows behind the halo columns (gcge_hip_mat_create_local_ghosts)");
+  const int world = mA->part_world;
+  int rank = -1;
+  for (int r = 0; r < world; ++r) if (mA->h_part[r] == mA->row_begin && mA->h_part[r + 1] == (long)mA->row_begin + mA->nrows) rank = r;
+  GCGE_REQUIRE(rank >= 0, "MultiGridCreate on a row slab: the slab is one of the partition's");
+  GCGE_CSR cA; std::vector<int> rp, ci; std::vector<double> va;
+  download_csr(mA, &cA, rp, ci, va);
+  for (size_t k = 0; k < (size_t)mA->nnz; ++k) ci[k] = ci[k] < mA->nrows ? mA->row_begin + ci[k] : mA->h_ghost_global[ci[k] - mA->nrows];   // local -> GLOBAL columns
+  cA.row_begin = mA->row_begin; cA.ncols = (int)mA->h_part[world];
+  int dims[3] = {0, 0, 0};
+  if (!gcge_mg_detect_grid(&cA, dims, nullptr) || (long)dims[0] * dims[1] * dims[2] != mA->h_part[world]) {
+    fprintf(stderr, "MultiGridCreate (HIP back-end): a row slab is coarsened along a detected grid only; this matrix shows none\n");
+    abort();
+  }
+  GCGE_MG mg; long* parts = nullptr;
+  const int rc = gcge_mg_build_slab(&cA, dims, mA->h_part, rank, world, *num_levels, 0.0, &mg, &parts);
+  if (rc != 0) { fprintf(stderr, "MultiGridCreate (HIP back-end): gcge_mg_build_slab failed (%d) — slabs must be whole planes of the %d x %d x %d grid\n", rc, dims[0], dims[1], dims[2]); abort(); }
+  const int L = mg.num_levels;
+  MgHold h;
+  *A_array = (void**)calloc(L, sizeof(void*));
+  *P_array = (void**)calloc(L > 1 ? L - 1 : 1, sizeof(void*));
+  if (B_array != nullptr) *B_array = (void**)calloc(L, sizeof(void*));
+  (*A_array)[0] = A;
+  if (B_array != nullptr) (*B_array)[0] = B;
+  const int buf_cols = mA->buf_cols > 0 ? mA->buf_cols : 128;
+  for (int l = 1; l < L; ++l) {
+    const long* pl = parts + (size_t)l * (world + 1);
+    GCGE_HIP_MAT* a = g_slab_factory != nullptr
+        ? g_slab_factory(pl, world, rank, mg.A[l].rowptr, mg.A[l].colidx, mg.A[l].val, buf_cols, g_slab_factory_ctx)
+        : gcge_hip_mat_create_slab(pl, mg.A[l].rowptr, mg.A[l].colidx, mg.A[l].val, buf_cols);
+    GCGE_REQUIRE(a != nullptr, "MultiGridCreate: construction of a coarse slab");
+    if (a->h_part == nullptr) gcge_hip_mat_set_partition(a, pl, world);
+    (*A_array)[l] = a; h.owned.push_back(a);
+  }
+  for (int l = 0; l + 1 < L; ++l) {
+    GCGE_HIP_MAT* p = gcge_hip_mat_create_rect(mg.P[l].nrows, mg.P[l].ncols, mg.P[l].rowptr, mg.P[l].colidx, mg.P[l].val,
+                                               mg.PT[l].rowptr, mg.PT[l].colidx, mg.PT[l].val);
+    GCGE_REQUIRE(p != nullptr, "MultiGridCreate: upload of a prolongation");
+    (*P_array)[l] = p; h.owned.push_back(p);
+  }
+  if (getenv("GCGE_MG_TRACE") != nullptr)
+    for (int l = 0; l < L; ++l)
+      fprintf(stderr, "MultiGridCreate: rank %d of %d, level %d: %d of %ld rows, %ld non-zeros, grid %d x %d x %d, K1 form %s\n", rank, world, l, mg.A[l].nrows,
+              parts[(size_t)l * (world + 1) + world], (long)mg.A[l].nnz, mg.dims[l][0], mg.dims[l][1], mg.dims[l][2], gcge_hip_mat_spmm_form((const GCGE_HIP_MAT*)(*A_array)[l]));
+  gcge_mg_free(&mg);
+  free(parts);
+  h.A_array = *A_array;
+  g_mg.push_back(h);
+  *num_levels = L;
+}
+
 extern "C" void gcge_hip_multigrid_create(void*** A_array, void*** B_array, void*** P_array, int* num_levels, void* A, void* B, struct OPS_* ops) {
   const GCGE_HIP_MAT_* mA = (const GCGE_HIP_MAT_*)A; const GCGE_HIP_MAT_* mB = (const GCGE_HIP_MAT_*)B;
   const double t0 = mg_now();
   GCGE_REQUIRE(mA != nullptr && mA->rect_ncols == 0 && num_levels != nullptr && *num_levels >= 1, "MultiGridCreate: a square matrix and a level count");
-  if (mA->nghost > 0 || GCGE_GetComm() != nullptr) {
-    fprintf(stderr, "MultiGridCreate (HIP back-end): row-partitioned matrices are not coarsened yet — one rank only\n");
-    abort();
+  if (mA->nghost > 0 || mA->part_world > 1) {
+    multigrid_create_slab(A_array, B_array, P_array, num_levels, mA, A, B);
+    g_mg_seconds = mg_now() - t0;
+    return;
   }
   GCGE_CSR cA, cB; std::vector<int> rpA, ciA, rpB, ciB; std::vector<double> vaA, vaB;
   download_csr(mA, &cA, rpA, ciA, vaA);

@@ -273,5 +273,6 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_slab(const long* part, const int* r
                                               send_rows.data(), buf_cols);
     if (rc != 0) { gcge_hip_mat_destroy(A); return nullptr; }
   }
+  gcge_hip_mat_set_partition(A, part, world);      // (MultiGridCreate coarsens a slab from it: multigrid.hip)
   return A;
 }

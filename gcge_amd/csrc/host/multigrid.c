@@ -33,22 +33,23 @@ static int cmp_int(const void *a, const void *b) { int x = *(const int*)a, y = *
 
 int gcge_mg_detect_grid(const GCGE_CSR *A, int dims[3], int *arm_out)
 {
-	const int n = A->nrows;
+	/* a whole matrix, or a slab of its rows [row_begin, row_begin + nrows) with GLOBAL columns (ncols = the global size) */
+	const int nloc = A->nrows, n = A->ncols > A->nrows ? A->ncols : A->nrows; const long rb = A->row_begin;
 	int *off = NULL, noff = 0, cap = 0, *freq = NULL, nfreq = 0, i, arm, nx, nxy = 0;
 	long sampled = 0, step;
-	if (n < 8 || A->ncols != n || A->row_begin != 0) return 0;
+	if (nloc < 8 || (A->ncols != nloc && A->ncols < rb + nloc)) return 0;
 	/* positive column offsets of a sample of rows (all of them up to 2^20 rows), with their counts */
-	step = n > (1 << 20) ? n / (1 << 20) : 1;
+	step = nloc > (1 << 20) ? nloc / (1 << 20) : 1;
 	{
 		/* offsets are collected row by row into a list, sorted, run-length counted */
 		long r; size_t tot = 0;
-		for (r = 0; r < n; r += step) tot += (size_t)(A->rowptr[r + 1] - A->rowptr[r]);
+		for (r = 0; r < nloc; r += step) tot += (size_t)(A->rowptr[r + 1] - A->rowptr[r]);
 		off = (int*)malloc((tot ? tot : 1) * sizeof(int));
 		if (off == NULL) return 0;
-		for (r = 0; r < n; r += step, ++sampled) {
+		for (r = 0; r < nloc; r += step, ++sampled) {
 			int k;
 			for (k = A->rowptr[r]; k < A->rowptr[r + 1]; ++k)
-				if (A->colidx[k] > r) off[noff++] = A->colidx[k] - (int)r;
+				if (A->colidx[k] > rb + r) off[noff++] = (int)(A->colidx[k] - (rb + r));
 		}
 		qsort(off, noff, sizeof(int), cmp_int);
 		cap = 64; freq = (int*)malloc(cap * sizeof(int));
@@ -81,10 +82,10 @@ int gcge_mg_detect_grid(const GCGE_CSR *A, int dims[3], int *arm_out)
 	 * next line starts there), every other sampled point has one */
 	{
 		long r, bad = 0, seen = 0;
-		for (r = 0; r < n; r += step) {
+		for (r = 0; r < nloc; r += step) {
 			int k, has = 0;
-			for (k = A->rowptr[r]; k < A->rowptr[r + 1]; ++k) has |= A->colidx[k] == r + 1;
-			if ((r + 1) % nx == 0) { ++seen; bad += has; }
+			for (k = A->rowptr[r]; k < A->rowptr[r + 1]; ++k) has |= A->colidx[k] == rb + r + 1;
+			if ((rb + r + 1) % nx == 0) { ++seen; bad += has; }
 		}
 		if (seen > 0 && bad * 10 > seen) return 0;
 	}
@@ -347,5 +348,113 @@ int gcge_mg_build(const GCGE_CSR *A, const GCGE_CSR *B, int max_levels, int min_
 		if (have_grid) { dims[0] = cdims[0]; dims[1] = cdims[1]; dims[2] = cdims[2]; }
 	}
 	if (have_grid) { l = mg->num_levels - 1; mg->dims[l][0] = dims[0]; mg->dims[l][1] = dims[1]; mg->dims[l][2] = dims[2]; }
+	return 0;
+}
+
+/* ---------------------------------------------------------------- row slabs (one rank per GPU)
+ * A slab that is whole grid planes, cut on EVEN plane numbers, coarsens by itself: the 2 x 2 x 2 cells of its rows lie inside it, so
+ * P is local (owned fine rows x owned coarse rows, no halo) and the coarse slab = scale * sum over the cells' rows, columns mapped
+ * to GLOBAL coarse indices through the grid (halo columns included).  The coarse slab goes through the back-end's slab constructor
+ * like any row-partitioned matrix (ghost list, halo plan).  Every rank evaluates the SAME stopping rule from the shared partition:
+ * a level is coarsened while every slab starts on an even plane and holds an even number of planes (the last one may end on the
+ * grid's last, odd plane).  Reference: the MPI back-ends get this from PETSc GAMG / BoomerAMG (app/app_slepc.c:648-728). */
+typedef struct { int col; int idx; double val; } SlabEnt;
+static int cmp_ent(const void *a, const void *b)
+{
+	const SlabEnt *x = (const SlabEnt*)a, *y = (const SlabEnt*)b;
+	if (x->col != y->col) return (x->col > y->col) - (x->col < y->col);
+	return (x->idx > y->idx) - (x->idx < y->idx);
+}
+static inline long grid_agg(long g, const int d[3], int cx, int cy)
+{
+	const long x = g % d[0], y = (g / d[0]) % d[1], z = g / ((long)d[0] * d[1]);
+	return (x / 2) + (long)cx * ((y / 2) + (long)cy * (z / 2));
+}
+static int slab_coarsenable(const int d[3], const long *part, int world)
+{
+	const long plane = (long)d[0] * d[1]; int r;
+	if (d[2] < 2) return 0;
+	for (r = 0; r < world; ++r) {
+		long z0, z1;
+		if (part[r] % plane != 0 || part[r + 1] % plane != 0) return 0;
+		z0 = part[r] / plane; z1 = part[r + 1] / plane;
+		if (z1 <= z0 || (z0 & 1)) return 0;
+		if ((z1 & 1) && z1 != d[2]) return 0;
+	}
+	return 1;
+}
+int gcge_mg_build_slab(const GCGE_CSR *A, const int dims[3], const long *part, int rank, int world, int max_levels, double scale,
+		GCGE_MG *mg, long **part_levels_out)
+{
+	int l, d[3] = {dims[0], dims[1], dims[2]};
+	long *parts;
+	memset(mg, 0, sizeof *mg);
+	if (max_levels < 1) max_levels = 1;
+	if (scale <= 0.0) scale = g_scale;
+	if (A->row_begin != part[rank] || A->nrows != (int)(part[rank + 1] - part[rank]) || (long)d[0] * d[1] * d[2] != part[world]) return -2;
+	mg->A = (GCGE_CSR*)calloc(max_levels, sizeof(GCGE_CSR));
+	mg->P = (GCGE_CSR*)calloc(max_levels, sizeof(GCGE_CSR));
+	mg->PT = (GCGE_CSR*)calloc(max_levels, sizeof(GCGE_CSR));
+	mg->dims = (int (*)[3])calloc(max_levels, sizeof(int[3]));
+	parts = (long*)calloc((size_t)max_levels * (world + 1), sizeof(long));
+	if (!mg->A || !mg->P || !mg->PT || !mg->dims || !parts) { gcge_mg_free(mg); free(parts); return -3; }
+	mg->A[0] = *A; mg->num_levels = 1;
+	memcpy(parts, part, (size_t)(world + 1) * sizeof(long));
+	mg->dims[0][0] = d[0]; mg->dims[0][1] = d[1]; mg->dims[0][2] = d[2];
+	for (l = 0; l + 1 < max_levels; ++l) {
+		const GCGE_CSR *Af = &mg->A[l];
+		const long *pf = parts + (size_t)l * (world + 1); long *pc = parts + (size_t)(l + 1) * (world + 1);
+		const int cx = (d[0] + 1) / 2, cy = (d[1] + 1) / 2, cz = (d[2] + 1) / 2, nf = Af->nrows;
+		const long plane = (long)d[0] * d[1], cplane = (long)cx * cy, rb = pf[rank];
+		GCGE_CSR *Ac = &mg->A[l + 1];
+		int r, nc, *agg, *ptr = NULL, *mem = NULL, I, rc = 0; int64_t tot = 0;
+		if (!slab_coarsenable(d, pf, world)) break;
+		for (r = 0; r <= world; ++r) pc[r] = ((pf[r] / plane + 1) / 2) * cplane;
+		if (pc[world] != cplane * cz) { rc = -2; goto fail; }
+		nc = (int)(pc[rank + 1] - pc[rank]);
+		agg = (int*)malloc((size_t)(nf > 0 ? nf : 1) * sizeof(int));       /* LOCAL coarse row of every owned fine row */
+		if (agg == NULL) { rc = -3; goto fail; }
+		for (r = 0; r < nf; ++r) agg[r] = (int)(grid_agg(rb + r, d, cx, cy) - pc[rank]);
+		if ((rc = gcge_mg_prolongation(agg, nf, nc, &mg->P[l], &mg->PT[l])) != 0) { free(agg); goto fail; }
+		if (aggregate_members(agg, nf, nc, &ptr, &mem) != 0) { free(agg); rc = -3; goto fail; }
+		/* coarse slab: per coarse row the entries of its members, columns -> global coarse index, merged in arrival order */
+		Ac->nrows = nc; Ac->ncols = (int)pc[world]; Ac->row_begin = (int)pc[rank];
+		Ac->rowptr = (int*)calloc((size_t)nc + 1, sizeof(int));
+		{
+			int64_t cap = 0; SlabEnt *buf; int maxlen = 0;
+			for (I = 0; I < nc; ++I) { int q, len = 0; for (q = ptr[I]; q < ptr[I + 1]; ++q) len += Af->rowptr[mem[q] + 1] - Af->rowptr[mem[q]]; cap += len; if (len > maxlen) maxlen = len; }
+			Ac->colidx = (int*)malloc((size_t)(cap > 0 ? cap : 1) * sizeof(int));       /* upper bound: no merging */
+			Ac->val = (double*)malloc((size_t)(cap > 0 ? cap : 1) * sizeof(double));
+			buf = (SlabEnt*)malloc((size_t)(maxlen > 0 ? maxlen : 1) * sizeof(SlabEnt));
+			if (!Ac->rowptr || !Ac->colidx || !Ac->val || !buf) { free(buf); free(agg); free(ptr); free(mem); rc = -3; goto fail; }
+			for (I = 0; I < nc; ++I) {
+				int q, k, len = 0, a;
+				for (q = ptr[I]; q < ptr[I + 1]; ++q) {
+					const int fr = mem[q];
+					for (k = Af->rowptr[fr]; k < Af->rowptr[fr + 1]; ++k) {
+						buf[len].col = (int)grid_agg(Af->colidx[k], d, cx, cy); buf[len].idx = len; buf[len].val = Af->val[k]; ++len;
+					}
+				}
+				qsort(buf, len, sizeof(SlabEnt), cmp_ent);
+				for (a = 0; a < len; ) {
+					int b = a; double sum = 0.0;
+					while (b < len && buf[b].col == buf[a].col) { sum += buf[b].val; ++b; }
+					Ac->colidx[tot] = buf[a].col; Ac->val[tot] = sum * scale; ++tot;
+					a = b;
+				}
+				Ac->rowptr[I + 1] = (int)tot;
+			}
+			free(buf);
+		}
+		Ac->nnz = tot;
+		free(agg); free(ptr); free(mem);
+		mg->num_levels = l + 2;
+		d[0] = cx; d[1] = cy; d[2] = cz;
+		mg->dims[l + 1][0] = cx; mg->dims[l + 1][1] = cy; mg->dims[l + 1][2] = cz;
+		continue;
+fail:
+		mg->num_levels = l + 2; gcge_mg_free(mg); free(parts); return rc;
+	}
+	*part_levels_out = parts;
 	return 0;
 }

@@ -378,7 +378,30 @@ def hip_slab_matrix(hip, comm, A, n_global, part, cap_cols=128):
                             cap_cols, C.cast(cb, C.c_void_p), None)
     g.gcge_hip_mat_set_halo_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     g.gcge_hip_mat_set_halo_async(mat, C.cast(comm._begin_cb, C.c_void_p), C.cast(comm._end_cb, C.c_void_p))
+    # the partition of all ranks travels with the handle: ops->MultiGridCreate coarsens a slab from it (csrc/hip/multigrid.hip)
+    g.gcge_hip_mat_set_partition.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.c_int]
+    g.gcge_hip_mat_set_partition(mat, (C.c_long * len(part))(*[int(v) for v in part]), len(part) - 1)
     return mat
+
+
+def install_slab_factory(hip, comm):
+    """Coarse slabs of a multigrid hierarchy (ops->MultiGridCreate on a row slab) through THIS transport: registers hip_slab_matrix as
+    the back-end's slab constructor (gcge_hip_set_slab_factory; the default is gcge_hip_mat_create_slab over RCCL).  Returns the
+    callback object (keep it alive)."""
+    FACT = C.CFUNCTYPE(C.c_void_p, C.POINTER(C.c_long), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                       C.c_int, C.c_void_p)
+
+    def factory(part_p, world, rank, rowptr, colidx, val, buf_cols, ctx):
+        part = [int(part_p[i]) for i in range(world + 1)]
+        nrows = part[rank + 1] - part[rank]
+        A = CSR(nrows, part[world], part[rank], int(rowptr[nrows]), rowptr, colidx, val)
+        m = hip_slab_matrix(hip, comm, A, part[world], part, cap_cols=buf_cols)      # (rewrites colidx to local numbering in place)
+        return m.value
+    cb = FACT(_loud(factory))
+    hip.g.gcge_hip_set_slab_factory.argtypes = [C.c_void_p, C.c_void_p]
+    hip.g.gcge_hip_set_slab_factory(C.cast(cb, C.c_void_p), None)
+    comm._keep.append(cb)
+    return cb
 
 
 def weak_scaling_box(N, world):

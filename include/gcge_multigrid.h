@@ -27,7 +27,7 @@ extern "C" {
 /* nx, ny, nz of a lexicographic grid (index x + nx (y + ny z)) whose neighbour couplings the rows of A show: +-1 ... +-arm
  * along a line, multiples of nx between lines, of nx ny between planes (1-D and 2-D grids: ny and / or nz = 1).
  * Returns 1 and fills dims[3] (and *arm, may be NULL), 0 when the rows show no such grid.                          */
-int gcge_mg_detect_grid (const GCGE_CSR *A, int dims[3], int *arm);
+int gcge_mg_detect_grid (const GCGE_CSR *A, int dims[3], int *arm);     /* also: a slab of rows with GLOBAL columns (ncols = global size) */
 
 /* 2 x 2 x 2 aggregates of an nx x ny x nz grid (the last aggregate of an odd direction holds one layer):
  * agg[r] = coarse index of row r, cdims = coarse grid.  Returns the number of aggregates.                          */
@@ -59,6 +59,15 @@ typedef struct GCGE_MG_ {
  * (fewer than 1.5 x fewer rows).  Returns 0 and fills mg (mg->num_levels >= 1), -3 out of memory.                  */
 int  gcge_mg_build (const GCGE_CSR *A, const GCGE_CSR *B, int max_levels, int min_rows, double scale, GCGE_MG *mg);
 void gcge_mg_free (GCGE_MG *mg);
+
+/* The hierarchy of ONE row slab (one rank per GPU): A holds rows [part[rank], part[rank + 1]) with GLOBAL columns of a matrix on the
+ * lexicographic grid `dims`; every slab is whole planes.  A level is coarsened while every slab starts on an even plane and holds an
+ * even number of planes (the last may end on the grid's last, odd plane) — every rank evaluates that from the shared partition, so
+ * all ranks build the same number of levels.  mg->A[l] (l >= 1): the coarse slab with GLOBAL coarse columns, row_begin =
+ * part_levels[l * (world + 1) + rank]; mg->P[l] / PT[l]: local (owned fine rows x owned coarse rows: the cells of a slab lie inside
+ * it).  part_levels (free with free()): the row partition of every level.  Returns 0; -2: the slab is not whole planes of `dims`. */
+int gcge_mg_build_slab (const GCGE_CSR *A, const int dims[3], const long *part, int rank, int world, int max_levels, double scale,
+		GCGE_MG *mg, long **part_levels_out);
 
 /* process-wide defaults the back-ends' MultiGridCreate slots use (the slot's signature has no room for them,
  * src/ops.h:134): scale as above (default 0.5), min_rows (default 64), theta of the graph aggregation (default 0.25) */

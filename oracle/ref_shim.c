@@ -428,3 +428,31 @@ void ref_from_i_to_j_dense(int num_levels, int *n, double *P_flat, int level_i, 
 	free(blk); free(ws); free(P); free(P_array);
 	OPS_Destroy(&ops);
 }
+/* The literal drop-in of the multigrid leg: the REFERENCE's BlockAMG (src/ops_lin_sol.c:466-715), its BlockPCG as the smoother and
+ * its DefaultMultiVecFromItoJ, over a table another back-end filled (OPS_HIP_Set) — hierarchy from THAT back-end's
+ * ops->MultiGridCreate, work blocks from its MultiVecCreateByMat; b / x are its blocks of m columns.  The set-up of
+ * test/test_eig_sol_SiO2_MAT.c:96-128,160-170.  Returns the number of levels the back-end delivered. */
+int ref_block_amg_foreign(void *foreign_ops, void *matA, int num_levels, int *max_iter, double *rate, double *tol,
+		int m, void **b, void **x, double *residual_out)
+{
+	OPS *ops = (OPS*)foreign_ops;
+	void **A_array = NULL, **B_array = NULL, **P_array = NULL; void ***ws[5];
+	double *dbl = calloc(6 * m + 8, sizeof(double)); int *iw = calloc(2 * m + 8, sizeof(int));
+	int l, i, start[2] = {0, 0}, end[2] = {m, m};
+	OPS_Setup(ops);
+	if (!g_verbose) { ops->Printf = quiet_printf; ops->lapack_ops->Printf = quiet_printf; }
+	if (ops->MultiGridCreate == NULL) return -1;
+	ops->MultiGridCreate(&A_array, &B_array, &P_array, &num_levels, matA, NULL, ops);
+	for (i = 0; i < 5; ++i) {
+		ws[i] = calloc(num_levels, sizeof(void**));
+		for (l = 0; l < num_levels; ++l) ops->MultiVecCreateByMat(&ws[i][l], m, A_array[l], ops);
+	}
+	MultiLinearSolverSetup_BlockAMG(max_iter, rate, tol, "abs", A_array, P_array, num_levels, ws, dbl, iw, NULL, ops);
+	ops->MultiLinearSolver(A_array[0], b, x, start, end, ops);
+	if (residual_out) *residual_out = ((BlockAMGSolver*)ops->multi_linear_solver_workspace)->residual;
+	for (i = 0; i < 5; ++i) { for (l = 0; l < num_levels; ++l) ops->MultiVecDestroy(&ws[i][l], m, ops); free(ws[i]); }
+	l = num_levels;
+	ops->MultiGridDestroy(&A_array, &B_array, &P_array, &l, ops);
+	free(dbl); free(iw);
+	return num_levels;
+}

@@ -176,6 +176,20 @@ def main():
     rel = np.max(np.abs(ev[:res.nevConv] - exact) / exact)
     assert res.nevConv >= 8 and rel < 1e-10, (res.nevConv, res.numIter, rel, list(ev[:10]))
     note = ""
+    if mode in ("hip", "hip_native") and os.environ.get("GCGE_TEST_AMG"):
+        # 3b. BlockAMG across ranks (round 5): every rank coarsens its own slab (whole planes, even cuts), the coarse slabs get their
+        # own halo plans through the slab constructor of THIS transport, the fused CG smooths every level with its sums reduced over
+        # the ranks, transfers are local.  Same Ritz values, no more outer iterations than the plain solver.
+        if mode == "hip":
+            gdist.install_slab_factory(be, comm)
+        levels = int(os.environ["GCGE_TEST_AMG"])
+        ev_a, res_a = run_gcg(be.ops_handle, mat, None, ["-nevConv", 8, "-gcge_compW_orth_method", "chol", "-gcge_amg_levels", levels], flag=1)
+        ex_a = exact if res_a.nevConv <= res.nevConv else (box_exact(dims, res_a.nevConv) if not sio2 else None)
+        k_a = min(res_a.nevConv, len(ex_a))
+        rel_a = np.max(np.abs(ev_a[:k_a] - ex_a[:k_a]) / ex_a[:k_a])
+        assert res_a.nevConv >= 8 and rel_a < 1e-10, ("BlockAMG across ranks", res_a.nevConv, res_a.numIter, rel_a)
+        assert res_a.numIter <= res.numIter + 3, (res_a.numIter, res.numIter)
+        note += " amg(%d levels): nevConv=%d numIter=%d rel=%.2e" % (levels, res_a.nevConv, res_a.numIter, rel_a)
     if mode in ("hip", "hip_native") and not sio2:
         # 4. the REFERENCE's compiled GCG / orthonormalisation (oracle/_ref, its own OPS_Setup, flag 1 = the back-end's
         # solver) over a table only OPS_HIP_Set has touched, on the same slab matrices: OPS_HIP_Set installs

@@ -255,3 +255,38 @@ def mg_hierarchy(A, max_levels, scale=0.0, min_rows=0, B=None):
     h.gcge_mg_free.argtypes = [C.POINTER(MG)]
     h.gcge_mg_free(C.byref(mg))
     return out
+
+
+def mg_hierarchy_slab(A_slab, dims, part, rank, max_levels, scale=0.0):
+    """gcge_mg_build_slab (csrc/host/multigrid.c) of one row slab with GLOBAL columns: {"A": [scipy slabs with global columns],
+    "P": [...local...], "part": [[...] per level], "dims": [...]}."""
+    import scipy.sparse as sp
+    from gcge_amd.lib import CSR
+    h = host_lib()
+
+    class MG(C.Structure):
+        _fields_ = [("num_levels", C.c_int), ("A", C.POINTER(CSR)), ("B", C.POINTER(CSR)), ("P", C.POINTER(CSR)),
+                    ("PT", C.POINTER(CSR)), ("dims", C.POINTER(C.c_int * 3))]
+    mg = MG()
+    world = len(part) - 1
+    parr = (C.c_long * (world + 1))(*[int(v) for v in part])
+    d = (C.c_int * 3)(*dims)
+    pl = C.POINTER(C.c_long)()
+    h.gcge_mg_build_slab.argtypes = [C.POINTER(CSR), C.POINTER(C.c_int * 3), C.POINTER(C.c_long), C.c_int, C.c_int, C.c_int, C.c_double,
+                                     C.POINTER(MG), C.POINTER(C.POINTER(C.c_long))]
+    rc = h.gcge_mg_build_slab(C.byref(A_slab), C.byref(d), parr, rank, world, max_levels, scale, C.byref(mg), C.byref(pl))
+    assert rc == 0, rc
+
+    def to_sp(c):
+        rp = np.ctypeslib.as_array(c.rowptr, shape=(c.nrows + 1,)).copy()
+        ci = np.ctypeslib.as_array(c.colidx, shape=(max(1, int(c.nnz)),))[:int(c.nnz)].copy()
+        va = np.ctypeslib.as_array(c.val, shape=(max(1, int(c.nnz)),))[:int(c.nnz)].copy()
+        return sp.csr_matrix((va, ci, rp), shape=(c.nrows, c.ncols))
+    L = mg.num_levels
+    out = {"A": [to_sp(mg.A[lev]) for lev in range(L)], "P": [to_sp(mg.P[lev]) for lev in range(L - 1)],
+           "part": [[pl[lev * (world + 1) + r] for r in range(world + 1)] for lev in range(L)],
+           "dims": [tuple(mg.dims[lev]) for lev in range(L)]}
+    h.gcge_mg_free.argtypes = [C.POINTER(MG)]
+    h.gcge_mg_free(C.byref(mg))
+    C.CDLL(None).free(pl)
+    return out

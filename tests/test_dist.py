@@ -168,6 +168,22 @@ def test_ranks_on_one_gpu_hip_sio2_star_sweep_on_plane_aligned_slabs(world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,dims", [(2, (8, 8, 16)), (3, (8, 8, 24))])
+def test_ranks_on_one_gpu_block_amg_on_slabs(world, dims):
+    """BlockAMG with a row-partitioned hierarchy (round 5): ops->MultiGridCreate coarsens every rank's slab by itself
+    (gcge_mg_build_slab: whole planes, even cuts), coarse slabs through the transport's slab constructor, the fused CG as the
+    smoother of every level with its sums reduced over the ranks — GCG with -gcge_amg_levels against the closed form and the plain
+    solver, two and three ranks sharing the one GPU over gloo."""
+    _run("hip", world=world, dims=dims, rank_env={r: {"GCGE_TEST_AMG": "3"} for r in range(world)})
+
+
+@pytest.mark.gpu
+def test_native_worker_as_one_rank_block_amg():
+    """The same through the production constructor (gcge_hip_mat_create_slab, RCCL from C) as a world of one rank."""
+    _run("hip_native", world=1, dims=(8, 8, 16), rank_env={0: {"GCGE_TEST_AMG": "3"}})
+
+
+@pytest.mark.gpu
 def test_two_ranks_disagree_on_the_cg_ring_length():
     """The fused CG's direction ring is sized from each rank's own free memory (or GCGE_CG_RING); the length decides
     the column window and with it the length of the per-iteration all-reduces, so the ranks must settle on one

@@ -132,6 +132,42 @@ def test_aggregation_hierarchy_is_galerkin(kind, size):
         assert Ac[mid, mid] == 12.0 and Ac[mid, mid + 1] == -2.0 and Ac[mid, mid + c] == -2.0 and Ac[mid, mid + c * c] == -2.0
 
 
+@pytest.mark.parametrize("kind,dims,world", [("lap3d", (6, 6, 16), 2), ("lap3d", (5, 7, 24), 3), ("sio2", (12, 12, 12), 1), ("lap3d", (6, 6, 8), 4)])
+def test_slab_hierarchy_equals_the_rows_of_the_whole_hierarchy(kind, dims, world):
+    """gcge_mg_build_slab: every rank coarsens its own slab (whole planes, cut on even plane numbers) — stacked, the coarse slabs ARE
+    the coarse matrix of the whole-matrix hierarchy at every level, the local prolongations are the diagonal blocks of the global one,
+    and every rank stops at the same level (the shared stopping rule)."""
+    import ctypes
+    import scipy.sparse as sp
+    from helpers import mg_hierarchy_slab
+    from gcge_amd.lib import CSR
+    h = host_lib()
+    plane, nz = dims[0] * dims[1], dims[2]
+    n = plane * nz
+
+    def gen(rb, re_):
+        if kind == "sio2":
+            A, _ = make_problem("sio2", dims[0], row_begin=rb, row_end=re_, K=6, R0=1.5, R1=2.0, seed=12345)
+            return A
+        A = CSR()
+        h.gcge_problem_lap3d_box(dims[0], dims[1], dims[2], ctypes.c_int64(rb), ctypes.c_int64(re_), ctypes.byref(A))
+        return A
+    whole = mg_hierarchy(gen(0, -1 if kind == "sio2" else n), 6, scale=0.5, min_rows=1)
+    zcut = [2 * ((nz // 2) * r // world) for r in range(world)] + [nz]           # even plane numbers
+    part = [z * plane for z in zcut]
+    slabs = [mg_hierarchy_slab(gen(part[r], part[r + 1]), dims, part, r, 6, scale=0.5) for r in range(world)]
+    L = len(slabs[0]["A"])
+    assert all(len(sl["A"]) == L for sl in slabs) and L >= 2
+    for lev in range(1, L):
+        stacked = sp.vstack([sl["A"][lev] for sl in slabs]).tocsr()
+        want = whole["A"][lev]
+        assert stacked.shape == want.shape and abs(stacked - want).max() <= 1e-13 * abs(want).max(), lev
+        assert slabs[0]["dims"][lev] == whole["dims"][lev]
+        Pg = sp.block_diag([sl["P"][lev - 1] for sl in slabs]).tocsr()
+        assert abs(Pg - whole["P"][lev - 1]).max() == 0.0
+        assert all(sl["part"][lev] == slabs[0]["part"][lev] for sl in slabs)
+
+
 # ---------------------------------------------------------------------------------------------- host: BlockAMG vs the reference
 def _check_amg_case(backend, Ah, Ph, key, n0):
     g = G[key]
@@ -295,3 +331,50 @@ def test_gcg_with_block_amg_on_hip_matches_oracle(hip, oracle, kind, size, nev, 
     hip.free_matrix(mA)
     if mB is not None:
         hip.free_matrix(mB)
+
+
+@pytest.mark.gpu
+def test_reference_block_amg_over_the_hip_table(hip):
+    """The literal drop-in of the multigrid leg: the REFERENCE's compiled BlockAMG + BlockPCG + DefaultMultiVecFromItoJ
+    (oracle/_ref/libgcge_ref.so, src/ops_lin_sol.c:466-715, src/ops_multi_grid.c:69-117) over a table only OPS_HIP_Set touched —
+    hierarchy from the HIP MultiGridCreate slot, rectangular prolongations through MatDotMultiVec / MatTransDotMultiVec, work
+    blocks from MultiVecCreateByMat of the level matrices (set-up of test/test_eig_sol_SiO2_MAT.c:96-128,160-170) — against OUR
+    BlockAMG over the same table with the slot-level smoother: the same x; and against a direct solve after enough cycles."""
+    import os
+    import scipy.sparse.linalg as sla
+    import pyoracle as po
+    ref = po.ref_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref/libgcge_ref.so not present")
+    A, _ = make_problem("lap3d", 12)
+    S = csr_to_scipy(A)
+    n, m = A.nrows, 6
+    mA = hip.matrix(A)
+    ops2 = C.c_void_p()
+    hip.h.OPS_Create(C.byref(ops2))
+    hip.g.OPS_HIP_Set(ops2)
+    b = F(uniform(201, (n, m)) - 0.5)
+    vb = hip.mv_from_numpy(mA, b)
+    vx = hip.mv_from_numpy(mA, np.zeros_like(b))
+    max_iter = [3, 4, 4, 3, 3, 8, 0]
+    rate, tol = [1e-30] * 3, [1e-30] * 3
+    mi = (C.c_int * len(max_iter))(*max_iter); ra = (C.c_double * 3)(*rate); to = (C.c_double * 3)(*tol)
+    res = C.c_double()
+    ref.ref_block_amg_foreign.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L = ref.ref_block_amg_foreign(ops2, mA, 3, mi, ra, to, m, vb, vx, C.byref(res))
+    assert L == 3
+    x_ref = hip.mv_to_numpy(vx, n, 0, m)
+    os.environ["GCGE_AMG_HOST_SMOOTHER"] = "1"
+    try:
+        Ah, Ph, done = slot_multigrid(hip, mA, None, 3)
+        x_own, _, res_own = block_amg_solve(hip, Ah, Ph, b, np.zeros_like(b), max_iter, rate, tol)
+        done()
+    finally:
+        os.environ.pop("GCGE_AMG_HOST_SMOOTHER", None)
+    assert np.max(np.abs(x_ref - x_own)) <= 1e-10 * np.max(np.abs(x_own))
+    assert abs(res.value - res_own) <= 1e-8 * abs(res_own)
+    xs = sla.spsolve(S.tocsc(), b)
+    assert np.max(np.abs(x_ref - xs)) / np.max(np.abs(xs)) < 0.05          # three V-cycles: two digits
+    hip.ops.mv_destroy(vb, m)
+    hip.ops.mv_destroy(vx, m)
+    hip.free_matrix(mA)
