@@ -631,9 +631,14 @@ def main():
     g.gcge_hip_profile_kind.restype = C.c_long
     g.gcge_hip_profile_kind.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 
-    def prof(kind, ncols):
+    g.gcge_hip_profile_kind_rows.restype = C.c_long
+    g.gcge_hip_profile_kind_rows.argtypes = [C.c_int, C.c_int, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+
+    def prof(kind, ncols, all_levels=False):
+        # the launches on THIS matrix (A.nrows local rows): with BlockAMG the fused CG runs the same kernels on every level of the
+        # hierarchy — a roofline figure belongs to one problem size, the finest level's; all_levels: every launch (time shares)
         ms_, by_ = C.c_double(), C.c_double()
-        c_ = g.gcge_hip_profile_kind(kind, ncols, C.byref(ms_), C.byref(by_))
+        c_ = g.gcge_hip_profile_kind_rows(kind, ncols, 0 if all_levels else A.nrows, C.byref(ms_), C.byref(by_))
         return int(c_), ms_.value, by_.value
 
     ci, ai = C.c_long(), C.c_long()
@@ -643,7 +648,7 @@ def main():
     g.gcge_hip_bpcg_time_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_double), C.c_int]
     g.gcge_hip_bpcg_time_stats(C.byref(cg_its), C.byref(cg_sec), 0)
     stats = {k: prof(k, args.block) for k in (0, 2, 3)}
-    spmm_ms_all = sum(prof(k, 0)[1] for k in (0, 2, 3))
+    spmm_ms_all = sum(prof(k, 0, all_levels=True)[1] for k in (0, 2, 3))
     g.gcge_hip_profile_enable(0)
     # in-solve rate of the dense kernels per shape (north_star: "MFMA utilisation for the TSQR/Gram kernels reported against
     # gfx950 peak"): 2 n k m flop of a launch / its HIP-event duration, summed per (kernel, k, m) over the timed steps

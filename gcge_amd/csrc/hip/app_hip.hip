@@ -320,7 +320,7 @@ extern "C" void gcge_hip_set_random_mode(int mode, unsigned long long seed) { g_
 // ------------------------------------------------------------------ SpMM launch profiling
 // HIP events around every K1 launch on the launch stream (bench.py: roofline.achieved =
 // algorithmic bytes / average launch duration, measured live inside the timed region).
-struct SpmmEvent { hipEvent_t e0, e1; int m; double bytes; int kind; };   // kind 0: product (plain or with the column sums), 2 / 3: CG passes
+struct SpmmEvent { hipEvent_t e0, e1; int m; double bytes; int kind; long rows; };   // rows: local rows of the matrix (a solver may run the same kernels on several: the levels of a multigrid cycle)   // kind 0: product (plain or with the column sums), 2 / 3: CG passes
 static std::vector<SpmmEvent> g_prof;
 static int g_prof_on = 0;
 extern "C" void gcge_hip_profile_enable(int on) {
@@ -334,11 +334,17 @@ extern "C" long gcge_hip_profile_kind(int kind, int ncols, double* total_ms, dou
 extern "C" long gcge_hip_profile_spmm(int ncols, double* total_ms, double* total_alg_bytes) {
   return gcge_hip_profile_kind(0, ncols, total_ms, total_alg_bytes);
 }
+extern "C" long gcge_hip_profile_kind_rows(int kind, int ncols, long nrows, double* total_ms, double* total_alg_bytes);
 extern "C" long gcge_hip_profile_kind(int kind, int ncols, double* total_ms, double* total_alg_bytes) {
+  return gcge_hip_profile_kind_rows(kind, ncols, 0, total_ms, total_alg_bytes);
+}
+// ... restricted to the launches on matrices of `nrows` local rows (0: all).  With BlockAMG as the solver the fused CG runs the same
+// kernels on every level of the hierarchy; a roofline figure belongs to ONE problem size (bench.py: the finest level).
+extern "C" long gcge_hip_profile_kind_rows(int kind, int ncols, long nrows, double* total_ms, double* total_alg_bytes) {
   long cnt = 0; double ms = 0.0, by = 0.0;
   GCGE_HIP_CHECK(hipDeviceSynchronize());
   for (auto& e : g_prof) {
-    if (e.kind != kind || (ncols > 0 && e.m != ncols)) continue;
+    if (e.kind != kind || (ncols > 0 && e.m != ncols) || (nrows > 0 && e.rows != nrows)) continue;
     float t = 0.f;
     GCGE_HIP_CHECK(hipEventElapsedTime(&t, e.e0, e.e1));
     ms += t; by += e.bytes; ++cnt;
@@ -886,7 +892,7 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
   if (g_prof_on) {   // (on a row slab the interval also holds the halo exchange)
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
     ev.kind = 0;
-    ev.m = m;   // algorithmic bytes: values+indices once, row pointers once, X once, Y once
+    ev.m = m; ev.rows = A->nrows;   // algorithmic bytes: values+indices once, row pointers once, X once, Y once
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
@@ -949,7 +955,7 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
     SpmmEvent ev;
     if (g_prof_on) {
       GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
-      ev.m = m; ev.kind = 0;
+      ev.m = m; ev.rows = A->nrows; ev.kind = 0;
       ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
       GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
     }
@@ -993,7 +999,7 @@ extern "C" void gcge_hip_spmm_dot2_mv(void* mat, void** x, void** y, int* start,
   SpmmEvent ev;
   if (g_prof_on) {   // the fused kernel IS the K1 launch of a CG step (same algorithmic bytes: the dots add no HBM traffic)
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
-    ev.m = m; ev.kind = 0;
+    ev.m = m; ev.rows = A->nrows; ev.kind = 0;
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
@@ -1036,7 +1042,7 @@ extern "C" int gcge_hip_spmm_dot2_dev(void* mat, void** x, void** y, int cx, int
   SpmmEvent ev;
   if (g_prof_on) {
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
-    ev.m = m; ev.kind = 0;
+    ev.m = m; ev.rows = A->nrows; ev.kind = 0;
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 16.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
@@ -1097,7 +1103,7 @@ extern "C" int gcge_hip_cg_pass1_dev(void* mat, void** p, int c0, int m, double*
   SpmmEvent ev;
   if (g_prof_on) {   // algorithmic bytes: matrix once, p once
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
-    ev.m = m; ev.kind = 2;
+    ev.m = m; ev.rows = A->nrows; ev.kind = 2;
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 8.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
@@ -1133,7 +1139,7 @@ extern "C" int gcge_hip_cg_pass2_dev(void* mat, void** p, void** r, void** pnew,
   SpmmEvent ev;
   if (g_prof_on) {   // algorithmic bytes: matrix once, p and r read, r and p_new written
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
-    ev.m = m; ev.kind = 3;
+    ev.m = m; ev.rows = A->nrows; ev.kind = 3;
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 32.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }
@@ -1170,7 +1176,7 @@ extern "C" int gcge_hip_cg_pass2i_dev(void* mat, void** p, void** pprev, void** 
   SpmmEvent ev;
   if (g_prof_on) {   // algorithmic bytes: matrix once, p and p_prev read, p_new written
     GCGE_HIP_CHECK(hipEventCreate(&ev.e0)); GCGE_HIP_CHECK(hipEventCreate(&ev.e1));
-    ev.m = m; ev.kind = 3;
+    ev.m = m; ev.rows = A->nrows; ev.kind = 3;
     ev.bytes = 12.0 * (double)A->nnz + 4.0 * ((double)A->nrows + 1.0) + 24.0 * (double)A->nrows * m;
     GCGE_HIP_CHECK(hipEventRecord(ev.e0, g_stream));
   }

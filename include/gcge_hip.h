@@ -188,6 +188,9 @@ long gcge_hip_profile_spmm (int ncols, double *total_ms, double *total_alg_bytes
 /*     by kind: 0 = MatDotMultiVec products (what gcge_hip_profile_spmm returns), 2 / 3 = first / second pass of a
  *     block-CG iteration in its recompute form (below); ncols == 0: all widths                                    */
 long gcge_hip_profile_kind (int kind, int ncols, double *total_ms, double *total_alg_bytes);
+/*     ... restricted to launches on matrices of nrows local rows (0: all): with BlockAMG the same kernels run on every level of the
+ *     hierarchy, and a roofline figure belongs to one problem size                                                              */
+long gcge_hip_profile_kind_rows (int kind, int ncols, long nrows, double *total_ms, double *total_alg_bytes);
 
 /* ---- K7: small dense symmetric eigensolver on the device (replaces dsyevx, src/ops_eig_sol_gcg.c:1201-1203) ------
  * all eigenpairs of the symmetric n x n matrix a (HOST, column-major, ld lda; triangle `uplo` is read): w ascending,
