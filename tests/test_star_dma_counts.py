@@ -33,7 +33,9 @@ def test_hand_counted_waits_of_the_dma_sweep_match_the_disassembly(tmp_path):
             code = line.split(";")[0].strip()
             if code and not code.startswith("."):
                 kernels[name]["code"].append(code)
-    assert len(kernels) == 4, list(kernels)
+    # four product kernels (DOT x SLAB) + the timing probe of round 5 (third template flag: own points requested at the strips' lead,
+    # tools/star_lead_probe.py) — the probe issues the same operations per step, so it is held to the same counts
+    assert len(kernels) == 5 and sum(n.startswith("_ZN4gcge17spmm_star3_kernelILb0ELb0ELb1E") for n in kernels) == 1, list(kernels)
     for name, k in kernels.items():
         want = 9 if k["dot"] else 7
         code = k["code"]
