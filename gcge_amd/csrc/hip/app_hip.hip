@@ -104,6 +104,7 @@ struct GcgeHipMV {
   long ld;
   int nrows, nrows_alloc, ncols;
   const GCGE_HIP_MAT_* mat;   // shape donor (row partition)
+  GcgePerm* perm;             // the row order of the matrix this block was created for (NULL / identity: the caller's order); see mat_upload.hip
   // column-wise Gram-Schmidt over the slots (see "one sweep per column" below): the state lives in the block it belongs to
   int pend_col; double pend_fac;                       // a scaling of column pend_col held back (pend_col < 0: none)
   int spec_c0, spec_c1; unsigned long spec_epoch;      // Gram column of [spec_c0, spec_c1) computed on the way by the call of epoch spec_epoch
@@ -396,9 +397,11 @@ static void pool_free(void* q, size_t bytes) {
 }
 
 // ------------------------------------------------------------------ multivector
-static GcgeHipMV* mv_new(int nrows, int nghost, int ncols, const GCGE_HIP_MAT_* mat) {
+static inline const GcgePerm* real_perm(const GcgePerm* p) { return (p != nullptr && !p->identity) ? p : nullptr; }
+static GcgeHipMV* mv_new(int nrows, int nghost, int ncols, const GCGE_HIP_MAT_* mat, GcgePerm* perm) {
   GcgeHipMV* v = (GcgeHipMV*)calloc(1, sizeof(GcgeHipMV));
   v->nrows = nrows; v->nrows_alloc = nrows + nghost; v->ncols = ncols; v->mat = mat; v->pend_col = -1;
+  v->perm = gcge_hip_perm_acquire(perm);
   v->ld = ((long)(ncols > 0 ? ncols : 1) + 7) / 8 * 8;
   const size_t bytes = (size_t)v->nrows_alloc * v->ld * sizeof(double);
   v->bytes = bytes ? bytes : 8;
@@ -408,17 +411,17 @@ static GcgeHipMV* mv_new(int nrows, int nghost, int ncols, const GCGE_HIP_MAT_* 
 }
 static void HIP_MultiVecCreateByMat(void*** mv, int num_vec, void* mat, struct OPS_* ops) {
   const GCGE_HIP_MAT_* A = (const GCGE_HIP_MAT_*)mat;
-  if (A->rect_ncols > 0) { *mv = (void**)mv_new(A->rect_ncols, 0, num_vec, nullptr); return; }   // app_ccs.c:43: rows = the matrix's COLUMNS
-  *mv = (void**)mv_new(A->nrows, A->nghost, num_vec, A);
+  if (A->rect_ncols > 0) { *mv = (void**)mv_new(A->rect_ncols, 0, num_vec, nullptr, nullptr); return; }   // app_ccs.c:43: rows = the matrix's COLUMNS
+  *mv = (void**)mv_new(A->nrows, A->nghost, num_vec, A, A->perm);
 }
 static void HIP_MultiVecCreateByMultiVec(void*** mv, int num_vec, void** src, struct OPS_* ops) {
   const GcgeHipMV* s = (const GcgeHipMV*)src;
-  *mv = (void**)mv_new(s->nrows, s->nrows_alloc - s->nrows, num_vec, s->mat);
+  *mv = (void**)mv_new(s->nrows, s->nrows_alloc - s->nrows, num_vec, s->mat, s->perm);
 }
 static void HIP_MultiVecDestroy(void*** mv, int num_vec, struct OPS_* ops) {
   GcgeHipMV* v = *(GcgeHipMV**)mv;
   enter();
-  if (v) { delete v->spec_dots; pool_free(v->d, v->bytes); free(v); }
+  if (v) { delete v->spec_dots; pool_free(v->d, v->bytes); gcge_hip_perm_release(v->perm); free(v); }
   *mv = nullptr;
 }
 static void flush_pending() {
@@ -444,11 +447,18 @@ extern "C" void gcge_hip_mv_from_host(void** mv, int c0, int c1, const double* h
   const int n = v->nrows;
   GCGE_REQUIRE(c0 >= 0 && c1 <= v->ncols && ldh >= n, "gcge_hip_mv_from_host: ranges");
   const int panel = 32;
+  const GcgePerm* P = real_perm(v->perm);          // the block lives in the back-end's own row order: device row i = the caller's row perm[i]
+  std::vector<double> tmp;
+  if (P != nullptr) tmp.resize((size_t)n * panel);
   for (int c = c0; c < c1; c += panel) {
     const int m = (c1 - c < panel) ? c1 - c : panel;
     double* st = stage_d((size_t)n * m);
-    GCGE_HIP_CHECK(hipMemcpy2DAsync(st, (size_t)n * sizeof(double), host + (size_t)(c - c0) * ldh,
-                                    (size_t)ldh * sizeof(double), (size_t)n * sizeof(double), m,
+    const double* src = host + (size_t)(c - c0) * ldh; size_t lds_ = (size_t)ldh;
+    if (P != nullptr) {
+      for (int j = 0; j < m; ++j) { const double* hj = host + (size_t)(c - c0 + j) * ldh; double* tj = tmp.data() + (size_t)j * n; for (int i = 0; i < n; ++i) tj[i] = hj[P->perm[i]]; }
+      src = tmp.data(); lds_ = (size_t)n;
+    }
+    GCGE_HIP_CHECK(hipMemcpy2DAsync(st, (size_t)n * sizeof(double), src, lds_ * sizeof(double), (size_t)n * sizeof(double), m,
                                     hipMemcpyHostToDevice, g_stream));
     gcge_hip_colmajor_to_rowmajor(n, m, st, n, v->d + c, v->ld, g_stream);
     GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
@@ -460,14 +470,20 @@ extern "C" void gcge_hip_mv_to_host(void** mv, int c0, int c1, double* host, lon
   const int n = v->nrows;
   GCGE_REQUIRE(c0 >= 0 && c1 <= v->ncols && ldh >= n, "gcge_hip_mv_to_host: ranges");
   const int panel = 32;
+  const GcgePerm* P = real_perm(v->perm);
+  std::vector<double> tmp;
+  if (P != nullptr) tmp.resize((size_t)n * panel);
   for (int c = c0; c < c1; c += panel) {
     const int m = (c1 - c < panel) ? c1 - c : panel;
     double* st = stage_d((size_t)n * m);
     gcge_hip_rowmajor_to_colmajor(n, m, v->d + c, v->ld, st, n, g_stream);
-    GCGE_HIP_CHECK(hipMemcpy2DAsync(host + (size_t)(c - c0) * ldh, (size_t)ldh * sizeof(double), st,
+    double* dst = P != nullptr ? tmp.data() : host + (size_t)(c - c0) * ldh;
+    GCGE_HIP_CHECK(hipMemcpy2DAsync(dst, (P != nullptr ? (size_t)n : (size_t)ldh) * sizeof(double), st,
                                     (size_t)n * sizeof(double), (size_t)n * sizeof(double), m,
                                     hipMemcpyDeviceToHost, g_stream));
     GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));
+    if (P != nullptr)
+      for (int j = 0; j < m; ++j) { double* hj = host + (size_t)(c - c0 + j) * ldh; const double* tj = tmp.data() + (size_t)j * n; for (int i = 0; i < n; ++i) hj[P->perm[i]] = tj[i]; }
   }
 }
 
@@ -882,6 +898,8 @@ static void HIP_MatDotMultiVec(void* mat, void** x, void** y, int* start, int* e
   }
   GCGE_REQUIRE(vx->nrows == vy->nrows, "MatDotMultiVec: equal row counts");
   if (A != nullptr) GCGE_REQUIRE(A->nrows == vy->nrows && A->nrows + A->nghost <= vx->nrows_alloc, "MatDotMultiVec: matrix/vector shapes");
+  // blocks and matrix must live in ONE row order (the back-end re-orders matrices without a grid: mat_upload.hip "row orders")
+  if (A != nullptr) GCGE_REQUIRE(real_perm(vx->perm) == real_perm(A->perm) && real_perm(vy->perm) == real_perm(A->perm), "MatDotMultiVec: the blocks were created for a matrix in another row order");
   if (A == nullptr) {
     gcge_hip_axpby(vy->nrows, 1.0, vx->d + start[0], vx->ld, 0.0, vy->d + start[1], vy->ld, m, g_stream);
     return;

@@ -77,7 +77,16 @@ struct GCGE_HIP_MAT_ {
   // row slabs: the global rows behind the halo columns (host copy, nghost ints; NULL: not named) and the row partition of all ranks
   // (host, part_world + 1 entries; NULL: unknown) — what MultiGridCreate needs to coarsen a slab (multigrid.hip)
   int* h_ghost_global; long* h_part; int part_world;
+  // round 5: the row order the back-end chose for itself (mat_upload.hip "row orders"): the device arrays hold P A P^T, every block of
+  // vectors created for this matrix lives in the same order; NULL: the caller's order
+  struct GcgePerm* perm;
 };
+// One row order per problem size and process: every matrix of n rows (A, then B of a generalised problem) and every block of vectors
+// created for them share it.  perm[new] = old, iperm[old] = new; identity: a matrix of this size was uploaded in the caller's order and
+// later ones of the same size must follow it.  Reference-counted by matrices and blocks.
+struct GcgePerm { int n; int* perm; int* iperm; int identity; long refs; unsigned id; };
+extern "C" struct GcgePerm* gcge_hip_perm_acquire(struct GcgePerm* p);      // ++refs (NULL passes through)
+extern "C" void gcge_hip_perm_release(struct GcgePerm* p);
 extern "C" void gcge_hip_halo_native_free(struct GCGE_HIP_MAT_* A);
 // multigrid.hip: the MultiGridCreate / MultiGridDestroy slots of OPS_HIP_Set and the block-CG smoother it registers for BlockAMG
 extern "C" void gcge_hip_multigrid_create(void*** A_array, void*** B_array, void*** P_array, int* num_levels, void* A, void* B, struct OPS_* ops);

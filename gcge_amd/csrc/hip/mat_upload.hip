@@ -311,13 +311,122 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_local(int nrows, int ncols_local, i
                                                    const int* rowptr, const int* colidx, const double* val) {
   return gcge_hip_mat_create_local_ghosts(nrows, ncols_local, nglobal, row_begin, rowptr, colidx, val, nullptr);
 }
+// ---------------------------------------------------------------------------------------------------------------- row orders
+// (round 5)  A whole matrix (one rank) that shows neither a pattern form nor a grid in the order it arrives in is
+// re-ordered INSIDE the handle: grid coordinates recovered from the graph of a star stencil (gcge_hip_reorder_star_grid: scan order,
+// the plane sweep applies again) or reverse Cuthill-McKee (a banded matrix gathers from a window of X).  The solver never sees it:
+// handles are opaque, blocks of vectors created for the matrix live in the new order, gcge_hip_mv_to_host / from_host
+// and the reference-order random fill translate.  mode: 0 automatic (matrices of >= 65 536 rows without a fast form), 1 every matrix
+// without a fast form (tests), -1 never.
+extern "C" void gcge_hip_star_next_geometry(int nrows, int nx, int ny, int nz, const int* box_of_row);
+extern "C" long gcge_hip_reorder_star_grid(int n, const int* rowptr, const int* colidx, const double* val, int* dims, int* box_of_row);
+extern "C" int gcge_hip_reorder_rcm(int n, const int* rowptr, const int* colidx, int* perm);
+extern "C" double gcge_hip_mean_bandwidth(int n, const int* rowptr, const int* colidx, const int* iperm);
+static int g_reorder_mode = 0;
+extern "C" void gcge_hip_spmm_reorder_mode(int mode) { g_reorder_mode = mode; }
+static std::vector<GcgePerm*> g_perms;          // live orders, one per n
+static unsigned g_perm_next_id = 1;
+static char g_reorder_kind[64] = "";
+extern "C" const char* gcge_hip_mat_row_order(const GCGE_HIP_MAT* A) {
+  if (A == nullptr || A->perm == nullptr || A->perm->identity) return "as given";
+  return g_reorder_kind[0] ? g_reorder_kind : "reordered";
+}
+extern "C" GcgePerm* gcge_hip_perm_acquire(GcgePerm* p) { if (p) ++p->refs; return p; }
+extern "C" void gcge_hip_perm_release(GcgePerm* p) {
+  if (p == nullptr || --p->refs > 0) return;
+  for (size_t i = 0; i < g_perms.size(); ++i) if (g_perms[i] == p) { g_perms.erase(g_perms.begin() + (long)i); break; }
+  free(p->perm); free(p->iperm); free(p);
+}
+static GcgePerm* perm_find(int n) { for (GcgePerm* p : g_perms) if (p->n == n) return p; return nullptr; }
+static GcgePerm* perm_register(int n, const int* perm /* NULL: identity */) {
+  GcgePerm* p = (GcgePerm*)calloc(1, sizeof(GcgePerm));
+  p->n = n; p->identity = perm == nullptr; p->id = g_perm_next_id++;
+  if (perm != nullptr) {
+    p->perm = (int*)malloc((size_t)n * sizeof(int)); p->iperm = (int*)malloc((size_t)n * sizeof(int));
+    memcpy(p->perm, perm, (size_t)n * sizeof(int));
+    for (int i = 0; i < n; ++i) p->iperm[perm[i]] = i;
+  }
+  g_perms.push_back(p);
+  return p;
+}
+// P A P^T as CSR with ascending columns: new row i = old row perm[i], old column c -> iperm[c]
+static void permute_csr(int n, const int* rowptr, const int* colidx, const double* val, const GcgePerm* P,
+                        std::vector<int>& rp, std::vector<int>& ci, std::vector<double>& va) {
+  rp.resize((size_t)n + 1); ci.resize((size_t)rowptr[n] ? (size_t)rowptr[n] : 1); va.resize(ci.size());
+  rp[0] = 0;
+  for (int i = 0; i < n; ++i) rp[i + 1] = rp[i] + (rowptr[P->perm[i] + 1] - rowptr[P->perm[i]]);
+  gcge_parallel_chunks(n, gcge_upload_threads(), [&](int, long r0, long r1) {
+    std::vector<std::pair<int, double>> tmp;
+    for (long i = r0; i < r1; ++i) {
+      const int o = P->perm[i];
+      tmp.clear();
+      for (int k = rowptr[o]; k < rowptr[o + 1]; ++k) tmp.emplace_back(P->iperm[colidx[k]], val[k]);
+      std::sort(tmp.begin(), tmp.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+      int q = rp[i];
+      for (auto& e : tmp) { ci[q] = e.first; va[q] = e.second; ++q; }
+    }
+  });
+}
 extern "C" GCGE_HIP_MAT* gcge_hip_mat_create(int nrows, int nglobal, int row_begin, const int* rowptr,
                                              const int* colidx, const double* val) {
   if (row_begin != 0 || nrows != nglobal) {
     fprintf(stderr, "gcge_hip_mat_create: a row slab needs gcge_dist_localize + gcge_hip_mat_create_local\n");
     return nullptr;
   }
-  return gcge_hip_mat_create_local(nrows, nrows, nglobal, 0, rowptr, colidx, val);
+  const bool timing = getenv("GCGE_UPLOAD_TIMING") != nullptr;
+  std::vector<int> rp, ci; std::vector<double> va;
+  // a matrix of this size lives in this process already: the new one shares its row order (B after A of a generalised problem)
+  if (GcgePerm* P = perm_find(nrows)) {
+    if (P->identity) {
+      GCGE_HIP_MAT* A = gcge_hip_mat_create_local(nrows, nrows, nglobal, 0, rowptr, colidx, val);
+      if (A != nullptr) A->perm = gcge_hip_perm_acquire(P);
+      return A;
+    }
+    permute_csr(nrows, rowptr, colidx, val, P, rp, ci, va);
+    GCGE_HIP_MAT* A = gcge_hip_mat_create_local(nrows, nrows, nglobal, 0, rp.data(), ci.data(), va.data());
+    if (A != nullptr) A->perm = gcge_hip_perm_acquire(P);
+    return A;
+  }
+  GCGE_HIP_MAT* A = gcge_hip_mat_create_local(nrows, nrows, nglobal, 0, rowptr, colidx, val);
+  if (A == nullptr) return nullptr;
+  const bool fast = A->d_pid != nullptr || A->star != nullptr;
+  const bool want = g_reorder_mode == 1 || (g_reorder_mode == 0 && nrows >= 65536);
+  if (fast || !want || nrows < 64) { A->perm = gcge_hip_perm_acquire(perm_register(nrows, nullptr)); return A; }
+  // no fast form in the order given: look for a better one
+  double t0 = upload_now();
+  std::vector<int> perm((size_t)nrows), box((size_t)nrows);
+  int dims[3] = {0, 0, 0};
+  bool have = false, grid = false;
+  const long placed = gcge_hip_reorder_star_grid(nrows, rowptr, colidx, val, dims, box.data());
+  if (placed > 0) {                                       // scan order of the recovered grid: ascending box index
+    for (int i = 0; i < nrows; ++i) perm[i] = i;
+    std::sort(perm.begin(), perm.end(), [&](int a, int b) { return box[a] < box[b]; });
+    have = grid = true;
+    snprintf(g_reorder_kind, sizeof g_reorder_kind, "grid %d x %d x %d recovered from the star couplings", dims[0], dims[1], dims[2]);
+  } else if (gcge_hip_reorder_rcm(nrows, rowptr, colidx, perm.data()) == 0) {
+    std::vector<int> ip((size_t)nrows);
+    for (int i = 0; i < nrows; ++i) ip[perm[i]] = i;
+    const double b0 = gcge_hip_mean_bandwidth(nrows, rowptr, colidx, nullptr), b1 = gcge_hip_mean_bandwidth(nrows, rowptr, colidx, ip.data());
+    have = b1 < 0.5 * b0;                                 // (a matrix that is banded already stays as it is)
+    snprintf(g_reorder_kind, sizeof g_reorder_kind, "reverse Cuthill-McKee (mean |i - j| %.0f -> %.0f)", b0, b1);
+  }
+  if (timing) fprintf(stderr, "gcge_hip upload: %-28s %.3f s (%s)\n", "row order", upload_now() - t0, have ? g_reorder_kind : "kept as given");
+  if (!have) { A->perm = gcge_hip_perm_acquire(perm_register(nrows, nullptr)); return A; }
+  gcge_hip_mat_destroy(A);
+  GcgePerm* P = perm_register(nrows, perm.data());
+  permute_csr(nrows, rowptr, colidx, val, P, rp, ci, va);
+  if (grid && (long)dims[0] * dims[1] * dims[2] != nrows) {   // a masked grid (ball): name the geometry for the plane sweep's row map
+    std::vector<int> bsorted((size_t)nrows);
+    for (int i = 0; i < nrows; ++i) bsorted[i] = box[perm[i]];
+    gcge_hip_star_next_geometry(nrows, dims[0], dims[1], dims[2], bsorted.data());
+    A = gcge_hip_mat_create_local(nrows, nrows, nglobal, 0, rp.data(), ci.data(), va.data());
+    gcge_hip_star_next_geometry(0, 0, 0, 0, nullptr);
+  } else {
+    A = gcge_hip_mat_create_local(nrows, nrows, nglobal, 0, rp.data(), ci.data(), va.data());
+  }
+  if (A == nullptr) { gcge_hip_perm_release(gcge_hip_perm_acquire(P)); return nullptr; }
+  A->perm = gcge_hip_perm_acquire(P);
+  return A;
 }
 // A matrix on a MASKED grid (one rank): row r is grid point box_of_row[r] = x + nx (y + ny z) of an nx x ny x nz box, rows in scan
 // order — the real-space DFT matrices behind BASELINE config 5 live on the grid points inside a sphere (PARSEC).  With the
@@ -328,7 +437,8 @@ extern "C" void gcge_hip_star_next_geometry(int nrows, int nx, int ny, int nz, c
 extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_grid(int nrows, const int* rowptr, const int* colidx, const double* val,
                                                   int nx, int ny, int nz, const int* box_of_row) {
   if (box_of_row != nullptr && nx > 0 && ny > 0 && nz > 0) gcge_hip_star_next_geometry(nrows, nx, ny, nz, box_of_row);
-  GCGE_HIP_MAT* A = gcge_hip_mat_create(nrows, nrows, 0, rowptr, colidx, val);
+  GCGE_HIP_MAT* A = gcge_hip_mat_create_local(nrows, nrows, nrows, 0, rowptr, colidx, val);      // (the caller named the geometry: the rows stay as given)
+  if (A != nullptr) { GcgePerm* P = perm_find(nrows); if (P == nullptr) P = perm_register(nrows, nullptr); if (P->identity) A->perm = gcge_hip_perm_acquire(P); }
   gcge_hip_star_next_geometry(0, 0, 0, 0, nullptr);                   // (not consumed when the matrix took a pattern form)
   return A;
 }
@@ -356,7 +466,7 @@ extern "C" void gcge_hip_mat_set_halo_async(GCGE_HIP_MAT* A, gcge_halo_exchange_
 extern "C" void gcge_hip_mat_destroy(GCGE_HIP_MAT* A) {
   if (!A) return;
   hipFree(A->d_rowptr); hipFree(A->d_colidx); hipFree(A->d_val);
-  if (A->rect_ncols > 0) { hipFree(A->d_t_rowptr); hipFree(A->d_t_colidx); hipFree(A->d_t_val); free(A); return; }   // a prolongation (multigrid.hip)
+  if (A->rect_ncols > 0) { hipFree(A->d_t_rowptr); hipFree(A->d_t_colidx); hipFree(A->d_t_val); gcge_hip_perm_release(A->perm); free(A); return; }   // a prolongation (multigrid.hip)
   hipFree(A->d_orp); hipFree(A->d_pcol); hipFree(A->d_pval);
   if (A->d_pid) { hipFree(A->d_pid); hipFree(A->d_tab); }
   if (A->d_rowval) hipFree(A->d_rowval);
@@ -367,6 +477,7 @@ extern "C" void gcge_hip_mat_destroy(GCGE_HIP_MAT* A) {
   if (A->star != nullptr) gcge_hip_star_free(A->star);
   if (A->native_halo != nullptr) gcge_hip_halo_native_free(A);   // RCCL plan + the exchange buffers it owns (rccl_comm.hip)
   free(A->h_ghost_global); free(A->h_part);
+  gcge_hip_perm_release(A->perm);
   free(A);
 }
 // the row partition of all ranks a slab belongs to (world + 1 offsets): recorded by gcge_hip_mat_create_slab, or by whoever built

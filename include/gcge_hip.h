@@ -213,6 +213,15 @@ int gcge_hip_gram (int nrows, const double *d_q, long ldq, int k, const double *
 void gcge_hip_pool_release (void);
 void gcge_hip_pool_enable (int on);
 size_t gcge_hip_pool_cached_bytes (void);
+/*     row orders (csrc/hip/mat_upload.hip, reorder.hip): a whole matrix (gcge_hip_mat_create, one rank) that shows neither a pattern
+ *     form nor a grid in the order it arrives in is re-ordered inside the handle — grid coordinates recovered from the graph of a
+ *     star stencil (scan order: the plane sweep applies again) or reverse Cuthill-McKee.  Blocks of vectors created for it live in
+ *     the same order; gcge_hip_mv_to_host / from_host translate; a later matrix of the same size (B) adopts the order.
+ *     mode: 0 automatic (>= 65 536 rows), 1 every matrix without a fast form (tests), -1 never                                   */
+void gcge_hip_spmm_reorder_mode (int mode);
+const char *gcge_hip_mat_row_order (const GCGE_HIP_MAT *A);      /* "as given" or what the upload did */
+long gcge_hip_reorder_star_grid (int n, const int *rowptr, const int *colidx, const double *val, int *dims, int *box_of_row);   /* host only */
+int  gcge_hip_reorder_rcm (int n, const int *rowptr, const int *colidx, int *perm);                                            /* host only: perm[new] = old */
 void gcge_hip_set_spmm_path (int path);   /* 0 automatic (pattern > star rows + block form of the rest > dense blocks + remainder > pad-8 > CSR), 2 no pattern kernels (nor the star sweep), 3 pad-8 / CSR only, 4 no dense blocks */
 /*     tile path (csrc/hip/spmm_tile.hip): matrices without a pattern form whose rows are long enough (>= 12 entries on
  *     average; automatic rule: see mode) are additionally kept as row tiles (bricks of a detected grid, or runs of rows) with 16-bit positions into
