@@ -107,15 +107,18 @@ extern "C" long gcge_hip_reorder_star_grid(int n, const int* rowptr, const int* 
   g_reason = 0;
   if (n < 64) GIVE_UP;
   // 1. the stencil's coefficient values: the frequent off-diagonal values of a sample of rows
-  std::map<uint64_t, long> hist;
+  std::vector<uint64_t> vals_;                                          // (sorted and run-length counted: a std::map of millions of distinct values is slow)
   const long step = n > 200000 ? n / 200000 : 1;
   long sampled = 0;
   for (long r = 0; r < n; r += step) {
     if (rowptr[r + 1] - rowptr[r] > 64) continue;                        // (rows inside dense blocks: hundreds of unrelated values)
     ++sampled;
-    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) if (colidx[k] != r && val[k] != 0.0) ++hist[dbits(val[k])];
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) if (colidx[k] != r && val[k] != 0.0) vals_.push_back(dbits(val[k]));
   }
   if (sampled < 32) GIVE_UP;
+  std::sort(vals_.begin(), vals_.end());
+  std::vector<std::pair<uint64_t, long>> hist;
+  for (size_t i = 0; i < vals_.size(); ) { size_t j = i; while (j < vals_.size() && vals_[j] == vals_[i]) ++j; hist.emplace_back(vals_[i], (long)(j - i)); i = j; }
   long maxc = 0;
   for (auto& kv : hist) maxc = std::max(maxc, kv.second);
   if (maxc < 2 * sampled) GIVE_UP;                                     // (an interior star row carries every coefficient 6 times)
