@@ -401,7 +401,7 @@ static inline const GcgePerm* real_perm(const GcgePerm* p) { return (p != nullpt
 static GcgeHipMV* mv_new(int nrows, int nghost, int ncols, const GCGE_HIP_MAT_* mat, GcgePerm* perm) {
   GcgeHipMV* v = (GcgeHipMV*)calloc(1, sizeof(GcgeHipMV));
   v->nrows = nrows; v->nrows_alloc = nrows + nghost; v->ncols = ncols; v->mat = mat; v->pend_col = -1;
-  v->perm = gcge_hip_perm_acquire(perm);
+  v->perm = real_perm(perm) != nullptr ? gcge_hip_perm_acquire(perm) : nullptr;   // (the caller's order needs no record: only matrices pin "as given" for their size)
   v->ld = ((long)(ncols > 0 ? ncols : 1) + 7) / 8 * 8;
   const size_t bytes = (size_t)v->nrows_alloc * v->ld * sizeof(double);
   v->bytes = bytes ? bytes : 8;
@@ -434,6 +434,8 @@ static void flush_pending() {
   }
 }
 extern "C" int gcge_hip_mv_nrows(void** mv) { return ((GcgeHipMV*)mv)->nrows; }
+// id of the row order a block lives in (0: the caller's): scratch blocks kept between calls belong to ONE order (block_pcg.hip)
+extern "C" unsigned gcge_hip_mv_row_order_id(void** mv) { const GcgePerm* p = real_perm(((GcgeHipMV*)mv)->perm); return p ? p->id : 0u; }
 extern "C" int gcge_hip_mv_ncols(void** mv) { return ((GcgeHipMV*)mv)->ncols; }
 extern "C" double* gcge_hip_mv_device_ptr(void** mv, long* ld) {
   enter();

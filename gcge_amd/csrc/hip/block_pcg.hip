@@ -458,7 +458,9 @@ static void reduce_over_ranks(double* v, int n) {
 // size — the levels of a multigrid cycle (BlockAMG smooths every level with this CG) — must not rebuild its blocks and ring on
 // every call: the set of the shape that is left is PARKED (up to 8 row counts) and taken out again when that shape comes back.
 // A change of the column count within a shape drops that shape's ring, as before.
-struct BpcgParked { void** mv_ws[4]; void** ring[17]; int ring_len, ws_cols, ws_rows; };
+extern "C" unsigned gcge_hip_mv_row_order_id(void** mv);
+struct BpcgParked { void** mv_ws[4]; void** ring[17]; int ring_len, ws_cols, ws_rows; unsigned order; };
+static unsigned g_ws_order = 0;      // row order (mat_upload.hip "row orders") of the CURRENT set's blocks: they were created like the x block of that call
 static BpcgParked g_parked[8]; static int g_nparked = 0;
 static void bpcg_destroy_set(BpcgParked* q, struct OPS_* ops) {
   for (int i = 1; i < q->ring_len; ++i) if (q->ring[i]) ops->MultiVecDestroy(&q->ring[i], q->ws_cols, ops);
@@ -466,18 +468,28 @@ static void bpcg_destroy_set(BpcgParked* q, struct OPS_* ops) {
   memset(q, 0, sizeof *q);
 }
 static void bpcg_shape(HipBpcg* s, int n, int nrhs, void** mv_x, struct OPS_* ops) {
-  if (s->ws_cols >= nrhs && s->ws_rows == n) return;
+  const unsigned order = gcge_hip_mv_row_order_id(mv_x);
+  if (s->ws_cols >= nrhs && s->ws_rows == n && g_ws_order == order) return;
+  if (s->ws_rows == n && g_ws_order != order && s->mv_ws[0] != nullptr) {   // same size, another row order: the blocks belong to the other matrix
+    BpcgParked q; memcpy(q.mv_ws, s->mv_ws, sizeof q.mv_ws); memcpy(q.ring, s->ring, sizeof q.ring); q.ring_len = s->ring_len; q.ws_cols = s->ws_cols;
+    bpcg_destroy_set(&q, ops);
+    memset(s->mv_ws, 0, sizeof s->mv_ws); memset(s->ring, 0, sizeof s->ring); s->ring_len = 0; s->ws_cols = 0; s->ws_rows = 0;
+  }
   if (s->ws_rows != n) {
     if (s->ws_rows > 0 && s->mv_ws[0] != nullptr) {          // park the current set
       if (g_nparked == 8) { bpcg_destroy_set(&g_parked[0], ops); memmove(&g_parked[0], &g_parked[1], 7 * sizeof(BpcgParked)); --g_nparked; }
       BpcgParked* q = &g_parked[g_nparked++];
       memcpy(q->mv_ws, s->mv_ws, sizeof q->mv_ws); memcpy(q->ring, s->ring, sizeof q->ring);
-      q->ring_len = s->ring_len; q->ws_cols = s->ws_cols; q->ws_rows = s->ws_rows;
+      q->ring_len = s->ring_len; q->ws_cols = s->ws_cols; q->ws_rows = s->ws_rows; q->order = g_ws_order;
       memset(s->mv_ws, 0, sizeof s->mv_ws); memset(s->ring, 0, sizeof s->ring); s->ring_len = 0; s->ws_cols = 0; s->ws_rows = 0;
+    }
+    for (int i = 0; i < g_nparked; ++i) if (g_parked[i].ws_rows == n && g_parked[i].order != order) {   // parked for another row order: gone
+      bpcg_destroy_set(&g_parked[i], ops);
+      memmove(&g_parked[i], &g_parked[i + 1], (size_t)(g_nparked - 1 - i) * sizeof(BpcgParked)); --g_nparked; --i;
     }
     for (int i = 0; i < g_nparked; ++i) if (g_parked[i].ws_rows == n) {     // a parked set of this row count comes back
       memcpy(s->mv_ws, g_parked[i].mv_ws, sizeof s->mv_ws); memcpy(s->ring, g_parked[i].ring, sizeof s->ring);
-      s->ring_len = g_parked[i].ring_len; s->ws_cols = g_parked[i].ws_cols; s->ws_rows = n;
+      s->ring_len = g_parked[i].ring_len; s->ws_cols = g_parked[i].ws_cols; s->ws_rows = n; g_ws_order = order;
       memmove(&g_parked[i], &g_parked[i + 1], (size_t)(g_nparked - 1 - i) * sizeof(BpcgParked)); --g_nparked;
       break;
     }
@@ -489,7 +501,7 @@ static void bpcg_shape(HipBpcg* s, int n, int nrhs, void** mv_x, struct OPS_* op
     if (s->mv_ws[i]) ops->MultiVecDestroy(&s->mv_ws[i], s->ws_cols, ops);
     if (i < 3) ops->MultiVecCreateByMultiVec(&s->mv_ws[i], nrhs, mv_x, ops);
   }
-  s->ws_cols = nrhs; s->ws_rows = n;
+  s->ws_cols = nrhs; s->ws_rows = n; g_ws_order = order;
 }
 static void bpcg_ring(HipBpcg* s, void* mat, void** mv_x, double sigma, struct OPS_* ops) {
   long ldp = 0;

@@ -106,12 +106,13 @@ def reorder_on(hip):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,size,kw,want_form,want_order", [
-    ("lap3d", 16, {}, "spmm_pattern", "grid 16 x 16 x 16 recovered"),
-    ("sio2", 24, dict(K=12, R0=2.0, R1=5.0, seed=12345), "spmm_star", "grid 24 x 24 x 24 recovered"),
-    ("sio2ball", 28, dict(K=8, R0=1.5, R1=3.0, seed=12345), "spmm_star", "recovered"),
+    ("lap3d", 17, {}, "spmm_pattern", "grid 17 x 17 x 17 recovered"),
+    ("sio2", 23, dict(K=11, R0=2.0, R1=5.0, seed=12345), "spmm_star", "grid 23 x 23 x 23 recovered"),
+    ("sio2ball", 27, dict(K=8, R0=1.5, R1=3.0, seed=12345), "spmm_star", "recovered"),
 ])
 def test_permuted_grid_matrices_take_the_grid_kernels_again(reorder_on, kind, size, kw, want_form, want_order):
-    """A randomly permuted Laplacian / SiO2-like matrix / ball matrix: the upload recovers the grid, the K1 form is the one of the
+    """(Sizes no other test uses: a matrix of the same size that is still alive in the process pins its row order for later ones.)
+    A randomly permuted Laplacian / SiO2-like matrix / ball matrix: the upload recovers the grid, the K1 form is the one of the
     natural order, products (odd offsets, 1 ... 66 columns), inner products and a round trip through the host agree with scipy on the
     PERMUTED arrays; with the re-ordering switched off the same handle calls give the same numbers through the generic kernels."""
     hip = reorder_on
@@ -164,7 +165,7 @@ def test_permuted_grid_matrices_take_the_grid_kernels_again(reorder_on, kind, si
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,size,nev,kw,amg", [("lap3d", 16, 10, {}, 3), ("sio2", 20, 10, dict(K=8, R0=1.5, R1=3.0, seed=12345), 0), ("fe3d", 12, 10, {}, 0)])
+@pytest.mark.parametrize("kind,size,nev,kw,amg", [("lap3d", 18, 10, {}, 3), ("sio2", 21, 10, dict(K=8, R0=1.5, R1=3.0, seed=12345), 0), ("fe3d", 19, 10, {}, 0)])
 def test_gcg_on_permuted_matrices_matches_the_oracle(reorder_on, oracle, kind, size, nev, kw, amg):
     """Whole eigensolves on randomly permuted matrices (standard and generalised: B adopts A's row order) with the fused CG — and with
     BlockAMG on the recovered grid — against the CPU oracle on the same permuted arrays: Ritz values <= 1e-10; the eigenvectors

@@ -33,6 +33,12 @@ g.gcge_hip_profile_spmm.restype = C.c_long
 g.gcge_hip_profile_spmm.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 g.gcge_hip_mat_spmm_form.restype = C.c_char_p
 g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+if os.environ.get("PROBE_TILE_MODE") is not None:          # 1: row tiles (spmm_tile.hip) for every matrix without a pattern form
+    g.gcge_hip_spmm_tile_mode.argtypes = [C.c_int]
+    g.gcge_hip_spmm_tile_mode(int(os.environ["PROBE_TILE_MODE"]))
+if os.environ.get("PROBE_REORDER_MODE") is not None:       # -1: keep the rows as given (the state before round 5)
+    g.gcge_hip_spmm_reorder_mode.argtypes = [C.c_int]
+    g.gcge_hip_spmm_reorder_mode(int(os.environ["PROBE_REORDER_MODE"]))
 
 
 def measure(tag, S, check=None):
