@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--plain-steps", type=int, default=2,
                     help="with --amg: additional solves with the plain fused block CG (30 iterations) after the timed region -> plain_block_cg "
                          "(the configuration rounds 1-4 reported as value)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the legs after the timed region (plain_block_cg, roofline_k1_c5, dropin_reference_stack)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the legs after the timed region (plain_block_cg, roofline_k1_c5, roofline_k1_permuted, dropin_reference_stack)")
     ap.add_argument("--cpu-like-size", type=int, default=48, help="grid size of the like-for-like CPU sample (config 2's solver shape on the CPU reference)")
     ap.add_argument("--amg", type=int, default=-1,
                     help="levels (>= 2) of the multigrid hierarchy: the W systems are solved by BlockAMG (one V-cycle, fused block CG as the "
@@ -325,6 +325,60 @@ def k1_plain_leg(hip, mat, A, m, what):
     return {"bound": "hbm", "kernel": "%s: Y = A X, K1 (MatDotMultiVec), m=%d" % (form, m), "what": what, "achieved": alg / (avg_ms * 1e-3) / 1e9,
             "peak": 8000.0, "unit": "GB/s", "frac": alg / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "launches": int(cnt),
             "avg_launch_ms": avg_ms, "alg_bytes_per_launch": alg, "n": int(A.nrows), "nnz": int(A.nnz)}
+
+
+def k1_permuted_leg(hip, args):
+    """roofline_k1_permuted: K1 on a matrix that shows NO grid in the order it arrives in — the SiO2-like matrix (128^3 grid, K = 839:
+    config 5's density) under a random symmetric permutation, as a file with its own numbering would deliver it.  The upload recovers
+    the grid from the star couplings and keeps P A P^T inside the handle (csrc/hip/reorder.hip); with the re-ordering switched off the
+    same arrays take dense blocks + pad-8.  Both measured here (20 products each), checked against scipy on the permuted arrays."""
+    import numpy as np
+    import scipy.sparse as sp
+    from gcge_amd.lib import CSR, make_problem
+    g = hip.g
+    G, K, m = 128, 839, 64
+    A0, _ = make_problem("sio2", G, K=K, R0=2.0, R1=5.0, seed=12345)
+    n, nnz = A0.nrows, int(A0.nnz)
+    S = sp.csr_matrix((np.ctypeslib.as_array(A0.val, shape=(nnz,)), np.ctypeslib.as_array(A0.colidx, shape=(nnz,)),
+                       np.ctypeslib.as_array(A0.rowptr, shape=(n + 1,))), shape=(n, n))
+    p = np.random.default_rng(20240601).permutation(n)
+    ip = np.empty(n, dtype=np.int32)
+    ip[p] = np.arange(n, dtype=np.int32)
+    Sp = S[p].tocsr()                      # rows in the new order ...
+    Sp.indices = ip[Sp.indices]            # ... columns renamed ...
+    Sp.has_sorted_indices = False
+    Sp.sort_indices()                      # ... ascending inside every row again
+    hip.h.gcge_csr_free(C.byref(A0))
+    rp, ci, va = (np.ascontiguousarray(Sp.indptr, dtype=np.int32), np.ascontiguousarray(Sp.indices, dtype=np.int32),
+                  np.ascontiguousarray(Sp.data, dtype=np.float64))
+    A = CSR(n, n, 0, nnz, rp.ctypes.data_as(C.POINTER(C.c_int)), ci.ctypes.data_as(C.POINTER(C.c_int)), va.ctypes.data_as(C.POINTER(C.c_double)))
+    g.gcge_hip_spmm_reorder_mode.argtypes = [C.c_int]
+    g.gcge_hip_mat_row_order.restype = C.c_char_p
+    g.gcge_hip_mat_row_order.argtypes = [C.c_void_p]
+    out = {}
+    xh = np.asfortranarray(np.random.default_rng(1).random((n, 2)) - 0.5)
+    for tag, mode in (("rows_as_given", -1), ("row_order_chosen_at_upload", 0)):
+        g.gcge_hip_spmm_reorder_mode(mode)
+        t0 = time.perf_counter()
+        mat = hip.matrix(A)
+        hip.sync()
+        up = time.perf_counter() - t0
+        r = k1_plain_leg(hip, mat, A, m, "SiO2-like %d^3 (K = %d, n=%d, nnz=%d) under a random symmetric permutation" % (G, K, n, nnz))
+        r["upload_seconds"] = up
+        r["row_order"] = g.gcge_hip_mat_row_order(mat).decode()
+        x = hip.mv_from_numpy(mat, xh)
+        y = hip.ops.mv_create(2, mat)
+        hip.ops.spmm(mat, x, y, (0, 0), (2, 2))
+        want = Sp @ xh
+        r["max_rel_err_vs_scipy"] = float(np.max(np.abs(hip.mv_to_numpy(y, n, 0, 2) - want)) / np.max(np.abs(want)))
+        hip.ops.mv_destroy(x, 2)
+        hip.ops.mv_destroy(y, 2)
+        hip.free_matrix(mat)
+        out[tag] = r
+    g.gcge_hip_spmm_reorder_mode(0)
+    res = out["row_order_chosen_at_upload"]
+    res["rows_as_given"] = {k: out["rows_as_given"][k] for k in ("kernel", "avg_launch_ms", "frac", "achieved", "upload_seconds", "max_rel_err_vs_scipy")}
+    return res
 
 
 def dropin_leg(hip, mat, args):
@@ -850,6 +904,7 @@ def main():
                 g.gcge_hip_pool_release()
                 return k1_c5_leg(hip, args)
             leg("roofline_k1_c5", k1c5)
+            leg("roofline_k1_permuted", lambda: k1_permuted_leg(hip, args))
         if c3 and world == 1 and not args.no_extra:
             leg("roofline_k1_spmm_A", lambda: k1_plain_leg(hip, mat, A, args.block, "stiffness matrix A (7-point stencil x h), config 3"))
             leg("roofline_k1_spmm_B", lambda: k1_plain_leg(hip, matB, Bc, args.block, "consistent mass matrix B (15-point stencil x h^3), config 3"))

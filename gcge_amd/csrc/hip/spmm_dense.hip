@@ -20,6 +20,7 @@
 // than a quarter of the joined rows are dropped again; blocks below 16 rows, 32 columns or 35 % fill are not formed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 #include <algorithm>
@@ -48,6 +49,8 @@ struct DenseMat {
   DenseSn* d_sn; DenseItem* d_items; int* d_rows; int* d_cols; double* d_vals;
   int* d_orp; int* d_pcol; double* d_pval; long noct;   // remainder, pad-8 form
   int* d_rowmap; int nlisted;                            // remainder given as a list of rows (gcge_hip_dense_build_rows); NULL: all rows
+  int* d_padlist; int npad;
+  int nlayers; int layer_item[9];                        // blocks of layer l: items [layer_item[l], layer_item[l + 1]); one launch per layer, in order                              // ... of them the rows whose remainder is NOT empty: what the pad-8 kernel walks (ADDING to Y)
   void* rem_tile;                                        // remainder in tile form (spmm_tile.hip) when that path is switched on
 };
 
@@ -59,10 +62,15 @@ struct DenseHost {
 
 // One wave per 32 rows of a block and pass of up to 64 columns.  (Two consecutive 32-row blocks per wave — 16 MFMAs per X row
 // fetched instead of 8 — was measured: 0.82 against 0.77 ms on the SiO2-like matrix; 216 VGPRs halve the waves per SIMD.)
-//   A fragment (values): lane l holds D[row 16 f + (l & 15)][column 4 g + (l >> 4)]   — stored in exactly this order
-//   B fragment (X rows): lane l holds X[C[4 g + (l >> 4)]][c0 + 16 cf + (l & 15)]
-//   accumulators:        lane l, register t of tile (f, cf): row 16 f + 4 t + (l >> 4), column c0 + 16 cf + (l & 15)
-//   FULL: m is a multiple of 64 — the four column fragments of a gather are one address plus immediate offsets.
+// Every load is 16 bytes per lane: the texture-address path charges an 8-byte load like a 16-byte one (spmm_pad8.hip), and with
+// 8-byte loads (two for the values, four for the X rows per column group: the round-4 form) eight waves asked a CU's L1 for 96 B per
+// clock — the kernel ran at the address path's rate, 47 TF, not at the MFMA's.  So the fragments are laid out for PAIRS:
+//   A fragment (values): lane l holds D[row 16 f + (l & 15)][column 4 g + (l >> 4)], f = 0, 1 — stored as that pair, one load
+//   B fragment (X rows): lane l holds X[C[4 g + (l >> 4)]][c0 + 4 (l & 15) + cf], cf = 0 .. 3 — 32 contiguous bytes, two loads;
+//                        the 16 lanes of a row cover its 512 bytes (MFMA column (l & 15) of fragment cf IS result column 4 (l & 15) + cf)
+//   accumulators:        lane l, register t of tile (f, cf): row 16 f + 4 t + (l >> 4), column c0 + 4 (l & 15) + cf — 32 contiguous bytes again
+//   FULL: m is a multiple of 64 (no column tests).
+typedef double v2dd __attribute__((ext_vector_type(2)));
 template <bool FULL>
 __global__ __launch_bounds__(256, FULL ? 3 : 2) void spmm_dense_kernel(
     const DenseItem* __restrict__ items, int nitems, const DenseSn* __restrict__ sns, const int* __restrict__ rows,
@@ -76,36 +84,37 @@ __global__ __launch_bounds__(256, FULL ? 3 : 2) void spmm_dense_kernel(
   const DenseSn S = sns[it.sn];
   const int li = lane & 15, kk = lane >> 4;
   const int ng = S.ng;
-  const double* __restrict__ vp = vals + S.val_off + (size_t)it.block * ng * 128 + lane;
+  const v2dd* __restrict__ vp = reinterpret_cast<const v2dd*>(vals + S.val_off + (size_t)it.block * ng * 128) + lane;
   const int* __restrict__ cp = cols + S.col_off + kk;
   const int* __restrict__ rp = rows + S.row_off + 32 * it.block;
   for (int c0 = 0; c0 < m; c0 += 64) {
-    const double* __restrict__ xb = x + c0 + li;
-    int xo[4];
-#pragma unroll
-    for (int cf = 0; cf < 4; ++cf) xo[cf] = FULL || c0 + 16 * cf + li < m ? 16 * cf : -(c0 + li);
+    // my four columns c0 + 4 li .. + 3 as two pairs; a pair past the end (m is even: a pair is in or out) re-reads column 0, never stored
+    const bool in0 = FULL || c0 + 4 * li < m, in1 = FULL || c0 + 4 * li + 2 < m;
+    const double* __restrict__ xb0 = x + (in0 ? c0 + 4 * li : 0);
+    const double* __restrict__ xb1 = x + (in1 ? c0 + 4 * li + 2 : 0);
     v4d acc[2][4];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int cf = 0; cf < 4; ++cf) acc[f][cf] = v4d{0.0, 0.0, 0.0, 0.0};
     // FOUR register sets, the loads three column groups ahead of the MFMAs that use them: the block values stream from HBM
-    // (read once, 1.7 GB on the SiO2-like matrix) and only two waves fit a SIMD (64 accumulator registers), so with ONE group of
-    // lookahead every group waited most of a memory round trip behind 8 MFMAs (0.72 ms = 37 TF; the gathers of the X rows are not
-    // what it waits for: profiles/r04_star/README.md).  ng is even (padded at upload); groups past the end are clamped re-reads
-    // whose MFMAs are skipped.
-    double a[4][2], b[4][4];
-    auto load = [&](double (&av)[2], double (&bv)[4], int g, int col) {
-      av[0] = vp[(size_t)g * 128]; av[1] = vp[(size_t)g * 128 + 64];
-      const double* __restrict__ xr = xb + (size_t)col * ldx;
-#pragma unroll
-      for (int cf = 0; cf < 4; ++cf) bv[cf] = FULL ? xr[16 * cf] : xr[xo[cf]];
+    // (read once, 1.7 GB on the SiO2-like matrix) and only two waves fit a SIMD (64 accumulator registers).  ng is even (padded at
+    // upload); groups past the end are clamped re-reads whose MFMAs are skipped.
+    v2dd a[4], b[4][2];
+    auto load = [&](v2dd& av, v2dd (&bv)[2], int g, int col) {
+      av = vp[(size_t)g * 64];
+      bv[0] = *reinterpret_cast<const v2dd*>(xb0 + (size_t)col * ldx);
+      bv[1] = *reinterpret_cast<const v2dd*>(xb1 + (size_t)col * ldx);
     };
-    auto mfma = [&](const double (&av)[2], const double (&bv)[4]) {
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int cf = 0; cf < 4; ++cf) acc[f][cf] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[f], bv[cf], acc[f][cf], 0, 0, 0);
+    auto mfma = [&](const v2dd& av, const v2dd (&bv)[2]) {
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv[0].x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv[0].y, acc[0][1], 0, 0, 0);
+      acc[0][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv[1].x, acc[0][2], 0, 0, 0);
+      acc[0][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv[1].y, acc[0][3], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv[0].x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv[0].y, acc[1][1], 0, 0, 0);
+      acc[1][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv[1].x, acc[1][2], 0, 0, 0);
+      acc[1][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv[1].y, acc[1][3], 0, 0, 0);
     };
     auto colof = [&](int g) { return cp[4 * min(g, ng - 1)]; };
     // column indices a whole round (four groups) ahead of the gathers that use them
@@ -133,24 +142,23 @@ __global__ __launch_bounds__(256, FULL ? 3 : 2) void spmm_dense_kernel(
       __builtin_amdgcn_sched_barrier(0);
       cA = nA; cB = nB; cC = nC; cD = nD;
     }
-    // Y[R] += block: every row belongs to one block only and the remainder kernel has finished (stream order)
+    // Y[R] += block: every row belongs to one block of this launch only and what wrote Y before has finished (stream order)
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int r = rp[16 * f + 4 * t + kk];
-#pragma unroll
-        for (int cf = 0; cf < 4; ++cf) {
-          const int c = c0 + 16 * cf + li;
-          if (r >= 0 && c < m) { double* q = y + (size_t)r * ldy + c; *q += acc[f][cf][t]; }
-        }
+        if (r < 0) continue;
+        double* q = y + (size_t)r * ldy + c0 + 4 * li;
+        if (in0) { v2dd* q0 = reinterpret_cast<v2dd*>(q); v2dd o = *q0; o.x += acc[f][0][t]; o.y += acc[f][1][t]; *q0 = o; }
+        if (in1) { v2dd* q1 = reinterpret_cast<v2dd*>(q + 2); v2dd o = *q1; o.x += acc[f][2][t]; o.y += acc[f][3][t]; *q1 = o; }
       }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ detection (host)
 static bool dense_build_host(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, int min_len,
-                             DenseHost* H) {
+                             DenseHost* H, int min_rows = 16) {
   std::vector<int> seeds;
   for (int r = 0; r < nrows; ++r) if (rowptr[r + 1] - rowptr[r] >= min_len) seeds.push_back(r);
   if (seeds.empty()) return false;
@@ -158,15 +166,21 @@ static bool dense_build_host(int nrows, int ncols_local, const int* rowptr, cons
   std::vector<int> assigned((size_t)nrows, -1), stamp((size_t)ncols_local, -1), pos((size_t)ncols_local, 0), cnt;
   std::vector<int> cand, R, C;
   int id = 0;
+  std::vector<int> C0;
   for (int r0 : seeds) {
     if (assigned[r0] != -1) continue;
-    const int n0 = rowptr[r0 + 1] - rowptr[r0];
+    // the candidate column set: the seed's columns AND its own index — the rows a sweep leaves come without their diagonal
+    // (spmm_star.hip takes it), so column r0 is missing from row r0 alone; without it every other row of the block kept ONE entry
+    // outside (a listed row per block row: 3.8e5 rows of 2 entries on the SiO2-like matrix)
+    C0.assign(colidx + rowptr[r0], colidx + rowptr[r0 + 1]);
+    // (a linear search: the columns of a slab's rows are ascending by GLOBAL index, not by the local one)
+    if (r0 < ncols_local && !getenv("GCGE_DENSE_NO_OWN_COLUMN") && std::find(C0.begin(), C0.end(), r0) == C0.end()) C0.push_back(r0);
+    const int n0 = (int)C0.size();
     ++id;
-    for (int q = rowptr[r0]; q < rowptr[r0 + 1]; ++q) stamp[colidx[q]] = id;
+    for (int c : C0) stamp[c] = id;
     // candidate rows: the rows whose index is a column of the seed (structural symmetry), not yet in a block
     R.clear();
-    for (int q = rowptr[r0]; q < rowptr[r0 + 1]; ++q) {
-      const int r = colidx[q];
+    for (int r : C0) {
       if (r >= nrows || assigned[r] != -1) continue;
       const int len = rowptr[r + 1] - rowptr[r];
       if (2 * len < min_len) continue;
@@ -174,15 +188,15 @@ static bool dense_build_host(int nrows, int ncols_local, const int* rowptr, cons
       for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) ov += stamp[colidx[p]] == id;
       if (2 * ov >= len && 4 * ov >= n0) R.push_back(r);
     }
-    if ((int)R.size() < 16) { assigned[r0] = -2; continue; }
+    if ((int)R.size() < min_rows) { assigned[r0] = -2; continue; }
     // columns of the seed that at least a quarter of the joined rows use
     C.clear(); cnt.assign((size_t)n0, 0);
-    for (int q = rowptr[r0]; q < rowptr[r0 + 1]; ++q) { pos[colidx[q]] = q - rowptr[r0]; }
+    for (int q = 0; q < n0; ++q) pos[C0[q]] = q;
     for (int r : R) for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) if (stamp[colidx[p]] == id) ++cnt[pos[colidx[p]]];
     long filled = 0;
-    for (int q = rowptr[r0]; q < rowptr[r0 + 1]; ++q)
-      if (4L * cnt[q - rowptr[r0]] >= (long)R.size()) { C.push_back(colidx[q]); filled += cnt[q - rowptr[r0]]; }
-      else stamp[colidx[q]] = -1;   // dropped
+    for (int q = 0; q < n0; ++q)
+      if (4L * cnt[q] >= (long)R.size()) { C.push_back(C0[q]); filled += cnt[q]; }
+      else stamp[C0[q]] = -1;   // dropped
     if ((int)C.size() < 32 || (double)filled < 0.35 * (double)R.size() * (double)C.size()) { assigned[r0] = -2; continue; }
     std::sort(R.begin(), R.end()); std::sort(C.begin(), C.end());
     const int sn = (int)H->sn.size();
@@ -201,7 +215,7 @@ static bool dense_build_host(int nrows, int ncols_local, const int* rowptr, cons
         const int c = colidx[p];
         if (stamp[c] != id) continue;
         const size_t k = (size_t)pos[c], g = k / 4, kq = k % 4;
-        D[((b * ng + g) * 2 + f) * 64 + kq * 16 + i] = val[p];
+        D[((b * ng + g) * 64 + kq * 16 + i) * 2 + f] = val[p];
         ++H->dense_nnz;
       }
     }
@@ -239,7 +253,11 @@ static bool dense_build_host(int nrows, int ncols_local, const int* rowptr, cons
 using namespace gcge;
 
 static int g_dense_mode = 0;     // 0 automatic, 1 rows of >= 24 entries may seed a block (tests), -1 never
+static int g_dense_layers = 4;      // launches of the block kernel at most (1: the round-4 form, every row in one block only)
+static int g_dense_layer_len = 32;  // rows of at least this many entries seed a block of a later layer
+extern "C" void gcge_hip_spmm_dense_layers(int layers, int seed_len) { g_dense_layers = layers >= 1 ? layers : 4; g_dense_layer_len = seed_len >= 24 ? seed_len : 32; }
 static int g_dense_min_len = 96;
+extern "C" void gcge_hip_spmm_dense_min_len(int len) { g_dense_min_len = len >= 24 ? len : 96; }   // rows of at least this many entries may seed a block
 extern "C" void gcge_hip_spmm_dense_mode(int mode) { g_dense_mode = mode; }
 extern "C" int gcge_hip_spmm_dense_mode_get(void) { return g_dense_mode; }
 
@@ -266,7 +284,7 @@ extern "C" long gcge_hip_dense_selfcheck(int nrows, int ncols_local, const int* 
       owner[r] = (int)s;
       const size_t b = ir / 32, f = (ir % 32) / 16, i = ir % 16;
       for (int k = 0; k < 4 * S.ng; ++k) {
-        const double v = H.vals[(size_t)S.val_off + ((b * S.ng + k / 4) * 2 + f) * 64 + (k % 4) * 16 + i];
+        const double v = H.vals[(size_t)S.val_off + ((b * S.ng + k / 4) * 64 + (k % 4) * 16 + i) * 2 + f];
         uint64_t bits; memcpy(&bits, &v, 8);
         if (bits != 0) got[r].emplace_back(H.cols[(size_t)S.col_off + k], v);
       }
@@ -298,6 +316,7 @@ extern "C" void gcge_hip_dense_free(void* dm) {
   hipFree(D->d_sn); hipFree(D->d_items); hipFree(D->d_rows); hipFree(D->d_cols); hipFree(D->d_vals);
   hipFree(D->d_orp); hipFree(D->d_pcol); hipFree(D->d_pval);
   if (D->d_rowmap) hipFree(D->d_rowmap);
+  if (D->d_padlist) hipFree(D->d_padlist);
   if (D->rem_tile) gcge_hip_tile_free(D->rem_tile);
   delete D;
 }
@@ -319,20 +338,55 @@ extern "C" void* gcge_hip_dense_build(int nrows, int ncols_local, const int* row
 // pad-8 part of the remainder then walks a list of the other rows only and leaves those rows of Y alone
 extern "C" void* gcge_hip_dense_build_rows(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val, const unsigned char* not_listed) {
   if (g_dense_mode < 0 || nrows <= 0) return nullptr;
+  if (const char* e = getenv("GCGE_DENSE_LAYERS")) g_dense_layers = atoi(e) >= 1 ? atoi(e) : g_dense_layers;   // (measurements / bisection)
   const int min_len = g_dense_mode == 1 ? 24 : g_dense_min_len;
   DenseHost H;
-  if (!dense_build_host(nrows, ncols_local, rowptr, colidx, val, min_len, &H)) return nullptr;
   const long nnz = rowptr[nrows];
-  if (g_dense_mode == 0 && 10 * H.dense_nnz < nnz) return nullptr;   // blocks hold less than a tenth of the matrix: not worth a second launch
+  bool blocks = dense_build_host(nrows, ncols_local, rowptr, colidx, val, min_len, &H);
+  if (blocks && not_listed == nullptr && g_dense_mode == 0 && 10 * H.dense_nnz < nnz) return nullptr;   // blocks hold less than a tenth of the matrix: not worth a second launch
+  if (!blocks) {
+    if (not_listed == nullptr) return nullptr;
+    // the rows a sweep leaves, and no block among them (a star with a few irregular rows, or none): all of it is the listed remainder
+    H = DenseHost();
+    H.rem_rowptr.assign(rowptr, rowptr + nrows + 1); H.rem_col.assign(colidx, colidx + nnz); H.rem_val.assign(val, val + nnz);
+  }
+  // LAYERS.  No row lies in two blocks of one launch (that is what makes Y[R] += block safe without atomics), so a row inside two
+  // overlapping atom balls leaves the entries of the second ball to the remainder: a few rows with hundreds of entries each, and the
+  // pad-8 list walks a row with ONE wave — on the SiO2-like matrix of config 5 the list's 4.9e6 non-zeros took 0.43 ms, all of it the
+  // tail of its longest rows.  The remainder is therefore searched again (shorter seeds, smaller row sets) and what it yields becomes a
+  // second, third ... launch of the block kernel, ordered behind the first by the stream: one owner per row and launch, still bit-reproducible.
+  std::vector<int> layer_item = {0, (int)H.items.size()};
+  if (blocks && g_dense_layers > 1) {
+    for (int l = 1; l < g_dense_layers && l < 8; ++l) {
+      DenseHost H2;
+      if (!dense_build_host(nrows, ncols_local, H.rem_rowptr.data(), H.rem_col.data(), H.rem_val.data(), g_dense_layer_len, &H2, 8)) break;
+      const int sn0 = (int)H.sn.size(), row0 = (int)H.rows.size(), col0 = (int)H.cols.size(); const long val0 = (long)H.vals.size();
+      for (DenseSn S : H2.sn) { S.row_off += row0; S.col_off += col0; S.val_off += val0; H.sn.push_back(S); }
+      for (DenseItem it : H2.items) { it.sn += sn0; H.items.push_back(it); }
+      H.rows.insert(H.rows.end(), H2.rows.begin(), H2.rows.end());
+      H.cols.insert(H.cols.end(), H2.cols.begin(), H2.cols.end());
+      H.vals.insert(H.vals.end(), H2.vals.begin(), H2.vals.end());
+      H.dense_nnz += H2.dense_nnz;
+      H.rem_rowptr.swap(H2.rem_rowptr); H.rem_col.swap(H2.rem_col); H.rem_val.swap(H2.rem_val);
+      layer_item.push_back((int)H.items.size());
+    }
+  }
   DenseMat* D = new DenseMat();
+  D->nlayers = (int)layer_item.size() - 1;
+  for (int l = 0; l <= D->nlayers; ++l) D->layer_item[l] = layer_item[l];
   D->nsn = (int)H.sn.size(); D->nitems = (int)H.items.size(); D->nrows = nrows;
   D->dense_entries = (long)H.vals.size(); D->dense_nnz = H.dense_nnz; D->rem_nnz = H.rem_rowptr[nrows];
   D->d_sn = to_device(H.sn); D->d_items = to_device(H.items); D->d_rows = to_device(H.rows); D->d_cols = to_device(H.cols);
   D->d_vals = to_device(H.vals);
   std::vector<double>().swap(H.vals);
   // remainder in pad-8 form: every row padded to a multiple of 8 entries with (own column, 0.0)
-  std::vector<int> list;
-  for (int r = 0; r < nrows; ++r) if (not_listed == nullptr || !not_listed[r]) list.push_back(r);
+  // With a list the remainder is ADDED to what the sweep wrote: rows whose remainder is empty (every entry inside their block: most
+  // rows of a block) are not walked at all — each would cost a read and a write of its Y row for nothing; `all` (every row that is
+  // not `not_listed`) stays the list of the column sums over those rows (gcge_hip_dense_row_list).
+  std::vector<int> list, all;
+  for (int r = 0; r < nrows; ++r)
+    if (not_listed == nullptr) list.push_back(r);
+    else if (!not_listed[r]) { all.push_back(r); if (H.rem_rowptr[r + 1] > H.rem_rowptr[r]) list.push_back(r); }
   const int nl = (int)list.size();
   std::vector<int> orp((size_t)nl + 1);
   size_t noct = 0;
@@ -347,8 +401,10 @@ extern "C" void* gcge_hip_dense_build_rows(int nrows, int ncols_local, const int
   }
   D->noct = (long)noct;
   D->d_orp = to_device(orp); D->d_pcol = to_device(pc); D->d_pval = to_device(pv);
-  D->nlisted = nl;
-  D->d_rowmap = not_listed != nullptr ? to_device(list) : nullptr;
+  D->nlisted = not_listed != nullptr ? (int)all.size() : nl;
+  D->d_rowmap = not_listed != nullptr ? to_device(all) : nullptr;
+  D->npad = nl;
+  D->d_padlist = not_listed != nullptr ? to_device(list) : nullptr;
   // (a listed remainder stays with the pad-8 kernel: a tile writes all of its rows)
   D->rem_tile = not_listed != nullptr ? nullptr : gcge_hip_tile_build_for(nrows, ncols_local, H.rem_rowptr.data(), H.rem_col.data(), H.rem_val.data(), 1);   // NULL: pad-8
   return D;
@@ -379,18 +435,23 @@ extern "C" int gcge_hip_dense_spmm(const void* dm, const double* d_x, long ldx, 
   if ((ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15) || d_x == d_y) return -1;
   const bool add = (which & 4) != 0 && D->d_rowmap != nullptr;
   which &= 3;
+  if (!add && D->d_rowmap != nullptr && which != 2) return -1;      // a listed remainder only ever adds (rows without a remainder are not walked)
   if (which != 2 && D->rem_tile != nullptr) {
     const int rc = gcge_hip_tile_spmm(D->rem_tile, d_x, ldx, d_y, ldy, ncols, stream);
     if (rc != 0) return rc;
-  } else if (which != 2 && D->nlisted > 0) {
-    gcge_hip_spmm_pad8_auto((double)D->noct / D->nlisted);
-    if (add) gcge_hip_spmm_pad8_row_map_add(D->d_rowmap); else gcge_hip_spmm_pad8_row_map(D->d_rowmap);
-    const int rc = gcge_hip_pad8_spmm(D->nlisted, D->d_orp, D->d_pcol, D->d_pval, d_x, ldx, d_y, ldy, ncols, stream);
+  } else if (which != 2 && D->npad > 0) {
+    gcge_hip_spmm_pad8_auto((double)D->noct / D->npad);
+    if (add) gcge_hip_spmm_pad8_row_map_add(D->d_padlist); else gcge_hip_spmm_pad8_row_map(nullptr);
+    const int rc = gcge_hip_pad8_spmm(D->npad, D->d_orp, D->d_pcol, D->d_pval, d_x, ldx, d_y, ldy, ncols, stream);
     gcge_hip_spmm_pad8_row_map(nullptr);
     if (rc != 0) return rc;
   }
-  if (which != 1 && D->nitems > 0)
-    hipLaunchKernelGGL((ncols % 64 == 0 ? spmm_dense_kernel<true> : spmm_dense_kernel<false>), dim3((unsigned)((D->nitems + 3) / 4)), dim3(256), 0, (hipStream_t)stream, D->d_items, D->nitems,
-                       D->d_sn, D->d_rows, D->d_cols, D->d_vals, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols);
+  if (which != 1)
+    for (int l = 0; l < D->nlayers; ++l) {
+      const int i0 = D->layer_item[l], ni = D->layer_item[l + 1] - i0;
+      if (ni <= 0) continue;
+      hipLaunchKernelGGL((ncols % 64 == 0 ? spmm_dense_kernel<true> : spmm_dense_kernel<false>), dim3((unsigned)((ni + 3) / 4)), dim3(256), 0, (hipStream_t)stream, D->d_items + i0, ni,
+                         D->d_sn, D->d_rows, D->d_cols, D->d_vals, d_x, (size_t)ldx, d_y, (size_t)ldy, ncols);
+    }
   return (int)hipGetLastError();
 }

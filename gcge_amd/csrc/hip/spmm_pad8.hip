@@ -55,7 +55,9 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 // the SpMM input): per-block partials go to dot_partial[blockIdx.x * m + j].  Blocks walk the row
 // chunks grid-stride (chunk = blockIdx.x, += gridDim.x): consecutive blocks still work on
 // consecutive chunks at the same time, and the number of partials stays small.
-template <int LPR, int BATCH, int ST, int DOT>
+// ACC = 1 (a list of rows ADDED to what another kernel wrote; rpw <= 4): the listed rows' Y values are requested when the wave
+// starts, beside the index loads — fetched at the end of each row they cost a memory round trip per row (short rows: the whole time).
+template <int LPR, int BATCH, int ST, int DOT, int ACC = 0>
 __global__ __launch_bounds__(256) void spmm_pad8_kernel(
     int nrows, const int* __restrict__ orp, const int* __restrict__ pcol,
     const double* __restrict__ pval, const double* __restrict__ x, size_t ldx,
@@ -99,6 +101,15 @@ __global__ __launch_bounds__(256) void spmm_pad8_kernel(
     }
   }
 
+  double yo0[4] = {0.0, 0.0, 0.0, 0.0}, yo1[4] = {0.0, 0.0, 0.0, 0.0};
+  if (ACC) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = rowmap[min(row0 + q, (long)nrows - 1)];
+      const double2 v = *reinterpret_cast<const double2*>(y + (size_t)rr * ldy + (act ? c0 : 0));
+      yo0[q] = v.x; yo1[q] = v.y;
+    }
+  }
   const long myend = 8L * orp[row0 + 1 + min(lane, nr - 1)];
   // positions are counted relative to the wave's first padded non-zero
   const long s = 8L * orp[row0];
@@ -118,7 +129,10 @@ __global__ __launch_bounds__(256) void spmm_pad8_kernel(
     if (G >= 8) { acc0 += shfl_xor_f64(acc0, 8); acc1 += shfl_xor_f64(acc1, 8); }      \
     if (act && g == 0) {                                                               \
       double* yq = rowmap != nullptr ? y + (size_t)rowmap[row0 + r] * ldy + c0 : yl + (size_t)r * ldy; \
-      if (accumulate) { const double2 yo = *reinterpret_cast<const double2*>(yq); acc0 += yo.x; acc1 += yo.y; }   /* Y += (a listed remainder on top of what another kernel wrote) */ \
+      if (ACC) {   /* Y += (a listed remainder on top of what another kernel wrote) */ \
+        acc0 += r == 0 ? yo0[0] : (r == 1 ? yo0[1] : (r == 2 ? yo0[2] : yo0[3]));         \
+        acc1 += r == 0 ? yo1[0] : (r == 1 ? yo1[1] : (r == 2 ? yo1[2] : yo1[3]));         \
+      } else if (accumulate) { const double2 yo = *reinterpret_cast<const double2*>(yq); acc0 += yo.x; acc1 += yo.y; } \
       store_row16<ST>(yq, acc0, acc1);                                                 \
     }                                                                                  \
     if (DOT) {                                                                         \
@@ -214,6 +228,8 @@ extern "C" void gcge_hip_spmm_pad8_tune(int rows_per_wave, int batch, int store_
   if (col_pass >= 0) g_p8_pass = col_pass;  // 0: widest pass that fits (<=128 columns)
 }
 
+static int g_p8_acc_early = 1;   // adding lists request their Y rows up front (0: at the end of each row, the round-4 form)
+extern "C" void gcge_hip_spmm_pad8_acc_early(int on) { g_p8_acc_early = on != 0; }
 static int g_p8_gridcap = 0;   // 0: one chunk per block
 extern "C" void gcge_hip_spmm_pad8_gridcap(int cap) { g_p8_gridcap = cap; }
 // optional per-XCD chunk schedule (device array of 8*len ints) valid for ONE rows-per-wave value
@@ -225,6 +241,13 @@ extern "C" void gcge_hip_spmm_pad8_schedule(const int* d_sched, int len, int row
 template <int LPR, int BATCH, int ST>
 static void p8_launch(int nrows, const int* orp, const int* pcol, const double* pval,
                       const double* x, size_t ldx, double* y, size_t ldy, int m, hipStream_t st) {
+  if (g_p8_accumulate && g_p8_rowmap != nullptr && g_p8_acc_early) {
+    const int rpw = g_p8_rpw < 4 ? g_p8_rpw : 4;
+    const long nch = ((long)nrows + 4 * rpw - 1) / (4 * rpw);
+    hipLaunchKernelGGL((spmm_pad8_kernel<LPR, BATCH, ST, 0, 1>), dim3((unsigned)nch), dim3(256), 0, st, nrows, orp, pcol, pval, x, ldx, y, ldy, m,
+                       rpw, nch, (double*)nullptr, (const int*)nullptr, 0, g_p8_rowmap, 1);
+    return;
+  }
   const unsigned rows_per_block = 4u * (unsigned)g_p8_rpw;
   const long nchunks = ((long)nrows + rows_per_block - 1) / rows_per_block;
   long grid = nchunks;
