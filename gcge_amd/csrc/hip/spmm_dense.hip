@@ -11,8 +11,10 @@
 // registers, an X row fetched for a k-step feeds 2 row fragments (32 rows), so the block's X rows cross L1 |R| / 32
 // times instead of |R| times, and the values stream through once for all (up to) 64 columns of a pass.
 // What does not belong to a block (the stencil part, rows near block borders) stays a CSR matrix — the REMAINDER —
-// and takes the pad-8 kernel first (Y = A_rem X); no row lies in two blocks, so the second launch adds into Y without
-// atomics and the result is bit-reproducible.
+// and takes the pad-8 kernel first (Y = A_rem X; under the plane sweep of spmm_star.hip: Y += over a LIST of the rows that have a
+// remainder at all); no row lies in two blocks of one launch, so the launches that follow add into Y without atomics and the result is
+// bit-reproducible.  Rows inside two overlapping atom balls get the second ball's entries from a second LAYER of blocks (a second
+// launch, found by searching the remainder again): see gcge_hip_dense_build_rows.
 //
 // Detection (host, O(nnz of the long rows)): seeds = rows of >= min_len entries, longest first; the seed's columns
 // are the candidate set C0; structural symmetry makes the rows whose INDEX lies in C0 the candidate rows; a
@@ -174,7 +176,7 @@ static bool dense_build_host(int nrows, int ncols_local, const int* rowptr, cons
     // outside (a listed row per block row: 3.8e5 rows of 2 entries on the SiO2-like matrix)
     C0.assign(colidx + rowptr[r0], colidx + rowptr[r0 + 1]);
     // (a linear search: the columns of a slab's rows are ascending by GLOBAL index, not by the local one)
-    if (r0 < ncols_local && !getenv("GCGE_DENSE_NO_OWN_COLUMN") && std::find(C0.begin(), C0.end(), r0) == C0.end()) C0.push_back(r0);
+    if (r0 < ncols_local && std::find(C0.begin(), C0.end(), r0) == C0.end()) C0.push_back(r0);
     const int n0 = (int)C0.size();
     ++id;
     for (int c : C0) stamp[c] = id;

@@ -14,9 +14,10 @@
 //     halo strips on each side are loaded from global memory one step ahead (64-byte segments, 4 lanes per row);
 //   * per step and patch 640 X rows are fetched for 256 results (2.5 x; the patch core of plane z + 6 and the arms of plane z),
 //     no matrix entry is read at all.
-// What is not clean — rows inside atom blocks, rows with any other entry — stays a CSR matrix (the remainder, every entry of
-// those rows) and takes the block / tile / pad-8 forms; the remainder is multiplied first (its pad-8 part is a LIST of the other rows,
-// gcge_hip_dense_build_rows: the clean rows are neither read nor written there), this kernel then writes the clean ones.  One result per row either way: bit-reproducible.
+// EVERY row takes star + diagonal from the sweep (star_build_host: A = S + D + R); what a row holds beyond that — the entries of the
+// atom blocks, a star entry that differs from the coefficient — is the REMAINDER R, a CSR matrix of those rows alone, ADDED to the
+// sweep's result by the kernels that follow it on the stream (dense blocks in layers + a pad-8 list, spmm_dense.hip).  One writer per
+// row and launch: bit-reproducible.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
