@@ -530,6 +530,8 @@ extern "C" int gcge_hip_mat_form_stats(const GCGE_HIP_MAT* A, double* out) {
   }
   return 1;
 }
+extern "C" int gcge_hip_star_masked_form(const void* sm);
+extern "C" int gcge_hip_mat_star_masked_form(const GCGE_HIP_MAT* A) { return A->star != nullptr ? gcge_hip_star_masked_form(A->star) : 0; }
 // the grid form (spmm_star.hip): out[0..5] = nx, ny, nz, arm length of the star, rows it multiplies, rows of the matrix.  0: none.
 extern "C" int gcge_hip_mat_star_stats(const GCGE_HIP_MAT* A, long* out) {
   if (A->star == nullptr) return 0;

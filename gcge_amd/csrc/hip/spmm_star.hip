@@ -50,6 +50,9 @@ struct StarMat {
   StarGeom g; int R; bool iso; long nclean, nrows; StarCoef c; double* d_diag; unsigned char* d_clean;   // d_clean[local row]: 1 = nothing but the star and a diagonal
   int* d_map;   // masked grids: d_map[box index] = row, -1 where the point is not a row (NULL: every grid point is a row)
   int* d_prange;   // masked grids: for every 16 x 16 patch the first / last + 1 plane in which it has rows   // d_diag[local row]: the row's diagonal entry, NaN: not a clean row
+  void* d_lines;   // masked grids whose lines are runs of rows: (base, xs | xe << 16) per line (y, z) — the third form (spmm_star3m_kernel); NULL: second form
+  int* d_prange3;  // ... and the plane ranges of its 16 x 8 patches
+  int* d_order3; int npatch3;   // ... and those of them that have rows, longest range first
 };
 
 // staging plan of a thread: unit u = tid + 1024 q, point u >> 2, 16-byte part u & 3
@@ -493,6 +496,215 @@ __global__ __launch_bounds__(1024) void spmm_star3_kernel(int nx, int ny, int zs
 #undef own
 #undef own_m
 
+// ---------------------------------------------------------------------------------------------- the third form on a masked grid
+// The points of a convex domain inside the box, numbered in scan order (x fastest): every grid LINE (y, z) is one run of rows, so
+//     row of point (x, y, z) = base(y, z) + x   for xs(y, z) <= x < xe(y, z),   no row elsewhere
+// and a table of (base, xs | xe << 16) per line replaces the point-wise map of the second form.  The waves are laid out so that
+// everything a wave touches in one request lies on ONE line — its own 8 points (a wave is half a patch line), and each of its three
+// DMA pieces (a side strip of one patch line: 6 points, 48 of the 64 lanes; half a line of the top / bottom strips: 8 points) —
+// hence every lookup is wave-uniform: a SCALAR load (s_load_dwordx2, the scalar cache, lgkmcnt), no vector register, no entry in
+// the vmcnt queue the hand-counted waits of the third form rely on.  40 pieces per plane instead of 36 (the side strips take a
+// piece per line); lanes without a row request row 0 and are masked when the strips are copied into the plane image, as before.
+struct StarLine { int base; int xr; };            // xr = xs | xe << 16; an empty line: 0
+constexpr int STAR3M_ZLO = STAR_R, STAR3M_ZHI = STAR_R + 3, STAR3M_YLO = STAR_R, STAR3M_YHI = STAR3_TY + STAR_R;   // guard lines of the table
+constexpr int STAR3M_PIECES = 40;
+constexpr int STAR3M_RING = STAR3M_PIECES * 64;                              // v2d entries of one strip buffer (40 960 B)
+constexpr unsigned STAR3M_LDS = (STAR3_IMG + 2 * STAR3M_RING) * 16;          // 153 600 B
+__device__ __forceinline__ void star3_dma64(const void* addr, unsigned lds_dst) {   // one piece: lane l -> lds_dst + 16 l, 64-bit lane addresses
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(addr), "s"(lds_dst) : "memory");
+}
+#define S3SLOT(U, k) (((U) + (k) + STAR_R + 2 * STAR3_Q) % STAR3_Q)
+template <bool DOT>
+__global__ __launch_bounds__(1024) void spmm_star3m_kernel(int nx, int ny, int nz, StarCoef cf, const double* __restrict__ diag,
+    const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols, int zlo, int zhi, int zlen, int ntx,
+    double* __restrict__ partial, const unsigned char* __restrict__ cleanf, const unsigned long long* __restrict__ lines,
+    const int* __restrict__ prange, const int* __restrict__ order) {
+  constexpr int LPP = STAR3_LPP, TY = STAR3_TY;
+  const unsigned ldx32 = (unsigned)ldx;                                   // (< 2^31: checked on the host) row * ldx in one v_mad_u64_u32
+  const int nyp = ny + STAR3M_YLO + STAR3M_YHI;
+  extern __shared__ __align__(16) unsigned char star3_smem[];
+  v2d* img = reinterpret_cast<v2d*>(star3_smem);
+  v2d* ring = img + STAR3_IMG;
+  const unsigned ring0 = (unsigned)(uintptr_t)ring;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // a wave is half a patch line: lane l is point 8 (wave & 1) + (l >> 3) of line wave >> 1, part l & 7 — what depends on the wave is
+  // kept in scalar registers and added where it is used (there is no vector register to spare: 128 of 128)
+  const int part = lane & 7, pt = lane >> 3;
+  const int py = wave >> 1, pxs = 8 * (wave & 1);
+  // workgroup -> patch: the patches that have rows at all, LONGEST z range first (the upload sorts them) — the patches of a ball
+  // differ in length by the chord of the sphere, and in launch order the last workgroups to start were among the longest
+  unsigned bq, by, bz;
+  star_block_of(0, bq, by, bz);
+  const int bx = order[bq];
+  const int tile_x = bx % ntx, tile_y = bx / ntx;
+  const int x0 = tile_x * STAR_T, y0 = tile_y * TY;
+  const int z0 = max(zlo + (int)by * zlen, prange[2 * bx]);
+  const int z1 = min(min(zhi, zlo + ((int)by + 1) * zlen), prange[2 * bx + 1]);
+  const int c0 = 2 * LPP * bz;
+  const bool cvalid = c0 + 2 * part < ncols;
+  const int col = cvalid ? c0 + 2 * part : c0;
+  if (z0 >= z1) {                                                         // nothing of this patch in this z range (uniform, before any barrier)
+    if (DOT && tid < LPP && c0 + 2 * tid < ncols) {
+      double* out = partial + ((size_t)bq + (size_t)gridDim.x * by) * 2 * ncols;
+      out[c0 + 2 * tid] = 0.0; out[c0 + 2 * tid + 1] = 0.0; out[ncols + c0 + 2 * tid] = 0.0; out[ncols + c0 + 2 * tid + 1] = 0.0;
+    }
+    return;
+  }
+  const int gxs = x0 + pxs, gy = y0 + py;                                 // my point: (gxs + pt, gy)
+  const int gx = gxs + pt;
+  const bool inside = gx < nx && cvalid;
+  const int sbase = ((py + STAR_R) * STAR_PW + (pxs + STAR_R)) * LPP;     // my slot of the plane image: sbase + lane
+  const int slot = sbase + lane;
+  // the line (yy, zz) — wave-uniform arguments.  The table carries empty guard lines round the box (STAR3M_ZLO planes below, _ZHI
+  // above, _YLO / _YHI lines): whatever a step asks for is one 8-byte scalar load, no clamp, no select
+  auto line_at = [&](int zz, int yy) -> StarLine {
+    const unsigned long long raw = lines[(size_t)(zz + STAR3M_ZLO) * nyp + (yy + STAR3M_YLO)];
+    return StarLine{(int)(unsigned)raw, (int)(unsigned)(raw >> 32)};
+  };
+  auto on_line = [&](const StarLine& L, int xx) -> bool { return xx >= (L.xr & 0xffff) && xx < (L.xr >> 16); };
+  // my three pieces: 0 = a side strip of patch line wave / 2 (left: even waves), 1 and 2 = halves of the lines above / below.
+  // Lane l of a piece is point l >> 3 of it, part l & 7: everything else about a piece is wave-uniform (scalar registers) —
+  //   hya: its line's y in the grid, hxa: the x of its first point, hu: where its first point sits in the plane image, hld: in a strip buffer
+  int hya[3], hxa[3], hu[3]; unsigned hld[3];
+  {
+    const int q1 = wave, q2 = 16 + (wave & 7);                            // (waves 8 .. 15 repeat pieces 32 .. 39: every wave issues exactly three)
+    const int d1 = q1 >> 1, d2 = q2 >> 1;
+    const int hy0 = wave >> 1, hy1 = d1 < 6 ? d1 - 6 : d1 + 2, hy2 = d2 < 6 ? d2 - 6 : d2 + 2;
+    const int hx0 = (wave & 1) ? STAR_T : -STAR_R, hx1 = 8 * (q1 & 1), hx2 = 8 * (q2 & 1);
+    hya[0] = y0 + hy0; hya[1] = y0 + hy1; hya[2] = y0 + hy2;
+    hxa[0] = x0 + hx0; hxa[1] = x0 + hx1; hxa[2] = x0 + hx2;
+    hu[0] = ((hy0 + STAR_R) * STAR_PW + (hx0 + STAR_R)) * LPP; hu[1] = ((hy1 + STAR_R) * STAR_PW + (hx1 + STAR_R)) * LPP; hu[2] = ((hy2 + STAR_R) * STAR_PW + (hx2 + STAR_R)) * LPP;
+    hld[0] = (unsigned)wave * 64u; hld[1] = (unsigned)(16 + q1) * 64u; hld[2] = (unsigned)(16 + q2) * 64u;   // (v2d units)
+  }
+  auto ld_own = [&](int zz, const StarLine& L) -> v2d {
+    const bool ok = inside && on_line(L, gx);
+    const int row = ok ? L.base + gx : 0;
+    return star2_and(*reinterpret_cast<const v2d*>(x + ((size_t)(unsigned)row * ldx32 + col)), ok ? ~0ull : 0ull);
+  };
+  auto ld_diag = [&](int zz, const StarLine& L) -> double {
+    const bool ok = inside && on_line(L, gx) && zz < z1;
+    const int row = ok ? L.base + gx : 0;
+    unsigned long long b = __builtin_bit_cast(unsigned long long, diag[row]);
+    const unsigned long long m = ok ? ~0ull : 0ull;
+    b = (b & m) | (0x7ff8000000000000ull & ~m);
+    return __builtin_bit_cast(double, b);
+  };
+  // (the flag is requested and the sums are formed without DOT as well: hipcc's register allocation of the leaner variant spilled
+  //  four vector registers, and a scratch access is a vector-memory operation the hand-counted waits do not know)
+  auto ld_clean = [&](int zz, const StarLine& L) -> int {
+    const bool ok = inside && on_line(L, gx) && zz < z1;
+    return (int)cleanf[ok ? L.base + gx : 0];
+  };
+  // the three pieces of a plane into strip buffer `sl`; L: the lines they lie on in that plane
+  auto dma_plane = [&](int sl, const StarLine (&L)[3]) {
+    const unsigned dst = ring0 + (unsigned)sl * (STAR3M_RING * 16);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int ax = hxa[j] + pt;
+      const int row = on_line(L[j], ax) ? L[j].base + ax : 0;
+      star3_dma64(x + ((size_t)(unsigned)row * ldx32 + col), dst + hld[j] * 16u);
+    }
+  };
+  auto copy_strips = [&](int sl, const StarLine (&L)[3]) {
+    const v2d* src = ring + sl * STAR3M_RING + lane;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const v2d v = src[hld[j]];
+      const bool ok = cvalid && on_line(L[j], hxa[j] + pt);
+      if (j > 0 || pt < STAR_R) img[hu[j] + lane] = star2_and(v, ok ? ~0ull : 0ull);   // (lanes 48 .. 63 of a side piece carry nothing)
+    }
+  };
+  // ---- prologue
+  v2d qv[STAR3_Q];
+#pragma unroll
+  for (int t = 0; t < STAR3_Q - 1; ++t) { const StarLine L = line_at(z0 - STAR_R + t, gy); qv[t] = ld_own(z0 - STAR_R + t, L); }
+  qv[STAR3_Q - 1] = v2d{0.0, 0.0};
+  { const StarLine La[3] = {line_at(z0, hya[0]), line_at(z0, hya[1]), line_at(z0, hya[2])};
+    const StarLine Lb[3] = {line_at(z0 + 1, hya[0]), line_at(z0 + 1, hya[1]), line_at(z0 + 1, hya[2])};
+    dma_plane(0, La);
+    dma_plane(1, Lb); }
+  double dg3[3]; int cl3[3];
+  { const StarLine L0 = line_at(z0, gy), L1 = line_at(z0 + 1, gy);
+    dg3[0] = ld_diag(z0, L0); dg3[1] = ld_diag(z0 + 1, L1); dg3[2] = 0.0;
+    cl3[0] = ld_clean(z0, L0); cl3[1] = ld_clean(z0 + 1, L1); cl3[2] = 0; }
+  v2d spw = v2d{0.0, 0.0}, sww = v2d{0.0, 0.0};
+  star3_vmwait<0>();
+  __syncthreads();
+
+  for (int zb = z0; zb < z1; zb += STAR3_Q) {
+#define STAR3M_STEP(U)                                                                                                      \
+    {                                                                                                                       \
+      const int z = zb + (U);                                                                                               \
+      if (z >= z1) break;                                                                                                   \
+      const int sl = (z - z0) & 1;                                                                                          \
+      /* the step's lookups first (scalar loads: their latency passes behind the wait and the copy): the lines of my pieces in  \
+         plane z (masks of the copy) and z + 2 (the next request), of my own point in z (the row of Y), z + 2 and z + 8 */     \
+      const StarLine Lc[3] = {line_at(z, hya[0]), line_at(z, hya[1]), line_at(z, hya[2])};                                  \
+      const StarLine Ln[3] = {line_at(z + 2, hya[0]), line_at(z + 2, hya[1]), line_at(z + 2, hya[2])};                      \
+      const StarLine L0 = line_at(z, gy), L2 = line_at(z + 2, gy), L8 = line_at(z + STAR_R + 2, gy);                        \
+      if ((U) == 0 && zb == z0) { /* (the prologue waited for everything) */ }                                              \
+      else star3_vmwait<9>();                            /* as in the third form: 3 pieces + own + diagonal + flag per step */ \
+      copy_strips(sl, Lc);                                                                                                  \
+      img[slot] = qv[S3SLOT(U, 0)];                                                                                         \
+      __syncthreads();                                                                                                      \
+      dma_plane(sl, Ln);                                                                                                    \
+      qv[S3SLOT(U, STAR_R + 2)] = ld_own(z + STAR_R + 2, L8);                                                               \
+      dg3[((U) + 2) % 3] = ld_diag(z + 2, L2);                                                                              \
+      cl3[((U) + 2) % 3] = ld_clean(z + 2, L2);                                                                             \
+      const double dg = dg3[(U) % 3];                                                                                       \
+      const int cl = cl3[(U) % 3];                                                                                          \
+      const double d0 = dg == dg ? dg : 0.0;                                                                                \
+      v2d acc = qv[S3SLOT(U, 0)] * d0;                                                                                      \
+      const v2d* pl = img + slot;                                                                                           \
+      _Pragma("unroll") for (int k = 1; k <= STAR_R; ++k) {                                                                 \
+        const v2d zsum = qv[S3SLOT(U, -k)] + qv[S3SLOT(U, k)];                                                              \
+        const v2d xsum = pl[-LPP * k] + pl[LPP * k];                                                                        \
+        const v2d ysum = pl[-LPP * k * STAR_PW] + pl[LPP * k * STAR_PW];                                                    \
+        const v2d s6 = (zsum + xsum) + ysum;                                                                                \
+        acc.x = fma(cf.cz[k], s6.x, acc.x); acc.y = fma(cf.cz[k], s6.y, acc.y);                                              \
+      }                                                                                                                     \
+      if (dg == dg) {                                                                                                       \
+        const size_t yrow = (size_t)(unsigned)(L0.base + gx);                                                               \
+        __builtin_nontemporal_store(acc, reinterpret_cast<v2d*>(y + yrow * ldy + col));                                     \
+        if (cl != 0) {                        /* (without DOT the sums are formed and dropped: see ld_clean) */              \
+          const v2d xc = qv[S3SLOT(U, 0)];                                                                                  \
+          spw.x = fma(xc.x, acc.x, spw.x); spw.y = fma(xc.y, acc.y, spw.y);                                                  \
+          sww.x = fma(acc.x, acc.x, sww.x); sww.y = fma(acc.y, acc.y, sww.y);                                                \
+        }                                                                                                                   \
+      }                                                                                                                     \
+      __syncthreads();                                                                                                      \
+    }
+    STAR3M_STEP(0) STAR3M_STEP(1) STAR3M_STEP(2) STAR3M_STEP(3) STAR3M_STEP(4) STAR3M_STEP(5) STAR3M_STEP(6) STAR3M_STEP(7)
+    STAR3M_STEP(8) STAR3M_STEP(9) STAR3M_STEP(10) STAR3M_STEP(11) STAR3M_STEP(12) STAR3M_STEP(13) STAR3M_STEP(14)
+#undef STAR3M_STEP
+  }
+  star3_vmwait<0>();                                     // no piece may land after the block has released its LDS
+  if (!DOT) asm volatile("" : : "v"(spw.x), "v"(spw.y), "v"(sww.x), "v"(sww.y));
+  if (DOT) {
+    __syncthreads();
+    const int t2 = 64 * wave + lane;                     // (= threadIdx.x, rebuilt: not kept in a register through the sweep)
+    img[t2] = spw; img[1024 + t2] = sww;
+    __syncthreads();
+    const int pidx = t2 / LPP;
+    for (int h = 512 / LPP; h > 0; h >>= 1) {
+      if (pidx < h) {
+        const v2d a = img[t2 + LPP * h], b = img[1024 + t2 + LPP * h];
+        img[t2].x += a.x; img[t2].y += a.y; img[1024 + t2].x += b.x; img[1024 + t2].y += b.y;
+      }
+      __syncthreads();
+    }
+    if (pidx == 0 && cvalid) {
+      double* out = partial + ((size_t)bq + (size_t)gridDim.x * by) * 2 * ncols;
+      out[col] = img[t2].x; out[col + 1] = img[t2].y;
+      out[ncols + col] = img[1024 + t2].x; out[ncols + col + 1] = img[1024 + t2].y;
+    }
+  }
+}
+#undef S3SLOT
+
 // partial[b * 2 m + j] = sum over the block's listed rows of x[r, j] y[r, j]; at + m: of y[r, j]^2 (rows = list[i]); 256 threads =
 // 4 row lanes x 64 columns, as coldots2_partial of vec_kernels.hip
 __global__ __launch_bounds__(256) void star_coldots2_rows(int nlist, const int* __restrict__ list, const double* __restrict__ x, size_t ldx,
@@ -882,6 +1094,10 @@ static int g_star_infer = 1;  // 1: a matrix without a lexicographic grid is tri
 extern "C" void gcge_hip_spmm_star_infer(int on) { g_star_infer = on != 0; }
 static int g_star_form = 3;   // 2: second form of the sweep (registers stage the halo strips), 3: third form (LDS-DMA strips, 16-column passes)
 extern "C" void gcge_hip_spmm_star_form(int form) { g_star_form = form == 3 ? 3 : 2; }
+static int g_star_masked_zchunks = 0;  // masked third form: z ranges per patch (0: the rule of the other forms)
+extern "C" void gcge_hip_spmm_star_masked_zchunks(int n) { g_star_masked_zchunks = n; }
+static int g_star_masked_third = 1;   // masked grids with a line table take the third form (0: the second form with its point-wise map, round 4)
+extern "C" void gcge_hip_spmm_star_masked_third(int on) { g_star_masked_third = on != 0; }
 static int g_star_lpp = 4;    // second form: 8 = 16-column passes on 16 x 8 patches (128-byte pieces of the rows), 4 = 8 columns on 16 x 16 (64-byte pieces)
 extern "C" void gcge_hip_spmm_star_lanes(int lpp) { g_star_lpp = lpp == 4 ? 4 : 8; }
 static int g_star_xcd = 22;   // 0: workgroups in launch order; 1 / G >= 2: XCD-aware orders (star_block_of): runs of 22 patches (two patch rows of the 171^2 plane) per XCD are 2 % faster than launch order (2.78 against 2.84 ms, profiles/r04_star/16, gpurun_out/r5/09)
@@ -1001,6 +1217,7 @@ extern "C" void gcge_hip_star_free(void* sm) {
   if (!S) return;
   hipFree(S->d_diag); hipFree(S->d_clean);
   if (S->d_map) { hipFree(S->d_map); hipFree(S->d_prange); }
+  if (S->d_lines) { hipFree(S->d_lines); hipFree(S->d_prange3); hipFree(S->d_order3); }
   delete S;
 }
 
@@ -1037,7 +1254,7 @@ extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin,
   }
   if (!ok) { delete H; return nullptr; }
   StarMat* S = new StarMat();
-  S->d_map = nullptr; S->d_prange = nullptr;
+  S->d_map = nullptr; S->d_prange = nullptr; S->d_lines = nullptr; S->d_prange3 = nullptr; S->d_order3 = nullptr; S->npatch3 = 0;
   if (M.box != nullptr) {
     GCGE_HIP_CHECK(hipMalloc(&S->d_map, H->inv.size() * sizeof(int)));
     GCGE_HIP_CHECK(hipMemcpy(S->d_map, H->inv.data(), H->inv.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1051,10 +1268,39 @@ extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin,
     }
     GCGE_HIP_CHECK(hipMalloc(&S->d_prange, pr.size() * sizeof(int)));
     GCGE_HIP_CHECK(hipMemcpy(S->d_prange, pr.data(), pr.size() * sizeof(int), hipMemcpyHostToDevice));
+    // the line table of the third form: every grid line one run of rows (scan order: row = base + x), box edges below 65536
+    const int nyp = ny + STAR3M_YLO + STAR3M_YHI, nzp = nz + STAR3M_ZLO + STAR3M_ZHI;
+    std::vector<StarLine> ln((size_t)nyp * nzp, StarLine{0, 0});
+    bool runs = nx < 32768 && nrows > 0;
+    const int nty8 = (ny + STAR3_TY - 1) / STAR3_TY;
+    std::vector<int> pr3((size_t)2 * ntx * nty8);
+    for (int p = 0; p < ntx * nty8; ++p) { pr3[2 * p] = nz; pr3[2 * p + 1] = 0; }
+    for (int r = 0; r < nrows && runs; ++r) {
+      const long b = M.box[r];
+      const int z = (int)(b / ((long)nx * ny)), y = (int)((b / nx) % ny), x = (int)(b % nx);
+      StarLine& L = ln[(size_t)(z + STAR3M_ZLO) * nyp + (y + STAR3M_YLO)];
+      if (L.xr == 0) { L.base = r - x; L.xr = x | (x + 1) << 16; }
+      else if (r - x == L.base && x == (L.xr >> 16)) L.xr = (L.xr & 0xffff) | (x + 1) << 16;
+      else runs = false;                                                 // a hole in the line: the point-wise map of the second form
+      const int p = (y / STAR3_TY) * ntx + x / STAR_T;
+      pr3[2 * p] = std::min(pr3[2 * p], z); pr3[2 * p + 1] = std::max(pr3[2 * p + 1], z + 1);
+    }
+    if (runs) {
+      GCGE_HIP_CHECK(hipMalloc(&S->d_lines, ln.size() * sizeof(StarLine)));
+      GCGE_HIP_CHECK(hipMemcpy(S->d_lines, ln.data(), ln.size() * sizeof(StarLine), hipMemcpyHostToDevice));
+      GCGE_HIP_CHECK(hipMalloc(&S->d_prange3, pr3.size() * sizeof(int)));
+      GCGE_HIP_CHECK(hipMemcpy(S->d_prange3, pr3.data(), pr3.size() * sizeof(int), hipMemcpyHostToDevice));
+      std::vector<int> ord;
+      for (int p = 0; p < ntx * nty8; ++p) if (pr3[2 * p + 1] > pr3[2 * p]) ord.push_back(p);
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return pr3[2 * a + 1] - pr3[2 * a] > pr3[2 * b + 1] - pr3[2 * b]; });
+      S->npatch3 = (int)ord.size();
+      GCGE_HIP_CHECK(hipMalloc(&S->d_order3, std::max<size_t>(ord.size(), 1) * sizeof(int)));
+      GCGE_HIP_CHECK(hipMemcpy(S->d_order3, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
   }
   S->g = H->g; S->R = H->R; S->nclean = H->nclean; S->nrows = nrows; S->c = H->c;
   S->iso = memcmp(H->c.cx, H->c.cy, sizeof(H->c.cx)) == 0 && memcmp(H->c.cx, H->c.cz, sizeof(H->c.cx)) == 0;
-  if (S->d_map != nullptr && !S->iso) { hipFree(S->d_map); hipFree(S->d_prange); delete S; delete H; return nullptr; }   // (masked grids: the one-coefficient-set kernel only)
+  if (S->d_map != nullptr && !S->iso) { hipFree(S->d_map); hipFree(S->d_prange); if (S->d_lines) { hipFree(S->d_lines); hipFree(S->d_prange3); hipFree(S->d_order3); } delete S; delete H; return nullptr; }   // (masked grids: the one-coefficient-set kernel only)
   GCGE_HIP_CHECK(hipMalloc(&S->d_diag, (size_t)nrows * sizeof(double)));
   GCGE_HIP_CHECK(hipMemcpy(S->d_diag, H->diag.data(), (size_t)nrows * sizeof(double), hipMemcpyHostToDevice));
   std::vector<double>().swap(H->diag);
@@ -1069,6 +1315,12 @@ extern "C" void gcge_hip_star_release_remainder(void) { if (g_star_last) { delet
 
 extern "C" const unsigned char* gcge_hip_star_host_mask(void) {   // 1: a star row (valid until gcge_hip_star_release_remainder)
   return g_star_last ? (const unsigned char*)g_star_last->clean.data() : nullptr;
+}
+// 0: every grid point is a row; 2 / 3: a masked grid swept by the second (point-wise row map) / third form (line table, LDS-DMA strips)
+extern "C" int gcge_hip_star_masked_form(const void* sm) {
+  const StarMat* S = (const StarMat*)sm;
+  if (S->d_map == nullptr) return 0;
+  return (g_star_form == 3 && S->iso && S->d_lines != nullptr && g_star_masked_third) ? 3 : 2;
 }
 extern "C" void gcge_hip_star_stats(const void* sm, long* out) {   // nx, ny, nz, arm length, clean rows, rows, first / last + 1 plane of the slab
   const StarMat* S = (const StarMat*)sm;
@@ -1099,18 +1351,22 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
   const bool mapped = S->d_map != nullptr;
   // third form (LDS-DMA strips, two planes of prefetch): one coefficient set, every grid point a row, lane offsets of a plane in 32 bits
   const bool third = g_star_form == 3 && iso && !mapped && (double)g.nx * g.ny * (double)ldx * 8.0 < 4.0e9;
-  const int lpp = third ? 8 : (!iso || mapped || g_star_lpp == 4) ? 4 : 8;   // (per-axis coefficients / masked grids: the 8-column form, which needs fewer registers)
+  // ... and on a masked grid with a line table (spmm_star3m_kernel: 64-bit lane addresses, no size limit)
+  const bool third_m = g_star_form == 3 && iso && mapped && S->d_lines != nullptr && g_star_masked_third && ldx < (1L << 31);
+  const int lpp = (third || third_m) ? 8 : (!iso || mapped || g_star_lpp == 4) ? 4 : 8;   // (per-axis coefficients / masked grids: the 8-column form, which needs fewer registers)
   const int ty = 64 / lpp;
   const int ntx = (g.nx + STAR_T - 1) / STAR_T, nty = (g.ny + ty - 1) / ty, npass = (ncols + 2 * lpp - 1) / (2 * lpp);
   // z ranges: ONE where the patches x passes already give every CU two workgroups' worth of work (each range re-reads 12 planes
   // of warm-up: 171^3, 64 columns: 1 / 2 / 3 / 4 ranges = 3.93 / 4.26 / 4.35 / 4.47 ms for the whole product), otherwise enough
   // ranges of at least 24 planes to get there
   int zchunks = (int)std::max(1L, std::min((long)nzl / 24, (2L * 256 + (long)ntx * nty * npass - 1) / ((long)ntx * nty * npass)));
+  if (third_m && g_star_masked_zchunks > 0) zchunks = std::max(1, std::min(g_star_masked_zchunks, nzl / 24));
   const int zlen = (nzl + zchunks - 1) / zchunks;
   zchunks = (nzl + zlen - 1) / zlen;
-  const int nb = ntx * nty * zchunks;
-  if (count_only) return nb;
-  const dim3 grid((unsigned)(ntx * nty), (unsigned)zchunks, (unsigned)npass);
+  const int npatch = third_m ? S->npatch3 : ntx * nty;                 // (masked third form: only the patches that have rows)
+  const int nb = npatch * zchunks;
+  if (count_only || nb == 0) return nb;
+  const dim3 grid((unsigned)npatch, (unsigned)zchunks, (unsigned)npass);
   // operands in global plane numbering (see the kernel): the slab's first plane is plane zs of the grid
   const long shift = g.mid_off;                                       // = - plane_rows * zs
   const double* xv = (const double*)((uintptr_t)d_x + (uintptr_t)(shift * ldx * (long)sizeof(double)));
@@ -1147,6 +1403,20 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
     if (dot) { if (slab) STAR_LAUNCH3(true, true); else STAR_LAUNCH3(true, false); }
     else     { if (slab) STAR_LAUNCH3(false, true); else STAR_LAUNCH3(false, false); }
 #undef STAR_LAUNCH3
+    return nb;
+  }
+  if (third_m) {
+    static bool attr_m = false;
+    if (!attr_m) {
+      bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_star3m_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STAR3M_LDS) == hipSuccess;
+      ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_star3m_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STAR3M_LDS) == hipSuccess;
+      if (!ok) { (void)hipGetLastError(); fprintf(stderr, "gcge_hip: %u bytes of LDS refused for the third form of the sweep (masked grids)\n", STAR3M_LDS); abort(); }
+      attr_m = true;
+    }
+    if (dot) hipLaunchKernelGGL((spmm_star3m_kernel<true>), grid, dim3(1024), STAR3M_LDS, stream, g.nx, g.ny, g.nz, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy,
+                                ncols, zlo, zhi, zlen, ntx, part, (const unsigned char*)S->d_clean, (const unsigned long long*)S->d_lines, (const int*)S->d_prange3, (const int*)S->d_order3);
+    else     hipLaunchKernelGGL((spmm_star3m_kernel<false>), grid, dim3(1024), STAR3M_LDS, stream, g.nx, g.ny, g.nz, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy,
+                                ncols, zlo, zhi, zlen, ntx, part, (const unsigned char*)S->d_clean, (const unsigned long long*)S->d_lines, (const int*)S->d_prange3, (const int*)S->d_order3);
     return nb;
   }
   if (mapped) {          // masked grid: one rank, one coefficient set (checked at upload)

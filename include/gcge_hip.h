@@ -262,6 +262,16 @@ int  gcge_hip_star_infer_grid (int nrows, const int *rowptr, const int *colidx, 
 int  gcge_hip_star_grid (int nrows, long row_begin, long nglobal, const int *rowptr, const int *colidx_global,
 		const double *val, long *out);
 int  gcge_hip_mat_star_stats (const GCGE_HIP_MAT *A, long *out /* nx, ny, nz, arm length, star rows, rows, first / last + 1 plane of the slab */);   /* 0: the matrix has no grid form */
+/* masked grids (gcge_hip_mat_create_grid, or a geometry recovered at upload): 3 = swept by the third form through a LINE table (every
+ * grid line one run of rows), 2 = by the second form through a point-wise row map, 0 = every grid point is a row / no grid form.
+ * gcge_hip_spmm_star_masked_third(0) keeps the second form (measurements).                                            */
+int  gcge_hip_mat_star_masked_form (const GCGE_HIP_MAT *A);
+void gcge_hip_spmm_star_masked_third (int on);
+/* K1 block form: rows of at least `len` entries seed a dense block (default 96); at most `layers` launches of the block kernel (rows
+ * inside overlapping blocks get the later ones), later layers seeded by rows of at least `seed_len` entries (defaults 4, 32)       */
+void gcge_hip_spmm_dense_min_len (int len);
+void gcge_hip_spmm_dense_layers (int layers, int seed_len);
+void gcge_hip_spmm_pad8_acc_early (int on);      /* adding row lists request their Y rows when a wave starts (default) */
 void gcge_hip_star_product_stats (long *products, long *split);   /* products through the grid form so far, and how many swept their interior planes while the halo travelled */
 /*     stencils whose coefficients differ from row to row: the pattern table is then built from the rows' column OFFSETS
  *     only and the values are streamed per row (8 doubles per row), so such matrices keep the pattern kernels (tables of

@@ -1438,14 +1438,16 @@ def test_star_sweep_spmm_vs_oracle(both, case):
         g.gcge_hip_spmm_dense_mode(0)
 
 
-@pytest.mark.parametrize("G,kw", [(24, dict(K=8, R0=1.5, R1=3.0)), (28, dict(K=20, R0=2.0, R1=5.0))])
-def test_star_sweep_on_a_masked_grid_vs_oracle(both, G, kw):
+@pytest.mark.parametrize("form", [3, 2])
+@pytest.mark.parametrize("G,kw", [(24, dict(K=8, R0=1.5, R1=3.0)), (28, dict(K=20, R0=2.0, R1=5.0)), (40, dict(K=30, R0=2.0, R1=4.0))])
+def test_star_sweep_on_a_masked_grid_vs_oracle(both, G, kw, form):
     """K1 on a MASKED grid: the SiO2-like operator on the ball inscribed in the box, rows = grid points inside in scan order (the
     layout of the PARSEC matrices behind BASELINE config 5).  With the geometry named (gcge_hip_mat_create_grid) the star rows
     take the plane sweep through a row map, the rest dense blocks + listed rows; against the CPU oracle, scipy and the same
     matrix uploaded WITHOUT the geometry — once with the recovery of the geometry from the rows switched off (dense blocks +
     pad-8), once as any caller uploads it (gcge_hip_mat_create recovers lines, planes and their shifts from the couplings and
-    takes the sweep as well): plain products, odd ranges, the product with column sums."""
+    takes the sweep as well): plain products, odd ranges, the product with column sums.  form 3: the third form of the sweep
+    through the line table (default), form 2: the second form through the point-wise row map (round 4)."""
     from gcge_amd.lib import ball_geometry
     hip, ora = both
     g = hip.g
@@ -1453,6 +1455,9 @@ def test_star_sweep_on_a_masked_grid_vs_oracle(both, G, kw):
     g.gcge_hip_mat_spmm_form.restype = C.c_char_p
     g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
     g.gcge_hip_spmm_dense_mode(1)
+    g.gcge_hip_spmm_star_masked_third.argtypes = [C.c_int]
+    g.gcge_hip_mat_star_masked_form.argtypes = [C.c_void_p]
+    g.gcge_hip_spmm_star_masked_third(1 if form == 3 else 0)
     try:
         A, _ = make_problem("sio2ball", G, **kw)
         box = ball_geometry(G)
@@ -1464,6 +1469,7 @@ def test_star_sweep_on_a_masked_grid_vs_oracle(both, G, kw):
         assert g.gcge_hip_mat_spmm_form(mh).decode().startswith("spmm_star+spmm_dense"), g.gcge_hip_mat_spmm_form(mh).decode()
         assert g.gcge_hip_mat_spmm_form(mi).decode().startswith("spmm_star+spmm_dense"), g.gcge_hip_mat_spmm_form(mi).decode()
         assert not g.gcge_hip_mat_spmm_form(mp).decode().startswith("spmm_star")
+        assert g.gcge_hip_mat_star_masked_form(mh) == form and g.gcge_hip_mat_star_masked_form(mi) == form and g.gcge_hip_mat_star_masked_form(mp) == 0
         st, si = (C.c_long * 8)(), (C.c_long * 8)()
         g.gcge_hip_mat_star_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
         assert g.gcge_hip_mat_star_stats(mh, st) and g.gcge_hip_mat_star_stats(mi, si)
@@ -1499,6 +1505,7 @@ def test_star_sweep_on_a_masked_grid_vs_oracle(both, G, kw):
     finally:
         g.gcge_hip_spmm_star_infer(1)
         g.gcge_hip_spmm_dense_mode(0)
+        g.gcge_hip_spmm_star_masked_third(1)
 
 
 def test_gcg_on_a_masked_grid_with_the_sweep_matches_reference_run(hip):
