@@ -235,6 +235,19 @@ static void rccl_exchange_int(const int* sendbuf, const int* send_cnt, int* recv
 // partitioned product needs is set up here, collectively (every rank of the communicator calls it): ghost list and
 // local renumbering, who needs which of my rows (one all-gather of the per-slab counts, then the index lists by
 // grouped send/recv), exchange buffers of buf_cols columns.  part: world + 1 row offsets, part[world] = n_global.
+// ... of a matrix on a MASKED grid (gcge_hip_mat_create_grid on one rank): box_of_global_row[r] = x + nx (y + ny z) of global row r,
+// rows in scan order, the partition cut between grid LINES (gcge_dist_partition_lines) — the slab keeps the plane sweep, its halo rows
+// are found through the line table (spmm_star.hip).  NULL geometry: gcge_hip_mat_create_slab.
+extern "C" void gcge_hip_star_next_geometry_cols(int ncols_local, int nx, int ny, int nz, const int* box_of_local_col);
+static const int* g_slab_box = nullptr; static int g_slab_dims[3] = {0, 0, 0};
+extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_slab(const long* part, const int* rowptr, const int* colidx_global, const double* val, int buf_cols);
+extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_slab_grid(const long* part, const int* rowptr, const int* colidx_global, const double* val, int buf_cols,
+                                                       int nx, int ny, int nz, const int* box_of_global_row) {
+  g_slab_box = box_of_global_row; g_slab_dims[0] = nx; g_slab_dims[1] = ny; g_slab_dims[2] = nz;
+  GCGE_HIP_MAT* A = gcge_hip_mat_create_slab(part, rowptr, colidx_global, val, buf_cols);
+  g_slab_box = nullptr;
+  return A;
+}
 extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_slab(const long* part, const int* rowptr, const int* colidx_global,
                                                   const double* val, int buf_cols) {
   if (gcge_hip_init(-1) != 0) return nullptr;
@@ -265,7 +278,15 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_slab(const long* part, const int* r
   gcge_free_ints(srows);
   if (gcge_dist_localize(&S, ghosts, ng) != 0) { gcge_free_ints(ghosts); return nullptr; }
   // (the halo rows' global ids travel with the arrays: a slab of a grid matrix cut on plane boundaries keeps the plane sweep)
+  std::vector<int> box_local;
+  if (g_slab_box != nullptr) {                                       // masked grid: the box index of every local column (own rows, then halo rows)
+    box_local.resize((size_t)nrows + ng);
+    for (int r = 0; r < nrows; ++r) box_local[r] = g_slab_box[part[rank] + r];
+    for (int k = 0; k < ng; ++k) box_local[(size_t)nrows + k] = g_slab_box[ghosts[k]];
+    gcge_hip_star_next_geometry_cols(nrows + ng, g_slab_dims[0], g_slab_dims[1], g_slab_dims[2], box_local.data());
+  }
   GCGE_HIP_MAT* A = gcge_hip_mat_create_local_ghosts(nrows, nrows + ng, (int)n_global, (int)part[rank], rowptr, cols.data(), val, ghosts);
+  if (g_slab_box != nullptr) gcge_hip_star_next_geometry_cols(0, 0, 0, 0, nullptr);   // (not consumed when the slab took another form)
   gcge_free_ints(ghosts);
   if (A == nullptr) return nullptr;
   if (world > 1) {

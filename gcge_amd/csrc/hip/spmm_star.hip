@@ -53,6 +53,7 @@ struct StarMat {
   void* d_lines;   // masked grids whose lines are runs of rows: (base, xs | xe << 16) per line (y, z) — the third form (spmm_star3m_kernel); NULL: second form
   int* d_prange3;  // ... and the plane ranges of its 16 x 8 patches
   int* d_order3; int npatch3;   // ... and those of them that have rows, longest range first
+  bool masked_slab;             // a row slab of a masked grid (halo rows among the lines: third form only, no interior / boundary split)
 };
 
 // staging plan of a thread: unit u = tid + 1024 q, point u >> 2, 16-byte part u & 3
@@ -520,7 +521,7 @@ template <bool DOT>
 __global__ __launch_bounds__(1024) void spmm_star3m_kernel(int nx, int ny, int nz, StarCoef cf, const double* __restrict__ diag,
     const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int ncols, int zlo, int zhi, int zlen, int ntx,
     double* __restrict__ partial, const unsigned char* __restrict__ cleanf, const unsigned long long* __restrict__ lines,
-    const int* __restrict__ prange, const int* __restrict__ order) {
+    const int* __restrict__ prange, const int* __restrict__ order, int nown) {
   constexpr int LPP = STAR3_LPP, TY = STAR3_TY;
   const unsigned ldx32 = (unsigned)ldx;                                   // (< 2^31: checked on the host) row * ldx in one v_mad_u64_u32
   const int nyp = ny + STAR3M_YLO + STAR3M_YHI;
@@ -584,8 +585,9 @@ __global__ __launch_bounds__(1024) void spmm_star3m_kernel(int nx, int ny, int n
     const int row = ok ? L.base + gx : 0;
     return star2_and(*reinterpret_cast<const v2d*>(x + ((size_t)(unsigned)row * ldx32 + col)), ok ? ~0ull : 0ull);
   };
+  // (row < nown: a line of the output plane may belong to the neighbouring slab — read like any halo row, never written)
   auto ld_diag = [&](int zz, const StarLine& L) -> double {
-    const bool ok = inside && on_line(L, gx) && zz < z1;
+    const bool ok = inside && on_line(L, gx) && zz < z1 && L.base + gx < nown;
     const int row = ok ? L.base + gx : 0;
     unsigned long long b = __builtin_bit_cast(unsigned long long, diag[row]);
     const unsigned long long m = ok ? ~0ull : 0ull;
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(1024) void spmm_star3m_kernel(int nx, int ny, int n
   // (the flag is requested and the sums are formed without DOT as well: hipcc's register allocation of the leaner variant spilled
   //  four vector registers, and a scratch access is a vector-memory operation the hand-counted waits do not know)
   auto ld_clean = [&](int zz, const StarLine& L) -> int {
-    const bool ok = inside && on_line(L, gx) && zz < z1;
+    const bool ok = inside && on_line(L, gx) && zz < z1 && L.base + gx < nown;
     return (int)cleanf[ok ? L.base + gx : 0];
   };
   // the three pieces of a plane into strip buffer `sl`; L: the lines they lie on in that plane
@@ -752,6 +754,7 @@ struct StarRows {
   int nrows, ncols_local; long row_begin, nglobal; const int* ghost; const int *rowptr, *colidx; const double* val;
   bool global_cols = false;                                           // colidx holds global columns already (partitioners)
   const int* box = nullptr; int bnx = 0, bny = 0, bnz = 0;
+  bool box_cols = false;                                              // box[] covers every LOCAL column (a row slab of a masked grid: own rows, then halo rows)
   long gcol(int c) const { return box != nullptr ? (long)box[c] : global_cols ? (long)c : c < nrows ? row_begin + c : (long)ghost[c - nrows]; }
   long gpos(int r) const { return box != nullptr ? (long)box[r] : row_begin + r; }
 };
@@ -802,9 +805,10 @@ static bool star_detect(const StarRows& M, StarHost* H) {
   if (R > STAR_R || sy <= 2L * STAR_R || sz % sy != 0 || sz / sy <= 2L * STAR_R || M.nglobal % sz != 0 || M.nglobal / sz < 2) return false;
   StarGeom& g = H->g;
   g.nx = (int)sy; g.ny = (int)(sz / sy); g.nz = (int)(M.nglobal / sz); H->R = R;
-  if (M.box != nullptr) {            // a masked domain: the box is the grid, the rows are found through the map (one rank)
-    if (g.nx != M.bnx || g.ny != M.bny || g.nz != M.bnz || M.ncols_local != nrows) return false;
+  if (M.box != nullptr) {            // a masked domain: the box is the grid, the rows are found through the map / the line table
+    if (g.nx != M.bnx || g.ny != M.bny || g.nz != M.bnz || (M.ncols_local != nrows && !M.box_cols)) return false;
     g.zs = 0; g.ze = g.nz;
+    if (M.box_cols) { g.zs = (int)(M.box[0] / sz); g.ze = (int)(M.box[nrows - 1] / sz) + 1; }   // a slab: the planes its own rows touch
   } else {
     // the slab must be whole planes (a partition cut inside a plane keeps the other forms: gcge_amd.dist.partition_by_nnz(align=))
     if (M.row_begin % sz != 0 || (long)nrows % sz != 0) return false;
@@ -825,8 +829,10 @@ static bool star_detect(const StarRows& M, StarHost* H) {
     *off = (long)nrows + idx - first;
     return true;
   };
-  if (!run((long)g.zmin * sz, (long)(g.zs - g.zmin) * sz, &g.lo_off)) return false;
-  if (!run((long)g.ze * sz, (long)(g.zmax - g.ze) * sz, &g.hi_off)) return false;
+  if (M.box == nullptr) {             // (a masked grid finds its halo rows through the line table, line by line)
+    if (!run((long)g.zmin * sz, (long)(g.zs - g.zmin) * sz, &g.lo_off)) return false;
+    if (!run((long)g.ze * sz, (long)(g.zmax - g.ze) * sz, &g.hi_off)) return false;
+  }
   // coefficients: the most frequent value of every offset among the sampled rows; the star must be symmetric
   memset(&H->c, 0, sizeof(H->c));
   for (int axis = 0; axis < 3; ++axis) {
@@ -862,7 +868,7 @@ static bool star_detect(const StarRows& M, StarHost* H) {
 // differs from the star: on the SiO2-like matrix two thirds of the non-zeros the listed rows held before were plain star entries.
 static bool star_build_host(const StarRows& M, StarHost* H) {
   const int nrows = M.nrows; const int* rowptr = M.rowptr; const int* colidx = M.colidx; const double* val = M.val;
-  if (M.ncols_local != nrows && M.ghost == nullptr) return false;     // halo columns of unknown origin: the other forms
+  if (M.ncols_local != nrows && M.ghost == nullptr && !M.box_cols) return false;     // halo columns of unknown origin: the other forms
   if (!star_detect(M, H)) return false;
   const StarGeom& gm = H->g;
   const int nx = gm.nx, ny = gm.ny, nz = gm.nz;
@@ -880,8 +886,9 @@ static bool star_build_host(const StarRows& M, StarHost* H) {
   inv.clear();
   if (M.box != nullptr) {
     inv.assign((size_t)M.nglobal, -1);
-    for (int r = 0; r < nrows; ++r) {
-      if (M.box[r] < 0 || M.box[r] >= M.nglobal || inv[M.box[r]] != -1 || (r > 0 && M.box[r] <= M.box[r - 1])) return false;   // (scan order, no point twice)
+    const int ncl = M.box_cols ? M.ncols_local : nrows;               // (a slab: the halo rows too — ascending among themselves)
+    for (int r = 0; r < ncl; ++r) {
+      if (M.box[r] < 0 || M.box[r] >= M.nglobal || inv[M.box[r]] != -1 || (r > 0 && r != nrows && M.box[r] <= M.box[r - 1])) return false;   // (scan order, no point twice)
       inv[M.box[r]] = r;
     }
   }
@@ -1226,9 +1233,13 @@ extern "C" void gcge_hip_star_free(void* sm) {
 // ghost: the global rows behind the halo columns nrows .. ncols_local - 1 (ascending; NULL on one rank).
 static StarHost* g_star_last = nullptr;
 // geometry of the NEXT matrix handed to gcge_hip_star_build (gcge_hip_mat_create_grid sets it, the build consumes it)
-static struct { int nrows, nx, ny, nz; const int* box; } g_star_geom = {0, 0, 0, 0, nullptr};
+static struct { int nrows, nx, ny, nz; const int* box; bool cols; } g_star_geom = {0, 0, 0, 0, nullptr, false};
 extern "C" void gcge_hip_star_next_geometry(int nrows, int nx, int ny, int nz, const int* box_of_row) {
-  g_star_geom.nrows = nrows; g_star_geom.nx = nx; g_star_geom.ny = ny; g_star_geom.nz = nz; g_star_geom.box = box_of_row;
+  g_star_geom.nrows = nrows; g_star_geom.nx = nx; g_star_geom.ny = ny; g_star_geom.nz = nz; g_star_geom.box = box_of_row; g_star_geom.cols = false;
+}
+// a ROW SLAB of a masked grid: the box index of every local column — the own rows, then the halo rows (ascending by global row)
+extern "C" void gcge_hip_star_next_geometry_cols(int ncols_local, int nx, int ny, int nz, const int* box_of_local_col) {
+  g_star_geom.nrows = ncols_local; g_star_geom.nx = nx; g_star_geom.ny = ny; g_star_geom.nz = nz; g_star_geom.box = box_of_local_col; g_star_geom.cols = true;
 }
 extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin, long nglobal, const int* ghost, const int* rowptr,
                                      const int* colidx, const double* val, const int** rem_rowptr, const int** rem_col, const double** rem_val) {
@@ -1236,8 +1247,11 @@ extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin,
   StarHost* H = new StarHost();
   StarRows M = {nrows, ncols_local, row_begin, nglobal, ghost, rowptr, colidx, val};
   if (g_star_geom.box != nullptr) {
-    if (g_star_geom.nrows == nrows && ncols_local == nrows && row_begin == 0) {
+    if (!g_star_geom.cols && g_star_geom.nrows == nrows && ncols_local == nrows && row_begin == 0) {
       M.box = g_star_geom.box; M.bnx = g_star_geom.nx; M.bny = g_star_geom.ny; M.bnz = g_star_geom.nz;
+      M.nglobal = (long)M.bnx * M.bny * M.bnz;
+    } else if (g_star_geom.cols && g_star_geom.nrows == ncols_local) {
+      M.box = g_star_geom.box; M.bnx = g_star_geom.nx; M.bny = g_star_geom.ny; M.bnz = g_star_geom.nz; M.box_cols = true;
       M.nglobal = (long)M.bnx * M.bny * M.bnz;
     }
     g_star_geom.box = nullptr;
@@ -1275,13 +1289,15 @@ extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin,
     const int nty8 = (ny + STAR3_TY - 1) / STAR3_TY;
     std::vector<int> pr3((size_t)2 * ntx * nty8);
     for (int p = 0; p < ntx * nty8; ++p) { pr3[2 * p] = nz; pr3[2 * p + 1] = 0; }
-    for (int r = 0; r < nrows && runs; ++r) {
+    const int ncl = M.box_cols ? M.ncols_local : nrows;               // (a slab: the halo rows have lines as well; a line is own OR halo)
+    for (int r = 0; r < ncl && runs; ++r) {
       const long b = M.box[r];
       const int z = (int)(b / ((long)nx * ny)), y = (int)((b / nx) % ny), x = (int)(b % nx);
       StarLine& L = ln[(size_t)(z + STAR3M_ZLO) * nyp + (y + STAR3M_YLO)];
       if (L.xr == 0) { L.base = r - x; L.xr = x | (x + 1) << 16; }
-      else if (r - x == L.base && x == (L.xr >> 16)) L.xr = (L.xr & 0xffff) | (x + 1) << 16;
-      else runs = false;                                                 // a hole in the line: the point-wise map of the second form
+      else if (r - x == L.base && x == (L.xr >> 16) && r != nrows) L.xr = (L.xr & 0xffff) | (x + 1) << 16;
+      else runs = false;                                                 // a hole in the line (or a line cut by the partition): the point-wise map of the second form
+      if (r >= nrows) continue;
       const int p = (y / STAR3_TY) * ntx + x / STAR_T;
       pr3[2 * p] = std::min(pr3[2 * p], z); pr3[2 * p + 1] = std::max(pr3[2 * p + 1], z + 1);
     }
@@ -1298,8 +1314,12 @@ extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin,
       GCGE_HIP_CHECK(hipMemcpy(S->d_order3, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice));
     }
   }
+  S->masked_slab = M.box != nullptr && M.box_cols && ncols_local != nrows;
   S->g = H->g; S->R = H->R; S->nclean = H->nclean; S->nrows = nrows; S->c = H->c;
   S->iso = memcmp(H->c.cx, H->c.cy, sizeof(H->c.cx)) == 0 && memcmp(H->c.cx, H->c.cz, sizeof(H->c.cx)) == 0;
+  if (S->masked_slab && (S->d_lines == nullptr || !S->iso)) {         // a slab of a masked grid: the line table or nothing (the row map of the second form knows no halo rows)
+    hipFree(S->d_map); hipFree(S->d_prange); if (S->d_lines) { hipFree(S->d_lines); hipFree(S->d_prange3); hipFree(S->d_order3); } delete S; delete H; return nullptr;
+  }
   if (S->d_map != nullptr && !S->iso) { hipFree(S->d_map); hipFree(S->d_prange); if (S->d_lines) { hipFree(S->d_lines); hipFree(S->d_prange3); hipFree(S->d_order3); } delete S; delete H; return nullptr; }   // (masked grids: the one-coefficient-set kernel only)
   GCGE_HIP_CHECK(hipMalloc(&S->d_diag, (size_t)nrows * sizeof(double)));
   GCGE_HIP_CHECK(hipMemcpy(S->d_diag, H->diag.data(), (size_t)nrows * sizeof(double), hipMemcpyHostToDevice));
@@ -1320,7 +1340,7 @@ extern "C" const unsigned char* gcge_hip_star_host_mask(void) {   // 1: a star r
 extern "C" int gcge_hip_star_masked_form(const void* sm) {
   const StarMat* S = (const StarMat*)sm;
   if (S->d_map == nullptr) return 0;
-  return (g_star_form == 3 && S->iso && S->d_lines != nullptr && g_star_masked_third) ? 3 : 2;
+  return (S->iso && S->d_lines != nullptr && (S->masked_slab || (g_star_form == 3 && g_star_masked_third))) ? 3 : 2;
 }
 extern "C" void gcge_hip_star_stats(const void* sm, long* out) {   // nx, ny, nz, arm length, clean rows, rows, first / last + 1 plane of the slab
   const StarMat* S = (const StarMat*)sm;
@@ -1331,6 +1351,7 @@ extern "C" void gcge_hip_star_stats(const void* sm, long* out) {   // nx, ny, nz
 // STAR_R planes on either side of an output plane whatever the arm length).  Returns 0 when the slab has no halo or no such plane.
 extern "C" int gcge_hip_star_interior(const void* sm, int* ilo, int* ihi) {
   const StarGeom& g = ((const StarMat*)sm)->g;
+  if (((const StarMat*)sm)->masked_slab) { if (ilo) *ilo = g.zs; if (ihi) *ihi = g.ze; return 0; }   // (its first / last plane may be shared with a neighbour: one sweep after the exchange)
   const int lo = g.zmin < g.zs ? g.zs + STAR_R : g.zs, hi = g.ze < g.zmax ? g.ze - STAR_R : g.ze;
   if (ilo) *ilo = lo;
   if (ihi) *ihi = hi;
@@ -1352,7 +1373,7 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
   // third form (LDS-DMA strips, two planes of prefetch): one coefficient set, every grid point a row, lane offsets of a plane in 32 bits
   const bool third = g_star_form == 3 && iso && !mapped && (double)g.nx * g.ny * (double)ldx * 8.0 < 4.0e9;
   // ... and on a masked grid with a line table (spmm_star3m_kernel: 64-bit lane addresses, no size limit)
-  const bool third_m = g_star_form == 3 && iso && mapped && S->d_lines != nullptr && g_star_masked_third && ldx < (1L << 31);
+  const bool third_m = iso && mapped && S->d_lines != nullptr && ldx < (1L << 31) && (S->masked_slab || (g_star_form == 3 && g_star_masked_third));
   const int lpp = (third || third_m) ? 8 : (!iso || mapped || g_star_lpp == 4) ? 4 : 8;   // (per-axis coefficients / masked grids: the 8-column form, which needs fewer registers)
   const int ty = 64 / lpp;
   const int ntx = (g.nx + STAR_T - 1) / STAR_T, nty = (g.ny + ty - 1) / ty, npass = (ncols + 2 * lpp - 1) / (2 * lpp);
@@ -1414,12 +1435,13 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
       attr_m = true;
     }
     if (dot) hipLaunchKernelGGL((spmm_star3m_kernel<true>), grid, dim3(1024), STAR3M_LDS, stream, g.nx, g.ny, g.nz, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy,
-                                ncols, zlo, zhi, zlen, ntx, part, (const unsigned char*)S->d_clean, (const unsigned long long*)S->d_lines, (const int*)S->d_prange3, (const int*)S->d_order3);
+                                ncols, zlo, zhi, zlen, ntx, part, (const unsigned char*)S->d_clean, (const unsigned long long*)S->d_lines, (const int*)S->d_prange3, (const int*)S->d_order3, (int)S->nrows);
     else     hipLaunchKernelGGL((spmm_star3m_kernel<false>), grid, dim3(1024), STAR3M_LDS, stream, g.nx, g.ny, g.nz, S->c, (const double*)S->d_diag, d_x, (size_t)ldx, d_y, (size_t)ldy,
-                                ncols, zlo, zhi, zlen, ntx, part, (const unsigned char*)S->d_clean, (const unsigned long long*)S->d_lines, (const int*)S->d_prange3, (const int*)S->d_order3);
+                                ncols, zlo, zhi, zlen, ntx, part, (const unsigned char*)S->d_clean, (const unsigned long long*)S->d_lines, (const int*)S->d_prange3, (const int*)S->d_order3, (int)S->nrows);
     return nb;
   }
   if (mapped) {          // masked grid: one rank, one coefficient set (checked at upload)
+    if (S->masked_slab) { fprintf(stderr, "gcge_hip: a row slab of a masked grid has the third form of the sweep only (leading dimension %ld)\n", ldx); abort(); }
     if (dot) hipLaunchKernelGGL((spmm_star2_kernel<true, true, false, 4, 0, true>), grid, dim3(1024), 0, stream, STAR_ARGS);
     else     hipLaunchKernelGGL((spmm_star2_kernel<false, true, false, 4, 0, true>), grid, dim3(1024), 0, stream, STAR_ARGS);
     return nb;

@@ -319,9 +319,21 @@ class NativeComm:
         self.hip.g.gcge_hip_comm_stats(C.byref(a), C.byref(e))
         return a.value
 
-    def slab_matrix(self, A, part, cap_cols=128):
-        """A: CSR slab with GLOBAL column indices (rows part[rank] .. part[rank+1]).  Collective."""
+    def slab_matrix(self, A, part, cap_cols=128, geometry=None):
+        """A: CSR slab with GLOBAL column indices (rows part[rank] .. part[rank+1]).  Collective.  geometry = (dims, box_global): a
+        matrix on a masked grid, cuts between grid lines (partition_lines): gcge_hip_mat_create_slab_grid."""
         parr = (C.c_long * (self.world + 1))(*part)
+        if geometry is not None:
+            dims, box_global = geometry
+            bg = np.ascontiguousarray(box_global, dtype=np.int32)
+            f = self.hip.g.gcge_hip_mat_create_slab_grid
+            f.restype = C.c_void_p
+            f.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int,
+                          C.POINTER(C.c_int)]
+            m = f(parr, A.rowptr, A.colidx, A.val, cap_cols, int(dims[0]), int(dims[1]), int(dims[2]), bg.ctypes.data_as(C.POINTER(C.c_int)))
+            if not m:
+                raise RuntimeError("gcge_hip_mat_create_slab_grid failed")
+            return C.c_void_p(m)
         m = self.hip.g.gcge_hip_mat_create_slab(parr, A.rowptr, A.colidx, A.val, cap_cols)
         if not m:
             raise RuntimeError("gcge_hip_mat_create_slab failed")
@@ -356,11 +368,36 @@ def install(hip, dist, rank, world, stage_through_host=False):
     return comm
 
 
-def hip_slab_matrix(hip, comm, A, n_global, part, cap_cols=128):
-    """Upload a CSR slab (GLOBAL columns on entry) and install its halo plan."""
+def partition_lines(box_global, nx, world):
+    """Row partition of a matrix on a MASKED grid (box_global[r] = x + nx (y + ny z), rows in scan order) with every cut between two
+    grid LINES, as even in rows as that allows: what gcge_hip_mat_create_slab_grid / hip_slab_matrix(geometry=) need to keep the
+    plane sweep on every slab (a line is one run of rows of ONE rank)."""
+    box = np.asarray(box_global, dtype=np.int64)
+    n = int(box.size)
+    starts = np.concatenate([[0], np.nonzero(box[1:] // nx != box[:-1] // nx)[0] + 1, [n]])     # first row of every line, and n
+    part = [0]
+    for q in range(1, world):
+        want = q * n // world
+        k = int(np.searchsorted(starts, want))
+        cand = [int(starts[j]) for j in (k - 1, k) if 0 <= j < len(starts)]
+        cut = min(cand, key=lambda c: abs(c - want))
+        part.append(max(cut, part[-1]))
+    part.append(n)
+    return part
+
+
+def hip_slab_matrix(hip, comm, A, n_global, part, cap_cols=128, geometry=None):
+    """Upload a CSR slab (GLOBAL columns on entry) and install its halo plan.  geometry = (dims, box_global): the matrix lives on a
+    masked grid (box index of every GLOBAL row); with cuts between grid lines (partition_lines) the slab keeps the plane sweep."""
     g = hip.g
     ghosts = localize_slab(A)
     send_rows, send_cnt, recv_cnt = comm.plan_halo(ghosts, part)
+    if geometry is not None:
+        dims, box_global = geometry
+        bg = np.asarray(box_global, dtype=np.int32)
+        box_local = np.ascontiguousarray(np.concatenate([bg[A.row_begin:A.row_begin + A.nrows], bg[np.asarray(ghosts, dtype=np.int64)]]), dtype=np.int32)
+        g.gcge_hip_star_next_geometry_cols.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        g.gcge_hip_star_next_geometry_cols(int(box_local.size), int(dims[0]), int(dims[1]), int(dims[2]), box_local.ctypes.data_as(C.POINTER(C.c_int)))
     # (the halo rows' global ids go with the arrays: a slab of a grid matrix cut on plane boundaries keeps the plane sweep)
     g.gcge_hip_mat_create_local_ghosts.restype = C.c_void_p
     g.gcge_hip_mat_create_local_ghosts.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
@@ -368,6 +405,8 @@ def hip_slab_matrix(hip, comm, A, n_global, part, cap_cols=128):
     gh = np.ascontiguousarray(ghosts, dtype=np.int32)
     m = g.gcge_hip_mat_create_local_ghosts(A.nrows, A.ncols, n_global, A.row_begin, A.rowptr, A.colidx, A.val,
                                            gh.ctypes.data_as(C.POINTER(C.c_int)))
+    if geometry is not None:
+        g.gcge_hip_star_next_geometry_cols(0, 0, 0, 0, None)          # (not consumed when the slab took another form)
     if not m:
         raise RuntimeError("gcge_hip_mat_create_local_ghosts failed")
     mat = C.c_void_p(m)

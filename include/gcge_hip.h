@@ -123,6 +123,14 @@ int  gcge_hip_comm_is_native (const GCGE_COMM *comm);
  *     RCCL; products then move buf_cols columns of halo rows per grouped ncclSend/ncclRecv, event-ordered            */
 GCGE_HIP_MAT *gcge_hip_mat_create_slab (const long *part, const int *rowptr, const int *colidx_global,
 		const double *val, int buf_cols);
+/*     ... of a matrix on a MASKED grid (the real-space DFT matrices behind BASELINE config 5 on more than one device; reference
+ *     test/submit.sh:9-15): box_of_global_row[r] = x + nx (y + ny z) of GLOBAL row r (rows in scan order), the partition cut between
+ *     grid lines (gcge_amd.dist.partition_lines).  The slab keeps the plane sweep: own and halo rows are found through one line table.
+ *     gcge_hip_star_next_geometry_cols: the same for callers that build the slab themselves (gcge_hip_mat_create_local_ghosts): the
+ *     box index of every LOCAL column (own rows, then halo rows), consumed by the next upload                                      */
+GCGE_HIP_MAT *gcge_hip_mat_create_slab_grid (const long *part, const int *rowptr, const int *colidx_global, const double *val,
+		int buf_cols, int nx, int ny, int nz, const int *box_of_global_row);
+void gcge_hip_star_next_geometry_cols (int ncols_local, int nx, int ny, int nz, const int *box_of_local_col);
 /*     the same for a slab matrix that already has LOCAL column indices (gcge_hip_mat_create_local) and a plan computed
  *     elsewhere: npeer slabs, peer[q] = communicator rank owning slab q, rows shipped to / received from it, the
  *     local rows to ship grouped by destination slab                                                               */

@@ -32,13 +32,31 @@ def main():
     dims = (8, 8, 10)      # planes of 64 rows: the slab matrices qualify for the chain layout of the pattern SpMM
     sio2 = None            # "sio2:G": SiO2-like matrix on a G^3 grid (rows of very different length), rows split by nnz
     star = False           # "sio2star:G": the same with cuts on plane boundaries — every slab keeps the plane sweep of spmm_star.hip
-    if len(sys.argv) > 2 and sys.argv[2].startswith("sio2star:"):
+    ball = None            # "sio2ball:G": the same operator on the BALL inside the box (a masked grid, rows in scan order), cuts between grid lines
+    geometry = None
+    if len(sys.argv) > 2 and sys.argv[2].startswith("sio2ball:"):
+        ball = int(sys.argv[2].split(":")[1])
+    elif len(sys.argv) > 2 and sys.argv[2].startswith("sio2star:"):
         sio2, star = int(sys.argv[2].split(":")[1]), True
     elif len(sys.argv) > 2 and sys.argv[2].startswith("sio2:"):
         sio2 = int(sys.argv[2].split(":")[1])
     elif len(sys.argv) > 2:
         dims = tuple(int(t) for t in sys.argv[2].split(","))
-    if sio2:
+    if ball:
+        from gcge_amd.lib import make_problem, ball_geometry
+        kw = dict(K=12, R0=1.5, R1=3.0, seed=12345)
+        box = ball_geometry(ball)
+        n_global = int(box.size)
+        Ag, _ = make_problem("sio2ball", ball, **kw)
+        assert Ag.nrows == n_global
+        S = csr_to_scipy(Ag)
+        part = gdist.partition_lines(box, ball, world)
+        assert part[0] == 0 and part[-1] == n_global and all(part[q] < part[q + 1] for q in range(world)), part
+        assert all(q == 0 or box[part[q]] // ball != box[part[q] - 1] // ball for q in range(world)), "cuts must lie between grid lines"
+        A, _ = make_problem("sio2ball", ball, row_begin=part[rank], row_end=part[rank + 1], **kw)
+        geometry = ((ball, ball, ball), box)
+        sio2 = ball            # (the checks below that only ask "an SiO2-like matrix?")
+    elif sio2:
         from gcge_amd.lib import make_problem
         kw = dict(K=8 if star else 40, R0=1.5, R1=3.0, seed=12345)
         n_global = sio2 ** 3
@@ -91,24 +109,63 @@ def main():
         from gcge_amd import HipBackend
         torch.cuda.set_device(rank)
         be = HipBackend(device=rank)
-        if star:
+        if star or ball:
             be.g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
             be.g.gcge_hip_spmm_dense_mode(1)          # small atoms: rows of >= 24 entries may seed a block
         comm = gdist.NativeComm(be, dist, rank, world)
-        mat = comm.slab_matrix(A, part, cap_cols=64 if star else 8)
+        mat = comm.slab_matrix(A, part, cap_cols=64 if (star or ball) else 8, geometry=geometry)
         be.set_random_mode(1, 777)
     else:
         from gcge_amd import HipBackend
         be = HipBackend(device=0)
-        if star:
+        if star or ball:
             be.g.gcge_hip_spmm_dense_mode.argtypes = [C.c_int]
             be.g.gcge_hip_spmm_dense_mode(1)          # small atoms: rows of >= 24 entries may seed a block
         comm = gdist.install(be, dist, rank, world, stage_through_host=True)
-        mat = gdist.hip_slab_matrix(be, comm, A, n_global, part, cap_cols=64 if star else 4)   # small cap: exercises the column chunking
+        mat = gdist.hip_slab_matrix(be, comm, A, n_global, part, cap_cols=64 if (star or ball) else 4, geometry=geometry)   # small cap: exercises the column chunking
         be.set_random_mode(1, 777)
         be.g.gcge_hip_mat_pattern_chain.argtypes = [C.c_void_p]
         assert sio2 or be.g.gcge_hip_mat_pattern_chain(mat) >= 1, "slab matrix with halo columns should keep the chain layout"
 
+    if ball and mode in ("hip", "hip_native"):
+        # every slab of the masked grid kept the plane sweep (third form through the line table: own and halo rows), and multiplies right
+        g = be.g
+        g.gcge_hip_mat_spmm_form.restype = C.c_char_p
+        g.gcge_hip_mat_spmm_form.argtypes = [C.c_void_p]
+        g.gcge_hip_mat_star_masked_form.argtypes = [C.c_void_p]
+        g.gcge_hip_mat_star_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+        g.gcge_hip_star_product_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        form = g.gcge_hip_mat_spmm_form(mat).decode()
+        assert form.startswith("spmm_star+spmm_dense"), (rank, form)
+        assert g.gcge_hip_mat_star_masked_form(mat) == 3, "a slab of a masked grid takes the third form of the sweep"
+        st = (C.c_long * 8)()
+        assert g.gcge_hip_mat_star_stats(mat, st) == 1 and tuple(st[:4]) == (ball, ball, ball, 6) and st[5] == n_loc, list(st)
+        assert st[4] >= 0.7 * n_loc, ("most rows of the slab are star rows", list(st))
+        plane = ball * ball
+        assert (st[6], st[7]) == (int(box[part[rank]]) // plane, int(box[part[rank + 1] - 1]) // plane + 1), (list(st), part)
+        Xw = uniform(6, (n_global, 66)) - 0.5
+        Yw = S @ Xw
+        xw = be.mv_from_numpy(mat, Xw[part[rank]:part[rank + 1], :])
+        yw = be.ops.mv_create(66, mat)
+        g.gcge_hip_spmm_dot2_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        p0, s0_ = C.c_long(), C.c_long()
+        g.gcge_hip_star_product_stats(C.byref(p0), C.byref(s0_))
+        for m, a, b in [(64, 0, 0), (16, 2, 4), (17, 1, 0), (30, 3, 2), (66, 0, 0), (2, 8, 0)]:
+            be.ops.spmm(mat, xw, yw, (a, b), (a + m, b + m))
+            got = be.mv_to_numpy(yw, n_loc, b, b + m)
+            err = np.max(np.abs(got - Yw[part[rank]:part[rank + 1], a:a + m]))
+            assert err < 1e-12, "sweep on a slab of a masked grid (m=%d, columns %d -> %d) differs: %g" % (m, a, b, err)
+        for m, a, b in [(64, 0, 0), (30, 4, 2)]:
+            dots, yy = np.zeros(m), np.zeros(m)
+            g.gcge_hip_spmm_dot2_mv(mat, xw, yw, (C.c_int * 2)(a, b), (C.c_int * 2)(a + m, b + m), dots.ctypes.data, yy.ctypes.data, be.ops_handle)
+            Yl, Xl = Yw[part[rank]:part[rank + 1], a:a + m], Xw[part[rank]:part[rank + 1], a:a + m]
+            assert np.max(np.abs(be.mv_to_numpy(yw, n_loc, b, b + m) - Yl)) < 1e-12
+            assert np.allclose(dots, (Xl * Yl).sum(0), rtol=1e-11, atol=1e-9) and np.allclose(yy, (Yl * Yl).sum(0), rtol=1e-11), m
+        p1, s1_ = C.c_long(), C.c_long()
+        g.gcge_hip_star_product_stats(C.byref(p1), C.byref(s1_))
+        assert world == 1 or p1.value - p0.value >= 7, "the products did not go through the grid form"   # (one rank: no exchange, the whole-matrix path — not counted)
+        be.ops.mv_destroy(xw, 66); be.ops.mv_destroy(yw, 66)
     if star and mode in ("hip", "hip_native"):
         # every slab took the grid form, sits where the partition put it, and sweeps its inner planes while the halo travels
         g = be.g

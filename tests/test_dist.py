@@ -59,6 +59,11 @@ def test_three_ranks_gloo_sio2_rows_split_by_nnz():
     _run("oracle", world=3, spec="sio2:14")
 
 
+def test_two_ranks_gloo_ball_cuts_between_grid_lines():
+    """partition_lines on the ball matrix (a masked grid: cuts between grid lines), slabs generated per rank, whole solve on the CPU oracle."""
+    _run("oracle", world=2, spec="sio2ball:14")
+
+
 def test_two_ranks_gloo_sio2_cuts_on_plane_boundaries():
     """partition_by_nnz(align = plane of the grid read off a slab) over gloo, then the whole solve on the CPU oracle."""
     _run("oracle", world=2, spec="sio2star:16")
@@ -140,7 +145,7 @@ def test_native_worker_as_one_rank():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("spec", [None, "sio2:16", "sio2star:24"])
+@pytest.mark.parametrize("spec", [None, "sio2:16", "sio2star:24", "sio2ball:24"])
 def test_two_ranks_two_gpus_rccl_native(spec):
     """the world > 1 branches of gcge_hip_mat_create_slab (all-gather of the per-slab counts, grouped send/recv of the
     index lists), the split halo exchange next to the all-reduces on one communicator and the device-scalar CG — two ranks on
@@ -165,6 +170,22 @@ def test_ranks_on_one_gpu_hip_sio2_star_sweep_on_plane_aligned_slabs(world):
     the halo rows; products with and without the interior / boundary split, odd column ranges, the product with its column
     sums, a whole SPMD solve, all against the global matrix."""
     _run("hip", world=world, spec="sio2star:24")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,G", [(2, 24), (3, 28)])
+def test_ranks_on_one_gpu_hip_slabs_of_a_masked_grid_keep_the_sweep(world, G):
+    """Row slabs of a MASKED grid (the PARSEC matrices behind BASELINE config 5 on more than one device): the
+    SiO2-like operator on the ball, partition cut between grid lines (gdist.partition_lines), geometry named to the slab constructor —
+    every slab keeps the plane sweep (third form: own AND halo rows found through one line table), its products (plain, odd column
+    ranges, with the column sums) and a whole SPMD solve against the global matrix."""
+    _run("hip", world=world, spec="sio2ball:%d" % G)
+
+
+@pytest.mark.gpu
+def test_native_worker_one_rank_slab_of_a_masked_grid():
+    """gcge_hip_mat_create_slab_grid (RCCL constructor with the geometry named) as a world of one rank."""
+    _run("hip_native", world=1, spec="sio2ball:24")
 
 
 @pytest.mark.gpu
