@@ -103,6 +103,18 @@ def test_rccl_native_loopback_one_gpu(dims):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("G", [28])
+def test_rccl_native_loopback_sweep_on_a_slab_of_a_masked_grid(G):
+    """The same on the ball (a masked grid, cut between two grid lines): the slab's halo rows — lines of the planes above, found through
+    the line table — arrive by grouped ncclSend/ncclRecv from C; products, products with sums, the fused CG with narrow halo buffers."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_loopback_worker.py"), str(G), "native_ball"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "rccl loop-back ok" in p.stdout, p.stdout[-3000:]
+    print(p.stdout[-300:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("G", [24, 40])
 def test_rccl_native_loopback_star_sweep_on_a_slab(G):
     """The plane sweep of spmm_star.hip on a row slab over the production transport: slab 0 of a two-slab SiO2-like matrix
