@@ -34,7 +34,10 @@ def main():
     star = False           # "sio2star:G": the same with cuts on plane boundaries — every slab keeps the plane sweep of spmm_star.hip
     ball = None            # "sio2ball:G": the same operator on the BALL inside the box (a masked grid, rows in scan order), cuts between grid lines
     geometry = None
-    if len(sys.argv) > 2 and sys.argv[2].startswith("sio2ball:"):
+    ballfile = False       # "ballfile:G": the ball matrix as a Matrix-Market FILE — no geometry named: recovered from the rows of the file
+    if len(sys.argv) > 2 and sys.argv[2].startswith("ballfile:"):
+        ball, ballfile = int(sys.argv[2].split(":")[1]), True
+    elif len(sys.argv) > 2 and sys.argv[2].startswith("sio2ball:"):
         ball = int(sys.argv[2].split(":")[1])
     elif len(sys.argv) > 2 and sys.argv[2].startswith("sio2star:"):
         sio2, star = int(sys.argv[2].split(":")[1]), True
@@ -50,11 +53,46 @@ def main():
         Ag, _ = make_problem("sio2ball", ball, **kw)
         assert Ag.nrows == n_global
         S = csr_to_scipy(Ag)
-        part = gdist.partition_lines(box, ball, world)
+        bdims = (ball, ball, ball)
+        keep = []
+        if ballfile:
+            # what a user of the reference's SiO2 file has: a file, no grid.  Rank 0 writes it, every rank reads it, recovers the geometry
+            # from the rows (gcge_hip_star_infer_grid: host only), cuts between the recovered lines and takes its rows out of the file's CSR
+            import tempfile
+            from gcge_amd import load_matrix_market
+            from gcge_amd.lib import hip_lib
+            path = os.path.join(tempfile.gettempdir(), "gcge_ballfile_%s_%d.mtx" % (os.environ.get("MASTER_PORT", "0"), ball))
+            h.gcge_save_matrix_market.argtypes = [C.c_char_p, C.POINTER(CSR), C.c_int]
+            if rank == 0:
+                assert h.gcge_save_matrix_market(path.encode(), C.byref(Ag), 1) == 0
+            dist.barrier()
+            L = load_matrix_market(path)
+            dist.barrier()
+            if rank == 0:
+                os.remove(path)
+            assert (L.nrows, L.nnz) == (Ag.nrows, Ag.nnz)
+            gl = hip_lib()
+            gl.gcge_hip_star_infer_grid.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+            fd = (C.c_int * 3)()
+            fbox = np.zeros(n_global, dtype=np.int32)
+            assert gl.gcge_hip_star_infer_grid(L.nrows, L.rowptr, L.colidx, fd, fbox.ctypes.data_as(C.POINTER(C.c_int))) == 1, "no grid found in the rows of the file"
+            bdims, box = tuple(int(v) for v in fd), fbox
+            assert all(d <= ball for d in bdims) and np.all(np.diff(box.astype(np.int64)) > 0), (bdims,)
+        part = gdist.partition_lines(box, bdims[0], world)
         assert part[0] == 0 and part[-1] == n_global and all(part[q] < part[q + 1] for q in range(world)), part
-        assert all(q == 0 or box[part[q]] // ball != box[part[q] - 1] // ball for q in range(world)), "cuts must lie between grid lines"
-        A, _ = make_problem("sio2ball", ball, row_begin=part[rank], row_end=part[rank + 1], **kw)
-        geometry = ((ball, ball, ball), box)
+        assert all(q == 0 or box[part[q]] // bdims[0] != box[part[q] - 1] // bdims[0] for q in range(world)), "cuts must lie between grid lines"
+        if ballfile:
+            rp = np.ctypeslib.as_array(L.rowptr, shape=(n_global + 1,))
+            lo, hi = int(rp[part[rank]]), int(rp[part[rank + 1]])
+            srp = np.ascontiguousarray(rp[part[rank]:part[rank + 1] + 1] - lo, dtype=np.int32)
+            sci = np.ascontiguousarray(np.ctypeslib.as_array(L.colidx, shape=(int(L.nnz),))[lo:hi], dtype=np.int32)
+            sva = np.ascontiguousarray(np.ctypeslib.as_array(L.val, shape=(int(L.nnz),))[lo:hi], dtype=np.float64)
+            keep += [srp, sci, sva]
+            A = CSR(part[rank + 1] - part[rank], n_global, part[rank], hi - lo, srp.ctypes.data_as(C.POINTER(C.c_int)),
+                    sci.ctypes.data_as(C.POINTER(C.c_int)), sva.ctypes.data_as(C.POINTER(C.c_double)))
+        else:
+            A, _ = make_problem("sio2ball", ball, row_begin=part[rank], row_end=part[rank + 1], **kw)
+        geometry = (bdims, box)
         sio2 = ball            # (the checks below that only ask "an SiO2-like matrix?")
     elif sio2:
         from gcge_amd.lib import make_problem
@@ -139,9 +177,9 @@ def main():
         assert form.startswith("spmm_star+spmm_dense"), (rank, form)
         assert g.gcge_hip_mat_star_masked_form(mat) == 3, "a slab of a masked grid takes the third form of the sweep"
         st = (C.c_long * 8)()
-        assert g.gcge_hip_mat_star_stats(mat, st) == 1 and tuple(st[:4]) == (ball, ball, ball, 6) and st[5] == n_loc, list(st)
+        assert g.gcge_hip_mat_star_stats(mat, st) == 1 and tuple(st[:4]) == tuple(bdims) + (6,) and st[5] == n_loc, list(st)
         assert st[4] >= 0.7 * n_loc, ("most rows of the slab are star rows", list(st))
-        plane = ball * ball
+        plane = bdims[0] * bdims[1]
         assert (st[6], st[7]) == (int(box[part[rank]]) // plane, int(box[part[rank + 1] - 1]) // plane + 1), (list(st), part)
         Xw = uniform(6, (n_global, 66)) - 0.5
         Yw = S @ Xw

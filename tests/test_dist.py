@@ -195,6 +195,14 @@ def test_ranks_on_one_gpu_hip_slabs_of_a_masked_grid_keep_the_sweep(world, G):
 
 
 @pytest.mark.gpu
+def test_two_ranks_on_one_gpu_masked_grid_from_a_file_geometry_recovered():
+    """The flow for the reference's real SiO2 file on two devices: a Matrix-Market file (no grid named), every rank recovers the
+    geometry from the file's rows (gcge_hip_star_infer_grid), the rows are cut between the recovered grid lines, each rank uploads its
+    slab with that geometry — the slabs keep the plane sweep (third form), products and the SPMD solve match the global matrix."""
+    _run("hip", world=2, spec="ballfile:24")
+
+
+@pytest.mark.gpu
 def test_native_worker_one_rank_slab_of_a_masked_grid():
     """gcge_hip_mat_create_slab_grid (RCCL constructor with the geometry named) as a world of one rank."""
     _run("hip_native", world=1, spec="sio2ball:24")
