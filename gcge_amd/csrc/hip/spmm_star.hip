@@ -53,7 +53,8 @@ struct StarMat {
   void* d_lines;   // masked grids whose lines are runs of rows: (base, xs | xe << 16) per line (y, z) — the third form (spmm_star3m_kernel); NULL: second form
   int* d_prange3;  // ... and the plane ranges of its 16 x 8 patches
   int* d_order3; int npatch3;   // ... and those of them that have rows, longest range first
-  bool masked_slab;             // a row slab of a masked grid (halo rows among the lines: third form only, no interior / boundary split)
+  bool masked_slab;             // a row slab of a masked grid (halo rows among the lines: third form only)
+  int shared_lo, shared_hi;     // ... 1: its first / last plane holds lines of the neighbouring slab as well (the cut runs between lines)
 };
 
 // staging plan of a thread: unit u = tid + 1024 q, point u >> 2, 16-byte part u & 3
@@ -1060,6 +1061,7 @@ static bool star_infer_box(int nrows, const int* rowptr, const int* colidx, std:
           const int c = colidx[q];
           if (c < r1 || c >= s1) continue;
           const int lc = lineof[c], xc = xoff[lc] + (c - lstart[lc]), yc = lc - pstart[p + 1];
+          if (x - xc <= -(1 << 20) || x - xc >= (1 << 20) || y - yc <= -(1 << 20) || y - yc >= (1 << 20)) return false;   // (the key packs two 22-bit fields)
           ++pv[(long)(x - xc + (1 << 20)) * (1L << 22) + (y - yc + (1 << 20))];
         }
       }
@@ -1080,7 +1082,9 @@ static bool star_infer_box(int nrows, const int* rowptr, const int* colidx, std:
       xmin = std::min(xmin, x0); xmax = std::max(xmax, x1); ymin = std::min(ymin, y); ymax = std::max(ymax, y);
     }
   const long nx = xmax - xmin + 1, ny = ymax - ymin + 1, nz = np;
-  if (nx * ny * nz >= (1L << 31) || nx * ny * nz > 64L * nrows) return false;   // (a box far larger than the domain: the lines did not line up)
+  // a box far larger than the domain: the lines did not line up (a ball fills 52 % of its box, a thin slab of one more: 8 x the rows is
+  // ample — and bounds the point-wise map of the box, 4 bytes per box point on the host and on the device, by 32 bytes per row)
+  if (nx * ny * nz >= (1L << 31) || nx * ny * nz > 8L * nrows) return false;
   box_->resize((size_t)nrows);
   for (int p = 0; p < np; ++p)
     for (int l = pstart[p]; l < pstart[p + 1]; ++l) {
@@ -1315,6 +1319,15 @@ extern "C" void* gcge_hip_star_build(int nrows, int ncols_local, long row_begin,
     }
   }
   S->masked_slab = M.box != nullptr && M.box_cols && ncols_local != nrows;
+  S->shared_lo = S->shared_hi = 0;
+  if (S->masked_slab) {
+    const long pl = (long)H->g.nx * H->g.ny;
+    for (int c = nrows; c < ncols_local; ++c) {
+      const int z = (int)(M.box[c] / pl);
+      if (z == H->g.zs) S->shared_lo = 1;
+      if (z == H->g.ze - 1) S->shared_hi = 1;
+    }
+  }
   S->g = H->g; S->R = H->R; S->nclean = H->nclean; S->nrows = nrows; S->c = H->c;
   S->iso = memcmp(H->c.cx, H->c.cy, sizeof(H->c.cx)) == 0 && memcmp(H->c.cx, H->c.cz, sizeof(H->c.cx)) == 0;
   if (S->masked_slab && (S->d_lines == nullptr || !S->iso)) {         // a slab of a masked grid: the line table or nothing (the row map of the second form knows no halo rows)
@@ -1351,7 +1364,15 @@ extern "C" void gcge_hip_star_stats(const void* sm, long* out) {   // nx, ny, nz
 // STAR_R planes on either side of an output plane whatever the arm length).  Returns 0 when the slab has no halo or no such plane.
 extern "C" int gcge_hip_star_interior(const void* sm, int* ilo, int* ihi) {
   const StarGeom& g = ((const StarMat*)sm)->g;
-  if (((const StarMat*)sm)->masked_slab) { if (ilo) *ilo = g.zs; if (ihi) *ihi = g.ze; return 0; }   // (its first / last plane may be shared with a neighbour: one sweep after the exchange)
+  if (((const StarMat*)sm)->masked_slab) {
+    // a plane shared with the neighbour holds halo lines itself: every output plane within R of it waits for the exchange
+    const StarMat* S = (const StarMat*)sm;
+    const int lo = g.zmin < g.zs || S->shared_lo ? g.zs + STAR_R + S->shared_lo : g.zs;
+    const int hi = g.ze < g.zmax || S->shared_hi ? g.ze - STAR_R - S->shared_hi : g.ze;
+    if (ilo) *ilo = lo;
+    if (ihi) *ihi = hi;
+    return hi > lo;
+  }
   const int lo = g.zmin < g.zs ? g.zs + STAR_R : g.zs, hi = g.ze < g.zmax ? g.ze - STAR_R : g.ze;
   if (ilo) *ilo = lo;
   if (ihi) *ihi = hi;
@@ -1402,7 +1423,9 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
     switch (g_star_dbg) { STAR_DBG(1) STAR_DBG(2) STAR_DBG(8) STAR_DBG(3) STAR_DBG(9) STAR_DBG(16) default: break; }
   const bool dot = part != nullptr;
   if (third) {
-    static bool attr_set = false;
+    static bool attr_dev[64] = {};                                    // per device: a process may drive several
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_dev[dev_ & 63];
     if (!attr_set) {
       bool ok = true;
       ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_star3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STAR3_LDS) == hipSuccess;
@@ -1415,7 +1438,8 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
 #define STAR_LAUNCH3(DOT, SLAB) hipLaunchKernelGGL((spmm_star3_kernel<DOT, SLAB>), grid, dim3(1024), STAR3_LDS, stream, g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax, \
                                                    dlo, dhi, S->c, dv, xv, (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part, cv, g_star_xcd)
     if (g_star_dbg == 32 && !dot && !slab) {
-      static bool probe_attr = false;
+      static bool probe_dev[64] = {};
+      bool& probe_attr = probe_dev[dev_ & 63];
       if (!probe_attr) { GCGE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_star3_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STAR3_LDS)); probe_attr = true; }
       hipLaunchKernelGGL((spmm_star3_kernel<false, false, true>), grid, dim3(1024), STAR3_LDS, stream, g.nx, g.ny, g.zs, g.ze, g.zmin, g.zmax,
                          dlo, dhi, S->c, dv, xv, (size_t)ldx, yv, (size_t)ldy, ncols, zlo, zhi, zlen, ntx, part, cv, g_star_xcd);
@@ -1427,7 +1451,9 @@ static int star_launch(const StarMat* S, const double* d_x, long ldx, double* d_
     return nb;
   }
   if (third_m) {
-    static bool attr_m = false;
+    static bool attr_mdev[64] = {};
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    bool& attr_m = attr_mdev[dev_ & 63];
     if (!attr_m) {
       bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_star3m_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STAR3M_LDS) == hipSuccess;
       ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_star3m_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STAR3M_LDS) == hipSuccess;

@@ -187,22 +187,32 @@ def main():
         yw = be.ops.mv_create(66, mat)
         g.gcge_hip_spmm_dot2_mv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                             C.c_void_p, C.c_void_p, C.c_void_p]
-        p0, s0_ = C.c_long(), C.c_long()
-        g.gcge_hip_star_product_stats(C.byref(p0), C.byref(s0_))
-        for m, a, b in [(64, 0, 0), (16, 2, 4), (17, 1, 0), (30, 3, 2), (66, 0, 0), (2, 8, 0)]:
-            be.ops.spmm(mat, xw, yw, (a, b), (a + m, b + m))
-            got = be.mv_to_numpy(yw, n_loc, b, b + m)
-            err = np.max(np.abs(got - Yw[part[rank]:part[rank + 1], a:a + m]))
-            assert err < 1e-12, "sweep on a slab of a masked grid (m=%d, columns %d -> %d) differs: %g" % (m, a, b, err)
-        for m, a, b in [(64, 0, 0), (30, 4, 2)]:
-            dots, yy = np.zeros(m), np.zeros(m)
-            g.gcge_hip_spmm_dot2_mv(mat, xw, yw, (C.c_int * 2)(a, b), (C.c_int * 2)(a + m, b + m), dots.ctypes.data, yy.ctypes.data, be.ops_handle)
-            Yl, Xl = Yw[part[rank]:part[rank + 1], a:a + m], Xw[part[rank]:part[rank + 1], a:a + m]
-            assert np.max(np.abs(be.mv_to_numpy(yw, n_loc, b, b + m) - Yl)) < 1e-12
-            assert np.allclose(dots, (Xl * Yl).sum(0), rtol=1e-11, atol=1e-9) and np.allclose(yy, (Yl * Yl).sum(0), rtol=1e-11), m
-        p1, s1_ = C.c_long(), C.c_long()
-        g.gcge_hip_star_product_stats(C.byref(p1), C.byref(s1_))
-        assert world == 1 or p1.value - p0.value >= 7, "the products did not go through the grid form"   # (one rank: no exchange, the whole-matrix path — not counted)
+        g.gcge_hip_set_halo_overlap.argtypes = [C.c_int]
+        for overlap in (0, 1):
+            # (overlap: the planes at least 6 away from a plane that holds halo lines — a neighbour's planes, or the slab's own first /
+            #  last plane when the cut runs through it — are swept while the halo travels, the others after the exchange)
+            g.gcge_hip_set_halo_overlap(overlap)
+            p0, s0_ = C.c_long(), C.c_long()
+            g.gcge_hip_star_product_stats(C.byref(p0), C.byref(s0_))
+            for m, a, b in [(64, 0, 0), (16, 2, 4), (17, 1, 0), (30, 3, 2), (66, 0, 0), (2, 8, 0)]:
+                be.ops.spmm(mat, xw, yw, (a, b), (a + m, b + m))
+                got = be.mv_to_numpy(yw, n_loc, b, b + m)
+                err = np.max(np.abs(got - Yw[part[rank]:part[rank + 1], a:a + m]))
+                assert err < 1e-12, "sweep on a slab of a masked grid (overlap=%d, m=%d, columns %d -> %d) differs: %g" % (overlap, m, a, b, err)
+            for m, a, b in [(64, 0, 0), (30, 4, 2)]:
+                dots, yy = np.zeros(m), np.zeros(m)
+                g.gcge_hip_spmm_dot2_mv(mat, xw, yw, (C.c_int * 2)(a, b), (C.c_int * 2)(a + m, b + m), dots.ctypes.data, yy.ctypes.data, be.ops_handle)
+                Yl, Xl = Yw[part[rank]:part[rank + 1], a:a + m], Xw[part[rank]:part[rank + 1], a:a + m]
+                assert np.max(np.abs(be.mv_to_numpy(yw, n_loc, b, b + m) - Yl)) < 1e-12
+                assert np.allclose(dots, (Xl * Yl).sum(0), rtol=1e-11, atol=1e-9) and np.allclose(yy, (Yl * Yl).sum(0), rtol=1e-11), (overlap, m)
+            p1, s1_ = C.c_long(), C.c_long()
+            g.gcge_hip_star_product_stats(C.byref(p1), C.byref(s1_))
+            assert world == 1 or p1.value - p0.value >= 7, "the products did not go through the grid form"   # (one rank: no exchange, the whole-matrix path — not counted)
+            inner = (st[7] - st[6]) - 7 * ((rank > 0) + (rank < world - 1))       # planes that surely need no halo row
+            if world > 1 and overlap and inner > 0:
+                assert s1_.value - s0_.value >= 5, "no product swept its interior planes while the halo travelled"
+            if not overlap:
+                assert s1_.value == s0_.value
         be.ops.mv_destroy(xw, 66); be.ops.mv_destroy(yw, 66)
     if star and mode in ("hip", "hip_native"):
         # every slab took the grid form, sits where the partition put it, and sweeps its inner planes while the halo travels
