@@ -358,7 +358,9 @@ extern "C" void* gcge_hip_dense_build_rows(int nrows, int ncols_local, const int
   // tail of its longest rows.  The remainder is therefore searched again (shorter seeds, smaller row sets) and what it yields becomes a
   // second, third ... launch of the block kernel, ordered behind the first by the stream: one owner per row and launch, still bit-reproducible.
   std::vector<int> layer_item = {0, (int)H.items.size()};
-  if (blocks && g_dense_layers > 1) {
+  // (only under the sweep: there the remainder holds nothing but what differs from the star; on a whole matrix every stencil row of
+  //  >= 32 entries would be tried as a seed again in every layer — 20 s of upload at 2·10⁶ rows for nothing)
+  if (blocks && g_dense_layers > 1 && not_listed != nullptr) {
     for (int l = 1; l < g_dense_layers && l < 8; ++l) {
       DenseHost H2;
       if (!dense_build_host(nrows, ncols_local, H.rem_rowptr.data(), H.rem_col.data(), H.rem_val.data(), g_dense_layer_len, &H2, 8)) break;
