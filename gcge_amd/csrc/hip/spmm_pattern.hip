@@ -38,7 +38,7 @@ extern "C" void gcge_hip_reduce_partials_slabs(const double* d_partial, int nblo
                                                double* d_out, void* stream);
 extern "C" int gcge_hip_ring_pass(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, long L, int nw,
                                   long nb, const double* d_x, long ldx, int m, double* part, long yyo,
-                                  const double* d_lambda, void* stream, long maxoff, double* d_y, long ldy);
+                                  const double* d_lambda, void* stream, long maxoff, double* d_y, long ldy, int gy);
 
 namespace gcge {
 
@@ -485,6 +485,20 @@ __global__ __launch_bounds__(64 * NW) void spmm_pattern_chain2_kernel(
     const double* __restrict__ x, size_t ldx, double* __restrict__ y, size_t ldy, int m, long ntiles, long line,
     double* __restrict__ dot_partial, long yy_offset, int xcd_runs, CgArgs cg) {
   constexpr int DOT = MODE != 0;
+  // gridDim.y > 1: the 16-column passes of one operation in ONE launch (grids that would leave CUs idle pass by pass: the coarse
+  // levels of a multigrid hierarchy); pass blockIdx.y works on columns [16 y, 16 y + 16) of every operand, m = all the columns
+  if (gridDim.y > 1) {
+    const int c0 = 16 * (int)blockIdx.y;
+    x += c0; if (y != nullptr) y += c0;
+    if (dot_partial != nullptr) dot_partial += (size_t)blockIdx.y * gridDim.x * 16;
+    if (cg.r != nullptr) cg.r += c0;
+    if (cg.pnew != nullptr) cg.pnew += c0;
+    if (cg.alpha != nullptr) cg.alpha += c0;
+    if (cg.beta != nullptr) cg.beta += c0;
+    if (cg.flag != nullptr) cg.flag += c0;
+    if (cg.b != nullptr) cg.b += c0;
+    m = min(m - c0, 16);
+  }
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
   __shared__ v2d xch[2][NW][64];
@@ -563,6 +577,16 @@ static long pat_ntiles(long nrows, long line) {
 // 0: use the plain chain kernel
 static int g_pass_streams = 0;   // > 1: the 16-column passes of a CG sweep on that many side streams (gcge_hip_pattern_cg_vals)
 extern "C" void gcge_hip_cg_pass_streams(int n) { g_pass_streams = n < 0 ? 0 : (n > 4 ? 4 : n); }
+// Column passes of one operation merged into ONE launch (gridDim.y = passes) when a pass alone has at most this many blocks:
+// a 128^3 level of a multigrid hierarchy has 128 blocks of 16 waves per pass — half the CUs idle, 64^3 an eighth of them.
+// Same blocks, same partial sums, same results bit for bit; the finest level of config 2 (512 blocks) keeps its passes apart
+// (a pass's working set per XCD is what its L2 holds).  0: never.
+static int g_pass_merge_blocks = -1;   // -1: not set yet (GCGE_PASS_MERGE in the environment, else 256)
+extern "C" void gcge_hip_spmm_pass_merge(int max_blocks) { g_pass_merge_blocks = max_blocks < 0 ? 0 : max_blocks; }
+static int pass_merge_blocks() {
+  if (g_pass_merge_blocks < 0) { const char* e = getenv("GCGE_PASS_MERGE"); g_pass_merge_blocks = e ? atoi(e) : 256; if (g_pass_merge_blocks < 0) g_pass_merge_blocks = 0; }
+  return g_pass_merge_blocks;
+}
 static int g_chain2_nw = 16;
 static int g_chain2_xcd = 2;   // 2: runs of 4 neighbouring tiles per XCD (pass 2 6.50 -> 6.42 ms, fabric reads down); 1: one contiguous eighth of
                                // the tiles per XCD (slower: 3.43 vs 3.19 ms at 256^3); 0: tiles in block order
@@ -590,12 +614,13 @@ static long pat_grid(long span, long ntiles) {
 template <int LT, int MODE, bool VALS>
 static long pat_launch(long nrows, const unsigned short* pid, const void* tab, int npat, const double* x, size_t ldx,
                        double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st,
-                       long cline, int nw, const CgArgs& cg) {
+                       long cline, int nw, const CgArgs& cg, int gy = 1) {
   const int ntab = npat * LT;
+  if (gy > 1 && cline <= 0) return -1;   // merged column passes: the chain2 kernel only
   if (cline > 0) {   // chain + line exchange: nw waves per block, lines of `cline` rows
     if (LT < 5) return -1;
     const long nlines = (nrows + cline - 1) / cline, ntl = (nlines + nw - 1) / nw * (cline / 8);
-#define GCGE_C2(NWV) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), MODE, NWV, VALS>), dim3((unsigned)nb), dim3(64 * NWV), \
+#define GCGE_C2(NWV) hipLaunchKernelGGL((spmm_pattern_chain2_kernel<(LT < 5 ? 5 : LT), MODE, NWV, VALS>), dim3((unsigned)nb, (unsigned)gy), dim3(64 * NWV), \
                        (size_t)ntab * sizeof(PatEntry), st, nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, ntl, cline, partial, yy_off, g_chain2_xcd, cg)
     if (nw == 16) GCGE_C2(16); else if (nw == 8) GCGE_C2(8); else GCGE_C2(4);
 #undef GCGE_C2
@@ -621,18 +646,18 @@ static long pat_launch(long nrows, const unsigned short* pid, const void* tab, i
 template <int MODE>
 static long pat_dispatch(int lt, long nrows, const unsigned short* pid, const void* tab, int npat, const double* x,
                          size_t ldx, double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st,
-                         long cline = 0, int nw = 4, const CgArgs& cg = CgArgs{}) {
+                         long cline = 0, int nw = 4, const CgArgs& cg = CgArgs{}, int gy = 1) {
   if (cg.rowval != nullptr) {   // offsets-only table, values streamed per row (tables of at most 8 slots)
     switch (lt) {
-      case 7: return pat_launch<7, MODE, true>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
-      case 8: return pat_launch<8, MODE, true>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
+      case 7: return pat_launch<7, MODE, true>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg, gy);
+      case 8: return pat_launch<8, MODE, true>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg, gy);
       default: return -1;
     }
   }
   switch (lt) {
-    case 7: return pat_launch<7, MODE, false>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
-    case 8: return pat_launch<8, MODE, false>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
-    case 16: return pat_launch<16, MODE, false>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg);
+    case 7: return pat_launch<7, MODE, false>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg, gy);
+    case 8: return pat_launch<8, MODE, false>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg, gy);
+    case 16: return pat_launch<16, MODE, false>(nrows, pid, tab, npat, x, ldx, y, ldy, m, partial, yy_off, nb, line, st, cline, nw, cg, gy);
     default: return -1;
   }
 }
@@ -695,17 +720,20 @@ extern "C" int gcge_hip_pattern_spmm_vals(int nrows, const unsigned short* d_pid
     double* partc = d_dots ? gcge_hip_partial_ws((size_t)nbc * 16 * npassc * 2) : nullptr;
     const long yyc = (long)nbc * 16 * npassc;
     bool ring = near > 0 && lt == 7 && d_x != d_y && d_rowval == nullptr;
+    const bool merge = npassc > 1 && nbc <= pass_merge_blocks();   // all passes in one launch (gridDim.y)
     for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
-      const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
+      const int m = merge ? ncols : ((ncols - c0 < 16) ? ncols - c0 : 16);
+      const int gy = merge ? npassc : 1;
       double* pp = partc ? partc + (size_t)ps * nbc * 16 : nullptr;
       if (ring) {
         if (gcge_hip_ring_pass(d_dots ? 1 : 0, nrows, d_pid, d_tab, npat, L, nw, nbc, d_x + c0, ldx, m, pp, yyc, nullptr, stc, near,
-                               d_y + c0, ldy) == 0) continue;
+                               d_y + c0, ldy, gy) == 0) { if (merge) break; continue; }
         ring = false;   // declined (first pass): the chain2 kernel below
       }
-      long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyc, nbc, 8, stc, L, nw, cgv)
-                        : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nbc, 8, stc, L, nw, cgv);
+      long rcl = d_dots ? pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyc, nbc, 8, stc, L, nw, cgv, gy)
+                        : pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nbc, 8, stc, L, nw, cgv, gy);
       if (rcl < 0) return -1;
+      if (merge) break;
     }
     if (d_dots) gcge_hip_reduce_partials16(partc, (int)nbc, nbc * 16, ncols, d_dots, stc);
     if (d_dots && d_dots_yy) gcge_hip_reduce_partials16(partc + yyc, (int)nbc, nbc * 16, ncols, d_dots_yy, stc);
@@ -808,7 +836,9 @@ extern "C" int gcge_hip_pattern_cg_vals(int mode, int nrows, const unsigned shor
   static hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   static hipEvent_t ev_fork = nullptr, ev_join[4];
   const hipStream_t st_main = st;
-  const int nside = (g_pass_streams > 1 && npass > 1) ? std::min(g_pass_streams, std::min(npass, 4)) : 0;
+  const bool merge = nw > 0 && npass > 1 && nb <= pass_merge_blocks();   // all passes in one launch (gridDim.y)
+  const int gy = merge ? npass : 1;
+  const int nside = (g_pass_streams > 1 && npass > 1 && !merge) ? std::min(g_pass_streams, std::min(npass, 4)) : 0;
   if (nside > 0) {
     if (ev_fork == nullptr) {
       GCGE_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -821,32 +851,36 @@ extern "C" int gcge_hip_pattern_cg_vals(int mode, int nrows, const unsigned shor
     for (int q = 0; q < nside; ++q) { GCGE_HIP_CHECK(hipEventRecord(ev_join[q], side[q])); GCGE_HIP_CHECK(hipStreamWaitEvent(st_main, ev_join[q], 0)); }
   };
   for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
-    const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
+    const int m = merge ? ncols : ((ncols - c0 < 16) ? ncols - c0 : 16);
     double* pp = part + (size_t)ps * nb * 16;
     long rc;
     if (nside > 0) st = side[ps % nside];
     if (ring) {
-      if (gcge_hip_ring_pass(mode, nrows, d_pid, d_tab, npat, L, nw, nb, d_x + c0, ldx, m, pp, yyo, mode == 4 ? d_alpha + c0 : nullptr, st, near, nullptr, 0) == 0) continue;
+      if (gcge_hip_ring_pass(mode, nrows, d_pid, d_tab, npat, L, nw, nb, d_x + c0, ldx, m, pp, yyo, mode == 4 ? d_alpha + c0 : nullptr, st, near, nullptr, 0, gy) == 0) {
+        if (merge) break;
+        continue;
+      }
       ring = false;   // declined (first pass): the chain2 kernel below
     }
-    if (mode == 2) { CgArgs cg = CgArgs{}; cg.rowval = d_rowval; rc = pat_dispatch<2>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg); }
+    if (mode == 2) { CgArgs cg = CgArgs{}; cg.rowval = d_rowval; rc = pat_dispatch<2>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg, gy); }
     else if (mode == 4) {
       const CgArgs cg = {nullptr, 0, nullptr, 0, d_alpha + c0, nullptr, nullptr, nullptr, 0, d_rowval};
-      rc = pat_dispatch<4>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
+      rc = pat_dispatch<4>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg, gy);
     } else if (mode == 5) {
       const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, nullptr, nullptr, nullptr, d_b + c0, (size_t)ldb, d_rowval};
-      rc = pat_dispatch<5>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
+      rc = pat_dispatch<5>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg, gy);
     } else if (mode == 6) {
       const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, nullptr, nullptr, nullptr, 0, d_rowval};
-      rc = pat_dispatch<6>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
+      rc = pat_dispatch<6>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg, gy);
     } else if (mode == 7) {   // d_r: p_{k-1} (read only), d_b: the previous iteration's beta
       const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0, d_b + c0, 0, d_rowval};
-      rc = pat_dispatch<7>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
+      rc = pat_dispatch<7>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg, gy);
     } else {
       const CgArgs cg = {d_r + c0, (size_t)ldr, d_pnew + c0, (size_t)ldp, d_alpha + c0, d_beta + c0, d_flag + c0, nullptr, 0, d_rowval};
-      rc = pat_dispatch<3>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg);
+      rc = pat_dispatch<3>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, nullptr, 0, m, pp, yyo, nb, line, st, cline, nw, cg, gy);
     }
     if (rc < 0) { join(); return -1; }
+    if (merge) break;
   }
   join();
   st = st_main;

@@ -273,6 +273,14 @@ __global__ __launch_bounds__(64 * NW) void spmm_ring_kernel(
     const double* __restrict__ x, size_t ldx, int m, int ntiles, long line, long step_rows, int xcd_runs,
     double* __restrict__ dot_partial, long yy_offset, const double* __restrict__ lambda, double* __restrict__ y, size_t ldy) {
   static_assert(MODE == 0 || MODE == 1 || MODE == 2 || MODE == 4, "product (with sums) and the passes that store nothing");
+  // gridDim.y > 1: the 16-column passes of one operation in one launch (spmm_pattern.hip, g_pass_merge_blocks): pass blockIdx.y
+  // works on columns [16 y, 16 y + 16) of X / Y / lambda and on its own slab of partial sums, m = all the columns
+  if (gridDim.y > 1) {
+    const int c0 = 16 * (int)blockIdx.y;
+    x += c0; if (y != nullptr) y += c0; if (lambda != nullptr) lambda += c0;
+    if (dot_partial != nullptr) dot_partial += (size_t)blockIdx.y * gridDim.x * 16;
+    m = min(m - c0, 16);
+  }
   constexpr int R = DP + 3;
   constexpr unsigned PB = Plane<NW>::PB;
   extern __shared__ __align__(16) unsigned char smem_raw[];   // ONE LDS object: ring | table | coefficients | reduction
@@ -344,7 +352,7 @@ extern "C" void gcge_hip_spmm_ring_tune(int on, int depth) { g_ring_on = on; if 
 
 template <int MODE, int NW, int DP, bool WIDE>
 static int ring_launch(long nb, hipStream_t st, long nrows, const unsigned short* pid, const void* tab, int ntab, const double* x,
-                       size_t ldx, int m, long ntl, long line, double* part, long yyo, const double* lambda, double* y, size_t ldy) {
+                       size_t ldx, int m, long ntl, long line, double* part, long yyo, const double* lambda, double* y, size_t ldy, int gy) {
   constexpr unsigned PB = Plane<NW>::PB;
   if (ntl > 0x7fffffffL) return -1;
   // tiles of a block: b0, b0 + nb, ... — one grid plane apart when nb is a whole number of line groups
@@ -359,7 +367,7 @@ static int ring_launch(long nb, hipStream_t st, long nrows, const unsigned short
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return -1; }
     granted = lds;
   }
-  hipLaunchKernelGGL((spmm_ring_kernel<MODE, NW, DP, WIDE>), dim3((unsigned)nb), dim3(64 * NW), lds, st, nrows, pid,
+  hipLaunchKernelGGL((spmm_ring_kernel<MODE, NW, DP, WIDE>), dim3((unsigned)nb, (unsigned)gy), dim3(64 * NW), lds, st, nrows, pid,
                      (const PatEntry*)tab, ntab, x, ldx, m, (int)ntl, line, step_rows, g_ring_xcd, part, yyo, lambda, y, ldy);
   return 0;
 }
@@ -369,21 +377,21 @@ extern "C" long gcge_hip_spmm_ring_launches(void) { return g_ring_launches; }
 
 template <int MODE, int NW, bool WIDE>
 static int ring_pass_mode(long nb, hipStream_t st, long nrows, const unsigned short* pid, const void* tab, int ntab, const double* x,
-                          size_t ldx, int m, long ntl, long L, double* part, long yyo, const double* lambda, double* y, size_t ldy) {
+                          size_t ldx, int m, long ntl, long L, double* part, long yyo, const double* lambda, double* y, size_t ldy, int gy) {
   int rc = -1;
-  if (g_ring_depth == 3) rc = ring_launch<MODE, NW, 3, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda, y, ldy);
-  if (rc != 0) rc = ring_launch<MODE, NW, 2, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda, y, ldy);
+  if (g_ring_depth == 3) rc = ring_launch<MODE, NW, 3, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda, y, ldy, gy);
+  if (rc != 0) rc = ring_launch<MODE, NW, 2, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda, y, ldy, gy);
   return rc;
 }
 template <int NW, bool WIDE>
 static int ring_pass_nw(int mode, long nb, hipStream_t st, long nrows, const unsigned short* pid, const void* tab, int ntab,
                         const double* x, size_t ldx, int m, long ntl, long L, double* part, long yyo, const double* lambda,
-                        double* y, size_t ldy) {
+                        double* y, size_t ldy, int gy) {
   switch (mode) {
-    case 0: return ring_pass_mode<0, NW, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, nullptr, 0, nullptr, y, ldy);
-    case 1: return ring_pass_mode<1, NW, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, nullptr, y, ldy);
-    case 2: return ring_pass_mode<2, NW, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, nullptr, nullptr, 0);
-    case 4: return ring_pass_mode<4, NW, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda, nullptr, 0);
+    case 0: return ring_pass_mode<0, NW, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, nullptr, 0, nullptr, y, ldy, gy);
+    case 1: return ring_pass_mode<1, NW, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, nullptr, y, ldy, gy);
+    case 2: return ring_pass_mode<2, NW, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, nullptr, nullptr, 0, gy);
+    case 4: return ring_pass_mode<4, NW, WIDE>(nb, st, nrows, pid, tab, ntab, x, ldx, m, ntl, L, part, yyo, lambda, nullptr, 0, gy);
   }
   return -1;
 }
@@ -395,7 +403,8 @@ static int ring_pass_nw(int mode, long nb, hipStream_t st, long nrows, const uns
 // maxoff: the largest |column offset| (rows) in the table: decides between 32-bit lane offsets and 64-bit addresses.
 extern "C" int gcge_hip_ring_pass(int mode, int nrows, const unsigned short* d_pid, const void* d_tab, int npat, long L, int nw,
                                   long nb, const double* d_x, long ldx, int m, double* part, long yyo,
-                                  const double* d_lambda, void* stream, long maxoff, double* d_y, long ldy) {
+                                  const double* d_lambda, void* stream, long maxoff, double* d_y, long ldy, int gy) {
+  if (gy < 1) gy = 1;
   if (!g_ring_on || (mode != 0 && mode != 1 && mode != 2 && mode != 4) || (nrows & 7) || nrows < 8 || ((uintptr_t)d_pid & 15) || L % 8 || L < 8) return -1;
   if (((uintptr_t)d_x & 15) || (ldx & 1)) return -1;
   const long nlines = ((long)nrows + L - 1) / L, ntl = (nlines + nw - 1) / nw * (L / 8);
@@ -407,12 +416,12 @@ extern "C" int gcge_hip_ring_pass(int mode, int nrows, const unsigned short* d_p
   int rc = -1;
   // lane offset = 2 GiB + (row in slice, column pair) + stencil offset, as an unsigned 32-bit number
   const bool wide = g_ring_wide || (double)(maxoff + 16) * (double)ldx * 8.0 >= 2147483648.0 - 4096.0;
-#define GCGE_RING_NW(N) (wide ? ring_pass_nw<N, true>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda, d_y, (size_t)ldy) \
-                              : ring_pass_nw<N, false>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda, d_y, (size_t)ldy))
+#define GCGE_RING_NW(N) (wide ? ring_pass_nw<N, true>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda, d_y, (size_t)ldy, gy) \
+                              : ring_pass_nw<N, false>(mode, nb, st, nrows, d_pid, d_tab, ntab, d_x, (size_t)ldx, m, ntl, L, part, yyo, d_lambda, d_y, (size_t)ldy, gy))
   if (nw == 16) rc = GCGE_RING_NW(16);
   else if (nw == 8) rc = GCGE_RING_NW(8);
   else if (nw == 4) rc = GCGE_RING_NW(4);
 #undef GCGE_RING_NW
-  if (rc == 0) ++g_ring_launches;
+  if (rc == 0) g_ring_launches += gy;   // column passes that took the ring (a merged launch carries gy of them)
   return rc;
 }

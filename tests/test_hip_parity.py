@@ -993,6 +993,55 @@ def test_fused_cg_device_scalars_equal_host_scalars(hip):
     hip.free_matrix(mat)
 
 
+@pytest.mark.parametrize("size,nrhs", [(32, 64), (24, 40), (16, 22), (64, 64)])
+def test_merged_column_passes_equal_separate_passes(hip, size, nrhs):
+    """Grids whose 16-column passes would leave CUs idle (the coarse levels of a multigrid hierarchy: a 128^3 level has 128
+    blocks per pass) run all passes of an operation as ONE launch, pass = blockIdx.y (spmm_pattern.hip g_pass_merge_blocks,
+    chain2 and ring kernels).  Same blocks, same partial sums: product, residual norms and a whole fused-CG solve (start
+    sweep, both passes, stored and rebuilt residual) are bit-identical to the launches pass by pass, ragged widths included."""
+    g = hip.g
+    g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
+    g.gcge_hip_spmm_pass_merge.argtypes = [C.c_int]
+    g.gcge_hip_bpcg_residual_form.argtypes = [C.c_int]
+    FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+    g.gcge_hip_residual_hook.restype = C.c_void_p
+    hook = FN(g.gcge_hip_residual_hook())
+    A, _ = make_problem("lap3d", size)
+    S = csr_to_scipy(A); n = A.nrows
+    mat = hip.matrix(A)
+    Bm = uniform(91, (n, nrhs)) - 0.5
+    X0 = uniform(92, (n, nrhs)) - 0.5
+    lam = uniform(93, (nrhs,)) * 3.0
+    out = {}
+    try:
+        for merge in (256, 0):
+            g.gcge_hip_spmm_pass_merge(merge)
+            xin = hip.mv_from_numpy(mat, X0); y = hip.mv_from_numpy(mat, np.full((n, nrhs), 3.0))
+            hip.ops.spmm(mat, xin, y, (0, 0), (nrhs, nrhs))
+            rs = np.zeros(nrhs)
+            assert hook(mat, None, xin, 0, nrhs, lam.ctypes.data, rs.ctypes.data) == 1
+            res = [hip.mv_to_numpy(y, n, 0, nrhs), rs]
+            hip.ops.mv_destroy(y, nrhs); hip.ops.mv_destroy(xin, nrhs)
+            for form in (1, 2):                       # residual rebuilt from the directions / stored
+                g.gcge_hip_bpcg_residual_form(form)
+                g.gcge_hip_bpcg_setup(hip.ops_handle, 9, 1e-3, 1e-12, b"abs")
+                b = hip.mv_from_numpy(mat, Bm); x = hip.mv_from_numpy(mat, X0)
+                hip.ops.multi_linear_solver(mat, b, x, (0, 0), (nrhs, nrhs))
+                it = C.c_int(); g.gcge_hip_bpcg_stats(None, None, C.byref(it))
+                res += [hip.mv_to_numpy(x, n, 0, nrhs), it.value]
+                hip.ops.mv_destroy(b, nrhs); hip.ops.mv_destroy(x, nrhs)
+            out[merge] = res
+    finally:
+        g.gcge_hip_spmm_pass_merge(256)
+        g.gcge_hip_bpcg_residual_form(0)
+        g.gcge_hip_bpcg_setup(hip.ops_handle, 30, 1e-2, 1e-14, b"abs")
+    np.testing.assert_allclose(out[256][0], S @ X0, rtol=0, atol=1e-13 * np.abs(S @ X0).max())
+    for a, b in zip(out[256], out[0]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    assert out[256][3] > 0 and out[256][5] > 0
+    hip.free_matrix(mat)
+
+
 def test_fused_cg_small_direction_ring(hip):
     """Direction rings of 2 extra slots (what is left at BASELINE config 4's shape, where the solver's own blocks take 244 of
     288 GB) against the full ring and against no ring at all (GCGE_CG_RING caps the slots): x is brought up to date every
