@@ -1272,6 +1272,75 @@ extern "C" int gcge_hip_cg_start_scaled_mv(void* mat, void** x, int xc0, const d
   return 0;
 }
 
+// ---- two steps of a V-cycle in one sweep each (GCGE_SetBlockAMGFusions, include/gcge_solver.h; csrc/host/lin_sol.c) ------------
+// r[:, rc0:rc0+m) = b[:, bc0:bc0+m) - A x[:, xc0:xc0+m): the start sweep of the block CG (kernel MODE 5) with ONE store — the
+// product is rounded on its own and then subtracted from b, exactly what MatDotMultiVec + MultiVecAxpby(1, b, -1, r) leave
+// (reference src/ops_lin_sol.c:596-606): 3 block streams instead of 5.  Pattern matrices only; 0 = declined, nothing touched.
+static int HIP_AmgResidual(void* mat, void** b, int bc0, void** x, int xc0, void** r, int rc0, int m, struct OPS_* ops) {
+  (void)ops;
+  GCGE_HIP_MAT_* A = (GCGE_HIP_MAT_*)mat;
+  GcgeHipMV *vx = (GcgeHipMV*)x, *vb = (GcgeHipMV*)b, *vr = (GcgeHipMV*)r;
+  if (A == nullptr || A->rect_ncols > 0 || A->d_pid == nullptr || g_spmm_path != 0 || m <= 0) return 0;
+  if ((m & 1) || (xc0 & 1) || (bc0 & 1) || (rc0 & 1) || (vx->ld & 1) || (vb->ld & 1) || (vr->ld & 1)) return 0;
+  if (((uintptr_t)vx->d & 15) || ((uintptr_t)vb->d & 15) || ((uintptr_t)vr->d & 15)) return 0;
+  if (vr == vx || vr == vb || (A->nghost > 0 && m > A->buf_cols)) return 0;
+  if (xc0 < 0 || xc0 + m > vx->ncols || bc0 < 0 || bc0 + m > vb->ncols || rc0 < 0 || rc0 + m > vr->ncols) return 0;
+  if (A->nrows != vx->nrows || A->nrows != vb->nrows || A->nrows != vr->nrows || A->nrows + A->nghost > vx->nrows_alloc) return 0;
+  if (real_perm(vx->perm) != real_perm(A->perm) || real_perm(vb->perm) != real_perm(A->perm) || real_perm(vr->perm) != real_perm(A->perm)) return 0;
+  enter();
+  SlotTimer tm_("AMG residual (fused)", m);
+  double* dd = stage_d(6 * (size_t)m);                         // the sweep's column sums |r_j|^2: not used here
+  const CgPass cg = {5, vr->d + rc0, vr->ld, vr->d + rc0, vr->ld, nullptr, nullptr, nullptr, vb->d + bc0, vb->ld};
+  const int rc = spmm_halo(A, vx, xc0, nullptr, 0, m, dd, nullptr, &cg);
+  GCGE_REQUIRE(rc == 0, "AMG residual: kernel launch");
+  return 1;
+}
+
+// xf[:, f0:f0+m) += P xc[:, c0:c0+m) for a prolongation with ONE entry per row (aggregation: gcge_multigrid.h) — the product is
+// rounded, then added (no fused multiply-add), as MatDotMultiVec into a work block + MultiVecAxpby(1, work, 1, xf) do
+// (reference src/ops_lin_sol.c:626-640): the fine block is read and written once, the work block not at all.
+typedef double v2d_pa __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void prolong_add_kernel(long nrows, const int* __restrict__ colidx, const double* __restrict__ val,
+    const double* __restrict__ xc, long ldc, double* __restrict__ xf, long ldf, int m2, int tpr) {
+#pragma clang fp contract(off)
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr, rpb = 256 / tpr;
+  if (tx >= m2) return;
+  const long slab = (((nrows + gridDim.x - 1) / gridDim.x) + rpb - 1) / rpb * rpb;
+  const long rend = min(nrows, ((long)blockIdx.x + 1) * slab);
+  for (long row = (long)blockIdx.x * slab + ty; row < rend; row += 2L * rpb) {
+    const long row2 = row + rpb;
+    const bool two = row2 < rend;
+    const long rb = two ? row2 : row;
+    const int ca = colidx[row], cb = colidx[rb];
+    const double va = val[row], vb = val[rb];
+    const v2d_pa ea = *reinterpret_cast<const v2d_pa*>(xc + (long)ca * ldc + 2 * tx);
+    const v2d_pa eb = *reinterpret_cast<const v2d_pa*>(xc + (long)cb * ldc + 2 * tx);
+    const v2d_pa fa = __builtin_nontemporal_load(reinterpret_cast<const v2d_pa*>(xf + row * ldf + 2 * tx));
+    const v2d_pa fb = __builtin_nontemporal_load(reinterpret_cast<const v2d_pa*>(xf + rb * ldf + 2 * tx));
+    const v2d_pa ta = {va * ea.x, va * ea.y}, tb = {vb * eb.x, vb * eb.y};
+    __builtin_nontemporal_store(v2d_pa{ta.x + fa.x, ta.y + fa.y}, reinterpret_cast<v2d_pa*>(xf + row * ldf + 2 * tx));
+    if (two) __builtin_nontemporal_store(v2d_pa{tb.x + fb.x, tb.y + fb.y}, reinterpret_cast<v2d_pa*>(xf + rb * ldf + 2 * tx));
+  }
+}
+static int HIP_AmgProlongAdd(void* matP, void** xc, int c0, void** xf, int f0, int m, struct OPS_* ops) {
+  (void)ops;
+  GCGE_HIP_MAT_* P = (GCGE_HIP_MAT_*)matP;
+  GcgeHipMV *vc = (GcgeHipMV*)xc, *vf = (GcgeHipMV*)xf;
+  if (P == nullptr || P->rect_ncols <= 0 || P->rect_one_per_row == 0 || m <= 0 || m / 2 > 256) return 0;
+  if ((m & 1) || (c0 & 1) || (f0 & 1) || (vc->ld & 1) || (vf->ld & 1) || ((uintptr_t)vc->d & 15) || ((uintptr_t)vf->d & 15) || vc == vf) return 0;
+  if (vc->nrows != P->rect_ncols || vf->nrows != P->nrows || c0 < 0 || c0 + m > vc->ncols || f0 < 0 || f0 + m > vf->ncols) return 0;
+  enter();
+  SlotTimer tm_("AMG prolongation + correction (fused)", m);
+  const int m2 = m / 2;
+  int tpr = 1; while (tpr < m2) tpr *= 2;
+  const int rpb = 256 / tpr;
+  long g = ((long)P->nrows + (long)rpb * 8 - 1) / ((long)rpb * 8); if (g > 8192) g = 8192; if (g < 1) g = 1;
+  hipLaunchKernelGGL(prolong_add_kernel, dim3((unsigned)g), dim3(256), 0, g_stream, (long)P->nrows, (const int*)P->d_colidx, (const double*)P->d_val,
+                     (const double*)(vc->d + c0), (long)vc->ld, vf->d + f0, (long)vf->ld, m2, tpr);
+  GCGE_REQUIRE(hipGetLastError() == hipSuccess, "AMG prolongation + correction: kernel launch");
+  return 1;
+}
+
 // Residuals of Ritz pairs of a standard problem in one read of x (GCGE_RESIDUAL_FN, include/gcge_ops.h; kernel MODE 4 of
 // spmm_pattern.hip): res_sq[j] = sum over the local rows of ((A x_j) - lambda_j x_j)^2.  Declines (0) for B != NULL and
 // blocks that cannot be walked in 16-byte column pairs; matrices without pattern form take resid_sq_stored above.  Odd
@@ -1434,4 +1503,5 @@ extern "C" void OPS_HIP_Set(struct OPS_* ops) {
   ops->MultiGridCreate          = gcge_hip_multigrid_create;
   ops->MultiGridDestroy         = gcge_hip_multigrid_destroy;
   GCGE_SetBlockAMGSmoother(gcge_hip_amg_smoother_setup, gcge_hip_amg_smoother_residual, (void*)HIP_MatDotMultiVec);
+  GCGE_SetBlockAMGFusions(HIP_AmgResidual, HIP_AmgProlongAdd, (void*)HIP_MatDotMultiVec);   // r = b - A x and x += P e as one sweep each
 }

@@ -74,6 +74,7 @@ struct GCGE_HIP_MAT_ {
   // rectangular matrices (the prolongations P_l of a multigrid hierarchy, multigrid.hip): nrows x rect_ncols in d_rowptr / d_colidx /
   // d_val, the transpose as a second CSR triple; rect_ncols == 0: an ordinary (symmetric) matrix
   int rect_ncols; int *d_t_rowptr, *d_t_colidx; double* d_t_val;
+  int rect_one_per_row;   // 1: every row of a rectangular matrix holds exactly one entry (aggregation prolongations: the fused x += P e)
   // row slabs: the global rows behind the halo columns (host copy, nghost ints; NULL: not named) and the row partition of all ranks
   // (host, part_world + 1 entries; NULL: unknown) — what MultiGridCreate needs to coarsen a slab (multigrid.hip)
   int* h_ghost_global; long* h_part; int part_world;

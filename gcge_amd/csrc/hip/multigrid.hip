@@ -31,6 +31,8 @@ extern "C" GCGE_HIP_MAT* gcge_hip_mat_create_rect(int nrows, int ncols, const in
   GCGE_REQUIRE(nrows > 0 && ncols > 0 && (size_t)t_rowptr[ncols] == nnz, "gcge_hip_mat_create_rect: the two triples hold the same entries");
   for (size_t k = 0; k < nnz; ++k) GCGE_REQUIRE(colidx[k] >= 0 && colidx[k] < ncols && t_colidx[k] >= 0 && t_colidx[k] < nrows, "gcge_hip_mat_create_rect: index in range");
   P->nrows = nrows; P->nglobal = nrows; P->nnz = (long)nnz; P->rect_ncols = ncols;
+  P->rect_one_per_row = nnz == (size_t)nrows;
+  for (int r = 0; r < nrows && P->rect_one_per_row; ++r) P->rect_one_per_row = rowptr[r + 1] - rowptr[r] == 1;
   auto up = [](const void* h, size_t bytes) { void* d = nullptr; GCGE_HIP_CHECK(hipMalloc(&d, bytes ? bytes : 8)); GCGE_HIP_CHECK(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return d; };
   P->d_rowptr = (int*)up(rowptr, ((size_t)nrows + 1) * sizeof(int));
   P->d_colidx = (int*)up(colidx, nnz * sizeof(int));

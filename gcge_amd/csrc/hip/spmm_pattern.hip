@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
         v2d rn = {rv.x - a0, rv.y - a1};
         if (ok) {
           __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.r + (size_t)row * cg.ldr + 2 * i));
-          __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.pnew + (size_t)row * cg.ldp + 2 * i));
+          if (cg.pnew != cg.r) __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.pnew + (size_t)row * cg.ldp + 2 * i));   // (equal: the residual alone, a V-cycle's r = b - A x)
         }
         d0 = fma(wgt * rn.x, rn.x, d0); d1 = fma(wgt * rn.y, rn.y, d1);
       }
@@ -420,7 +420,7 @@ __device__ __forceinline__ void chain2_body(
       v2d rn = {rv.x - a0, rv.y - a1};
       if (ok) {
         __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.r + (size_t)row * cg.ldr + 2 * i));
-        __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.pnew + (size_t)row * cg.ldp + 2 * i));
+        if (cg.pnew != cg.r) __builtin_nontemporal_store(rn, reinterpret_cast<v2d*>(cg.pnew + (size_t)row * cg.ldp + 2 * i));   // (equal: the residual alone)
       }
       d0 = fma(wgt * rn.x, rn.x, d0); d1 = fma(wgt * rn.y, rn.y, d1);
     }

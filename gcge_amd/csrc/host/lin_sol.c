@@ -156,6 +156,17 @@ static int own_smoother(struct OPS_ *ops)
 	       getenv("GCGE_AMG_HOST_SMOOTHER") == NULL;
 }
 int GCGE_HasBlockAMGSmoother(struct OPS_ *ops) { return own_smoother(ops); }
+/* residual and prolongation + correction as one sweep each where the back-end of this table offers them (include/gcge_solver.h) */
+static GCGE_AMG_RESIDUAL_FN g_fuse_residual = NULL; static GCGE_AMG_PROLONG_ADD_FN g_fuse_prolong = NULL;
+static void *g_fuse_owner = NULL;
+void GCGE_SetBlockAMGFusions(GCGE_AMG_RESIDUAL_FN residual, GCGE_AMG_PROLONG_ADD_FN prolong_add, void *owner)
+{
+	g_fuse_residual = residual; g_fuse_prolong = prolong_add; g_fuse_owner = owner;
+}
+static int own_fusions(struct OPS_ *ops)
+{
+	return g_fuse_owner != NULL && g_fuse_owner == (void*)ops->MatDotMultiVec && getenv("GCGE_AMG_NO_FUSIONS") == NULL;
+}
 static void smoother_setup(int max_iter, double rate, double tol, const char *tol_type, void **mv_ws[3], double *dbl_ws,
 		int *int_ws, struct OPS_ *ops)
 {
@@ -174,6 +185,7 @@ static void BlockAlgebraicMultiGrid(int current_level, void **mv_b, void **mv_x,
 	BlockAMGSolver *bamg = (BlockAMGSolver*)ops->multi_linear_solver_workspace;
 	void (*multi_linear_sol)(void*, void**, void**, int*, int*, struct OPS_*) = ops->MultiLinearSolver;
 	const int coarsest_level = bamg->num_levels - 1, block_size = end_bx[1] - start_bx[1];
+	const int fused = own_fusions(ops);
 	void *A = bamg->A_array[current_level];
 	void **mv_ws[3], **mv_r, **coarse_b, **coarse_x;
 	int start[2], end[2];
@@ -190,9 +202,12 @@ static void BlockAlgebraicMultiGrid(int current_level, void **mv_b, void **mv_x,
 		/* r = b - A x */
 		start[0] = start_bx[1]; end[0] = end_bx[1]; start[1] = 0; end[1] = block_size;
 		mv_r = bamg->mv_array_ws[2][current_level];
-		ops->MatDotMultiVec(A, mv_x, mv_r, start, end, ops);
-		start[0] = start_bx[0]; end[0] = end_bx[0]; start[1] = 0; end[1] = block_size;
-		ops->MultiVecAxpby(1.0, mv_b, -1.0, mv_r, start, end, ops);
+		if (!(fused && g_fuse_residual != NULL &&
+				g_fuse_residual(A, mv_b, start_bx[0], mv_x, start_bx[1], mv_r, 0, block_size, ops))) {
+			ops->MatDotMultiVec(A, mv_x, mv_r, start, end, ops);
+			start[0] = start_bx[0]; end[0] = end_bx[0]; start[1] = 0; end[1] = block_size;
+			ops->MultiVecAxpby(1.0, mv_b, -1.0, mv_r, start, end, ops);
+		}
 		/* restrict, zero start, recurse */
 		coarse_b = bamg->mv_array_ws[0][coarse_level];
 		coarse_x = bamg->mv_array_ws[1][coarse_level];
@@ -202,9 +217,12 @@ static void BlockAlgebraicMultiGrid(int current_level, void **mv_b, void **mv_x,
 		ops->multi_linear_solver_workspace = (void*)bamg;
 		BlockAlgebraicMultiGrid(coarse_level, coarse_b, coarse_x, start, end, ops);
 		/* prolongate and correct */
-		ops->MultiVecFromItoJ(bamg->P_array, coarse_level, current_level, coarse_x, mv_r, start, end, bamg->mv_array_ws[4], ops);
-		start[0] = 0; end[0] = block_size; start[1] = start_bx[1]; end[1] = end_bx[1];
-		ops->MultiVecAxpby(1.0, mv_r, 1.0, mv_x, start, end, ops);
+		if (!(fused && g_fuse_prolong != NULL &&
+				g_fuse_prolong(bamg->P_array[current_level], coarse_x, 0, mv_x, start_bx[1], block_size, ops))) {
+			ops->MultiVecFromItoJ(bamg->P_array, coarse_level, current_level, coarse_x, mv_r, start, end, bamg->mv_array_ws[4], ops);
+			start[0] = 0; end[0] = block_size; start[1] = start_bx[1]; end[1] = end_bx[1];
+			ops->MultiVecAxpby(1.0, mv_r, 1.0, mv_x, start, end, ops);
+		}
 		/* post-smoothing */
 		smoother_setup(bamg->max_iter[current_level * 2 + 2], bamg->rate[current_level], bamg->tol[current_level],
 				bamg->tol_type, mv_ws, bamg->dbl_ws, bamg->int_ws, ops);

@@ -95,6 +95,15 @@ typedef void   (*GCGE_SMOOTHER_SETUP_FN) (int max_iter, double rate, double tol,
 typedef double (*GCGE_SMOOTHER_RESIDUAL_FN) (struct OPS_ *ops);
 void GCGE_SetBlockAMGSmoother (GCGE_SMOOTHER_SETUP_FN setup, GCGE_SMOOTHER_RESIDUAL_FN residual, void *owner);
 int  GCGE_HasBlockAMGSmoother (struct OPS_ *ops);      /* 1: a smoother is registered for THIS table and not switched off */
+/*     Two steps of a V-cycle that a back-end may do in one sweep each for ITS table (owner as above), with the arithmetic
+ *     of the slot calls they replace (src/ops_lin_sol.c:596-606, :626-640) — results identical bit for bit:
+ *       residual(A, b, b0, x, x0, r, r0, ncols, ops):  r[:, r0..) = b[:, b0..) - A x[:, x0..)   (MatDotMultiVec + MultiVecAxpby)
+ *       prolong_add(P, xc, c0, xf, f0, ncols, ops):    xf[:, f0..) += P xc[:, c0..)             (MultiVecFromItoJ + MultiVecAxpby)
+ *     each returns 1 when it did the work and 0 to decline (the V-cycle then issues the slot calls).
+ *     GCGE_AMG_NO_FUSIONS=1 in the environment keeps the slot calls.                                                      */
+typedef int (*GCGE_AMG_RESIDUAL_FN) (void *A, void **b, int b0, void **x, int x0, void **r, int r0, int ncols, struct OPS_ *ops);
+typedef int (*GCGE_AMG_PROLONG_ADD_FN) (void *P, void **xc, int c0, void **xf, int f0, int ncols, struct OPS_ *ops);
+void GCGE_SetBlockAMGFusions (GCGE_AMG_RESIDUAL_FN residual, GCGE_AMG_PROLONG_ADD_FN prolong_add, void *owner);
 /*     BlockAMG as the solver of GCG's W systems, the way the reference's SiO2 driver sets it up under OPS_USE_AMG
  *     (test/test_eig_sol_SiO2_MAT.c:96-128,160-170): hierarchy from ops->MultiGridCreate (at most max_levels), work blocks of
  *     block_size columns per level, max_iter = {cycles, smooth0, smooth0, smooth, smooth, ...} (reference: {1, 5, 5, 4, 4, ...}),

@@ -334,6 +334,39 @@ def test_gcg_with_block_amg_on_hip_matches_oracle(hip, oracle, kind, size, nev, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,size,m", [("lap3d", 16, 8), ("lap3d", 24, 22), ("fe3d", 12, 6), ("sio2", 14, 4)])
+def test_block_amg_fused_vcycle_steps_equal_the_slot_calls(hip, kind, size, m, monkeypatch):
+    """The V-cycle's residual r = b - A x and its correction x += P e as one sweep each on the HIP table (GCGE_SetBlockAMGFusions:
+    the CG's start sweep with a single store, a prolongation kernel that adds in place) against the slot calls they replace
+    (MatDotMultiVec + MultiVecAxpby, MultiVecFromItoJ + MultiVecAxpby; reference src/ops_lin_sol.c:596-640): the same x bit for
+    bit, and the solve converges to the direct solution."""
+    import scipy.sparse.linalg as sla
+    A, _ = make_problem(kind, size)
+    S = csr_to_scipy(A)
+    n = A.nrows
+    mA = hip.matrix(A)
+    Ah, Ph, done = slot_multigrid(hip, mA, None, 3)
+    b = uniform(301, (n, m)) - 0.5
+    x0 = uniform(302, (n, m)) - 0.5
+    L = len(Ah)
+    max_iter = [2] + [3, 4] * L
+    rate, tol = [1e-30] * L, [1e-30] * L
+    out = {}
+    for tag in ("fused", "slots"):
+        if tag == "slots":
+            monkeypatch.setenv("GCGE_AMG_NO_FUSIONS", "1")
+        out[tag] = block_amg_solve(hip, Ah, Ph, b, x0, max_iter, rate, tol)
+    monkeypatch.delenv("GCGE_AMG_NO_FUSIONS")
+    assert np.array_equal(out["fused"][0], out["slots"][0])
+    assert out["fused"][1] == out["slots"][1] and out["fused"][2] == out["slots"][2]
+    x, _, _ = block_amg_solve(hip, Ah, Ph, b, x0, [40] + [3, 4] * L, rate, [1e-11] + [1e-30] * (L - 1))
+    ref = sla.spsolve(S.tocsc(), b)
+    assert np.max(np.abs(x - ref)) < 1e-8 * np.max(np.abs(ref))
+    done()
+    hip.free_matrix(mA)
+
+
+@pytest.mark.gpu
 def test_reference_block_amg_over_the_hip_table(hip):
     """The literal drop-in of the multigrid leg: the REFERENCE's compiled BlockAMG + BlockPCG + DefaultMultiVecFromItoJ
     (oracle/_ref/libgcge_ref.so, src/ops_lin_sol.c:466-715, src/ops_multi_grid.c:69-117) over a table only OPS_HIP_Set touched —
