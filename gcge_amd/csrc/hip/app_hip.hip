@@ -1341,6 +1341,53 @@ static int HIP_AmgProlongAdd(void* matP, void** xc, int c0, void** xf, int f0, i
   return 1;
 }
 
+// b[:, bc0:bc0+m) = x[:, xc0:xc0+m) diag(scale): the right-hand sides (lambda_j + sigma) x_j of the GCG driver's W systems for a
+// BlockAMG that takes them as scale factors (GCGE_SetBlockAMGFormRhs) — one read, one write, each product rounded once like the
+// column scaling after a copy (MatDotMultiVec(B = NULL) + MultiVecLinearComb: reference src/ops_eig_sol_gcg.c:560-577)
+__global__ __launch_bounds__(256) void scaled_copy_kernel(long nrows, const double* __restrict__ x, long ldx, double* __restrict__ b, long ldb,
+    int m2, const double* __restrict__ scale, int tpr) {
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr, rpb = 256 / tpr;
+  if (tx >= m2) return;
+  const v2d_pa sc = {scale[2 * tx], scale[2 * tx + 1]};
+  const long slab = (((nrows + gridDim.x - 1) / gridDim.x) + rpb - 1) / rpb * rpb;
+  const long rend = min(nrows, ((long)blockIdx.x + 1) * slab);
+  long row = (long)blockIdx.x * slab + ty;
+  for (; row + 3L * rpb < rend; row += 4L * rpb) {
+    v2d_pa a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d_pa*>(x + (row + (long)u * rpb) * ldx + 2 * tx));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v2d_pa{a[u].x * sc.x, a[u].y * sc.y}, reinterpret_cast<v2d_pa*>(b + (row + (long)u * rpb) * ldb + 2 * tx));
+  }
+  for (; row < rend; row += rpb) {
+    const v2d_pa a = *reinterpret_cast<const v2d_pa*>(x + row * ldx + 2 * tx);
+    *reinterpret_cast<v2d_pa*>(b + row * ldb + 2 * tx) = v2d_pa{a.x * sc.x, a.y * sc.y};
+  }
+}
+static int HIP_AmgFormRhs(void** b, int bc0, void** x, int xc0, const double* scale, int m, struct OPS_* ops) {
+  (void)ops;
+  GcgeHipMV *vb = (GcgeHipMV*)b, *vx = (GcgeHipMV*)x;
+  if (scale == nullptr || m <= 0 || m / 2 > 256 || (m & 1) || (bc0 & 1) || (xc0 & 1) || (vb->ld & 1) || (vx->ld & 1)) return 0;
+  if (((uintptr_t)vb->d & 15) || ((uintptr_t)vx->d & 15) || vb->nrows != vx->nrows) return 0;
+  if (bc0 < 0 || bc0 + m > vb->ncols || xc0 < 0 || xc0 + m > vx->ncols) return 0;
+  if (vb == vx && bc0 < xc0 + m && xc0 < bc0 + m) return 0;
+  enter();
+  SlotTimer tm_("AMG right-hand sides (x diag(scale))", m);
+  double* dd = stage_d((size_t)m);
+  double* hs = stage_h((size_t)m);
+  GCGE_HIP_CHECK(hipStreamSynchronize(g_stream));   // the staging buffers are reused
+  memcpy(hs, scale, m * sizeof(double));
+  GCGE_HIP_CHECK(hipMemcpyAsync(dd, hs, m * sizeof(double), hipMemcpyHostToDevice, g_stream));
+  const int m2 = m / 2;
+  int tpr = 1; while (tpr < m2) tpr *= 2;
+  const int rpb = 256 / tpr;
+  long g = ((long)vx->nrows + (long)rpb * 8 - 1) / ((long)rpb * 8); if (g > 8192) g = 8192; if (g < 1) g = 1;
+  hipLaunchKernelGGL(scaled_copy_kernel, dim3((unsigned)g), dim3(256), 0, g_stream, (long)vx->nrows, (const double*)(vx->d + xc0), (long)vx->ld,
+                     vb->d + bc0, (long)vb->ld, m2, (const double*)dd, tpr);
+  GCGE_REQUIRE(hipGetLastError() == hipSuccess, "AMG right-hand sides: kernel launch");
+  return 1;
+}
+
 // Residuals of Ritz pairs of a standard problem in one read of x (GCGE_RESIDUAL_FN, include/gcge_ops.h; kernel MODE 4 of
 // spmm_pattern.hip): res_sq[j] = sum over the local rows of ((A x_j) - lambda_j x_j)^2.  Declines (0) for B != NULL and
 // blocks that cannot be walked in 16-byte column pairs; matrices without pattern form take resid_sq_stored above.  Odd
@@ -1504,4 +1551,5 @@ extern "C" void OPS_HIP_Set(struct OPS_* ops) {
   ops->MultiGridDestroy         = gcge_hip_multigrid_destroy;
   GCGE_SetBlockAMGSmoother(gcge_hip_amg_smoother_setup, gcge_hip_amg_smoother_residual, (void*)HIP_MatDotMultiVec);
   GCGE_SetBlockAMGFusions(HIP_AmgResidual, HIP_AmgProlongAdd, (void*)HIP_MatDotMultiVec);   // r = b - A x and x += P e as one sweep each
+  GCGE_SetBlockAMGFormRhs(HIP_AmgFormRhs, (void*)HIP_MatDotMultiVec);                         // b = x diag(scale) in one sweep
 }

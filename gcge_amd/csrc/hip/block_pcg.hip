@@ -614,9 +614,26 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
   // and neither reads nor needs b; every other route forms b first, here, on the device.
   const double* rhs_scale = GCGE_GetLinearSolverRhsScale();
   bool p0_done = false;
+  // Will the iteration rebuild its residual from the directions (device-scalar loop of the recompute form, MODE 7 below)?  Then the
+  // block r is never read, and the one-sweep starts store p0 alone (r and p0 name the same block: single store, 3 block streams
+  // instead of 4 — the two smoothing calls of a V-cycle start this way).  Same conditions as where the loop is chosen further down;
+  // the ring is sized first (bpcg_ring is collective: every rank gets here in the same call as before, only earlier).
+  bool start_without_r = false;
+  if (nrhs <= 512 && cg_vec_ok(nrhs, {dw, dr, dp, dx}, {ldw, ldr, ldp, ldx}) && sigma == 0.0 && gcge_hip_cg_recompute_pays(mat) &&
+      getenv("GCGE_CG_START_STORES_R") == nullptr) {
+    bpcg_ring(s, mat, mv_x, sigma, ops);
+    const int R0p = s->ring_len >= 2 ? s->ring_len : 1;
+    const bool rec_p = R0p > 1 && gcge_hip_cg_fusable(mat, s->ring[0], nrhs) && !(nrhs & 1);
+    const int Rp = R0p + ((rec_p && R0p < 16 && getenv("GCGE_CG_NO_W_SLOT") == nullptr) ? 1 : 0);   // (idle blocks can only add slots)
+    GCGE_COMM* comm_p = GCGE_GetComm();
+    start_without_r = rec_p && Rp >= 3 && getenv("GCGE_CG_HOST_SCALARS") == nullptr && s->max_iter <= 4000 &&
+                      (comm_p == nullptr || gcge_hip_comm_is_native(comm_p)) &&
+                      (g_residual_form == 1 || (g_residual_form == 0 && s->rate >= 1e-4 && s->max_iter <= 100));
+  }
+  void** start_r = start_without_r ? s->mv_ws[1] : s->mv_ws[0];
   if (rhs_scale != nullptr) {
     if (0 != strcmp(s->tol_type, "rel") && sigma == 0.0 && gcge_hip_cg_recompute_pays(mat) &&   // ("rel" needs |b|: b is formed)
-        gcge_hip_cg_start_scaled_mv(mat, mv_x, start_bx[1], rhs_scale, s->mv_ws[0], s->mv_ws[1], 0, nrhs, rho2.data()) == 0) {
+        gcge_hip_cg_start_scaled_mv(mat, mv_x, start_bx[1], rhs_scale, start_r, s->mv_ws[1], 0, nrhs, rho2.data()) == 0) {
       reduce_over_ranks(rho2.data(), nrhs);
       p0_done = true;
     } else if (0 != strcmp(s->tol_type, "rel") && sigma == 0.0 && mat != nullptr && nrhs <= 512 && getenv("GCGE_CG_NO_FUSED_START") == nullptr &&
@@ -671,7 +688,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
   if (p0_done) {
     // started from the scale factors above
   } else if (sigma == 0.0 && gcge_hip_cg_recompute_pays(mat) &&
-      gcge_hip_cg_start_mv(mat, mv_x, start_bx[1], mv_b, start_bx[0], s->mv_ws[0], s->mv_ws[1], 0, nrhs, rho2.data()) == 0) {
+      gcge_hip_cg_start_mv(mat, mv_x, start_bx[1], mv_b, start_bx[0], start_r, s->mv_ws[1], 0, nrhs, rho2.data()) == 0) {
     reduce_over_ranks(rho2.data(), nrhs);
     p0_done = true;
   } else {
@@ -796,6 +813,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       // 1e-2 in 30); a caller asking for more keeps the stored residual — gcge_hip_bpcg_residual_form overrides
       // either way, tests/test_hip_parity.py::test_fused_cg_tight_tolerances compares the two forms down to 1e-13.
       const bool implicit_r = R >= 3 && (g_residual_form == 1 || (g_residual_form == 0 && s->rate >= 1e-4 && s->max_iter <= 100));
+      if (start_without_r && p0_done && !(recompute && implicit_r)) { fprintf(stderr, "HIP_BlockPCG: the start sweep left no residual but the iteration needs one\n"); abort(); }
       double* d_betaB = d_ahist2 + 16 * cap;   // second beta buffer: beta_k and beta_{k-1} alternate between the two
       if (implicit_r) {
         GCGE_HIP_CHECK(hipMemsetAsync(d_beta, 0, cap * sizeof(double), st));
@@ -890,6 +908,7 @@ static void HIP_BlockPCG_run(void* mat, void** mv_b, void** mv_x, int* start_bx,
       s->residual = s->h_pin[0];
       return;
     }
+    if (start_without_r && p0_done && nact > 0) { fprintf(stderr, "HIP_BlockPCG: the start sweep left no residual but the host loop needs one\n"); abort(); }
     // stored-product form without a stored residual: same rule as the device-scalar loop above
     const bool host_implicit_r = !recompute && R >= 3 && (g_residual_form == 1 || (g_residual_form == 0 && s->rate >= 1e-4 && s->max_iter <= 100));
     std::vector<double> bprev_host(nrhs, 0.0);

@@ -163,6 +163,8 @@ void GCGE_SetBlockAMGFusions(GCGE_AMG_RESIDUAL_FN residual, GCGE_AMG_PROLONG_ADD
 {
 	g_fuse_residual = residual; g_fuse_prolong = prolong_add; g_fuse_owner = owner;
 }
+static GCGE_AMG_FORM_RHS_FN g_fuse_rhs = NULL; static void *g_fuse_rhs_owner = NULL;
+void GCGE_SetBlockAMGFormRhs(GCGE_AMG_FORM_RHS_FN form_rhs, void *owner) { g_fuse_rhs = form_rhs; g_fuse_rhs_owner = owner; }
 static int own_fusions(struct OPS_ *ops)
 {
 	return g_fuse_owner != NULL && g_fuse_owner == (void*)ops->MatDotMultiVec && getenv("GCGE_AMG_NO_FUSIONS") == NULL;
@@ -238,12 +240,27 @@ static void BlockAMG(void *mat, void **mv_b, void **mv_x, int *start_bx, int *en
 {
 	BlockAMGSolver *bamg = (BlockAMGSolver*)ops->multi_linear_solver_workspace;
 	int idx;
+	/* systems declared as b = x diag(scale) (only to a BlockAMG that registered for them: MultiLinearSolverSetup_BlockAMG):
+	 * b is formed here, once, from the initial guess; the smoothing calls then see an ordinary right-hand side */
+	const double *rhs_scale = GCGE_GetLinearSolverRhsScale();
 	(void)mat;      /* level 0 of the hierarchy IS the matrix (src/ops_lin_sol.c:477) */
+	if (rhs_scale != NULL) {
+		const int ncols = end_bx[1] - start_bx[1];
+		if (!(g_fuse_rhs != NULL && g_fuse_rhs_owner == (void*)ops->MatDotMultiVec &&
+				g_fuse_rhs(mv_b, start_bx[0], mv_x, start_bx[1], rhs_scale, ncols, ops))) {
+			int s[2], e[2];
+			s[0] = start_bx[1]; e[0] = end_bx[1]; s[1] = start_bx[0]; e[1] = end_bx[0];
+			ops->MultiVecAxpby(1.0, mv_x, 0.0, mv_b, s, e, ops);
+			ops->MultiVecLinearComb(NULL, mv_b, 0, s, e, NULL, 0, (double*)rhs_scale, 1, ops);
+		}
+		GCGE_SetLinearSolverRhsScale(NULL);
+	}
 	for (idx = 0; idx < bamg->max_iter[0]; ++idx) {
 		BlockAlgebraicMultiGrid(0, mv_b, mv_x, start_bx, end_bx, ops);
 		bamg->niter = idx + 1;
 		if (bamg->residual < bamg->tol[0]) break;
 	}
+	if (rhs_scale != NULL) GCGE_SetLinearSolverRhsScale(rhs_scale);   /* (the caller clears it) */
 }
 
 void MultiLinearSolverSetup_BlockAMG(int *max_iter, double *rate, double *tol, const char *tol_type,
@@ -261,4 +278,7 @@ void MultiLinearSolverSetup_BlockAMG(int *max_iter, double *rate, double *tol, c
 	bamg.niter = 0; bamg.residual = -1.0;
 	ops->multi_linear_solver_workspace = (void*)&bamg;
 	ops->MultiLinearSolver = BlockAMG;
+	/* over a back-end that forms b = x diag(scale) in one sweep, BlockAMG takes the GCG driver's scaled right-hand sides */
+	GCGE_SetRhsScaleCapabilityOfBlockAMG((g_fuse_rhs != NULL && g_fuse_rhs_owner == (void*)ops->MatDotMultiVec &&
+			getenv("GCGE_AMG_NO_FUSIONS") == NULL) ? (void*)BlockAMG : NULL);
 }

@@ -45,11 +45,13 @@ int  GCGE_GetLocalInnerProdReduces(void) { return g_local_ip_reduces && g_comm !
 static GCGE_RESIDUAL_FN g_res_hook = NULL; static void *g_res_owner = NULL;
 void GCGE_SetResidualHook(GCGE_RESIDUAL_FN fn, void *owner) { g_res_hook = fn; g_res_owner = owner; }
 GCGE_RESIDUAL_FN GCGE_GetResidualHook(void *owner) { return (g_res_hook != NULL && owner == g_res_owner) ? g_res_hook : NULL; }
-static void *g_rhs_scale_owner = NULL; static const double *g_rhs_scale = NULL;
-void GCGE_SetRhsScaleCapability(void *owner) { g_rhs_scale_owner = owner; }
+/* (two owners: a back-end's block CG and, over it, BlockAMG where the back-end forms b in one sweep — lin_sol.c) */
+static void *g_rhs_scale_owner[2] = {NULL, NULL}; static const double *g_rhs_scale = NULL;
+void GCGE_SetRhsScaleCapability(void *owner) { g_rhs_scale_owner[0] = owner; }
+void GCGE_SetRhsScaleCapabilityOfBlockAMG(void *owner) { g_rhs_scale_owner[1] = owner; }
 int GCGE_HasRhsScaleCapability(void *owner)
 {
-	return g_rhs_scale_owner != NULL && owner == g_rhs_scale_owner && getenv("GCGE_NO_RHS_SCALE") == NULL;
+	return owner != NULL && (owner == g_rhs_scale_owner[0] || owner == g_rhs_scale_owner[1]) && getenv("GCGE_NO_RHS_SCALE") == NULL;
 }
 void GCGE_SetLinearSolverRhsScale(const double *scale) { g_rhs_scale = scale; }
 const double *GCGE_GetLinearSolverRhsScale(void) { return g_rhs_scale; }

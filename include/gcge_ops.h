@@ -178,6 +178,7 @@ GCGE_RESIDUAL_FN GCGE_GetResidualHook (void *owner);
  * (it may use that block as scratch).  The reference forms b through MatDotMultiVec + MultiVecLinearComb
  * (src/ops_eig_sol_gcg.c:560-577): two block sweeps and a third read at the start of the solve. */
 void       GCGE_SetRhsScaleCapability (void *owner);
+void       GCGE_SetRhsScaleCapabilityOfBlockAMG (void *owner);   /* second owner: BlockAMG over a back-end that forms b in one sweep (NULL: none) */
 int        GCGE_HasRhsScaleCapability (void *owner);
 void       GCGE_SetLinearSolverRhsScale (const double *scale);   /* NULL: b is an ordinary right-hand side */
 const double *GCGE_GetLinearSolverRhsScale (void);

@@ -100,10 +100,15 @@ int  GCGE_HasBlockAMGSmoother (struct OPS_ *ops);      /* 1: a smoother is regis
  *       residual(A, b, b0, x, x0, r, r0, ncols, ops):  r[:, r0..) = b[:, b0..) - A x[:, x0..)   (MatDotMultiVec + MultiVecAxpby)
  *       prolong_add(P, xc, c0, xf, f0, ncols, ops):    xf[:, f0..) += P xc[:, c0..)             (MultiVecFromItoJ + MultiVecAxpby)
  *     each returns 1 when it did the work and 0 to decline (the V-cycle then issues the slot calls).
- *     GCGE_AMG_NO_FUSIONS=1 in the environment keeps the slot calls.                                                      */
+ *     GCGE_AMG_NO_FUSIONS=1 in the environment keeps the slot calls.
+ *       form_rhs(b, b0, x, x0, scale, ncols, ops):  b[:, b0..) = x[:, x0..) diag(scale) — with it BlockAMG takes the GCG driver's
+ *     "b = x diag(scale)" systems (GCGE_SetRhsScaleCapability, include/gcge_ops.h) and forms b itself in one sweep (the driver's
+ *     MatDotMultiVec(B = NULL) + MultiVecLinearComb are two: reference src/ops_eig_sol_gcg.c:560-577); NULL: b comes formed.     */
 typedef int (*GCGE_AMG_RESIDUAL_FN) (void *A, void **b, int b0, void **x, int x0, void **r, int r0, int ncols, struct OPS_ *ops);
 typedef int (*GCGE_AMG_PROLONG_ADD_FN) (void *P, void **xc, int c0, void **xf, int f0, int ncols, struct OPS_ *ops);
+typedef int (*GCGE_AMG_FORM_RHS_FN) (void **b, int b0, void **x, int x0, const double *scale, int ncols, struct OPS_ *ops);
 void GCGE_SetBlockAMGFusions (GCGE_AMG_RESIDUAL_FN residual, GCGE_AMG_PROLONG_ADD_FN prolong_add, void *owner);
+void GCGE_SetBlockAMGFormRhs (GCGE_AMG_FORM_RHS_FN form_rhs, void *owner);
 /*     BlockAMG as the solver of GCG's W systems, the way the reference's SiO2 driver sets it up under OPS_USE_AMG
  *     (test/test_eig_sol_SiO2_MAT.c:96-128,160-170): hierarchy from ops->MultiGridCreate (at most max_levels), work blocks of
  *     block_size columns per level, max_iter = {cycles, smooth0, smooth0, smooth, smooth, ...} (reference: {1, 5, 5, 4, 4, ...}),

@@ -1,4 +1,4 @@
-# C2 with BlockAMG: the V-cycle's fused residual / correction on and off — one line per run
+# C2 with BlockAMG: A/B of the round-5 switches, one line per run:  bash tools/amg_fusion_ab.sh TAG=ENV[,ENV...] ...
 set -e
 mkdir -p gpurun_out/r5b
 run() {  # tag, env, args...
@@ -8,8 +8,10 @@ run() {  # tag, env, args...
 import json
 d=json.loads(open("gpurun_out/r5b/ab_$tag.json").read().strip().splitlines()[-1])
 c=d["config"]
-print("$tag", "value", round(d["value"],3), "s/solve", round(d["ms_per_step"]/1e3,3), "its", c["gcg_iterations"], "conv", c["nev_converged"], "cg", c["cg_iterations"], "linsol", round(c["phase_seconds"]["linsol"],3), flush=True)
+print("$tag", "value", round(d["value"],3), "s/solve", round(d["ms_per_step"]/1e3,3), "its", c["gcg_iterations"], "conv", c["nev_converged"], "cg", c["cg_iterations"], "linsol", round(c["phase_seconds"]["linsol"],3), "roofline", round(d["roofline"]["frac"],3), flush=True)
 P
 }
-run slots GCGE_AMG_NO_FUSIONS=1
-run fused GCGE_AMG_NO_FUSIONS_OFF=1
+for spec in "$@"; do
+  tag=${spec%%=*}; envs=${spec#*=}
+  run $tag "$(echo $envs | tr ',' ' ')"
+done
