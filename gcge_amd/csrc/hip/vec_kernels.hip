@@ -287,6 +287,22 @@ extern "C" int gcge_hip_axpby(int nrows, double alpha, const double* d_x, long l
   }
   const bool vec2 = (m % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)d_y & 15) == 0) &&
                     (mode >= 2 || ((ldx % 2 == 0) && (((uintptr_t)d_x & 15) == 0)));
+  // A wide range that starts on an odd column of both blocks (the solver's X / P / W ranges move with the number of locked pairs) or
+  // has an odd width: the odd columns at its ends go through the element-wise kernel, the even-aligned middle through the 16-byte
+  // lanes (the element-wise kernel moves a 128-column copy at 3.6 TB/s).  Same operation per element.
+  if (!vec2 && mode <= 2 && m >= 8 && ldy % 2 == 0 && (mode == 2 || ldx % 2 == 0) && (long)nrows >= 1024 &&
+      (mode == 2 || (((uintptr_t)d_x & 15) == ((uintptr_t)d_y & 15)))) {
+    const int head = (((uintptr_t)d_y & 15) == 8) ? 1 : 0;         // one column up to the next 16-byte boundary
+    const int tail = (m - head) % 2;
+    const int mid = m - head - tail;
+    if (mid >= 2 && (head || tail)) {
+      const double* xm = d_x ? d_x + head : nullptr;
+      if (head) hipLaunchKernelGGL(axpby_kernel, dim3(grid_for((long)nrows)), dim3(256), 0, st, (long)nrows, alpha, d_x, ldx, beta, d_y, ldy, 1, mode);
+      if (tail) hipLaunchKernelGGL(axpby_kernel, dim3(grid_for((long)nrows)), dim3(256), 0, st, (long)nrows, alpha, d_x ? d_x + head + mid : nullptr, ldx, beta,
+                                   d_y + head + mid, ldy, 1, mode);
+      return gcge_hip_axpby(nrows, alpha, xm, ldx, beta, d_y + head, ldy, mid, stream);
+    }
+  }
   // x == y with different column ranges (column copies inside one block) is fine for the row form as well: a thread reads
   // and writes only its own (row, column pair)
   if (vec2 && mode <= 2 && m / 2 <= 256 && (long)nrows >= 1024) {

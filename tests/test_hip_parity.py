@@ -149,6 +149,34 @@ def test_gram_and_dots_vs_oracle(both):
         _close(got, ora.ops.inner_prod("D", xo, yo, (s, s + 1), (s + k, s + 1 + k), ld=2), tol=1e-12, what="dots D")
 
 
+def test_axpby_on_odd_column_ranges(hip):
+    """K4 on wide column ranges that start on an odd column or have an odd width (the solver's X / P / W ranges move with the
+    number of locked pairs): the odd columns at the ends go through the element-wise kernel, the middle through the 16-byte
+    lanes (vec_kernels.hip) — against numpy, all three modes, columns outside the range untouched, copies inside one block."""
+    import torch
+    g = hip.g
+    g.gcge_hip_axpby.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_long, C.c_double, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
+    n, ldx, ldy = 5003, 140, 274
+    X0 = np.ascontiguousarray(uniform(51, (n, ldx)) - 0.5); Y0 = np.ascontiguousarray(uniform(52, (n, ldy)) - 0.5)   # row-major blocks
+    for m, xo, yo in [(9, 1, 1), (64, 3, 5), (127, 1, 3), (128, 1, 7), (128, 2, 3), (33, 0, 0), (130, 5, 141)]:
+        for alpha, beta, use_x in [(1.0, 0.0, True), (0.75, -1.5, True), (0.0, 2.5, False)]:
+            X = torch.from_numpy(X0).cuda(); Y = torch.from_numpy(Y0).cuda()
+            assert g.gcge_hip_axpby(n, alpha, X.data_ptr() + 8 * xo if use_x else None, ldx, beta, Y.data_ptr() + 8 * yo, ldy, m, None) == 0
+            torch.cuda.synchronize()
+            ref = Y0.copy()
+            ref[:, yo:yo + m] = (alpha * X0[:, xo:xo + m] if use_x else 0.0) + (beta * Y0[:, yo:yo + m] if beta != 0.0 else 0.0)
+            got = Y.cpu().numpy()
+            assert np.max(np.abs(got - ref)) <= 4e-16 * 3.0, (m, xo, yo, alpha, beta)
+            assert np.array_equal(got[:, :yo], Y0[:, :yo]) and np.array_equal(got[:, yo + m:], Y0[:, yo + m:])
+    # a copy between two ranges of ONE block (different parity of the origins: element-wise; same parity: peeled)
+    for src, dst, m in [(1, 131, 127), (2, 133, 64), (1, 140, 130)]:
+        Y = torch.from_numpy(Y0).cuda()
+        assert g.gcge_hip_axpby(n, 1.0, Y.data_ptr() + 8 * src, ldy, 0.0, Y.data_ptr() + 8 * dst, ldy, m, None) == 0
+        torch.cuda.synchronize()
+        ref = Y0.copy(); ref[:, dst:dst + m] = Y0[:, src:src + m]
+        assert np.array_equal(Y.cpu().numpy(), ref)
+
+
 def test_lincomb_axpby_vs_oracle(both):
     hip, ora = both
     A, mh, mo = _pair_mats(both, "lap3d", 13)
