@@ -89,6 +89,18 @@ __global__ __launch_bounds__(256) void spmm_pattern_kernel(
   constexpr int DOT = MODE != 0;       // the row's own X value rides in buf[LT]
   constexpr int UPD = MODE == 3 || MODE == 5 || MODE == 7;   // its R value (MODE 5: right-hand side, MODE 7: p_{k-1}) in buf[LT + 1]
   constexpr int RES = MODE == 4;
+  if (gridDim.y > 1) {   // the 16-column passes of one operation in one launch (see spmm_pattern_chain2_kernel): pass = blockIdx.y
+    const int c0 = 16 * (int)blockIdx.y;
+    x += c0; if (y != nullptr) y += c0;
+    if (dot_partial != nullptr) dot_partial += (size_t)blockIdx.y * gridDim.x * 16;
+    if (cg.r != nullptr) cg.r += c0;
+    if (cg.pnew != nullptr) cg.pnew += c0;
+    if (cg.alpha != nullptr) cg.alpha += c0;
+    if (cg.beta != nullptr) cg.beta += c0;
+    if (cg.flag != nullptr) cg.flag += c0;
+    if (cg.b != nullptr) cg.b += c0;
+    m = min(m - c0, 16);
+  }
   extern __shared__ __align__(16) unsigned char smem_raw[];
   PatEntry* s_tab = reinterpret_cast<PatEntry*>(smem_raw);
   for (int e = threadIdx.x; e < ntab; e += 256) s_tab[e] = tab[e];
@@ -580,7 +592,8 @@ extern "C" void gcge_hip_cg_pass_streams(int n) { g_pass_streams = n < 0 ? 0 : (
 // Column passes of one operation merged into ONE launch (gridDim.y = passes) when a pass alone has at most this many blocks:
 // a 128^3 level of a multigrid hierarchy has 128 blocks of 16 waves per pass — half the CUs idle, 64^3 an eighth of them.
 // Same blocks, same partial sums, same results bit for bit; the finest level of config 2 (512 blocks) keeps its passes apart
-// (a pass's working set per XCD is what its L2 holds).  0: never.
+// (a pass's working set per XCD is what its L2 holds).  The plain pattern kernel (blocks of 4 waves: the FE pair of config 3, 312
+// blocks per pass at n = 10^6) follows the same rule counted in waves: merged while a pass has at most 16 x this many.  0: never.
 static int g_pass_merge_blocks = -1;   // -1: not set yet (GCGE_PASS_MERGE in the environment, else 256)
 extern "C" void gcge_hip_spmm_pass_merge(int max_blocks) { g_pass_merge_blocks = max_blocks < 0 ? 0 : max_blocks; }
 static int pass_merge_blocks() {
@@ -616,7 +629,7 @@ static long pat_launch(long nrows, const unsigned short* pid, const void* tab, i
                        double* y, size_t ldy, int m, double* partial, long yy_off, long nb, long line, hipStream_t st,
                        long cline, int nw, const CgArgs& cg, int gy = 1) {
   const int ntab = npat * LT;
-  if (gy > 1 && cline <= 0) return -1;   // merged column passes: the chain2 kernel only
+  if (gy > 1 && cline <= 0 && line < 0) return -1;   // merged column passes: the chain2 and the plain kernel
   if (cline > 0) {   // chain + line exchange: nw waves per block, lines of `cline` rows
     if (LT < 5) return -1;
     const long nlines = (nrows + cline - 1) / cline, ntl = (nlines + nw - 1) / nw * (cline / 8);
@@ -638,7 +651,7 @@ static long pat_launch(long nrows, const unsigned short* pid, const void* tab, i
       return nb;
     }
   }
-  hipLaunchKernelGGL((spmm_pattern_kernel<LT, MODE, VALS>), dim3((unsigned)nb), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
+  hipLaunchKernelGGL((spmm_pattern_kernel<LT, MODE, VALS>), dim3((unsigned)nb, (unsigned)gy), dim3(256), (size_t)ntab * sizeof(PatEntry), st,
                      nrows, pid, (const PatEntry*)tab, ntab, x, ldx, y, ldy, m, pat_ntiles(nrows, line), line, partial, yy_off, cg);
   return nb;
 }
@@ -720,7 +733,7 @@ extern "C" int gcge_hip_pattern_spmm_vals(int nrows, const unsigned short* d_pid
     double* partc = d_dots ? gcge_hip_partial_ws((size_t)nbc * 16 * npassc * 2) : nullptr;
     const long yyc = (long)nbc * 16 * npassc;
     bool ring = near > 0 && lt == 7 && d_x != d_y && d_rowval == nullptr;
-    const bool merge = npassc > 1 && nbc <= pass_merge_blocks();   // all passes in one launch (gridDim.y)
+    const bool merge = npassc > 1 && nbc * nw <= 16L * pass_merge_blocks();   // all passes in one launch (gridDim.y): a pass alone fills at most 16 waves per CU
     for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
       const int m = merge ? ncols : ((ncols - c0 < 16) ? ncols - c0 : 16);
       const int gy = merge ? npassc : 1;
@@ -767,14 +780,17 @@ extern "C" int gcge_hip_pattern_spmm_vals(int nrows, const unsigned short* d_pid
   const long nb = pat_grid(span, pat_ntiles(nrows, line));
   double* part = d_dots ? gcge_hip_partial_ws((size_t)nb * 16 * npass * 2) : nullptr;
   const long yyo = (long)nb * 16 * npass;
+  const bool mergep = npass > 1 && nb * 4 <= 16L * pass_merge_blocks();   // plain kernel: blocks of 4 waves
   for (int c0 = 0, ps = 0; c0 < ncols; c0 += 16, ++ps) {
-    const int m = (ncols - c0 < 16) ? ncols - c0 : 16;
+    const int m = mergep ? ncols : ((ncols - c0 < 16) ? ncols - c0 : 16);
+    const int gy = mergep ? npass : 1;
     if (d_dots) {
       double* pp = part + (size_t)ps * nb * 16;
-      if (pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyo, nb, line, st, 0, 4, cgv) < 0) return -1;
-    } else if (pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nb, line, st, 0, 4, cgv) < 0) {
+      if (pat_dispatch<1>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, pp, yyo, nb, line, st, 0, 4, cgv, gy) < 0) return -1;
+    } else if (pat_dispatch<0>(lt, nrows, d_pid, d_tab, npat, d_x + c0, (size_t)ldx, d_y + c0, (size_t)ldy, m, nullptr, 0, nb, line, st, 0, 4, cgv, gy) < 0) {
       return -1;
     }
+    if (mergep) break;
   }
   if (d_dots) gcge_hip_reduce_partials16(part, (int)nb, nb * 16, ncols, d_dots, st);   // all passes in one launch
   if (d_dots && d_dots_yy) gcge_hip_reduce_partials16(part + yyo, (int)nb, nb * 16, ncols, d_dots_yy, st);
@@ -836,7 +852,7 @@ extern "C" int gcge_hip_pattern_cg_vals(int mode, int nrows, const unsigned shor
   static hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   static hipEvent_t ev_fork = nullptr, ev_join[4];
   const hipStream_t st_main = st;
-  const bool merge = nw > 0 && npass > 1 && nb <= pass_merge_blocks();   // all passes in one launch (gridDim.y)
+  const bool merge = npass > 1 && nb * (nw > 0 ? nw : 4) <= 16L * pass_merge_blocks();   // all passes in one launch (gridDim.y); plain kernel: blocks of 4 waves
   const int gy = merge ? npass : 1;
   const int nside = (g_pass_streams > 1 && npass > 1 && !merge) ? std::min(g_pass_streams, std::min(npass, 4)) : 0;
   if (nside > 0) {
