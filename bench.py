@@ -79,9 +79,11 @@ def parse():
     ap.add_argument("--amg", type=int, default=-1,
                     help="levels (>= 2) of the multigrid hierarchy: the W systems are solved by BlockAMG (one V-cycle, fused block CG as the "
                          "smoother; reference src/ops_lin_sol.c:466-715 set up as test/test_eig_sol_SiO2_MAT.c:96-128) instead of 30 block-CG "
-                         "iterations; 0 = plain block CG; default: 6 for config c2 on one rank, 0 otherwise")
+                         "iterations; 0 = plain block CG; default: 6 for configs c2 / c3 / c4, 5 for c5 on one GPU, 0 otherwise")
+    ap.add_argument("--amg-cycles", type=int, default=1, help="V-cycles per call of BlockAMG (the reference's SiO2 set-up: 1)")
     ap.add_argument("--amg-scale", type=float, default=0.0, help="coarse operators A_{l+1} = scale P^T A_l P (0: the back-end's default 0.5, include/gcge_multigrid.h)")
-    ap.add_argument("--amg-smooth", default="3,4", help="CG smoothing iterations before and after the coarse correction: finest level, coarser levels")
+    ap.add_argument("--amg-smooth", default=None, help="CG smoothing iterations before and after the coarse correction: finest level, coarser levels "
+                                                       "(default 3,4; config c5: 12,6 — its 2000 outlying eigenvalues need a longer smoothing polynomial)")
     a = ap.parse_args()
     if a.config == "c4":
         a.nev, a.block, a.nevmax = 200, 128, 400
@@ -92,7 +94,11 @@ def parse():
     if a.size <= 0:
         a.size = 171 if a.config == "c5" else 100 if a.config == "c3" else 256
     if a.amg < 0:
-        a.amg = 6 if (a.config in ("c2", "c3", "c4")) else 0      # (row slabs coarsen by themselves: csrc/hip/multigrid.hip)
+        # (row slabs coarsen by themselves: csrc/hip/multigrid.hip; config 5 on one GPU: 37.9 s with BlockAMG 12 / 6 against 44.7 s with
+        #  30 plain CG iterations, profiles/r05_amg/12_...; on row slabs it keeps the plain block CG)
+        a.amg = 6 if (a.config in ("c2", "c3", "c4")) else (5 if (a.config == "c5" and a.gpus == 1) else 0)
+    if a.amg_smooth is None:
+        a.amg_smooth = "12,6" if a.config == "c5" else "3,4"
     if a.rehearse:
         os.environ["GCGE_BENCH_REHEARSE"] = "1"
     return a
@@ -611,7 +617,7 @@ def main():
             hip.h.gcge_mg_set_defaults.argtypes = [C.c_double, C.c_int, C.c_double]
             hip.h.gcge_mg_set_defaults(args.amg_scale, 0, -1.0)
         t_a = time.perf_counter()
-        amg = C.c_void_p(hip.h.GCGE_AMGCreate(mat, None, args.amg, args.block, 1, s0, s1, 1e-2, hip.ops_handle))
+        amg = C.c_void_p(hip.h.GCGE_AMGCreate(mat, None, args.amg, args.block, args.amg_cycles, s0, s1, 1e-2, hip.ops_handle))
         hip.sync()
         amg_setup_seconds = time.perf_counter() - t_a
         amg_levels = C.cast(amg, C.POINTER(C.c_int * 8)).contents[6]     # GCGE_AMG: three pointers, then num_levels
@@ -819,8 +825,8 @@ def main():
         cands = [r for r in (r_k1, r_p1, r_p2) if r is not None]
         dominant = max(cands, key=lambda r: r["share_of_step"]) if cands else None
         wsolver = ("fused device block-CG (30 its, rate 1e-2)" if amg is None else
-                   "BlockAMG (%d levels of 2x2x2 aggregates, 1 V-cycle, %s fused-CG smoothing its before and after the coarse correction, rate 1e-2)"
-                   % (amg_levels, args.amg_smooth.replace(",", " / ")))
+                   "BlockAMG (%d levels of 2x2x2 aggregates, %d V-cycle%s, %s fused-CG smoothing its before and after the coarse correction, rate 1e-2)"
+                   % (amg_levels, args.amg_cycles, "" if args.amg_cycles == 1 else "s", args.amg_smooth.replace(",", " / ")))
         cfg = {"workload": "%s, nev=%d, block=%d, nevMax=%d, %s, tol abs 1e-1 rel 1e-8, %s, "
                            "X/W orthonormalisation '%s', device RNG start block" % (workload, args.nev, args.block, args.nevmax, "B = mass matrix" if c3 else "B=NULL", wsolver, args.orth),
                "amg_levels": amg_levels, "amg_setup_seconds": amg_setup_seconds,
