@@ -83,7 +83,8 @@ def parse():
     ap.add_argument("--amg-cycles", type=int, default=1, help="V-cycles per call of BlockAMG (the reference's SiO2 set-up: 1)")
     ap.add_argument("--amg-scale", type=float, default=0.0, help="coarse operators A_{l+1} = scale P^T A_l P (0: the back-end's default 0.5, include/gcge_multigrid.h)")
     ap.add_argument("--amg-smooth", default=None, help="CG smoothing iterations before and after the coarse correction: finest level, coarser levels "
-                                                       "(default 3,4; config c5: 12,6 — its 2000 outlying eigenvalues need a longer smoothing polynomial)")
+                                                       "(default 3,4; config c5: 8,24 — the coarse levels carry the projected atoms, 2000 outlying eigenvalues, "
+                                                       "and must be smoothed long enough to resolve them: profiles/r05_amg/13_...)")
     a = ap.parse_args()
     if a.config == "c4":
         a.nev, a.block, a.nevmax = 200, 128, 400
@@ -94,11 +95,11 @@ def parse():
     if a.size <= 0:
         a.size = 171 if a.config == "c5" else 100 if a.config == "c3" else 256
     if a.amg < 0:
-        # (row slabs coarsen by themselves: csrc/hip/multigrid.hip; config 5 on one GPU: 37.9 s with BlockAMG 12 / 6 against 44.7 s with
-        #  30 plain CG iterations, profiles/r05_amg/12_...; on row slabs it keeps the plain block CG)
+        # (row slabs coarsen by themselves: csrc/hip/multigrid.hip; config 5 on one GPU: 14.0 s with BlockAMG 8 / 24 against 44.7 s with
+        #  30 plain CG iterations, profiles/r05_amg/13_...; on row slabs it keeps the plain block CG)
         a.amg = 6 if (a.config in ("c2", "c3", "c4")) else (5 if (a.config == "c5" and a.gpus == 1) else 0)
     if a.amg_smooth is None:
-        a.amg_smooth = "12,6" if a.config == "c5" else "3,4"
+        a.amg_smooth = "8,24" if a.config == "c5" else "3,4"
     if a.rehearse:
         os.environ["GCGE_BENCH_REHEARSE"] = "1"
     return a
