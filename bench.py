@@ -492,6 +492,8 @@ def main():
     from gcge_amd import HipBackend, make_problem, run_gcg
     from gcge_amd import dist as gdist
     hip = HipBackend(device=local_rank)
+    if os.environ.get("GCGE_BENCH_STAR_MODE"):      # diagnostics: -1 = no matrix takes the plane sweep (gcge_hip_spmm_star_mode)
+        hip.g.gcge_hip_spmm_star_mode(int(os.environ["GCGE_BENCH_STAR_MODE"]))
     g = hip.g
     g.gcge_hip_bpcg_setup.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
     g.gcge_hip_profile_enable.argtypes = [C.c_int]
@@ -552,7 +554,8 @@ def main():
             part0 = gdist.row_partition(n_global, world)
             A0, _ = make_problem("sio2", N, row_begin=part0[rank], row_end=part0[rank + 1], **kw)
             # cuts on plane boundaries (a plane of N^2 rows is 1 / N of the matrix): every slab keeps the plane sweep of spmm_star.hip
-            part = gdist.partition_by_nnz(dist, A0, part0, align=N * N) if world > 1 else part0
+            # (with BlockAMG: on EVEN plane numbers, so that every slab coarsens by itself — csrc/hip/multigrid.hip)
+            part = gdist.partition_by_nnz(dist, A0, part0, align=(2 if args.amg >= 2 else 1) * N * N) if world > 1 else part0
             A, _ = make_problem("sio2", N, row_begin=part[rank], row_end=part[rank + 1], **kw)
             t_upload0 = time.perf_counter()
             mat = comm.slab_matrix(A, part) if isinstance(comm, gdist.NativeComm) else gdist.hip_slab_matrix(hip, comm, A, n_global, part)

@@ -219,6 +219,13 @@ def test_ranks_on_one_gpu_block_amg_on_slabs(world, dims):
 
 
 @pytest.mark.gpu
+def test_two_ranks_on_one_gpu_block_amg_on_slabs_of_the_sio2_like_matrix():
+    """The same on the SiO2-like matrix (12th-order stencil + atom blocks that cross the cut): slabs in grid form on every level that
+    still shows the star, coarse slabs through the slab constructor, smoothing through the stored-product CG with halo exchange."""
+    _run("hip", world=2, spec="sio2star:24", rank_env={r: {"GCGE_TEST_AMG": "3"} for r in range(2)})
+
+
+@pytest.mark.gpu
 def test_native_worker_as_one_rank_block_amg():
     """The same through the production constructor (gcge_hip_mat_create_slab, RCCL from C) as a world of one rank."""
     _run("hip_native", world=1, dims=(8, 8, 16), rank_env={0: {"GCGE_TEST_AMG": "3"}})
