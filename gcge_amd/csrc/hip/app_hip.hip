@@ -24,7 +24,7 @@
 
 extern "C" {
 int gcge_hip_pad8_spmm_dot(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval, const double* d_x,
-                           long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream);
+                           long ldx, double* d_y, long ldy, int ncols, double* d_dots, void* stream, long x_own_row0);
 void gcge_hip_spmm_pad8_auto(double avg_octets_per_row);
 int gcge_hip_pattern_width(int max_row_len);
 void* gcge_hip_tile_build(int nrows, int ncols_local, const int* rowptr, const int* colidx, const double* val);
@@ -772,7 +772,7 @@ static int spmm_rows(GCGE_HIP_MAT_* A, long r0, long r1, const double* dx, long 
     rc = gcge_hip_tile_spmm(A->tile, dx, ldx, dy, ldy, m, g_stream);   // whole-matrix products only: a tile's rows are not a row range
   if (rc != -1) return rc;
   if (d_dots) {   // generic fused kernel (the caller checked its contract), y.y by a second pass over y
-    rc = gcge_hip_pad8_spmm_dot(nr, A->d_orp + r0, A->d_pcol, A->d_pval, dx, ldx, y, ldy, m, d_dots, g_stream);
+    rc = gcge_hip_pad8_spmm_dot(nr, A->d_orp + r0, A->d_pcol, A->d_pval, dx, ldx, y, ldy, m, d_dots, g_stream, r0);   // (x.y over the strip's OWN rows of x)
     if (rc == 0 && d_yy) rc = gcge_hip_coldots(nr, y, ldy, y, ldy, m, d_yy, g_stream);
     return rc;
   }

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void spmm_pad8_kernel(
     int nrows, const int* __restrict__ orp, const int* __restrict__ pcol,
     const double* __restrict__ pval, const double* __restrict__ x, size_t ldx,
     double* __restrict__ y, size_t ldy, int m, int rpw, long nchunks, double* __restrict__ dot_partial,
-    const int* __restrict__ sched, int sched_len, const int* __restrict__ rowmap, int accumulate) {
+    const int* __restrict__ sched, int sched_len, const int* __restrict__ rowmap, int accumulate, long own0) {
   constexpr int G = 64 / LPR;  // non-zeros per wave instruction
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -91,12 +91,13 @@ __global__ __launch_bounds__(256) void spmm_pad8_kernel(
   if (row0 >= nrows) continue;
   const int nr = min(rpw, (int)(nrows - row0));
   double* __restrict__ yl = y + (size_t)row0 * ldy + c0;
-  // DOT: the wave's own rows of X (rpw <= 4), loaded up front
+  // DOT: the wave's own rows of X (rpw <= 4), loaded up front.  own0: the row of X that belongs to row 0 of this launch — a launch
+  // over a row strip [r0, r1) of a slab gathers through the WHOLE block x (columns are local row numbers) while its own rows start at r0
   double xo0[4] = {0.0, 0.0, 0.0, 0.0}, xo1[4] = {0.0, 0.0, 0.0, 0.0};
   if (DOT) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const double2 v = *reinterpret_cast<const double2*>(xl + (size_t)min(row0 + q, (long)nrows - 1) * ldx);
+      const double2 v = *reinterpret_cast<const double2*>(xl + (size_t)(own0 + min(row0 + q, (long)nrows - 1)) * ldx);
       xo0[q] = v.x; xo1[q] = v.y;
     }
   }
@@ -245,7 +246,7 @@ static void p8_launch(int nrows, const int* orp, const int* pcol, const double* 
     const int rpw = g_p8_rpw < 4 ? g_p8_rpw : 4;
     const long nch = ((long)nrows + 4 * rpw - 1) / (4 * rpw);
     hipLaunchKernelGGL((spmm_pad8_kernel<LPR, BATCH, ST, 0, 1>), dim3((unsigned)nch), dim3(256), 0, st, nrows, orp, pcol, pval, x, ldx, y, ldy, m,
-                       rpw, nch, (double*)nullptr, (const int*)nullptr, 0, g_p8_rowmap, 1);
+                       rpw, nch, (double*)nullptr, (const int*)nullptr, 0, g_p8_rowmap, 1, 0L);
     return;
   }
   const unsigned rows_per_block = 4u * (unsigned)g_p8_rpw;
@@ -255,16 +256,16 @@ static void p8_launch(int nrows, const int* orp, const int* pcol, const double* 
   const int* sched = nullptr; int slen = 0;
   if (g_p8_sched != nullptr && g_p8_sched_rpw == g_p8_rpw) { sched = g_p8_sched; slen = g_p8_sched_len; grid = g_p8_sched_grid; }
   hipLaunchKernelGGL((spmm_pad8_kernel<LPR, BATCH, ST, 0>), dim3((unsigned)grid), dim3(256), 0, st, nrows, orp,
-                     pcol, pval, x, ldx, y, ldy, m, g_p8_rpw, nchunks, (double*)nullptr, sched, slen, g_p8_rowmap, g_p8_accumulate);
+                     pcol, pval, x, ldx, y, ldy, m, g_p8_rpw, nchunks, (double*)nullptr, sched, slen, g_p8_rowmap, g_p8_accumulate, 0L);
 }
 // fused SpMM + column dots: rows_per_wave fixed at 4, at most `grid` partial rows
 template <int LPR>
 static void p8_launch_dot(int nrows, const int* orp, const int* pcol, const double* pval, const double* x,
-                          size_t ldx, double* y, size_t ldy, int m, double* partial, long grid, hipStream_t st) {
+                          size_t ldx, double* y, size_t ldy, int m, double* partial, long grid, hipStream_t st, long own0) {
   const int rpw = 4;   // the kernel keeps the wave's own X rows in 4 register pairs; fewer rows per wave do not pay here
   const long nchunks = ((long)nrows + 4 * rpw - 1) / (4 * rpw);
   hipLaunchKernelGGL((spmm_pad8_kernel<LPR, 4, 1, 1>), dim3((unsigned)grid), dim3(256), 0, st, nrows, orp, pcol,
-                     pval, x, ldx, y, ldy, m, rpw, nchunks, partial, (const int*)nullptr, 0, (const int*)nullptr, 0);
+                     pval, x, ldx, y, ldy, m, rpw, nchunks, partial, (const int*)nullptr, 0, (const int*)nullptr, 0, own0);
 }
 template <int LPR, int BATCH>
 static void p8_store(int nrows, const int* orp, const int* pcol, const double* pval,
@@ -288,10 +289,12 @@ static void p8_batch(int nrows, const int* orp, const int* pcol, const double* p
 extern "C" double* gcge_hip_partial_ws(size_t len);
 extern "C" void gcge_hip_reduce_partials(const double* d_partial, int nblocks, int len, double* d_out, void* stream);
 
-// Y = A X and d_dots[j] = sum_r X[r,j] Y[r,j] in one pass (ncols <= 128).  -1: alignment contract not met.
+// Y = A X and d_dots[j] = sum_r X[x_own_row0 + r, j] Y[r,j] in one pass (ncols <= 128).  -1: alignment contract not met.
+// d_orp / d_y start at the launch's first row; d_x is the block the column indices point into, x_own_row0 the row of d_x that
+// belongs to the launch's first row (0 for a whole matrix, r0 for the strip [r0, r1) of a split product on a row slab).
 extern "C" int gcge_hip_pad8_spmm_dot(int nrows, const int* d_orp, const int* d_pcol, const double* d_pval,
                                       const double* d_x, long ldx, double* d_y, long ldy, int ncols,
-                                      double* d_dots, void* stream) {
+                                      double* d_dots, void* stream, long x_own_row0) {
   if (nrows <= 0 || ncols <= 0) return 0;
   if (ncols > 128 || (ncols & 1) || (ldx & 1) || (ldy & 1) || ((uintptr_t)d_x & 15) || ((uintptr_t)d_y & 15)) return -1;
   hipStream_t st = (hipStream_t)stream;
@@ -299,10 +302,10 @@ extern "C" int gcge_hip_pad8_spmm_dot(int nrows, const int* d_orp, const int* d_
   const long nchunks = ((long)nrows + 4 * rpw - 1) / (4 * rpw);
   const long grid = nchunks < 8192 ? nchunks : 8192;
   double* part = gcge_hip_partial_ws((size_t)grid * ncols);
-  if (ncols > 64) p8_launch_dot<64>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st);
-  else if (ncols > 32) p8_launch_dot<32>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st);
-  else if (ncols > 16) p8_launch_dot<16>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st);
-  else p8_launch_dot<8>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st);
+  if (ncols > 64) p8_launch_dot<64>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st, x_own_row0);
+  else if (ncols > 32) p8_launch_dot<32>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st, x_own_row0);
+  else if (ncols > 16) p8_launch_dot<16>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st, x_own_row0);
+  else p8_launch_dot<8>(nrows, d_orp, d_pcol, d_pval, d_x, ldx, d_y, ldy, ncols, part, grid, st, x_own_row0);
   gcge_hip_reduce_partials(part, (int)grid, ncols, d_dots, st);
   return (int)hipGetLastError();
 }

@@ -59,12 +59,14 @@ def partition_by_nnz(dist, A, part, bucket=None, align=None):
     `part` (any contiguous one, e.g. row_partition).  Every rank sums its row lengths over buckets of `bucket` global
     rows, the sums are gathered, and the cuts are put at the bucket boundaries nearest to k/world of the total.
     align: cuts only at multiples of `align` rows — the plane size nx * ny of a grid matrix (grid_of), so that every slab is
-    whole planes and keeps the plane sweep of spmm_star.hip; a plane of 171^2 rows is 0.6 % of BASELINE config 5's matrix."""
+    whole planes and keeps the plane sweep of spmm_star.hip; a plane of 171^2 rows is 0.6 % of BASELINE config 5's matrix.  A multiple
+    of the plane size (2^(L-1) planes: the cuts a slab hierarchy of L levels wants, csrc/host/multigrid.c) need not divide the row
+    count: the last unit is then a short one (171 planes = 10 units of 16 planes + 11 planes)."""
     world = len(part) - 1
     n_global = part[-1]
     rank = dist.get_rank()
     if align is not None:
-        if n_global % align != 0 or n_global // align < world:
+        if n_global // align < world:
             align = None                                  # fewer planes than ranks: free cuts
         else:
             bucket = align

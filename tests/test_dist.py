@@ -82,6 +82,17 @@ def test_row_partition_helpers():
     assert list(ghosts) == list(range(16, 32)) + list(range(64, 80))      # one plane on each side
     ci = np.ctypeslib.as_array(A.colidx, shape=(int(A.nnz),))
     assert ci.min() == 0 and ci.max() == 32 + 32 - 1 and A.ncols == 64
+    # cuts in units that do not divide the row count (2^(L-1) planes of a grid with an odd plane count: what a slab hierarchy of L levels
+    # wants, bench.py --config c5 --gpus N): every cut a multiple of the unit, the short last unit stays with the last rank
+    N = 171
+    for world, L in [(2, 5), (4, 4), (8, 3)]:
+        unit = (1 << (L - 1)) * N * N
+        nb = (N ** 3 + unit - 1) // unit
+        w = np.full(nb, float(unit)); w[-1] = N ** 3 - (nb - 1) * unit
+        cuts = gdist.cuts_by_weight(w, world, unit, N ** 3)
+        assert cuts[0] == 0 and cuts[-1] == N ** 3 and all(c % unit == 0 for c in cuts[:-1]) and all(a < b for a, b in zip(cuts, cuts[1:])), cuts
+        share = np.diff(cuts) / (N ** 3 / world)
+        assert share.max() <= 1.15, (world, L, share)
 
 
 @pytest.mark.gpu
@@ -223,6 +234,37 @@ def test_two_ranks_on_one_gpu_block_amg_on_slabs_of_the_sio2_like_matrix():
     """The same on the SiO2-like matrix (12th-order stencil + atom blocks that cross the cut): slabs in grid form on every level that
     still shows the star, coarse slabs through the slab constructor, smoothing through the stored-product CG with halo exchange."""
     _run("hip", world=2, spec="sio2star:24", rank_env={r: {"GCGE_TEST_AMG": "3"} for r in range(2)})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,atoms,levels", [(48, "60,2.0,5.0", 4), (96, "350,2.0,5.0", 5)])
+def test_two_ranks_on_one_gpu_every_level_of_the_slab_hierarchy_multiplies_right(size, atoms, levels):
+    """Every level of the slab hierarchy of the SiO2-like matrix (tests/slab_level_worker.py): uploaded through the slab constructor,
+    product and product-with-column-sums (the fused CG's entry point, gcge_hip_spmm_dot2_mv) against the slab's rows on the host, with
+    and without the interior rows swept while the halo travels.  The coarse levels leave the grid form (pad-8 rows, then repeated
+    patterns): the 96^3 case is where the fused product + x.y sums over a ROW STRIP read the strip's own rows of x from row 0 of the
+    block (round 5: column sums off by 6e-5 on levels 2 and 3 with the split exchange — BlockAMG on slabs deeper than two levels
+    did not converge)."""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "slab_level_worker.py"), str(size), atoms, str(levels)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+        assert "rank %d: worst relative error" % r in o and "products OK on every level" in o, o[-2000:]
+    assert "PASS levels=%d" % levels in outs[0], outs[0][-1500:]
 
 
 @pytest.mark.gpu

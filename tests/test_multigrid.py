@@ -133,7 +133,7 @@ def test_aggregation_hierarchy_is_galerkin(kind, size):
 
 
 @pytest.mark.parametrize("kind,dims,world", [("lap3d", (6, 6, 16), 2), ("lap3d", (5, 7, 24), 3), ("sio2", (12, 12, 12), 1), ("lap3d", (6, 6, 8), 4),
-                                             ("sio2", (16, 16, 16), 2), ("sio2", (12, 12, 12), 3)])
+                                             ("sio2", (16, 16, 16), 2), ("sio2", (12, 12, 12), 3), ("lap3d", (6, 5, 19), 2), ("sio2", (19, 19, 19), 2)])
 def test_slab_hierarchy_equals_the_rows_of_the_whole_hierarchy(kind, dims, world):
     """gcge_mg_build_slab: every rank coarsens its own slab (whole planes, cut on even plane numbers) — stacked, the coarse slabs ARE
     the coarse matrix of the whole-matrix hierarchy at every level, the local prolongations are the diagonal blocks of the global one,
