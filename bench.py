@@ -79,7 +79,7 @@ def parse():
     ap.add_argument("--amg", type=int, default=-1,
                     help="levels (>= 2) of the multigrid hierarchy: the W systems are solved by BlockAMG (one V-cycle, fused block CG as the "
                          "smoother; reference src/ops_lin_sol.c:466-715 set up as test/test_eig_sol_SiO2_MAT.c:96-128) instead of 30 block-CG "
-                         "iterations; 0 = plain block CG; default: 6 for configs c2 / c3 / c4, 5 for c5 on one GPU, 5 / 4 / 3 for c5 on 2 / 4 / 8 row slabs")
+                         "iterations; 0 = plain block CG; default: 6 for configs c2 / c3 / c4, 5 for c5 (one GPU or row slabs)")
     ap.add_argument("--amg-cycles", type=int, default=1, help="V-cycles per call of BlockAMG (the reference's SiO2 set-up: 1)")
     ap.add_argument("--amg-scale", type=float, default=0.0, help="coarse operators A_{l+1} = scale P^T A_l P (0: the back-end's default 0.5, include/gcge_multigrid.h)")
     ap.add_argument("--amg-smooth", default=None, help="CG smoothing iterations before and after the coarse correction: finest level, coarser levels "
@@ -96,14 +96,10 @@ def parse():
         a.size = 171 if a.config == "c5" else 100 if a.config == "c3" else 256
     if a.amg < 0:
         # (row slabs coarsen by themselves: csrc/hip/multigrid.hip; config 5 on one GPU: 14.0 s with BlockAMG 8 / 24 against 44.7 s with
-        #  30 plain CG iterations, profiles/r05_amg/13_...; on row slabs of config 5 the cuts must stay on EVEN plane numbers down the
-        #  hierarchy — cuts on multiples of 2^(L-1) planes for L levels — while the rows are cut by non-zeros: as many levels as leave
-        #  every rank at least four such units, at most 5 (2 ranks: 5, 4 ranks: 4, 8 ranks: 3 levels at 171 planes); the rehearsal on two
-        #  slabs of a 96^3 grid: 22.8 s with 5 levels against 66.0 s with 30 plain CG iterations, profiles/r05_amg/19_...)
-        if a.config == "c5" and a.gpus > 1:
-            a.amg = max([L for L in range(2, 6) if (1 << (L - 1)) * 4 * a.gpus <= a.size] or [0])
-        else:
-            a.amg = 6 if (a.config in ("c2", "c3", "c4")) else (5 if a.config == "c5" else 0)
+        #  30 plain CG iterations, profiles/r05_amg/13_...; row slabs of config 5 the same: cut by non-zeros on ANY plane boundary, every
+        #  rank pairs its own planes — the rehearsals on two slabs sharing a GPU: 96^3 22.8 s with 5 levels against 66.0 s with 30 plain CG
+        #  iterations, 88^3 with an odd cut on level 1 44 outer iterations like the even cuts, profiles/r05_amg/19_..., 22_...)
+        a.amg = 6 if (a.config in ("c2", "c3", "c4")) else (5 if a.config == "c5" else 0)
     if a.amg_smooth is None:
         a.amg_smooth = "8,24" if a.config == "c5" else "3,4"
     if a.rehearse:
@@ -560,9 +556,10 @@ def main():
             part0 = gdist.row_partition(n_global, world)
             A0, _ = make_problem("sio2", N, row_begin=part0[rank], row_end=part0[rank + 1], **kw)
             # cuts on plane boundaries (a plane of N^2 rows is 1 / N of the matrix): every slab keeps the plane sweep of spmm_star.hip
-            # (with BlockAMG of L levels: on multiples of 2^(L-1) planes, so that the cuts stay even on every level that is coarsened and
-            #  every slab coarsens by itself — gcge_mg_build_slab, csrc/host/multigrid.c)
-            part = gdist.partition_by_nnz(dist, A0, part0, align=((1 << (args.amg - 1)) if args.amg >= 2 else 1) * N * N) if world > 1 else part0
+            # (BlockAMG: every slab of whole planes coarsens by itself, each rank pairing its own planes — gcge_mg_build_slab,
+            #  csrc/host/multigrid.c; GCGE_BENCH_CUT_PLANES = 2^(L-1): cuts that stay even down L levels = the whole-matrix hierarchy)
+            cut_planes = int(os.environ.get("GCGE_BENCH_CUT_PLANES", "0")) or 1
+            part = gdist.partition_by_nnz(dist, A0, part0, align=cut_planes * N * N) if world > 1 else part0
             A, _ = make_problem("sio2", N, row_begin=part[rank], row_end=part[rank + 1], **kw)
             t_upload0 = time.perf_counter()
             mat = comm.slab_matrix(A, part) if isinstance(comm, gdist.NativeComm) else gdist.hip_slab_matrix(hip, comm, A, n_global, part)

@@ -8,7 +8,7 @@
 // real-space Hamiltonian its blocks, exactly like a matrix the caller uploads.  The prolongations are rectangular matrices
 // (GCGE_HIP_MAT_::rect_ncols): CSR of P for MatDotMultiVec, CSR of P^T for MatTransDotMultiVec, both through the generic CSR
 // kernel (spmm.hip) — one non-zero per fine row, every fine row of the block read or written exactly once.
-// Row slabs (one rank per GPU): a slab of whole planes cut on even plane numbers coarsens by itself — local prolongations, coarse slabs
+// Row slabs (one rank per GPU): a slab of whole planes coarsens by itself (every rank pairs its own planes) — local prolongations, coarse slabs
 // through the slab constructor (gcge_hip_mat_create_slab over RCCL, or a registered factory: the tests' torch.distributed transport).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -76,7 +76,7 @@ static void download_csr(const GCGE_HIP_MAT_* A, GCGE_CSR* out, std::vector<int>
 static gcge_hip_slab_factory_fn g_slab_factory = nullptr; static void* g_slab_factory_ctx = nullptr;
 extern "C" void gcge_hip_set_slab_factory(gcge_hip_slab_factory_fn fn, void* ctx) { g_slab_factory = fn; g_slab_factory_ctx = ctx; }
 
-// a row slab (one rank per GPU): whole planes of a detected grid, cut on even plane numbers — every rank coarsens its own slab
+// a row slab (one rank per GPU): whole planes of a detected grid, cut on any plane boundary — every rank coarsens its own slab
 // (gcge_mg_build_slab), the coarse slabs go through the slab constructor (ghost list, halo plan: collective)
 static void multigrid_create_slab(void*** A_array, void*** B_array, void*** P_array, int* num_levels, const GCGE_HIP_MAT_* mA, void* A, void* B) {
   GCGE_REQUIRE(mA->h_part != nullptr && mA->part_world >= 1, "MultiGridCreate on a row slab: the partition of all ranks (gcge_hip_mat_create_slab / gcge_hip_mat_set_partition)");

@@ -352,12 +352,17 @@ int gcge_mg_build(const GCGE_CSR *A, const GCGE_CSR *B, int max_levels, int min_
 }
 
 /* ---------------------------------------------------------------- row slabs (one rank per GPU)
- * A slab that is whole grid planes, cut on EVEN plane numbers, coarsens by itself: the 2 x 2 x 2 cells of its rows lie inside it, so
- * P is local (owned fine rows x owned coarse rows, no halo) and the coarse slab = scale * sum over the cells' rows, columns mapped
- * to GLOBAL coarse indices through the grid (halo columns included).  The coarse slab goes through the back-end's slab constructor
- * like any row-partitioned matrix (ghost list, halo plan).  Every rank evaluates the SAME stopping rule from the shared partition:
- * a level is coarsened while every slab starts on an even plane and holds an even number of planes (the last one may end on the
- * grid's last, odd plane).  Reference: the MPI back-ends get this from PETSc GAMG / BoomerAMG (app/app_slepc.c:648-728). */
+ * A slab that is whole grid planes coarsens by itself: every rank pairs ITS OWN planes from its first one (z0, z0 + 1), (z0 + 2,
+ * z0 + 3), ... — an odd plane count ends in a thinner last cell, like the last plane of an odd grid — so the 2 x 2 x 2 cells of its
+ * rows lie inside it, P is local (owned fine rows x owned coarse rows, no halo) and the coarse slab = scale * sum over the cells'
+ * rows, columns mapped to GLOBAL coarse indices through the grid and the SHARED partition (a column in a neighbour's planes belongs
+ * to the cell the neighbour's pairing puts it in).  With cuts on even plane numbers this is the whole-matrix hierarchy, row for row;
+ * with a cut on an odd plane the cells next to it differ from that hierarchy's — still a partition of the rows, still Galerkin
+ * (A_{l+1} = scale P^T A_l P with P = the ranks' prolongations stacked diagonally): a hierarchy as good, cut where the non-zeros
+ * balance.  The coarse grid has sum_r ceil(planes_r / 2) planes.  The coarse slab goes through the back-end's slab constructor like
+ * any row-partitioned matrix (ghost list, halo plan).  Every rank evaluates the SAME stopping rule from the shared partition: a level
+ * is coarsened while every cut lies on a plane boundary, every slab holds a plane and some slab holds two.
+ * Reference: the MPI back-ends get this from PETSc GAMG / BoomerAMG (app/app_slepc.c:648-728). */
 typedef struct { int col; int idx; double val; } SlabEnt;
 static int cmp_ent(const void *a, const void *b)
 {
@@ -365,29 +370,31 @@ static int cmp_ent(const void *a, const void *b)
 	if (x->col != y->col) return (x->col > y->col) - (x->col < y->col);
 	return (x->idx > y->idx) - (x->idx < y->idx);
 }
-static inline long grid_agg(long g, const int d[3], int cx, int cy)
+/* global fine row -> global coarse row: x, y halved on the grid, z through the owner's pairing (zf[r]: first fine plane of rank r,
+ * zc[r]: its first coarse plane; zf[world] = the plane count) */
+static inline long slab_agg(long g, const int d[3], int cx, int cy, const long *zf, const long *zc, int world)
 {
 	const long x = g % d[0], y = (g / d[0]) % d[1], z = g / ((long)d[0] * d[1]);
-	return (x / 2) + (long)cx * ((y / 2) + (long)cy * (z / 2));
+	int lo = 0, hi = world - 1;
+	while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (zf[mid] <= z) lo = mid; else hi = mid - 1; }
+	return (x / 2) + (long)cx * ((y / 2) + (long)cy * (zc[lo] + (z - zf[lo]) / 2));
 }
 static int slab_coarsenable(const int d[3], const long *part, int world)
 {
-	const long plane = (long)d[0] * d[1]; int r;
+	const long plane = (long)d[0] * d[1]; int r, two = 0;
 	if (d[2] < 2) return 0;
 	for (r = 0; r < world; ++r) {
-		long z0, z1;
 		if (part[r] % plane != 0 || part[r + 1] % plane != 0) return 0;
-		z0 = part[r] / plane; z1 = part[r + 1] / plane;
-		if (z1 <= z0 || (z0 & 1)) return 0;
-		if ((z1 & 1) && z1 != d[2]) return 0;
+		if (part[r + 1] <= part[r]) return 0;
+		if (part[r + 1] - part[r] >= 2 * plane) two = 1;
 	}
-	return 1;
+	return two;
 }
 int gcge_mg_build_slab(const GCGE_CSR *A, const int dims[3], const long *part, int rank, int world, int max_levels, double scale,
 		GCGE_MG *mg, long **part_levels_out)
 {
 	int l, d[3] = {dims[0], dims[1], dims[2]};
-	long *parts;
+	long *parts, *zf, *zc;
 	memset(mg, 0, sizeof *mg);
 	if (max_levels < 1) max_levels = 1;
 	if (scale <= 0.0) scale = g_scale;
@@ -397,24 +404,29 @@ int gcge_mg_build_slab(const GCGE_CSR *A, const int dims[3], const long *part, i
 	mg->PT = (GCGE_CSR*)calloc(max_levels, sizeof(GCGE_CSR));
 	mg->dims = (int (*)[3])calloc(max_levels, sizeof(int[3]));
 	parts = (long*)calloc((size_t)max_levels * (world + 1), sizeof(long));
-	if (!mg->A || !mg->P || !mg->PT || !mg->dims || !parts) { gcge_mg_free(mg); free(parts); return -3; }
+	zf = (long*)calloc(2 * ((size_t)world + 1), sizeof(long)); zc = zf ? zf + world + 1 : NULL;
+	if (!mg->A || !mg->P || !mg->PT || !mg->dims || !parts || !zf) { gcge_mg_free(mg); free(parts); free(zf); return -3; }
 	mg->A[0] = *A; mg->num_levels = 1;
 	memcpy(parts, part, (size_t)(world + 1) * sizeof(long));
 	mg->dims[0][0] = d[0]; mg->dims[0][1] = d[1]; mg->dims[0][2] = d[2];
 	for (l = 0; l + 1 < max_levels; ++l) {
 		const GCGE_CSR *Af = &mg->A[l];
 		const long *pf = parts + (size_t)l * (world + 1); long *pc = parts + (size_t)(l + 1) * (world + 1);
-		const int cx = (d[0] + 1) / 2, cy = (d[1] + 1) / 2, cz = (d[2] + 1) / 2, nf = Af->nrows;
+		const int cx = (d[0] + 1) / 2, cy = (d[1] + 1) / 2, nf = Af->nrows; int cz;
 		const long plane = (long)d[0] * d[1], cplane = (long)cx * cy, rb = pf[rank];
 		GCGE_CSR *Ac = &mg->A[l + 1];
 		int r, nc, *agg, *ptr = NULL, *mem = NULL, I, rc = 0; int64_t tot = 0;
 		if (!slab_coarsenable(d, pf, world)) break;
-		for (r = 0; r <= world; ++r) pc[r] = ((pf[r] / plane + 1) / 2) * cplane;
-		if (pc[world] != cplane * cz) { rc = -2; goto fail; }
+		zc[0] = 0;
+		for (r = 0; r <= world; ++r) zf[r] = pf[r] / plane;
+		for (r = 0; r < world; ++r) zc[r + 1] = zc[r] + (zf[r + 1] - zf[r] + 1) / 2;       /* every rank pairs its own planes */
+		for (r = 0; r <= world; ++r) pc[r] = zc[r] * cplane;
+		cz = (int)zc[world];
+		if (zf[world] != d[2] || cz >= d[2]) { rc = -2; goto fail; }
 		nc = (int)(pc[rank + 1] - pc[rank]);
 		agg = (int*)malloc((size_t)(nf > 0 ? nf : 1) * sizeof(int));       /* LOCAL coarse row of every owned fine row */
 		if (agg == NULL) { rc = -3; goto fail; }
-		for (r = 0; r < nf; ++r) agg[r] = (int)(grid_agg(rb + r, d, cx, cy) - pc[rank]);
+		for (r = 0; r < nf; ++r) agg[r] = (int)(slab_agg(rb + r, d, cx, cy, zf, zc, world) - pc[rank]);
 		if ((rc = gcge_mg_prolongation(agg, nf, nc, &mg->P[l], &mg->PT[l])) != 0) { free(agg); goto fail; }
 		if (aggregate_members(agg, nf, nc, &ptr, &mem) != 0) { free(agg); rc = -3; goto fail; }
 		/* coarse slab: per coarse row the entries of its members, columns -> global coarse index, merged in arrival order */
@@ -432,7 +444,7 @@ int gcge_mg_build_slab(const GCGE_CSR *A, const int dims[3], const long *part, i
 				for (q = ptr[I]; q < ptr[I + 1]; ++q) {
 					const int fr = mem[q];
 					for (k = Af->rowptr[fr]; k < Af->rowptr[fr + 1]; ++k) {
-						buf[len].col = (int)grid_agg(Af->colidx[k], d, cx, cy); buf[len].idx = len; buf[len].val = Af->val[k]; ++len;
+						buf[len].col = (int)slab_agg(Af->colidx[k], d, cx, cy, zf, zc, world); buf[len].idx = len; buf[len].val = Af->val[k]; ++len;
 					}
 				}
 				qsort(buf, len, sizeof(SlabEnt), cmp_ent);
@@ -453,8 +465,9 @@ int gcge_mg_build_slab(const GCGE_CSR *A, const int dims[3], const long *part, i
 		mg->dims[l + 1][0] = cx; mg->dims[l + 1][1] = cy; mg->dims[l + 1][2] = cz;
 		continue;
 fail:
-		mg->num_levels = l + 2; gcge_mg_free(mg); free(parts); return rc;
+		mg->num_levels = l + 2; gcge_mg_free(mg); free(parts); free(zf); return rc;
 	}
+	free(zf);
 	*part_levels_out = parts;
 	return 0;
 }

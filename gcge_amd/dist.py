@@ -60,8 +60,9 @@ def partition_by_nnz(dist, A, part, bucket=None, align=None):
     rows, the sums are gathered, and the cuts are put at the bucket boundaries nearest to k/world of the total.
     align: cuts only at multiples of `align` rows — the plane size nx * ny of a grid matrix (grid_of), so that every slab is
     whole planes and keeps the plane sweep of spmm_star.hip; a plane of 171^2 rows is 0.6 % of BASELINE config 5's matrix.  A multiple
-    of the plane size (2^(L-1) planes: the cuts a slab hierarchy of L levels wants, csrc/host/multigrid.c) need not divide the row
-    count: the last unit is then a short one (171 planes = 10 units of 16 planes + 11 planes)."""
+    of the plane size (2^(L-1) planes: cuts that stay on even planes down L levels of a slab hierarchy, which then equals the whole
+    matrix's, csrc/host/multigrid.c) need not divide the row count: the last unit is then a short one (171 planes = 10 units of 16
+    planes + 11 planes)."""
     world = len(part) - 1
     n_global = part[-1]
     rank = dist.get_rank()

@@ -87,7 +87,7 @@ GCGE_HIP_MAT *gcge_hip_mat_create_rect (int nrows, int ncols, const int *rowptr,
 		const int *t_rowptr, const int *t_colidx, const double *t_val);      /* CSR of P and CSR of P^T */
 GCGE_HIP_MAT *gcge_hip_mat_create_rect_csr (const GCGE_CSR *P);              /* the transpose is formed here */
 double gcge_hip_multigrid_seconds (void);    /* host + upload time of the last MultiGridCreate */
-/*     Row slabs (one rank per GPU): a slab that is whole planes of a detected grid, cut on even plane numbers, coarsens by itself
+/*     Row slabs (one rank per GPU): a slab that is whole planes of a detected grid (cut on any plane boundary) coarsens by itself
  *     (gcge_mg_build_slab, include/gcge_multigrid.h: local prolongations, coarse slabs with global columns); every coarse slab goes
  *     through the slab constructor — gcge_hip_mat_create_slab over RCCL by default, or the function registered here (a transport of
  *     the caller's: the torch.distributed callbacks of the tests).  MultiGridCreate needs the partition of all ranks:

@@ -61,9 +61,11 @@ int  gcge_mg_build (const GCGE_CSR *A, const GCGE_CSR *B, int max_levels, int mi
 void gcge_mg_free (GCGE_MG *mg);
 
 /* The hierarchy of ONE row slab (one rank per GPU): A holds rows [part[rank], part[rank + 1]) with GLOBAL columns of a matrix on the
- * lexicographic grid `dims`; every slab is whole planes.  A level is coarsened while every slab starts on an even plane and holds an
- * even number of planes (the last may end on the grid's last, odd plane) — every rank evaluates that from the shared partition, so
- * all ranks build the same number of levels.  mg->A[l] (l >= 1): the coarse slab with GLOBAL coarse columns, row_begin =
+ * lexicographic grid `dims`; every slab is whole planes.  Every rank pairs ITS OWN planes from its first one (an odd count ends in a
+ * thinner cell), columns in a neighbour's planes follow the neighbour's pairing through the shared partition: with cuts on even planes
+ * the levels are the whole-matrix hierarchy's rows, with a cut on an odd plane the cells next to it are the rank's own — Galerkin
+ * either way.  A level is coarsened while every slab holds a plane and some slab two — every rank evaluates that from the shared
+ * partition, so all ranks build the same number of levels; level l + 1 has sum_r ceil(planes_r / 2) planes.  mg->A[l] (l >= 1): the coarse slab with GLOBAL coarse columns, row_begin =
  * part_levels[l * (world + 1) + rank]; mg->P[l] / PT[l]: local (owned fine rows x owned coarse rows: the cells of a slab lie inside
  * it).  part_levels (free with free()): the row partition of every level.  Returns 0; -2: the slab is not whole planes of `dims`. */
 int gcge_mg_build_slab (const GCGE_CSR *A, const int dims[3], const long *part, int rank, int world, int max_levels, double scale,

@@ -104,8 +104,9 @@ def main():
         A0, _ = make_problem("sio2", sio2, row_begin=part0[rank], row_end=part0[rank + 1], **kw)
         if star:
             assert gdist.grid_of(A0) == (sio2, sio2, sio2, 6)
-        # (with BlockAMG behind it: cuts on EVEN plane numbers, so that every slab coarsens by itself)
-        part = gdist.partition_by_nnz(dist, A0, part0, align=(2 if os.environ.get("GCGE_TEST_AMG") else 1) * sio2 * sio2 if star else None)
+        # (with BlockAMG of L levels behind it: cuts in units of 2^(L-1) planes, so that they stay even on every level that is coarsened)
+        amg_unit = (1 << (int(os.environ["GCGE_TEST_AMG"]) - 1)) if os.environ.get("GCGE_TEST_AMG") else 1
+        part = gdist.partition_by_nnz(dist, A0, part0, align=amg_unit * sio2 * sio2 if star else None)
         assert not star or all(p % (sio2 * sio2) == 0 for p in part), part
         A, _ = make_problem("sio2", sio2, row_begin=part[rank], row_end=part[rank + 1], **kw)
         nnz_all = [None] * world

@@ -5,7 +5,7 @@ result is compared with the same slab's rows applied on the host (scipy).  Narro
 stops converging with more than two levels.
 
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 \
-    tests/slab_level_worker.py SIZE [K,R0,R1] [LEVELS]
+    tests/slab_level_worker.py SIZE [K,R0,R1] [LEVELS] [PLANES PER CUT UNIT]
 """
 import ctypes as C
 import os
@@ -34,7 +34,9 @@ def main():
     part0 = gdist.row_partition(n_global, world)
     A0, _ = make_problem("sio2", N, row_begin=part0[rank], row_end=part0[rank + 1], **kw)
     # cuts on plane numbers that stay EVEN down the hierarchy (gcge_mg_build_slab stops coarsening at the first odd cut)
-    part = gdist.partition_by_nnz(dist, A0, part0, align=(1 << (levels - 1)) * N * N)
+    # (argv[4] = 1: cuts on ANY plane boundary — every rank pairs its own planes, the cells next to an odd cut are the rank's own)
+    unit = int(sys.argv[4]) if len(sys.argv) > 4 else (1 << (levels - 1))
+    part = gdist.partition_by_nnz(dist, A0, part0, align=unit * N * N)
     A, _ = make_problem("sio2", N, row_begin=part[rank], row_end=part[rank + 1], **kw)
     hier = mg_hierarchy_slab(A, (N, N, N), part, rank, levels, scale=0.5)
     be = HipBackend(device=0)

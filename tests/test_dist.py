@@ -237,20 +237,20 @@ def test_two_ranks_on_one_gpu_block_amg_on_slabs_of_the_sio2_like_matrix():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size,atoms,levels", [(48, "60,2.0,5.0", 4), (96, "350,2.0,5.0", 5)])
-def test_two_ranks_on_one_gpu_every_level_of_the_slab_hierarchy_multiplies_right(size, atoms, levels):
+@pytest.mark.parametrize("size,atoms,levels,unit", [(48, "60,2.0,5.0", 4, None), (96, "350,2.0,5.0", 5, None), (48, "60,2.0,5.0", 5, 1)])
+def test_two_ranks_on_one_gpu_every_level_of_the_slab_hierarchy_multiplies_right(size, atoms, levels, unit):
     """Every level of the slab hierarchy of the SiO2-like matrix (tests/slab_level_worker.py): uploaded through the slab constructor,
     product and product-with-column-sums (the fused CG's entry point, gcge_hip_spmm_dot2_mv) against the slab's rows on the host, with
     and without the interior rows swept while the halo travels.  The coarse levels leave the grid form (pad-8 rows, then repeated
     patterns): the 96^3 case is where the fused product + x.y sums over a ROW STRIP read the strip's own rows of x from row 0 of the
     block (round 5: column sums off by 6e-5 on levels 2 and 3 with the split exchange — BlockAMG on slabs deeper than two levels
-    did not converge)."""
+    did not converge).  unit = 1: cuts on any plane boundary, an odd one included — every rank pairs its own planes (csrc/host/multigrid.c)."""
     port = _free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "slab_level_worker.py"), str(size), atoms, str(levels)],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "slab_level_worker.py"), str(size), atoms, str(levels)] + ([str(unit)] if unit else []),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:

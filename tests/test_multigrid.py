@@ -135,7 +135,7 @@ def test_aggregation_hierarchy_is_galerkin(kind, size):
 @pytest.mark.parametrize("kind,dims,world", [("lap3d", (6, 6, 16), 2), ("lap3d", (5, 7, 24), 3), ("sio2", (12, 12, 12), 1), ("lap3d", (6, 6, 8), 4),
                                              ("sio2", (16, 16, 16), 2), ("sio2", (12, 12, 12), 3), ("lap3d", (6, 5, 19), 2), ("sio2", (19, 19, 19), 2)])
 def test_slab_hierarchy_equals_the_rows_of_the_whole_hierarchy(kind, dims, world):
-    """gcge_mg_build_slab: every rank coarsens its own slab (whole planes, cut on even plane numbers) — stacked, the coarse slabs ARE
+    """gcge_mg_build_slab: every rank coarsens its own slab (whole planes; here cut on even plane numbers) — stacked, the coarse slabs ARE
     the coarse matrix of the whole-matrix hierarchy at every level, the local prolongations are the diagonal blocks of the global one,
     and every rank stops at the same level (the shared stopping rule)."""
     import ctypes
@@ -159,7 +159,14 @@ def test_slab_hierarchy_equals_the_rows_of_the_whole_hierarchy(kind, dims, world
     slabs = [mg_hierarchy_slab(gen(part[r], part[r + 1]), dims, part, r, 6, scale=0.5) for r in range(world)]
     L = len(slabs[0]["A"])
     assert all(len(sl["A"]) == L for sl in slabs) and L >= 2
+    compared = 0
     for lev in range(1, L):
+        # (identical while the cuts of the level that is coarsened lie on even planes; past an odd cut every rank pairs its own planes and
+        #  the cells next to the cut differ from the whole hierarchy's: test_slab_hierarchy_with_cuts_on_odd_planes_is_galerkin)
+        fd = slabs[0]["dims"][lev - 1]
+        if any((c // (fd[0] * fd[1])) % 2 for c in slabs[0]["part"][lev - 1][:-1]):
+            break
+        compared += 1
         stacked = sp.vstack([sl["A"][lev] for sl in slabs]).tocsr()
         want = whole["A"][lev]
         assert stacked.shape == want.shape and abs(stacked - want).max() <= 1e-13 * abs(want).max(), lev
@@ -167,6 +174,52 @@ def test_slab_hierarchy_equals_the_rows_of_the_whole_hierarchy(kind, dims, world
         Pg = sp.block_diag([sl["P"][lev - 1] for sl in slabs]).tocsr()
         assert abs(Pg - whole["P"][lev - 1]).max() == 0.0
         assert all(sl["part"][lev] == slabs[0]["part"][lev] for sl in slabs)
+    assert compared >= 1
+
+
+@pytest.mark.parametrize("kind,dims,zcut", [("lap3d", (6, 5, 19), [0, 7, 19]), ("lap3d", (4, 6, 24), [0, 5, 6, 17, 24]), ("sio2", (16, 16, 16), [0, 9, 16]),
+                                            ("sio2", (19, 19, 19), [0, 5, 12, 19]), ("lap3d", (4, 4, 9), [0, 1, 2, 9])])
+def test_slab_hierarchy_with_cuts_on_odd_planes_is_galerkin(kind, dims, zcut):
+    """Cuts on ANY plane boundary (where the non-zeros balance): every rank pairs its own planes from its first one, so the cells next
+    to an odd cut differ from the whole-matrix hierarchy's — the levels are still A_{l+1} = scale P^T A_l P with P = the ranks' local
+    prolongations stacked diagonally, P a partition of the rows into cells of at most 2 x 2 x 2 grid points of ONE rank, columns of a
+    coarse slab global coarse indices through the shared partition, and every rank stops at the same level."""
+    import ctypes
+    import scipy.sparse as sp
+    from helpers import mg_hierarchy_slab
+    from gcge_amd.lib import CSR
+    h = host_lib()
+    plane, nz = dims[0] * dims[1], dims[2]
+    world = len(zcut) - 1
+
+    def gen(rb, re_):
+        if kind == "sio2":
+            A, _ = make_problem("sio2", dims[0], row_begin=rb, row_end=re_, K=6, R0=1.5, R1=2.0, seed=12345)
+            return A
+        A = CSR()
+        h.gcge_problem_lap3d_box(dims[0], dims[1], dims[2], ctypes.c_int64(rb), ctypes.c_int64(re_), ctypes.byref(A))
+        return A
+    part = [z * plane for z in zcut]
+    slabs = [mg_hierarchy_slab(gen(part[r], part[r + 1]), dims, part, r, 6, scale=0.5) for r in range(world)]
+    L = len(slabs[0]["A"])
+    assert all(len(sl["A"]) == L for sl in slabs) and L >= 3
+    fine = sp.vstack([sl["A"][0] for sl in slabs]).tocsr()
+    assert abs(fine - fine.T).max() == 0.0
+    for lev in range(1, L):
+        assert all(sl["part"][lev] == slabs[0]["part"][lev] and sl["dims"][lev] == slabs[0]["dims"][lev] for sl in slabs)
+        pl, pf, d, df = slabs[0]["part"][lev], slabs[0]["part"][lev - 1], slabs[0]["dims"][lev], slabs[0]["dims"][lev - 1]
+        cplane = d[0] * d[1]
+        # every rank halves ITS plane count (rounded up); the coarse grid holds the sum
+        assert [(pl[r + 1] - pl[r]) // cplane for r in range(world)] == [((pf[r + 1] - pf[r]) // (df[0] * df[1]) + 1) // 2 for r in range(world)]
+        assert d == ((df[0] + 1) // 2, (df[1] + 1) // 2, pl[-1] // cplane) and pl[-1] == d[0] * d[1] * d[2]
+        P = sp.block_diag([sl["P"][lev - 1] for sl in slabs]).tocsr()
+        assert P.shape == (pf[-1], pl[-1]) and np.all(np.asarray(P.sum(axis=1)).ravel() == 1.0)
+        cells = np.asarray(P.sum(axis=0)).ravel()
+        assert cells.min() >= 1 and cells.max() <= 8
+        stacked = sp.vstack([sl["A"][lev] for sl in slabs]).tocsr()
+        want = 0.5 * (P.T @ fine @ P)
+        assert stacked.shape == want.shape and abs(stacked - want).max() <= 1e-13 * abs(want).max(), lev
+        fine = stacked
 
 
 # ---------------------------------------------------------------------------------------------- host: BlockAMG vs the reference
