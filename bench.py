@@ -460,6 +460,14 @@ def cpu_like_for_like(args, hip):
                                 "max_rel_diff_vs_cpu_reference": float(np.max(np.abs(ev_g[:k] - ev[:k]) / np.abs(ev[:k]))) if k > 0 else None}}
 
 
+def slab_cut_planes(planes, world, levels):
+    """Planes per cut unit for row slabs of a grid matrix behind BlockAMG with `levels` levels (1 without it)."""
+    unit = 1
+    while levels >= 2 and 2 * unit <= (1 << (levels - 1)) and 2 * unit * 4 * world <= planes:
+        unit *= 2
+    return unit
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -557,8 +565,11 @@ def main():
             A0, _ = make_problem("sio2", N, row_begin=part0[rank], row_end=part0[rank + 1], **kw)
             # cuts on plane boundaries (a plane of N^2 rows is 1 / N of the matrix): every slab keeps the plane sweep of spmm_star.hip
             # (BlockAMG: every slab of whole planes coarsens by itself, each rank pairing its own planes — gcge_mg_build_slab,
-            #  csrc/host/multigrid.c; GCGE_BENCH_CUT_PLANES = 2^(L-1): cuts that stay even down L levels = the whole-matrix hierarchy)
-            cut_planes = int(os.environ.get("GCGE_BENCH_CUT_PLANES", "0")) or 1
+            #  csrc/host/multigrid.c.  Cuts in units of 2^k planes stay even for k levels: those levels are the whole-matrix hierarchy's
+            #  rows and keep the grid form of the sweep where it shows; next to an odd cut the cells are the rank's own and the level takes
+            #  blocks + tiles or pad-8 rows, profiles/r05_amg/24_...  The largest k <= levels - 1 that leaves every rank four units:
+            #  171 planes on 2 / 4 / 8 ranks: 16 / 8 / 4 planes.  GCGE_BENCH_CUT_PLANES overrides: 1 = any plane boundary.)
+            cut_planes = int(os.environ.get("GCGE_BENCH_CUT_PLANES", "0")) or slab_cut_planes(N, world, args.amg)
             part = gdist.partition_by_nnz(dist, A0, part0, align=cut_planes * N * N) if world > 1 else part0
             A, _ = make_problem("sio2", N, row_begin=part[rank], row_end=part[rank + 1], **kw)
             t_upload0 = time.perf_counter()

@@ -93,6 +93,13 @@ def test_row_partition_helpers():
         assert cuts[0] == 0 and cuts[-1] == N ** 3 and all(c % unit == 0 for c in cuts[:-1]) and all(a < b for a, b in zip(cuts, cuts[1:])), cuts
         share = np.diff(cuts) / (N ** 3 / world)
         assert share.max() <= 1.15, (world, L, share)
+    # bench.py's unit for slabs behind BlockAMG: the largest 2^k planes (k < levels) that leaves every rank four units
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_cuts", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert [b.slab_cut_planes(171, w, 5) for w in (2, 4, 8)] == [16, 8, 4]
+    assert b.slab_cut_planes(171, 8, 0) == 1 and b.slab_cut_planes(171, 2, 2) == 2 and b.slab_cut_planes(24, 2, 3) == 2 and b.slab_cut_planes(7, 8, 5) == 1
 
 
 @pytest.mark.gpu

@@ -178,7 +178,8 @@ def test_slab_hierarchy_equals_the_rows_of_the_whole_hierarchy(kind, dims, world
 
 
 @pytest.mark.parametrize("kind,dims,zcut", [("lap3d", (6, 5, 19), [0, 7, 19]), ("lap3d", (4, 6, 24), [0, 5, 6, 17, 24]), ("sio2", (16, 16, 16), [0, 9, 16]),
-                                            ("sio2", (19, 19, 19), [0, 5, 12, 19]), ("lap3d", (4, 4, 9), [0, 1, 2, 9])])
+                                            ("sio2", (19, 19, 19), [0, 5, 12, 19]), ("lap3d", (4, 4, 9), [0, 1, 2, 9]),
+                                            ("lap3d", (4, 4, 43), [0, 5, 11, 16, 21, 27, 32, 38, 43]), ("sio2", (21, 21, 21), [0, 2, 5, 8, 10, 13, 16, 18, 21])])
 def test_slab_hierarchy_with_cuts_on_odd_planes_is_galerkin(kind, dims, zcut):
     """Cuts on ANY plane boundary (where the non-zeros balance): every rank pairs its own planes from its first one, so the cells next
     to an odd cut differ from the whole-matrix hierarchy's — the levels are still A_{l+1} = scale P^T A_l P with P = the ranks' local
