@@ -223,6 +223,39 @@ def test_slab_hierarchy_with_cuts_on_odd_planes_is_galerkin(kind, dims, zcut):
         fine = stacked
 
 
+@pytest.mark.parametrize("zcut,min_star", [([0, 16, 32, 48], 0.95), ([0, 17, 31, 48], 0.40)])
+def test_coarse_slabs_of_the_sio2_like_matrix_keep_the_grid_form(zcut, min_star):
+    """Level 1 of a slab hierarchy of the SiO2-like matrix (48^3, three slabs) is a star again (arm length 3 on a 24 x 24 x nz grid) and
+    passes the host self-check of the plane sweep on a slab (star rows + remainder == CSR bit for bit, halo planes where the sweep's
+    addressing expects them): nearly every row with even cuts; with cuts on odd planes the rows within reach of a thin cell go to the
+    remainder — fewer star rows, same form."""
+    import ctypes as C
+    from helpers import mg_hierarchy_slab
+    from gcge_amd import dist as gdist
+    from gcge_amd.lib import CSR, hip_lib
+    g = hip_lib()
+    g.gcge_hip_star_selfcheck_slab.restype = C.c_long
+    g.gcge_hip_star_selfcheck_slab.argtypes = [C.c_int, C.c_int, C.c_long, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                               C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    N = 48
+    part = [z * N * N for z in zcut]
+    for r in range(3):
+        A, _ = make_problem("sio2", N, row_begin=part[r], row_end=part[r + 1], K=10, R0=2.0, R1=5.0, seed=12345)
+        hier = mg_hierarchy_slab(A, (N, N, N), part, r, 2, scale=0.5)
+        S = hier["A"][1].tocsr(); S.sort_indices()
+        pl, d = hier["part"][1], hier["dims"][1]
+        assert d[:2] == (24, 24) and d[2] == sum((zcut[q + 1] - zcut[q] + 1) // 2 for q in range(3))
+        rp = np.ascontiguousarray(S.indptr, dtype=np.int32); ci = np.array(S.indices, dtype=np.int32, copy=True); va = np.ascontiguousarray(S.data)
+        Al = CSR(S.shape[0], int(pl[-1]), int(pl[r]), int(S.nnz), rp.ctypes.data_as(C.POINTER(C.c_int)), ci.ctypes.data_as(C.POINTER(C.c_int)),
+                 va.ctypes.data_as(C.POINTER(C.c_double)))
+        gh = np.ascontiguousarray(gdist.localize_slab(Al), dtype=np.int32)
+        out = (C.c_long * 12)()
+        bad = g.gcge_hip_star_selfcheck_slab(Al.nrows, Al.ncols, int(pl[r]), int(pl[-1]), gh.ctypes.data_as(C.POINTER(C.c_int)), Al.rowptr, Al.colidx, Al.val, out)
+        assert bad == 0 and tuple(out[:4]) == (d[0], d[1], d[2], 3), (r, bad, list(out))
+        assert out[4] >= min_star * Al.nrows, (r, out[4], Al.nrows)
+        assert (out[5], out[6]) == (pl[r] // 576, pl[r + 1] // 576)
+
+
 # ---------------------------------------------------------------------------------------------- host: BlockAMG vs the reference
 def _check_amg_case(backend, Ah, Ph, key, n0):
     g = G[key]
